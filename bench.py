@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""Headline benchmark: MPC control steps / second (and candidate trajectories / second).
+
+A "step" is ONE control step of the hot path (all optimizer iterations: sample -> rollout -> reduce ->
+refit, plus the action/next-state tail) for every agent this process owns, closed-loop on the device:
+the state stays resident in HBM and the engine's own pendulum step plays the environment, so warm-starts
+are exercised.  Default workload = BASELINE.json configs[1]: Pendulum-v0 true dynamics, CEM,
+num_agents=1 per GPU, N=500, H=30, 5 iterations, k=50.  With --gpus N every rank owns its own agents
+(weak scaling, independent agents, RNG keyed by global agent id) and one RCCL all-gather per control
+step collects the packed (action | next_state | reward) records -- the only exchange the path has.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (optimizer, dynamics, N, A_per_gpu, H, iters, k)
+    "cfg1": dict(opt="RandomSearch", N=200, A=1, H=20, iters=1, k=0),
+    "cfg2": dict(opt="CEM", N=500, A=1, H=30, iters=5, k=50),
+    "cfg3": dict(opt="PI2", N=1000, A=8, H=30, iters=5, k=0),      # 64 agents over 8 GPUs = 8 per GPU
+    "cfg3full": dict(opt="PI2", N=1000, A=64, H=30, iters=5, k=0),
+}
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from blackbox_mpc_amd import _build
+    _build.build()
+    from blackbox_mpc_amd import _lib as L
+    from blackbox_mpc_amd.engine import Engine
+    from oracle import oracle_np as O      # inputs (start states) + the cpu_baseline leg only
+
+    c = CONFIGS[args.config]
+    opt = {"RandomSearch": L.OPT_RANDOM_SEARCH, "CEM": L.OPT_CEM, "PI2": L.OPT_PI2}[c["opt"]]
+    N, A, H, iters, k = c["N"], c["A"], c["H"], c["iters"], c["k"]
+    U, S = 1, 3
+    rec = U + S + 1
+    eng = Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=S, num_agents=A, planning_horizon=H,
+                 population_size=N, max_iterations=iters, num_elite=k, seed=0, agent_offset=rank * A,
+                 num_agents_global=world * A, device=local)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+
+    state = torch.from_numpy(O.pendulum_start_states(A, agent_offset=rank * A)).to(dev)
+    nxt = torch.empty_like(state)
+    record = torch.zeros((A, rec), device=dev, dtype=torch.float32)
+    gathered = torch.zeros((world * A, rec), device=dev, dtype=torch.float32) if world > 1 else None
+
+    def control_step():
+        nonlocal state, nxt
+        eng.optimize_dev(state.data_ptr(), record.data_ptr())
+        # environment = the engine's own model step on the chosen action
+        eng.step_dev(state.data_ptr(), record.data_ptr(), rec, A, nxt.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, record)
+        state, nxt = nxt, state
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        control_step()
+    fence()
+    eng.set_profiling(True)          # HIP events on the launch stream around every rollout-kernel launch
+    eng.get_profile()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        control_step()
+    fence()
+    t1 = time.perf_counter()
+    roll_ms, roll_n, kname = eng.get_profile()
+    eng.set_profiling(False)
+
+    elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    # un-instrumented repeat of the same K steps (events off) for the overhead of the instrumentation
+    fence()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        control_step()
+    fence()
+    t3 = time.perf_counter()
+
+    if rank == 0:
+        total_agents = world * A
+        steps_per_s = args.steps * total_agents / elapsed
+        traj_per_step = N * iters * total_agents
+        # algorithmic bytes per trajectory: 4*(H*U + 1) + 4*S/N   (SURVEY 8d / BASELINE.md)
+        bytes_per_traj = 4.0 * (H * U + 1) + 4.0 * S / N
+        launch_traj = N * A                                  # one rollout launch = all particles of my agents
+        avg_ms = roll_ms / max(roll_n, 1)
+        achieved = launch_traj * bytes_per_traj / (avg_ms * 1e-3) / 1e9 if roll_n else None
+        out = {
+            "metric": "MPC control-steps/sec (agent-control-steps; Pendulum true model, %s N=%d H=%d)" % (c["opt"], N, H),
+            "value": steps_per_s,
+            "unit": "control-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE %s: Pendulum-v0 true dynamics, %s, num_agents=%d/GPU, N=%d, H=%d, "
+                                   "%d iters%s, closed loop on device" % (args.config, c["opt"], A, N, H, iters,
+                                                                          (", k=%d" % k) if k else ""),
+                       "parallelism": "agents sharded %d/GPU, 1 RCCL all-gather of [A,%d] per control step" % (A, rec)
+                       if world > 1 else "single GPU"},
+            "candidate_trajectories_per_sec": steps_per_s * N * iters,
+            "dyn_steps_per_sec": steps_per_s * N * iters * H,
+            "ms_per_step_uninstrumented": (t3 - t2) / args.steps * 1e3,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "kernel": kname, "avg_launch_us": avg_ms * 1e3, "launches": roll_n,
+                         "algorithmic_bytes_per_launch": launch_traj * bytes_per_traj,
+                         "note": "fused rollout keeps the H-step recurrence in registers; the path is "
+                                 "VALU/latency bound, HBM fraction is nominal (see DESIGN.md)"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(O, c, H, N, A, iters, k)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(O, c, H, N, A, iters, k, budget_s=15.0):
+    """The NumPy oracle (op-for-op port of the reference's TF graph) timed on the host, 1 thread of
+    Python driving NumPy ops -- a bounded sample of the same workload."""
+    ev = O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))
+    rng = np.random.default_rng(0)
+    if c["opt"] == "CEM":
+        opt = O.CEM(ev, [-2.0], [2.0], horizon=H, max_iterations=iters, population=N, num_elite=k, num_agents=A)
+        mk = lambda: {"trunc": [O.truncated_normal_noise(rng, (N, A, H, 1)) for _ in range(iters)]}
+    elif c["opt"] == "PI2":
+        opt = O.PI2(ev, [-2.0], [2.0], horizon=H, max_iterations=iters, population=N, num_agents=A)
+        mk = lambda: {"trunc": [O.truncated_normal_noise(rng, (N, A, H, 1)) for _ in range(iters)]}
+    else:
+        opt = O.RandomSearch(ev, [-2.0], [2.0], horizon=H, population=N, num_agents=A)
+        mk = lambda: {"uniform": rng.random((N, A, H, 1)).astype(np.float32)}
+    state = O.pendulum_start_states(A)
+    n, t_used = 0, 0.0
+    while t_used < budget_s and n < 200:
+        noise = mk()
+        t0 = time.perf_counter()
+        act, nxt, _ = opt.call(state, noise)
+        t_used += time.perf_counter() - t0
+        state = nxt
+        n += 1
+    return {"value": n * A / t_used, "unit": "control-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d closed-loop control steps of the same workload with the NumPy oracle "
+                      "(oracle/oracle_np.py), noise generation excluded" % n}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,754 @@
+// C ABI (include/bbmpc.h) + engine implementation.  gfx950 only, no CPU fallback.
+#include "engine.hpp"
+
+#include <math.h>
+#include <stdio.h>
+
+namespace bbmpc {
+
+static thread_local std::string g_last_error;
+
+// ------------------------------------------------------------------------------------------------
+// construction
+// ------------------------------------------------------------------------------------------------
+static void upload(DevBuf<float>& b, const std::vector<float>& v) {
+    b.alloc(v.size());
+    HIP_CHECK(hipMemcpy(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+}
+
+Engine::Engine(const bbmpc_config& c) : cfg(c) {
+    REQUIRE(c.abi_version == BBMPC_ABI_VERSION, BBMPC_E_INVALID, "bbmpc_config.abi_version mismatch");
+    N = c.population_size; A = c.num_agents; H = c.planning_horizon; U = c.dim_u; S = c.dim_s;
+    iters = c.optimizer == BBMPC_OPT_RANDOM_SEARCH ? 1 : c.max_iterations;
+    if (c.optimizer == BBMPC_OPT_NONE) iters = 0;
+    k = c.num_elite;
+    REQUIRE(A >= 1 && H >= 1 && U >= 1 && S >= 1, BBMPC_E_INVALID, "num_agents, planning_horizon, dim_u, dim_s must be >= 1");
+    REQUIRE(c.action_low && c.action_high, BBMPC_E_INVALID, "action_low/action_high are required");
+    REQUIRE(c.optimizer >= BBMPC_OPT_NONE && c.optimizer <= BBMPC_OPT_SPSA, BBMPC_E_INVALID, "unknown optimizer");
+    REQUIRE(c.dynamics == BBMPC_DYN_PENDULUM || c.dynamics == BBMPC_DYN_MLP, BBMPC_E_INVALID, "unknown dynamics kind");
+    REQUIRE(c.reward == BBMPC_REW_PENDULUM || c.reward == BBMPC_REW_CHEETAH, BBMPC_E_INVALID, "unknown reward kind");
+    if (c.dynamics == BBMPC_DYN_PENDULUM)
+        REQUIRE(S == 3 && U == 1, BBMPC_E_INVALID, "PendulumTrueModel needs dim_s == 3 and dim_u == 1");
+    if (c.reward == BBMPC_REW_PENDULUM) REQUIRE(S >= 3, BBMPC_E_INVALID, "pendulum reward needs dim_s >= 3");
+    if (c.reward == BBMPC_REW_CHEETAH) REQUIRE(S >= 18, BBMPC_E_INVALID, "cheetah reward indexes state[17]: dim_s >= 18");
+    if (c.optimizer != BBMPC_OPT_NONE) {
+        REQUIRE(N >= 1, BBMPC_E_INVALID, "population_size must be >= 1");
+        REQUIRE(iters >= 0, BBMPC_E_INVALID, "max_iterations must be >= 0");
+        REQUIRE(N <= 8192, BBMPC_E_UNSUPPORTED, "population_size > 8192 not supported by the refit kernels yet");
+    } else {
+        N = 0;
+    }
+    if (c.optimizer == BBMPC_OPT_CEM || c.optimizer == BBMPC_OPT_CMAES)
+        REQUIRE(k >= 1 && k <= N, BBMPC_E_INVALID, "num_elite must be in [1, population_size]");
+    if (c.optimizer == BBMPC_OPT_CEM) REQUIRE(k <= 1024, BBMPC_E_UNSUPPORTED, "num_elite > 1024 not supported");
+    REQUIRE(c.optimizer != BBMPC_OPT_PSO && c.optimizer != BBMPC_OPT_CMAES && c.optimizer != BBMPC_OPT_SPSA,
+            BBMPC_E_UNSUPPORTED, "PSO / CMA-ES / SPSA kernels are not built yet");
+    REQUIRE(c.dynamics == BBMPC_DYN_PENDULUM, BBMPC_E_UNSUPPORTED, "learned-MLP dynamics kernels are not built yet");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        throw HipError(BBMPC_E_NO_DEVICE, "no HIP device available: this library has no CPU fallback");
+    if (c.device >= 0) {
+        REQUIRE(c.device < ndev, BBMPC_E_NO_DEVICE, "bbmpc_config.device out of range");
+        HIP_CHECK(hipSetDevice(c.device));
+    }
+    HIP_CHECK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+    stream = own_stream;
+
+    HU = H * U;
+    Nst = ((std::max(N, 1) + 63) / 64) * 64;
+    rec = U + S + 1;
+    lo.assign(c.action_low, c.action_low + U);
+    hi.assign(c.action_high, c.action_high + U);
+    upload(d_lo, lo);
+    upload(d_hi, hi);
+    d_state.alloc((size_t)A * S);
+    d_record.alloc((size_t)A * rec);
+    d_action.alloc((size_t)A * U);
+    d_action.zero(stream);
+    if (c.optimizer != BBMPC_OPT_NONE) {
+        // mean = (lo+hi)/2, var = (lo-hi)^2/16 tiled to [A,H,U]   cem.py:55-72, pi2.py:44-55
+        std::vector<float> m((size_t)A * HU), v((size_t)A * HU);
+        for (int i = 0; i < A * HU; ++i) {
+            const int u = i % U;
+            m[i] = (lo[u] + hi[u]) / 2.0f;
+            const float d = lo[u] - hi[u];
+            v[i] = (d * d) / 16.0f;
+        }
+        upload(d_prev_mean, m);
+        upload(d_var0, v);
+        d_mean.alloc(m.size());
+        d_var.alloc(m.size());
+        d_sigma.alloc(m.size());
+        d_samples.alloc((size_t)A * HU * Nst);
+        d_rewards.alloc((size_t)A * Nst);
+        d_penalty.alloc((size_t)A * Nst);
+        d_elites.alloc((size_t)A * std::max(k, 1));
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+Engine::~Engine() {
+    if (own_stream) (void)hipStreamSynchronize(own_stream);
+    for (auto e : ev_pool) (void)hipEventDestroy(e);
+    if (h_pin) (void)hipHostFree(h_pin);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+float* Engine::pinned(size_t count) {
+    if (count > h_pin_n) {
+        if (h_pin) (void)hipHostFree(h_pin);
+        h_pin = nullptr;
+        h_pin_n = 0;
+        HIP_CHECK(hipHostMalloc((void**)&h_pin, count * sizeof(float), hipHostMallocDefault));
+        h_pin_n = count;
+    }
+    return h_pin;
+}
+
+void Engine::reset() {
+    // CEM/PI2/SPSA reset(): previous solution <- bounds midpoint (cem.py:138-149, pi2.py:98-105)
+    if (cfg.optimizer == BBMPC_OPT_NONE || cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH) return;
+    std::vector<float> m((size_t)A * HU);
+    for (int i = 0; i < A * HU; ++i) m[i] = (lo[i % U] + hi[i % U]) / 2.0f;
+    HIP_CHECK(hipMemcpyAsync(d_prev_mean.p, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout helpers (host)
+// ------------------------------------------------------------------------------------------------
+void Engine::to_internal(const float* ref, int n_pop, float* out) const {
+    // [n,A,H,U] -> [A][HU][Nst]
+    for (int n = 0; n < n_pop; ++n)
+        for (int a = 0; a < A; ++a)
+            for (int j = 0; j < HU; ++j) out[((size_t)a * HU + j) * Nst + n] = ref[((size_t)n * A + a) * HU + j];
+}
+void Engine::from_internal(const float* in, int n_pop, float* ref) const {
+    for (int n = 0; n < n_pop; ++n)
+        for (int a = 0; a < A; ++a)
+            for (int j = 0; j < HU; ++j) ref[((size_t)n * A + a) * HU + j] = in[((size_t)a * HU + j) * Nst + n];
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling (HIP events on the launch stream around the dominant kernel)
+// ------------------------------------------------------------------------------------------------
+void Engine::prof_begin() {
+    if (!profiling) return;
+    if (ev_used + 2 > ev_pool.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreate(&e));
+            ev_pool.push_back(e);
+        }
+    }
+    HIP_CHECK(hipEventRecord(ev_pool[ev_used], stream));
+}
+void Engine::prof_end() {
+    if (!profiling) return;
+    HIP_CHECK(hipEventRecord(ev_pool[ev_used + 1], stream));
+    ev_used += 2;
+}
+void Engine::get_profile(double* ms, int64_t* launches) {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < ev_used; i += 2) {
+        float t = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&t, ev_pool[i], ev_pool[i + 1]));
+        tot += t;
+    }
+    *ms = tot;
+    *launches = (int64_t)(ev_used / 2);
+    ev_used = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------------------------
+void Engine::launch_rollout(int mode, bool pen, RolloutArgs& ra) {
+    // few trajectories -> one wave per workgroup so every wave gets its own SIMD (latency);
+    // many -> 256-thread workgroups.
+    const int bs = ((long)ra.n_pop * A <= 16384) ? 64 : 256;
+    dim3 grid((ra.n_pop + bs - 1) / bs, A), block(bs);
+    prof_begin();
+    if (mode == SRC_REF) {
+        const size_t lds = (size_t)bs * 33 * sizeof(float);
+        hipLaunchKernelGGL((k_rollout_pendulum<SRC_REF, false>), grid, block, lds, stream, ra);
+    } else if (mode == SRC_UNIFORM) {
+        hipLaunchKernelGGL((k_rollout_pendulum<SRC_UNIFORM, false>), grid, block, 0, stream, ra);
+    } else if (mode == SRC_TRUNC && !pen) {
+        hipLaunchKernelGGL((k_rollout_pendulum<SRC_TRUNC, false>), grid, block, 0, stream, ra);
+    } else if (mode == SRC_TRUNC && pen) {
+        hipLaunchKernelGGL((k_rollout_pendulum<SRC_TRUNC, true>), grid, block, 0, stream, ra);
+    } else if (mode == SRC_BUF) {
+        hipLaunchKernelGGL((k_rollout_pendulum<SRC_BUF, true>), grid, block, 0, stream, ra);
+    } else {
+        throw HipError(BBMPC_E_INVALID, "bad rollout mode");
+    }
+    HIP_CHECK(hipGetLastError());
+    prof_end();
+}
+
+void Engine::capture_trace(int it) {
+    if (!trace_on) return;
+    const size_t nr = (size_t)A * Nst, nm = (size_t)A * HU, ns = (size_t)A * HU * Nst, ne = (size_t)A * std::max(k, 1);
+    const int nit = std::max(iters, 1);
+    if (!t_rewards.p) {
+        t_rewards.alloc(nr * nit);
+        t_mean.alloc(nm * nit);
+        t_var.alloc(nm * nit);
+        t_samples.alloc(ns * nit);
+        t_elites.alloc(ne * nit);
+    }
+    HIP_CHECK(hipMemcpyAsync(t_rewards.p + nr * it, d_rewards.p, nr * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(t_mean.p + nm * it, d_mean.p, nm * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(t_var.p + nm * it, d_var.p, nm * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(t_samples.p + ns * it, d_samples.p, ns * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(t_elites.p + ne * it, d_elites.p, ne * 4, hipMemcpyDeviceToDevice, stream));
+}
+
+void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_out, uint32_t step) {
+    FinalArgs fa;
+    fa.A = A; fa.U = U; fa.S = S;
+    fa.agent_offset = cfg.agent_offset;
+    fa.fix_q1 = fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
+    fa.fix_q7 = fix(BBMPC_FIX_Q7_EXPL_NOISE_ZERO_MEAN);
+    fa.add_noise = add_noise;
+    fa.state = d_state_in;
+    fa.action = d_action.p;
+    fa.lo = d_lo.p; fa.hi = d_hi.p;
+    fa.inj = injected(BBMPC_NOISE_EXPLORATION);
+    fa.record = d_record_out;
+    fa.key = key(step);
+    fa.key.q_per_agent = (uint32_t)((U + 3) / 4);
+    hipLaunchKernelGGL(k_finalize_pendulum, dim3((A + 63) / 64), dim3(64), 0, stream, fa);
+    HIP_CHECK(hipGetLastError());
+}
+
+void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_record_out) {
+    REQUIRE(cfg.optimizer != BBMPC_OPT_NONE, BBMPC_E_STATE, "handle was created without an optimizer");
+    const uint32_t step = step_counter++;
+    RolloutArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.n_pop = N; ra.A = A; ra.H = H; ra.U = U; ra.S = S; ra.HU = HU; ra.Nst = Nst;
+    ra.agent_offset = cfg.agent_offset;
+    ra.fix_q1 = fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
+    ra.reward_kind = cfg.reward;
+    ra.state = d_state_in;
+    ra.mean = d_mean.p; ra.sigma = d_sigma.p;
+    ra.lo = d_lo.p; ra.hi = d_hi.p;
+    ra.samples = d_samples.p;
+    ra.rewards = d_rewards.p;
+    ra.penalty_out = d_penalty.p;
+    ra.key = key(step);
+
+    RefitArgs rf;
+    memset(&rf, 0, sizeof(rf));
+    rf.N = N; rf.A = A; rf.H = H; rf.U = U; rf.HU = HU; rf.Nst = Nst; rf.k = k;
+    rf.alpha = cfg.alpha;
+    rf.inv_lamda = 1.0f / cfg.lamda;
+    rf.rewards = d_rewards.p; rf.samples = d_samples.p;
+    rf.lo = d_lo.p; rf.hi = d_hi.p;
+    rf.mean = d_mean.p; rf.var = d_var.p; rf.sigma = d_sigma.p;
+    rf.elites = d_elites.p; rf.action = d_action.p;
+
+    const int nelem = A * HU;
+    const size_t inj_stride = (size_t)A * HU * Nst;
+    switch (cfg.optimizer) {
+        case BBMPC_OPT_RANDOM_SEARCH: {
+            ra.stream = BBMPC_NOISE_UNIFORM; ra.iter = 0;
+            ra.inj = injected(BBMPC_NOISE_UNIFORM);
+            launch_rollout(SRC_UNIFORM, false, ra);
+            hipLaunchKernelGGL(k_refit_argmax, dim3(A), dim3(REFIT_THREADS), 0, stream, rf);
+            HIP_CHECK(hipGetLastError());
+            capture_trace(0);
+            break;
+        }
+        case BBMPC_OPT_CEM: {
+            hipLaunchKernelGGL(k_dist_init, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, HU, U, d_lo.p, d_hi.p,
+                               d_prev_mean.p, d_var0.p, d_mean.p, d_var.p, d_sigma.p, 1);
+            // iters == 0: action = mean[:,0] of the untouched distribution
+            HIP_CHECK(hipMemcpy2DAsync(d_action.p, U * 4, d_prev_mean.p, HU * 4, U * 4, A, hipMemcpyDeviceToDevice, stream));
+            const float* inj_t = injected(BBMPC_NOISE_TRUNC_NORMAL);
+            // LDS budget for the refit: rewards + elite idx + elite tile
+            const int kpad = (k + 3) & ~3;
+            int JC = (int)((size_t)(60 * 1024 / 4 - Nst - kpad) / (size_t)k);
+            JC = std::max(1, std::min(JC, HU));
+            const size_t lds = (size_t)(Nst + kpad + (size_t)k * JC) * 4;
+            for (int it = 0; it < iters; ++it) {
+                ra.stream = BBMPC_NOISE_TRUNC_NORMAL; ra.iter = (uint32_t)it;
+                ra.inj = inj_t ? inj_t + inj_stride * it : nullptr;
+                launch_rollout(SRC_TRUNC, false, ra);
+                hipLaunchKernelGGL(k_refit_cem, dim3(A), dim3(REFIT_THREADS), lds, stream, rf, JC);
+                HIP_CHECK(hipGetLastError());
+                capture_trace(it);
+            }
+            if (fix(BBMPC_FIX_Q2_CEM_WARM_START))
+                HIP_CHECK(hipMemcpyAsync(d_prev_mean.p, d_mean.p, (size_t)nelem * 4, hipMemcpyDeviceToDevice, stream));
+            break;
+        }
+        case BBMPC_OPT_PI2: {
+            hipLaunchKernelGGL(k_dist_init, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, HU, U, d_lo.p, d_hi.p,
+                               d_prev_mean.p, d_var0.p, d_mean.p, d_var.p, d_sigma.p, 0);
+            HIP_CHECK(hipMemcpy2DAsync(d_action.p, U * 4, d_prev_mean.p, HU * 4, U * 4, A, hipMemcpyDeviceToDevice, stream));
+            const float* inj_t = injected(BBMPC_NOISE_TRUNC_NORMAL);
+            const size_t lds = (size_t)(Nst + 64) * 4;
+            for (int it = 0; it < iters; ++it) {
+                ra.stream = BBMPC_NOISE_TRUNC_NORMAL; ra.iter = (uint32_t)it;
+                ra.inj = inj_t ? inj_t + inj_stride * it : nullptr;
+                launch_rollout(SRC_TRUNC, true, ra);
+                hipLaunchKernelGGL(k_refit_pi2, dim3(A), dim3(REFIT_THREADS), lds, stream, rf);
+                HIP_CHECK(hipGetLastError());
+                capture_trace(it);
+            }
+            hipLaunchKernelGGL(k_shift_left, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, H, U, d_mean.p, d_prev_mean.p);
+            HIP_CHECK(hipGetLastError());
+            break;
+        }
+        default:
+            throw HipError(BBMPC_E_UNSUPPORTED, "optimizer not built yet");
+    }
+    finalize(d_state_in, add_noise, d_record_out, step);
+}
+
+void Engine::evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop, float* d_rew_out) {
+    // rewards come back in the reference layout [n_pop, A]; the kernel writes [A][stride] so use a scratch
+    // and a strided 2D copy (A is small).
+    REQUIRE(n_pop >= 1, BBMPC_E_INVALID, "n_pop must be >= 1");
+    const int st = ((n_pop + 63) / 64) * 64;
+    if (d_eval_rew.n < (size_t)A * st) d_eval_rew.alloc((size_t)A * st);
+    RolloutArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.n_pop = n_pop; ra.A = A; ra.H = H; ra.U = U; ra.S = S; ra.HU = HU; ra.Nst = st;
+    ra.agent_offset = cfg.agent_offset;
+    ra.fix_q1 = fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
+    ra.reward_kind = cfg.reward;
+    ra.state = d_state_in;
+    ra.seq = d_seq;
+    ra.rewards = d_eval_rew.p;
+    launch_rollout(SRC_REF, false, ra);
+    // [A][st] -> [n_pop][A]: per agent a strided copy (dst pitch A floats, width 1 float)
+    for (int a = 0; a < A; ++a)
+        HIP_CHECK(hipMemcpy2DAsync(d_rew_out + a, (size_t)A * 4, d_eval_rew.p + (size_t)a * st, 4, 4, n_pop,
+                                   hipMemcpyDeviceToDevice, stream));
+}
+
+void Engine::step_dev(const float* d_states, const float* d_actions, int astride, int batch, float* d_next, float* d_rew) {
+    REQUIRE(batch >= 1, BBMPC_E_INVALID, "batch must be >= 1");
+    hipLaunchKernelGGL(k_step_pendulum, dim3((batch + 63) / 64), dim3(64), 0, stream, d_states, d_actions, astride, batch,
+                       (int)fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER), d_next, d_rew);
+    HIP_CHECK(hipGetLastError());
+}
+
+void Engine::reward_dev(const float* d_cur, const float* d_next, const float* d_act, int batch, float* d_rew) {
+    hipLaunchKernelGGL(k_reward_only, dim3((batch + 63) / 64), dim3(64), 0, stream, d_cur, d_next, d_act, batch, S, U,
+                       cfg.reward, (int)fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER), d_rew);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// parity hooks
+// ------------------------------------------------------------------------------------------------
+void Engine::inject(int kind, const float* data, int64_t count) {
+    if (!data) {
+        inj.erase(kind);
+        return;
+    }
+    switch (kind) {
+        case BBMPC_NOISE_TRUNC_NORMAL:
+        case BBMPC_NOISE_UNIFORM:
+        case BBMPC_NOISE_RADEMACHER: {
+            const int nit = (kind == BBMPC_NOISE_UNIFORM) ? 1 : std::max(iters, 1);
+            const int64_t per = (int64_t)N * A * HU;
+            REQUIRE(count == per * nit, BBMPC_E_INVALID, "injected noise has the wrong element count");
+            std::vector<float> tmp((size_t)A * HU * Nst * nit, 0.0f);
+            for (int it = 0; it < nit; ++it) to_internal(data + per * it, N, tmp.data() + (size_t)A * HU * Nst * it);
+            auto& b = inj[kind];
+            b.alloc(tmp.size());
+            HIP_CHECK(hipMemcpy(b.p, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+            break;
+        }
+        case BBMPC_NOISE_EXPLORATION: {
+            REQUIRE(count == (int64_t)A * U, BBMPC_E_INVALID, "exploration noise must be [A,U]");
+            auto& b = inj[kind];
+            b.alloc((size_t)count);
+            HIP_CHECK(hipMemcpy(b.p, data, (size_t)count * 4, hipMemcpyHostToDevice));
+            break;
+        }
+        default:
+            throw HipError(BBMPC_E_UNSUPPORTED, "noise kind not supported yet");
+    }
+}
+
+__global__ void k_dump_noise(RngKey key, uint32_t stream, uint32_t iter, int N, int A, int HU, int agent_offset,
+                             float* out /* reference layout [N,A,HU] */) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * A * HU) return;
+    const int j = idx % HU, a = (idx / HU) % A, n = idx / (HU * A);
+    const U4 b = rng_block(key, stream, iter, (uint32_t)n, (uint32_t)(agent_offset + a), (uint32_t)j);
+    const uint32_t w = pick_word(b, (uint32_t)j);
+    float v;
+    if (stream == BBMPC_NOISE_UNIFORM || stream == BBMPC_NOISE_PSO_RESEED_UNIFORM || stream == BBMPC_NOISE_PSO_RESET_POS ||
+        stream == BBMPC_NOISE_PSO_RESET_VEL)
+        v = word_to_uniform(w);
+    else if (stream == BBMPC_NOISE_RADEMACHER)
+        v = word_to_rademacher(w);
+    else
+        v = word_to_trunc_normal(w);
+    out[idx] = v;
+}
+
+void Engine::dump_noise(int kind, int control_step, int iteration, float* out, int64_t count) {
+    int n = N, a = A, hu = HU;
+    RngKey kk = key((uint32_t)control_step);
+    if (kind == BBMPC_NOISE_EXPLORATION) {
+        n = 1; hu = U;
+        kk.q_per_agent = (uint32_t)((U + 3) / 4);
+    }
+    const int64_t total = (int64_t)n * a * hu;
+    REQUIRE(count == total, BBMPC_E_INVALID, "dump_noise: wrong element count");
+    DevBuf<float> tmp;
+    tmp.alloc((size_t)total);
+    hipLaunchKernelGGL(k_dump_noise, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, kk, (uint32_t)kind,
+                       (uint32_t)iteration, n, a, hu, cfg.agent_offset, tmp.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(out, tmp.p, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void Engine::get_trace(int it, int item, void* out, int64_t bytes) {
+    REQUIRE(trace_on && t_rewards.p, BBMPC_E_STATE, "trace capture is not enabled or no optimize() call yet");
+    REQUIRE(it >= 0 && it < std::max(iters, 1), BBMPC_E_INVALID, "trace iteration out of range");
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const size_t nr = (size_t)A * Nst, nm = (size_t)A * HU, ns = (size_t)A * HU * Nst, ne = (size_t)A * std::max(k, 1);
+    switch (item) {
+        case BBMPC_TRACE_REWARDS: {
+            REQUIRE(bytes == (int64_t)N * A * 4, BBMPC_E_INVALID, "trace rewards: wrong size");
+            std::vector<float> tmp(nr);
+            HIP_CHECK(hipMemcpy(tmp.data(), t_rewards.p + nr * it, nr * 4, hipMemcpyDeviceToHost));
+            float* o = (float*)out;
+            for (int n = 0; n < N; ++n)
+                for (int a = 0; a < A; ++a) o[(size_t)n * A + a] = tmp[(size_t)a * Nst + n];
+            break;
+        }
+        case BBMPC_TRACE_MEAN:
+        case BBMPC_TRACE_VAR: {
+            REQUIRE(bytes == (int64_t)nm * 4, BBMPC_E_INVALID, "trace mean/var: wrong size");
+            HIP_CHECK(hipMemcpy(out, (item == BBMPC_TRACE_MEAN ? t_mean.p : t_var.p) + nm * it, nm * 4, hipMemcpyDeviceToHost));
+            break;
+        }
+        case BBMPC_TRACE_ELITES: {
+            const size_t cnt = (cfg.optimizer == BBMPC_OPT_CEM) ? (size_t)A * k : (size_t)A;
+            REQUIRE(bytes == (int64_t)cnt * 4, BBMPC_E_INVALID, "trace elites: wrong size");
+            HIP_CHECK(hipMemcpy(out, t_elites.p + ne * it, cnt * 4, hipMemcpyDeviceToHost));
+            break;
+        }
+        case BBMPC_TRACE_SAMPLES: {
+            REQUIRE(bytes == (int64_t)N * A * HU * 4, BBMPC_E_INVALID, "trace samples: wrong size");
+            std::vector<float> tmp(ns);
+            HIP_CHECK(hipMemcpy(tmp.data(), t_samples.p + ns * it, ns * 4, hipMemcpyDeviceToHost));
+            from_internal(tmp.data(), N, (float*)out);
+            break;
+        }
+        default:
+            throw HipError(BBMPC_E_INVALID, "unknown trace item");
+    }
+}
+
+void Engine::get_state(const std::string& name, float* out, int64_t count) {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const size_t nm = (size_t)A * HU;
+    const float* src = nullptr;
+    if (name == "prev_mean") src = d_prev_mean.p;
+    else if (name == "mean") src = d_mean.p;
+    else if (name == "var") src = d_var.p;
+    else if (name == "sigma") src = d_sigma.p;
+    REQUIRE(src, BBMPC_E_INVALID, "unknown state tensor '" + name + "'");
+    REQUIRE(count == (int64_t)nm, BBMPC_E_INVALID, "state tensor has A*H*U elements");
+    HIP_CHECK(hipMemcpy(out, src, nm * 4, hipMemcpyDeviceToHost));
+}
+
+void Engine::set_state(const std::string& name, const float* data, int64_t count) {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const size_t nm = (size_t)A * HU;
+    float* dst = nullptr;
+    if (name == "prev_mean") dst = d_prev_mean.p;
+    else if (name == "var0") dst = d_var0.p;
+    REQUIRE(dst, BBMPC_E_INVALID, "unknown/unsettable state tensor '" + name + "'");
+    REQUIRE(count == (int64_t)nm, BBMPC_E_INVALID, "state tensor has A*H*U elements");
+    HIP_CHECK(hipMemcpy(dst, data, nm * 4, hipMemcpyHostToDevice));
+}
+
+}  // namespace bbmpc
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+using bbmpc::Engine;
+using bbmpc::HipError;
+
+struct bbmpc_handle_s {
+    Engine* e;
+};
+
+#define API_BEGIN try {
+#define API_END                                   \
+    }                                             \
+    catch (const HipError& ex) {                  \
+        bbmpc::g_last_error = ex.what();          \
+        return ex.code;                           \
+    }                                             \
+    catch (const std::exception& ex) {            \
+        bbmpc::g_last_error = ex.what();          \
+        return BBMPC_E_INVALID;                   \
+    }                                             \
+    return BBMPC_OK;
+
+#define CHECK_HANDLE(h) \
+    if (!(h) || !(h)->e) throw HipError(BBMPC_E_INVALID, "null handle")
+#define CHECK_PTR(p) \
+    if (!(p)) throw HipError(BBMPC_E_INVALID, "null pointer argument: " #p)
+
+extern "C" {
+
+int bbmpc_abi_version(void) { return BBMPC_ABI_VERSION; }
+const char* bbmpc_last_error(void) { return bbmpc::g_last_error.c_str(); }
+
+int bbmpc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int bbmpc_create(const bbmpc_config* cfg, bbmpc_handle* out) {
+    API_BEGIN
+    CHECK_PTR(cfg);
+    CHECK_PTR(out);
+    *out = nullptr;
+    Engine* e = new Engine(*cfg);
+    *out = new bbmpc_handle_s{e};
+    API_END
+}
+
+int bbmpc_destroy(bbmpc_handle h) {
+    API_BEGIN
+    if (h) {
+        delete h->e;
+        delete h;
+    }
+    API_END
+}
+
+int bbmpc_set_stream(bbmpc_handle h, void* s) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    HIP_CHECK(hipStreamSynchronize(h->e->stream));
+    h->e->stream = s ? (hipStream_t)s : h->e->own_stream;
+    API_END
+}
+
+int bbmpc_set_mlp(bbmpc_handle h, int32_t, const int32_t*, const int32_t*, const float* const*, const float* const*,
+                  int32_t, const float* const*) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    throw HipError(BBMPC_E_UNSUPPORTED, "learned-MLP dynamics kernels are not built yet");
+    API_END
+}
+
+int bbmpc_reset(bbmpc_handle h) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    h->e->reset();
+    API_END
+}
+
+int bbmpc_optimize_dev(bbmpc_handle h, const float* d_state, int32_t, int32_t noise, float* d_record) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(d_state);
+    CHECK_PTR(d_record);
+    h->e->optimize_dev(d_state, noise, d_record);
+    API_END
+}
+
+int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise, float* action, float* next_state,
+                   float* reward) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(state);
+    Engine& e = *h->e;
+    const size_t ns = (size_t)e.A * e.S, nr = (size_t)e.A * e.rec;
+    float* pin = e.pinned(ns + nr);
+    memcpy(pin, state, ns * 4);
+    HIP_CHECK(hipMemcpyAsync(e.d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e.stream));
+    (void)t;  // the reference evaluator accepts and ignores time_step (deterministic.py:26)
+    e.optimize_dev(e.d_state.p, noise, e.d_record.p);
+    HIP_CHECK(hipMemcpyAsync(pin + ns, e.d_record.p, nr * 4, hipMemcpyDeviceToHost, e.stream));
+    HIP_CHECK(hipStreamSynchronize(e.stream));
+    const float* r = pin + ns;
+    for (int a = 0; a < e.A; ++a) {
+        if (action) memcpy(action + (size_t)a * e.U, r + (size_t)a * e.rec, e.U * 4);
+        if (next_state) memcpy(next_state + (size_t)a * e.S, r + (size_t)a * e.rec + e.U, e.S * 4);
+        if (reward) reward[a] = r[(size_t)a * e.rec + e.U + e.S];
+    }
+    API_END
+}
+
+int bbmpc_evaluate_dev(bbmpc_handle h, const float* d_state, const float* d_seq, int32_t n_pop, float* d_rewards) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(d_state);
+    CHECK_PTR(d_seq);
+    CHECK_PTR(d_rewards);
+    h->e->evaluate_dev(d_state, d_seq, n_pop, d_rewards);
+    API_END
+}
+
+int bbmpc_evaluate(bbmpc_handle h, const float* state, const float* seq, int32_t n_pop, float* rewards) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(state);
+    CHECK_PTR(seq);
+    CHECK_PTR(rewards);
+    Engine& e = *h->e;
+    if (n_pop < 1) throw HipError(BBMPC_E_INVALID, "n_pop must be >= 1");
+    const size_t nseq = (size_t)n_pop * e.A * e.HU, nrew = (size_t)n_pop * e.A;
+    if (e.d_eval_seq.n < nseq + nrew) e.d_eval_seq.alloc(nseq + nrew);
+    HIP_CHECK(hipMemcpyAsync(e.d_state.p, state, (size_t)e.A * e.S * 4, hipMemcpyHostToDevice, e.stream));
+    HIP_CHECK(hipMemcpyAsync(e.d_eval_seq.p, seq, nseq * 4, hipMemcpyHostToDevice, e.stream));
+    e.evaluate_dev(e.d_state.p, e.d_eval_seq.p, n_pop, e.d_eval_seq.p + nseq);
+    HIP_CHECK(hipMemcpyAsync(rewards, e.d_eval_seq.p + nseq, nrew * 4, hipMemcpyDeviceToHost, e.stream));
+    HIP_CHECK(hipStreamSynchronize(e.stream));
+    API_END
+}
+
+int bbmpc_step_dev(bbmpc_handle h, const float* d_states, const float* d_actions, int32_t astride, int32_t batch,
+                   float* d_next, float* d_rew) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(d_states);
+    CHECK_PTR(d_actions);
+    h->e->step_dev(d_states, d_actions, astride, batch, d_next, d_rew);
+    API_END
+}
+
+int bbmpc_predict_next_state(bbmpc_handle h, const float* states, const float* actions, int32_t batch, float* next) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(states);
+    CHECK_PTR(actions);
+    CHECK_PTR(next);
+    Engine& e = *h->e;
+    if (batch < 1) throw HipError(BBMPC_E_INVALID, "batch must be >= 1");
+    const size_t ns = (size_t)batch * e.S, na = (size_t)batch * e.U;
+    if (e.d_step_a.n < 2 * ns + na) e.d_step_a.alloc(2 * ns + na);
+    float* ds = e.d_step_a.p; float* da = ds + ns; float* dn = da + na;
+    HIP_CHECK(hipMemcpyAsync(ds, states, ns * 4, hipMemcpyHostToDevice, e.stream));
+    HIP_CHECK(hipMemcpyAsync(da, actions, na * 4, hipMemcpyHostToDevice, e.stream));
+    e.step_dev(ds, da, e.U, batch, dn, nullptr);
+    HIP_CHECK(hipMemcpyAsync(next, dn, ns * 4, hipMemcpyDeviceToHost, e.stream));
+    HIP_CHECK(hipStreamSynchronize(e.stream));
+    API_END
+}
+
+int bbmpc_evaluate_next_reward(bbmpc_handle h, const float* states, const float* next_states, const float* actions,
+                               int32_t batch, float* rewards) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(states);
+    CHECK_PTR(next_states);
+    CHECK_PTR(actions);
+    CHECK_PTR(rewards);
+    Engine& e = *h->e;
+    if (batch < 1) throw HipError(BBMPC_E_INVALID, "batch must be >= 1");
+    const size_t ns = (size_t)batch * e.S, na = (size_t)batch * e.U;
+    if (e.d_step_b.n < 2 * ns + na + batch) e.d_step_b.alloc(2 * ns + na + batch);
+    float* dc = e.d_step_b.p; float* dn = dc + ns; float* da = dn + ns; float* dr = da + na;
+    HIP_CHECK(hipMemcpyAsync(dc, states, ns * 4, hipMemcpyHostToDevice, e.stream));
+    HIP_CHECK(hipMemcpyAsync(dn, next_states, ns * 4, hipMemcpyHostToDevice, e.stream));
+    HIP_CHECK(hipMemcpyAsync(da, actions, na * 4, hipMemcpyHostToDevice, e.stream));
+    e.reward_dev(dc, dn, da, batch, dr);
+    HIP_CHECK(hipMemcpyAsync(rewards, dr, (size_t)batch * 4, hipMemcpyDeviceToHost, e.stream));
+    HIP_CHECK(hipStreamSynchronize(e.stream));
+    API_END
+}
+
+int bbmpc_inject_noise(bbmpc_handle h, int32_t kind, const float* data, int64_t count) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    HIP_CHECK(hipStreamSynchronize(h->e->stream));
+    h->e->inject(kind, data, count);
+    API_END
+}
+
+int bbmpc_dump_noise(bbmpc_handle h, int32_t kind, int32_t control_step, int32_t iteration, float* out, int64_t count) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(out);
+    h->e->dump_noise(kind, control_step, iteration, out, count);
+    API_END
+}
+
+int bbmpc_set_trace(bbmpc_handle h, int32_t enabled) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    h->e->trace_on = enabled != 0;
+    API_END
+}
+
+int bbmpc_get_trace(bbmpc_handle h, int32_t iteration, int32_t item, void* out, int64_t bytes) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(out);
+    h->e->get_trace(iteration, item, out, bytes);
+    API_END
+}
+
+int bbmpc_get_state(bbmpc_handle h, const char* name, float* out, int64_t count) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(name);
+    CHECK_PTR(out);
+    h->e->get_state(name, out, count);
+    API_END
+}
+
+int bbmpc_set_state(bbmpc_handle h, const char* name, const float* data, int64_t count) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(name);
+    CHECK_PTR(data);
+    h->e->set_state(name, data, count);
+    API_END
+}
+
+int bbmpc_set_profiling(bbmpc_handle h, int32_t enabled) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    h->e->profiling = enabled != 0;
+    API_END
+}
+
+int bbmpc_get_profile(bbmpc_handle h, double* ms, int64_t* launches, const char** name) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(ms);
+    CHECK_PTR(launches);
+    h->e->get_profile(ms, launches);
+    if (name) *name = h->e->dominant_kernel;
+    API_END
+}
+
+int bbmpc_synchronize(bbmpc_handle h) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    HIP_CHECK(hipStreamSynchronize(h->e->stream));
+    API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+// Host-side engine behind the C ABI: owns device memory, the stream, RNG step
+// counter, injected-noise buffers and traces, and enqueues the per-control-step
+// kernel sequence of each optimizer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/bbmpc.h"
+#include "kernels_refit.hpp"
+#include "kernels_rollout.hpp"
+
+namespace bbmpc {
+
+struct HipError : std::runtime_error {
+    int code;
+    HipError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIP_CHECK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            throw HipError(BBMPC_E_HIP, std::string(#expr) + " failed: " + hipGetErrorString(_e) + \
+                                            " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+    } while (0)
+
+#define REQUIRE(cond, code, msg) \
+    do {                         \
+        if (!(cond)) throw HipError((code), (msg)); \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
+    }
+    void zero(hipStream_t s) {
+        if (p) HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), s));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+struct Engine {
+    bbmpc_config cfg;
+    int N, A, H, U, S, HU, Nst, iters, k;
+    int rec;                 // record width U+S+1
+    std::vector<float> lo, hi;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    uint32_t step_counter = 0;
+    bool trace_on = false, profiling = false;
+
+    // device state
+    DevBuf<float> d_lo, d_hi, d_state, d_record, d_action;
+    DevBuf<float> d_prev_mean, d_var0, d_mean, d_var, d_sigma;
+    DevBuf<float> d_samples, d_rewards, d_penalty;
+    DevBuf<int> d_elites;
+    // evaluate() scratch (grown on demand)
+    DevBuf<float> d_eval_seq, d_eval_rew, d_step_a, d_step_b, d_step_c, d_step_d;
+    // injected noise (internal layout), keyed by BBMPC_NOISE_*
+    std::map<int, DevBuf<float>> inj;
+    // traces
+    DevBuf<float> t_rewards, t_mean, t_var, t_samples;
+    DevBuf<int> t_elites;
+    // pinned staging
+    float* h_pin = nullptr;
+    size_t h_pin_n = 0;
+    // profiling
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    const char* dominant_kernel = "k_rollout_pendulum";
+
+    explicit Engine(const bbmpc_config& c);
+    ~Engine();
+
+    RngKey key(uint32_t step) const {
+        RngKey kk;
+        kk.k0 = (uint32_t)(cfg.seed & 0xffffffffu);
+        kk.k1 = (uint32_t)(cfg.seed >> 32);
+        kk.step = step;
+        kk.q_per_agent = (uint32_t)((HU + 3) / 4);
+        return kk;
+    }
+    bool fix(uint32_t bit) const { return (cfg.quirks & bit) != 0; }
+    const float* injected(int kind) const {
+        auto it = inj.find(kind);
+        return (it == inj.end() || !it->second.p) ? nullptr : it->second.p;
+    }
+    float* pinned(size_t count);
+
+    void reset();
+    void optimize_dev(const float* d_state_in, int add_noise, float* d_record_out);
+    void evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop, float* d_rew_out);
+    void step_dev(const float* d_states, const float* d_actions, int astride, int batch, float* d_next, float* d_rew);
+    void reward_dev(const float* d_cur, const float* d_next, const float* d_act, int batch, float* d_rew);
+
+    void inject(int kind, const float* data, int64_t count);
+    void dump_noise(int kind, int control_step, int iteration, float* out, int64_t count);
+    void get_trace(int iteration, int item, void* out, int64_t bytes);
+    void get_state(const std::string& name, float* out, int64_t count);
+    void set_state(const std::string& name, const float* data, int64_t count);
+    void get_profile(double* ms, int64_t* launches);
+
+    // helpers
+    void launch_rollout(int mode, bool pen, RolloutArgs& ra);
+    void prof_begin();
+    void prof_end();
+    void capture_trace(int it);
+    void finalize(const float* d_state_in, int add_noise, float* d_record_out, uint32_t step);
+    void to_internal(const float* ref, int n_pop, float* internal_host) const;     // [n,A,H,U] -> [A][HU][Nst]
+    void from_internal(const float* internal_host, int n_pop, float* ref) const;
+};
+
+}  // namespace bbmpc

@@ -1,0 +1,264 @@
+// Distribution-refit kernels: the "refit block" of each optimizer iteration
+// (SURVEY.md 3.2).  One workgroup per agent; rewards of the agent's population
+// sit in LDS, cross-lane reductions use wave64 shuffles.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "models.hpp"
+#include "rng.hpp"
+
+namespace bbmpc {
+
+constexpr int REFIT_THREADS = 1024;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// (value,index) arg-max with tf.math.argmax tie rule: first (lowest index) maximum wins.
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(i, o, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+struct RefitArgs {
+    int N, A, H, U, HU, Nst, k;
+    float alpha;           // CEM
+    float inv_lamda;       // PI2: 1/lamda
+    const float* rewards;  // [A][Nst]
+    const float* samples;  // [A][HU][Nst]
+    const float* lo;       // [U]
+    const float* hi;       // [U]
+    float* mean;           // [A][HU]  in/out
+    float* var;            // [A][HU]  in/out (CEM)
+    float* sigma;          // [A][HU]  out: sqrt of the constrained variance the NEXT iteration samples with
+    int* elites;           // [A][k] out (sorted, best first)   | RandomSearch/PSO: [A] best index
+    float* action;         // [A][U] out
+};
+
+// sigma = sqrt(min(((mean-lo)/2)^2, ((hi-mean)/2)^2, var))        cem.py:79-88
+__device__ __forceinline__ float cem_sigma(float mean, float var, float lo, float hi) {
+    const float lb = (mean - lo) / 2.0f;
+    const float ub = (hi - mean) / 2.0f;
+    return sqrtf(fminf(fminf(lb * lb, ub * ub), var));
+}
+
+// (Re)initialise the distribution at the start of a control step.
+// CEM quirk Q2: every control step restarts from the constructor mean/variance (cem.py:129-134).
+__global__ void k_dist_init(int A, int HU, int U, const float* lo, const float* hi, const float* prev_mean,
+                            const float* var0, float* mean, float* var, float* sigma, int constrain) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A * HU) return;
+    const int u = i % U;
+    const float m = prev_mean[i];
+    const float v = var0[i];
+    mean[i] = m;
+    if (var) var[i] = v;
+    sigma[i] = constrain ? cem_sigma(m, v, lo[u], hi[u]) : sqrtf(v);
+}
+
+// CEM refit  cem.py:97-125: top-k (sorted, ties -> lower index), elite mean / biased variance
+// (accumulated sequentially in elite order), alpha smoothing.
+// LDS: rewards[Nst] | elite idx[kpad] | elite tile [k][JC]
+__global__ __launch_bounds__(REFIT_THREADS) void k_refit_cem(RefitArgs p, int JC) {
+    extern __shared__ float smem[];
+    const int a = blockIdx.x;
+    const int tid = threadIdx.x;
+    float* r = smem;
+    int* eidx = (int*)(smem + p.Nst);
+    const int kpad = (p.k + 3) & ~3;
+    float* tile = smem + p.Nst + kpad;
+
+    for (int n = tid; n < p.N; n += REFIT_THREADS) r[n] = p.rewards[(size_t)a * p.Nst + n];
+    __syncthreads();
+    // rank of n = #{m : r[m] > r[n]  or  (r[m] == r[n] and m < n)}; all lanes read the same r[m] (broadcast)
+    for (int n = tid; n < p.N; n += REFIT_THREADS) {
+        const float rn = r[n];
+        int rank = 0;
+        for (int m = 0; m < p.N; ++m) {
+            const float rm = r[m];
+            rank += (rm > rn || (rm == rn && m < n)) ? 1 : 0;
+        }
+        if (rank < p.k) eidx[rank] = n;
+    }
+    __syncthreads();
+    if (p.elites)
+        for (int e = tid; e < p.k; e += REFIT_THREADS) p.elites[a * p.k + e] = eidx[e];
+
+    const float inv_k = (float)p.k;
+    for (int j0 = 0; j0 < p.HU; j0 += JC) {
+        const int jc = min(JC, p.HU - j0);
+        __syncthreads();
+        for (int idx = tid; idx < p.k * jc; idx += REFIT_THREADS) {
+            const int jj = idx / p.k, e = idx % p.k;
+            tile[e * JC + jj] = p.samples[(size_t)(a * p.HU + j0 + jj) * p.Nst + eidx[e]];
+        }
+        __syncthreads();
+        if (tid < jc) {
+            const int j = j0 + tid;
+            float sum = 0.0f;
+            for (int e = 0; e < p.k; ++e) sum = sum + tile[e * JC + tid];
+            const float em = sum / inv_k;                                  // reduce_mean = sum / k
+            float vs = 0.0f;
+            for (int e = 0; e < p.k; ++e) {
+                const float d = tile[e * JC + tid] - em;
+                vs = vs + d * d;
+            }
+            const float ev = vs / inv_k;
+            const int aj = a * p.HU + j;
+            const float one_m = 1.0f - p.alpha;
+            const float m = p.alpha * p.mean[aj] + one_m * em;             // cem.py:121-122
+            const float v = p.alpha * p.var[aj] + one_m * ev;              // cem.py:123-125
+            p.mean[aj] = m;
+            p.var[aj] = v;
+            const int u = j % p.U;
+            p.sigma[aj] = cem_sigma(m, v, p.lo[u], p.hi[u]);
+            if (j < p.U) p.action[a * p.U + j] = m;                        // mean[:, 0]  cem.py:135
+        }
+    }
+}
+
+// PI2 refit  pi2.py:78-87: softmin weights over the population, weighted mean of the (feasible) samples.
+// LDS: omega[Nst] | scratch[32]
+__global__ __launch_bounds__(REFIT_THREADS) void k_refit_pi2(RefitArgs p) {
+    extern __shared__ float smem[];
+    float* om = smem;
+    float* red = smem + p.Nst;
+    const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = REFIT_THREADS / 64;
+
+    float lmin = INFINITY;
+    for (int n = tid; n < p.N; n += REFIT_THREADS) {
+        const float c = -p.rewards[(size_t)a * p.Nst + n];               // costs = -rewards
+        om[n] = c;
+        lmin = fminf(lmin, c);
+    }
+    lmin = wave_min(lmin);
+    if (lane == 0) red[wv] = lmin;
+    __syncthreads();
+    float beta = red[lane < NW ? lane : 0];
+    beta = wave_min(beta);                                               // pi2.py:81
+    __syncthreads();
+    float lsum = 0.0f;
+    for (int n = tid; n < p.N; n += REFIT_THREADS) {
+        const float pr = expf((-p.inv_lamda) * (om[n] - beta));          // pi2.py:82
+        om[n] = pr;
+        lsum += pr;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[wv] = lsum;
+    __syncthreads();
+    float eta = (lane < NW) ? red[lane] : 0.0f;
+    eta = wave_sum(eta);                                                 // pi2.py:83
+    const float inv_eta = 1.0f / eta;
+    __syncthreads();
+    for (int n = tid; n < p.N; n += REFIT_THREADS) om[n] = inv_eta * om[n];   // pi2.py:85
+    __syncthreads();
+    // new_mean[j] = sum_n samples[j][n] * omega[n]: one wave per j, lanes stride the population (coalesced)
+    for (int j = wv; j < p.HU; j += NW) {
+        const float* row = p.samples + (size_t)(a * p.HU + j) * p.Nst;
+        float acc = 0.0f;
+        for (int n = lane; n < p.N; n += 64) acc += row[n] * om[n];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            p.mean[a * p.HU + j] = acc;                                  // pi2.py:86-87
+            if (j < p.U) p.action[a * p.U + j] = acc;                    // new_mean[:, 0]
+        }
+    }
+}
+
+// warm start: prev = [mean[:,1:], mean[:,-1:]]   pi2.py:92-93 / spsa.py:114-115
+__global__ void k_shift_left(int A, int H, int U, const float* mean, float* prev) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A * H * U) return;
+    const int u = i % U, h = (i / U) % H, a = i / (U * H);
+    const int hs = (h + 1 < H) ? h + 1 : H - 1;
+    prev[i] = mean[(a * H + hs) * U + u];
+}
+
+// RandomSearch refit  random_search.py:43-47: per-agent argmax (first maximum), take its first action.
+__global__ __launch_bounds__(REFIT_THREADS) void k_refit_argmax(RefitArgs p) {
+    __shared__ float sv[REFIT_THREADS / 64];
+    __shared__ int si[REFIT_THREADS / 64];
+    const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = REFIT_THREADS / 64;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int n = tid; n < p.N; n += REFIT_THREADS) {
+        const float v = p.rewards[(size_t)a * p.Nst + n];
+        if (v > bv || (v == bv && n < bi)) { bv = v; bi = n; }
+    }
+    // a population of all -inf / never-greater values still needs a valid index: argmax returns 0 then
+    if (bi == 0x7fffffff && tid < p.N) bi = tid;
+    wave_argmax(bv, bi);
+    if (lane == 0) { sv[wv] = bv; si[wv] = bi; }
+    __syncthreads();
+    if (wv == 0) {
+        bv = (lane < NW) ? sv[lane] : -INFINITY;
+        bi = (lane < NW) ? si[lane] : 0x7fffffff;
+        wave_argmax(bv, bi);
+        if (bi == 0x7fffffff) bi = 0;
+        if (lane == 0 && p.elites) p.elites[a] = bi;
+        if (lane < p.U) p.action[a * p.U + lane] = p.samples[(size_t)(a * p.HU + lane) * p.Nst + bi];
+    }
+}
+
+// Tail of OptimizerBase.__call__  optimizer_base.py:82-94 for the analytic pendulum:
+// optional exploration noise (+clip), one model step on the [A] rows, pack (action|next_state|reward).
+struct FinalArgs {
+    int A, U, S;
+    int agent_offset;
+    int fix_q1, fix_q7;
+    int add_noise;
+    const float* state;     // [A,S]
+    const float* action;    // [A,U]
+    const float* lo;
+    const float* hi;
+    const float* inj;       // injected exploration noise [A,U] or null
+    float* record;          // [A][U+S+1]
+    RngKey key;
+};
+
+__device__ __forceinline__ float exploration_action(const FinalArgs& p, int a, int u, float act) {
+    if (!p.add_noise) return act;
+    float xi;
+    if (p.inj) xi = p.inj[a * p.U + u];
+    else {
+        U4 b = rng_block(p.key, 10u /*BBMPC_NOISE_EXPLORATION*/, 0u, 0u, (uint32_t)(p.agent_offset + a), (uint32_t)u);
+        xi = word_to_trunc_normal(pick_word(b, (uint32_t)u));
+    }
+    const float lo = p.lo[u], hi = p.hi[u];
+    const float d = lo - hi;
+    const float var = (d * d) / 16.0f * 0.05f;                    // optimizer_base.py:46-48
+    const float mean = p.fix_q7 ? 0.0f : (hi + lo) / 2.0f;        // :49-50 (quirk Q7: bounds midpoint)
+    const float noise = xi * sqrtf(var) + mean;                   // :83-86
+    return clipf(act + noise, lo, hi);                            // :87-90
+}
+
+__global__ void k_finalize_pendulum(FinalArgs p) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= p.A) return;
+    const PendulumModel model{p.fix_q1 != 0};
+    float s[3] = {p.state[a * 3 + 0], p.state[a * 3 + 1], p.state[a * 3 + 2]};
+    float act[1];
+    act[0] = exploration_action(p, a, 0, p.action[a]);
+    const float r = model.step(s, act);
+    float* rec = p.record + (size_t)a * (1 + 3 + 1);
+    rec[0] = act[0];
+    rec[1] = s[0];
+    rec[2] = s[1];
+    rec[3] = s[2];
+    rec[4] = r;
+}
+
+}  // namespace bbmpc

@@ -1,0 +1,95 @@
+// Leaf math of the hot path as device functors: analytic pendulum model and the
+// two reward functions.  fp32, one rounding per reference TF op (the library is
+// built with -ffp-contract=off so no multiply-add is fused behind our back).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace bbmpc {
+
+#define BBMPC_PI_F     3.14159274101257324f   /* float32(np.pi)   */
+#define BBMPC_TWO_PI_F 6.28318548202514648f   /* float32(2*np.pi) */
+
+// tf.clip_by_value semantics that let NaN through (min(max(x,lo),hi) on NaN stays NaN in TF/Eigen)
+__device__ __forceinline__ float clipf(float x, float lo, float hi) {
+    return (x < lo) ? lo : ((x > hi) ? hi : x);
+}
+
+// TF FloorMod on floats (used by `%` in utils/pendulum.py:7): fmod, then move into the divisor's sign.
+__device__ __forceinline__ float floormodf(float x, float y) {
+    float r = fmodf(x, y);
+    if (r != 0.0f && ((y < 0.0f) != (r < 0.0f))) r = r + y;
+    return r;
+}
+
+// reward kinds (bbmpc.h)
+constexpr int REW_PENDULUM = 1;
+constexpr int REW_CHEETAH = 2;
+
+// pendulum_reward_function utils/pendulum.py:10-35 AS EXECUTED by
+// trajectory_evaluators/deterministic.py:65-66 (quirk Q1): the third positional
+// argument (named `actions`) receives next_state.  theta = atan2(cur[1],cur[0]).
+__device__ __forceinline__ float pendulum_reward_from_theta(float theta, float thdot, float act_term_sumsq) {
+    float ang = floormodf(theta + BBMPC_PI_F, BBMPC_TWO_PI_F) - BBMPC_PI_F;     // :5-7
+    float first = ang * ang + 0.1f * (thdot * thdot);
+    return (-first) - 0.001f * act_term_sumsq;
+}
+
+// Generic-S reward dispatch used by the learned-dynamics path and the single-step API.
+// cur/nxt have S entries, act has U entries.
+__device__ __forceinline__ float reward_generic(int kind, bool fix_q1, const float* cur, const float* act,
+                                                const float* nxt, int S, int U) {
+    if (kind == REW_PENDULUM) {
+        float theta = atan2f(cur[1], cur[0]);
+        float ss = 0.0f;
+        if (fix_q1) {
+            for (int u = 0; u < U; ++u) ss = ss + act[u] * act[u];
+        } else {
+            for (int s = 0; s < S; ++s) ss = ss + nxt[s] * nxt[s];
+        }
+        return pendulum_reward_from_theta(theta, cur[2], ss);
+    }
+    // reward_function tutorials/mujoco/cost_func.py:5-22 (HalfCheetahEnvModified, S=20)
+    float r = 0.0f;
+    if (cur[5] >= 0.2f) r = r + (-10.0f);
+    if (cur[6] >= 0.0f) r = r + (-10.0f);
+    if (cur[7] >= 0.0f) r = r + (-10.0f);
+    r = r + (nxt[17] - cur[17]) / 0.01f;
+    float ss = 0.0f;
+    for (int u = 0; u < U; ++u) ss = ss + act[u] * act[u];
+    r = r - 0.0f * ss;
+    return r;
+}
+
+// PendulumTrueModel.__call__ utils/pendulum.py:58-92 + true-model handler
+// (process_input = concat, process_output = delta + state, system_dynamics_handler.py:116-118,149-151)
+// + as-executed reward, fused.  State s = (cos th, sin th, thdot) is advanced in place;
+// returns the step reward.  Quirk Q9: th integrates the unclipped speed, torque unclipped.
+struct PendulumModel {
+    static constexpr int S = 3;
+    static constexpr int U = 1;
+    bool fix_q1;
+
+    __device__ __forceinline__ float step(float (&s)[3], const float (&a)[1]) const {
+        const float u = a[0];
+        const float theta = atan2f(s[1], s[0]);                 // :82 (the reward's atan2 has identical inputs)
+        float acc = -15.0f * sinf(theta + BBMPC_PI_F);          // -3g/(2l) = -15
+        acc = acc + 3.0f * u;                                   // 3/(m l^2) = 3
+        float nthd = s[2] + acc * 0.05f;                        // :83-85
+        const float nth = theta + nthd * 0.05f;                 // :86 (unclipped speed)
+        nthd = clipf(nthd, -8.0f, 8.0f);                        // :87
+        float sn, cs;
+        sincosf(nth, &sn, &cs);
+        // deviation = new - x[:, :3]; next = deviation + current   (:91, transforms.py:34)
+        const float n0 = (cs - s[0]) + s[0];
+        const float n1 = (sn - s[1]) + s[1];
+        const float n2 = (nthd - s[2]) + s[2];
+        float ss;
+        if (fix_q1) ss = u * u;
+        else ss = (n0 * n0 + n1 * n1) + n2 * n2;
+        const float r = pendulum_reward_from_theta(theta, s[2], ss);
+        s[0] = n0; s[1] = n1; s[2] = n2;
+        return r;
+    }
+};
+
+}  // namespace bbmpc

@@ -1,0 +1,124 @@
+// Counter-based RNG of the engine (Philox4x32-10) and the transforms that turn
+// raw words into the *standard* draws the optimizers consume.
+//
+// The reference draws from TensorFlow's stateful, never-seeded Philox streams
+// (tf.random.truncated_normal cem.py:90 / pi2.py:65 / pso.py:121 /
+// optimizer_base.py:83, tf.random.uniform random_search.py:40 / pso.py:130 /
+// spsa.py:73, tf.random.normal pso.py:108-109 / cma_es.py:139).  Those streams
+// are not reproducible even run-to-run of the reference, so the engine defines
+// its own scheme, keyed so that (a) any element can be regenerated anywhere
+// (no sample storage needed for it) and (b) results do not depend on how agents
+// are sharded over GPUs:
+//
+//   key     = (seed_lo, seed_hi)
+//   counter = ( n,                       particle index
+//               ga * Q + (j >> 2),       ga = GLOBAL agent id, j = h*U+u, Q = ceil(H*U/4)
+//               control_step,            number of optimize() calls so far on this handle
+//               (stream << 16) | iter )  stream = BBMPC_NOISE_* kind, iter = optimizer iteration
+//   element j uses output word (j & 3).
+//
+// Standard draws from a word x:
+//   U(0,1)      : u = ((x >> 9) + 0.5) * 2^-23           (23 random mantissa bits, never 0 or 1)
+//   trunc normal: z = sqrt(2) * erfinv((2u-1) * erf(sqrt 2))   -- exact inverse-CDF of N(0,1)
+//                 conditioned on |z| < 2, the distribution tf.random.truncated_normal samples
+//                 by rejection; one uniform per draw, no loop.
+//   normal      : Box-Muller on word pairs (x0,x1),(x2,x3).
+//   rademacher  : +1 if top bit set else -1.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bbmpc {
+
+struct U4 { uint32_t x, y, z, w; };
+
+__host__ __device__ __forceinline__ void mulhilo(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
+    uint64_t p = (uint64_t)a * (uint64_t)b;
+    hi = (uint32_t)(p >> 32);
+    lo = (uint32_t)p;
+}
+
+__host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0, lo0, hi1, lo1;
+        mulhilo(0xD2511F53u, c.x, hi0, lo0);
+        mulhilo(0xCD9E8D57u, c.z, hi1, lo1);
+        U4 n;
+        n.x = hi1 ^ c.y ^ k0;
+        n.y = lo1;
+        n.z = hi0 ^ c.w ^ k1;
+        n.w = lo0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__host__ __device__ __forceinline__ float word_to_uniform(uint32_t x) {
+    return ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-07f;   // 2^-23
+}
+
+// Giles' single-precision erfinv, central branch (valid for w < 5, i.e. |x| < 0.99662).
+__device__ __forceinline__ float erfinv_central(float x) {
+    float w = -__logf((1.0f - x) * (1.0f + x));
+    w = w - 2.5f;
+    float p = 2.81022636e-08f;
+    p = fmaf(p, w, 3.43273939e-07f);
+    p = fmaf(p, w, -3.5233877e-06f);
+    p = fmaf(p, w, -4.39150654e-06f);
+    p = fmaf(p, w, 0.00021858087f);
+    p = fmaf(p, w, -0.00125372503f);
+    p = fmaf(p, w, -0.00417768164f);
+    p = fmaf(p, w, 0.246640727f);
+    p = fmaf(p, w, 1.50140941f);
+    return p * x;
+}
+
+__device__ __forceinline__ float word_to_trunc_normal(uint32_t x) {
+    float u = word_to_uniform(x);
+    float t = (2.0f * u - 1.0f) * 0.9544997361036416f;     // erf(sqrt(2)) = P(|z|<2)
+    float z = 1.4142135623730951f * erfinv_central(t);
+    // polynomial error could in principle land exactly on the bound; keep strictly inside
+    return fminf(fmaxf(z, -1.9999999f), 1.9999999f);
+}
+
+__device__ __forceinline__ float word_to_rademacher(uint32_t x) {
+    return (x & 0x80000000u) ? 1.0f : -1.0f;
+}
+
+// Box-Muller: two words -> two N(0,1)
+__device__ __forceinline__ void words_to_normal2(uint32_t x0, uint32_t x1, float& z0, float& z1) {
+    float u1 = word_to_uniform(x0);
+    float u2 = word_to_uniform(x1);
+    float r = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincosf(6.283185307179586f * u2, &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+struct RngKey {
+    uint32_t k0, k1;      // seed
+    uint32_t step;        // control step
+    uint32_t q_per_agent; // Q = ceil(H*U/4)
+};
+
+// Raw words for the 4-element block containing element j of particle n, global agent ga.
+__device__ __forceinline__ U4 rng_block(const RngKey& key, uint32_t stream, uint32_t iter, uint32_t n,
+                                        uint32_t ga, uint32_t j) {
+    U4 c;
+    c.x = n;
+    c.y = ga * key.q_per_agent + (j >> 2);
+    c.z = key.step;
+    c.w = (stream << 16) | iter;
+    return philox4x32_10(c, key.k0, key.k1);
+}
+
+__device__ __forceinline__ uint32_t pick_word(const U4& r, uint32_t j) {
+    uint32_t l = j & 3u;
+    return l == 0 ? r.x : (l == 1 ? r.y : (l == 2 ? r.z : r.w));
+}
+
+}  // namespace bbmpc

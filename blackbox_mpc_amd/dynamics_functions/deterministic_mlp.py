@@ -1,0 +1,70 @@
+"""Learned deterministic MLP dynamics (reference dynamics_functions/deterministic_mlp.py:5-51).
+
+A weights container: Dense kernels [in,out] + biases, Keras default init
+(Glorot-uniform / zeros).  The forward pass runs on the GPU inside the fused
+rollout kernel (MFMA path); training is out of scope of this engine."""
+import numpy as np
+
+from .. import _lib as L
+
+_ACT = {None: L.ACT_NONE, "linear": L.ACT_NONE, "none": L.ACT_NONE, "tanh": L.ACT_TANH, "relu": L.ACT_RELU,
+        "sigmoid": L.ACT_SIGMOID}
+
+
+def _act_code(a):
+    if a is None or isinstance(a, str):
+        key = a.lower() if isinstance(a, str) else None
+    else:  # a callable such as np.tanh / torch.tanh / tf.math.tanh: resolve by name
+        key = getattr(a, "__name__", str(a)).lower()
+    if key not in _ACT:
+        raise ValueError("unsupported activation %r (supported: tanh, relu, sigmoid, None)" % (a,))
+    return _ACT[key]
+
+
+class DeterministicMLP:
+    _bbmpc_dynamics_kind = L.DYN_MLP
+
+    def __init__(self, layers, activation_functions, loss_fn=None, name=None, seed=None):
+        if len(activation_functions) != len(layers) - 1:
+            raise ValueError("need one activation per Dense layer")
+        self.name = name
+        self.layer_sizes = [int(v) for v in layers]
+        self.activation_codes = [_act_code(a) for a in activation_functions]
+        rng = np.random.default_rng(seed)
+        self.weights, self.biases = [], []
+        for i in range(1, len(layers)):
+            lim = np.sqrt(6.0 / (layers[i - 1] + layers[i]))
+            self.weights.append(rng.uniform(-lim, lim, size=(layers[i - 1], layers[i])).astype(np.float32))
+            self.biases.append(np.zeros((layers[i],), np.float32))
+        self.loss_fn = loss_fn
+        self._version = 0
+
+    def set_weights(self, weights, biases):
+        if len(weights) != len(self.weights):
+            raise ValueError("expected %d layers" % len(self.weights))
+        for i, (w, b) in enumerate(zip(weights, biases)):
+            w = np.asarray(w, np.float32)
+            b = np.asarray(b, np.float32)
+            if w.shape != self.weights[i].shape or b.shape != self.biases[i].shape:
+                raise ValueError("layer %d shape mismatch" % i)
+            self.weights[i], self.biases[i] = w.copy(), b.copy()
+        self._version += 1
+
+    def save(self, path):
+        np.savez(path, n_layers=len(self.weights), layers=np.array(self.layer_sizes),
+                 activations=np.array(self.activation_codes),
+                 **{"W%d" % i: w for i, w in enumerate(self.weights)},
+                 **{"b%d" % i: b for i, b in enumerate(self.biases)})
+
+    @classmethod
+    def load(cls, path):
+        z = np.load(path)
+        inv = {v: k for k, v in _ACT.items() if k in (None, "tanh", "relu", "sigmoid")}
+        m = cls(list(z["layers"]), [inv[int(c)] for c in z["activations"]])
+        n = int(z["n_layers"])
+        m.set_weights([z["W%d" % i] for i in range(n)], [z["b%d" % i] for i in range(n)])
+        return m
+
+    def __call__(self, x, train=False):
+        raise NotImplementedError("DeterministicMLP.forward runs fused inside the engine's rollout kernels; use "
+                                  "DeterministicTrajectoryEvaluator.predict_next_state")

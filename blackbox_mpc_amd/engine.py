@@ -1,0 +1,191 @@
+"""Thin object wrapper over the C ABI handle (include/bbmpc.h).  NumPy in, NumPy
+out; device-pointer variants take integer addresses (e.g. torch `data_ptr()`)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Engine:
+    def __init__(self, optimizer, dynamics, reward, action_low, action_high, dim_s, num_agents,
+                 planning_horizon, population_size=0, max_iterations=0, num_elite=0, seed=0, quirks=0,
+                 agent_offset=0, num_agents_global=None, device=-1, alpha=0.25, lamda=1.0,
+                 pso_c1=0.3, pso_c2=0.5, pso_w=0.2, pso_v0_fraction=0.01,
+                 spsa_alpha=0.602, spsa_gamma=0.101, spsa_a=0.01, spsa_c=0.3,
+                 cma_alpha_cov=2.0, cma_h_sigma=1.0):
+        self._h = ctypes.c_void_p()
+        self._lo = L.f32c(np.asarray(action_low).reshape(-1))
+        self._hi = L.f32c(np.asarray(action_high).reshape(-1))
+        if self._lo.shape != self._hi.shape:
+            raise ValueError("action_low/action_high shapes differ")
+        c = L.Config()
+        c.abi_version = L.ABI_VERSION
+        c.optimizer, c.dynamics, c.reward = int(optimizer), int(dynamics), int(reward)
+        c.population_size, c.num_agents = int(population_size), int(num_agents)
+        c.planning_horizon, c.dim_u, c.dim_s = int(planning_horizon), int(self._lo.shape[0]), int(dim_s)
+        c.max_iterations = int(max_iterations or 0)
+        c.num_elite = int(num_elite)
+        c.agent_offset = int(agent_offset)
+        c.num_agents_global = int(num_agents_global if num_agents_global is not None else num_agents)
+        c.device = int(device)
+        c.quirks = int(quirks)
+        c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        c.alpha, c.lamda = float(alpha), float(lamda)
+        c.pso_c1, c.pso_c2, c.pso_w, c.pso_v0_fraction = float(pso_c1), float(pso_c2), float(pso_w), float(pso_v0_fraction)
+        c.spsa_alpha, c.spsa_gamma, c.spsa_a, c.spsa_c = float(spsa_alpha), float(spsa_gamma), float(spsa_a), float(spsa_c)
+        c.cma_alpha_cov, c.cma_h_sigma = float(cma_alpha_cov), float(cma_h_sigma)
+        c.action_low = self._lo.ctypes.data_as(L.c_float_p)
+        c.action_high = self._hi.ctypes.data_as(L.c_float_p)
+        self.cfg = c
+        self.N, self.A, self.H = c.population_size, c.num_agents, c.planning_horizon
+        self.U, self.S = c.dim_u, c.dim_s
+        self.iters = 1 if optimizer == L.OPT_RANDOM_SEARCH else c.max_iterations
+        self.k = c.num_elite
+        L.check(L.lib.bbmpc_create(ctypes.byref(c), ctypes.byref(self._h)))
+
+    # -- lifecycle -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            L.lib.bbmpc_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        L.check(L.lib.bbmpc_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def set_mlp(self, weights, biases, activations, stats=None):
+        n = len(weights)
+        ws = [L.f32c(w) for w in weights]
+        bs = [L.f32c(b) for b in biases]
+        dims = [ws[0].shape[0]] + [w.shape[1] for w in ws]
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            if w.ndim != 2 or w.shape[0] != dims[i] or b.shape != (w.shape[1],):
+                raise ValueError("layer %d: kernel must be [in,out] and bias [out]" % i)
+        dims_a = (ctypes.c_int32 * (n + 1))(*dims)
+        acts_a = (ctypes.c_int32 * n)(*[int(a) for a in activations])
+        wp = (ctypes.c_void_p * n)(*[w.ctypes.data for w in ws])
+        bp = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
+        if stats is not None:
+            st = [L.f32c(np.asarray(s).reshape(-1)) for s in stats]
+            sp = (ctypes.c_void_p * 6)(*[s.ctypes.data for s in st])
+            L.check(L.lib.bbmpc_set_mlp(self._h, n, dims_a, acts_a, wp, bp, 1, sp))
+        else:
+            L.check(L.lib.bbmpc_set_mlp(self._h, n, dims_a, acts_a, wp, bp, 0, None))
+
+    def reset(self):
+        L.check(L.lib.bbmpc_reset(self._h))
+
+    def synchronize(self):
+        L.check(L.lib.bbmpc_synchronize(self._h))
+
+    # -- hot path --------------------------------------------------------------------------
+    def optimize(self, state, t=0, add_exploration_noise=False):
+        state = L.f32c(state)
+        if state.shape != (self.A, self.S):
+            raise ValueError("state must be [num_agents, dim_S] = [%d, %d], got %s" % (self.A, self.S, state.shape))
+        action = np.empty((self.A, self.U), np.float32)
+        nxt = np.empty((self.A, self.S), np.float32)
+        rew = np.empty((self.A,), np.float32)
+        L.check(L.lib.bbmpc_optimize(self._h, L.ptr(state), int(t), int(bool(add_exploration_noise)),
+                                     L.ptr(action), L.ptr(nxt), L.ptr(rew)))
+        return action, nxt, rew
+
+    def optimize_dev(self, d_state, d_record, t=0, add_exploration_noise=False):
+        L.check(L.lib.bbmpc_optimize_dev(self._h, ctypes.c_void_p(d_state), int(t), int(bool(add_exploration_noise)),
+                                         ctypes.c_void_p(d_record)))
+
+    def evaluate(self, state, action_sequences):
+        state = L.f32c(state)
+        seq = L.f32c(action_sequences)
+        if state.shape != (self.A, self.S):
+            raise ValueError("current_states must be [%d, %d], got %s" % (self.A, self.S, state.shape))
+        if seq.ndim != 4 or seq.shape[1:] != (self.A, self.H, self.U):
+            raise ValueError("action_sequences must be [n, %d, %d, %d], got %s" % (self.A, self.H, self.U, seq.shape))
+        n = seq.shape[0]
+        out = np.empty((n, self.A), np.float32)
+        if n == 0:
+            return out
+        L.check(L.lib.bbmpc_evaluate(self._h, L.ptr(state), L.ptr(seq), n, L.ptr(out)))
+        return out
+
+    def evaluate_dev(self, d_state, d_seq, n_pop, d_rewards):
+        L.check(L.lib.bbmpc_evaluate_dev(self._h, ctypes.c_void_p(d_state), ctypes.c_void_p(d_seq), int(n_pop),
+                                         ctypes.c_void_p(d_rewards)))
+
+    def predict_next_state(self, states, actions):
+        states, actions = L.f32c(states), L.f32c(actions)
+        b = states.shape[0]
+        if states.shape != (b, self.S) or actions.shape != (b, self.U):
+            raise ValueError("states [B,%d] / actions [B,%d] expected" % (self.S, self.U))
+        out = np.empty((b, self.S), np.float32)
+        if b:
+            L.check(L.lib.bbmpc_predict_next_state(self._h, L.ptr(states), L.ptr(actions), b, L.ptr(out)))
+        return out
+
+    def evaluate_next_reward(self, states, next_states, actions):
+        states, next_states, actions = L.f32c(states), L.f32c(next_states), L.f32c(actions)
+        b = states.shape[0]
+        out = np.empty((b,), np.float32)
+        if b:
+            L.check(L.lib.bbmpc_evaluate_next_reward(self._h, L.ptr(states), L.ptr(next_states), L.ptr(actions), b,
+                                                     L.ptr(out)))
+        return out
+
+    def step_dev(self, d_states, d_actions, action_stride, batch, d_next_states, d_rewards=0):
+        L.check(L.lib.bbmpc_step_dev(self._h, ctypes.c_void_p(d_states), ctypes.c_void_p(d_actions),
+                                     int(action_stride), int(batch), ctypes.c_void_p(d_next_states),
+                                     ctypes.c_void_p(d_rewards or 0)))
+
+    # -- parity hooks ----------------------------------------------------------------------
+    def inject_noise(self, kind, data):
+        if data is None:
+            L.check(L.lib.bbmpc_inject_noise(self._h, int(kind), None, 0))
+            return
+        d = L.f32c(data)
+        L.check(L.lib.bbmpc_inject_noise(self._h, int(kind), L.ptr(d), d.size))
+
+    def dump_noise(self, kind, control_step, iteration, shape):
+        out = np.empty(shape, np.float32)
+        L.check(L.lib.bbmpc_dump_noise(self._h, int(kind), int(control_step), int(iteration), L.ptr(out), out.size))
+        return out
+
+    def set_trace(self, enabled=True):
+        L.check(L.lib.bbmpc_set_trace(self._h, int(bool(enabled))))
+
+    def get_trace(self, iteration, item):
+        if item == L.TRACE_REWARDS:
+            out = np.empty((self.N, self.A), np.float32)
+        elif item in (L.TRACE_MEAN, L.TRACE_VAR):
+            out = np.empty((self.A, self.H, self.U), np.float32)
+        elif item == L.TRACE_ELITES:
+            out = np.empty((self.A, self.k) if self.cfg.optimizer == L.OPT_CEM else (self.A,), np.int32)
+        elif item == L.TRACE_SAMPLES:
+            out = np.empty((self.N, self.A, self.H, self.U), np.float32)
+        else:
+            raise ValueError(item)
+        L.check(L.lib.bbmpc_get_trace(self._h, int(iteration), int(item), L.ptr(out), out.nbytes))
+        return out
+
+    def get_state(self, name, shape=None):
+        out = np.empty(shape if shape is not None else (self.A, self.H, self.U), np.float32)
+        L.check(L.lib.bbmpc_get_state(self._h, name.encode(), L.ptr(out), out.size))
+        return out
+
+    def set_state(self, name, data):
+        d = L.f32c(data)
+        L.check(L.lib.bbmpc_set_state(self._h, name.encode(), L.ptr(d), d.size))
+
+    # -- measurement -----------------------------------------------------------------------
+    def set_profiling(self, enabled=True):
+        L.check(L.lib.bbmpc_set_profiling(self._h, int(bool(enabled))))
+
+    def get_profile(self):
+        ms, n, name = ctypes.c_double(), ctypes.c_int64(), ctypes.c_char_p()
+        L.check(L.lib.bbmpc_get_profile(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(name)))
+        return ms.value, n.value, (name.value or b"").decode()

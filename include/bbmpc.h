@@ -1,0 +1,211 @@
+/*
+ * bbmpc.h -- C ABI of the MI355X-native sampling-MPC rollout engine.
+ *
+ * The reference (ossamaAhmed/blackbox_mpc v0.3) has no FFI: its hot path is a
+ * Python class API that hands one tf.function graph call per control step to
+ * TensorFlow.  This header declares what a maintainer of the reference would
+ * bind (ctypes stub in INTEGRATION.md) to replace that graph call.  Each entry
+ * point cites the reference interface it stands in for; paths are relative to
+ * /root/reference/blackbox_mpc/.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative
+ *     BBMPC_E_* code; bbmpc_last_error() gives the message for the calling thread.
+ *   - host-pointer entry points are synchronous: outputs are valid on return.
+ *     *_dev entry points take device (HBM) pointers, enqueue on the handle's
+ *     stream and return immediately.
+ *   - the caller owns every buffer it passes; the handle owns device memory,
+ *     stream, events.  One handle = one caller thread at a time (the reference's
+ *     optimizers hold mutable tf.Variable state and are not re-entrant either).
+ *   - tensors are float32, C-contiguous, in the reference's layouts:
+ *       states [A,S], action sequences [N,A,H,U], rewards [N,A].
+ *   - there is NO CPU fallback: every compute entry point fails with
+ *     BBMPC_E_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef BBMPC_H
+#define BBMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBMPC_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+#define BBMPC_OK              0
+#define BBMPC_E_INVALID      -1   /* bad argument / unsupported configuration */
+#define BBMPC_E_NO_DEVICE    -2   /* no usable HIP device                      */
+#define BBMPC_E_HIP          -3   /* a HIP runtime call failed                 */
+#define BBMPC_E_STATE        -4   /* call sequence error (e.g. MLP weights not set) */
+#define BBMPC_E_UNSUPPORTED  -5   /* valid in the reference, not built yet     */
+
+/* ---- enums -------------------------------------------------------------- */
+/* optimizers/: random_search.py, cem.py, pi2.py, pso.py, cma_es.py, spsa.py */
+#define BBMPC_OPT_NONE          0   /* evaluator-only handle */
+#define BBMPC_OPT_RANDOM_SEARCH 1
+#define BBMPC_OPT_CEM           2
+#define BBMPC_OPT_PI2           3
+#define BBMPC_OPT_PSO           4
+#define BBMPC_OPT_CMAES         5
+#define BBMPC_OPT_SPSA          6
+
+/* dynamics plugin: utils/pendulum.py:38-92 | dynamics_functions/deterministic_mlp.py:5-51 */
+#define BBMPC_DYN_PENDULUM 1
+#define BBMPC_DYN_MLP      2
+
+/* reward plugin: utils/pendulum.py:10-35 | tutorials/mujoco/cost_func.py:5-22 */
+#define BBMPC_REW_PENDULUM 1
+#define BBMPC_REW_CHEETAH  2
+
+/* Dense activations (tutorials use tf.math.tanh and None) */
+#define BBMPC_ACT_NONE    0
+#define BBMPC_ACT_TANH    1
+#define BBMPC_ACT_RELU    2
+#define BBMPC_ACT_SIGMOID 3
+
+/* quirk switches; a set bit OPTS OUT of the reference's as-executed behaviour
+ * (SURVEY.md section 8 quirk register).  Default 0 = bug-compatible. */
+#define BBMPC_FIX_Q1_REWARD_ARG_ORDER   (1u << 0)  /* pendulum reward uses actions, not next_state */
+#define BBMPC_FIX_Q2_CEM_WARM_START     (1u << 1)  /* CEM keeps shifted mean across control steps  */
+#define BBMPC_FIX_Q7_EXPL_NOISE_ZERO_MEAN (1u << 2)
+#define BBMPC_CMAES_PER_AGENT           (1u << 8)  /* independent CMA-ES per agent (deviation, shards) */
+
+/* noise kinds for bbmpc_inject_noise (standard draws, reference layout) */
+#define BBMPC_NOISE_TRUNC_NORMAL 1  /* [iters][N,A,H,U] unit normal, |z|<2: cem.py:90 pi2.py:65 */
+#define BBMPC_NOISE_UNIFORM      2  /* [N,A,H,U] U[0,1): random_search.py:40                     */
+#define BBMPC_NOISE_RADEMACHER   3  /* [iters][N,A,H,U] +-1: spsa.py:73-75                        */
+#define BBMPC_NOISE_NORMAL       4  /* CMA-ES [iters][N,n] N(0,1): cma_es.py:139                  */
+#define BBMPC_NOISE_PSO_SCALARS  5  /* [iters][2] N(0,1): pso.py:107-109                          */
+#define BBMPC_NOISE_PSO_RESEED_TRUNC   6  /* [N,A,H,U]: pso.py:121-127 */
+#define BBMPC_NOISE_PSO_RESEED_UNIFORM 7  /* [N,A,H,U]: pso.py:130-131 */
+#define BBMPC_NOISE_PSO_RESET_POS      8  /* [N,A,H,U]: pso.py:147-149 */
+#define BBMPC_NOISE_PSO_RESET_VEL      9  /* [N,A,H,U]: pso.py:151-152 */
+#define BBMPC_NOISE_EXPLORATION       10  /* [A,U] unit trunc normal: optimizer_base.py:83-86 */
+
+/* trace items for bbmpc_get_trace (per-iteration parity data) */
+#define BBMPC_TRACE_REWARDS 1   /* [N,A]  (SPSA: [2N,A], plus then minus)   */
+#define BBMPC_TRACE_MEAN    2   /* [A,H,U] distribution mean / solution after the iteration */
+#define BBMPC_TRACE_VAR     3   /* [A,H,U] (CEM)                             */
+#define BBMPC_TRACE_ELITES  4   /* int32 [A,k] (CEM), [A] best index (RandomSearch/PSO) */
+#define BBMPC_TRACE_SAMPLES 5   /* [N,A,H,U] action sequences that were rolled out */
+
+typedef struct bbmpc_handle_s* bbmpc_handle;
+
+/* Mirrors the constructor kwargs of OptimizerBase + the six optimizers
+ * (optimizer_base.py:6-50; cem.py:7-10; pi2.py:9-11; random_search.py:7-8;
+ *  pso.py:7-11; cma_es.py:7-10; spsa.py:7-12). */
+typedef struct bbmpc_config {
+    int32_t abi_version;        /* BBMPC_ABI_VERSION */
+    int32_t optimizer;          /* BBMPC_OPT_* */
+    int32_t dynamics;           /* BBMPC_DYN_* */
+    int32_t reward;             /* BBMPC_REW_* */
+    int32_t population_size;    /* N */
+    int32_t num_agents;         /* A  (agents owned by THIS handle / GPU) */
+    int32_t planning_horizon;   /* H */
+    int32_t dim_u;              /* U = env_action_space.shape[0] */
+    int32_t dim_s;              /* S = env_observation_space.shape[0] */
+    int32_t max_iterations;     /* ignored by RandomSearch */
+    int32_t num_elite;          /* CEM, CMA-ES */
+    int32_t agent_offset;       /* global id of local agent 0 (agent sharding; RNG is keyed by global id) */
+    int32_t num_agents_global;  /* total agents across all shards (>= num_agents) */
+    int32_t device;             /* HIP device ordinal, -1 = current */
+    uint32_t quirks;            /* BBMPC_FIX_* / mode bits */
+    uint32_t reserved0;
+    uint64_t seed;              /* engine RNG seed (Philox key) */
+    float alpha;                /* CEM smoothing (cem.py:10) */
+    float lamda;                /* PI2 temperature (pi2.py:11) */
+    float pso_c1, pso_c2, pso_w, pso_v0_fraction;           /* pso.py:9-11 */
+    float spsa_alpha, spsa_gamma, spsa_a, spsa_c;           /* spsa.py:9-12 */
+    float cma_alpha_cov, cma_h_sigma;                       /* cma_es.py:10 */
+    const float* action_low;    /* [U] env_action_space.low  */
+    const float* action_high;   /* [U] env_action_space.high */
+} bbmpc_config;
+
+/* ---- library ------------------------------------------------------------ */
+int         bbmpc_abi_version(void);
+const char* bbmpc_last_error(void);
+/* number of usable gfx950 devices (0 when none; never fails) */
+int         bbmpc_device_count(void);
+
+/* ---- lifecycle ---------------------------------------------------------- */
+/* Stands in for MPCPolicy.__init__ / Optimizer.__init__ + set_trajectory_evaluator
+ * (policies/mpc_policy.py:58-122; optimizer_base.py:105-115). */
+int bbmpc_create(const bbmpc_config* cfg, bbmpc_handle* out);
+int bbmpc_destroy(bbmpc_handle h);
+/* Launch on a caller-provided hipStream_t (e.g. torch's current stream); NULL = handle's own. */
+int bbmpc_set_stream(bbmpc_handle h, void* hip_stream);
+
+/* DeterministicMLP weights + SystemDynamicsHandler normalisation stats
+ * (deterministic_mlp.py:5-25 Dense kernels [in,out] row-major, biases [out];
+ *  system_dynamics_handler.py:84-95 six stats vectors).
+ * dims has n_layers+1 entries, dims[0] = S+U, dims[n_layers] = S.
+ * stats = {mean_states[S], std_states[S], mean_actions[U], std_actions[U],
+ *          mean_targets[S], std_targets[S]} or NULL when is_normalized == 0. */
+int bbmpc_set_mlp(bbmpc_handle h, int32_t n_layers, const int32_t* dims, const int32_t* activations,
+                  const float* const* weights, const float* const* biases,
+                  int32_t is_normalized, const float* const* stats);
+
+/* Optimizer.reset()  (cem.py:138-149, pi2.py:98-105, pso.py:143-160, cma_es.py:215-227, spsa.py:119-127) */
+int bbmpc_reset(bbmpc_handle h);
+
+/* ---- hot path ----------------------------------------------------------- */
+/* OptimizerBase.__call__(current_state, time_step, add_exploration_noise)
+ * -> (action[A,U], next_state[A,S], reward[A])      optimizer_base.py:55-95 */
+int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t time_step, int32_t add_exploration_noise,
+                   float* action, float* next_state, float* reward);
+/* Same with device pointers; record is [A, U+S+1] = (action | next_state | reward) per agent. */
+int bbmpc_optimize_dev(bbmpc_handle h, const float* d_state, int32_t time_step, int32_t add_exploration_noise,
+                       float* d_record);
+
+/* DeterministicTrajectoryEvaluator.__call__(current_states[A,S], action_sequences[n_pop,A,H,U], t)
+ * -> rewards[n_pop,A]                 trajectory_evaluators/deterministic.py:26-77 */
+int bbmpc_evaluate(bbmpc_handle h, const float* state, const float* action_sequences, int32_t n_pop,
+                   float* rewards);
+int bbmpc_evaluate_dev(bbmpc_handle h, const float* d_state, const float* d_action_sequences, int32_t n_pop,
+                       float* d_rewards);
+
+/* .predict_next_state(states[B,S], actions[B,U]) -> [B,S]      deterministic.py:79-103 */
+int bbmpc_predict_next_state(bbmpc_handle h, const float* states, const float* actions, int32_t batch,
+                             float* next_states);
+/* .evaluate_next_reward(cur[B,S], next[B,S], actions[B,U]) -> [B]   deterministic.py:105-127 */
+int bbmpc_evaluate_next_reward(bbmpc_handle h, const float* states, const float* next_states,
+                               const float* actions, int32_t batch, float* rewards);
+/* device-pointer env step used by the closed-loop harness: action rows are read with
+ * `action_stride` floats between consecutive rows (so a record buffer can be passed). */
+int bbmpc_step_dev(bbmpc_handle h, const float* d_states, const float* d_actions, int32_t action_stride,
+                   int32_t batch, float* d_next_states, float* d_rewards);
+
+/* ---- parity / test hooks ------------------------------------------------ */
+/* Replace the engine's Philox draws of `kind` by caller-supplied standard noise
+ * (reference layout, see BBMPC_NOISE_*).  count = number of floats.  data == NULL
+ * clears the injection for that kind.  Injected tensors are consumed by every
+ * subsequent control step until cleared. */
+int bbmpc_inject_noise(bbmpc_handle h, int32_t kind, const float* data, int64_t count);
+/* Write the standard noise the engine's own Philox scheme produces for (kind, control_step, iteration),
+ * in the reference layout -- lets tests check the generator against its documented definition. */
+int bbmpc_dump_noise(bbmpc_handle h, int32_t kind, int32_t control_step, int32_t iteration, float* out,
+                     int64_t count);
+/* Enable per-iteration trace capture (costs extra device copies; off by default). */
+int bbmpc_set_trace(bbmpc_handle h, int32_t enabled);
+int bbmpc_get_trace(bbmpc_handle h, int32_t iteration, int32_t item, void* out, int64_t bytes);
+/* Read / write optimizer state tensors by name ("mean","var","pos","vel","pbest","pbest_r",
+ * "gbest","gbest_r","m","sigma","C","B","D","p_sigma","p_C"), reference layout. */
+int bbmpc_get_state(bbmpc_handle h, const char* name, float* out, int64_t count);
+int bbmpc_set_state(bbmpc_handle h, const char* name, const float* data, int64_t count);
+
+/* ---- measurement -------------------------------------------------------- */
+/* When enabled the handle brackets every launch of its dominant (rollout) kernel with HIP events on
+ * the launch stream; bbmpc_get_profile returns the accumulated device time and launch count since
+ * the last call and resets them. */
+int bbmpc_set_profiling(bbmpc_handle h, int32_t enabled);
+int bbmpc_get_profile(bbmpc_handle h, double* rollout_ms_total, int64_t* rollout_launches,
+                      const char** kernel_name);
+/* Block until everything enqueued on the handle's stream has finished. */
+int bbmpc_synchronize(bbmpc_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBMPC_H */
