@@ -75,9 +75,9 @@ def main():
 
     def control_step():
         nonlocal state, nxt
-        eng.optimize_dev(state.data_ptr(), record.data_ptr())
-        # environment = the engine's own model step on the chosen action
-        eng.step_dev(state.data_ptr(), record.data_ptr(), rec, A, nxt.data_ptr())
+        # closed loop: the environment is the engine's own model, so the predicted next state
+        # the control step already produced IS the next observation -- it never leaves HBM.
+        eng.optimize_dev(state.data_ptr(), record.data_ptr(), d_next_state=nxt.data_ptr())
         if world > 1:
             dist.all_gather_into_tensor(gathered, record)
         state, nxt = nxt, state

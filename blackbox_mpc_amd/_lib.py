@@ -81,7 +81,7 @@ def _load():
                                   ctypes.POINTER(vp), i32, ctypes.POINTER(vp)]
     lib.bbmpc_reset.argtypes = [vp]
     lib.bbmpc_optimize.argtypes = [vp, vp, i32, i32, vp, vp, vp]
-    lib.bbmpc_optimize_dev.argtypes = [vp, vp, i32, i32, vp]
+    lib.bbmpc_optimize_dev.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.bbmpc_evaluate.argtypes = [vp, vp, vp, i32, vp]
     lib.bbmpc_evaluate_dev.argtypes = [vp, vp, vp, i32, vp]
     lib.bbmpc_predict_next_state.argtypes = [vp, vp, vp, i32, vp]

@@ -3,6 +3,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace bbmpc {
 
@@ -55,6 +56,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
     HIP_CHECK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
     stream = own_stream;
 
+    if (const char* fm = getenv("BBMPC_FUSED")) fused_mode = atoi(fm);
     HU = H * U;
     Nst = ((std::max(N, 1) + 63) / 64) * 64;
     rec = U + S + 1;
@@ -189,8 +191,7 @@ void Engine::launch_rollout(int mode, bool pen, RolloutArgs& ra) {
     prof_end();
 }
 
-void Engine::capture_trace(int it) {
-    if (!trace_on) return;
+void Engine::ensure_trace() {
     const size_t nr = (size_t)A * Nst, nm = (size_t)A * HU, ns = (size_t)A * HU * Nst, ne = (size_t)A * std::max(k, 1);
     const int nit = std::max(iters, 1);
     if (!t_rewards.p) {
@@ -200,6 +201,12 @@ void Engine::capture_trace(int it) {
         t_samples.alloc(ns * nit);
         t_elites.alloc(ne * nit);
     }
+}
+
+void Engine::capture_trace(int it) {
+    if (!trace_on) return;
+    const size_t nr = (size_t)A * Nst, nm = (size_t)A * HU, ns = (size_t)A * HU * Nst, ne = (size_t)A * std::max(k, 1);
+    ensure_trace();
     HIP_CHECK(hipMemcpyAsync(t_rewards.p + nr * it, d_rewards.p, nr * 4, hipMemcpyDeviceToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(t_mean.p + nm * it, d_mean.p, nm * 4, hipMemcpyDeviceToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(t_var.p + nm * it, d_var.p, nm * 4, hipMemcpyDeviceToDevice, stream));
@@ -207,7 +214,7 @@ void Engine::capture_trace(int it) {
     HIP_CHECK(hipMemcpyAsync(t_elites.p + ne * it, d_elites.p, ne * 4, hipMemcpyDeviceToDevice, stream));
 }
 
-void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_out, uint32_t step) {
+void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step) {
     FinalArgs fa;
     fa.A = A; fa.U = U; fa.S = S;
     fa.agent_offset = cfg.agent_offset;
@@ -219,15 +226,88 @@ void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_ou
     fa.lo = d_lo.p; fa.hi = d_hi.p;
     fa.inj = injected(BBMPC_NOISE_EXPLORATION);
     fa.record = d_record_out;
+    fa.next_state = d_next_out;
     fa.key = key(step);
     fa.key.q_per_agent = (uint32_t)((U + 3) / 4);
     hipLaunchKernelGGL(k_finalize_pendulum, dim3((A + 63) / 64), dim3(64), 0, stream, fa);
     HIP_CHECK(hipGetLastError());
 }
 
-void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_record_out) {
+bool Engine::use_fused() const {
+    if (cfg.dynamics != BBMPC_DYN_PENDULUM) return false;
+    if (cfg.optimizer != BBMPC_OPT_RANDOM_SEARCH && cfg.optimizer != BBMPC_OPT_CEM && cfg.optimizer != BBMPC_OPT_PI2) return false;
+    if (fused_mode == 0) return false;
+    if (fused_mode == 1) return true;
+    // auto: one workgroup per agent keeps a whole control step in one launch.  When a handful of agents
+    // own very large populations the per-iteration kernels spread the rollouts over more CUs instead.
+    return (long)N <= 2048 || A >= 64;
+}
+
+template <int OPT>
+static void launch_fused(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
+    const size_t limit = 160 * 1024;
+    if (lds_base + lds_samples <= limit) {
+        auto fn = k_fused_pendulum<OPT, true>;
+        static size_t configured = 0;
+        if (lds_base + lds_samples > configured) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limit));
+            configured = limit;
+        }
+        hipLaunchKernelGGL(fn, dim3(e.A), dim3(threads), lds_base + lds_samples, e.stream, fa);
+    } else {
+        auto fn = k_fused_pendulum<OPT, false>;
+        hipLaunchKernelGGL(fn, dim3(e.A), dim3(threads), lds_base, e.stream, fa);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step) {
+    FusedArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.N = N; fa.A = A; fa.H = H; fa.U = U; fa.HU = HU; fa.Nst = Nst; fa.k = k; fa.iters = iters;
+    fa.agent_offset = cfg.agent_offset;
+    fa.fix_q1 = fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
+    fa.fix_q7 = fix(BBMPC_FIX_Q7_EXPL_NOISE_ZERO_MEAN);
+    fa.add_noise = add_noise;
+    fa.warm_start = fix(BBMPC_FIX_Q2_CEM_WARM_START);
+    fa.alpha = cfg.alpha;
+    fa.inv_lamda = 1.0f / cfg.lamda;
+    fa.state = d_state_in;
+    fa.lo = d_lo.p; fa.hi = d_hi.p;
+    fa.prev_mean = d_prev_mean.p; fa.var0 = d_var0.p;
+    fa.mean_out = d_mean.p; fa.var_out = d_var.p;
+    fa.samples_g = d_samples.p;
+    fa.inj = injected(cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH ? BBMPC_NOISE_UNIFORM : BBMPC_NOISE_TRUNC_NORMAL);
+    fa.inj_expl = injected(BBMPC_NOISE_EXPLORATION);
+    fa.record = d_record_out;
+    fa.next_state = d_next_out;
+    if (trace_on) {
+        ensure_trace();
+        fa.t_rewards = t_rewards.p; fa.t_mean = t_mean.p; fa.t_var = t_var.p; fa.t_elites = t_elites.p; fa.t_samples = t_samples.p;
+    }
+    fa.key = key(step);
+    const int threads = std::min(1024, ((N + 63) / 64) * 64);
+    const int HUp = (HU + 3) & ~3, kp = (std::max(k, 1) + 3) & ~3;
+    const size_t lds_base = (size_t)(Nst + 3 * HUp + kp + 64) * 4;
+    const size_t lds_samples = (size_t)HU * Nst * 4;
+    prof_begin();
+    switch (cfg.optimizer) {
+        case BBMPC_OPT_RANDOM_SEARCH: launch_fused<FOPT_RS>(*this, fa, threads, lds_base, lds_samples); break;
+        case BBMPC_OPT_CEM: launch_fused<FOPT_CEM>(*this, fa, threads, lds_base, lds_samples); break;
+        default: launch_fused<FOPT_PI2>(*this, fa, threads, lds_base, lds_samples); break;
+    }
+    prof_end();
+}
+
+void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out) {
     REQUIRE(cfg.optimizer != BBMPC_OPT_NONE, BBMPC_E_STATE, "handle was created without an optimizer");
     const uint32_t step = step_counter++;
+    if (use_fused()) {
+        dominant_kernel = "k_fused_pendulum";
+        optimize_fused(d_state_in, add_noise, d_record_out, d_next_out, step);
+        return;
+    }
+    dominant_kernel = "k_rollout_pendulum";
     RolloutArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.n_pop = N; ra.A = A; ra.H = H; ra.U = U; ra.S = S; ra.HU = HU; ra.Nst = Nst;
@@ -308,7 +388,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
         default:
             throw HipError(BBMPC_E_UNSUPPORTED, "optimizer not built yet");
     }
-    finalize(d_state_in, add_noise, d_record_out, step);
+    finalize(d_state_in, add_noise, d_record_out, d_next_out, step);
 }
 
 void Engine::evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop, float* d_rew_out) {
@@ -567,12 +647,14 @@ int bbmpc_reset(bbmpc_handle h) {
     API_END
 }
 
-int bbmpc_optimize_dev(bbmpc_handle h, const float* d_state, int32_t, int32_t noise, float* d_record) {
+int bbmpc_optimize_dev(bbmpc_handle h, const float* d_state, int32_t, int32_t noise, float* d_record,
+                       float* d_next_state) {
     API_BEGIN
     CHECK_HANDLE(h);
     CHECK_PTR(d_state);
     CHECK_PTR(d_record);
-    h->e->optimize_dev(d_state, noise, d_record);
+    if (d_next_state == d_state) throw HipError(BBMPC_E_INVALID, "d_next_state must not alias d_state");
+    h->e->optimize_dev(d_state, noise, d_record, d_next_state);
     API_END
 }
 
@@ -587,7 +669,7 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
     memcpy(pin, state, ns * 4);
     HIP_CHECK(hipMemcpyAsync(e.d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e.stream));
     (void)t;  // the reference evaluator accepts and ignores time_step (deterministic.py:26)
-    e.optimize_dev(e.d_state.p, noise, e.d_record.p);
+    e.optimize_dev(e.d_state.p, noise, e.d_record.p, nullptr);
     HIP_CHECK(hipMemcpyAsync(pin + ns, e.d_record.p, nr * 4, hipMemcpyDeviceToHost, e.stream));
     HIP_CHECK(hipStreamSynchronize(e.stream));
     const float* r = pin + ns;

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/bbmpc.h"
+#include "kernels_fused.hpp"
 #include "kernels_refit.hpp"
 #include "kernels_rollout.hpp"
 
@@ -66,6 +67,7 @@ struct Engine {
     hipStream_t own_stream = nullptr, stream = nullptr;
     uint32_t step_counter = 0;
     bool trace_on = false, profiling = false;
+    int fused_mode = -1;     // -1 auto, 0 never, 1 always (env BBMPC_FUSED)
 
     // device state
     DevBuf<float> d_lo, d_hi, d_state, d_record, d_action;
@@ -106,7 +108,10 @@ struct Engine {
     float* pinned(size_t count);
 
     void reset();
-    void optimize_dev(const float* d_state_in, int add_noise, float* d_record_out);
+    void optimize_dev(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out);
+    bool use_fused() const;
+    void optimize_fused(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step);
+    void ensure_trace();
     void evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop, float* d_rew_out);
     void step_dev(const float* d_states, const float* d_actions, int astride, int batch, float* d_next, float* d_rew);
     void reward_dev(const float* d_cur, const float* d_next, const float* d_act, int batch, float* d_rew);
@@ -123,7 +128,7 @@ struct Engine {
     void prof_begin();
     void prof_end();
     void capture_trace(int it);
-    void finalize(const float* d_state_in, int add_noise, float* d_record_out, uint32_t step);
+    void finalize(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step);
     void to_internal(const float* ref, int n_pop, float* internal_host) const;     // [n,A,H,U] -> [A][HU][Nst]
     void from_internal(const float* internal_host, int n_pop, float* ref) const;
 };

@@ -1,0 +1,290 @@
+// Persistent per-control-step kernel for the analytic (true-model) path.
+//
+// One workgroup owns one agent for the WHOLE control step: distribution init, every optimizer
+// iteration (sample -> H-step rollout -> reward -> top-k / softmin / argmax -> refit) and the
+// OptimizerBase.__call__ tail (exploration noise, predicted next state + reward) run inside a single
+// launch, synchronised only by workgroup barriers.  Nothing but the [A,S] state comes in and the
+// packed [A,U+S+1] record goes out; rewards, the sampling distribution and (when they fit) the
+// candidate action sequences live in LDS, so an optimizer iteration moves no HBM traffic at all.
+//
+// Replaces, per control step, what the reference executes as one tf.function graph:
+//   OptimizerBase.__call__ (optimizer_base.py:55-95) -> {CEM,PI2,RandomSearch}._optimize
+//   (cem.py:74-136, pi2.py:58-96, random_search.py:38-48) -> DeterministicTrajectoryEvaluator.__call__
+//   (deterministic.py:26-77) -> PendulumTrueModel / pendulum_reward_function (utils/pendulum.py).
+#pragma once
+#include "kernels_refit.hpp"
+#include "kernels_rollout.hpp"
+
+namespace bbmpc {
+
+constexpr int FOPT_RS = 1;
+constexpr int FOPT_CEM = 2;
+constexpr int FOPT_PI2 = 3;
+
+struct FusedArgs {
+    int N, A, H, U, HU, Nst, k, iters;
+    int agent_offset;
+    int fix_q1, fix_q7, add_noise;
+    int warm_start;          // CEM: BBMPC_FIX_Q2 (keep the mean across control steps)
+    float alpha, inv_lamda;
+    const float* state;      // [A,3]
+    const float* lo;
+    const float* hi;
+    float* prev_mean;        // [A][HU] in/out (warm start)
+    const float* var0;       // [A][HU]
+    float* mean_out;         // [A][HU] last mean (get_state)
+    float* var_out;          // [A][HU]
+    float* samples_g;        // [A][HU][Nst] global scratch when the samples do not fit in LDS
+    const float* inj;        // injected standard noise [iters][A][HU][Nst] or null
+    const float* inj_expl;   // injected exploration noise [A,U] or null
+    float* record;           // [A][U+S+1]
+    float* next_state;       // optional contiguous [A,S]
+    // traces (null when disabled): [iters][A][Nst], [iters][A][HU], [iters][A][HU], [iters][A][k], [iters][A][HU][Nst]
+    float* t_rewards;
+    float* t_mean;
+    float* t_var;
+    int* t_elites;
+    float* t_samples;
+    RngKey key;
+};
+
+__device__ __forceinline__ float block_min(float v, float* red, int tid, int nw) {
+    v = wave_min(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float r = red[(tid & 63) < nw ? (tid & 63) : 0];
+    r = wave_min(r);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* red, int tid, int nw) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float r = ((tid & 63) < nw) ? red[tid & 63] : 0.0f;
+    r = wave_sum(r);
+    __syncthreads();
+    return r;
+}
+
+// LDS carve (floats): rewards[Nst] | mean[HUp] | var[HUp] | sigma[HUp] | eidx[kp] | red[64] | samples[HU][Nst]
+template <int OPT, bool SAMPLES_LDS>
+__global__ void k_fused_pendulum(FusedArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int a = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int nw = nthr >> 6;
+    const int HUp = (p.HU + 3) & ~3;
+    const int kp = (p.k + 3) & ~3;
+    float* rew = smem;
+    float* mean = rew + p.Nst;
+    float* var = mean + HUp;
+    float* sigma = var + HUp;
+    int* eidx = (int*)(sigma + HUp);
+    float* red = (float*)(eidx + kp);
+    float* samp = SAMPLES_LDS ? (red + 64) : (p.samples_g + (size_t)a * p.HU * p.Nst);
+    const PendulumModel model{p.fix_q1 != 0};
+    const float lo = p.lo[0], hi = p.hi[0];
+    const float s0 = p.state[a * 3 + 0], s1 = p.state[a * 3 + 1], s2 = p.state[a * 3 + 2];
+
+    // ---- distribution init (cem.py:129-132 starts every control step from the ctor mean/var, quirk Q2)
+    for (int j = tid; j < p.HU; j += nthr) {
+        const float m = p.prev_mean[a * p.HU + j];
+        const float v = p.var0[a * p.HU + j];
+        mean[j] = m;
+        var[j] = v;
+        sigma[j] = (OPT == FOPT_CEM) ? cem_sigma(m, v, lo, hi) : sqrtf(v);
+    }
+    __syncthreads();
+
+    float action0 = (OPT == FOPT_RS) ? 0.0f : mean[0];          // iters == 0 -> untouched mean[:,0]
+
+    for (int it = 0; it < p.iters; ++it) {
+        // ---- sample + rollout: one lane per trajectory, state in VGPRs
+        const float* inj = p.inj ? p.inj + ((size_t)it * p.A + a) * p.HU * p.Nst : nullptr;
+        for (int n = tid; n < p.N; n += nthr) {
+            float s[3] = {s0, s1, s2};
+            float total = 0.0f, pen = 0.0f;
+            U4 blk = {0, 0, 0, 0};
+            for (int t = 0; t < p.H; ++t) {
+                float xi;
+                if (inj) xi = inj[(size_t)t * p.Nst + n];
+                else {
+                    if ((t & 3) == 0)
+                        blk = rng_block(p.key, OPT == FOPT_RS ? 2u : 1u, (uint32_t)it, (uint32_t)n,
+                                        (uint32_t)(p.agent_offset + a), (uint32_t)t);
+                    const uint32_t w = pick_word(blk, (uint32_t)t);
+                    xi = (OPT == FOPT_RS) ? word_to_uniform(w) : word_to_trunc_normal(w);
+                }
+                float x;
+                if (OPT == FOPT_RS) x = xi * (hi - lo) + lo;                 // random_search.py:40-41
+                else x = xi * sigma[t] + mean[t];                            // cem.py:90-94 / pi2.py:65-69
+                if (OPT == FOPT_PI2) {                                       // pi2.py:70-75
+                    const float xf = clipf(x, lo, hi);
+                    const float d = x - xf;
+                    pen = pen + d * d;
+                    x = xf;
+                }
+                samp[(size_t)t * p.Nst + n] = x;
+                float act[1] = {x};
+                total = total + model.step(s, act);
+            }
+            if (total != total) total = -1.0e6f;                             // deterministic.py:75-77
+            if (OPT == FOPT_PI2) {
+                const float nr = sqrtf(pen);
+                total = total - nr * nr;
+            }
+            rew[n] = total;
+        }
+        __syncthreads();
+        if (p.t_rewards) {
+            for (int n = tid; n < p.N; n += nthr) p.t_rewards[((size_t)it * p.A + a) * p.Nst + n] = rew[n];
+            for (int i = tid; i < p.HU * p.Nst; i += nthr) {
+                const int j = i / p.Nst, n = i % p.Nst;
+                if (n < p.N) p.t_samples[(((size_t)it * p.A + a) * p.HU + j) * p.Nst + n] = samp[(size_t)j * p.Nst + n];
+            }
+        }
+
+        // ---- refit
+        if (OPT == FOPT_CEM) {
+            // top-k, sorted, ties -> lower index (tf.nn.top_k, cem.py:97-99): exact rank by counting
+            for (int n = tid; n < p.N; n += nthr) {
+                const float rn = rew[n];
+                int rank = 0;
+                const int n4 = p.N & ~3;
+                for (int m = 0; m < n4; m += 4) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(rew + m);
+                    rank += (r4.x > rn || (r4.x == rn && m + 0 < n)) ? 1 : 0;
+                    rank += (r4.y > rn || (r4.y == rn && m + 1 < n)) ? 1 : 0;
+                    rank += (r4.z > rn || (r4.z == rn && m + 2 < n)) ? 1 : 0;
+                    rank += (r4.w > rn || (r4.w == rn && m + 3 < n)) ? 1 : 0;
+                }
+                for (int m = n4; m < p.N; ++m) {
+                    const float rm = rew[m];
+                    rank += (rm > rn || (rm == rn && m < n)) ? 1 : 0;
+                }
+                if (rank < p.k) eidx[rank] = n;
+            }
+            __syncthreads();
+            if (p.t_elites)
+                for (int e = tid; e < p.k; e += nthr) p.t_elites[((size_t)it * p.A + a) * p.k + e] = eidx[e];
+            const float kf = (float)p.k;
+            for (int j = tid; j < p.HU; j += nthr) {
+                const float* row = samp + (size_t)j * p.Nst;
+                float sum = 0.0f;
+                for (int e = 0; e < p.k; ++e) sum = sum + row[eidx[e]];          // sequential, elite order
+                const float em = sum / kf;                                       // cem.py:112
+                float vs = 0.0f;
+                for (int e = 0; e < p.k; ++e) {
+                    const float d = row[eidx[e]] - em;
+                    vs = vs + d * d;
+                }
+                const float ev = vs / kf;                                        // cem.py:113-119
+                const float one_m = 1.0f - p.alpha;
+                const float m = p.alpha * mean[j] + one_m * em;                  // cem.py:121-122
+                const float v = p.alpha * var[j] + one_m * ev;                   // cem.py:123-125
+                mean[j] = m;
+                var[j] = v;
+                sigma[j] = cem_sigma(m, v, lo, hi);
+            }
+            __syncthreads();
+            action0 = mean[0];                                                   // cem.py:135
+        } else if (OPT == FOPT_PI2) {
+            float lmin = INFINITY;
+            for (int n = tid; n < p.N; n += nthr) {
+                const float c = -rew[n];                                         // pi2.py:78
+                rew[n] = c;
+                lmin = fminf(lmin, c);
+            }
+            const float beta = block_min(lmin, red, tid, nw);                    // pi2.py:81
+            float lsum = 0.0f;
+            for (int n = tid; n < p.N; n += nthr) {
+                const float pr = expf((-p.inv_lamda) * (rew[n] - beta));         // pi2.py:82
+                rew[n] = pr;
+                lsum += pr;
+            }
+            const float eta = block_sum(lsum, red, tid, nw);                     // pi2.py:83
+            const float inv_eta = 1.0f / eta;
+            for (int n = tid; n < p.N; n += nthr) rew[n] = inv_eta * rew[n];      // pi2.py:85
+            __syncthreads();
+            // new_mean[j] = sum_n x[j][n] * omega[n]   (pi2.py:86-87): one wave per j
+            for (int j = tid >> 6; j < p.HU; j += nw) {
+                const float* row = samp + (size_t)j * p.Nst;
+                float acc = 0.0f;
+                for (int n = tid & 63; n < p.N; n += 64) acc += row[n] * rew[n];
+                acc = wave_sum(acc);
+                if ((tid & 63) == 0) mean[j] = acc;
+            }
+            __syncthreads();
+            action0 = mean[0];                                                   // pi2.py:94
+        } else {  // RandomSearch: argmax, first maximum (random_search.py:43-47)
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+            for (int n = tid; n < p.N; n += nthr) {
+                const float v = rew[n];
+                if (v > bv || (v == bv && n < bi)) { bv = v; bi = n; }
+            }
+            wave_argmax(bv, bi);
+            int* redi = (int*)(red + 32);
+            if ((tid & 63) == 0) { red[tid >> 6] = bv; redi[tid >> 6] = bi; }
+            __syncthreads();
+            bv = ((tid & 63) < nw) ? red[tid & 63] : -INFINITY;
+            bi = ((tid & 63) < nw) ? redi[tid & 63] : 0x7fffffff;
+            wave_argmax(bv, bi);
+            if (bi == 0x7fffffff) bi = 0;
+            action0 = samp[bi];                                                  // sample[best][t=0]
+            if (p.t_elites && tid == 0) p.t_elites[a] = bi;
+            __syncthreads();
+        }
+        if (p.t_mean && OPT != FOPT_RS)
+            for (int j = tid; j < p.HU; j += nthr) {
+                p.t_mean[((size_t)it * p.A + a) * p.HU + j] = mean[j];
+                p.t_var[((size_t)it * p.A + a) * p.HU + j] = var[j];
+            }
+    }
+
+    // ---- state carried to the next control step
+    if (OPT != FOPT_RS) {
+        for (int j = tid; j < p.HU; j += nthr) {
+            p.mean_out[a * p.HU + j] = mean[j];
+            p.var_out[a * p.HU + j] = var[j];
+            if (OPT == FOPT_PI2) {                                               // shift-left warm start pi2.py:92-93
+                const int js = (j + 1 < p.HU) ? j + 1 : p.HU - 1;
+                p.prev_mean[a * p.HU + j] = mean[js];
+            } else if (p.warm_start) {
+                p.prev_mean[a * p.HU + j] = mean[j];
+            }
+        }
+    }
+
+    // ---- OptimizerBase.__call__ tail (optimizer_base.py:82-94)
+    if (tid == 0) {
+        FinalArgs fa;
+        fa.A = p.A; fa.U = 1; fa.S = 3;
+        fa.agent_offset = p.agent_offset;
+        fa.fix_q1 = p.fix_q1; fa.fix_q7 = p.fix_q7;
+        fa.add_noise = p.add_noise;
+        fa.lo = p.lo; fa.hi = p.hi;
+        fa.inj = p.inj_expl;
+        fa.key = p.key;
+        fa.key.q_per_agent = 1;
+        float s[3] = {s0, s1, s2};
+        float act[1];
+        act[0] = exploration_action(fa, a, 0, action0);
+        const float r = model.step(s, act);
+        float* rec = p.record + (size_t)a * 5;
+        rec[0] = act[0];
+        rec[1] = s[0];
+        rec[2] = s[1];
+        rec[3] = s[2];
+        rec[4] = r;
+        if (p.next_state) {
+            p.next_state[a * 3 + 0] = s[0];
+            p.next_state[a * 3 + 1] = s[1];
+            p.next_state[a * 3 + 2] = s[2];
+        }
+    }
+}
+
+}  // namespace bbmpc

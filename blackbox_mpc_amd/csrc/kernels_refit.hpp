@@ -95,7 +95,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_refit_cem(RefitArgs p, int JC
     if (p.elites)
         for (int e = tid; e < p.k; e += REFIT_THREADS) p.elites[a * p.k + e] = eidx[e];
 
-    const float inv_k = (float)p.k;
+    const float kf = (float)p.k;
     for (int j0 = 0; j0 < p.HU; j0 += JC) {
         const int jc = min(JC, p.HU - j0);
         __syncthreads();
@@ -108,13 +108,13 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_refit_cem(RefitArgs p, int JC
             const int j = j0 + tid;
             float sum = 0.0f;
             for (int e = 0; e < p.k; ++e) sum = sum + tile[e * JC + tid];
-            const float em = sum / inv_k;                                  // reduce_mean = sum / k
+            const float em = sum / kf;                                  // reduce_mean = sum / k
             float vs = 0.0f;
             for (int e = 0; e < p.k; ++e) {
                 const float d = tile[e * JC + tid] - em;
                 vs = vs + d * d;
             }
-            const float ev = vs / inv_k;
+            const float ev = vs / kf;
             const int aj = a * p.HU + j;
             const float one_m = 1.0f - p.alpha;
             const float m = p.alpha * p.mean[aj] + one_m * em;             // cem.py:121-122
@@ -226,6 +226,7 @@ struct FinalArgs {
     const float* hi;
     const float* inj;       // injected exploration noise [A,U] or null
     float* record;          // [A][U+S+1]
+    float* next_state;      // optional contiguous [A,S]
     RngKey key;
 };
 
@@ -259,6 +260,11 @@ __global__ void k_finalize_pendulum(FinalArgs p) {
     rec[2] = s[1];
     rec[3] = s[2];
     rec[4] = r;
+    if (p.next_state) {
+        p.next_state[a * 3 + 0] = s[0];
+        p.next_state[a * 3 + 1] = s[1];
+        p.next_state[a * 3 + 2] = s[2];
+    }
 }
 
 }  // namespace bbmpc

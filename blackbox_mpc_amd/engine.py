@@ -96,9 +96,9 @@ class Engine:
                                      L.ptr(action), L.ptr(nxt), L.ptr(rew)))
         return action, nxt, rew
 
-    def optimize_dev(self, d_state, d_record, t=0, add_exploration_noise=False):
+    def optimize_dev(self, d_state, d_record, t=0, add_exploration_noise=False, d_next_state=0):
         L.check(L.lib.bbmpc_optimize_dev(self._h, ctypes.c_void_p(d_state), int(t), int(bool(add_exploration_noise)),
-                                         ctypes.c_void_p(d_record)))
+                                         ctypes.c_void_p(d_record), ctypes.c_void_p(d_next_state or 0)))
 
     def evaluate(self, state, action_sequences):
         state = L.f32c(state)

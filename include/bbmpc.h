@@ -155,9 +155,11 @@ int bbmpc_reset(bbmpc_handle h);
  * -> (action[A,U], next_state[A,S], reward[A])      optimizer_base.py:55-95 */
 int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t time_step, int32_t add_exploration_noise,
                    float* action, float* next_state, float* reward);
-/* Same with device pointers; record is [A, U+S+1] = (action | next_state | reward) per agent. */
+/* Same with device pointers; record is [A, U+S+1] = (action | next_state | reward) per agent.
+ * d_next_state (optional, may be NULL) additionally receives the predicted next state as a contiguous
+ * [A,S] tensor, so a closed-loop caller can feed it straight back as the next d_state. */
 int bbmpc_optimize_dev(bbmpc_handle h, const float* d_state, int32_t time_step, int32_t add_exploration_noise,
-                       float* d_record);
+                       float* d_record, float* d_next_state);
 
 /* DeterministicTrajectoryEvaluator.__call__(current_states[A,S], action_sequences[n_pop,A,H,U], t)
  * -> rewards[n_pop,A]                 trajectory_evaluators/deterministic.py:26-77 */

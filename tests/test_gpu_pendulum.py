@@ -35,6 +35,14 @@ def _oracle_eval():
     return O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))
 
 
+@pytest.fixture(params=["fused", "per_iteration_kernels"], autouse=True)
+def kernel_path(request, monkeypatch):
+    """every optimizer test runs on both device paths: the persistent one-launch-per-control-step kernel
+    and the per-iteration rollout + refit kernels."""
+    monkeypatch.setenv("BBMPC_FUSED", "1" if request.param == "fused" else "0")
+    return request.param
+
+
 def _engine(L, opt, A, H, N=0, iters=0, k=0, **kw):
     from blackbox_mpc_amd.engine import Engine
     return Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, LO, HI, dim_s=3, num_agents=A, planning_horizon=H,
