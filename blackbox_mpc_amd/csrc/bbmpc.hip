@@ -288,7 +288,10 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     fa.key = key(step);
     const int threads = std::min(1024, ((N + 63) / 64) * 64);
     const int HUp = (HU + 3) & ~3, kp = (std::max(k, 1) + 3) & ~3;
-    const size_t lds_base = (size_t)(Nst + 3 * HUp + kp + 64) * 4;
+    int tile_floats = 0;
+    if (cfg.optimizer == BBMPC_OPT_CEM && (size_t)HU * (kp | 1) * 4 <= 48 * 1024) tile_floats = (HU * (kp | 1) + 3) & ~3;
+    fa.tile_floats = tile_floats;
+    const size_t lds_base = (size_t)(Nst + 3 * HUp + kp + 64 + tile_floats) * 4;
     const size_t lds_samples = (size_t)HU * Nst * 4;
     prof_begin();
     switch (cfg.optimizer) {

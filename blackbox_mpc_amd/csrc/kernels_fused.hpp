@@ -26,6 +26,7 @@ struct FusedArgs {
     int agent_offset;
     int fix_q1, fix_q7, add_noise;
     int warm_start;          // CEM: BBMPC_FIX_Q2 (keep the mean across control steps)
+    int tile_floats;         // CEM elite tile size in LDS (multiple of 4; 0 = gather straight from the samples)
     float alpha, inv_lamda;
     const float* state;      // [A,3]
     const float* lo;
@@ -67,7 +68,7 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nw)
     return r;
 }
 
-// LDS carve (floats): rewards[Nst] | mean[HUp] | var[HUp] | sigma[HUp] | eidx[kp] | red[64] | samples[HU][Nst]
+// LDS carve (floats): rewards[Nst] | mean[HUp] | var[HUp] | sigma[HUp] | eidx[kp] | red[64] | tile[tile_floats] | samples[HU][Nst]
 template <int OPT, bool SAMPLES_LDS>
 __global__ void k_fused_pendulum(FusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -83,7 +84,8 @@ __global__ void k_fused_pendulum(FusedArgs p) {
     float* sigma = var + HUp;
     int* eidx = (int*)(sigma + HUp);
     float* red = (float*)(eidx + kp);
-    float* samp = SAMPLES_LDS ? (red + 64) : (p.samples_g + (size_t)a * p.HU * p.Nst);
+    float* tile = red + 64;
+    float* samp = SAMPLES_LDS ? (tile + p.tile_floats) : (p.samples_g + (size_t)a * p.HU * p.Nst);
     const PendulumModel model{p.fix_q1 != 0};
     const float lo = p.lo[0], hi = p.hi[0];
     const float s0 = p.state[a * 3 + 0], s1 = p.state[a * 3 + 1], s2 = p.state[a * 3 + 2];
@@ -149,37 +151,56 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         // ---- refit
         if (OPT == FOPT_CEM) {
             // top-k, sorted, ties -> lower index (tf.nn.top_k, cem.py:97-99): exact rank by counting
-            for (int n = tid; n < p.N; n += nthr) {
-                const float rn = rew[n];
+            //   rank(n) = #{m < n : r[m] >= r[n]} + #{m > n : r[m] > r[n]}
+            // A wave's lanes hold 64 consecutive n, so the m-range splits wave-uniformly into
+            // [0, base) (>=), the wave's own 64 (full tie rule) and [base+64, N) (>): two instructions
+            // per comparison outside the 64-wide diagonal block; every lane reads the same r[m] (broadcast).
+            for (int n0 = (tid & ~63); n0 < p.N; n0 += nthr) {
+                const int n = n0 + (tid & 63);
+                const float rn = (n < p.N) ? rew[n] : -INFINITY;
                 int rank = 0;
-                const int n4 = p.N & ~3;
-                for (int m = 0; m < n4; m += 4) {
+                for (int m = 0; m < n0; m += 4) {                       // n0 is a multiple of 64
                     const float4 r4 = *reinterpret_cast<const float4*>(rew + m);
-                    rank += (r4.x > rn || (r4.x == rn && m + 0 < n)) ? 1 : 0;
-                    rank += (r4.y > rn || (r4.y == rn && m + 1 < n)) ? 1 : 0;
-                    rank += (r4.z > rn || (r4.z == rn && m + 2 < n)) ? 1 : 0;
-                    rank += (r4.w > rn || (r4.w == rn && m + 3 < n)) ? 1 : 0;
+                    rank += (r4.x >= rn) + (r4.y >= rn) + (r4.z >= rn) + (r4.w >= rn);
                 }
-                for (int m = n4; m < p.N; ++m) {
+                const int dend = min(n0 + 64, p.N);
+                for (int m = n0; m < dend; ++m) {
                     const float rm = rew[m];
                     rank += (rm > rn || (rm == rn && m < n)) ? 1 : 0;
                 }
-                if (rank < p.k) eidx[rank] = n;
+                const int n4 = dend + ((p.N - dend) & ~3);
+                for (int m = dend; m < n4; m += 4) {                    // dend is a multiple of 64 unless == N
+                    const float4 r4 = *reinterpret_cast<const float4*>(rew + m);
+                    rank += (r4.x > rn) + (r4.y > rn) + (r4.z > rn) + (r4.w > rn);
+                }
+                for (int m = n4; m < p.N; ++m) rank += (rew[m] > rn);
+                if (n < p.N && rank < p.k) eidx[rank] = n;
             }
             __syncthreads();
             if (p.t_elites)
                 for (int e = tid; e < p.k; e += nthr) p.t_elites[((size_t)it * p.A + a) * p.k + e] = eidx[e];
+            // elite statistics.  Gather pass: all lanes pull the k*HU elite elements into a dense
+            // [HU][tp] LDS tile, then lane j walks its row
+            // sequentially in elite order (the oracle's summation order) with contiguous LDS reads.
             const float kf = (float)p.k;
+            const int tp = kp | 1;                                   // odd row pitch: conflict-free row walks
+            const bool tile_ok = p.tile_floats >= p.HU * tp;
+            if (tile_ok) {
+                for (int i = tid; i < p.HU * p.k; i += nthr) {
+                    const int j = i / p.k, e = i % p.k;
+                    tile[j * tp + e] = samp[(size_t)j * p.Nst + eidx[e]];
+                }
+                __syncthreads();
+            }
             for (int j = tid; j < p.HU; j += nthr) {
                 const float* row = samp + (size_t)j * p.Nst;
                 float sum = 0.0f;
-                for (int e = 0; e < p.k; ++e) sum = sum + row[eidx[e]];          // sequential, elite order
+                if (tile_ok) for (int e = 0; e < p.k; ++e) sum = sum + tile[j * tp + e];
+                else for (int e = 0; e < p.k; ++e) sum = sum + row[eidx[e]];      // sequential, elite order
                 const float em = sum / kf;                                       // cem.py:112
                 float vs = 0.0f;
-                for (int e = 0; e < p.k; ++e) {
-                    const float d = row[eidx[e]] - em;
-                    vs = vs + d * d;
-                }
+                if (tile_ok) for (int e = 0; e < p.k; ++e) { const float d = tile[j * tp + e] - em; vs = vs + d * d; }
+                else for (int e = 0; e < p.k; ++e) { const float d = row[eidx[e]] - em; vs = vs + d * d; }
                 const float ev = vs / kf;                                        // cem.py:113-119
                 const float one_m = 1.0f - p.alpha;
                 const float m = p.alpha * mean[j] + one_m * em;                  // cem.py:121-122

@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "fastmath.hpp"
+
 namespace bbmpc {
 
 #define BBMPC_PI_F     3.14159274101257324f   /* float32(np.pi)   */
@@ -16,6 +18,7 @@ __device__ __forceinline__ float clipf(float x, float lo, float hi) {
 
 // TF FloorMod on floats (used by `%` in utils/pendulum.py:7): fmod, then move into the divisor's sign.
 __device__ __forceinline__ float floormodf(float x, float y) {
+    if (y > 0.0f) return bb_floormod_pos(x, y);
     float r = fmodf(x, y);
     if (r != 0.0f && ((y < 0.0f) != (r < 0.0f))) r = r + y;
     return r;
@@ -29,7 +32,7 @@ constexpr int REW_CHEETAH = 2;
 // trajectory_evaluators/deterministic.py:65-66 (quirk Q1): the third positional
 // argument (named `actions`) receives next_state.  theta = atan2(cur[1],cur[0]).
 __device__ __forceinline__ float pendulum_reward_from_theta(float theta, float thdot, float act_term_sumsq) {
-    float ang = floormodf(theta + BBMPC_PI_F, BBMPC_TWO_PI_F) - BBMPC_PI_F;     // :5-7
+    float ang = bb_floormod_pos(theta + BBMPC_PI_F, BBMPC_TWO_PI_F) - BBMPC_PI_F;   // :5-7
     float first = ang * ang + 0.1f * (thdot * thdot);
     return (-first) - 0.001f * act_term_sumsq;
 }
@@ -39,7 +42,7 @@ __device__ __forceinline__ float pendulum_reward_from_theta(float theta, float t
 __device__ __forceinline__ float reward_generic(int kind, bool fix_q1, const float* cur, const float* act,
                                                 const float* nxt, int S, int U) {
     if (kind == REW_PENDULUM) {
-        float theta = atan2f(cur[1], cur[0]);
+        float theta = bb_atan2f(cur[1], cur[0]);
         float ss = 0.0f;
         if (fix_q1) {
             for (int u = 0; u < U; ++u) ss = ss + act[u] * act[u];
@@ -71,14 +74,14 @@ struct PendulumModel {
 
     __device__ __forceinline__ float step(float (&s)[3], const float (&a)[1]) const {
         const float u = a[0];
-        const float theta = atan2f(s[1], s[0]);                 // :82 (the reward's atan2 has identical inputs)
-        float acc = -15.0f * sinf(theta + BBMPC_PI_F);          // -3g/(2l) = -15
+        const float theta = bb_atan2f(s[1], s[0]);              // :82 (the reward's atan2 has identical inputs)
+        float acc = -15.0f * bb_sinf(theta + BBMPC_PI_F);       // -3g/(2l) = -15
         acc = acc + 3.0f * u;                                   // 3/(m l^2) = 3
         float nthd = s[2] + acc * 0.05f;                        // :83-85
         const float nth = theta + nthd * 0.05f;                 // :86 (unclipped speed)
         nthd = clipf(nthd, -8.0f, 8.0f);                        // :87
         float sn, cs;
-        sincosf(nth, &sn, &cs);
+        bb_sincosf(nth, &sn, &cs);
         // deviation = new - x[:, :3]; next = deviation + current   (:91, transforms.py:34)
         const float n0 = (cs - s[0]) + s[0];
         const float n1 = (sn - s[1]) + s[1];
