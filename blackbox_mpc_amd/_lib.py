@@ -19,6 +19,7 @@ FIX_Q1_REWARD_ARG_ORDER = 1 << 0
 FIX_Q2_CEM_WARM_START = 1 << 1
 FIX_Q7_EXPL_NOISE_ZERO_MEAN = 1 << 2
 CMAES_PER_AGENT = 1 << 8
+STRICT_MATH = 1 << 9
 NOISE_TRUNC_NORMAL, NOISE_UNIFORM, NOISE_RADEMACHER, NOISE_NORMAL, NOISE_PSO_SCALARS = 1, 2, 3, 4, 5
 NOISE_PSO_RESEED_TRUNC, NOISE_PSO_RESEED_UNIFORM, NOISE_PSO_RESET_POS, NOISE_PSO_RESET_VEL = 6, 7, 8, 9
 NOISE_EXPLORATION = 10

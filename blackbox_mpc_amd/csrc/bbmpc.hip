@@ -173,20 +173,20 @@ void Engine::launch_rollout(int mode, bool pen, RolloutArgs& ra) {
     const int bs = ((long)ra.n_pop * A <= 16384) ? 64 : 256;
     dim3 grid((ra.n_pop + bs - 1) / bs, A), block(bs);
     prof_begin();
-    if (mode == SRC_REF) {
-        const size_t lds = (size_t)bs * 33 * sizeof(float);
-        hipLaunchKernelGGL((k_rollout_pendulum<SRC_REF, false>), grid, block, lds, stream, ra);
-    } else if (mode == SRC_UNIFORM) {
-        hipLaunchKernelGGL((k_rollout_pendulum<SRC_UNIFORM, false>), grid, block, 0, stream, ra);
-    } else if (mode == SRC_TRUNC && !pen) {
-        hipLaunchKernelGGL((k_rollout_pendulum<SRC_TRUNC, false>), grid, block, 0, stream, ra);
-    } else if (mode == SRC_TRUNC && pen) {
-        hipLaunchKernelGGL((k_rollout_pendulum<SRC_TRUNC, true>), grid, block, 0, stream, ra);
-    } else if (mode == SRC_BUF) {
-        hipLaunchKernelGGL((k_rollout_pendulum<SRC_BUF, true>), grid, block, 0, stream, ra);
-    } else {
-        throw HipError(BBMPC_E_INVALID, "bad rollout mode");
-    }
+    const bool fm = !fix(BBMPC_STRICT_MATH);
+    const size_t lds_ms = (size_t)2 * HU * sizeof(float);
+#define LAUNCH_ROLL(M, P, L)                                                                               \
+    do {                                                                                                   \
+        if (fm) hipLaunchKernelGGL((k_rollout_pendulum<M, P, true>), grid, block, (L), stream, ra);       \
+        else hipLaunchKernelGGL((k_rollout_pendulum<M, P, false>), grid, block, (L), stream, ra);         \
+    } while (0)
+    if (mode == SRC_REF) LAUNCH_ROLL(SRC_REF, false, (size_t)bs * 33 * sizeof(float));
+    else if (mode == SRC_UNIFORM) LAUNCH_ROLL(SRC_UNIFORM, false, 0);
+    else if (mode == SRC_TRUNC && !pen) LAUNCH_ROLL(SRC_TRUNC, false, lds_ms);
+    else if (mode == SRC_TRUNC && pen) LAUNCH_ROLL(SRC_TRUNC, true, lds_ms);
+    else if (mode == SRC_BUF) LAUNCH_ROLL(SRC_BUF, true, 0);
+    else throw HipError(BBMPC_E_INVALID, "bad rollout mode");
+#undef LAUNCH_ROLL
     HIP_CHECK(hipGetLastError());
     prof_end();
 }
@@ -246,16 +246,17 @@ bool Engine::use_fused() const {
 template <int OPT>
 static void launch_fused(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
     const size_t limit = 160 * 1024;
+    const bool fastm = !e.fix(BBMPC_STRICT_MATH);
     if (lds_base + lds_samples <= limit) {
-        auto fn = k_fused_pendulum<OPT, true>;
-        static size_t configured = 0;
-        if (lds_base + lds_samples > configured) {
+        auto fn = fastm ? k_fused_pendulum<OPT, true, true> : k_fused_pendulum<OPT, true, false>;
+        static bool configured[2] = {false, false};
+        if (!configured[fastm]) {
             HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limit));
-            configured = limit;
+            configured[fastm] = true;
         }
         hipLaunchKernelGGL(fn, dim3(e.A), dim3(threads), lds_base + lds_samples, e.stream, fa);
     } else {
-        auto fn = k_fused_pendulum<OPT, false>;
+        auto fn = fastm ? k_fused_pendulum<OPT, false, true> : k_fused_pendulum<OPT, false, false>;
         hipLaunchKernelGGL(fn, dim3(e.A), dim3(threads), lds_base, e.stream, fa);
     }
     HIP_CHECK(hipGetLastError());
@@ -285,6 +286,11 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
         ensure_trace();
         fa.t_rewards = t_rewards.p; fa.t_mean = t_mean.p; fa.t_var = t_var.p; fa.t_elites = t_elites.p; fa.t_samples = t_samples.p;
     }
+    static long long* dbg_buf = nullptr;
+    if (getenv("BBMPC_DBG")) {
+        if (!dbg_buf) HIP_CHECK(hipHostMalloc((void**)&dbg_buf, 64 * 8, hipHostMallocDefault));
+        fa.dbg = dbg_buf;
+    }
     fa.key = key(step);
     const int threads = std::min(1024, ((N + 63) / 64) * 64);
     const int HUp = (HU + 3) & ~3, kp = (std::max(k, 1) + 3) & ~3;
@@ -300,6 +306,14 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
         default: launch_fused<FOPT_PI2>(*this, fa, threads, lds_base, lds_samples); break;
     }
     prof_end();
+    if (fa.dbg) {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (step == 5) {
+            fprintf(stderr, "[dbg] phase clocks (10ns units) rel. to start:");
+            for (int i = 0; i <= 1 + iters * 4; ++i) fprintf(stderr, " %lld", fa.dbg[i] - fa.dbg[0]);
+            fprintf(stderr, "\n[dbg] shader clocks: %lld over %lld wall ticks => %.1f MHz\n", fa.dbg[41] - fa.dbg[40], fa.dbg[1 + iters * 4] - fa.dbg[0], (double)(fa.dbg[41] - fa.dbg[40]) / ((double)(fa.dbg[1 + iters * 4] - fa.dbg[0]) * 0.01));
+        }
+    }
 }
 
 void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out) {

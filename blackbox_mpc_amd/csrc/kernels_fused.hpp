@@ -46,8 +46,11 @@ struct FusedArgs {
     float* t_var;
     int* t_elites;
     float* t_samples;
+    long long* dbg;          // optional phase clocks (debug)
     RngKey key;
 };
+
+#define BB_DBG(slot) do { if (p.dbg && tid == 0 && a == 0) p.dbg[(slot)] = (long long)wall_clock64(); } while (0)
 
 __device__ __forceinline__ float block_min(float v, float* red, int tid, int nw) {
     v = wave_min(v);
@@ -69,7 +72,7 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nw)
 }
 
 // LDS carve (floats): rewards[Nst] | mean[HUp] | var[HUp] | sigma[HUp] | eidx[kp] | red[64] | tile[tile_floats] | samples[HU][Nst]
-template <int OPT, bool SAMPLES_LDS>
+template <int OPT, bool SAMPLES_LDS, bool FASTM>
 __global__ void k_fused_pendulum(FusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int a = blockIdx.x;
@@ -102,11 +105,14 @@ __global__ void k_fused_pendulum(FusedArgs p) {
 
     float action0 = (OPT == FOPT_RS) ? 0.0f : mean[0];          // iters == 0 -> untouched mean[:,0]
 
+    BB_DBG(0);
+    if (p.dbg && tid == 0 && a == 0) p.dbg[40] = (long long)clock64();
     for (int it = 0; it < p.iters; ++it) {
+        BB_DBG(1 + it * 4);
         // ---- sample + rollout: one lane per trajectory, state in VGPRs
         const float* inj = p.inj ? p.inj + ((size_t)it * p.A + a) * p.HU * p.Nst : nullptr;
         for (int n = tid; n < p.N; n += nthr) {
-            float s[3] = {s0, s1, s2};
+            Roller<FASTM> roll(p.fix_q1 != 0, s0, s1, s2);
             float total = 0.0f, pen = 0.0f;
             U4 blk = {0, 0, 0, 0};
             for (int t = 0; t < p.H; ++t) {
@@ -129,8 +135,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                     x = xf;
                 }
                 samp[(size_t)t * p.Nst + n] = x;
-                float act[1] = {x};
-                total = total + model.step(s, act);
+                total = total + roll.step(x);
             }
             if (total != total) total = -1.0e6f;                             // deterministic.py:75-77
             if (OPT == FOPT_PI2) {
@@ -139,7 +144,9 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             }
             rew[n] = total;
         }
+        BB_DBG(2 + it * 4);
         __syncthreads();
+        BB_DBG(3 + it * 4);
         if (p.t_rewards) {
             for (int n = tid; n < p.N; n += nthr) p.t_rewards[((size_t)it * p.A + a) * p.Nst + n] = rew[n];
             for (int i = tid; i < p.HU * p.Nst; i += nthr) {
@@ -159,16 +166,19 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                 const int n = n0 + (tid & 63);
                 const float rn = (n < p.N) ? rew[n] : -INFINITY;
                 int rank = 0;
+#pragma unroll 8
                 for (int m = 0; m < n0; m += 4) {                       // n0 is a multiple of 64
                     const float4 r4 = *reinterpret_cast<const float4*>(rew + m);
                     rank += (r4.x >= rn) + (r4.y >= rn) + (r4.z >= rn) + (r4.w >= rn);
                 }
                 const int dend = min(n0 + 64, p.N);
+#pragma unroll 8
                 for (int m = n0; m < dend; ++m) {
                     const float rm = rew[m];
                     rank += (rm > rn || (rm == rn && m < n)) ? 1 : 0;
                 }
                 const int n4 = dend + ((p.N - dend) & ~3);
+#pragma unroll 8
                 for (int m = dend; m < n4; m += 4) {                    // dend is a multiple of 64 unless == N
                     const float4 r4 = *reinterpret_cast<const float4*>(rew + m);
                     rank += (r4.x > rn) + (r4.y > rn) + (r4.z > rn) + (r4.w > rn);
@@ -177,6 +187,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                 if (n < p.N && rank < p.k) eidx[rank] = n;
             }
             __syncthreads();
+            BB_DBG(4 + it * 4);
             if (p.t_elites)
                 for (int e = tid; e < p.k; e += nthr) p.t_elites[((size_t)it * p.A + a) * p.k + e] = eidx[e];
             // elite statistics.  Gather pass: all lanes pull the k*HU elite elements into a dense
@@ -194,13 +205,30 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             }
             for (int j = tid; j < p.HU; j += nthr) {
                 const float* row = samp + (size_t)j * p.Nst;
-                float sum = 0.0f;
-                if (tile_ok) for (int e = 0; e < p.k; ++e) sum = sum + tile[j * tp + e];
-                else for (int e = 0; e < p.k; ++e) sum = sum + row[eidx[e]];      // sequential, elite order
-                const float em = sum / kf;                                       // cem.py:112
-                float vs = 0.0f;
-                if (tile_ok) for (int e = 0; e < p.k; ++e) { const float d = tile[j * tp + e] - em; vs = vs + d * d; }
-                else for (int e = 0; e < p.k; ++e) { const float d = row[eidx[e]] - em; vs = vs + d * d; }
+                float sum = 0.0f, vs = 0.0f, em;
+                if (tile_ok && p.k <= 64) {
+                    // whole elite row into registers with all LDS reads in flight at once, then the
+                    // strictly sequential (elite-order) sums run register-to-register
+                    float v[64];
+#pragma unroll
+                    for (int e = 0; e < 64; ++e) v[e] = (e < p.k) ? tile[j * tp + e] : 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 64; ++e) sum = (e < p.k) ? sum + v[e] : sum;
+                    em = sum / kf;                                               // cem.py:112
+#pragma unroll
+                    for (int e = 0; e < 64; ++e) {
+                        const float d = v[e] - em;
+                        vs = (e < p.k) ? vs + d * d : vs;
+                    }
+                } else if (tile_ok) {
+                    for (int e = 0; e < p.k; ++e) sum = sum + tile[j * tp + e];
+                    em = sum / kf;
+                    for (int e = 0; e < p.k; ++e) { const float d = tile[j * tp + e] - em; vs = vs + d * d; }
+                } else {
+                    for (int e = 0; e < p.k; ++e) sum = sum + row[eidx[e]];      // sequential, elite order
+                    em = sum / kf;
+                    for (int e = 0; e < p.k; ++e) { const float d = row[eidx[e]] - em; vs = vs + d * d; }
+                }
                 const float ev = vs / kf;                                        // cem.py:113-119
                 const float one_m = 1.0f - p.alpha;
                 const float m = p.alpha * mean[j] + one_m * em;                  // cem.py:121-122
@@ -265,6 +293,8 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             }
     }
 
+    BB_DBG(1 + p.iters * 4);
+    if (p.dbg && tid == 0 && a == 0) p.dbg[41] = (long long)clock64();
     // ---- state carried to the next control step
     if (OPT != FOPT_RS) {
         for (int j = tid; j < p.HU; j += nthr) {

@@ -47,8 +47,10 @@ struct RolloutArgs {
 };
 
 // Candidate element j of particle n, agent a.  `blk` caches the Philox block across calls.
+// `ms` (LDS) holds this agent's mean[HU] | sigma[HU] for SRC_TRUNC so that the sequential recurrence
+// never waits on a global load (the sample stores would otherwise order behind/ahead of them).
 template <int MODE>
-__device__ __forceinline__ float candidate(const RolloutArgs& p, int n, int a, int j, int u, U4& blk) {
+__device__ __forceinline__ float candidate(const RolloutArgs& p, int n, int a, int j, int u, U4& blk, const float* ms) {
     const int aj = a * p.HU + j;
     if constexpr (MODE == SRC_BUF) {
         return p.cand[(size_t)aj * p.Nst + n];
@@ -62,33 +64,30 @@ __device__ __forceinline__ float candidate(const RolloutArgs& p, int n, int a, i
             xi = (MODE == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
         }
         if constexpr (MODE == SRC_UNIFORM) {
-            return xi * (p.hi[u] - p.lo[u]) + p.lo[u];          // tf.random.uniform: rnd*(max-min)+min
+            const float l = p.lo[u];
+            return xi * (p.hi[u] - l) + l;                      // tf.random.uniform: rnd*(max-min)+min
         } else {
-            return xi * p.sigma[aj] + p.mean[aj];               // tf.random.truncated_normal: rnd*stddev+mean
+            return xi * ms[p.HU + j] + ms[j];                   // tf.random.truncated_normal: rnd*stddev+mean
         }
     }
 }
 
 // blockDim.x threads = consecutive particles of agent blockIdx.y.
-template <int MODE, bool PEN>
+template <int MODE, bool PEN, bool FASTM>
 __global__ void k_rollout_pendulum(RolloutArgs p) {
     constexpr int U = PendulumModel::U;
     const int a = blockIdx.y;
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = n < p.n_pop;
-    const PendulumModel model{p.fix_q1 != 0};
-    float s[3];
-    s[0] = p.state[a * 3 + 0];
-    s[1] = p.state[a * 3 + 1];
-    s[2] = p.state[a * 3 + 2];
+    Roller<FASTM> roll(p.fix_q1 != 0, p.state[a * 3 + 0], p.state[a * 3 + 1], p.state[a * 3 + 2]);
     float total = 0.0f, pen = 0.0f;
     U4 blk = {0, 0, 0, 0};
+    extern __shared__ float tile[];
 
     if constexpr (MODE == SRC_REF) {
         // Stage the block's action rows through LDS: global reads run along each particle's
         // contiguous [H*U] row (coalesced), the recurrence then reads its own row from LDS
         // (row pitch TJ+1 words -> conflict-free).
-        extern __shared__ float tile[];
         constexpr int TJ = 32;
         const int rows = blockDim.x;
         const int n0 = blockIdx.x * blockDim.x;
@@ -105,23 +104,28 @@ __global__ void k_rollout_pendulum(RolloutArgs p) {
             __syncthreads();
             if (active) {
                 for (int c = 0; c < tj; c += U) {
-                    float act[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) act[u] = tile[threadIdx.x * (TJ + 1) + c + u];
-                    total = total + model.step(s, act);
+                    total = total + roll.step(tile[threadIdx.x * (TJ + 1) + c]);
                 }
             }
         }
     } else {
+        if constexpr (MODE == SRC_TRUNC) {
+            for (int j = threadIdx.x; j < p.HU; j += blockDim.x) {
+                tile[j] = p.mean[a * p.HU + j];
+                tile[p.HU + j] = p.sigma[a * p.HU + j];
+            }
+            __syncthreads();
+        }
+        const float lo0 = p.lo[0], hi0 = p.hi[0];
         if (active) {
             for (int t = 0; t < p.H; ++t) {
                 float act[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int j = t * U + u;
-                    float x = candidate<MODE>(p, n, a, j, u, blk);
+                    float x = candidate<MODE>(p, n, a, j, u, blk, tile);
                     if constexpr (PEN) {
-                        const float xf = clipf(x, p.lo[u], p.hi[u]);
+                        const float xf = clipf(x, lo0, hi0);
                         const float d = x - xf;
                         pen = pen + d * d;
                         x = xf;
@@ -129,7 +133,7 @@ __global__ void k_rollout_pendulum(RolloutArgs p) {
                     if (p.samples) p.samples[(size_t)(a * p.HU + j) * p.Nst + n] = x;
                     act[u] = x;
                 }
-                total = total + model.step(s, act);
+                total = total + roll.step(act[0]);
             }
         }
     }

@@ -95,4 +95,65 @@ struct PendulumModel {
     }
 };
 
+// The same recurrence carried as (theta, thdot) instead of (cos, sin, thdot).
+//
+// The reference re-derives theta = atan2(sin, cos) from the state every step (utils/pendulum.py:82 and
+// again in the reward :27) after having just computed sin/cos of the new angle (:88-89).  Since
+// atan2(sin x, cos x) is the principal value of x, the angle can be carried directly: per step this
+// drops one atan2 and one sincos (about 3/4 of the instructions).  What changes numerically is only
+// fp32 rounding noise of the 1e-7 class the libm choice already introduces (the reference's own
+// (cos - s0) + s0 round trip perturbs the angle by up to 0.5 ulp(1)); sum(next_state**2) uses
+// cos^2 + sin^2 = 1.  The strict, op-for-op PendulumModel above stays available
+// (BBMPC_STRICT_MATH) and both are held to the same parity tolerances.
+struct PendulumAngleModel {
+    bool fix_q1;
+    float theta, thd;
+
+    __device__ __forceinline__ void init(float s0, float s1, float s2) {
+        theta = bb_atan2f(s1, s0);
+        thd = s2;
+    }
+    __device__ __forceinline__ float step(float u) {
+        const float t1 = theta + BBMPC_PI_F;
+        float acc = -15.0f * bb_sinf_0_2pi(t1);
+        acc = acc + 3.0f * u;
+        float nthd = thd + acc * 0.05f;
+        const float nth = theta + nthd * 0.05f;
+        nthd = clipf(nthd, -8.0f, 8.0f);
+        const float n2 = (nthd - thd) + thd;
+        const float ss = fix_q1 ? u * u : 1.0f + n2 * n2;
+        const float ang = bb_floormod_pos(t1, BBMPC_TWO_PI_F) - BBMPC_PI_F;
+        const float first = ang * ang + 0.1f * (thd * thd);
+        const float r = (-first) - 0.001f * ss;
+        theta = bb_wrap_pi(nth);
+        thd = n2;
+        return r;
+    }
+};
+
+// Uniform rollout interface over the two formulations.
+template <bool FASTM>
+struct Roller;
+template <>
+struct Roller<false> {
+    PendulumModel m;
+    float s[3];
+    __device__ __forceinline__ Roller(bool fix_q1, float s0, float s1, float s2) : m{fix_q1} {
+        s[0] = s0; s[1] = s1; s[2] = s2;
+    }
+    __device__ __forceinline__ float step(float u) {
+        const float a[1] = {u};
+        return m.step(s, a);
+    }
+};
+template <>
+struct Roller<true> {
+    PendulumAngleModel m;
+    __device__ __forceinline__ Roller(bool fix_q1, float s0, float s1, float s2) {
+        m.fix_q1 = fix_q1;
+        m.init(s0, s1, s2);
+    }
+    __device__ __forceinline__ float step(float u) { return m.step(u); }
+};
+
 }  // namespace bbmpc

@@ -71,6 +71,8 @@ extern "C" {
 #define BBMPC_FIX_Q2_CEM_WARM_START     (1u << 1)  /* CEM keeps shifted mean across control steps  */
 #define BBMPC_FIX_Q7_EXPL_NOISE_ZERO_MEAN (1u << 2)
 #define BBMPC_CMAES_PER_AGENT           (1u << 8)  /* independent CMA-ES per agent (deviation, shards) */
+#define BBMPC_STRICT_MATH               (1u << 9)  /* pendulum rollouts op-for-op as the reference (atan2/sincos every
+                                                      step) instead of carrying the angle; same tolerances, slower */
 
 /* noise kinds for bbmpc_inject_noise (standard draws, reference layout) */
 #define BBMPC_NOISE_TRUNC_NORMAL 1  /* [iters][N,A,H,U] unit normal, |z|<2: cem.py:90 pi2.py:65 */

@@ -35,16 +35,24 @@ def _oracle_eval():
     return O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))
 
 
-@pytest.fixture(params=["fused", "per_iteration_kernels"], autouse=True)
+_MODE = {"quirks": 0}
+
+
+@pytest.fixture(params=["fused-angle", "fused-strict", "periter-angle", "periter-strict"], autouse=True)
 def kernel_path(request, monkeypatch):
-    """every optimizer test runs on both device paths: the persistent one-launch-per-control-step kernel
-    and the per-iteration rollout + refit kernels."""
-    monkeypatch.setenv("BBMPC_FUSED", "1" if request.param == "fused" else "0")
-    return request.param
+    """every test runs on both device paths (the persistent one-launch-per-control-step kernel and the
+    per-iteration rollout + refit kernels) and with both formulations of the pendulum recurrence (the
+    default angle-carried one and the op-for-op BBMPC_STRICT_MATH one): same tolerances for all four."""
+    path, math = request.param.split("-")
+    monkeypatch.setenv("BBMPC_FUSED", "1" if path == "fused" else "0")
+    _MODE["quirks"] = (1 << 9) if math == "strict" else 0
+    yield request.param
+    _MODE["quirks"] = 0
 
 
 def _engine(L, opt, A, H, N=0, iters=0, k=0, **kw):
     from blackbox_mpc_amd.engine import Engine
+    kw["quirks"] = kw.get("quirks", 0) | _MODE["quirks"]
     return Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, LO, HI, dim_s=3, num_agents=A, planning_horizon=H,
                   population_size=N, max_iterations=iters, num_elite=k, **kw)
 
