@@ -243,23 +243,32 @@ bool Engine::use_fused() const {
     return (long)N <= 2048 || A >= 64;
 }
 
-template <int OPT>
-static void launch_fused(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
+template <int OPT, bool FASTM, bool INJ>
+static void launch_fused3(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
     const size_t limit = 160 * 1024;
-    const bool fastm = !e.fix(BBMPC_STRICT_MATH);
     if (lds_base + lds_samples <= limit) {
-        auto fn = fastm ? k_fused_pendulum<OPT, true, true> : k_fused_pendulum<OPT, true, false>;
-        static bool configured[2] = {false, false};
-        if (!configured[fastm]) {
+        auto fn = k_fused_pendulum<OPT, true, FASTM, INJ>;
+        static bool configured = false;
+        if (!configured) {
             HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limit));
-            configured[fastm] = true;
+            configured = true;
         }
         hipLaunchKernelGGL(fn, dim3(e.A), dim3(threads), lds_base + lds_samples, e.stream, fa);
     } else {
-        auto fn = fastm ? k_fused_pendulum<OPT, false, true> : k_fused_pendulum<OPT, false, false>;
+        auto fn = k_fused_pendulum<OPT, false, FASTM, INJ>;
         hipLaunchKernelGGL(fn, dim3(e.A), dim3(threads), lds_base, e.stream, fa);
     }
     HIP_CHECK(hipGetLastError());
+}
+
+template <int OPT>
+static void launch_fused(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
+    const bool fastm = !e.fix(BBMPC_STRICT_MATH);
+    const bool inj = fa.inj != nullptr;
+    if (fastm && !inj) launch_fused3<OPT, true, false>(e, fa, threads, lds_base, lds_samples);
+    else if (fastm && inj) launch_fused3<OPT, true, true>(e, fa, threads, lds_base, lds_samples);
+    else if (!fastm && !inj) launch_fused3<OPT, false, false>(e, fa, threads, lds_base, lds_samples);
+    else launch_fused3<OPT, false, true>(e, fa, threads, lds_base, lds_samples);
 }
 
 void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step) {

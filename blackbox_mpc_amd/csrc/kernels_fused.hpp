@@ -50,7 +50,7 @@ struct FusedArgs {
     RngKey key;
 };
 
-#define BB_DBG(slot) do { if (p.dbg && tid == 0 && a == 0) p.dbg[(slot)] = (long long)wall_clock64(); } while (0)
+#define BB_DBG(slot) do { if (p.dbg && tid == 0 && a == 0) dbg_lds[(slot)] = (long long)wall_clock64(); } while (0)
 
 __device__ __forceinline__ float block_min(float v, float* red, int tid, int nw) {
     v = wave_min(v);
@@ -72,7 +72,7 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nw)
 }
 
 // LDS carve (floats): rewards[Nst] | mean[HUp] | var[HUp] | sigma[HUp] | eidx[kp] | red[64] | tile[tile_floats] | samples[HU][Nst]
-template <int OPT, bool SAMPLES_LDS, bool FASTM>
+template <int OPT, bool SAMPLES_LDS, bool FASTM, bool INJ>
 __global__ void k_fused_pendulum(FusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int a = blockIdx.x;
@@ -89,6 +89,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
     float* red = (float*)(eidx + kp);
     float* tile = red + 64;
     float* samp = SAMPLES_LDS ? (tile + p.tile_floats) : (p.samples_g + (size_t)a * p.HU * p.Nst);
+    __shared__ long long dbg_lds[48];
     const PendulumModel model{p.fix_q1 != 0};
     const float lo = p.lo[0], hi = p.hi[0];
     const float s0 = p.state[a * 3 + 0], s1 = p.state[a * 3 + 1], s2 = p.state[a * 3 + 2];
@@ -106,29 +107,44 @@ __global__ void k_fused_pendulum(FusedArgs p) {
     float action0 = (OPT == FOPT_RS) ? 0.0f : mean[0];          // iters == 0 -> untouched mean[:,0]
 
     BB_DBG(0);
-    if (p.dbg && tid == 0 && a == 0) p.dbg[40] = (long long)clock64();
+    if (p.dbg && tid == 0 && a == 0) dbg_lds[40] = (long long)clock64();
     for (int it = 0; it < p.iters; ++it) {
         BB_DBG(1 + it * 4);
         // ---- sample + rollout: one lane per trajectory, state in VGPRs
-        const float* inj = p.inj ? p.inj + ((size_t)it * p.A + a) * p.HU * p.Nst : nullptr;
+        // The 4 candidate actions of Philox block b+1 are generated while the recurrence steps through
+        // block b: their instructions carry no dependence on the state, so they fill the latency
+        // shadows of the sequential theta/thdot chain (all straight-line code inside a block).
+        const float* inj = INJ ? p.inj + ((size_t)it * p.A + a) * p.HU * p.Nst : nullptr;
+        const int nblk = p.H >> 2, rem = p.H & 3;
+        const uint32_t rstream = (OPT == FOPT_RS) ? 2u : 1u;
         for (int n = tid; n < p.N; n += nthr) {
             Roller<FASTM> roll(p.fix_q1 != 0, s0, s1, s2);
             float total = 0.0f, pen = 0.0f;
-            U4 blk = {0, 0, 0, 0};
-            for (int t = 0; t < p.H; ++t) {
-                float xi;
-                if (inj) xi = inj[(size_t)t * p.Nst + n];
-                else {
-                    if ((t & 3) == 0)
-                        blk = rng_block(p.key, OPT == FOPT_RS ? 2u : 1u, (uint32_t)it, (uint32_t)n,
-                                        (uint32_t)(p.agent_offset + a), (uint32_t)t);
-                    const uint32_t w = pick_word(blk, (uint32_t)t);
-                    xi = (OPT == FOPT_RS) ? word_to_uniform(w) : word_to_trunc_normal(w);
+            float xn[4];
+            auto gen = [&](int b, float (&x)[4]) {
+                float xi[4];
+                if (INJ) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xi[i] = (4 * b + i < p.H) ? inj[(size_t)(4 * b + i) * p.Nst + n] : 0.0f;
+                } else {
+                    const U4 w = rng_block(p.key, rstream, (uint32_t)it, (uint32_t)n, (uint32_t)(p.agent_offset + a),
+                                           (uint32_t)(4 * b));
+                    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        xi[i] = (OPT == FOPT_RS) ? word_to_uniform(ww[i]) : word_to_trunc_normal(ww[i]);
                 }
-                float x;
-                if (OPT == FOPT_RS) x = xi * (hi - lo) + lo;                 // random_search.py:40-41
-                else x = xi * sigma[t] + mean[t];                            // cem.py:90-94 / pi2.py:65-69
-                if (OPT == FOPT_PI2) {                                       // pi2.py:70-75
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = min(4 * b + i, p.H - 1);
+                    float v;
+                    if (OPT == FOPT_RS) v = xi[i] * (hi - lo) + lo;              // random_search.py:40-41
+                    else v = xi[i] * sigma[t] + mean[t];                         // cem.py:90-94 / pi2.py:65-69
+                    x[i] = v;
+                }
+            };
+            auto consume = [&](int t, float x) {
+                if (OPT == FOPT_PI2) {                                           // pi2.py:70-75
                     const float xf = clipf(x, lo, hi);
                     const float d = x - xf;
                     pen = pen + d * d;
@@ -136,7 +152,17 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                 }
                 samp[(size_t)t * p.Nst + n] = x;
                 total = total + roll.step(x);
+            };
+            gen(0, xn);
+            for (int b = 0; b < nblk; ++b) {
+                const float x0 = xn[0], x1 = xn[1], x2 = xn[2], x3 = xn[3];
+                gen(b + 1, xn);          // one block ahead (the block past the end is generated and dropped)
+                consume(4 * b + 0, x0);
+                consume(4 * b + 1, x1);
+                consume(4 * b + 2, x2);
+                consume(4 * b + 3, x3);
             }
+            for (int i = 0; i < rem; ++i) consume(4 * nblk + i, xn[i]);
             if (total != total) total = -1.0e6f;                             // deterministic.py:75-77
             if (OPT == FOPT_PI2) {
                 const float nr = sqrtf(pen);
@@ -165,11 +191,11 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             for (int n0 = (tid & ~63); n0 < p.N; n0 += nthr) {
                 const int n = n0 + (tid & 63);
                 const float rn = (n < p.N) ? rew[n] : -INFINITY;
-                int rank = 0;
+                int rank = 0, rk0 = 0, rk1 = 0, rk2 = 0, rk3 = 0;     // independent chains
 #pragma unroll 8
                 for (int m = 0; m < n0; m += 4) {                       // n0 is a multiple of 64
                     const float4 r4 = *reinterpret_cast<const float4*>(rew + m);
-                    rank += (r4.x >= rn) + (r4.y >= rn) + (r4.z >= rn) + (r4.w >= rn);
+                    rk0 += (r4.x >= rn); rk1 += (r4.y >= rn); rk2 += (r4.z >= rn); rk3 += (r4.w >= rn);
                 }
                 const int dend = min(n0 + 64, p.N);
 #pragma unroll 8
@@ -181,9 +207,10 @@ __global__ void k_fused_pendulum(FusedArgs p) {
 #pragma unroll 8
                 for (int m = dend; m < n4; m += 4) {                    // dend is a multiple of 64 unless == N
                     const float4 r4 = *reinterpret_cast<const float4*>(rew + m);
-                    rank += (r4.x > rn) + (r4.y > rn) + (r4.z > rn) + (r4.w > rn);
+                    rk0 += (r4.x > rn); rk1 += (r4.y > rn); rk2 += (r4.z > rn); rk3 += (r4.w > rn);
                 }
                 for (int m = n4; m < p.N; ++m) rank += (rew[m] > rn);
+                rank += (rk0 + rk1) + (rk2 + rk3);
                 if (n < p.N && rank < p.k) eidx[rank] = n;
             }
             __syncthreads();
@@ -294,7 +321,10 @@ __global__ void k_fused_pendulum(FusedArgs p) {
     }
 
     BB_DBG(1 + p.iters * 4);
-    if (p.dbg && tid == 0 && a == 0) p.dbg[41] = (long long)clock64();
+    if (p.dbg && tid == 0 && a == 0) {
+        dbg_lds[41] = (long long)clock64();
+        for (int i = 0; i < 48; ++i) p.dbg[i] = dbg_lds[i];
+    }
     // ---- state carried to the next control step
     if (OPT != FOPT_RS) {
         for (int j = tid; j < p.HU; j += nthr) {

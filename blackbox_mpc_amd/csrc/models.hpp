@@ -122,7 +122,8 @@ struct PendulumAngleModel {
         nthd = clipf(nthd, -8.0f, 8.0f);
         const float n2 = (nthd - thd) + thd;
         const float ss = fix_q1 ? u * u : 1.0f + n2 * n2;
-        const float ang = bb_floormod_pos(t1, BBMPC_TWO_PI_F) - BBMPC_PI_F;
+        // t1 is in [0, 2pi] (theta is a principal value): FloorMod reduces to one exact conditional subtract
+        const float ang = ((t1 >= BBMPC_TWO_PI_F) ? t1 - BBMPC_TWO_PI_F : t1) - BBMPC_PI_F;
         const float first = ang * ang + 0.1f * (thd * thd);
         const float r = (-first) - 0.001f * ss;
         theta = bb_wrap_pi(nth);
