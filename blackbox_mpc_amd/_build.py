@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbbmpc.so")
 SOURCES = ["bbmpc.hip"]
-HEADERS = ["engine.hpp", "kernels_rollout.hpp", "kernels_refit.hpp", "models.hpp", "rng.hpp", "kernels_mlp.hpp",
+HEADERS = ["engine.hpp", "kernels_rollout.hpp", "kernels_refit.hpp", "models.hpp", "rng.hpp", "kernels_mlp.hpp", "kernels_fused.hpp", "fastmath.hpp", "topk.hpp",
            "kernels_opt.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          # one rounding per reference op: never contract a*b+c behind the source's back

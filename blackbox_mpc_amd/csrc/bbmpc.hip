@@ -245,7 +245,7 @@ bool Engine::use_fused() const {
 
 template <int OPT, bool FASTM, bool INJ>
 static void launch_fused3(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
-    const size_t limit = 160 * 1024;
+    const size_t limit = 159 * 1024;   // 160 KiB per CU minus the kernel's small static LDS
     if (lds_base + lds_samples <= limit) {
         auto fn = k_fused_pendulum<OPT, true, FASTM, INJ>;
         static bool configured = false;
@@ -306,7 +306,7 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     int tile_floats = 0;
     if (cfg.optimizer == BBMPC_OPT_CEM && (size_t)HU * (kp | 1) * 4 <= 48 * 1024) tile_floats = (HU * (kp | 1) + 3) & ~3;
     fa.tile_floats = tile_floats;
-    const size_t lds_base = (size_t)(Nst + 3 * HUp + kp + 64 + tile_floats) * 4;
+    const size_t lds_base = (size_t)(Nst + 3 * HUp + kp + 64 + TOPK_HIST_WORDS + 2 * kp + tile_floats) * 4;
     const size_t lds_samples = (size_t)HU * Nst * 4;
     prof_begin();
     switch (cfg.optimizer) {
@@ -378,9 +378,10 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
             const float* inj_t = injected(BBMPC_NOISE_TRUNC_NORMAL);
             // LDS budget for the refit: rewards + elite idx + elite tile
             const int kpad = (k + 3) & ~3;
-            int JC = (int)((size_t)(60 * 1024 / 4 - Nst - kpad) / (size_t)k);
+            const int fixed = Nst + kpad + TOPK_HIST_WORDS + 2 * kpad;
+            int JC = (int)((size_t)(62 * 1024 / 4 - fixed) / (size_t)k);
             JC = std::max(1, std::min(JC, HU));
-            const size_t lds = (size_t)(Nst + kpad + (size_t)k * JC) * 4;
+            const size_t lds = (size_t)(fixed + (size_t)k * JC) * 4;
             for (int it = 0; it < iters; ++it) {
                 ra.stream = BBMPC_NOISE_TRUNC_NORMAL; ra.iter = (uint32_t)it;
                 ra.inj = inj_t ? inj_t + inj_stride * it : nullptr;

@@ -14,6 +14,7 @@
 #pragma once
 #include "kernels_refit.hpp"
 #include "kernels_rollout.hpp"
+#include "topk.hpp"
 
 namespace bbmpc {
 
@@ -71,7 +72,8 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nw)
     return r;
 }
 
-// LDS carve (floats): rewards[Nst] | mean[HUp] | var[HUp] | sigma[HUp] | eidx[kp] | red[64] | tile[tile_floats] | samples[HU][Nst]
+// LDS carve (4-byte words): rewards[Nst] | mean[HUp] | var[HUp] | sigma[HUp] | eidx[kp] | red[64] | hist[272] |
+//                            ekeys[2*kp] | tile[tile_floats] | samples[HU][Nst]      (every piece a multiple of 16 B)
 template <int OPT, bool SAMPLES_LDS, bool FASTM, bool INJ>
 __global__ void k_fused_pendulum(FusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -87,7 +89,9 @@ __global__ void k_fused_pendulum(FusedArgs p) {
     float* sigma = var + HUp;
     int* eidx = (int*)(sigma + HUp);
     float* red = (float*)(eidx + kp);
-    float* tile = red + 64;
+    uint32_t* hist = (uint32_t*)(red + 64);
+    unsigned long long* ekeys = (unsigned long long*)(hist + TOPK_HIST_WORDS);
+    float* tile = (float*)(ekeys + kp);
     float* samp = SAMPLES_LDS ? (tile + p.tile_floats) : (p.samples_g + (size_t)a * p.HU * p.Nst);
     __shared__ long long dbg_lds[48];
     const PendulumModel model{p.fix_q1 != 0};
@@ -183,37 +187,8 @@ __global__ void k_fused_pendulum(FusedArgs p) {
 
         // ---- refit
         if (OPT == FOPT_CEM) {
-            // top-k, sorted, ties -> lower index (tf.nn.top_k, cem.py:97-99): exact rank by counting
-            //   rank(n) = #{m < n : r[m] >= r[n]} + #{m > n : r[m] > r[n]}
-            // A wave's lanes hold 64 consecutive n, so the m-range splits wave-uniformly into
-            // [0, base) (>=), the wave's own 64 (full tie rule) and [base+64, N) (>): two instructions
-            // per comparison outside the 64-wide diagonal block; every lane reads the same r[m] (broadcast).
-            for (int n0 = (tid & ~63); n0 < p.N; n0 += nthr) {
-                const int n = n0 + (tid & 63);
-                const float rn = (n < p.N) ? rew[n] : -INFINITY;
-                int rank = 0, rk0 = 0, rk1 = 0, rk2 = 0, rk3 = 0;     // independent chains
-#pragma unroll 8
-                for (int m = 0; m < n0; m += 4) {                       // n0 is a multiple of 64
-                    const float4 r4 = *reinterpret_cast<const float4*>(rew + m);
-                    rk0 += (r4.x >= rn); rk1 += (r4.y >= rn); rk2 += (r4.z >= rn); rk3 += (r4.w >= rn);
-                }
-                const int dend = min(n0 + 64, p.N);
-#pragma unroll 8
-                for (int m = n0; m < dend; ++m) {
-                    const float rm = rew[m];
-                    rank += (rm > rn || (rm == rn && m < n)) ? 1 : 0;
-                }
-                const int n4 = dend + ((p.N - dend) & ~3);
-#pragma unroll 8
-                for (int m = dend; m < n4; m += 4) {                    // dend is a multiple of 64 unless == N
-                    const float4 r4 = *reinterpret_cast<const float4*>(rew + m);
-                    rk0 += (r4.x > rn); rk1 += (r4.y > rn); rk2 += (r4.z > rn); rk3 += (r4.w > rn);
-                }
-                for (int m = n4; m < p.N; ++m) rank += (rew[m] > rn);
-                rank += (rk0 + rk1) + (rk2 + rk3);
-                if (n < p.N && rank < p.k) eidx[rank] = n;
-            }
-            __syncthreads();
+            // exact sorted top-k (tf.nn.top_k, cem.py:97-99): LDS radix select, see topk.hpp
+            block_topk_sorted(rew, p.N, p.k, eidx, hist, ekeys, tid, nthr);
             BB_DBG(4 + it * 4);
             if (p.t_elites)
                 for (int e = tid; e < p.k; e += nthr) p.t_elites[((size_t)it * p.A + a) * p.k + e] = eidx[e];
@@ -224,10 +199,8 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             const int tp = kp | 1;                                   // odd row pitch: conflict-free row walks
             const bool tile_ok = p.tile_floats >= p.HU * tp;
             if (tile_ok) {
-                for (int i = tid; i < p.HU * p.k; i += nthr) {
-                    const int j = i / p.k, e = i % p.k;
-                    tile[j * tp + e] = samp[(size_t)j * p.Nst + eidx[e]];
-                }
+                for (int j = tid >> 6; j < p.HU; j += nw)                 // one wave per row, lanes over elites
+                    for (int e = tid & 63; e < p.k; e += 64) tile[j * tp + e] = samp[(size_t)j * p.Nst + eidx[e]];
                 __syncthreads();
             }
             for (int j = tid; j < p.HU; j += nthr) {

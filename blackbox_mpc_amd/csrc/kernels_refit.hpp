@@ -6,6 +6,7 @@
 #include <math.h>
 #include "models.hpp"
 #include "rng.hpp"
+#include "topk.hpp"
 
 namespace bbmpc {
 
@@ -69,7 +70,7 @@ __global__ void k_dist_init(int A, int HU, int U, const float* lo, const float* 
 
 // CEM refit  cem.py:97-125: top-k (sorted, ties -> lower index), elite mean / biased variance
 // (accumulated sequentially in elite order), alpha smoothing.
-// LDS: rewards[Nst] | elite idx[kpad] | elite tile [k][JC]
+// LDS: rewards[Nst] | elite idx[kpad] | hist[272] | ekeys[2*kpad] | elite tile [k][JC]
 __global__ __launch_bounds__(REFIT_THREADS) void k_refit_cem(RefitArgs p, int JC) {
     extern __shared__ float smem[];
     const int a = blockIdx.x;
@@ -77,21 +78,13 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_refit_cem(RefitArgs p, int JC
     float* r = smem;
     int* eidx = (int*)(smem + p.Nst);
     const int kpad = (p.k + 3) & ~3;
-    float* tile = smem + p.Nst + kpad;
+    uint32_t* hist = (uint32_t*)(eidx + kpad);
+    unsigned long long* ekeys = (unsigned long long*)(hist + TOPK_HIST_WORDS);
+    float* tile = (float*)(ekeys + kpad);
 
     for (int n = tid; n < p.N; n += REFIT_THREADS) r[n] = p.rewards[(size_t)a * p.Nst + n];
     __syncthreads();
-    // rank of n = #{m : r[m] > r[n]  or  (r[m] == r[n] and m < n)}; all lanes read the same r[m] (broadcast)
-    for (int n = tid; n < p.N; n += REFIT_THREADS) {
-        const float rn = r[n];
-        int rank = 0;
-        for (int m = 0; m < p.N; ++m) {
-            const float rm = r[m];
-            rank += (rm > rn || (rm == rn && m < n)) ? 1 : 0;
-        }
-        if (rank < p.k) eidx[rank] = n;
-    }
-    __syncthreads();
+    block_topk_sorted(r, p.N, p.k, eidx, hist, ekeys, tid, REFIT_THREADS);
     if (p.elites)
         for (int e = tid; e < p.k; e += REFIT_THREADS) p.elites[a * p.k + e] = eidx[e];
 
