@@ -304,7 +304,6 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     const int threads = std::min(1024, ((N + 63) / 64) * 64);
     const int HUp = (HU + 3) & ~3, kp = (std::max(k, 1) + 3) & ~3;
     int tile_floats = 0;
-    if (cfg.optimizer == BBMPC_OPT_CEM && (size_t)HU * (kp | 1) * 4 <= 48 * 1024) tile_floats = (HU * (kp | 1) + 3) & ~3;
     fa.tile_floats = tile_floats;
     const size_t lds_base = (size_t)(Nst + 3 * HUp + kp + 64 + TOPK_HIST_WORDS + 2 * kp + tile_floats) * 4;
     const size_t lds_samples = (size_t)HU * Nst * 4;
@@ -320,6 +319,9 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
         if (step == 5) {
             fprintf(stderr, "[dbg] phase clocks (10ns units) rel. to start:");
             for (int i = 0; i <= 1 + iters * 4; ++i) fprintf(stderr, " %lld", fa.dbg[i] - fa.dbg[0]);
+            fprintf(stderr, "\n[dbg] iter0 per-wave rollout end:");
+            for (int i = 24; i < 32; ++i) fprintf(stderr, " %lld", fa.dbg[i] - fa.dbg[0]);
+            fprintf(stderr, "  gather-done %lld stats-done %lld", fa.dbg[32] - fa.dbg[0], fa.dbg[33] - fa.dbg[0]);
             fprintf(stderr, "\n[dbg] shader clocks: %lld over %lld wall ticks => %.1f MHz\n", fa.dbg[41] - fa.dbg[40], fa.dbg[1 + iters * 4] - fa.dbg[0], (double)(fa.dbg[41] - fa.dbg[40]) / ((double)(fa.dbg[1 + iters * 4] - fa.dbg[0]) * 0.01));
         }
     }

@@ -174,6 +174,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             }
             rew[n] = total;
         }
+        if (p.dbg && a == 0 && it == 0 && (tid & 63) == 0) dbg_lds[24 + (tid >> 6) % 8] = (long long)wall_clock64();
         BB_DBG(2 + it * 4);
         __syncthreads();
         BB_DBG(3 + it * 4);
@@ -192,51 +193,32 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             BB_DBG(4 + it * 4);
             if (p.t_elites)
                 for (int e = tid; e < p.k; e += nthr) p.t_elites[((size_t)it * p.A + a) * p.k + e] = eidx[e];
-            // elite statistics.  Gather pass: all lanes pull the k*HU elite elements into a dense
-            // [HU][tp] LDS tile, then lane j walks its row
-            // sequentially in elite order (the oracle's summation order) with contiguous LDS reads.
+            // elite statistics (cem.py:112-125): one wave per (h,u) row, lanes over the elites; mean and
+            // biased variance by wave butterfly sums (two-pass, as the reference computes it).
             const float kf = (float)p.k;
-            const int tp = kp | 1;                                   // odd row pitch: conflict-free row walks
-            const bool tile_ok = p.tile_floats >= p.HU * tp;
-            if (tile_ok) {
-                for (int j = tid >> 6; j < p.HU; j += nw)                 // one wave per row, lanes over elites
-                    for (int e = tid & 63; e < p.k; e += 64) tile[j * tp + e] = samp[(size_t)j * p.Nst + eidx[e]];
-                __syncthreads();
-            }
-            for (int j = tid; j < p.HU; j += nthr) {
+            for (int j = tid >> 6; j < p.HU; j += nw) {
                 const float* row = samp + (size_t)j * p.Nst;
-                float sum = 0.0f, vs = 0.0f, em;
-                if (tile_ok && p.k <= 64) {
-                    // whole elite row into registers with all LDS reads in flight at once, then the
-                    // strictly sequential (elite-order) sums run register-to-register
-                    float v[64];
-#pragma unroll
-                    for (int e = 0; e < 64; ++e) v[e] = (e < p.k) ? tile[j * tp + e] : 0.0f;
-#pragma unroll
-                    for (int e = 0; e < 64; ++e) sum = (e < p.k) ? sum + v[e] : sum;
-                    em = sum / kf;                                               // cem.py:112
-#pragma unroll
-                    for (int e = 0; e < 64; ++e) {
-                        const float d = v[e] - em;
-                        vs = (e < p.k) ? vs + d * d : vs;
-                    }
-                } else if (tile_ok) {
-                    for (int e = 0; e < p.k; ++e) sum = sum + tile[j * tp + e];
-                    em = sum / kf;
-                    for (int e = 0; e < p.k; ++e) { const float d = tile[j * tp + e] - em; vs = vs + d * d; }
-                } else {
-                    for (int e = 0; e < p.k; ++e) sum = sum + row[eidx[e]];      // sequential, elite order
-                    em = sum / kf;
-                    for (int e = 0; e < p.k; ++e) { const float d = row[eidx[e]] - em; vs = vs + d * d; }
+                float sum = 0.0f;
+                for (int e = tid & 63; e < p.k; e += 64) sum += row[eidx[e]];
+                sum = wave_sum(sum);
+                const float em = sum / kf;                                       // cem.py:112
+                float vs = 0.0f;
+                for (int e = tid & 63; e < p.k; e += 64) {
+                    const float d = row[eidx[e]] - em;
+                    vs += d * d;
                 }
-                const float ev = vs / kf;                                        // cem.py:113-119
-                const float one_m = 1.0f - p.alpha;
-                const float m = p.alpha * mean[j] + one_m * em;                  // cem.py:121-122
-                const float v = p.alpha * var[j] + one_m * ev;                   // cem.py:123-125
-                mean[j] = m;
-                var[j] = v;
-                sigma[j] = cem_sigma(m, v, lo, hi);
+                vs = wave_sum(vs);
+                if ((tid & 63) == 0) {
+                    const float ev = vs / kf;                                    // cem.py:113-119
+                    const float one_m = 1.0f - p.alpha;
+                    const float m = p.alpha * mean[j] + one_m * em;              // cem.py:121-122
+                    const float v = p.alpha * var[j] + one_m * ev;               // cem.py:123-125
+                    mean[j] = m;
+                    var[j] = v;
+                    sigma[j] = cem_sigma(m, v, lo, hi);
+                }
             }
+            if (it == 0) BB_DBG(33);
             __syncthreads();
             action0 = mean[0];                                                   // cem.py:135
         } else if (OPT == FOPT_PI2) {

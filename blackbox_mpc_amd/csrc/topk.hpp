@@ -1,17 +1,19 @@
 // Exact sorted top-k of a workgroup's LDS-resident rewards: tf.nn.top_k(sorted=True) semantics
 // (cem.py:97-99) -- larger first, ties -> lower index first.
 //
-// MSD radix select on order-preserving 32-bit keys: 4 passes x 8 bits, each pass one LDS histogram
-// (ds_add_u32) + one 256-bin scan by a single wave, i.e. O(N) work per pass instead of the O(N^2)
-// comparison count of ranking by counting.  That pins the k-th key exactly; the <= k winners are then
-// compacted and ranked among themselves (k^2 comparisons on 64-bit (key,index) words).
+// MSD radix select on order-preserving 32-bit keys: <= 4 passes of 8-bit digits taken below the bits
+// all keys share, each pass one LDS histogram (ds_add_u32) + one 256-bin scan by a single wave, i.e.
+// O(N) work per pass instead of the O(N^2) comparison count of ranking by counting.  That pins the
+// k-th key exactly; the <= k winners are then compacted and ranked among themselves (k^2 comparisons
+// on 64-bit (key,index) words).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace bbmpc {
 
-constexpr int TOPK_HIST_WORDS = 272;   // 256 bins + 16 control words
+constexpr int TOPK_HIST_WORDS = 272;   // 256 bins + 16 control words (256.. bucket, 257 wanted, 258 bucket size,
+                                       // 259 compaction cursor, 260/261 key min/max)
 
 // smaller key == better (larger reward); equal rewards <=> equal keys (-0 is folded onto +0 first)
 __device__ __forceinline__ uint32_t reward_key(float r) {
@@ -34,14 +36,41 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int k, int* eidx, uint32_t* hist,
                                                   unsigned long long* ekeys, int tid, int nthr) {
     const int lane = tid & 63;
-    uint32_t prefix = 0, remaining = (uint32_t)k;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
+    // Key range first: digits are taken from the highest bit where min and max differ.  Rewards of one
+    // population mostly share sign + exponent, so a fixed top-8-bit digit would send a whole wave's
+    // ds_add_u32 to one or two bins (serialised); digits below the common prefix spread over the bins.
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (int n = tid; n < N; n += nthr) {
+        const uint32_t key = reward_key(vals[n]);
+        kmin = min(kmin, key);
+        kmax = max(kmax, key);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+    }
+    if (tid == 0) { hist[260] = 0xFFFFFFFFu; hist[261] = 0u; }
+    __syncthreads();
+    if (lane == 0) { atomicMin(&hist[260], kmin); atomicMax(&hist[261], kmax); }
+    __syncthreads();
+    kmin = hist[260];
+    kmax = hist[261];
+    const uint32_t diff = kmin ^ kmax;
+    int top = diff ? 32 - __clz(diff) : 0;        // number of low bits that are not common to all keys
+    uint32_t T = (top >= 32) ? 0u : (kmin >> top) << top;   // common high bits
+    uint32_t remaining = (uint32_t)k;
+    if (top == 0 && tid == 0) hist[258] = (uint32_t)N;       // every key equal
+    while (top > 0) {
+        const int width = top >= 8 ? 8 : top;
+        const int shift = top - width;
+        const uint32_t dmask = (1u << width) - 1u;
         for (int i = tid; i < 256; i += nthr) hist[i] = 0;
         __syncthreads();
         for (int n = tid; n < N; n += nthr) {
             const uint32_t key = reward_key(vals[n]);
-            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            const bool in = (top >= 32) || ((key >> top) == (T >> top));
+            if (in) atomicAdd(&hist[(key >> shift) & dmask], 1u);
         }
         __syncthreads();
         if (tid < 64) {
@@ -60,14 +89,15 @@ __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int 
             }
         }
         __syncthreads();
-        prefix = (prefix << 8) | hist[256];
+        T |= hist[256] << shift;
         remaining = hist[257];
+        top = shift;
         __syncthreads();
     }
-    const uint32_t T = prefix;                   // key of the k-th best
-    const uint32_t eq_total = hist[258];         // population members with exactly that key
+    // T is now the key of the k-th best
     if (tid == 0) hist[259] = 0;
     __syncthreads();
+    const uint32_t eq_total = hist[258];         // population members with exactly that key
     for (int n = tid; n < N; n += nthr) {
         const uint32_t key = reward_key(vals[n]);
         bool take = key < T;
@@ -85,12 +115,29 @@ __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int 
         }
     }
     __syncthreads();
-    for (int e = tid; e < k; e += nthr) {
-        const unsigned long long mine = ekeys[e];
-        int rank = 0;
-        for (int o = 0; o < k; ++o) rank += (ekeys[o] < mine) ? 1 : 0;
-        eidx[rank] = (int)(uint32_t)(mine & 0xFFFFFFFFull);
+    // rank the k winners among themselves with the whole workgroup: thread (e, chunk) counts how many
+    // winners in its chunk precede winner e, partial counts meet in LDS (eidx doubles as the counter array).
+    for (int e = tid; e < k; e += nthr) eidx[e] = 0;
+    __syncthreads();
+    const int kp64 = (k + 63) & ~63;                 // e runs over full waves so chunk ids are wave-uniform
+    const int nchunk = max(1, nthr / kp64);
+    const int clen = (k + nchunk - 1) / nchunk;
+    for (int t = tid; t < kp64 * nchunk; t += nthr) {
+        const int e = t % kp64, c = t / kp64;
+        if (e < k) {
+            const unsigned long long mine = ekeys[e];
+            const int o0 = c * clen, o1 = min(k, o0 + clen);
+            int cnt = 0;
+#pragma unroll 4
+            for (int o = o0; o < o1; ++o) cnt += (ekeys[o] < mine) ? 1 : 0;
+            if (cnt) atomicAdd((uint32_t*)&eidx[e], (uint32_t)cnt);
+        }
     }
+    __syncthreads();
+    int myrank = -1, myidx = 0;
+    if (tid < k) { myrank = eidx[tid]; myidx = (int)(uint32_t)(ekeys[tid] & 0xFFFFFFFFull); }
+    __syncthreads();                                 // callers guarantee k <= nthr
+    if (myrank >= 0) eidx[myrank] = myidx;
     __syncthreads();
 }
 
