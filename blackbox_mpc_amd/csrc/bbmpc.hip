@@ -44,7 +44,6 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
     if (c.optimizer == BBMPC_OPT_CEM) REQUIRE(k <= 1024, BBMPC_E_UNSUPPORTED, "num_elite > 1024 not supported");
     REQUIRE(c.optimizer != BBMPC_OPT_PSO && c.optimizer != BBMPC_OPT_CMAES && c.optimizer != BBMPC_OPT_SPSA,
             BBMPC_E_UNSUPPORTED, "PSO / CMA-ES / SPSA kernels are not built yet");
-    REQUIRE(c.dynamics == BBMPC_DYN_PENDULUM, BBMPC_E_UNSUPPORTED, "learned-MLP dynamics kernels are not built yet");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -167,7 +166,102 @@ void Engine::get_profile(double* ms, int64_t* launches) {
 // ------------------------------------------------------------------------------------------------
 // launches
 // ------------------------------------------------------------------------------------------------
+void Engine::set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, const float* const* w, const float* const* b,
+                     int is_normalized, const float* const* stats) {
+    REQUIRE(cfg.dynamics == BBMPC_DYN_MLP, BBMPC_E_STATE, "handle was not created with BBMPC_DYN_MLP");
+    REQUIRE(n_layers >= 1 && n_layers <= MLP_MAX_LAYERS, BBMPC_E_UNSUPPORTED, "1..4 Dense layers are supported");
+    REQUIRE(dims && acts && w && b, BBMPC_E_INVALID, "null argument");
+    REQUIRE(dims[0] == S + U && dims[n_layers] == S, BBMPC_E_INVALID, "MLP must map dim_S+dim_U -> dim_S");
+    HIP_CHECK(hipStreamSynchronize(stream));
+    memset(&mlp, 0, sizeof(mlp));
+    mlp.n_layers = n_layers;
+    int hidden_tiles = 1;
+    for (int l = 0; l <= n_layers; ++l) {
+        REQUIRE(dims[l] >= 1, BBMPC_E_INVALID, "layer width must be >= 1");
+        mlp.dims[l] = dims[l];
+        mlp.tiles[l] = (dims[l] + 15) / 16;
+        if (l >= 1 && l < n_layers) hidden_tiles = std::max(hidden_tiles, mlp.tiles[l]);
+    }
+    REQUIRE(hidden_tiles <= 16 * MLP_TMAX, BBMPC_E_UNSUPPORTED, "hidden width > 512 not supported");
+    REQUIRE(mlp.tiles[0] <= 8 && mlp.tiles[n_layers] <= 4, BBMPC_E_UNSUPPORTED, "dim_S+dim_U <= 128 and dim_S <= 64 supported");
+    mlp_nw = std::min(16, std::max(hidden_tiles, std::max(1, (16 * (S + U) + 63) / 64 / 4)));
+    for (int l = 0; l < n_layers; ++l) {
+        REQUIRE(acts[l] >= BBMPC_ACT_NONE && acts[l] <= BBMPC_ACT_SIGMOID, BBMPC_E_INVALID, "unknown activation");
+        REQUIRE(w[l] && b[l], BBMPC_E_INVALID, "null weight/bias pointer");
+        mlp.act[l] = acts[l];
+        const int K = dims[l], M = dims[l + 1], IT = mlp.tiles[l], OT = mlp.tiles[l + 1];
+        std::vector<float> wp((size_t)OT * IT * 256, 0.0f), bp((size_t)OT * 256, 0.0f);
+        for (int ot = 0; ot < OT; ++ot) {
+            for (int it = 0; it < IT; ++it)
+                for (int s = 0; s < 4; ++s)
+                    for (int ln = 0; ln < 64; ++ln) {
+                        const int k = it * 16 + 4 * (ln >> 4) + s, o = ot * 16 + (ln & 15);
+                        if (k < K && o < M) wp[(((size_t)ot * IT + it) * 4 + s) * 64 + ln] = w[l][(size_t)k * M + o];
+                    }
+            for (int ln = 0; ln < 64; ++ln)
+                for (int r = 0; r < 4; ++r) {
+                    const int o = ot * 16 + (ln >> 4) * 4 + r;
+                    if (o < M) bp[((size_t)ot * 64 + ln) * 4 + r] = b[l][o];
+                }
+        }
+        upload(d_wpack[l], wp);
+        upload(d_bpack[l], bp);
+        mlp.wpack[l] = d_wpack[l].p;
+        mlp.bpack[l] = d_bpack[l].p;
+    }
+    mlp.normalized = is_normalized ? 1 : 0;
+    if (is_normalized) {
+        REQUIRE(stats, BBMPC_E_INVALID, "normalisation statistics are required when is_normalized != 0");
+        std::vector<float> st;
+        const int lens[6] = {S, S, U, U, S, S};
+        for (int i = 0; i < 6; ++i) {
+            REQUIRE(stats[i], BBMPC_E_INVALID, "null statistics vector");
+            st.insert(st.end(), stats[i], stats[i] + lens[i]);
+        }
+        upload(d_stats, st);
+        float* q = d_stats.p;
+        mlp.mean_s = q; q += S;
+        mlp.std_s = q; q += S;
+        mlp.mean_a = q; q += U;
+        mlp.std_a = q; q += U;
+        mlp.mean_t = q; q += S;
+        mlp.std_t = q;
+    }
+    mlp_ready = true;
+}
+
+void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_particle_state, float* final_state) {
+    REQUIRE(mlp_ready, BBMPC_E_STATE, "learned dynamics: call bbmpc_set_mlp before computing");
+    MlpRolloutArgs q;
+    memset(&q, 0, sizeof(q));
+    q.r = ra;
+    q.m = mlp;
+    q.mode = mode;
+    q.pen = pen ? 1 : 0;
+    q.per_particle_state = per_particle_state ? 1 : 0;
+    q.final_state = final_state;
+    q.nw = mlp_nw;
+    const MlpLds lay = mlp_lds_layout(mlp, ra.H, U, S, mlp_nw);
+    const size_t lds = (size_t)lay.total * sizeof(float);
+    REQUIRE(lds <= 159 * 1024, BBMPC_E_UNSUPPORTED, "planning horizon x action dim too large for the LDS action block");
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_rollout_mlp, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        configured = 159 * 1024;
+    }
+    dim3 grid((ra.n_pop + MLP_TP - 1) / MLP_TP, per_particle_state ? 1 : A), block(mlp_nw * 64);
+    prof_begin();
+    hipLaunchKernelGGL(k_rollout_mlp, grid, block, lds, stream, q);
+    HIP_CHECK(hipGetLastError());
+    prof_end();
+}
+
 void Engine::launch_rollout(int mode, bool pen, RolloutArgs& ra) {
+    if (cfg.dynamics == BBMPC_DYN_MLP) {
+        dominant_kernel = "k_rollout_mlp";
+        launch_rollout_mlp(mode, pen, ra, false, nullptr);
+        return;
+    }
     // few trajectories -> one wave per workgroup so every wave gets its own SIMD (latency);
     // many -> 256-thread workgroups.
     const int bs = ((long)ra.n_pop * A <= 16384) ? 64 : 256;
@@ -229,7 +323,23 @@ void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_ou
     fa.next_state = d_next_out;
     fa.key = key(step);
     fa.key.q_per_agent = (uint32_t)((U + 3) / 4);
-    hipLaunchKernelGGL(k_finalize_pendulum, dim3((A + 63) / 64), dim3(64), 0, stream, fa);
+    if (cfg.dynamics == BBMPC_DYN_PENDULUM) {
+        hipLaunchKernelGGL(k_finalize_pendulum, dim3((A + 63) / 64), dim3(64), 0, stream, fa);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    // learned dynamics: exploration noise, one model step on the [A] rows, pack the record
+    if (add_noise) {
+        hipLaunchKernelGGL(k_explore, dim3((A * U + 63) / 64), dim3(64), 0, stream, fa, d_action.p);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (!d_fin_next.p) {
+        d_fin_next.alloc((size_t)A * S);
+        d_fin_rew.alloc((size_t)((A + 63) / 64) * 64);
+    }
+    step_dev(d_state_in, d_action.p, U, A, d_fin_next.p, d_fin_rew.p);
+    hipLaunchKernelGGL(k_pack_record, dim3((A * rec + 63) / 64), dim3(64), 0, stream, A, U, S, d_action.p, d_fin_next.p,
+                       d_fin_rew.p, d_record_out, d_next_out);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -444,6 +554,37 @@ void Engine::evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop
 
 void Engine::step_dev(const float* d_states, const float* d_actions, int astride, int batch, float* d_next, float* d_rew) {
     REQUIRE(batch >= 1, BBMPC_E_INVALID, "batch must be >= 1");
+    if (cfg.dynamics == BBMPC_DYN_MLP) {
+        // one-step rollout of `batch` independent rows: per-particle start states, H = 1, actions as a
+        // [batch,1,1,U] sequence (gathered to a contiguous block first when they come strided)
+        const float* acts_c = d_actions;
+        if (astride != U) {
+            if (d_step_act.n < (size_t)batch * U) d_step_act.alloc((size_t)batch * U);
+            HIP_CHECK(hipMemcpy2DAsync(d_step_act.p, (size_t)U * 4, d_actions, (size_t)astride * 4, (size_t)U * 4, batch,
+                                       hipMemcpyDeviceToDevice, stream));
+            acts_c = d_step_act.p;
+        }
+        const int st_ = ((batch + 63) / 64) * 64;
+        float* rew = d_rew;
+        if (!rew) {
+            if (d_step_c.n < (size_t)st_) d_step_c.alloc((size_t)st_);
+            rew = d_step_c.p;
+        }
+        RolloutArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.n_pop = batch; ra.A = 1; ra.H = 1; ra.U = U; ra.S = S; ra.HU = U; ra.Nst = st_;
+        ra.fix_q1 = fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
+        ra.reward_kind = cfg.reward;
+        ra.state = d_states;
+        ra.seq = acts_c;
+        ra.lo = d_lo.p; ra.hi = d_hi.p;
+        ra.rewards = rew;
+        const bool prof = profiling;
+        profiling = false;
+        launch_rollout_mlp(SRC_REF, false, ra, true, d_next);
+        profiling = prof;
+        return;
+    }
     hipLaunchKernelGGL(k_step_pendulum, dim3((batch + 63) / 64), dim3(64), 0, stream, d_states, d_actions, astride, batch,
                        (int)fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER), d_next, d_rew);
     HIP_CHECK(hipGetLastError());
@@ -661,11 +802,11 @@ int bbmpc_set_stream(bbmpc_handle h, void* s) {
     API_END
 }
 
-int bbmpc_set_mlp(bbmpc_handle h, int32_t, const int32_t*, const int32_t*, const float* const*, const float* const*,
-                  int32_t, const float* const*) {
+int bbmpc_set_mlp(bbmpc_handle h, int32_t n_layers, const int32_t* dims, const int32_t* acts, const float* const* w,
+                  const float* const* b, int32_t is_normalized, const float* const* stats) {
     API_BEGIN
     CHECK_HANDLE(h);
-    throw HipError(BBMPC_E_UNSUPPORTED, "learned-MLP dynamics kernels are not built yet");
+    h->e->set_mlp(n_layers, dims, acts, w, b, is_normalized, stats);
     API_END
 }
 

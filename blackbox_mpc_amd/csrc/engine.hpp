@@ -13,6 +13,7 @@
 
 #include "../../include/bbmpc.h"
 #include "kernels_fused.hpp"
+#include "kernels_mlp.hpp"
 #include "kernels_refit.hpp"
 #include "kernels_rollout.hpp"
 
@@ -74,6 +75,12 @@ struct Engine {
     DevBuf<float> d_prev_mean, d_var0, d_mean, d_var, d_sigma;
     DevBuf<float> d_samples, d_rewards, d_penalty;
     DevBuf<int> d_elites;
+    // learned dynamics (bbmpc_set_mlp)
+    bool mlp_ready = false;
+    MlpDesc mlp;
+    int mlp_nw = 1;
+    DevBuf<float> d_wpack[MLP_MAX_LAYERS], d_bpack[MLP_MAX_LAYERS], d_stats;
+    DevBuf<float> d_fin_next, d_fin_rew, d_step_act;
     // evaluate() scratch (grown on demand)
     DevBuf<float> d_eval_seq, d_eval_rew, d_step_a, d_step_b, d_step_c, d_step_d;
     // injected noise (internal layout), keyed by BBMPC_NOISE_*
@@ -125,6 +132,9 @@ struct Engine {
 
     // helpers
     void launch_rollout(int mode, bool pen, RolloutArgs& ra);
+    void launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_particle_state, float* final_state);
+    void set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, const float* const* w, const float* const* b,
+                 int is_normalized, const float* const* stats);
     void prof_begin();
     void prof_end();
     void capture_trace(int it);

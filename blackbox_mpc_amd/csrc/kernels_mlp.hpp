@@ -1,0 +1,339 @@
+// Learned-dynamics rollout on the matrix cores (fp32-in / fp32-accumulate MFMA, exact fp32 products).
+//
+// Fuses, per candidate trajectory and planning step (reference files under blackbox_mpc/):
+//   SystemDynamicsHandler.process_input   dynamics_handlers/system_dynamics_handler.py:97-126  (z-score + concat)
+//   DeterministicMLP.__call__             dynamics_functions/deterministic_mlp.py:27-51        (Dense stack)
+//   SystemDynamicsHandler.process_output  :128-161 + utils/transforms.py:20-34                 (de-normalise + s + delta)
+//   reward_function                       tutorials/mujoco/cost_func.py:5-22 | utils/pendulum.py:10-35
+//   DeterministicTrajectoryEvaluator.__call__  trajectory_evaluators/deterministic.py:26-77    (H-step loop, NaN guard)
+//
+// Mapping.  A workgroup owns a tile of 16 particles (MFMA N dimension) of one agent for the whole
+// H-step recurrence.  The layer is evaluated transposed, out^T[M x 16] = W^T[M x K] . x^T[K x 16], with
+// v_mfma_f32_16x16x4_f32: A = a 16x4 slab of W^T, B = 4 input features x 16 particles, D = 16 output
+// features x 16 particles.  The D fragment of lane l holds features 4*(l>>4)+{0..3} of particle l&15
+// -- exactly the four B operands that lane needs for the next layer when the k index inside an MFMA is
+// taken as "feature 4*(l>>4)+s".  So a layer's output is written to LDS as one float4 per lane per
+// 16-feature tile and every wave of the next layer reads its B operands back with one ds_read_b128
+// per tile: no transposes, no shuffles.  Output tiles of a layer are dealt round-robin to the waves;
+// the last (narrow) layer is split along K instead (each wave multiplies the tiles it owns into all
+// output tiles) and the partial sums meet in LDS, where the epilogue (bias, de-normalise, residual,
+// next-step normalisation, reward) runs.  Weights are pre-packed in operand order
+// (wpack[layer][ot][it][s][lane]) so every A operand is one coalesced 256-byte load.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_refit.hpp"
+#include "kernels_rollout.hpp"
+#include "models.hpp"
+#include "rng.hpp"
+
+namespace bbmpc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MLP_MAX_LAYERS = 4;
+constexpr int MLP_TP = 16;          // particles per workgroup tile
+constexpr int MLP_TMAX = 2;         // output tiles per wave per layer
+
+constexpr int ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2, ACT_SIGMOID = 3;
+
+struct MlpDesc {
+    int n_layers;
+    int dims[MLP_MAX_LAYERS + 1];        // dims[0] = S+U ... dims[L] = S
+    int tiles[MLP_MAX_LAYERS + 1];       // ceil(dims/16)
+    int act[MLP_MAX_LAYERS];
+    const float* wpack[MLP_MAX_LAYERS];  // [OT][IT][4][64]
+    const float* bpack[MLP_MAX_LAYERS];  // [OT][64][4]
+    int normalized;
+    const float* mean_s;                 // [S]
+    const float* std_s;                  // [S]
+    const float* mean_a;                 // [U]
+    const float* std_a;                  // [U]
+    const float* mean_t;                 // [S]
+    const float* std_t;                  // [S]
+};
+
+struct MlpRolloutArgs {
+    RolloutArgs r;            // shared fields (n_pop, dims, sources, outputs, rng)
+    MlpDesc m;
+    int mode;                 // SRC_*
+    int pen;                  // clip + penalty (PI2 / PSO / CMA-ES / SPSA candidates)
+    int per_particle_state;   // state is [n_pop, S] (single-step API) instead of [A, S]
+    float* final_state;       // optional [A? n_pop][S] written after the last step (per_particle_state layout)
+    int nw;                   // waves per workgroup
+};
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    if (act == ACT_TANH) return tanhf(x);
+    if (act == ACT_RELU) return fmaxf(x, 0.0f);
+    if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-x));
+    return x;
+}
+
+// LDS carve, in floats (all pieces multiples of 4 floats = 16 B):
+//   xs   [IT0][64][4]        normalised layer-0 input tiles
+//   actA [ITmax][64][4]      ping
+//   actB [ITmax][64][4]      pong
+//   part [NW][OTlast][64][4] K-split partial sums of the last layer
+//   st   [2][16][Sp]         raw state, double buffered (Sp = S rounded up to 4)
+//   acts [H][16][Up]         raw (feasible) actions of the tile (Up = U rounded up to 4... kept U)
+//   misc [64]
+struct MlpLds {
+    int xs, actA, actB, part, st, acts, misc, total;
+};
+__host__ __device__ inline MlpLds mlp_lds_layout(const MlpDesc& m, int H, int U, int S, int nw) {
+    MlpLds l;
+    int itmax = 1;
+    for (int i = 1; i < m.n_layers; ++i) itmax = itmax > m.tiles[i] ? itmax : m.tiles[i];
+    const int Sp = (S + 3) & ~3;
+    int o = 0;
+    l.xs = o;   o += m.tiles[0] * 256;
+    l.actA = o; o += itmax * 256;
+    l.actB = o; o += itmax * 256;
+    l.part = o; o += nw * m.tiles[m.n_layers] * 256;
+    l.st = o;   o += 2 * MLP_TP * Sp;
+    l.acts = o; o += ((H * MLP_TP * U + 3) & ~3);
+    l.misc = o; o += 64;
+    l.total = o;
+    return l;
+}
+
+// One dense layer, output-tile split.  in: LDS tiles [IT][64] float4; out: LDS tiles [OT][64] float4.
+__device__ __forceinline__ void mlp_layer_out_split(const MlpDesc& m, int l, const float* in, float* out, int wave,
+                                                    int lane, int nw) {
+    const int IT = m.tiles[l], OT = m.tiles[l + 1];
+    const float* __restrict__ wp = m.wpack[l];
+    const float* __restrict__ bp = m.bpack[l];
+    for (int ot = wave; ot < OT; ot += nw) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(bp + ((size_t)ot * 64 + lane) * 4);   // bias enters as C
+        const float* w = wp + ((size_t)ot * IT) * 256 + lane;
+#pragma unroll 2
+        for (int it = 0; it < IT; ++it) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(in + ((size_t)it * 64 + lane) * 4);
+            const float a0 = w[(size_t)it * 256 + 0];
+            const float a1 = w[(size_t)it * 256 + 64];
+            const float a2 = w[(size_t)it * 256 + 128];
+            const float a3 = w[(size_t)it * 256 + 192];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b.w, acc, 0, 0, 0);
+        }
+        const int a = m.act[l];
+        acc.x = apply_act(acc.x, a);
+        acc.y = apply_act(acc.y, a);
+        acc.z = apply_act(acc.z, a);
+        acc.w = apply_act(acc.w, a);
+        *reinterpret_cast<f32x4*>(out + ((size_t)ot * 64 + lane) * 4) = acc;
+    }
+}
+
+// Last layer, K split: wave multiplies the input tiles it owns (it = wave, wave+nw, ...) into every
+// output tile and leaves partial sums in part[wave][ot][lane].
+__device__ __forceinline__ void mlp_layer_k_split(const MlpDesc& m, int l, const float* in, float* part, int wave,
+                                                  int lane, int nw) {
+    const int IT = m.tiles[l], OT = m.tiles[l + 1];
+    const float* __restrict__ wp = m.wpack[l];
+    for (int ot = 0; ot < OT; ++ot) {
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int it = wave; it < IT; it += nw) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(in + ((size_t)it * 64 + lane) * 4);
+            const float* w = wp + ((size_t)ot * IT + it) * 256 + lane;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[64], b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[128], b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[192], b.w, acc, 0, 0, 0);
+        }
+        *reinterpret_cast<f32x4*>(part + (((size_t)wave * OT + ot) * 64 + lane) * 4) = acc;
+    }
+}
+
+// address (in floats) of feature f of particle p inside a tile array [T][64][4]
+__device__ __forceinline__ int tile_addr(int f, int p) {
+    return (((f >> 4) * 64) + (((f & 15) >> 2) * 16 + p)) * 4 + (f & 3);
+}
+
+__global__ void k_rollout_mlp(MlpRolloutArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const RolloutArgs& p = q.r;
+    const MlpDesc& m = q.m;
+    const int a = blockIdx.y;
+    const int n0 = blockIdx.x * MLP_TP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = q.nw, nthr = nw * 64;
+    const int S = p.S, U = p.U, H = p.H, L = m.n_layers;
+    const int Sp = (S + 3) & ~3;
+    const MlpLds lay = mlp_lds_layout(m, H, U, S, nw);
+    float* xs = smem + lay.xs;
+    float* actbuf[2] = {smem + lay.actA, smem + lay.actB};
+    float* part = smem + lay.part;
+    float* st = smem + lay.st;
+    float* acts = smem + lay.acts;
+    const bool normd = m.normalized != 0;
+
+    // ---- prologue 1: the tile's whole action block [H][16][U] (candidate -> clip/penalty -> store)
+    float pen_part = 0.0f;                         // this thread's share of the penalty (thread = (p,u) pair)
+    for (int i = tid; i < MLP_TP * U; i += nthr) {
+        const int pp = i / U, u = i % U;           // consecutive threads: consecutive u of one particle
+        const int n = n0 + pp;
+        const bool live = n < p.n_pop;
+        U4 blk = {0, 0, 0, 0};
+        const float lo = p.lo[u], hi = p.hi[u];
+        for (int t = 0; t < H; ++t) {
+            const int j = t * U + u;
+            float x = 0.0f;
+            if (live) {
+                if (q.mode == SRC_REF) {
+                    x = p.seq[((size_t)n * p.A + a) * p.HU + j];
+                } else if (q.mode == SRC_BUF) {
+                    x = p.cand[((size_t)a * p.HU + j) * p.Nst + n];
+                } else {
+                    float xi;
+                    if (p.inj) xi = p.inj[((size_t)a * p.HU + j) * p.Nst + n];
+                    else {
+                        blk = rng_block(p.key, p.stream, p.iter, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)j);
+                        const uint32_t w = pick_word(blk, (uint32_t)j);
+                        xi = (q.mode == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
+                    }
+                    if (q.mode == SRC_UNIFORM) x = xi * (hi - lo) + lo;
+                    else x = xi * p.sigma[a * p.HU + j] + p.mean[a * p.HU + j];
+                }
+                if (q.pen) {
+                    const float xf = clipf(x, lo, hi);
+                    const float d = x - xf;
+                    pen_part = pen_part + d * d;
+                    x = xf;
+                }
+                if (p.samples) p.samples[((size_t)a * p.HU + j) * p.Nst + n] = x;
+            }
+            acts[(t * MLP_TP + pp) * U + u] = x;
+        }
+    }
+    // ---- prologue 2: initial raw state + zero the padded input tiles
+    for (int i = tid; i < m.tiles[0] * 256; i += nthr) xs[i] = 0.0f;
+    for (int i = tid; i < MLP_TP * S; i += nthr) {
+        const int pp = i / S, s = i % S;
+        const int n = n0 + pp;
+        float v = 0.0f;
+        if (q.per_particle_state) v = (n < p.n_pop) ? p.state[(size_t)n * S + s] : 0.0f;
+        else v = p.state[a * S + s];
+        st[pp * Sp + s] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < MLP_TP * (S + U); i += nthr) {          // normalised layer-0 input for t = 0
+        const int f = i / MLP_TP, pp = i % MLP_TP;
+        float v;
+        if (f < S) {
+            v = st[pp * Sp + f];
+            if (normd) v = (v - m.mean_s[f]) / (m.std_s[f] + 1e-7f);
+        } else {
+            v = acts[(0 * MLP_TP + pp) * U + (f - S)];
+            if (normd) v = (v - m.mean_a[f - S]) / (m.std_a[f - S] + 1e-7f);
+        }
+        xs[tile_addr(f, pp)] = v;
+    }
+    __syncthreads();
+
+    float total = 0.0f;                       // lanes 0..15 of wave 0: reward accumulator of particle `lane`
+    const int OTl = m.tiles[L];
+    for (int t = 0; t < H; ++t) {
+        float* cur = st + (t & 1) * MLP_TP * Sp;
+        float* nxt = st + ((t + 1) & 1) * MLP_TP * Sp;
+        // ---- dense layers
+        const float* in = xs;
+        for (int l = 0; l < L - 1; ++l) {
+            float* out = actbuf[l & 1];
+            mlp_layer_out_split(m, l, in, out, wave, lane, nw);
+            __syncthreads();
+            in = out;
+        }
+        mlp_layer_k_split(m, L - 1, in, part, wave, lane, nw);
+        __syncthreads();
+        // ---- epilogue: reduce partials, bias, last activation, de-normalise, residual; stage step t+1's input
+        const int nwp = min(nw, m.tiles[L - 1]);          // waves that actually produced partials
+        for (int i = tid; i < MLP_TP * (S + U); i += nthr) {
+            const int f = i / MLP_TP, pp = i % MLP_TP;
+            float v;
+            if (f < S) {
+                const int ot = f >> 4, ln = ((f & 15) >> 2) * 16 + pp, rg = f & 3;
+                float acc = m.bpack[L - 1][((size_t)ot * 64 + ln) * 4 + rg];
+                for (int w = 0; w < nwp; ++w) acc = acc + part[(((size_t)w * OTl + ot) * 64 + ln) * 4 + rg];
+                acc = apply_act(acc, m.act[L - 1]);
+                float dev = acc;
+                if (normd) dev = m.mean_t[f] + acc * (m.std_t[f] + 1e-7f);   // system_dynamics_handler.py:152-155
+                const float ns = dev + cur[pp * Sp + f];                        // transforms.py:34
+                nxt[pp * Sp + f] = ns;
+                v = ns;
+                if (normd) v = (v - m.mean_s[f]) / (m.std_s[f] + 1e-7f);
+            } else {
+                const int tn = (t + 1 < H) ? t + 1 : t;
+                v = acts[(tn * MLP_TP + pp) * U + (f - S)];
+                if (normd) v = (v - m.mean_a[f - S]) / (m.std_a[f - S] + 1e-7f);
+            }
+            xs[tile_addr(f, pp)] = v;
+        }
+        __syncthreads();
+        // ---- reward of step t (wave 0, one lane per particle) overlaps the next step's first layer
+        if (tid < MLP_TP) {
+            const float r = reward_generic(p.reward_kind, p.fix_q1 != 0, cur + tid * Sp, acts + (t * MLP_TP + tid) * U,
+                                           nxt + tid * Sp, S, U);
+            total = total + r;
+        }
+    }
+    // ---- penalties: sum the (p,u) shares in u order
+    __syncthreads();
+    float* pens = part;                                   // free now
+    if (q.pen)
+        for (int i = tid; i < MLP_TP * U; i += nthr) pens[i] = pen_part;
+    __syncthreads();
+    if (tid < MLP_TP) {
+        const int n = n0 + tid;
+        if (n < p.n_pop) {
+            if (total != total) total = -1.0e6f;                        // deterministic.py:75-77
+            if (q.pen) {
+                float pen = 0.0f;
+                for (int u = 0; u < U; ++u) pen = pen + pens[tid * U + u];
+                const float nr = sqrtf(pen);
+                pen = nr * nr;
+                total = total - pen;
+                if (p.penalty_out) p.penalty_out[(size_t)a * p.Nst + n] = pen;
+            }
+            p.rewards[(size_t)a * p.Nst + n] = total;
+        }
+    }
+    if (q.final_state) {
+        const float* fin = st + (H & 1) * MLP_TP * Sp;
+        for (int i = tid; i < MLP_TP * S; i += nthr) {
+            const int pp = i / S, s = i % S;
+            const int n = n0 + pp;
+            if (n < p.n_pop) q.final_state[((size_t)a * p.n_pop + n) * S + s] = fin[pp * Sp + s];
+        }
+    }
+}
+
+// ---- small helpers for the OptimizerBase.__call__ tail on the learned-dynamics path ----------------
+
+// action[a][u] += exploration noise, clip (optimizer_base.py:82-90)
+__global__ void k_explore(FinalArgs p, float* action) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.A * p.U) return;
+    const int a = i / p.U, u = i % p.U;
+    action[i] = exploration_action(p, a, u, action[i]);
+}
+
+// record[a] = (action | next_state | reward)
+__global__ void k_pack_record(int A, int U, int S, const float* action, const float* next_state, const float* reward,
+                              float* record, float* next_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rec = U + S + 1;
+    if (i >= A * rec) return;
+    const int a = i / rec, c = i % rec;
+    float v;
+    if (c < U) v = action[a * U + c];
+    else if (c < U + S) {
+        v = next_state[a * S + (c - U)];
+        if (next_out) next_out[a * S + (c - U)] = v;
+    } else v = reward[a];
+    record[i] = v;
+}
+
+}  // namespace bbmpc

@@ -1,0 +1,225 @@
+"""GPU parity tests for the learned-dynamics (MFMA) path, through the C ABI.
+
+Tolerances (fp32): the oracle's Dense layers accumulate in float64 and round once; the kernel accumulates in
+fp32 on the matrix cores (exact fp32 products, k-ordered), and tanh is the device libm's.  Stated bounds:
+  single model step  : rtol 2e-5 + atol 2e-5 on the next state
+  H-step rewards     : rtol 1e-3 + atol 1e-3 * H   ('rtol 1e-3 (MLP fp32-MFMA)')
+  refit mean/var     : atol 1e-4 given the same elite set (elite near-ties handled as in the pendulum tests)
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+ACT = {"tanh": 1, "relu": 2, "sigmoid": 3, None: 0}
+
+
+@pytest.fixture(scope="module")
+def L():
+    from blackbox_mpc_amd import _build
+    _build.build()
+    from blackbox_mpc_amd import _lib
+    assert _lib.device_count() >= 1
+    return _lib
+
+
+def _stats(S, U, seed):
+    rng = np.random.default_rng(seed)
+    return [rng.normal(0, 0.2, S).astype(F), rng.uniform(0.5, 1.5, S).astype(F),
+            rng.normal(0, 0.1, U).astype(F), rng.uniform(0.5, 1.5, U).astype(F),
+            rng.normal(0, 0.01, S).astype(F), rng.uniform(0.05, 0.15, S).astype(F)]
+
+
+def _problem(L, dims, acts, S, U, reward, normalized=True, seed=42, A=1, H=1, opt=None, N=0, iters=0, k=0, **kw):
+    from blackbox_mpc_amd.engine import Engine
+    ws, bs = O.make_mlp_params(dims, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    bs = [rng.normal(0, 0.05, b.shape).astype(F) for b in bs]
+    stats = _stats(S, U, seed + 2) if normalized else None
+    lo, hi = [-1.0] * U, [1.0] * U
+    rk = L.REW_CHEETAH if reward == "cheetah" else L.REW_PENDULUM
+    eng = Engine(opt if opt is not None else L.OPT_NONE, L.DYN_MLP, rk, lo, hi, dim_s=S, num_agents=A,
+                 planning_horizon=H, population_size=N, max_iterations=iters, num_elite=k, **kw)
+    eng.set_mlp(ws, bs, [ACT[a] for a in acts], stats)
+    handler = O.Handler(O.MLP(ws, bs, acts), False, normalized, stats)
+    ev = O.Evaluator(reward, handler)
+    return eng, ev, lo, hi
+
+
+CHEETAH = ([26, 200, 200, 20], ["tanh", "tanh", None], 20, 6, "cheetah")
+PEND_MLP = ([4, 32, 32, 32, 3], ["tanh", "tanh", "tanh", None], 3, 1, "pendulum")
+
+
+@pytest.mark.parametrize("spec,normalized", [(CHEETAH, True), (CHEETAH, False), (PEND_MLP, True),
+                                             (([26, 500, 500, 500, 20], ["tanh", "relu", "sigmoid", None], 20, 6, "cheetah"), True),
+                                             (([26, 20], [None], 20, 6, "cheetah"), True),
+                                             (([23, 40, 18], ["tanh", None], 18, 5, "cheetah"), True)])
+def test_single_step_matches_oracle(L, spec, normalized):
+    dims, acts, S, U, reward = spec
+    eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, normalized)
+    rng = np.random.default_rng(0)
+    B = 333
+    s = rng.normal(0, 0.5, (B, S)).astype(F)
+    if reward == "pendulum":
+        th = rng.uniform(-np.pi, np.pi, B)
+        s = np.stack([np.cos(th), np.sin(th), rng.uniform(-4, 4, B)], 1).astype(F)
+    a = rng.uniform(-1, 1, (B, U)).astype(F)
+    nxt = eng.predict_next_state(s, a)
+    nxt_o = ev.predict_next_state(s, a)
+    np.testing.assert_allclose(nxt, nxt_o, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(eng.evaluate_next_reward(s, nxt_o, a), ev.evaluate_next_reward(s, nxt_o, a),
+                               rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("spec,N,A,H", [(CHEETAH, 100, 1, 30), (CHEETAH, 37, 3, 50), (PEND_MLP, 200, 2, 20),
+                                        (CHEETAH, 1, 1, 1), (CHEETAH, 16, 1, 2)])
+def test_evaluator_matches_oracle(L, spec, N, A, H):
+    dims, acts, S, U, reward = spec
+    eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, True, A=A, H=H)
+    rng = np.random.default_rng(N + H)
+    states = O.cheetah_start_states(A, S) if reward == "cheetah" else O.pendulum_start_states(A)
+    seq = rng.uniform(-1, 1, (N, A, H, U)).astype(F)
+    got = eng.evaluate(states, seq)
+    want = ev(states, seq)
+    assert np.all(np.isfinite(want))
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3 * H)
+
+
+def test_evaluator_properties_at_config5_size(L):
+    # BASELINE config-5 shape (per GPU): N=2000, A=4, H=50, S=20, U=6.  Size-independent properties:
+    # agents are independent rows, particle order is irrelevant, a prefix of the population evaluates
+    # to the same values (bit-exact), and a 48-particle sample matches the oracle.
+    dims, acts, S, U, reward = CHEETAH
+    N, A, H = 2000, 4, 50
+    eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, True, A=A, H=H)
+    eng1, _, _, _ = _problem(L, dims, acts, S, U, reward, True, A=1, H=H)
+    rng = np.random.default_rng(5)
+    states = O.cheetah_start_states(A, S)
+    seq = rng.uniform(-1, 1, (N, A, H, U)).astype(F)
+    full = eng.evaluate(states, seq)
+    assert np.all(np.isfinite(full))
+    np.testing.assert_array_equal(full[:, 2], eng1.evaluate(states[2:3], seq[:, 2:3])[:, 0])
+    perm = rng.permutation(N)
+    np.testing.assert_array_equal(eng.evaluate(states, seq[perm]), full[perm])
+    np.testing.assert_array_equal(eng.evaluate(states, seq[:100]), full[:100])
+    sub = rng.choice(N, 48, replace=False)
+    np.testing.assert_allclose(full[sub], ev(states, seq[sub]), rtol=1e-3, atol=1e-3 * H)
+
+
+def test_nan_state_gives_minus_1e6(L):
+    dims, acts, S, U, reward = CHEETAH
+    eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, True, A=2, H=5)
+    states = O.cheetah_start_states(2, S)
+    states[0, 3] = np.nan
+    r = eng.evaluate(states, np.zeros((20, 2, 5, U), F))
+    assert np.all(r[:, 0] == F(-1e6)) and np.all(np.isfinite(r[:, 1])) and np.all(r[:, 1] > -1e5)
+
+
+def test_compute_before_set_mlp_is_an_error(L):
+    from blackbox_mpc_amd.engine import Engine
+    eng = Engine(L.OPT_NONE, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * 6, [1.0] * 6, dim_s=20, num_agents=1, planning_horizon=3)
+    with pytest.raises(L.BBMPCError) as ei:
+        eng.evaluate(np.zeros((1, 20), F), np.zeros((4, 1, 3, 6), F))
+    assert ei.value.code == L.E_STATE
+    with pytest.raises(L.BBMPCError):      # wrong input width
+        eng.set_mlp([np.zeros((25, 20), F)], [np.zeros(20, F)], [0], None)
+
+
+def _lockstep_select(L, eng, A, k, iters, rtol, atol):
+    hip_el = [eng.get_trace(it, L.TRACE_ELITES) for it in range(iters)]
+    hip_r = [eng.get_trace(it, L.TRACE_REWARDS) for it in range(iters)]
+
+    def select(it, r_o, own):
+        np.testing.assert_allclose(hip_r[it], r_o, rtol=rtol, atol=atol)
+        for a in range(A):
+            he = hip_el[it][a]
+            if set(own[a]) != set(he):
+                kth = np.sort(r_o[:, a])[::-1][k - 1]
+                for n in set(own[a]) ^ set(he):
+                    assert abs(r_o[n, a] - kth) <= 2 * (atol + rtol * abs(kth)), "elite sets differ beyond the tie tolerance"
+            np.testing.assert_array_equal(he, O.topk_desc(hip_r[it][:, a], k))
+        return hip_el[it]
+    return select
+
+
+@pytest.mark.parametrize("N,A,H,iters,k", [(1000, 1, 30, 5, 50), (96, 2, 8, 2, 12)])
+def test_cem_with_learned_dynamics_lockstep(L, N, A, H, iters, k):
+    dims, acts, S, U, reward = CHEETAH
+    eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, True, A=A, H=H, opt=L.OPT_CEM, N=N, iters=iters, k=k)
+    eng.set_trace(True)
+    rng = np.random.default_rng(N)
+    noise = {"trunc": [O.truncated_normal_noise(rng, (N, A, H, U)) for _ in range(iters)]}
+    eng.inject_noise(L.NOISE_TRUNC_NORMAL, np.stack(noise["trunc"]))
+    states = O.cheetah_start_states(A, S)
+    act, nxt, rew = eng.optimize(states)
+    cem = O.CEM(ev, lo, hi, horizon=H, max_iterations=iters, population=N, num_elite=k, num_agents=A)
+    cem._optimize(states, noise, forced_elites=_lockstep_select(L, eng, A, k, iters, 1e-3, 1e-3 * H))
+    for it in range(iters):
+        np.testing.assert_allclose(eng.get_trace(it, L.TRACE_SAMPLES), cem.trace[it]["samples"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(eng.get_trace(it, L.TRACE_MEAN), cem.trace[it]["mean"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(eng.get_trace(it, L.TRACE_VAR), cem.trace[it]["var"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(act, cem.trace[-1]["mean"][:, 0], rtol=0, atol=1e-4)
+    nxt_o = ev.predict_next_state(states, act)
+    np.testing.assert_allclose(nxt, nxt_o, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(rew, ev.evaluate_next_reward(states, nxt_o, act), rtol=1e-4, atol=1e-3)
+
+
+def test_pi2_and_random_search_with_learned_dynamics(L):
+    dims, acts, S, U, reward = CHEETAH
+    N, A, H, iters = 256, 2, 10, 2
+    states = O.cheetah_start_states(A, S)
+    rng = np.random.default_rng(3)
+    eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, True, A=A, H=H, opt=L.OPT_PI2, N=N, iters=iters, lamda=5.0)
+    eng.set_trace(True)
+    noise = {"trunc": [O.truncated_normal_noise(rng, (N, A, H, U)) for _ in range(iters)]}
+    eng.inject_noise(L.NOISE_TRUNC_NORMAL, np.stack(noise["trunc"]))
+    act, _, _ = eng.optimize(states)
+    pi2 = O.PI2(ev, lo, hi, horizon=H, max_iterations=iters, population=N, num_agents=A, lamda=5.0)
+    act_o, _, _ = pi2.call(states, noise)
+    for it in range(iters):
+        np.testing.assert_allclose(eng.get_trace(it, L.TRACE_REWARDS), pi2.trace[it]["rewards"], rtol=1e-3, atol=1e-2)
+        np.testing.assert_allclose(eng.get_trace(it, L.TRACE_MEAN), pi2.trace[it]["mean"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(act, act_o, rtol=0, atol=2e-3)
+
+    eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, True, A=A, H=H, opt=L.OPT_RANDOM_SEARCH, N=N)
+    eng.set_trace(True)
+    u01 = rng.random((N, A, H, U)).astype(F)
+    eng.inject_noise(L.NOISE_UNIFORM, u01)
+    act, _, _ = eng.optimize(states)
+    rs = O.RandomSearch(ev, lo, hi, horizon=H, population=N, num_agents=A)
+    act_o, _, _ = rs.call(states, {"uniform": u01})
+    r_hip = eng.get_trace(0, L.TRACE_REWARDS)
+    np.testing.assert_allclose(r_hip, rs.trace[0]["rewards"], rtol=1e-3, atol=1e-2)
+    best = eng.get_trace(0, L.TRACE_ELITES)
+    np.testing.assert_array_equal(best, np.argmax(r_hip, axis=0))
+    if np.array_equal(best, rs.trace[0]["best"]):
+        np.testing.assert_array_equal(act, act_o)
+
+
+def test_host_api_with_learned_dynamics(L, tmp_path):
+    from blackbox_mpc_amd.dynamics_functions import DeterministicMLP
+    from blackbox_mpc_amd.dynamics_handlers import SystemDynamicsHandler
+    from blackbox_mpc_amd.policies import MPCPolicy
+    from blackbox_mpc_amd.spaces import Box
+    from blackbox_mpc_amd.utils.cheetah import reward_function
+    S, U = 20, 6
+    act_space, obs_space = Box([-1.0] * U, [1.0] * U), Box([-10.0] * S, [10.0] * S)
+    mlp = DeterministicMLP(layers=[S + U, 200, 200, S], activation_functions=[np.tanh, np.tanh, None], seed=1)
+    ws, bs = O.make_mlp_params([S + U, 200, 200, S])
+    mlp.set_weights(ws, bs)
+    h = SystemDynamicsHandler(act_space, obs_space, dynamics_function=mlp, true_model=False, is_normalized=True)
+    stats = _stats(S, U, 9)
+    h.set_normalization_stats(*stats)
+    h.save(str(tmp_path))
+    h2 = SystemDynamicsHandler(act_space, obs_space, true_model=False, is_normalized=True, saved_model_dir=str(tmp_path))
+    pol = MPCPolicy(reward_function=reward_function, env_action_space=act_space, env_observation_space=obs_space,
+                    dynamics_handler=h2, optimizer_name="CEM", num_agents=2, planning_horizon=10, population_size=128,
+                    max_iterations=2, num_elite=16)
+    obs = O.cheetah_start_states(2, S)
+    a, n, r = pol.act(obs, 0)
+    assert a.shape == (2, U) and n.shape == (2, S) and r.shape == (2,)
+    ev = O.Evaluator("cheetah", O.Handler(O.MLP(ws, bs, ["tanh", "tanh", None]), False, True, stats))
+    np.testing.assert_allclose(n, ev.predict_next_state(obs, a), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(pol._trajectory_evaluator.predict_next_state(obs, a), n, rtol=1e-6, atol=1e-6)
