@@ -21,13 +21,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # name: (optimizer, dynamics, N, A_per_gpu, H, iters, k)
-    "cfg1": dict(opt="RandomSearch", N=200, A=1, H=20, iters=1, k=0),
-    "cfg2": dict(opt="CEM", N=500, A=1, H=30, iters=5, k=50),
-    "cfg3": dict(opt="PI2", N=1000, A=8, H=30, iters=5, k=0),      # 64 agents over 8 GPUs = 8 per GPU
-    "cfg3full": dict(opt="PI2", N=1000, A=64, H=30, iters=5, k=0),
+    # BASELINE.json configs; A = agents per GPU
+    "cfg1": dict(env="pendulum", opt="RandomSearch", N=200, A=1, H=20, iters=1, k=0),
+    "cfg2": dict(env="pendulum", opt="CEM", N=500, A=1, H=30, iters=5, k=50),
+    "cfg3": dict(env="pendulum", opt="PI2", N=1000, A=8, H=30, iters=5, k=0),      # 64 agents over 8 GPUs
+    "cfg3full": dict(env="pendulum", opt="PI2", N=1000, A=64, H=30, iters=5, k=0),  # all 64 agents on one GPU
+    "cfg4": dict(env="cheetah", opt="CEM", N=1000, A=1, H=30, iters=5, k=50),
+    "cfg5cem": dict(env="cheetah", opt="CEM", N=2000, A=4, H=50, iters=5, k=50),     # config-5 shape per GPU, CEM
+    "cfg5full": dict(env="cheetah", opt="CEM", N=2000, A=32, H=50, iters=5, k=50),   # all 32 agents on one GPU
 }
 HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TFLOPS = 157.3
+MLP_DIMS = [26, 200, 200, 20]
 
 
 def main():
@@ -60,15 +65,26 @@ def main():
     c = CONFIGS[args.config]
     opt = {"RandomSearch": L.OPT_RANDOM_SEARCH, "CEM": L.OPT_CEM, "PI2": L.OPT_PI2}[c["opt"]]
     N, A, H, iters, k = c["N"], c["A"], c["H"], c["iters"], c["k"]
-    U, S = 1, 3
+    mlp = c["env"] == "cheetah"
+    if mlp:
+        U, S = 6, 20
+        eng = Engine(opt, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=A, planning_horizon=H,
+                     population_size=N, max_iterations=iters, num_elite=k, seed=0, agent_offset=rank * A,
+                     num_agents_global=world * A, device=local)
+        ws, bs = O.make_mlp_params(MLP_DIMS, seed=42)          # Glorot-uniform / zero bias, last layer x0.1
+        eng.set_mlp(ws, bs, [L.ACT_TANH, L.ACT_TANH, L.ACT_NONE], cheetah_stats(S, U))
+        start = O.cheetah_start_states(A, S, agent_offset=rank * A)
+    else:
+        U, S = 1, 3
+        eng = Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=S, num_agents=A, planning_horizon=H,
+                     population_size=N, max_iterations=iters, num_elite=k, seed=0, agent_offset=rank * A,
+                     num_agents_global=world * A, device=local)
+        start = O.pendulum_start_states(A, agent_offset=rank * A)
     rec = U + S + 1
-    eng = Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=S, num_agents=A, planning_horizon=H,
-                 population_size=N, max_iterations=iters, num_elite=k, seed=0, agent_offset=rank * A,
-                 num_agents_global=world * A, device=local)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
 
-    state = torch.from_numpy(O.pendulum_start_states(A, agent_offset=rank * A)).to(dev)
+    state = torch.from_numpy(start).to(dev)
     nxt = torch.empty_like(state)
     record = torch.zeros((A, rec), device=dev, dtype=torch.float32)
     gathered = torch.zeros((world * A, rec), device=dev, dtype=torch.float32) if world > 1 else None
@@ -119,11 +135,29 @@ def main():
         traj_per_step = N * iters * total_agents
         # algorithmic bytes per trajectory: 4*(H*U + 1) + 4*S/N   (SURVEY 8d / BASELINE.md)
         bytes_per_traj = 4.0 * (H * U + 1) + 4.0 * S / N
-        launch_traj = N * A                                  # one rollout launch = all particles of my agents
         avg_ms = roll_ms / max(roll_n, 1)
-        achieved = launch_traj * bytes_per_traj / (avg_ms * 1e-3) / 1e9 if roll_n else None
+        fused = kname.startswith("k_fused")
+        # trajectories one launch of the dominant kernel processes: the persistent kernel runs every
+        # iteration of every local agent in one launch, the per-iteration kernels one iteration
+        launch_traj = N * A * (iters if fused else 1)
+        if mlp:
+            flops_per_traj = H * 2.0 * sum(MLP_DIMS[i] * MLP_DIMS[i + 1] for i in range(len(MLP_DIMS) - 1))
+            achieved = launch_traj * flops_per_traj / (avg_ms * 1e-3) / 1e12 if roll_n else None
+            roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None, "traffic": None,
+                    "algorithmic_flops_per_launch": launch_traj * flops_per_traj,
+                    "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32); peak = dense fp32 matrix rate"}
+        else:
+            achieved = launch_traj * bytes_per_traj / (avg_ms * 1e-3) / 1e9 if roll_n else None
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                    "algorithmic_bytes_per_launch": launch_traj * bytes_per_traj,
+                    "note": "the fused kernel keeps the H-step recurrence in registers/LDS: the path is VALU-issue "
+                            "bound, the HBM fraction is nominal (DESIGN.md)"}
+        roof.update({"kernel": kname, "avg_launch_us": avg_ms * 1e3, "launches": roll_n})
         out = {
-            "metric": "MPC control-steps/sec (agent-control-steps; Pendulum true model, %s N=%d H=%d)" % (c["opt"], N, H),
+            "metric": "MPC control-steps/sec (agent-control-steps; %s, %s N=%d H=%d)"
+                      % ("HalfCheetah learned MLP 26-200-200-20" if mlp else "Pendulum true model", c["opt"], N, H),
             "value": steps_per_s,
             "unit": "control-steps/s",
             "n_gpus": world,
@@ -135,20 +169,16 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE %s: Pendulum-v0 true dynamics, %s, num_agents=%d/GPU, N=%d, H=%d, "
-                                   "%d iters%s, closed loop on device" % (args.config, c["opt"], A, N, H, iters,
-                                                                          (", k=%d" % k) if k else ""),
+            "config": {"workload": "BASELINE %s: %s, %s, num_agents=%d/GPU, N=%d, H=%d, %d iters%s, closed loop on "
+                                   "device" % (args.config, "HalfCheetah(mod) S=20 U=6 learned MLP dynamics" if mlp
+                                               else "Pendulum-v0 true dynamics", c["opt"], A, N, H, iters,
+                                               (", k=%d" % k) if k else ""),
                        "parallelism": "agents sharded %d/GPU, 1 RCCL all-gather of [A,%d] per control step" % (A, rec)
                        if world > 1 else "single GPU"},
             "candidate_trajectories_per_sec": steps_per_s * N * iters,
             "dyn_steps_per_sec": steps_per_s * N * iters * H,
             "ms_per_step_uninstrumented": (t3 - t2) / args.steps * 1e3,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                         "kernel": kname, "avg_launch_us": avg_ms * 1e3, "launches": roll_n,
-                         "algorithmic_bytes_per_launch": launch_traj * bytes_per_traj,
-                         "note": "fused rollout keeps the H-step recurrence in registers; the path is "
-                                 "VALU/latency bound, HBM fraction is nominal (see DESIGN.md)"},
+            "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(O, c, H, N, A, iters, k)
@@ -157,21 +187,37 @@ def main():
         dist.destroy_process_group()
 
 
+def cheetah_stats(S, U):
+    """mu = 0, sigma = 1 for states/actions, targets mu = 0, sigma = 0.1"""
+    z, o = np.zeros, np.ones
+    return [z(S, np.float32), o(S, np.float32), z(U, np.float32), o(U, np.float32), z(S, np.float32),
+            np.full(S, 0.1, np.float32)]
+
+
 def cpu_baseline(O, c, H, N, A, iters, k, budget_s=15.0):
     """The NumPy oracle (op-for-op port of the reference's TF graph) timed on the host, 1 thread of
     Python driving NumPy ops -- a bounded sample of the same workload."""
-    ev = O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))
     rng = np.random.default_rng(0)
-    if c["opt"] == "CEM":
-        opt = O.CEM(ev, [-2.0], [2.0], horizon=H, max_iterations=iters, population=N, num_elite=k, num_agents=A)
-        mk = lambda: {"trunc": [O.truncated_normal_noise(rng, (N, A, H, 1)) for _ in range(iters)]}
-    elif c["opt"] == "PI2":
-        opt = O.PI2(ev, [-2.0], [2.0], horizon=H, max_iterations=iters, population=N, num_agents=A)
-        mk = lambda: {"trunc": [O.truncated_normal_noise(rng, (N, A, H, 1)) for _ in range(iters)]}
+    if c["env"] == "cheetah":
+        S, U = 20, 6
+        ws, bs = O.make_mlp_params(MLP_DIMS, seed=42)
+        ev = O.Evaluator("cheetah", O.Handler(O.MLP(ws, bs, ["tanh", "tanh", None]), False, True, cheetah_stats(S, U)))
+        lo, hi = [-1.0] * U, [1.0] * U
+        state = O.cheetah_start_states(A, S)
     else:
-        opt = O.RandomSearch(ev, [-2.0], [2.0], horizon=H, population=N, num_agents=A)
-        mk = lambda: {"uniform": rng.random((N, A, H, 1)).astype(np.float32)}
-    state = O.pendulum_start_states(A)
+        U = 1
+        ev = O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))
+        lo, hi = [-2.0], [2.0]
+        state = O.pendulum_start_states(A)
+    if c["opt"] == "CEM":
+        opt = O.CEM(ev, lo, hi, horizon=H, max_iterations=iters, population=N, num_elite=k, num_agents=A)
+        mk = lambda: {"trunc": [O.truncated_normal_noise(rng, (N, A, H, U)) for _ in range(iters)]}
+    elif c["opt"] == "PI2":
+        opt = O.PI2(ev, lo, hi, horizon=H, max_iterations=iters, population=N, num_agents=A)
+        mk = lambda: {"trunc": [O.truncated_normal_noise(rng, (N, A, H, U)) for _ in range(iters)]}
+    else:
+        opt = O.RandomSearch(ev, lo, hi, horizon=H, population=N, num_agents=A)
+        mk = lambda: {"uniform": rng.random((N, A, H, U)).astype(np.float32)}
     n, t_used = 0, 0.0
     while t_used < budget_s and n < 200:
         noise = mk()

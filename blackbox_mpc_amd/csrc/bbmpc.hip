@@ -544,6 +544,7 @@ void Engine::evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop
     ra.reward_kind = cfg.reward;
     ra.state = d_state_in;
     ra.seq = d_seq;
+    ra.lo = d_lo.p; ra.hi = d_hi.p;
     ra.rewards = d_eval_rew.p;
     launch_rollout(SRC_REF, false, ra);
     // [A][st] -> [n_pop][A]: per agent a strided copy (dst pitch A floats, width 1 float)
