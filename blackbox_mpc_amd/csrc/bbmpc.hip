@@ -184,7 +184,7 @@ void Engine::set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, con
     }
     REQUIRE(hidden_tiles <= 16 * MLP_TMAX, BBMPC_E_UNSUPPORTED, "hidden width > 512 not supported");
     REQUIRE(mlp.tiles[0] <= 8 && mlp.tiles[n_layers] <= 4, BBMPC_E_UNSUPPORTED, "dim_S+dim_U <= 128 and dim_S <= 64 supported");
-    mlp_nw = std::min(16, std::max(hidden_tiles, std::max(1, (16 * (S + U) + 63) / 64 / 4)));
+    mlp_nw = std::min(16, hidden_tiles);
     for (int l = 0; l < n_layers; ++l) {
         REQUIRE(acts[l] >= BBMPC_ACT_NONE && acts[l] <= BBMPC_ACT_SIGMOID, BBMPC_E_INVALID, "unknown activation");
         REQUIRE(w[l] && b[l], BBMPC_E_INVALID, "null weight/bias pointer");
@@ -244,14 +244,24 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     const MlpLds lay = mlp_lds_layout(mlp, ra.H, U, S, mlp_nw);
     const size_t lds = (size_t)lay.total * sizeof(float);
     REQUIRE(lds <= 159 * 1024, BBMPC_E_UNSUPPORTED, "planning horizon x action dim too large for the LDS action block");
-    static size_t configured = 0;
-    if (lds > 64 * 1024 && lds > configured) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_rollout_mlp, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        configured = 159 * 1024;
+    // weights-stationary specialisations (kernels_mlp.hpp)
+    int spec = 0;
+    const bool small_io = mlp.tiles[0] <= 2 && mlp.tiles[mlp.n_layers] <= 2;
+    if (small_io && mlp.n_layers == 3 && mlp.tiles[1] == mlp.tiles[2] && mlp.tiles[1] <= 16 && mlp_nw == mlp.tiles[1]) spec = 1;
+    if (small_io && mlp.n_layers == 4 && mlp.tiles[1] == mlp.tiles[2] && mlp.tiles[2] == mlp.tiles[3] && mlp.tiles[1] <= 4 &&
+        mlp_nw == mlp.tiles[1]) spec = 2;
+    if (getenv("BBMPC_MLP_GENERIC")) spec = 0;
+    const void* fn = spec == 1 ? (const void*)k_rollout_mlp<1> : (spec == 2 ? (const void*)k_rollout_mlp<2> : (const void*)k_rollout_mlp<0>);
+    static bool configured[3] = {false, false, false};
+    if (lds > 64 * 1024 && !configured[spec]) {
+        HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        configured[spec] = true;
     }
     dim3 grid((ra.n_pop + MLP_TP - 1) / MLP_TP, per_particle_state ? 1 : A), block(mlp_nw * 64);
     prof_begin();
-    hipLaunchKernelGGL(k_rollout_mlp, grid, block, lds, stream, q);
+    if (spec == 1) hipLaunchKernelGGL(k_rollout_mlp<1>, grid, block, lds, stream, q);
+    else if (spec == 2) hipLaunchKernelGGL(k_rollout_mlp<2>, grid, block, lds, stream, q);
+    else hipLaunchKernelGGL(k_rollout_mlp<0>, grid, block, lds, stream, q);
     HIP_CHECK(hipGetLastError());
     prof_end();
 }

@@ -77,7 +77,7 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 //   part [NW][OTlast][64][4] K-split partial sums of the last layer
 //   st   [2][16][Sp]         raw state, double buffered (Sp = S rounded up to 4)
 //   acts [H][16][Up]         raw (feasible) actions of the tile (Up = U rounded up to 4... kept U)
-//   misc [64]
+//   misc [16*U]             per-(particle,u) penalty shares
 struct MlpLds {
     int xs, actA, actB, part, st, acts, misc, total;
 };
@@ -93,7 +93,7 @@ __host__ __device__ inline MlpLds mlp_lds_layout(const MlpDesc& m, int H, int U,
     l.part = o; o += nw * m.tiles[m.n_layers] * 256;
     l.st = o;   o += 2 * MLP_TP * Sp;
     l.acts = o; o += ((H * MLP_TP * U + 3) & ~3);
-    l.misc = o; o += 64;
+    l.misc = o; o += ((MLP_TP * U + 63) & ~63);
     l.total = o;
     return l;
 }
@@ -153,6 +153,13 @@ __device__ __forceinline__ int tile_addr(int f, int p) {
     return (((f >> 4) * 64) + (((f & 15) >> 2) * 16 + p)) * 4 + (f & 3);
 }
 
+// SPEC selects a weights-stationary specialisation (all A operands of a wave live in VGPRs for the whole
+// H-step recurrence, the last hidden tile feeds the K-split layer straight from its accumulator):
+//   SPEC 0: generic -- any 1..4 layers, operands streamed from L2 every step
+//   SPEC 1: 2 hidden layers of equal width <= 256 (one output tile per wave, nw == hidden tiles),
+//           S+U <= 32, S <= 32            e.g. 26-200-200-20 (BASELINE configs 4-5): 68 weight VGPRs
+//   SPEC 2: 3 hidden layers of equal width <= 64, S+U <= 32, S <= 32   e.g. 4-32-32-32-3 (low-level tutorial)
+template <int SPEC>
 __global__ void k_rollout_mlp(MlpRolloutArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutArgs& p = q.r;
@@ -169,9 +176,41 @@ __global__ void k_rollout_mlp(MlpRolloutArgs q) {
     float* st = smem + lay.st;
     float* acts = smem + lay.acts;
     const bool normd = m.normalized != 0;
+    float* misc = smem + lay.misc;
+
+    constexpr int NH = SPEC == 1 ? 2 : (SPEC == 2 ? 3 : 1);        // hidden layers of the specialisation
+    constexpr int HTM = SPEC == 1 ? 16 : (SPEC == 2 ? 4 : 1);      // max hidden tiles
+    constexpr int IT0M = 2, OTLM = 2;
+    float wr_in[IT0M * 4];                     // layer 0: my output tile x input tiles
+    float wr_hid[(NH > 1 ? (NH - 1) : 1) * HTM * 4];               // hidden->hidden: my output tile x input tiles
+    float wr_out[OTLM * 4];                    // last layer: output tiles x MY input tile (K split)
+    f32x4 bias_r[NH];
+    if constexpr (SPEC != 0) {
+        const int HT = m.tiles[1];
+#pragma unroll
+        for (int it = 0; it < IT0M; ++it)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                wr_in[it * 4 + s] = (it < m.tiles[0]) ? m.wpack[0][(((size_t)wave * m.tiles[0] + it) * 4 + s) * 64 + lane] : 0.0f;
+#pragma unroll
+        for (int h = 1; h < NH; ++h)
+#pragma unroll
+            for (int it = 0; it < HTM; ++it)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    wr_hid[((h - 1) * HTM + it) * 4 + s] =
+                        (it < HT) ? m.wpack[h][(((size_t)wave * HT + it) * 4 + s) * 64 + lane] : 0.0f;
+#pragma unroll
+        for (int ot = 0; ot < OTLM; ++ot)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                wr_out[ot * 4 + s] = (ot < m.tiles[NH + 1]) ? m.wpack[NH][(((size_t)ot * HT + wave) * 4 + s) * 64 + lane] : 0.0f;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) bias_r[h] = *reinterpret_cast<const f32x4*>(m.bpack[h] + ((size_t)wave * 64 + lane) * 4);
+    }
 
     // ---- prologue 1: the tile's whole action block [H][16][U] (candidate -> clip/penalty -> store)
-    float pen_part = 0.0f;                         // this thread's share of the penalty (thread = (p,u) pair)
+    float pen_part = 0.0f;                         // penalty share of one (particle,u) pair
     for (int i = tid; i < MLP_TP * U; i += nthr) {
         const int pp = i / U, u = i % U;           // consecutive threads: consecutive u of one particle
         const int n = n0 + pp;
@@ -207,6 +246,8 @@ __global__ void k_rollout_mlp(MlpRolloutArgs q) {
             }
             acts[(t * MLP_TP + pp) * U + u] = x;
         }
+        misc[i] = pen_part;
+        pen_part = 0.0f;
     }
     // ---- prologue 2: initial raw state + zero the padded input tiles
     for (int i = tid; i < m.tiles[0] * 256; i += nthr) xs[i] = 0.0f;
@@ -239,14 +280,62 @@ __global__ void k_rollout_mlp(MlpRolloutArgs q) {
         float* cur = st + (t & 1) * MLP_TP * Sp;
         float* nxt = st + ((t + 1) & 1) * MLP_TP * Sp;
         // ---- dense layers
-        const float* in = xs;
-        for (int l = 0; l < L - 1; ++l) {
-            float* out = actbuf[l & 1];
-            mlp_layer_out_split(m, l, in, out, wave, lane, nw);
-            __syncthreads();
-            in = out;
+        if constexpr (SPEC == 0) {
+            const float* in = xs;
+            for (int l = 0; l < L - 1; ++l) {
+                float* out = actbuf[l & 1];
+                mlp_layer_out_split(m, l, in, out, wave, lane, nw);
+                __syncthreads();
+                in = out;
+            }
+            mlp_layer_k_split(m, L - 1, in, part, wave, lane, nw);
+        } else {
+            const int HT = m.tiles[1];
+            f32x4 acc = bias_r[0];
+#pragma unroll
+            for (int it = 0; it < IT0M; ++it) {
+                if (it < m.tiles[0]) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(xs + ((size_t)it * 64 + lane) * 4);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 0], b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 1], b.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 2], b.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 3], b.w, acc, 0, 0, 0);
+                }
+            }
+            acc.x = apply_act(acc.x, m.act[0]); acc.y = apply_act(acc.y, m.act[0]);
+            acc.z = apply_act(acc.z, m.act[0]); acc.w = apply_act(acc.w, m.act[0]);
+#pragma unroll
+            for (int h = 1; h < NH; ++h) {
+                float* out = actbuf[(h - 1) & 1];
+                *reinterpret_cast<f32x4*>(out + ((size_t)wave * 64 + lane) * 4) = acc;     // all-gather through LDS
+                __syncthreads();
+                acc = bias_r[h];
+#pragma unroll
+                for (int it = 0; it < HTM; ++it) {
+                    if (it < HT) {
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(out + ((size_t)it * 64 + lane) * 4);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[((h - 1) * HTM + it) * 4 + 0], b.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[((h - 1) * HTM + it) * 4 + 1], b.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[((h - 1) * HTM + it) * 4 + 2], b.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[((h - 1) * HTM + it) * 4 + 3], b.w, acc, 0, 0, 0);
+                    }
+                }
+                acc.x = apply_act(acc.x, m.act[h]); acc.y = apply_act(acc.y, m.act[h]);
+                acc.z = apply_act(acc.z, m.act[h]); acc.w = apply_act(acc.w, m.act[h]);
+            }
+            // last layer, K split: my own last-hidden tile (still in `acc`) times my slab of W_last
+#pragma unroll
+            for (int ot = 0; ot < OTLM; ++ot) {
+                if (ot < OTl) {
+                    f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 0], acc.x, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 1], acc.y, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 2], acc.z, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 3], acc.w, o, 0, 0, 0);
+                    *reinterpret_cast<f32x4*>(part + (((size_t)wave * OTl + ot) * 64 + lane) * 4) = o;
+                }
+            }
         }
-        mlp_layer_k_split(m, L - 1, in, part, wave, lane, nw);
         __syncthreads();
         // ---- epilogue: reduce partials, bias, last activation, de-normalise, residual; stage step t+1's input
         const int nwp = min(nw, m.tiles[L - 1]);          // waves that actually produced partials
@@ -281,10 +370,7 @@ __global__ void k_rollout_mlp(MlpRolloutArgs q) {
     }
     // ---- penalties: sum the (p,u) shares in u order
     __syncthreads();
-    float* pens = part;                                   // free now
-    if (q.pen)
-        for (int i = tid; i < MLP_TP * U; i += nthr) pens[i] = pen_part;
-    __syncthreads();
+    const float* pens = misc;
     if (tid < MLP_TP) {
         const int n = n0 + tid;
         if (n < p.n_pop) {
