@@ -42,8 +42,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
     if (c.optimizer == BBMPC_OPT_CEM || c.optimizer == BBMPC_OPT_CMAES)
         REQUIRE(k >= 1 && k <= N, BBMPC_E_INVALID, "num_elite must be in [1, population_size]");
     if (c.optimizer == BBMPC_OPT_CEM) REQUIRE(k <= 1024, BBMPC_E_UNSUPPORTED, "num_elite > 1024 not supported");
-    REQUIRE(c.optimizer != BBMPC_OPT_PSO && c.optimizer != BBMPC_OPT_CMAES && c.optimizer != BBMPC_OPT_SPSA,
-            BBMPC_E_UNSUPPORTED, "PSO / CMA-ES / SPSA kernels are not built yet");
+    REQUIRE(c.optimizer != BBMPC_OPT_CMAES, BBMPC_E_UNSUPPORTED, "CMA-ES kernels are not built yet");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -85,6 +84,20 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         d_rewards.alloc((size_t)A * Nst);
         d_penalty.alloc((size_t)A * Nst);
         d_elites.alloc((size_t)A * std::max(k, 1));
+        const size_t big = (size_t)A * HU * Nst;
+        if (c.optimizer == BBMPC_OPT_SPSA) {
+            d_cand_a.alloc(big);
+            d_cand_b.alloc(big);
+            d_rewards2.alloc((size_t)A * Nst);
+        }
+        if (c.optimizer == BBMPC_OPT_PSO) {
+            // constructor state of the reference: every Variable zero (pso.py:50-59), quirk Q4
+            d_cand_a.alloc(big); d_vel.alloc(big); d_pbest.alloc(big);
+            d_pbest_r.alloc((size_t)A * Nst); d_cond.alloc((size_t)A * Nst);
+            d_gbest.alloc((size_t)A * HU); d_gbest_r.alloc((size_t)A); d_gidx.alloc((size_t)A);
+            d_cand_a.zero(stream); d_vel.zero(stream); d_pbest.zero(stream); d_pbest_r.zero(stream);
+            d_cond.zero(stream); d_gbest.zero(stream); d_gbest_r.zero(stream); d_gidx.zero(stream);
+        }
     }
     HIP_CHECK(hipStreamSynchronize(stream));
 }
@@ -107,9 +120,35 @@ float* Engine::pinned(size_t count) {
     return h_pin;
 }
 
+OptArgs Engine::opt_args(uint32_t step, uint32_t iter) const {
+    OptArgs o;
+    o.N = N; o.A = A; o.H = H; o.U = U; o.HU = HU; o.Nst = Nst;
+    o.agent_offset = cfg.agent_offset;
+    o.lo = d_lo.p; o.hi = d_hi.p;
+    o.key = key(step);
+    o.iter = iter;
+    return o;
+}
+
+PsoState Engine::pso_state() {
+    PsoState s;
+    s.pos = d_cand_a.p; s.vel = d_vel.p; s.pbest = d_pbest.p; s.pbest_r = d_pbest_r.p;
+    s.gbest = d_gbest.p; s.gbest_r = d_gbest_r.p; s.cond = d_cond.p; s.gidx = d_gidx.p;
+    return s;
+}
+
 void Engine::reset() {
     // CEM/PI2/SPSA reset(): previous solution <- bounds midpoint (cem.py:138-149, pi2.py:98-105)
     if (cfg.optimizer == BBMPC_OPT_NONE || cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH) return;
+    if (cfg.optimizer == BBMPC_OPT_PSO) {
+        // PSOOptimizer.reset(): uniform positions / velocities, pbest = pos, rewards -inf  (pso.py:143-160)
+        const OptArgs oa = opt_args(step_counter, 0xFFFFu);
+        hipLaunchKernelGGL(k_pso_seed, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, pso_state(), d_var0.p,
+                           cfg.pso_v0_fraction, 1, injected(BBMPC_NOISE_PSO_RESET_POS), injected(BBMPC_NOISE_PSO_RESET_VEL));
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return;
+    }
     std::vector<float> m((size_t)A * HU);
     for (int i = 0; i < A * HU; ++i) m[i] = (lo[i % U] + hi[i % U]) / 2.0f;
     HIP_CHECK(hipMemcpyAsync(d_prev_mean.p, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice, stream));
@@ -534,10 +573,80 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
             HIP_CHECK(hipGetLastError());
             break;
         }
+        case BBMPC_OPT_SPSA:
+            optimize_spsa(ra, step);
+            break;
+        case BBMPC_OPT_PSO:
+            optimize_pso(ra, step);
+            break;
         default:
             throw HipError(BBMPC_E_UNSUPPORTED, "optimizer not built yet");
     }
     finalize(d_state_in, add_noise, d_record_out, d_next_out, step);
+}
+
+// SPSAOptimizer._optimize  spsa.py:61-117
+void Engine::optimize_spsa(RolloutArgs& ra, uint32_t step) {
+    const int nelem = A * HU;
+    // solution starts from _current_parameters (d_prev_mean); keep it in d_mean while iterating
+    HIP_CHECK(hipMemcpyAsync(d_mean.p, d_prev_mean.p, (size_t)nelem * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpy2DAsync(d_action.p, U * 4, d_prev_mean.p, HU * 4, U * 4, A, hipMemcpyDeviceToDevice, stream));
+    const float* inj_r = injected(BBMPC_NOISE_RADEMACHER);
+    const size_t inj_stride = (size_t)A * HU * Nst;
+    const float big_a = (float)iters / 10.0f;                                   // spsa.py:56
+    for (int it = 0; it < iters; ++it) {
+        const float tf = (float)it;
+        const float ak = cfg.spsa_a / (float)pow((double)((tf + 1.0f) + big_a), (double)cfg.spsa_alpha);   // :69
+        const float ck = cfg.spsa_c / (float)pow((double)(tf + 1.0f), (double)cfg.spsa_gamma);             // :70
+        const OptArgs oa = opt_args(step, (uint32_t)it);
+        hipLaunchKernelGGL(k_spsa_candidates, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, d_mean.p, ck,
+                           inj_r ? inj_r + inj_stride * it : nullptr, d_samples.p, d_cand_a.p, d_cand_b.p);
+        HIP_CHECK(hipGetLastError());
+        ra.samples = nullptr;              // candidates are clipped in place; delta lives in d_samples
+        ra.penalty_out = nullptr;
+        ra.cand = d_cand_a.p; ra.samples = d_cand_a.p; ra.rewards = d_rewards.p;
+        launch_rollout(SRC_BUF, true, ra);
+        ra.cand = d_cand_b.p; ra.samples = d_cand_b.p; ra.rewards = d_rewards2.p;
+        launch_rollout(SRC_BUF, true, ra);
+        hipLaunchKernelGGL(k_refit_spsa, dim3(A), dim3(REFIT_THREADS), (size_t)Nst * 4, stream, oa, d_rewards.p, d_rewards2.p,
+                           d_samples.p, ak, ck, d_mean.p, d_action.p);
+        HIP_CHECK(hipGetLastError());
+        if (trace_on) {
+            capture_trace(it);
+            if (!t_rewards2.p) t_rewards2.alloc((size_t)A * Nst * std::max(iters, 1));
+            HIP_CHECK(hipMemcpyAsync(t_rewards2.p + (size_t)A * Nst * it, d_rewards2.p, (size_t)A * Nst * 4,
+                                     hipMemcpyDeviceToDevice, stream));
+        }
+    }
+    hipLaunchKernelGGL(k_shift_left, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, H, U, d_mean.p, d_prev_mean.p);  // :114-115
+    HIP_CHECK(hipGetLastError());
+}
+
+// PSOOptimizer._optimize  pso.py:70-141
+void Engine::optimize_pso(RolloutArgs& ra, uint32_t step) {
+    PsoState ps = pso_state();
+    const float* inj_s = injected(BBMPC_NOISE_PSO_SCALARS);
+    for (int it = 0; it < iters; ++it) {
+        const OptArgs oa = opt_args(step, (uint32_t)it);
+        ra.cand = ps.pos; ra.samples = ps.pos; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
+        launch_rollout(SRC_BUF, true, ra);                     // clip + penalty + write the feasible positions back
+        hipLaunchKernelGGL(k_pso_best, dim3(A), dim3(REFIT_THREADS), 0, stream, oa, ps, d_rewards.p);
+        hipLaunchKernelGGL(k_pso_move, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, ps, cfg.pso_w, cfg.pso_c1,
+                           cfg.pso_c2, inj_s ? inj_s + 2 * it : nullptr);
+        HIP_CHECK(hipGetLastError());
+        if (trace_on) {
+            ensure_trace();
+            const size_t nr = (size_t)A * Nst, nm = (size_t)A * HU;
+            HIP_CHECK(hipMemcpyAsync(t_rewards.p + nr * it, d_rewards.p, nr * 4, hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(t_mean.p + nm * it, ps.gbest, nm * 4, hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(t_elites.p + (size_t)A * std::max(k, 1) * it, ps.gidx, (size_t)A * 4, hipMemcpyDeviceToDevice, stream));
+        }
+    }
+    hipLaunchKernelGGL(k_take_first, dim3((A * U + 63) / 64), dim3(64), 0, stream, A, HU, U, ps.gbest, d_action.p);      // :114
+    const OptArgs oa = opt_args(step, 0u);
+    hipLaunchKernelGGL(k_pso_seed, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, ps, d_var0.p, cfg.pso_v0_fraction, 0,
+                       injected(BBMPC_NOISE_PSO_RESEED_TRUNC), injected(BBMPC_NOISE_PSO_RESEED_UNIFORM));              // :116-138
+    HIP_CHECK(hipGetLastError());
 }
 
 void Engine::evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop, float* d_rew_out) {
@@ -616,10 +725,21 @@ void Engine::inject(int kind, const float* data, int64_t count) {
         return;
     }
     switch (kind) {
+        case BBMPC_NOISE_PSO_SCALARS: {
+            REQUIRE(count == (int64_t)2 * std::max(iters, 1), BBMPC_E_INVALID, "PSO scalar noise must be [iters][2]");
+            auto& b = inj[kind];
+            b.alloc((size_t)count);
+            HIP_CHECK(hipMemcpy(b.p, data, (size_t)count * 4, hipMemcpyHostToDevice));
+            break;
+        }
         case BBMPC_NOISE_TRUNC_NORMAL:
         case BBMPC_NOISE_UNIFORM:
-        case BBMPC_NOISE_RADEMACHER: {
-            const int nit = (kind == BBMPC_NOISE_UNIFORM) ? 1 : std::max(iters, 1);
+        case BBMPC_NOISE_RADEMACHER:
+        case BBMPC_NOISE_PSO_RESEED_TRUNC:
+        case BBMPC_NOISE_PSO_RESEED_UNIFORM:
+        case BBMPC_NOISE_PSO_RESET_POS:
+        case BBMPC_NOISE_PSO_RESET_VEL: {
+            const int nit = (kind == BBMPC_NOISE_TRUNC_NORMAL || kind == BBMPC_NOISE_RADEMACHER) ? std::max(iters, 1) : 1;
             const int64_t per = (int64_t)N * A * HU;
             REQUIRE(count == per * nit, BBMPC_E_INVALID, "injected noise has the wrong element count");
             std::vector<float> tmp((size_t)A * HU * Nst * nit, 0.0f);
@@ -684,12 +804,15 @@ void Engine::get_trace(int it, int item, void* out, int64_t bytes) {
     const size_t nr = (size_t)A * Nst, nm = (size_t)A * HU, ns = (size_t)A * HU * Nst, ne = (size_t)A * std::max(k, 1);
     switch (item) {
         case BBMPC_TRACE_REWARDS: {
-            REQUIRE(bytes == (int64_t)N * A * 4, BBMPC_E_INVALID, "trace rewards: wrong size");
+            const bool spsa = cfg.optimizer == BBMPC_OPT_SPSA;
+            REQUIRE(bytes == (int64_t)N * A * 4 * (spsa ? 2 : 1), BBMPC_E_INVALID, "trace rewards: wrong size");
             std::vector<float> tmp(nr);
-            HIP_CHECK(hipMemcpy(tmp.data(), t_rewards.p + nr * it, nr * 4, hipMemcpyDeviceToHost));
             float* o = (float*)out;
-            for (int n = 0; n < N; ++n)
-                for (int a = 0; a < A; ++a) o[(size_t)n * A + a] = tmp[(size_t)a * Nst + n];
+            for (int half = 0; half < (spsa ? 2 : 1); ++half) {
+                HIP_CHECK(hipMemcpy(tmp.data(), (half ? t_rewards2.p : t_rewards.p) + nr * it, nr * 4, hipMemcpyDeviceToHost));
+                for (int n = 0; n < N; ++n)
+                    for (int a = 0; a < A; ++a) o[((size_t)half * N + n) * A + a] = tmp[(size_t)a * Nst + n];
+            }
             break;
         }
         case BBMPC_TRACE_MEAN:
@@ -724,6 +847,33 @@ void Engine::get_state(const std::string& name, float* out, int64_t count) {
     else if (name == "mean") src = d_mean.p;
     else if (name == "var") src = d_var.p;
     else if (name == "sigma") src = d_sigma.p;
+    if (!src && cfg.optimizer == BBMPC_OPT_PSO) {
+        const float* big = nullptr;
+        if (name == "pos") big = d_cand_a.p;
+        else if (name == "vel") big = d_vel.p;
+        else if (name == "pbest") big = d_pbest.p;
+        if (big) {            // [N,A,H,U] reference layout
+            REQUIRE(count == (int64_t)N * A * HU, BBMPC_E_INVALID, "state tensor has N*A*H*U elements");
+            std::vector<float> tmp((size_t)A * HU * Nst);
+            HIP_CHECK(hipMemcpy(tmp.data(), big, tmp.size() * 4, hipMemcpyDeviceToHost));
+            from_internal(tmp.data(), N, out);
+            return;
+        }
+        if (name == "pbest_r") {
+            REQUIRE(count == (int64_t)N * A, BBMPC_E_INVALID, "pbest_r has N*A elements");
+            std::vector<float> tmp((size_t)A * Nst);
+            HIP_CHECK(hipMemcpy(tmp.data(), d_pbest_r.p, tmp.size() * 4, hipMemcpyDeviceToHost));
+            for (int n = 0; n < N; ++n)
+                for (int a = 0; a < A; ++a) out[(size_t)n * A + a] = tmp[(size_t)a * Nst + n];
+            return;
+        }
+        if (name == "gbest") src = d_gbest.p;
+        if (name == "gbest_r") {
+            REQUIRE(count == (int64_t)A, BBMPC_E_INVALID, "gbest_r has A elements");
+            HIP_CHECK(hipMemcpy(out, d_gbest_r.p, (size_t)A * 4, hipMemcpyDeviceToHost));
+            return;
+        }
+    }
     REQUIRE(src, BBMPC_E_INVALID, "unknown state tensor '" + name + "'");
     REQUIRE(count == (int64_t)nm, BBMPC_E_INVALID, "state tensor has A*H*U elements");
     HIP_CHECK(hipMemcpy(out, src, nm * 4, hipMemcpyDeviceToHost));

@@ -14,6 +14,7 @@
 #include "../../include/bbmpc.h"
 #include "kernels_fused.hpp"
 #include "kernels_mlp.hpp"
+#include "kernels_opt.hpp"
 #include "kernels_refit.hpp"
 #include "kernels_rollout.hpp"
 
@@ -81,6 +82,11 @@ struct Engine {
     int mlp_nw = 1;
     DevBuf<float> d_wpack[MLP_MAX_LAYERS], d_bpack[MLP_MAX_LAYERS], d_stats;
     DevBuf<float> d_fin_next, d_fin_rew, d_step_act;
+    // SPSA / PSO state (internal layout)
+    DevBuf<float> d_cand_a, d_cand_b, d_rewards2, d_vel, d_pbest, d_pbest_r, d_gbest, d_gbest_r, d_cond;
+    DevBuf<int> d_gidx;
+    DevBuf<float> t_rewards2;
+    bool pso_seeded = false;
     // evaluate() scratch (grown on demand)
     DevBuf<float> d_eval_seq, d_eval_rew, d_step_a, d_step_b, d_step_c, d_step_d;
     // injected noise (internal layout), keyed by BBMPC_NOISE_*
@@ -119,6 +125,10 @@ struct Engine {
     bool use_fused() const;
     void optimize_fused(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step);
     void ensure_trace();
+    void optimize_spsa(RolloutArgs& ra, uint32_t step);
+    void optimize_pso(RolloutArgs& ra, uint32_t step);
+    OptArgs opt_args(uint32_t step, uint32_t iter) const;
+    PsoState pso_state();
     void evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop, float* d_rew_out);
     void step_dev(const float* d_states, const float* d_actions, int astride, int batch, float* d_next, float* d_rew);
     void reward_dev(const float* d_cur, const float* d_next, const float* d_act, int batch, float* d_rew);

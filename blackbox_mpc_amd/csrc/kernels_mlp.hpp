@@ -63,8 +63,26 @@ struct MlpRolloutArgs {
     int nw;                   // waves per workgroup
 };
 
+// tanh on the hardware exp/rcp units: 1 - 2/(1 + e^{2|x|}) away from zero, odd Taylor polynomial near it
+// (the rational form cancels there).  |error| <= ~3e-7 absolute (tests/test_gpu_mlp.py sweeps it against
+// float64), i.e. a few ulp -- the class of difference the stated MLP tolerances already cover.
+__device__ __forceinline__ float bb_tanhf(float x) {
+    const float ax = fabsf(x);
+    const float x2 = x * x;
+    // |x| < 0.3: x - x^3/3 + 2x^5/15 - 17x^7/315 + 62x^9/2835   (next term < 2e-8 relative)
+    float p = 0.021869488536155203f;
+    p = fmaf(p, x2, -0.053968253968253971f);
+    p = fmaf(p, x2, 0.13333333333333333f);
+    p = fmaf(p, x2, -0.33333333333333331f);
+    const float small = fmaf(x * x2, p, x);
+    const float e = __expf(2.0f * ax);                       // inf for large |x| -> 1 - 0
+    const float big = 1.0f - 2.0f * __frcp_rn(1.0f + e);
+    const float r = (ax < 0.3f) ? small : copysignf(big, x);
+    return (x != x) ? x : r;
+}
+
 __device__ __forceinline__ float apply_act(float x, int act) {
-    if (act == ACT_TANH) return tanhf(x);
+    if (act == ACT_TANH) return bb_tanhf(x);
     if (act == ACT_RELU) return fmaxf(x, 0.0f);
     if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-x));
     return x;
@@ -78,8 +96,9 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 //   st   [2][16][Sp]         raw state, double buffered (Sp = S rounded up to 4)
 //   acts [H][16][Up]         raw (feasible) actions of the tile (Up = U rounded up to 4... kept U)
 //   misc [16*U]             per-(particle,u) penalty shares
+//   norm [..]               per-feature (mean, 1/(std+1e-7)) of the inputs, (mean_t, std_t+1e-7, last bias) of the outputs
 struct MlpLds {
-    int xs, actA, actB, part, st, acts, misc, total;
+    int xs, actA, actB, part, st, acts, misc, norm, total;
 };
 __host__ __device__ inline MlpLds mlp_lds_layout(const MlpDesc& m, int H, int U, int S, int nw) {
     MlpLds l;
@@ -94,6 +113,7 @@ __host__ __device__ inline MlpLds mlp_lds_layout(const MlpDesc& m, int H, int U,
     l.st = o;   o += 2 * MLP_TP * Sp;
     l.acts = o; o += ((H * MLP_TP * U + 3) & ~3);
     l.misc = o; o += ((MLP_TP * U + 63) & ~63);
+    l.norm = o; o += (((S + U) * 2 + S * 3 + 63) & ~63);
     l.total = o;
     return l;
 }
@@ -177,6 +197,11 @@ __global__ void k_rollout_mlp(MlpRolloutArgs q) {
     float* acts = smem + lay.acts;
     const bool normd = m.normalized != 0;
     float* misc = smem + lay.misc;
+    float* nmean = smem + lay.norm;             // [S+U] input means (0 when not normalised)
+    float* ninv = nmean + (S + U);              // [S+U] 1/(std + 1e-7)   (1 when not normalised)
+    float* tmean = ninv + (S + U);              // [S] target mean
+    float* tstd = tmean + S;                    // [S] target std + 1e-7
+    float* lbias = tstd + S;                    // [S] bias of the last layer
 
     constexpr int NH = SPEC == 1 ? 2 : (SPEC == 2 ? 3 : 1);        // hidden layers of the specialisation
     constexpr int HTM = SPEC == 1 ? 16 : (SPEC == 2 ? 4 : 1);      // max hidden tiles
@@ -249,6 +274,17 @@ __global__ void k_rollout_mlp(MlpRolloutArgs q) {
         misc[i] = pen_part;
         pen_part = 0.0f;
     }
+    for (int f = tid; f < S + U; f += nthr) {
+        const float mu = normd ? (f < S ? m.mean_s[f] : m.mean_a[f - S]) : 0.0f;
+        const float sd = normd ? (f < S ? m.std_s[f] : m.std_a[f - S]) : 1.0f;
+        nmean[f] = mu;
+        ninv[f] = normd ? 1.0f / (sd + 1e-7f) : 1.0f;          // system_dynamics_handler.py:119-122 (x - mu)/(sd + 1e-7)
+        if (f < S) {
+            tmean[f] = normd ? m.mean_t[f] : 0.0f;
+            tstd[f] = normd ? (m.std_t[f] + 1e-7f) : 1.0f;
+            lbias[f] = m.bpack[L - 1][((size_t)(f >> 4) * 64 + ((f & 15) >> 2) * 16) * 4 + (f & 3)];
+        }
+    }
     // ---- prologue 2: initial raw state + zero the padded input tiles
     for (int i = tid; i < m.tiles[0] * 256; i += nthr) xs[i] = 0.0f;
     for (int i = tid; i < MLP_TP * S; i += nthr) {
@@ -262,15 +298,8 @@ __global__ void k_rollout_mlp(MlpRolloutArgs q) {
     __syncthreads();
     for (int i = tid; i < MLP_TP * (S + U); i += nthr) {          // normalised layer-0 input for t = 0
         const int f = i / MLP_TP, pp = i % MLP_TP;
-        float v;
-        if (f < S) {
-            v = st[pp * Sp + f];
-            if (normd) v = (v - m.mean_s[f]) / (m.std_s[f] + 1e-7f);
-        } else {
-            v = acts[(0 * MLP_TP + pp) * U + (f - S)];
-            if (normd) v = (v - m.mean_a[f - S]) / (m.std_a[f - S] + 1e-7f);
-        }
-        xs[tile_addr(f, pp)] = v;
+        const float v = (f < S) ? st[pp * Sp + f] : acts[(0 * MLP_TP + pp) * U + (f - S)];
+        xs[tile_addr(f, pp)] = (v - nmean[f]) * ninv[f];
     }
     __syncthreads();
 
@@ -344,21 +373,20 @@ __global__ void k_rollout_mlp(MlpRolloutArgs q) {
             float v;
             if (f < S) {
                 const int ot = f >> 4, ln = ((f & 15) >> 2) * 16 + pp, rg = f & 3;
-                float acc = m.bpack[L - 1][((size_t)ot * 64 + ln) * 4 + rg];
-                for (int w = 0; w < nwp; ++w) acc = acc + part[(((size_t)w * OTl + ot) * 64 + ln) * 4 + rg];
+                const float* pp0 = part + (((size_t)ot) * 64 + ln) * 4 + rg;
+                float acc = lbias[f];
+#pragma unroll 4
+                for (int w = 0; w < nwp; ++w) acc = acc + pp0[(size_t)w * OTl * 256];
                 acc = apply_act(acc, m.act[L - 1]);
-                float dev = acc;
-                if (normd) dev = m.mean_t[f] + acc * (m.std_t[f] + 1e-7f);   // system_dynamics_handler.py:152-155
+                const float dev = normd ? tmean[f] + acc * tstd[f] : acc;       // system_dynamics_handler.py:152-155
                 const float ns = dev + cur[pp * Sp + f];                        // transforms.py:34
                 nxt[pp * Sp + f] = ns;
                 v = ns;
-                if (normd) v = (v - m.mean_s[f]) / (m.std_s[f] + 1e-7f);
             } else {
                 const int tn = (t + 1 < H) ? t + 1 : t;
                 v = acts[(tn * MLP_TP + pp) * U + (f - S)];
-                if (normd) v = (v - m.mean_a[f - S]) / (m.std_a[f - S] + 1e-7f);
             }
-            xs[tile_addr(f, pp)] = v;
+            xs[tile_addr(f, pp)] = (v - nmean[f]) * ninv[f];
         }
         __syncthreads();
         // ---- reward of step t (wave 0, one lane per particle) overlaps the next step's first layer

@@ -160,7 +160,7 @@ class Engine:
 
     def get_trace(self, iteration, item):
         if item == L.TRACE_REWARDS:
-            out = np.empty((self.N, self.A), np.float32)
+            out = np.empty(((2 if self.cfg.optimizer == L.OPT_SPSA else 1) * self.N, self.A), np.float32)
         elif item in (L.TRACE_MEAN, L.TRACE_VAR):
             out = np.empty((self.A, self.H, self.U), np.float32)
         elif item == L.TRACE_ELITES:
