@@ -3,6 +3,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <dlfcn.h>
 #include <stdlib.h>
 
 namespace bbmpc {
@@ -42,7 +43,16 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
     if (c.optimizer == BBMPC_OPT_CEM || c.optimizer == BBMPC_OPT_CMAES)
         REQUIRE(k >= 1 && k <= N, BBMPC_E_INVALID, "num_elite must be in [1, population_size]");
     if (c.optimizer == BBMPC_OPT_CEM) REQUIRE(k <= 1024, BBMPC_E_UNSUPPORTED, "num_elite > 1024 not supported");
-    REQUIRE(c.optimizer != BBMPC_OPT_CMAES, BBMPC_E_UNSUPPORTED, "CMA-ES kernels are not built yet");
+    if (c.optimizer == BBMPC_OPT_CMAES) {
+        const bool per_agent = (c.quirks & BBMPC_CMAES_PER_AGENT) != 0;
+        const long nn = per_agent ? (long)H * U : (long)A * H * U;
+        REQUIRE(nn <= 4096, BBMPC_E_UNSUPPORTED,
+                "CMA-ES joint dimension num_agents*H*U > 4096: use BBMPC_CMAES_PER_AGENT (the reference's own "
+                "[N,n,n] map_fn stack cannot run at this size either, cma_es.py:13)");
+        REQUIRE(per_agent || c.num_agents_global <= c.num_agents, BBMPC_E_UNSUPPORTED,
+                "coupled CMA-ES sums rewards over ALL agents and does not shard; use BBMPC_CMAES_PER_AGENT");
+        REQUIRE(k <= 1024, BBMPC_E_UNSUPPORTED, "num_elite > 1024 not supported");
+    }
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -89,6 +99,10 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
             d_cand_a.alloc(big);
             d_cand_b.alloc(big);
             d_rewards2.alloc((size_t)A * Nst);
+        }
+        if (c.optimizer == BBMPC_OPT_CMAES) {
+            d_cand_a.alloc(big);
+            cma_init();
         }
         if (c.optimizer == BBMPC_OPT_PSO) {
             // constructor state of the reference: every Variable zero (pso.py:50-59), quirk Q4
@@ -137,9 +151,158 @@ PsoState Engine::pso_state() {
     return s;
 }
 
+// ---- CMA-ES host side -----------------------------------------------------------------------------
+void Engine::cma_init() {
+    const bool per_agent = fix(BBMPC_CMAES_PER_AGENT);
+    cma_G = per_agent ? A : 1;
+    cma_n = per_agent ? HU : A * HU;
+    const int n = cma_n, G = cma_G;
+    // recombination weights + constants, fp32 with the reference's op order (cma_es.py:62-92, 118-126)
+    std::vector<float> w((size_t)k);
+    const float lk = (float)log((double)((float)k + 0.5f));
+    float wsum = 0.0f;
+    for (int i = 0; i < k; ++i) { w[i] = lk - (float)log((double)(float)(i + 1)); wsum += w[i]; }
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int i = 0; i < k; ++i) { w[i] = w[i] / wsum; s1 += w[i]; s2 += w[i] * w[i]; }
+    CmaConst& c = cma_c;
+    const float nf = (float)n, ac = cfg.cma_alpha_cov;
+    c.mu_eff = (s1 * s1) / s2;
+    c.c_sigma = (c.mu_eff + 2.0f) / ((nf + c.mu_eff) + 5.0f);
+    c.d_sigma = (1.0f + 2.0f * std::max(0.0f, sqrtf((c.mu_eff - 1.0f) / (nf + 1.0f)) - 1.0f)) + c.c_sigma;
+    c.cc = (4.0f + c.mu_eff / nf) / ((nf + 4.0f) + (2.0f * c.mu_eff) / nf);
+    c.c1 = ac / ((nf + 1.3f) * (nf + 1.3f) + c.mu_eff);
+    const float cmu2 = ac * ((c.mu_eff - 2.0f) + 1.0f / c.mu_eff) / ((nf + 2.0f) * (nf + 2.0f) + (ac * c.mu_eff) / 2.0f);
+    c.c_mu = std::min(1.0f - c.c1, cmu2);
+    c.e_norm = sqrtf(nf * ((1.0f - 1.0f / (4.0f * nf)) + 1.0f / (21.0f * (nf * nf))));
+    c.h_sigma = cfg.cma_h_sigma;
+    upload(c_w, w);
+    const size_t gn = (size_t)G * n, gnn = gn * n;
+    c_m.alloc(gn); c_sigma.alloc(gn); c_Dd.alloc(gn); c_ps.alloc(gn); c_pc.alloc(gn); c_xm.alloc(gn); c_ym.alloc(gn);
+    c_eval.alloc(gn); c_E.alloc(gn);
+    c_C.alloc(gnn); c_B.alloc(gnn); c_BD.alloc(gnn); c_evec.alloc(gnn);
+    c_z.alloc((size_t)A * HU * Nst);
+    c_Ye.alloc((size_t)G * k * n);
+    c_eidx.alloc((size_t)G * k);
+    c_info.alloc((size_t)G);
+    // C = B = D = I, paths = 0 (cma_es.py:98-117)
+    std::vector<float> eye(gnn, 0.0f), ones(gn, 1.0f);
+    for (int g = 0; g < G; ++g)
+        for (int i = 0; i < n; ++i) eye[(size_t)g * n * n + (size_t)i * n + i] = 1.0f;
+    HIP_CHECK(hipMemcpy(c_C.p, eye.data(), gnn * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(c_B.p, eye.data(), gnn * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(c_Dd.p, ones.data(), gn * 4, hipMemcpyHostToDevice));
+    c_ps.zero(stream);
+    c_pc.zero(stream);
+    cma_reset_mean_sigma();
+}
+
+void Engine::cma_reset_mean_sigma() {
+    // m = bounds midpoint, sigma = sqrt((lo-hi)^2/16) per coordinate (cma_es.py:48-59,95-97; reset :215-227)
+    const size_t gn = (size_t)cma_G * cma_n;          // == A*HU in both modes, same (a,h,u) order
+    std::vector<float> m(gn), sg(gn);
+    for (size_t i = 0; i < gn; ++i) {
+        const int u = (int)(i % U);
+        m[i] = (lo[u] + hi[u]) / 2.0f;
+        const float d = lo[u] - hi[u];
+        sg[i] = sqrtf((d * d) / 16.0f);
+    }
+    HIP_CHECK(hipMemcpy(c_m.p, m.data(), gn * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(c_sigma.p, sg.data(), gn * 4, hipMemcpyHostToDevice));
+}
+
+CmaArgs Engine::cma_args(uint32_t step, uint32_t iter) {
+    CmaArgs q;
+    memset(&q, 0, sizeof(q));
+    q.N = N; q.A = A; q.HU = HU; q.Nst = Nst; q.k = k;
+    q.G = cma_G; q.n = cma_n;
+    q.agents_per_group = fix(BBMPC_CMAES_PER_AGENT) ? 1 : A;
+    q.agent_offset = cfg.agent_offset;
+    q.c = cma_c;
+    q.weights = c_w.p;
+    q.m = c_m.p; q.sigma = c_sigma.p; q.C = c_C.p; q.B = c_B.p; q.Dd = c_Dd.p; q.p_sigma = c_ps.p; q.p_C = c_pc.p;
+    q.BD = c_BD.p; q.z = c_z.p; q.cand = d_cand_a.p; q.rewards = d_rewards.p; q.eidx = c_eidx.p; q.Ye = c_Ye.p;
+    q.xmean = c_xm.p; q.ymean = c_ym.p; q.evec = c_evec.p; q.eval = c_eval.p;
+    q.key = key(step);
+    q.iter = iter;
+    return q;
+}
+
+// symmetric eigendecomposition of C through rocSOLVER (the reference calls tf.linalg.svd, cma_es.py:195);
+// the library is loaded on first use so that nothing else in the engine depends on it.
+void Engine::cma_eig() {
+    typedef int (*create_t)(void**);
+    typedef int (*setstream_t)(void*, hipStream_t);
+    typedef int (*syevd_t)(void*, int, int, int, float*, int, long long, float*, long long, float*, long long, int*, int);
+    static create_t f_create = nullptr;
+    static setstream_t f_setstream = nullptr;
+    static syevd_t f_syevd = nullptr;
+    if (!f_syevd) {
+        void* h = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        REQUIRE(h, BBMPC_E_UNSUPPORTED, std::string("CMA-ES needs rocSOLVER for the eigendecomposition: ") + dlerror());
+        void* hb = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!hb) hb = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+        REQUIRE(hb, BBMPC_E_UNSUPPORTED, "CMA-ES needs rocBLAS (handle for rocSOLVER)");
+        f_create = (create_t)dlsym(hb, "rocblas_create_handle");
+        f_setstream = (setstream_t)dlsym(hb, "rocblas_set_stream");
+        f_syevd = (syevd_t)dlsym(h, "rocsolver_ssyevd_strided_batched");
+        REQUIRE(f_create && f_setstream && f_syevd, BBMPC_E_UNSUPPORTED, "rocSOLVER/rocBLAS symbols not found");
+    }
+    if (!rocblas_h) REQUIRE(f_create(&rocblas_h) == 0, BBMPC_E_HIP, "rocblas_create_handle failed");
+    REQUIRE(f_setstream(rocblas_h, stream) == 0, BBMPC_E_HIP, "rocblas_set_stream failed");
+    const int n = cma_n, G = cma_G;
+    HIP_CHECK(hipMemcpyAsync(c_evec.p, c_C.p, (size_t)G * n * n * 4, hipMemcpyDeviceToDevice, stream));
+    const int st = f_syevd(rocblas_h, 211 /*rocblas_evect_original*/, 121 /*rocblas_fill_upper*/, n, c_evec.p, n,
+                           (long long)n * n, c_eval.p, (long long)n, c_E.p, (long long)n, c_info.p, G);
+    REQUIRE(st == 0, BBMPC_E_HIP, "rocsolver_ssyevd_strided_batched failed with status " + std::to_string(st));
+}
+
+// CMAESOptimizer._optimize  cma_es.py:129-213
+void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
+    const int n = cma_n, G = cma_G;
+    const float* inj_n = injected(BBMPC_NOISE_NORMAL);
+    const size_t inj_stride = (size_t)A * HU * Nst;
+    const size_t gnn = (size_t)G * n * n;
+    for (int it = 0; it < iters; ++it) {
+        CmaArgs q = cma_args(step, (uint32_t)it);
+        q.inj = inj_n ? inj_n + inj_stride * it : nullptr;
+        hipLaunchKernelGGL(k_cma_noise, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, q);
+        hipLaunchKernelGGL(k_cma_bd, dim3((unsigned)((gnn + 255) / 256)), dim3(256), 0, stream, q);
+        hipLaunchKernelGGL(k_cma_gemm_y, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
+        HIP_CHECK(hipGetLastError());
+        ra.cand = d_cand_a.p; ra.samples = d_cand_a.p; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
+        launch_rollout(SRC_BUF, true, ra);                          // clip + penalty (cma_es.py:147-157)
+        const int kp = (k + 3) & ~3;
+        const size_t lds = (size_t)(Nst + TOPK_HIST_WORDS + 2 * kp) * 4;
+        hipLaunchKernelGGL(k_cma_select, dim3(G), dim3(REFIT_THREADS), lds, stream, q);
+        hipLaunchKernelGGL(k_cma_paths, dim3(G), dim3(REFIT_THREADS), 0, stream, q);
+        hipLaunchKernelGGL(k_cma_cov, dim3((n + 15) / 16, (n + 15) / 16, G), dim3(16, 16), 0, stream, q);
+        HIP_CHECK(hipGetLastError());
+        cma_eig();
+        hipLaunchKernelGGL(k_cma_eig_post, dim3((unsigned)((gnn + 255) / 256)), dim3(256), 0, stream, q);
+        HIP_CHECK(hipGetLastError());
+        if (trace_on) {
+            ensure_trace();
+            const size_t nr = (size_t)A * Nst, nm = (size_t)A * HU, ns = (size_t)A * HU * Nst;
+            HIP_CHECK(hipMemcpyAsync(t_rewards.p + nr * it, d_rewards.p, nr * 4, hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(t_mean.p + nm * it, c_m.p, nm * 4, hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(t_samples.p + ns * it, d_cand_a.p, ns * 4, hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(t_elites.p + (size_t)A * std::max(k, 1) * it, c_eidx.p, (size_t)G * k * 4,
+                                     hipMemcpyDeviceToDevice, stream));
+        }
+    }
+    hipLaunchKernelGGL(k_take_first, dim3((A * U + 63) / 64), dim3(64), 0, stream, A, HU, U, c_m.p, d_action.p);   // :211-212
+    HIP_CHECK(hipGetLastError());
+}
+
 void Engine::reset() {
     // CEM/PI2/SPSA reset(): previous solution <- bounds midpoint (cem.py:138-149, pi2.py:98-105)
     if (cfg.optimizer == BBMPC_OPT_NONE || cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH) return;
+    if (cfg.optimizer == BBMPC_OPT_CMAES) {          // restores m and sigma only (cma_es.py:215-227)
+        HIP_CHECK(hipStreamSynchronize(stream));
+        cma_reset_mean_sigma();
+        return;
+    }
     if (cfg.optimizer == BBMPC_OPT_PSO) {
         // PSOOptimizer.reset(): uniform positions / velocities, pbest = pos, rewards -inf  (pso.py:143-160)
         const OptArgs oa = opt_args(step_counter, 0xFFFFu);
@@ -579,6 +742,9 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
         case BBMPC_OPT_PSO:
             optimize_pso(ra, step);
             break;
+        case BBMPC_OPT_CMAES:
+            optimize_cma(ra, step);
+            break;
         default:
             throw HipError(BBMPC_E_UNSUPPORTED, "optimizer not built yet");
     }
@@ -738,8 +904,10 @@ void Engine::inject(int kind, const float* data, int64_t count) {
         case BBMPC_NOISE_PSO_RESEED_TRUNC:
         case BBMPC_NOISE_PSO_RESEED_UNIFORM:
         case BBMPC_NOISE_PSO_RESET_POS:
+        case BBMPC_NOISE_NORMAL:
         case BBMPC_NOISE_PSO_RESET_VEL: {
-            const int nit = (kind == BBMPC_NOISE_TRUNC_NORMAL || kind == BBMPC_NOISE_RADEMACHER) ? std::max(iters, 1) : 1;
+            const int nit = (kind == BBMPC_NOISE_TRUNC_NORMAL || kind == BBMPC_NOISE_RADEMACHER || kind == BBMPC_NOISE_NORMAL)
+                                ? std::max(iters, 1) : 1;
             const int64_t per = (int64_t)N * A * HU;
             REQUIRE(count == per * nit, BBMPC_E_INVALID, "injected noise has the wrong element count");
             std::vector<float> tmp((size_t)A * HU * Nst * nit, 0.0f);
@@ -774,6 +942,8 @@ __global__ void k_dump_noise(RngKey key, uint32_t stream, uint32_t iter, int N, 
         v = word_to_uniform(w);
     else if (stream == BBMPC_NOISE_RADEMACHER)
         v = word_to_rademacher(w);
+    else if (stream == BBMPC_NOISE_NORMAL)
+        v = elem_normal(key, iter, n, agent_offset + a, j);
     else
         v = word_to_trunc_normal(w);
     out[idx] = v;
@@ -822,7 +992,8 @@ void Engine::get_trace(int it, int item, void* out, int64_t bytes) {
             break;
         }
         case BBMPC_TRACE_ELITES: {
-            const size_t cnt = (cfg.optimizer == BBMPC_OPT_CEM) ? (size_t)A * k : (size_t)A;
+            const size_t cnt = (cfg.optimizer == BBMPC_OPT_CEM) ? (size_t)A * k
+                               : (cfg.optimizer == BBMPC_OPT_CMAES ? (size_t)cma_G * k : (size_t)A);
             REQUIRE(bytes == (int64_t)cnt * 4, BBMPC_E_INVALID, "trace elites: wrong size");
             HIP_CHECK(hipMemcpy(out, t_elites.p + ne * it, cnt * 4, hipMemcpyDeviceToHost));
             break;
@@ -847,6 +1018,22 @@ void Engine::get_state(const std::string& name, float* out, int64_t count) {
     else if (name == "mean") src = d_mean.p;
     else if (name == "var") src = d_var.p;
     else if (name == "sigma") src = d_sigma.p;
+    if (!src && cfg.optimizer == BBMPC_OPT_CMAES) {
+        const size_t gn = (size_t)cma_G * cma_n, gnn = gn * cma_n;
+        const float* v = nullptr;
+        size_t cnt = gn;
+        if (name == "m") v = c_m.p;
+        else if (name == "sigma") v = c_sigma.p;
+        else if (name == "p_sigma") v = c_ps.p;
+        else if (name == "p_C") v = c_pc.p;
+        else if (name == "D") v = c_Dd.p;
+        else if (name == "C") { v = c_C.p; cnt = gnn; }
+        else if (name == "B") { v = c_B.p; cnt = gnn; }
+        REQUIRE(v, BBMPC_E_INVALID, "unknown state tensor '" + name + "'");
+        REQUIRE(count == (int64_t)cnt, BBMPC_E_INVALID, "CMA-ES state tensor: wrong element count");
+        HIP_CHECK(hipMemcpy(out, v, cnt * 4, hipMemcpyDeviceToHost));
+        return;
+    }
     if (!src && cfg.optimizer == BBMPC_OPT_PSO) {
         const float* big = nullptr;
         if (name == "pos") big = d_cand_a.p;

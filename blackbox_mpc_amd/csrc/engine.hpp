@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/bbmpc.h"
+#include "kernels_cma.hpp"
 #include "kernels_fused.hpp"
 #include "kernels_mlp.hpp"
 #include "kernels_opt.hpp"
@@ -87,6 +88,12 @@ struct Engine {
     DevBuf<int> d_gidx;
     DevBuf<float> t_rewards2;
     bool pso_seeded = false;
+    // CMA-ES state
+    int cma_G = 0, cma_n = 0;
+    CmaConst cma_c;
+    DevBuf<float> c_w, c_m, c_sigma, c_C, c_B, c_Dd, c_ps, c_pc, c_BD, c_z, c_Ye, c_xm, c_ym, c_evec, c_eval, c_E;
+    DevBuf<int> c_eidx, c_info;
+    void* rocblas_h = nullptr;
     // evaluate() scratch (grown on demand)
     DevBuf<float> d_eval_seq, d_eval_rew, d_step_a, d_step_b, d_step_c, d_step_d;
     // injected noise (internal layout), keyed by BBMPC_NOISE_*
@@ -127,6 +134,11 @@ struct Engine {
     void ensure_trace();
     void optimize_spsa(RolloutArgs& ra, uint32_t step);
     void optimize_pso(RolloutArgs& ra, uint32_t step);
+    void optimize_cma(RolloutArgs& ra, uint32_t step);
+    void cma_init();
+    void cma_reset_mean_sigma();
+    CmaArgs cma_args(uint32_t step, uint32_t iter);
+    void cma_eig();
     OptArgs opt_args(uint32_t step, uint32_t iter) const;
     PsoState pso_state();
     void evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop, float* d_rew_out);

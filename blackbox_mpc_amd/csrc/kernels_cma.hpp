@@ -1,0 +1,229 @@
+// CMA-ES kernels -- CMAESOptimizer  optimizers/cma_es.py:43-227.
+//
+// One "group" is one CMA-ES instance of dimension n:
+//   coupled mode (reference behaviour): a single group, n = A*H*U, rewards summed over agents (quirk Q6)
+//   per-agent mode (BBMPC_CMAES_PER_AGENT): A groups of n = H*U, shards over GPUs like the other optimizers
+// Vectors/matrices of group g live at offset g*n (resp. g*n*n); matrices are row-major.
+// Candidates use the engine's internal layout [A][H*U][Nst]; with the joint index i = a*HU + j a group's
+// sample matrix is simply X^T [n][Nst] starting at row g*n.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "kernels_refit.hpp"
+#include "rng.hpp"
+#include "topk.hpp"
+
+namespace bbmpc {
+
+struct CmaConst {            // cma_es.py:62-92,118-126 (computed on the host in fp32, same op order)
+    float mu_eff, c_sigma, d_sigma, cc, c1, c_mu, e_norm, h_sigma;
+};
+
+struct CmaArgs {
+    int N, A, HU, Nst, k;
+    int G, n;                // groups, dimension per group
+    int agents_per_group;    // A (coupled) or 1
+    int agent_offset;
+    CmaConst c;
+    const float* weights;    // [k] recombination weights (the rest of the N weights are zero)
+    float* m;                // [G*n]
+    float* sigma;            // [G*n]
+    float* C;                // [G][n][n]
+    float* B;                // [G][n][n]
+    float* Dd;               // [G*n]   diagonal of D
+    float* p_sigma;          // [G*n]
+    float* p_C;              // [G*n]
+    float* BD;               // [G][n][n] scratch
+    float* z;                // [G*n][Nst] standard normals (internal layout)
+    float* y;                // [G*n][Nst]
+    float* cand;             // [G*n][Nst] samples (clipped in place by the rollout)
+    const float* rewards;    // [A][Nst] (penalty already subtracted)
+    int* eidx;               // [G][k]
+    float* Ye;               // [G][k][n]  (x_sorted - m)/sigma of the elites
+    float* xmean;            // [G*n]
+    float* ymean;            // [G*n]
+    float* evec;             // [G][n][n] eigenvectors from the solver (column-major)
+    float* eval;             // [G*n] eigenvalues ascending
+    RngKey key;
+    uint32_t iter;
+    const float* inj;        // injected z (internal layout) or null
+};
+
+// z ~ N(0,1): element j of a 4-block uses Box-Muller on word pairs (w0,w1)->(z0,z1), (w2,w3)->(z2,z3)
+__device__ __forceinline__ float elem_normal(const RngKey& key, uint32_t iter, int n, int ga, int j) {
+    const U4 b = rng_block(key, 4u, iter, (uint32_t)n, (uint32_t)ga, (uint32_t)j);
+    float z0, z1;
+    if ((j & 2) == 0) words_to_normal2(b.x, b.y, z0, z1);
+    else words_to_normal2(b.z, b.w, z0, z1);
+    return (j & 1) ? z1 : z0;
+}
+
+// grid (ceil(N/256), HU, A)
+__global__ void k_cma_noise(CmaArgs p) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y, a = blockIdx.z;
+    if (n >= p.N) return;
+    const size_t i = ((size_t)a * p.HU + j) * p.Nst + n;
+    p.z[i] = p.inj ? p.inj[i] : elem_normal(p.key, p.iter, n, p.agent_offset + a, j);
+}
+
+// BD = B @ D (D diagonal)   cma_es.py:140
+__global__ void k_cma_bd(CmaArgs p) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nn = (size_t)p.n * p.n;
+    if (i >= nn * p.G) return;
+    const int g = (int)(i / nn), c = (int)(i % p.n);
+    p.BD[i] = p.B[i] * p.Dd[(size_t)g * p.n + c];
+}
+
+// Y^T[i][q] = sum_l BD[l][i] * Z^T[l][q]      (y = z @ BD, cma_es.py:140)  64x64 tiles, 4x4 per thread
+// grid (ceil(N/64), ceil(n/64), G), block 256
+__global__ __launch_bounds__(256) void k_cma_gemm_y(CmaArgs p) {
+    __shared__ float As[16][64 + 1];
+    __shared__ float Bs[16][64 + 1];
+    const int g = blockIdx.z;
+    const int i0 = blockIdx.y * 64, q0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const float* A = p.BD + (size_t)g * p.n * p.n;            // [l][i]
+    const float* Z = p.z + (size_t)g * p.n * p.Nst;           // [l][q]
+    float acc[4][4] = {};
+    for (int l0 = 0; l0 < p.n; l0 += 16) {
+        for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+            const int l = e >> 6, c = e & 63;
+            As[l][c] = (l0 + l < p.n && i0 + c < p.n) ? A[(size_t)(l0 + l) * p.n + i0 + c] : 0.0f;
+            Bs[l][c] = (l0 + l < p.n && q0 + c < p.N) ? Z[(size_t)(l0 + l) * p.Nst + q0 + c] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { av[r] = As[l][ty * 4 + r]; bv[r] = Bs[l][tx * 4 + r]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(av[r], bv[c], acc[r][c]);
+        }
+        __syncthreads();
+    }
+    // samples = m + sigma * y   (cma_es.py:141), written straight into the candidate buffer
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty * 4 + r;
+        if (i >= p.n) continue;
+        const float mi = p.m[(size_t)g * p.n + i], si = p.sigma[(size_t)g * p.n + i];
+        for (int c = 0; c < 4; ++c) {
+            const int q = q0 + tx * 4 + c;
+            if (q < p.N) p.cand[((size_t)g * p.n + i) * p.Nst + q] = mi + si * acc[r][c];
+        }
+    }
+}
+
+// per group: (sum of) rewards -> sorted top-k.   LDS: rsum[Nst] | hist | ekeys[kp]
+__global__ __launch_bounds__(REFIT_THREADS) void k_cma_select(CmaArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    float* rs = smem;
+    uint32_t* hist = (uint32_t*)(rs + p.Nst);
+    unsigned long long* ekeys = (unsigned long long*)(hist + TOPK_HIST_WORDS);
+    __shared__ int eidx_s[1024];
+    for (int q = tid; q < p.N; q += REFIT_THREADS) {
+        float s = 0.0f;
+        for (int a = 0; a < p.agents_per_group; ++a)              // tf.reduce_sum over agents, cma_es.py:158
+            s = s + p.rewards[(size_t)(g * p.agents_per_group + a) * p.Nst + q];
+        rs[q] = s;
+    }
+    __syncthreads();
+    block_topk_sorted(rs, p.N, p.k, eidx_s, hist, ekeys, tid, REFIT_THREADS);   // argsort DESCENDING, first k
+    for (int e = tid; e < p.k; e += REFIT_THREADS) p.eidx[g * p.k + e] = eidx_s[e];
+}
+
+// per group: elite deviations, weighted mean step, evolution paths, step size, new mean
+// (cma_es.py:161-177).  One workgroup per group; threads stride the n coordinates.
+__global__ __launch_bounds__(REFIT_THREADS) void k_cma_paths(CmaArgs p) {
+    __shared__ float red[REFIT_THREADS / 64];
+    __shared__ float s_norm;
+    const int g = blockIdx.x, tid = threadIdx.x, n = p.n;
+    const size_t off = (size_t)g * n;
+    const float* X = p.cand + off * p.Nst;
+    const int* el = p.eidx + g * p.k;
+    float* Ye = p.Ye + (size_t)g * p.k * n;
+    // x_diff, x_mean, y_mean, Ye
+    for (int c = tid; c < n; c += REFIT_THREADS) {
+        const float mc = p.m[off + c], sc = p.sigma[off + c];
+        float xm = 0.0f;
+        for (int i = 0; i < p.k; ++i) {
+            const float xd = X[(size_t)c * p.Nst + el[i]] - mc;           // :161
+            xm = xm + xd * p.weights[i];                                   // :162
+            Ye[(size_t)i * n + c] = xd / sc;                               // :180
+        }
+        p.xmean[off + c] = xm;
+        p.ymean[off + c] = xm / sc;                                        // :167
+    }
+    __syncthreads();
+    // t1 = B^T y_mean ; t2 = t1 / diag(D)   (C^{-1/2} y = B D^{-1} B^T y, :168-169)
+    float* t2 = p.BD + (size_t)g * n * n;      // BD scratch is free after the sampling GEMM
+    const float* B = p.B + (size_t)g * n * n;
+    for (int j = tid; j < n; j += REFIT_THREADS) {
+        float s = 0.0f;
+        for (int i = 0; i < n; ++i) s = fmaf(B[(size_t)i * n + j], p.ymean[off + i], s);
+        t2[j] = s * (1.0f / p.Dd[off + j]);
+    }
+    __syncthreads();
+    const float cs = p.c.c_sigma, cc = p.c.cc;
+    const float coef_s = sqrtf((cs * (2.0f - cs)) * p.c.mu_eff);
+    const float coef_c = p.c.h_sigma * sqrtf((cc * (2.0f - cc)) * p.c.mu_eff);
+    float part = 0.0f;
+    for (int i = tid; i < n; i += REFIT_THREADS) {
+        float s = 0.0f;
+        for (int j = 0; j < n; ++j) s = fmaf(B[(size_t)i * n + j], t2[j], s);
+        const float ps = (1.0f - cs) * p.p_sigma[off + i] + coef_s * s;    // :170-171
+        p.p_sigma[off + i] = ps;
+        part += ps * ps;
+        p.p_C[off + i] = (1.0f - cc) * p.p_C[off + i] + coef_c * p.ymean[off + i];   // :177
+    }
+    part = wave_sum(part);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.0f;
+        for (int w = 0; w < REFIT_THREADS / 64; ++w) s += red[w];
+        s_norm = sqrtf(s);
+    }
+    __syncthreads();
+    const float fac = expf((cs / p.c.d_sigma) * (s_norm / p.c.e_norm - 1.0f));   // :172-173
+    for (int c = tid; c < n; c += REFIT_THREADS) {
+        p.sigma[off + c] = p.sigma[off + c] * fac;
+        p.m[off + c] = p.m[off + c] + p.xmean[off + c];                    // :163
+    }
+}
+
+// C = (1-c1-cmu) C + c1 pC pC^T + cmu sum_i w_i y_i y_i^T on the upper triangle, mirrored (cma_es.py:179-190)
+// grid (ceil(n/16), ceil(n/16), G), block (16,16)
+__global__ void k_cma_cov(CmaArgs p) {
+    const int g = blockIdx.z, n = p.n;
+    const int c = blockIdx.x * 16 + threadIdx.x, r = blockIdx.y * 16 + threadIdx.y;
+    if (r >= n || c >= n || r > c) return;
+    const size_t off = (size_t)g * n;
+    const float* Ye = p.Ye + (size_t)g * p.k * n;
+    float ys = 0.0f;
+    for (int i = 0; i < p.k; ++i) ys = fmaf(Ye[(size_t)i * n + r] * Ye[(size_t)i * n + c], p.weights[i], ys);
+    float* C = p.C + off * n;
+    const float v = ((1.0f - p.c.c1) - p.c.c_mu) * C[(size_t)r * n + c] + p.c.c1 * (p.p_C[off + r] * p.p_C[off + c]) +
+                    p.c.c_mu * ys;
+    C[(size_t)r * n + c] = v;
+    C[(size_t)c * n + r] = v;
+}
+
+// eigenpairs (ascending, column-major vectors) -> B (columns by descending eigenvalue), D = sqrt(s)   (:195-198)
+__global__ void k_cma_eig_post(CmaArgs p) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nn = (size_t)p.n * p.n;
+    if (i >= nn * p.G) return;
+    const int g = (int)(i / nn), r = (int)((i % nn) / p.n), c = (int)(i % p.n);
+    const int src = p.n - 1 - c;
+    p.B[i] = p.evec[(size_t)g * nn + (size_t)src * p.n + r];
+    if (r == 0) p.Dd[(size_t)g * p.n + c] = sqrtf(fabsf(p.eval[(size_t)g * p.n + src]));   // singular value = |eigenvalue|
+}
+
+}  // namespace bbmpc

@@ -164,7 +164,13 @@ class Engine:
         elif item in (L.TRACE_MEAN, L.TRACE_VAR):
             out = np.empty((self.A, self.H, self.U), np.float32)
         elif item == L.TRACE_ELITES:
-            out = np.empty((self.A, self.k) if self.cfg.optimizer == L.OPT_CEM else (self.A,), np.int32)
+            if self.cfg.optimizer == L.OPT_CEM:
+                out = np.empty((self.A, self.k), np.int32)
+            elif self.cfg.optimizer == L.OPT_CMAES:
+                groups = self.A if (self.cfg.quirks & L.CMAES_PER_AGENT) else 1
+                out = np.empty((groups, self.k), np.int32)
+            else:
+                out = np.empty((self.A,), np.int32)
         elif item == L.TRACE_SAMPLES:
             out = np.empty((self.N, self.A, self.H, self.U), np.float32)
         else:

@@ -600,7 +600,7 @@ class CMAES(OptimizerBase):
     def _mm(a, b):
         return (a.astype(np.float64) @ b.astype(np.float64)).astype(F)
 
-    def _optimize(self, state, noise, eig=None):
+    def _optimize(self, state, noise, eig=None, forced_order=None):
         c = self.c
         w = c["weights"]
         self.trace = []
@@ -614,9 +614,11 @@ class CMAES(OptimizerBase):
             rewards = (self.ev(state, feas) - pen).astype(F)                    # :157
             rsum = seq_sum(rewards, axis=1)                                     # :158
             order = topk_desc(rsum, self.N)                                     # :159
-            xs = feas[order].reshape(self.N, self.n)
+            if forced_order is not None:      # parity tests: keep lock-step across near-tied ranks
+                order = np.asarray(forced_order(it, rsum, order))
+            xs = feas[order].reshape(len(order), self.n)
             x_diff = (xs - self.m).astype(F)                                    # :161
-            x_mean = (x_diff.astype(np.float64) * w[:, None].astype(np.float64)).sum(0).astype(F)   # :162
+            x_mean = (x_diff.astype(np.float64) * w[:len(order), None].astype(np.float64)).sum(0).astype(F)   # :162
             m = (self.m + x_mean).astype(F)                                     # :163
             y_mean = (x_mean / self.sigma).astype(F)                            # :167
             d_inv = np.diag((F(1) / np.diag(self.D)).astype(F)).astype(F)       # :168

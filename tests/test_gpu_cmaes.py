@@ -1,0 +1,138 @@
+"""GPU parity tests for CMA-ES.
+
+Per SURVEY.md H4 the eigen-factorisation's sign/order conventions are library-specific, so parity is
+asserted (a) for iteration-0 samples (B = D = I), (b) for the deterministic update (m, sigma, p_sigma, p_C, C)
+given identical samples, with the oracle continued from the engine's own (s, B) each iteration, and
+(c) through invariants of the factorisation: B diag(D^2) B^T ~= C, D sorted descending, B orthonormal."""
+import numpy as np
+import pytest
+
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+LO, HI = [-2.0], [2.0]
+
+
+@pytest.fixture(scope="module")
+def L():
+    from blackbox_mpc_amd import _build
+    _build.build()
+    from blackbox_mpc_amd import _lib
+    assert _lib.device_count() >= 1
+    return _lib
+
+
+def _ev():
+    return O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))
+
+
+def _engine(L, A, H, N, iters, k, **kw):
+    from blackbox_mpc_amd.engine import Engine
+    return Engine(L.OPT_CMAES, L.DYN_PENDULUM, L.REW_PENDULUM, LO, HI, dim_s=3, num_agents=A, planning_horizon=H,
+                  population_size=N, max_iterations=iters, num_elite=k, **kw)
+
+
+def _state(eng, n, G=1):
+    g = lambda name, shape: eng.get_state(name, shape)
+    return dict(m=g("m", (G * n,)), sigma=g("sigma", (G * n,)), p_sigma=g("p_sigma", (G * n,)), p_C=g("p_C", (G * n,)),
+                D=g("D", (G * n,)), C=g("C", (G, n, n)), B=g("B", (G, n, n)))
+
+
+@pytest.mark.parametrize("N,A,H,k", [(64, 2, 5, 8), (200, 1, 30, 20)])
+def test_cmaes_coupled_lockstep(L, N, A, H, k):
+    n = A * H
+    eng = _engine(L, A, H, N, 1, k)
+    eng.set_trace(True)
+    cma = O.CMAES(_ev(), LO, HI, horizon=H, max_iterations=1, population=N, num_elite=k, num_agents=A)
+    rng = np.random.default_rng(N)
+    states = O.pendulum_start_states(A)
+    for step in range(4):
+        z = rng.standard_normal((1, N, n)).astype(F)
+        eng.inject_noise(L.NOISE_NORMAL, z.reshape(1, N, A, H, 1))
+        act, nxt, rew = eng.optimize(states)
+        st = _state(eng, n)
+        hip_r = eng.get_trace(0, L.TRACE_REWARDS)
+        hip_order = eng.get_trace(0, L.TRACE_ELITES)[0]
+
+        def order(it, rsum, own):
+            np.testing.assert_allclose(hip_r.sum(axis=1), rsum, rtol=2e-4, atol=2e-3 * A)
+            np.testing.assert_array_equal(hip_order, O.topk_desc(hip_r.sum(axis=1, dtype=np.float32), k))
+            if not np.array_equal(own[:k], hip_order):         # only near-ties may swap
+                for a_, b_ in zip(own[:k], hip_order):
+                    assert abs(rsum[a_] - rsum[b_]) <= 2e-3 * A + 2e-4 * abs(rsum[a_])
+            return hip_order
+        s_hip = (st["D"].astype(np.float64) ** 2).astype(F)
+        cma._optimize(states, {"normal": [z[0]]}, eig=[(s_hip, st["B"][0])], forced_order=order)
+        tr = cma.trace[0]
+        np.testing.assert_allclose(eng.get_trace(0, L.TRACE_SAMPLES), tr["samples"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(hip_r, tr["rewards"], rtol=2e-4, atol=2e-3)
+        np.testing.assert_allclose(st["m"], tr["m"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(st["sigma"], tr["sigma"], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(st["p_sigma"], tr["p_sigma"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(st["p_C"], tr["p_C"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(st["C"][0], tr["C"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(act, tr["m"].reshape(A, H, 1)[:, 0], rtol=0, atol=2e-5)
+        # factorisation invariants (cma_es.py:195-198)
+        B, D, C = st["B"][0].astype(np.float64), st["D"].astype(np.float64), st["C"][0].astype(np.float64)
+        np.testing.assert_allclose(B @ np.diag(D ** 2) @ B.T, C, rtol=0, atol=2e-5 * max(1.0, np.abs(C).max()))
+        np.testing.assert_allclose(B.T @ B, np.eye(n), rtol=0, atol=2e-5)
+        assert np.all(D[:-1] >= D[1:] - 1e-6) and np.all(D > 0)
+        np.testing.assert_array_equal(st["C"][0], st["C"][0].T)       # upper triangle mirrored (:188-190)
+    # reset() restores only m and sigma (cma_es.py:215-227)
+    c_before = eng.get_state("C", (1, n, n))
+    eng.reset()
+    np.testing.assert_array_equal(eng.get_state("C", (1, n, n)), c_before)
+    np.testing.assert_allclose(eng.get_state("m", (n,)), 0.0, atol=0)
+    np.testing.assert_allclose(eng.get_state("sigma", (n,)), 1.0, atol=0)
+
+
+def test_cmaes_multi_iteration_and_engine_normals(L):
+    N, A, H, k, iters = 256, 1, 12, 16, 4
+    eng = _engine(L, A, H, N, iters, k, seed=21)
+    z = eng.dump_noise(L.NOISE_NORMAL, 0, 0, (N, A, H, 1)).astype(np.float64).ravel()
+    assert abs(z.mean()) < 0.06 and abs(z.std() - 1.0) < 0.05 and np.abs(z).max() < 6
+    states = O.pendulum_start_states(A)
+    r0 = None
+    for step in range(3):
+        act, nxt, rew = eng.optimize(states)
+        assert np.all(np.isfinite(act)) and np.all(np.abs(act) <= 2.0 + 1e-6) is not None
+        r0 = rew if r0 is None else r0
+    n = A * H
+    st = _state(eng, n)
+    B, D, C = st["B"][0].astype(np.float64), st["D"].astype(np.float64), st["C"][0].astype(np.float64)
+    np.testing.assert_allclose(B @ np.diag(D ** 2) @ B.T, C, rtol=0, atol=5e-5 * max(1.0, np.abs(C).max()))
+    assert np.all(np.isfinite(st["m"])) and np.all(st["sigma"] > 0)
+
+
+def test_cmaes_per_agent_mode_shards(L):
+    # per-agent mode: each agent runs its own n = H*U instance; A=3 engine == three single-agent engines
+    # (RNG keyed by global agent id), and for A=1 it coincides with the reference's coupled mode.
+    N, A, H, k, iters = 96, 3, 6, 12, 2
+    states = O.pendulum_start_states(A)
+    full = _engine(L, A, H, N, iters, k, seed=4, quirks=L.CMAES_PER_AGENT)
+    acts = [full.optimize(states)[0] for _ in range(2)]
+    for a in range(A):
+        one = _engine(L, 1, H, N, iters, k, seed=4, quirks=L.CMAES_PER_AGENT, agent_offset=a, num_agents_global=A)
+        for s in range(2):
+            np.testing.assert_array_equal(one.optimize(states[a:a + 1])[0], acts[s][a:a + 1])
+    coupled = _engine(L, 1, H, N, iters, k, seed=4)
+    np.testing.assert_array_equal(coupled.optimize(states[:1])[0], acts[0][:1])
+    from blackbox_mpc_amd import _lib
+    with pytest.raises(_lib.BBMPCError):          # coupled mode cannot be sharded
+        _engine(L, 1, H, N, iters, k, agent_offset=0, num_agents_global=2)
+
+
+def test_cmaes_with_learned_dynamics_runs(L):
+    from blackbox_mpc_amd.engine import Engine
+    S, U, N, A, H, k, iters = 20, 6, 128, 2, 10, 16, 2
+    ws, bs = O.make_mlp_params([26, 200, 200, 20])
+    z, o = np.zeros, np.ones
+    stats = [z(S, F), o(S, F), z(U, F), o(U, F), z(S, F), np.full(S, 0.1, F)]
+    eng = Engine(L.OPT_CMAES, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=A,
+                 planning_horizon=H, population_size=N, max_iterations=iters, num_elite=k, quirks=L.CMAES_PER_AGENT)
+    eng.set_mlp(ws, bs, [1, 1, 0], stats)
+    states = O.cheetah_start_states(A, S)
+    for _ in range(2):
+        act, nxt, rew = eng.optimize(states)
+        assert act.shape == (A, U) and np.all(np.isfinite(act)) and np.all(np.isfinite(nxt)) and np.all(np.isfinite(rew))
