@@ -1,0 +1,96 @@
+"""Agent sharding across the GPUs of one node.
+
+Every optimizer reduction in the reference is per agent along the population axis and the evaluator
+treats rows independently, so agents shard with no data-path collective: rank r owns a contiguous block
+of agents, runs their whole control step locally (RNG keyed by GLOBAL agent id, so sharded == unsharded
+bit for bit) and one all-gather of the packed (action | next_state | reward) records per control step is
+the only exchange.  One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on ROCm;
+"gloo" on CPU for tests)."""
+import numpy as np
+
+
+def agent_shard(num_agents_global, world_size, rank):
+    """Contiguous block of agents owned by `rank`: (offset, count).  Sizes differ by at most one."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, extra = divmod(int(num_agents_global), int(world_size))
+    count = base + (1 if rank < extra else 0)
+    offset = rank * base + min(rank, extra)
+    return offset, count
+
+
+def gather_records(local_record, num_agents_global, group=None):
+    """All-gather the per-agent records of every rank into global agent order.
+
+    local_record: torch tensor [A_local, W] (device tensor for nccl, CPU tensor for gloo).
+    Returns a tensor [num_agents_global, W] on the same device, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    width = local_record.shape[1]
+    counts = [agent_shard(num_agents_global, world, r)[1] for r in range(world)]
+    cap = max(counts)
+    if all(c == cap for c in counts):
+        out = torch.empty((world * cap, width), dtype=local_record.dtype, device=local_record.device)
+        dist.all_gather_into_tensor(out, local_record.contiguous(), group=group)
+        return out
+    padded = torch.zeros((cap, width), dtype=local_record.dtype, device=local_record.device)
+    padded[:local_record.shape[0]] = local_record
+    out = torch.empty((world * cap, width), dtype=local_record.dtype, device=local_record.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * cap:r * cap + counts[r]] for r in range(world)], dim=0)
+
+
+class ShardedMPCPolicy:
+    """MPCPolicy over all agents with the agents sharded across the ranks of a process group.
+
+    policy_factory(agent_offset, num_agents_local, num_agents_global) must build the rank-local policy
+    (an MPCPolicy whose optimizer was created with those three values).  `act` takes the GLOBAL observation
+    batch [A_global, S] on every rank and returns the global (action, next_observation, reward) arrays."""
+
+    def __init__(self, policy_factory, num_agents_global, group=None, device=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self._group = group
+        self._world = dist.get_world_size(group)
+        self._rank = dist.get_rank(group)
+        self._A = int(num_agents_global)
+        self._offset, self._count = agent_shard(self._A, self._world, self._rank)
+        self._device = device
+        self._policy = policy_factory(self._offset, self._count, self._A) if self._count > 0 else None
+
+    @property
+    def local_agents(self):
+        return self._offset, self._count
+
+    def reset(self):
+        if self._policy is not None:
+            self._policy.reset()
+
+    def act(self, observations, t, exploration_noise=False):
+        import torch
+        obs = np.asarray(observations, dtype=np.float32)
+        if obs.ndim != 2 or obs.shape[0] != self._A:
+            raise ValueError("observations must be [num_agents_global, dim_S]")
+        if self._policy is not None:
+            a, n, r = self._policy.act(obs[self._offset:self._offset + self._count], t, exploration_noise)
+            rec = np.concatenate([a, n, np.asarray(r, np.float32).reshape(-1, 1)], axis=1).astype(np.float32)
+            self._widths = (a.shape[1], n.shape[1])
+        else:
+            rec = None
+        # ranks without agents still take part in the collective: learn the record width from rank 0
+        width = torch.tensor([rec.shape[1] if rec is not None else 0], dtype=torch.int64)
+        if self._device is not None:
+            width = width.to(self._device)
+        self._dist.all_reduce(width, op=self._dist.ReduceOp.MAX, group=self._group)
+        w = int(width.item())
+        if rec is None:
+            rec = np.zeros((0, w), np.float32)
+        local = torch.from_numpy(rec)
+        if self._device is not None:
+            local = local.to(self._device)
+        full = gather_records(local, self._A, self._group).cpu().numpy()
+        if not hasattr(self, "_widths"):
+            raise RuntimeError("a rank without agents cannot split the record; give every rank >= 1 agent")
+        u, s = self._widths
+        return full[:, :u], full[:, u:u + s], full[:, u + s]
