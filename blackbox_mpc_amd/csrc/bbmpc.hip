@@ -3,7 +3,6 @@
 
 #include <math.h>
 #include <stdio.h>
-#include <dlfcn.h>
 #include <stdlib.h>
 
 namespace bbmpc {
@@ -183,7 +182,7 @@ void Engine::cma_init() {
     c_z.alloc((size_t)A * HU * Nst);
     c_Ye.alloc((size_t)G * k * n);
     c_eidx.alloc((size_t)G * k);
-    c_info.alloc((size_t)G);
+    c_info.alloc(gn);           // SVD: column permutation
     // C = B = D = I, paths = 0 (cma_es.py:98-117)
     std::vector<float> eye(gnn, 0.0f), ones(gn, 1.0f);
     for (int g = 0; g < G; ++g)
@@ -221,40 +220,10 @@ CmaArgs Engine::cma_args(uint32_t step, uint32_t iter) {
     q.weights = c_w.p;
     q.m = c_m.p; q.sigma = c_sigma.p; q.C = c_C.p; q.B = c_B.p; q.Dd = c_Dd.p; q.p_sigma = c_ps.p; q.p_C = c_pc.p;
     q.BD = c_BD.p; q.z = c_z.p; q.cand = d_cand_a.p; q.rewards = d_rewards.p; q.eidx = c_eidx.p; q.Ye = c_Ye.p;
-    q.xmean = c_xm.p; q.ymean = c_ym.p; q.evec = c_evec.p; q.eval = c_eval.p;
+    q.xmean = c_xm.p; q.ymean = c_ym.p;
     q.key = key(step);
     q.iter = iter;
     return q;
-}
-
-// symmetric eigendecomposition of C through rocSOLVER (the reference calls tf.linalg.svd, cma_es.py:195);
-// the library is loaded on first use so that nothing else in the engine depends on it.
-void Engine::cma_eig() {
-    typedef int (*create_t)(void**);
-    typedef int (*setstream_t)(void*, hipStream_t);
-    typedef int (*syevd_t)(void*, int, int, int, float*, int, long long, float*, long long, float*, long long, int*, int);
-    static create_t f_create = nullptr;
-    static setstream_t f_setstream = nullptr;
-    static syevd_t f_syevd = nullptr;
-    if (!f_syevd) {
-        void* h = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-        REQUIRE(h, BBMPC_E_UNSUPPORTED, std::string("CMA-ES needs rocSOLVER for the eigendecomposition: ") + dlerror());
-        void* hb = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!hb) hb = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-        REQUIRE(hb, BBMPC_E_UNSUPPORTED, "CMA-ES needs rocBLAS (handle for rocSOLVER)");
-        f_create = (create_t)dlsym(hb, "rocblas_create_handle");
-        f_setstream = (setstream_t)dlsym(hb, "rocblas_set_stream");
-        f_syevd = (syevd_t)dlsym(h, "rocsolver_ssyevd_strided_batched");
-        REQUIRE(f_create && f_setstream && f_syevd, BBMPC_E_UNSUPPORTED, "rocSOLVER/rocBLAS symbols not found");
-    }
-    if (!rocblas_h) REQUIRE(f_create(&rocblas_h) == 0, BBMPC_E_HIP, "rocblas_create_handle failed");
-    REQUIRE(f_setstream(rocblas_h, stream) == 0, BBMPC_E_HIP, "rocblas_set_stream failed");
-    const int n = cma_n, G = cma_G;
-    HIP_CHECK(hipMemcpyAsync(c_evec.p, c_C.p, (size_t)G * n * n * 4, hipMemcpyDeviceToDevice, stream));
-    const int st = f_syevd(rocblas_h, 211 /*rocblas_evect_original*/, 121 /*rocblas_fill_upper*/, n, c_evec.p, n,
-                           (long long)n * n, c_eval.p, (long long)n, c_E.p, (long long)n, c_info.p, G);
-    REQUIRE(st == 0, BBMPC_E_HIP, "rocsolver_ssyevd_strided_batched failed with status " + std::to_string(st));
 }
 
 // CMAESOptimizer._optimize  cma_es.py:129-213
@@ -278,8 +247,7 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
         hipLaunchKernelGGL(k_cma_paths, dim3(G), dim3(REFIT_THREADS), 0, stream, q);
         hipLaunchKernelGGL(k_cma_cov, dim3((n + 15) / 16, (n + 15) / 16, G), dim3(16, 16), 0, stream, q);
         HIP_CHECK(hipGetLastError());
-        cma_eig();
-        hipLaunchKernelGGL(k_cma_eig_post, dim3((unsigned)((gnn + 255) / 256)), dim3(256), 0, stream, q);
+        hipLaunchKernelGGL(k_cma_svd, dim3(G), dim3(REFIT_THREADS), 0, stream, q, c_evec.p, c_eval.p, c_info.p, 15);
         HIP_CHECK(hipGetLastError());
         if (trace_on) {
             ensure_trace();
@@ -1014,10 +982,12 @@ void Engine::get_state(const std::string& name, float* out, int64_t count) {
     HIP_CHECK(hipStreamSynchronize(stream));
     const size_t nm = (size_t)A * HU;
     const float* src = nullptr;
+    if (cfg.optimizer == BBMPC_OPT_CMAES) goto cma_names;     // "sigma"/"m" etc. mean the CMA-ES state there
     if (name == "prev_mean") src = d_prev_mean.p;
     else if (name == "mean") src = d_mean.p;
     else if (name == "var") src = d_var.p;
     else if (name == "sigma") src = d_sigma.p;
+cma_names:
     if (!src && cfg.optimizer == BBMPC_OPT_CMAES) {
         const size_t gn = (size_t)cma_G * cma_n, gnn = gn * cma_n;
         const float* v = nullptr;

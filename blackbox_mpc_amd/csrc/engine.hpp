@@ -93,7 +93,6 @@ struct Engine {
     CmaConst cma_c;
     DevBuf<float> c_w, c_m, c_sigma, c_C, c_B, c_Dd, c_ps, c_pc, c_BD, c_z, c_Ye, c_xm, c_ym, c_evec, c_eval, c_E;
     DevBuf<int> c_eidx, c_info;
-    void* rocblas_h = nullptr;
     // evaluate() scratch (grown on demand)
     DevBuf<float> d_eval_seq, d_eval_rew, d_step_a, d_step_b, d_step_c, d_step_d;
     // injected noise (internal layout), keyed by BBMPC_NOISE_*
@@ -138,7 +137,6 @@ struct Engine {
     void cma_init();
     void cma_reset_mean_sigma();
     CmaArgs cma_args(uint32_t step, uint32_t iter);
-    void cma_eig();
     OptArgs opt_args(uint32_t step, uint32_t iter) const;
     PsoState pso_state();
     void evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop, float* d_rew_out);

@@ -43,8 +43,6 @@ struct CmaArgs {
     float* Ye;               // [G][k][n]  (x_sorted - m)/sigma of the elites
     float* xmean;            // [G*n]
     float* ymean;            // [G*n]
-    float* evec;             // [G][n][n] eigenvectors from the solver (column-major)
-    float* eval;             // [G*n] eigenvalues ascending
     RngKey key;
     uint32_t iter;
     const float* inj;        // injected z (internal layout) or null
@@ -215,15 +213,83 @@ __global__ void k_cma_cov(CmaArgs p) {
     C[(size_t)c * n + r] = v;
 }
 
-// eigenpairs (ascending, column-major vectors) -> B (columns by descending eigenvalue), D = sqrt(s)   (:195-198)
-__global__ void k_cma_eig_post(CmaArgs p) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nn = (size_t)p.n * p.n;
-    if (i >= nn * p.G) return;
-    const int g = (int)(i / nn), r = (int)((i % nn) / p.n), c = (int)(i % p.n);
-    const int src = p.n - 1 - c;
-    p.B[i] = p.evec[(size_t)g * nn + (size_t)src * p.n + r];
-    if (r == 0) p.Dd[(size_t)g * p.n + c] = sqrtf(fabsf(p.eval[(size_t)g * p.n + src]));   // singular value = |eigenvalue|
+// SVD of the symmetric covariance, s,U,_ = tf.linalg.svd(C)  (cma_es.py:195): B = U, D = diag(sqrt(s)).
+//
+// One-sided (Hestenes) Jacobi: rotate pairs of columns of A (= C) until they are mutually orthogonal;
+// then A V = U diag(s), so s_j = |a_j| and u_j = a_j / s_j.  Only column-pair operations are needed, and
+// the n/2 pairs of a round-robin round touch disjoint columns, so a round is embarrassingly parallel:
+// one workgroup per CMA-ES instance, one wave per pair, lanes along the column.  Columns are kept as
+// ROWS of At (C is symmetric, so At = C to start with) to make every access contiguous.  Singular values
+// are sorted descending at the end, as TF returns them.
+// scratch: At [G][n][n], norms [G*n], perm (int) [G*n]
+__global__ __launch_bounds__(REFIT_THREADS) void k_cma_svd(CmaArgs p, float* At_all, float* norms_all, int* perm_all,
+                                                           int max_sweeps) {
+    __shared__ int s_rotated;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
+    constexpr int NW = REFIT_THREADS / 64;
+    const size_t nn = (size_t)n * n;
+    float* At = At_all + (size_t)g * nn;
+    const float* C = p.C + (size_t)g * nn;
+    for (size_t i = tid; i < nn; i += REFIT_THREADS) At[i] = C[i];
+    __syncthreads();
+    const int m = (n + 1) & ~1;                 // players of the round-robin (one dummy when n is odd)
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (tid == 0) s_rotated = 0;
+        __syncthreads();
+        for (int r = 0; r < m - 1; ++r) {
+            for (int i = wv; i < m / 2; i += NW) {
+                int pa, pb;
+                if (i == 0) { pa = m - 1; pb = r; }
+                else { pa = (r + i) % (m - 1); pb = (r - i + (m - 1)) % (m - 1); }
+                if (pa >= n || pb >= n) continue;                        // dummy player sits out
+                float* x = At + (size_t)pa * n;
+                float* y = At + (size_t)pb * n;
+                float al = 0.0f, be = 0.0f, ga = 0.0f;
+                for (int e = lane; e < n; e += 64) {
+                    const float xv = x[e], yv = y[e];
+                    al = fmaf(xv, xv, al); be = fmaf(yv, yv, be); ga = fmaf(xv, yv, ga);
+                }
+                al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
+                if (fabsf(ga) <= 2e-6f * sqrtf(al * be) || ga == 0.0f) continue;   // fp32 dot-product noise floor
+                const float zeta = (be - al) / (2.0f * ga);
+                const float t = copysignf(1.0f, zeta) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
+                const float cs = 1.0f / sqrtf(1.0f + t * t), sn = cs * t;
+                for (int e = lane; e < n; e += 64) {
+                    const float xv = x[e], yv = y[e];
+                    x[e] = cs * xv - sn * yv;
+                    y[e] = sn * xv + cs * yv;
+                }
+                if (lane == 0) s_rotated = 1;
+            }
+            __syncthreads();
+        }
+        if (!s_rotated) break;
+    }
+    // singular values = column norms; order them descending (ties -> lower index)
+    float* norms = norms_all + (size_t)g * n;
+    int* perm = perm_all + (size_t)g * n;
+    for (int j = wv; j < n; j += NW) {
+        float al = 0.0f;
+        for (int e = lane; e < n; e += 64) { const float v = At[(size_t)j * n + e]; al = fmaf(v, v, al); }
+        al = wave_sum(al);
+        if (lane == 0) norms[j] = sqrtf(al);
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += REFIT_THREADS) {
+        const float nj = norms[j];
+        int rank = 0;
+        for (int o = 0; o < n; ++o) rank += (norms[o] > nj || (norms[o] == nj && o < j)) ? 1 : 0;
+        perm[rank] = j;
+    }
+    __syncthreads();
+    float* B = p.B + (size_t)g * nn;
+    for (size_t i = tid; i < nn; i += REFIT_THREADS) {
+        const int r = (int)(i / n), c = (int)(i % n);
+        const int src = perm[c];
+        const float sv = norms[src];
+        B[i] = (sv > 0.0f) ? At[(size_t)src * n + r] / sv : ((r == c) ? 1.0f : 0.0f);
+    }
+    for (int c = tid; c < n; c += REFIT_THREADS) p.Dd[(size_t)g * n + c] = sqrtf(norms[perm[c]]);   // D = diag(sqrt(s))
 }
 
 }  // namespace bbmpc
