@@ -13,7 +13,7 @@ for CFG in cfg2 cfg3 cfg4 cfg5cem; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/$CFG -o fetch -- python bench.py --config $CFG --steps 20 --warmup 2 --no-cpu-baseline > $OUT/$CFG.fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/$CFG -o write -- python bench.py --config $CFG --steps 20 --warmup 2 --no-cpu-baseline > $OUT/$CFG.write.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU -f csv -d $OUT/$CFG -o sq -- python bench.py --config $CFG --steps 20 --warmup 2 --no-cpu-baseline > $OUT/$CFG.sq.log 2>&1
-  tail -1 $OUT/$CFG.bench.log > $OUT/$CFG.bench.json
+  grep "^{\"metric\"" $OUT/$CFG.bench.log | tail -1 > $OUT/$CFG.bench.json
 done
 python tools/summarize_profiles.py $OUT $TAG
 ls -la profiles/ gpurun_out/profiles_$TAG 2>/dev/null | head -30
