@@ -49,12 +49,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    # BBMPC_BENCH_BACKEND=gloo + BBMPC_BENCH_ONE_DEVICE=1: rank-logic smoke test on a 1-GPU box (all ranks share
+    # device 0, records gathered through host memory); the real runs use nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("BBMPC_BENCH_BACKEND", "nccl")
+    if os.environ.get("BBMPC_BENCH_ONE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     from blackbox_mpc_amd import _build
     _build.build()
@@ -95,7 +103,13 @@ def main():
         # the control step already produced IS the next observation -- it never leaves HBM.
         eng.optimize_dev(state.data_ptr(), record.data_ptr(), d_next_state=nxt.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, record)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, record)
+            else:
+                host = record.cpu()
+                out = torch.empty((world * A, rec), dtype=torch.float32)
+                dist.all_gather_into_tensor(out, host)
+                gathered.copy_(out)
         state, nxt = nxt, state
 
     def fence():
@@ -116,7 +130,7 @@ def main():
     roll_ms, roll_n, kname = eng.get_profile()
     eng.set_profiling(False)
 
-    elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
@@ -155,6 +169,17 @@ def main():
                     "note": "the fused kernel keeps the H-step recurrence in registers/LDS: the path is VALU-issue "
                             "bound, the HBM fraction is nominal (DESIGN.md)"}
         roof.update({"kernel": kname, "avg_launch_us": avg_ms * 1e3, "launches": roll_n})
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+        # collected separately, (2*FETCH + WRITE)*1024 -- tools/profile_round.sh, profiles/*_hbm_traffic.json)
+        try:
+            import glob
+            tr = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]))
+            hit = [v for kn, v in tr.get(args.config, {}).items() if kname in kn]
+            if hit and world == 1:
+                roof["traffic"] = hit[0]
+                roof["traffic_source"] = "profiles/ (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes)"
+        except Exception:
+            pass
         out = {
             "metric": "MPC control-steps/sec (agent-control-steps; %s, %s N=%d H=%d)"
                       % ("HalfCheetah learned MLP 26-200-200-20" if mlp else "Pendulum true model", c["opt"], N, H),

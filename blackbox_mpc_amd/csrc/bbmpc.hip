@@ -421,15 +421,18 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     if (small_io && mlp.n_layers == 4 && mlp.tiles[1] == mlp.tiles[2] && mlp.tiles[2] == mlp.tiles[3] && mlp.tiles[1] <= 4 &&
         mlp_nw == mlp.tiles[1]) spec = 2;
     if (getenv("BBMPC_MLP_GENERIC")) spec = 0;
-    const void* fn = spec == 1 ? (const void*)k_rollout_mlp<1> : (spec == 2 ? (const void*)k_rollout_mlp<2> : (const void*)k_rollout_mlp<0>);
-    static bool configured[3] = {false, false, false};
+    const bool single_step = per_particle_state && ra.H == 1;
+    if (single_step) spec = 3;
+    const void* fn = spec == 3 ? (const void*)k_step_mlp : spec == 1 ? (const void*)k_rollout_mlp<1> : (spec == 2 ? (const void*)k_rollout_mlp<2> : (const void*)k_rollout_mlp<0>);
+    static bool configured[4] = {false, false, false, false};
     if (lds > 64 * 1024 && !configured[spec]) {
         HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         configured[spec] = true;
     }
     dim3 grid((ra.n_pop + MLP_TP - 1) / MLP_TP, per_particle_state ? 1 : A), block(mlp_nw * 64);
     prof_begin();
-    if (spec == 1) hipLaunchKernelGGL(k_rollout_mlp<1>, grid, block, lds, stream, q);
+    if (spec == 3) hipLaunchKernelGGL(k_step_mlp, grid, block, lds, stream, q);
+    else if (spec == 1) hipLaunchKernelGGL(k_rollout_mlp<1>, grid, block, lds, stream, q);
     else if (spec == 2) hipLaunchKernelGGL(k_rollout_mlp<2>, grid, block, lds, stream, q);
     else hipLaunchKernelGGL(k_rollout_mlp<0>, grid, block, lds, stream, q);
     HIP_CHECK(hipGetLastError());

@@ -180,7 +180,7 @@ __device__ __forceinline__ int tile_addr(int f, int p) {
 //           S+U <= 32, S <= 32            e.g. 26-200-200-20 (BASELINE configs 4-5): 68 weight VGPRs
 //   SPEC 2: 3 hidden layers of equal width <= 64, S+U <= 32, S <= 32   e.g. 4-32-32-32-3 (low-level tutorial)
 template <int SPEC>
-__global__ void k_rollout_mlp(MlpRolloutArgs q) {
+__device__ __forceinline__ void rollout_mlp_body(const MlpRolloutArgs& q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutArgs& p = q.r;
     const MlpDesc& m = q.m;
@@ -422,6 +422,16 @@ __global__ void k_rollout_mlp(MlpRolloutArgs q) {
             if (n < p.n_pop) q.final_state[((size_t)a * p.n_pop + n) * S + s] = fin[pp * Sp + s];
         }
     }
+}
+
+template <int SPEC>
+__global__ void k_rollout_mlp(MlpRolloutArgs q) {
+    rollout_mlp_body<SPEC>(q);
+}
+// same body under its own name for the H = 1 model step (predict_next_state / the __call__ tail), so that
+// profiler averages of the rollout kernel are not diluted by the tiny launches
+__global__ void k_step_mlp(MlpRolloutArgs q) {
+    rollout_mlp_body<0>(q);
 }
 
 // ---- small helpers for the OptimizerBase.__call__ tail on the learned-dynamics path ----------------
