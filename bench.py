@@ -94,25 +94,41 @@ def main():
 
     state = torch.from_numpy(start).to(dev)
     nxt = torch.empty_like(state)
-    record = torch.zeros((A, rec), device=dev, dtype=torch.float32)
-    gathered = torch.zeros((world * A, rec), device=dev, dtype=torch.float32) if world > 1 else None
+    # records / gathered results are double buffered: the all-gather of control step t runs on its own stream
+    # while step t+1 computes (the local optimizer never needs the other ranks' records)
+    records = [torch.zeros((A, rec), device=dev, dtype=torch.float32) for _ in range(2)]
+    gathered = [torch.zeros((world * A, rec), device=dev, dtype=torch.float32) for _ in range(2)] if world > 1 else None
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    comm_done = [None, None]
+    tick = [0]
 
     def control_step():
         nonlocal state, nxt
+        b = tick[0] & 1
+        tick[0] += 1
+        record = records[b]
+        if comm_done[b] is not None:
+            stream.wait_event(comm_done[b])          # the gather that last read this buffer has finished
         # closed loop: the environment is the engine's own model, so the predicted next state
         # the control step already produced IS the next observation -- it never leaves HBM.
         eng.optimize_dev(state.data_ptr(), record.data_ptr(), d_next_state=nxt.data_ptr())
         if world > 1:
-            if backend == "nccl":
-                dist.all_gather_into_tensor(gathered, record)
-            else:
-                host = record.cpu()
-                out = torch.empty((world * A, rec), dtype=torch.float32)
-                dist.all_gather_into_tensor(out, host)
-                gathered.copy_(out)
+            ready = torch.cuda.Event()
+            ready.record(stream)
+            comm_stream.wait_event(ready)
+            with torch.cuda.stream(comm_stream):
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(gathered[b], record)
+                else:
+                    out = torch.empty((world * A, rec), dtype=torch.float32)
+                    dist.all_gather_into_tensor(out, record.cpu())
+                    gathered[b].copy_(out)
+                comm_done[b] = torch.cuda.Event()
+                comm_done[b].record(comm_stream)
         state, nxt = nxt, state
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
