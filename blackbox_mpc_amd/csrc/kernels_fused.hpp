@@ -193,22 +193,25 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             BB_DBG(4 + it * 4);
             if (p.t_elites)
                 for (int e = tid; e < p.k; e += nthr) p.t_elites[((size_t)it * p.A + a) * p.k + e] = eidx[e];
-            // elite statistics (cem.py:112-125): one wave per (h,u) row, lanes over the elites; mean and
-            // biased variance by wave butterfly sums (two-pass, as the reference computes it).
+            // elite statistics (cem.py:112-125): one 16-lane DPP row per (h,u) element -- 4 elements per wave,
+            // every element of the horizon at once for H*U <= 4*waves; mean and biased variance two-pass,
+            // as the reference computes them.
             const float kf = (float)p.k;
-            for (int j = tid >> 6; j < p.HU; j += nw) {
-                const float* row = samp + (size_t)j * p.Nst;
+            const int sub = tid & 15;
+            for (int j = tid >> 4; j < ((p.HU + 3) & ~3); j += nthr >> 4) {       // all 16 lanes of a row share j
+                const bool live = j < p.HU;
+                const float* row = samp + (size_t)(live ? j : 0) * p.Nst;
                 float sum = 0.0f;
-                for (int e = tid & 63; e < p.k; e += 64) sum += row[eidx[e]];
-                sum = wave_sum(sum);
+                for (int e = sub; e < p.k; e += 16) sum += row[eidx[e]];
+                sum = row16_sum(sum);
                 const float em = sum / kf;                                       // cem.py:112
                 float vs = 0.0f;
-                for (int e = tid & 63; e < p.k; e += 64) {
+                for (int e = sub; e < p.k; e += 16) {
                     const float d = row[eidx[e]] - em;
                     vs += d * d;
                 }
-                vs = wave_sum(vs);
-                if ((tid & 63) == 0) {
+                vs = row16_sum(vs);
+                if (live && sub == 0) {
                     const float ev = vs / kf;                                    // cem.py:113-119
                     const float one_m = 1.0f - p.alpha;
                     const float m = p.alpha * mean[j] + one_m * em;              // cem.py:121-122

@@ -12,15 +12,48 @@ namespace bbmpc {
 
 constexpr int REFIT_THREADS = 1024;
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane primitives on DPP row operations (no LDS round trip; a ds_bpermute-based __shfl costs ~100+
+// cycles per step, a DPP-modified v_add ~8) -------------------------------------------------------------------
+#define BB_DPP_QUAD_XOR1 0xB1      /* quad_perm [1,0,3,2] */
+#define BB_DPP_QUAD_XOR2 0x4E      /* quad_perm [2,3,0,1] */
+#define BB_DPP_ROW_HALF_MIRROR 0x141
+#define BB_DPP_ROW_MIRROR 0x140
+#define BB_DPP_ROW_SHR(n) (0x110 + (n))
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+// every lane of a 16-lane row ends up with the row's sum
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<BB_DPP_QUAD_XOR1>(v);
+    v += dpp_f<BB_DPP_QUAD_XOR2>(v);
+    v += dpp_f<BB_DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f<BB_DPP_ROW_MIRROR>(v);
     return v;
 }
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_min(float v) {
+    v = fminf(v, dpp_f<BB_DPP_QUAD_XOR1>(v));
+    v = fminf(v, dpp_f<BB_DPP_QUAD_XOR2>(v));
+    v = fminf(v, dpp_f<BB_DPP_ROW_HALF_MIRROR>(v));
+    v = fminf(v, dpp_f<BB_DPP_ROW_MIRROR>(v));
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    const int i = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
+}
+__device__ __forceinline__ float wave_min(float v) {
+    v = row16_min(v);
+    const int i = __float_as_int(v);
+    return fminf(fminf(__int_as_float(__builtin_amdgcn_readlane(i, 0)), __int_as_float(__builtin_amdgcn_readlane(i, 16))),
+                 fminf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
 }
 // (value,index) arg-max with tf.math.argmax tie rule: first (lowest index) maximum wins.
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {

@@ -12,6 +12,13 @@
 
 namespace bbmpc {
 
+#ifdef BBMPC_TOPK_DBG
+__device__ long long g_topk_dbg[32];
+#define TK(slot) do { if (tid == 0 && blockIdx.x == 0) g_topk_dbg[(slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define TK(slot) do {} while (0)
+#endif
+
 constexpr int TOPK_HIST_WORDS = 272;   // 256 bins + 16 control words (256.. bucket, 257 wanted, 258 bucket size,
                                        // 259 compaction cursor, 260/261 key min/max)
 
@@ -22,13 +29,18 @@ __device__ __forceinline__ uint32_t reward_key(float r) {
     return ~asc;
 }
 
+// inclusive prefix sum over the 64 lanes: DPP row_shr scan inside each 16-lane row, row totals via readlane
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-    return v;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    const int t0 = __builtin_amdgcn_readlane(x, 15), t1 = __builtin_amdgcn_readlane(x, 31),
+              t2 = __builtin_amdgcn_readlane(x, 47);
+    const int row = lane >> 4;
+    x += (row >= 1 ? t0 : 0) + (row >= 2 ? t1 : 0) + (row >= 3 ? t2 : 0);
+    return (uint32_t)x;
 }
 
 // vals[N] in LDS (left untouched); eidx[k] out; hist[TOPK_HIST_WORDS] and ekeys[k] are LDS scratch.
@@ -36,6 +48,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int k, int* eidx, uint32_t* hist,
                                                   unsigned long long* ekeys, int tid, int nthr) {
     const int lane = tid & 63;
+    TK(0);
     // Key range first: digits are taken from the highest bit where min and max differ.  Rewards of one
     // population mostly share sign + exponent, so a fixed top-8-bit digit would send a whole wave's
     // ds_add_u32 to one or two bins (serialised); digits below the common prefix spread over the bins.
@@ -56,12 +69,15 @@ __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int 
     __syncthreads();
     kmin = hist[260];
     kmax = hist[261];
+    TK(1);
     const uint32_t diff = kmin ^ kmax;
     int top = diff ? 32 - __clz(diff) : 0;        // number of low bits that are not common to all keys
     uint32_t T = (top >= 32) ? 0u : (kmin >> top) << top;   // common high bits
     uint32_t remaining = (uint32_t)k;
     if (top == 0 && tid == 0) hist[258] = (uint32_t)N;       // every key equal
+    int passno = 0;
     while (top > 0) {
+        TK(2 + 4 * passno);
         const int width = top >= 8 ? 8 : top;
         const int shift = top - width;
         const uint32_t dmask = (1u << width) - 1u;
@@ -73,6 +89,7 @@ __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int 
             if (in) atomicAdd(&hist[(key >> shift) & dmask], 1u);
         }
         __syncthreads();
+        TK(3 + 4 * passno);
         if (tid < 64) {
             const uint4 c = *reinterpret_cast<const uint4*>(hist + 4 * lane);
             const uint32_t s = c.x + c.y + c.z + c.w;
@@ -88,22 +105,31 @@ __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int 
                 hist[258] = cnt;                 // how many keys the bucket holds
             }
         }
+        TK(4 + 4 * passno);
         __syncthreads();
+        TK(5 + 4 * passno);
+        ++passno;
         T |= hist[256] << shift;
         remaining = hist[257];
-        top = shift;
+        const bool whole_bucket = hist[258] == remaining;     // every key of the boundary bucket is a winner:
+        top = shift;                                            // the undecided low bits no longer matter
         __syncthreads();
+        if (whole_bucket) break;
     }
     // T is now the key of the k-th best
+    TK(20);
     if (tid == 0) hist[259] = 0;
     __syncthreads();
     const uint32_t eq_total = hist[258];         // population members with exactly that key
+    // `top` low bits may be undecided after an early exit; compare on the decided prefix
+    const uint32_t Tp = (top >= 32) ? 0u : (T >> top);
     for (int n = tid; n < N; n += nthr) {
         const uint32_t key = reward_key(vals[n]);
-        bool take = key < T;
-        if (key == T) {
-            if (eq_total == remaining) take = true;              // every tied member is in
-            else {                                               // rare: lowest indices among the ties win
+        const uint32_t kp_ = (top >= 32) ? 0u : (key >> top);
+        bool take = kp_ < Tp;
+        if (kp_ == Tp) {
+            if (eq_total == remaining) take = true;              // the whole boundary bucket is in
+            else {                                               // top == 0 here: exact ties, lowest indices win
                 uint32_t before = 0;
                 for (int m = 0; m < n; ++m) before += (reward_key(vals[m]) == T) ? 1u : 0u;
                 take = before < remaining;
@@ -115,6 +141,7 @@ __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int 
         }
     }
     __syncthreads();
+    TK(21);
     // rank the k winners among themselves with the whole workgroup: thread (e, chunk) counts how many
     // winners in its chunk precede winner e, partial counts meet in LDS (eidx doubles as the counter array).
     for (int e = tid; e < k; e += nthr) eidx[e] = 0;
@@ -139,6 +166,7 @@ __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int 
     __syncthreads();                                 // callers guarantee k <= nthr
     if (myrank >= 0) eidx[myrank] = myidx;
     __syncthreads();
+    TK(22);
 }
 
 }  // namespace bbmpc
