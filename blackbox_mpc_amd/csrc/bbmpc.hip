@@ -536,11 +536,11 @@ bool Engine::use_fused() const {
     return (long)N <= 2048 || A >= 64;
 }
 
-template <int OPT, bool FASTM, bool INJ>
-static void launch_fused3(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
+template <int OPT, bool FASTM, bool INJ, int ILP>
+static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
     const size_t limit = 159 * 1024;   // 160 KiB per CU minus the kernel's small static LDS
     if (lds_base + lds_samples <= limit) {
-        auto fn = k_fused_pendulum<OPT, true, FASTM, INJ>;
+        auto fn = k_fused_pendulum<OPT, true, FASTM, INJ, ILP>;
         static bool configured = false;
         if (!configured) {
             HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limit));
@@ -548,20 +548,26 @@ static void launch_fused3(Engine& e, FusedArgs& fa, int threads, size_t lds_base
         }
         hipLaunchKernelGGL(fn, dim3(e.A), dim3(threads), lds_base + lds_samples, e.stream, fa);
     } else {
-        auto fn = k_fused_pendulum<OPT, false, FASTM, INJ>;
+        auto fn = k_fused_pendulum<OPT, false, FASTM, INJ, ILP>;
         hipLaunchKernelGGL(fn, dim3(e.A), dim3(threads), lds_base, e.stream, fa);
     }
     HIP_CHECK(hipGetLastError());
 }
 
 template <int OPT>
-static void launch_fused(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
+static void launch_fused(Engine& e, FusedArgs& fa, int ilp, int threads, size_t lds_base, size_t lds_samples) {
     const bool fastm = !e.fix(BBMPC_STRICT_MATH);
     const bool inj = fa.inj != nullptr;
-    if (fastm && !inj) launch_fused3<OPT, true, false>(e, fa, threads, lds_base, lds_samples);
-    else if (fastm && inj) launch_fused3<OPT, true, true>(e, fa, threads, lds_base, lds_samples);
-    else if (!fastm && !inj) launch_fused3<OPT, false, false>(e, fa, threads, lds_base, lds_samples);
-    else launch_fused3<OPT, false, true>(e, fa, threads, lds_base, lds_samples);
+#define LF(F, I)                                                                              \
+    do {                                                                                      \
+        if (ilp == 2) launch_fused4<OPT, F, I, 2>(e, fa, threads, lds_base, lds_samples);    \
+        else launch_fused4<OPT, F, I, 1>(e, fa, threads, lds_base, lds_samples);             \
+    } while (0)
+    if (fastm && !inj) LF(true, false);
+    else if (fastm && inj) LF(true, true);
+    else if (!fastm && !inj) LF(false, false);
+    else LF(false, true);
+#undef LF
 }
 
 void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step) {
@@ -594,7 +600,11 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
         fa.dbg = dbg_buf;
     }
     fa.key = key(step);
-    const int threads = std::min(1024, ((N + 63) / 64) * 64);
+    // two trajectories per lane (one wave per SIMD for N <= 512) unless overridden
+    int ilp = 2;
+    if (const char* e_ilp = getenv("BBMPC_ILP")) ilp = atoi(e_ilp) == 1 ? 1 : 2;
+    const int per = (N + ilp - 1) / ilp;
+    const int threads = std::min(1024, std::max(((per + 63) / 64) * 64, ((std::max(k, 1) + 63) / 64) * 64));   // top-k needs k <= threads
     const int HUp = (HU + 3) & ~3, kp = (std::max(k, 1) + 3) & ~3;
     int tile_floats = 0;
     fa.tile_floats = tile_floats;
@@ -602,9 +612,9 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     const size_t lds_samples = (size_t)HU * Nst * 4;
     prof_begin();
     switch (cfg.optimizer) {
-        case BBMPC_OPT_RANDOM_SEARCH: launch_fused<FOPT_RS>(*this, fa, threads, lds_base, lds_samples); break;
-        case BBMPC_OPT_CEM: launch_fused<FOPT_CEM>(*this, fa, threads, lds_base, lds_samples); break;
-        default: launch_fused<FOPT_PI2>(*this, fa, threads, lds_base, lds_samples); break;
+        case BBMPC_OPT_RANDOM_SEARCH: launch_fused<FOPT_RS>(*this, fa, ilp, threads, lds_base, lds_samples); break;
+        case BBMPC_OPT_CEM: launch_fused<FOPT_CEM>(*this, fa, ilp, threads, lds_base, lds_samples); break;
+        default: launch_fused<FOPT_PI2>(*this, fa, ilp, threads, lds_base, lds_samples); break;
     }
     prof_end();
     if (fa.dbg) {

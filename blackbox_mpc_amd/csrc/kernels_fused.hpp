@@ -74,7 +74,7 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nw)
 
 // LDS carve (4-byte words): rewards[Nst] | mean[HUp] | var[HUp] | sigma[HUp] | eidx[kp] | red[64] | hist[272] |
 //                            ekeys[2*kp] | tile[tile_floats] | samples[HU][Nst]      (every piece a multiple of 16 B)
-template <int OPT, bool SAMPLES_LDS, bool FASTM, bool INJ>
+template <int OPT, bool SAMPLES_LDS, bool FASTM, bool INJ, int ILP>
 __global__ void k_fused_pendulum(FusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int a = blockIdx.x;
@@ -121,11 +121,23 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         const float* inj = INJ ? p.inj + ((size_t)it * p.A + a) * p.HU * p.Nst : nullptr;
         const int nblk = p.H >> 2, rem = p.H & 3;
         const uint32_t rstream = (OPT == FOPT_RS) ? 2u : 1u;
-        for (int n = tid; n < p.N; n += nthr) {
-            Roller<FASTM> roll(p.fix_q1 != 0, s0, s1, s2);
-            float total = 0.0f, pen = 0.0f;
-            float xn[4];
-            auto gen = [&](int b, float (&x)[4]) {
+        // ILP independent trajectories per lane: with half as many waves each SIMD runs a single wave whose two
+        // recurrences interleave in program order, instead of two waves fighting over issue slots.
+        for (int n0 = tid; n0 < p.N; n0 += ILP * nthr) {
+            int nn[ILP];
+            bool live[ILP];
+            Roller<FASTM> roll[ILP];
+            float total[ILP], pen[ILP], xn[ILP][4];
+#pragma unroll
+            for (int q = 0; q < ILP; ++q) {
+                live[q] = n0 + q * nthr < p.N;
+                nn[q] = live[q] ? n0 + q * nthr : n0;          // idle slots shadow particle n0 (never stored)
+                roll[q].init(p.fix_q1 != 0, s0, s1, s2);
+                total[q] = 0.0f;
+                pen[q] = 0.0f;
+            }
+            auto gen = [&](int q, int b) {
+                const int n = nn[q];
                 float xi[4];
                 if (INJ) {
 #pragma unroll
@@ -141,38 +153,48 @@ __global__ void k_fused_pendulum(FusedArgs p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int t = min(4 * b + i, p.H - 1);
-                    float v;
-                    if (OPT == FOPT_RS) v = xi[i] * (hi - lo) + lo;              // random_search.py:40-41
-                    else v = xi[i] * sigma[t] + mean[t];                         // cem.py:90-94 / pi2.py:65-69
-                    x[i] = v;
+                    if (OPT == FOPT_RS) xn[q][i] = xi[i] * (hi - lo) + lo;      // random_search.py:40-41
+                    else xn[q][i] = xi[i] * sigma[t] + mean[t];                 // cem.py:90-94 / pi2.py:65-69
                 }
             };
-            auto consume = [&](int t, float x) {
+            auto consume = [&](int q, int t, float x) {
                 if (OPT == FOPT_PI2) {                                           // pi2.py:70-75
                     const float xf = clipf(x, lo, hi);
                     const float d = x - xf;
-                    pen = pen + d * d;
+                    pen[q] = pen[q] + d * d;
                     x = xf;
                 }
-                samp[(size_t)t * p.Nst + n] = x;
-                total = total + roll.step(x);
+                if (live[q]) samp[(size_t)t * p.Nst + nn[q]] = x;
+                total[q] = total[q] + roll[q].step(x);
             };
-            gen(0, xn);
+#pragma unroll
+            for (int q = 0; q < ILP; ++q) gen(q, 0);
             for (int b = 0; b < nblk; ++b) {
-                const float x0 = xn[0], x1 = xn[1], x2 = xn[2], x3 = xn[3];
-                gen(b + 1, xn);          // one block ahead (the block past the end is generated and dropped)
-                consume(4 * b + 0, x0);
-                consume(4 * b + 1, x1);
-                consume(4 * b + 2, x2);
-                consume(4 * b + 3, x3);
+                float xc[ILP][4];
+#pragma unroll
+                for (int q = 0; q < ILP; ++q) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xc[q][i] = xn[q][i];
+                    gen(q, b + 1);       // one block ahead (the block past the end is generated and dropped)
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < ILP; ++q) consume(q, 4 * b + i, xc[q][i]);
             }
-            for (int i = 0; i < rem; ++i) consume(4 * nblk + i, xn[i]);
-            if (total != total) total = -1.0e6f;                             // deterministic.py:75-77
-            if (OPT == FOPT_PI2) {
-                const float nr = sqrtf(pen);
-                total = total - nr * nr;
+            for (int i = 0; i < rem; ++i)
+#pragma unroll
+                for (int q = 0; q < ILP; ++q) consume(q, 4 * nblk + i, xn[q][i]);
+#pragma unroll
+            for (int q = 0; q < ILP; ++q) {
+                float tot = total[q];
+                if (tot != tot) tot = -1.0e6f;                                   // deterministic.py:75-77
+                if (OPT == FOPT_PI2) {
+                    const float nr = sqrtf(pen[q]);
+                    tot = tot - nr * nr;
+                }
+                if (live[q]) rew[nn[q]] = tot;
             }
-            rew[n] = total;
         }
         if (p.dbg && a == 0 && it == 0 && (tid & 63) == 0) dbg_lds[24 + (tid >> 6) % 8] = (long long)wall_clock64();
         BB_DBG(2 + it * 4);

@@ -139,7 +139,12 @@ template <>
 struct Roller<false> {
     PendulumModel m;
     float s[3];
+    __device__ __forceinline__ Roller() : m{false} {}
     __device__ __forceinline__ Roller(bool fix_q1, float s0, float s1, float s2) : m{fix_q1} {
+        s[0] = s0; s[1] = s1; s[2] = s2;
+    }
+    __device__ __forceinline__ void init(bool fix_q1, float s0, float s1, float s2) {
+        m.fix_q1 = fix_q1;
         s[0] = s0; s[1] = s1; s[2] = s2;
     }
     __device__ __forceinline__ float step(float u) {
@@ -150,7 +155,12 @@ struct Roller<false> {
 template <>
 struct Roller<true> {
     PendulumAngleModel m;
+    __device__ __forceinline__ Roller() {}
     __device__ __forceinline__ Roller(bool fix_q1, float s0, float s1, float s2) {
+        m.fix_q1 = fix_q1;
+        m.init(s0, s1, s2);
+    }
+    __device__ __forceinline__ void init(bool fix_q1, float s0, float s1, float s2) {
         m.fix_q1 = fix_q1;
         m.init(s0, s1, s2);
     }
