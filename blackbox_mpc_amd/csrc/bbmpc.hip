@@ -12,6 +12,42 @@ static thread_local std::string g_last_error;
 // ------------------------------------------------------------------------------------------------
 // construction
 // ------------------------------------------------------------------------------------------------
+// truncated-normal quantile table (rng.hpp): q(i/2048) in float64 -> fp32, uploaded once per device
+static double erfinv_d(double y) {
+    // Newton on erf from a Giles-type start; converges to double precision in a few steps for |y| < 0.96
+    double w = -log((1.0 - y) * (1.0 + y)), x;
+    if (w < 5.0) {
+        w -= 2.5;
+        x = 2.81022636e-08; x = 3.43273939e-07 + x * w; x = -3.5233877e-06 + x * w; x = -4.39150654e-06 + x * w;
+        x = 0.00021858087 + x * w; x = -0.00125372503 + x * w; x = -0.00417768164 + x * w; x = 0.246640727 + x * w;
+        x = 1.50140941 + x * w;
+    } else {
+        w = sqrt(w) - 3.0;
+        x = -0.000200214257; x = 0.000100950558 + x * w; x = 0.00134934322 + x * w; x = -0.00367342844 + x * w;
+        x = 0.00573950773 + x * w; x = -0.0076224613 + x * w; x = 0.00943887047 + x * w; x = 1.00167406 + x * w;
+        x = 2.83297682 + x * w;
+    }
+    x *= y;
+    for (int it = 0; it < 4; ++it) x -= (erf(x) - y) / (1.1283791670955126 * exp(-x * x));
+    return x;
+}
+
+static void init_tnq_table() {
+    static std::map<int, bool> done;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (done[dev]) return;
+    std::vector<float> q(TNQ_SIZE + 1);
+    const double p2 = erf(sqrt(2.0));                       // P(|z| < 2)
+    for (int i = 0; i <= TNQ_SIZE; ++i) q[i] = (float)(sqrt(2.0) * erfinv_d((2.0 * i / TNQ_SIZE - 1.0) * p2));
+    q[0] = -2.0f;
+    q[TNQ_SIZE] = 2.0f;
+    std::vector<float2> tab(TNQ_SIZE);
+    for (int i = 0; i < TNQ_SIZE; ++i) tab[i] = make_float2(q[i], q[i + 1] - q[i]);
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tnq), tab.data(), sizeof(float2) * TNQ_SIZE));
+    done[dev] = true;
+}
+
 static void upload(DevBuf<float>& b, const std::vector<float>& v) {
     b.alloc(v.size());
     HIP_CHECK(hipMemcpy(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -62,6 +98,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
     }
     HIP_CHECK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
     stream = own_stream;
+    init_tnq_table();
 
     if (const char* fm = getenv("BBMPC_FUSED")) fused_mode = atoi(fm);
     HU = H * U;
@@ -601,8 +638,8 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     }
     fa.key = key(step);
     // two trajectories per lane (one wave per SIMD for N <= 512) unless overridden
-    int ilp = 2;
-    if (const char* e_ilp = getenv("BBMPC_ILP")) ilp = atoi(e_ilp) == 1 ? 1 : 2;
+    int ilp = 1;                 // measured: 2 waves/SIMD x 1 trajectory beats 1 wave/SIMD x 2 trajectories
+    if (const char* e_ilp = getenv("BBMPC_ILP")) ilp = atoi(e_ilp) == 2 ? 2 : 1;
     const int per = (N + ilp - 1) / ilp;
     const int threads = std::min(1024, std::max(((per + 63) / 64) * 64, ((std::max(k, 1) + 63) / 64) * 64));   // top-k needs k <= threads
     const int HUp = (HU + 3) & ~3, kp = (std::max(k, 1) + 3) & ~3;

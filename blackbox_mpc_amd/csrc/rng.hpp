@@ -19,9 +19,13 @@
 //
 // Standard draws from a word x:
 //   U(0,1)      : u = ((x >> 9) + 0.5) * 2^-23           (23 random mantissa bits, never 0 or 1)
-//   trunc normal: z = sqrt(2) * erfinv((2u-1) * erf(sqrt 2))   -- exact inverse-CDF of N(0,1)
-//                 conditioned on |z| < 2, the distribution tf.random.truncated_normal samples
-//                 by rejection; one uniform per draw, no loop.
+//   trunc normal: inverse-CDF sampling of N(0,1) conditioned on |z| < 2 (the distribution
+//                 tf.random.truncated_normal samples by rejection): one uniform per draw, no loop.
+//                 The quantile q(u) = sqrt(2)*erfinv((2u-1)*erf(sqrt 2)) is tabulated at u = i/2048 (float64 ->
+//                 fp32) and interpolated linearly: with v = x >> 9 (23 bits), i = v >> 12, f = ((v & 0xFFF)+0.5)/4096,
+//                 z = fma(f, q[i+1]-q[i], q[i]).  |z - q(u)| <= 2e-5 (tails; ~1e-6 in the bulk) -- a sampler
+//                 definition, not an approximation the results are compared through: oracle and engine consume
+//                 the same z.  ~7 instructions per draw instead of log + degree-8 polynomial.
 //   normal      : Box-Muller on word pairs (x0,x1),(x2,x3).
 //   rademacher  : +1 if top bit set else -1.
 #pragma once
@@ -76,12 +80,17 @@ __device__ __forceinline__ float erfinv_central(float x) {
     return p * x;
 }
 
+constexpr int TNQ_BITS = 11;
+constexpr int TNQ_SIZE = 1 << TNQ_BITS;                    // 2048 intervals
+// (q[i], q[i+1]-q[i]) pairs, filled once per device by the host (Engine constructor)
+__device__ float2 g_tnq[TNQ_SIZE];
+
 __device__ __forceinline__ float word_to_trunc_normal(uint32_t x) {
-    float u = word_to_uniform(x);
-    float t = (2.0f * u - 1.0f) * 0.9544997361036416f;     // erf(sqrt(2)) = P(|z|<2)
-    float z = 1.4142135623730951f * erfinv_central(t);
-    // polynomial error could in principle land exactly on the bound; keep strictly inside
-    return fminf(fmaxf(z, -1.9999999f), 1.9999999f);
+    const uint32_t v = x >> 9;                              // 23 random bits
+    const uint32_t i = v >> (23 - TNQ_BITS);
+    const float f = ((float)(v & ((1u << (23 - TNQ_BITS)) - 1u)) + 0.5f) * (1.0f / (float)(1u << (23 - TNQ_BITS)));
+    const float2 e = g_tnq[i];
+    return fmaf(f, e.y, e.x);                               // strictly inside (-2, 2): q[0] = -2, q[2048] = 2, 0 < f < 1
 }
 
 __device__ __forceinline__ float word_to_rademacher(uint32_t x) {

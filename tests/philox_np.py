@@ -45,10 +45,33 @@ def uniform(w):
     return (((w >> np.uint32(9)).astype(np.float64) + 0.5) * 2.0 ** -23).astype(np.float32)
 
 
+TNQ_BITS = 11
+
+
+def tnq_table():
+    """quantile of N(0,1) | |z|<2 at u = i/2048, float64 -> fp32 (rng.hpp)"""
+    from scipy.special import erf
+    i = np.arange((1 << TNQ_BITS) + 1, dtype=np.float64)
+    q = (np.sqrt(2.0) * erfinv((2.0 * i / (1 << TNQ_BITS) - 1.0) * erf(np.sqrt(2.0)))).astype(np.float32)
+    q[0], q[-1] = -2.0, 2.0
+    return q
+
+
 def trunc_normal(w):
+    q = tnq_table()
+    v = (w >> np.uint32(9)).astype(np.int64)
+    sh = 23 - TNQ_BITS
+    i = v >> sh
+    f = ((v & ((1 << sh) - 1)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / (1 << sh))
+    dz = (q[i + 1] - q[i]).astype(np.float32)
+    return (f.astype(np.float64) * dz.astype(np.float64) + q[i].astype(np.float64)).astype(np.float32)
+
+
+def trunc_normal_exact(w):
+    """the quantile function the table interpolates"""
     u = ((w >> np.uint32(9)).astype(np.float64) + 0.5) * 2.0 ** -23
     t = (2.0 * u - 1.0) * 0.9544997361036416
-    return (np.sqrt(2.0) * erfinv(t)).astype(np.float32)
+    return np.sqrt(2.0) * erfinv(t)
 
 
 def rademacher(w):

@@ -42,6 +42,24 @@ def test_sincos_accuracy(shim):
     assert np.abs(s[~big_s].astype(np.float64) - np.sin(x[~big_s].astype(np.float64))).max(initial=0) < 1e-7
 
 
+def test_sin_on_principal_angles(shim):
+    rng = np.random.default_rng(5)
+    pi32 = float(F(np.pi))
+    x = np.concatenate([rng.uniform(-np.pi, np.pi, 2_000_000), np.linspace(-pi32, pi32, 200_001),
+                        [pi32, -pi32, np.pi / 2, -np.pi / 2, 0.0, 1e-20, -1e-20]]).astype(F)
+    o = np.empty_like(x)
+    shim.shim_sin_pi(_p(x), x.size, _p(o))
+    ref = np.sin(x.astype(np.float64))
+    e = _ulps(o, ref)
+    big = np.abs(ref) > 1e-6
+    assert e[big].max() < 2.0 and e[big].mean() < 0.4
+    assert np.abs(o[~big].astype(np.float64) - ref[~big]).max() < 2e-8
+    assert np.array_equal(np.sign(o[big]), np.sign(ref[big]))
+    nan = np.array([np.nan], F)
+    shim.shim_sin_pi(_p(nan), 1, _p(nan))
+    assert np.isnan(nan[0])
+
+
 def test_sincos_falls_back_outside_fast_domain(shim):
     x = np.array([8.5, -100.0, 1e6, np.inf, np.nan, 3.0e38], F)
     s, c = np.empty_like(x), np.empty_like(x)
