@@ -95,6 +95,22 @@ BB_HD float bb_sinf_pi(float x) {
     return fmaf(r * s, p, r);
 }
 
+// sin(x) for x in [0, 2pi] (+- a few ulp): fold x itself onto [-pi/2, pi/2] -- pi - x on the middle half,
+// x - 2pi on the last quarter; the leading subtraction is exact (Sterbenz), the lo-part adds ~1e-15 -- and
+// evaluate the odd polynomial of bb_sinf_pi.  Same accuracy, and it keeps the rounding of the caller's argument.
+BB_HD float bb_sinf_fold_0_2pi(float x) {
+    const float a = (BB_PI_HI - x) + BB_PI_LO;                                  // pi - x
+    const float b = (x - 6.2831854820251465f) - (-1.7484555314695172e-07f);     // x - 2pi
+    const float r = (x <= BB_PIO2_HI) ? x : ((x <= 4.71238898038469f) ? a : b);
+    const float s = r * r;
+    float p = -2.408602561843054e-08f;
+    p = fmaf(p, s, 2.7536809739103774e-06f);
+    p = fmaf(p, s, -0.0001984109403565526f);
+    p = fmaf(p, s, 0.00833333283662796f);
+    p = fmaf(p, s, -0.1666666716337204f);
+    return fmaf(r * s, p, r);
+}
+
 // Principal value of an angle: x - 2pi*rint(x/2pi) in [-pi, pi], |x| < ~100.  This is what
 // atan2(sin x, cos x) returns, without evaluating either.
 BB_HD float bb_wrap_pi(float x) {

@@ -115,7 +115,7 @@ struct PendulumAngleModel {
     }
     __device__ __forceinline__ float step(float u) {
         const float t1 = theta + BBMPC_PI_F;
-        float acc = 15.0f * bb_sinf_pi(theta);                  // -15 sin(theta + pi) = 15 sin(theta)
+        float acc = -15.0f * bb_sinf_fold_0_2pi(t1);            // the reference's sin(theta + pi), argument rounded as there
         acc = acc + 3.0f * u;
         float nthd = thd + acc * 0.05f;
         const float nth = theta + nthd * 0.05f;

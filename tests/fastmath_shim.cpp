@@ -5,6 +5,7 @@
 extern "C" {
 void shim_sincos(const float* x, int n, float* s, float* c) { for (int i = 0; i < n; ++i) bbmpc::bb_sincosf(x[i], s + i, c + i); }
 void shim_sin_pi(const float* x, int n, float* o) { for (int i = 0; i < n; ++i) o[i] = bbmpc::bb_sinf_pi(x[i]); }
+void shim_sin_fold(const float* x, int n, float* o) { for (int i = 0; i < n; ++i) o[i] = bbmpc::bb_sinf_fold_0_2pi(x[i]); }
 void shim_atan2(const float* y, const float* x, int n, float* o) { for (int i = 0; i < n; ++i) o[i] = bbmpc::bb_atan2f(y[i], x[i]); }
 void shim_floormod(const float* x, float y, int n, float* o) { for (int i = 0; i < n; ++i) o[i] = bbmpc::bb_floormod_pos(x[i], y); }
 }

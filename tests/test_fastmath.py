@@ -60,6 +60,19 @@ def test_sin_on_principal_angles(shim):
     assert np.isnan(nan[0])
 
 
+def test_sin_folded_on_0_2pi(shim):
+    rng = np.random.default_rng(6)
+    x = np.concatenate([rng.uniform(0, 2 * np.pi, 2_000_000), np.linspace(0, 2 * np.pi, 200_001),
+                        [0.0, np.pi / 2, np.pi, 1.5 * np.pi, 2 * np.pi, float(F(2 * np.pi)), -2e-7, 6.2831860]]).astype(F)
+    o = np.empty_like(x)
+    shim.shim_sin_fold(_p(x), x.size, _p(o))
+    ref = np.sin(x.astype(np.float64))
+    e = _ulps(o, ref)
+    big = np.abs(ref) > 1e-6
+    assert e[big].max() < 2.0 and e[big].mean() < 0.4
+    assert np.abs(o[~big].astype(np.float64) - ref[~big]).max() < 2e-8
+
+
 def test_sincos_falls_back_outside_fast_domain(shim):
     x = np.array([8.5, -100.0, 1e6, np.inf, np.nan, 3.0e38], F)
     s, c = np.empty_like(x), np.empty_like(x)
