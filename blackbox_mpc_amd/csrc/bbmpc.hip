@@ -643,9 +643,7 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     const int per = (N + ilp - 1) / ilp;
     const int threads = std::min(1024, std::max(((per + 63) / 64) * 64, ((std::max(k, 1) + 63) / 64) * 64));   // top-k needs k <= threads
     const int HUp = (HU + 3) & ~3, kp = (std::max(k, 1) + 3) & ~3;
-    int tile_floats = 0;
-    fa.tile_floats = tile_floats;
-    const size_t lds_base = (size_t)(Nst + 3 * HUp + kp + 64 + TOPK_HIST_WORDS + 2 * kp + tile_floats) * 4;
+    const size_t lds_base = (size_t)(Nst + 3 * HUp + kp + 64 + TOPK_HIST_WORDS + 2 * kp) * 4;
     const size_t lds_samples = (size_t)HU * Nst * 4;
     prof_begin();
     switch (cfg.optimizer) {

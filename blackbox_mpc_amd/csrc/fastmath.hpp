@@ -57,28 +57,6 @@ BB_HD void bb_sincosf(float x, float* sn_out, float* cs_out) {
     *cs_out = ((q + 1) & 2) ? -b : b;
 }
 
-// sin(x) for x known to lie in [-1, 7.5] (the recurrence's theta + pi is in [0, 2pi]); no fallback,
-// NaN propagates.  Same reduction/polynomials as bb_sincosf.
-BB_HD float bb_sinf_0_2pi(float x) {
-    const float kf = rintf(x * 0.6366197723675814f);
-    float r = fmaf(-kf, BB_PIO2_HI, x);
-    r = fmaf(-kf, BB_PIO2_LO, r);
-    const float s = r * r;
-    float ps = 2.724304977164138e-06f;
-    ps = fmaf(ps, s, -0.00019840050663333386f);
-    ps = fmaf(ps, s, 0.008333331905305386f);
-    ps = fmaf(ps, s, -0.1666666716337204f);
-    const float sn = fmaf(r * s, ps, r);
-    float pc = -3.619722122039093e-07f;
-    pc = fmaf(pc, s, 2.490056249371264e-05f);
-    pc = fmaf(pc, s, -0.0013889208203181624f);
-    pc = fmaf(pc, s, 0.0416666679084301f);
-    const float cs = fmaf(s * s, pc, fmaf(s, -0.5f, 1.0f));
-    const int q = ((int)kf) & 3;
-    const float a = (q & 1) ? cs : sn;
-    return (q & 2) ? -a : a;
-}
-
 // sin(x) for a principal-value angle x in [-pi-eps, pi+eps]: one reflection onto [-pi/2, pi/2]
 // (sin(pi - x) = sin x, pi split hi+lo) and a single odd polynomial -- no quadrant bookkeeping, no cosine.
 // <= 1.9 ulp (mean 0.32), tests/test_fastmath.py.

@@ -36,7 +36,6 @@ struct CmaArgs {
     float* p_C;              // [G*n]
     float* BD;               // [G][n][n] scratch
     float* z;                // [G*n][Nst] standard normals (internal layout)
-    float* y;                // [G*n][Nst]
     float* cand;             // [G*n][Nst] samples (clipped in place by the rollout)
     const float* rewards;    // [A][Nst] (penalty already subtracted)
     int* eidx;               // [G][k]

@@ -27,7 +27,6 @@ struct FusedArgs {
     int agent_offset;
     int fix_q1, fix_q7, add_noise;
     int warm_start;          // CEM: BBMPC_FIX_Q2 (keep the mean across control steps)
-    int tile_floats;         // CEM elite tile size in LDS (multiple of 4; 0 = gather straight from the samples)
     float alpha, inv_lamda;
     const float* state;      // [A,3]
     const float* lo;
@@ -73,7 +72,7 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nw)
 }
 
 // LDS carve (4-byte words): rewards[Nst] | mean[HUp] | var[HUp] | sigma[HUp] | eidx[kp] | red[64] | hist[272] |
-//                            ekeys[2*kp] | tile[tile_floats] | samples[HU][Nst]      (every piece a multiple of 16 B)
+//                            ekeys[2*kp] | samples[HU][Nst]      (every piece a multiple of 16 B)
 template <int OPT, bool SAMPLES_LDS, bool FASTM, bool INJ, int ILP>
 __global__ void k_fused_pendulum(FusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -91,8 +90,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
     float* red = (float*)(eidx + kp);
     uint32_t* hist = (uint32_t*)(red + 64);
     unsigned long long* ekeys = (unsigned long long*)(hist + TOPK_HIST_WORDS);
-    float* tile = (float*)(ekeys + kp);
-    float* samp = SAMPLES_LDS ? (tile + p.tile_floats) : (p.samples_g + (size_t)a * p.HU * p.Nst);
+    float* samp = SAMPLES_LDS ? (float*)(ekeys + kp) : (p.samples_g + (size_t)a * p.HU * p.Nst);
     __shared__ long long dbg_lds[48];
     const PendulumModel model{p.fix_q1 != 0};
     const float lo = p.lo[0], hi = p.hi[0];

@@ -64,22 +64,6 @@ __host__ __device__ __forceinline__ float word_to_uniform(uint32_t x) {
     return ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-07f;   // 2^-23
 }
 
-// Giles' single-precision erfinv, central branch (valid for w < 5, i.e. |x| < 0.99662).
-__device__ __forceinline__ float erfinv_central(float x) {
-    float w = -__logf((1.0f - x) * (1.0f + x));
-    w = w - 2.5f;
-    float p = 2.81022636e-08f;
-    p = fmaf(p, w, 3.43273939e-07f);
-    p = fmaf(p, w, -3.5233877e-06f);
-    p = fmaf(p, w, -4.39150654e-06f);
-    p = fmaf(p, w, 0.00021858087f);
-    p = fmaf(p, w, -0.00125372503f);
-    p = fmaf(p, w, -0.00417768164f);
-    p = fmaf(p, w, 0.246640727f);
-    p = fmaf(p, w, 1.50140941f);
-    return p * x;
-}
-
 constexpr int TNQ_BITS = 11;
 constexpr int TNQ_SIZE = 1 << TNQ_BITS;                    // 2048 intervals
 // (q[i], q[i+1]-q[i]) pairs, filled once per device by the host (Engine constructor)
