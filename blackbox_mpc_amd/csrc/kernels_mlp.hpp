@@ -460,4 +460,259 @@ __global__ void k_pack_record(int A, int U, int S, const float* action, const fl
     record[i] = v;
 }
 
+
+// =================================================================================================
+// Pair mode: one workgroup advances TWO 16-particle tiles, software-pipelined.
+//
+// A tile-step is three barrier-separated stages
+//   A: layer 0 (IT0*4 MFMAs per wave) + activation, all-gather of h0 through LDS
+//   B: layer 1 (HT*4 dependent MFMAs per wave) + activation + K-split of the last layer (OTL*4 MFMAs)
+//   C: epilogue (reduce the partial sums, bias, de-normalise, residual, next input) -- VALU/LDS only
+// and the matrix pipe idles during C and most of A.  Tile Y runs one stage behind tile X, so every interval
+// pairs a matrix-heavy stage of one tile with the VALU/LDS stage of the other
+//      interval 3t: A_X(t) | C_Y(t-1)      3t+1: B_X(t) | A_Y(t)      3t+2: C_X(t) | B_Y(t)
+// (same three barriers per step, but for two tiles), weights are shared in VGPRs.  Tile counts are
+// compile-time so that each interval is straight-line code the scheduler can interleave.
+// Restricted to 2 hidden layers of HT tiles each, S+U <= 32, S <= 32 (BASELINE configs 4-5: HT = 13).
+template <int HT>
+__global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const RolloutArgs& p = q.r;
+    const MlpDesc& m = q.m;
+    constexpr int NW = HT, NT = HT * 64, IT0 = 2, OTL = 2;
+    const int a = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = p.S, U = p.U, H = p.H;
+    const int Sp = (S + 3) & ~3;
+    const bool normd = m.normalized != 0;
+    // ---- LDS carve
+    const int sz_xs = IT0 * 256, sz_h0 = HT * 256, sz_part = NW * OTL * 256, sz_st = 2 * MLP_TP * Sp,
+              sz_acts = (H * MLP_TP * U + 3) & ~3, sz_pen = (MLP_TP * U + 63) & ~63;
+    const int tile_sz = sz_xs + sz_h0 + sz_part + sz_st + sz_acts + sz_pen;
+    float* nmean = smem + 2 * tile_sz;
+    float* ninv = nmean + (S + U);
+    float* tmean = ninv + (S + U);
+    float* tstd = tmean + S;
+    float* lbias = tstd + S;
+    auto T_xs = [&](int ti) { return smem + ti * tile_sz; };
+    auto T_h0 = [&](int ti) { return smem + ti * tile_sz + sz_xs; };
+    auto T_part = [&](int ti) { return smem + ti * tile_sz + sz_xs + sz_h0; };
+    auto T_st = [&](int ti) { return smem + ti * tile_sz + sz_xs + sz_h0 + sz_part; };
+    auto T_acts = [&](int ti) { return smem + ti * tile_sz + sz_xs + sz_h0 + sz_part + sz_st; };
+    auto T_pen = [&](int ti) { return smem + ti * tile_sz + sz_xs + sz_h0 + sz_part + sz_st + sz_acts; };
+
+    // ---- stationary weights (operand order, see set_mlp)
+    float wr_in[IT0 * 4], wr_hid[HT * 4], wr_out[OTL * 4];
+#pragma unroll
+    for (int it = 0; it < IT0; ++it)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            wr_in[it * 4 + s] = (it < m.tiles[0]) ? m.wpack[0][(((size_t)wave * m.tiles[0] + it) * 4 + s) * 64 + lane] : 0.0f;
+#pragma unroll
+    for (int it = 0; it < HT; ++it)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wr_hid[it * 4 + s] = m.wpack[1][(((size_t)wave * HT + it) * 4 + s) * 64 + lane];
+#pragma unroll
+    for (int ot = 0; ot < OTL; ++ot)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            wr_out[ot * 4 + s] = (ot < m.tiles[3]) ? m.wpack[2][(((size_t)ot * HT + wave) * 4 + s) * 64 + lane] : 0.0f;
+    const f32x4 bias0 = *reinterpret_cast<const f32x4*>(m.bpack[0] + ((size_t)wave * 64 + lane) * 4);
+    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(m.bpack[1] + ((size_t)wave * 64 + lane) * 4);
+    const int act0 = m.act[0], act1 = m.act[1], act2 = m.act[2];
+
+    for (int f = tid; f < S + U; f += NT) {
+        const float mu = normd ? (f < S ? m.mean_s[f] : m.mean_a[f - S]) : 0.0f;
+        const float sd = normd ? (f < S ? m.std_s[f] : m.std_a[f - S]) : 1.0f;
+        nmean[f] = mu;
+        ninv[f] = normd ? 1.0f / (sd + 1e-7f) : 1.0f;
+        if (f < S) {
+            tmean[f] = normd ? m.mean_t[f] : 0.0f;
+            tstd[f] = normd ? (m.std_t[f] + 1e-7f) : 1.0f;
+            lbias[f] = m.bpack[2][((size_t)(f >> 4) * 64 + ((f & 15) >> 2) * 16) * 4 + (f & 3)];
+        }
+    }
+    // ---- prologue per tile: action block, start state
+    for (int ti = 0; ti < 2; ++ti) {
+        const int n0 = (blockIdx.x * 2 + ti) * MLP_TP;
+        float* acts = T_acts(ti);
+        float* pens = T_pen(ti);
+        float* st = T_st(ti);
+        float* xs = T_xs(ti);
+        for (int i = tid; i < MLP_TP * U; i += NT) {
+            const int pp = i / U, u = i % U;
+            const int n = n0 + pp;
+            const bool live = n < p.n_pop;
+            const float lo = p.lo[u], hi = p.hi[u];
+            float pen_part = 0.0f;
+            for (int t = 0; t < H; ++t) {
+                const int j = t * U + u;
+                float x = 0.0f;
+                if (live) {
+                    if (q.mode == SRC_REF) x = p.seq[((size_t)n * p.A + a) * p.HU + j];
+                    else if (q.mode == SRC_BUF) x = p.cand[((size_t)a * p.HU + j) * p.Nst + n];
+                    else {
+                        float xi;
+                        if (p.inj) xi = p.inj[((size_t)a * p.HU + j) * p.Nst + n];
+                        else {
+                            const U4 blk = rng_block(p.key, p.stream, p.iter, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)j);
+                            const uint32_t w = pick_word(blk, (uint32_t)j);
+                            xi = (q.mode == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
+                        }
+                        if (q.mode == SRC_UNIFORM) x = xi * (hi - lo) + lo;
+                        else x = xi * p.sigma[a * p.HU + j] + p.mean[a * p.HU + j];
+                    }
+                    if (q.pen) {
+                        const float xf = clipf(x, lo, hi);
+                        const float d = x - xf;
+                        pen_part = pen_part + d * d;
+                        x = xf;
+                    }
+                    if (p.samples) p.samples[((size_t)a * p.HU + j) * p.Nst + n] = x;
+                }
+                acts[(t * MLP_TP + pp) * U + u] = x;
+            }
+            pens[i] = pen_part;
+        }
+        for (int i = tid; i < sz_xs; i += NT) xs[i] = 0.0f;
+        for (int i = tid; i < MLP_TP * S; i += NT) st[(i / S) * Sp + (i % S)] = p.state[a * S + (i % S)];
+    }
+    __syncthreads();
+    for (int ti = 0; ti < 2; ++ti) {
+        float* xs = T_xs(ti);
+        const float* st = T_st(ti);
+        const float* acts = T_acts(ti);
+        for (int i = tid; i < MLP_TP * (S + U); i += NT) {
+            const int f = i / MLP_TP, pp = i % MLP_TP;
+            const float v = (f < S) ? st[pp * Sp + f] : acts[pp * U + (f - S)];
+            xs[tile_addr(f, pp)] = (v - nmean[f]) * ninv[f];
+        }
+    }
+    __syncthreads();
+
+    // ---- stages
+    auto stage_A = [&](int ti) {
+        const float* xs = T_xs(ti);
+        f32x4 acc = bias0;
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(xs + ((size_t)it * 64 + lane) * 4);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 0], b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 1], b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 2], b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 3], b.w, acc, 0, 0, 0);
+        }
+        acc.x = apply_act(acc.x, act0); acc.y = apply_act(acc.y, act0);
+        acc.z = apply_act(acc.z, act0); acc.w = apply_act(acc.w, act0);
+        *reinterpret_cast<f32x4*>(T_h0(ti) + ((size_t)wave * 64 + lane) * 4) = acc;
+    };
+    auto stage_B = [&](int ti) {
+        const float* h0 = T_h0(ti);
+        f32x4 acc = bias1;
+#pragma unroll
+        for (int it = 0; it < HT; ++it) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(h0 + ((size_t)it * 64 + lane) * 4);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 0], b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 1], b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 2], b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 3], b.w, acc, 0, 0, 0);
+        }
+        acc.x = apply_act(acc.x, act1); acc.y = apply_act(acc.y, act1);
+        acc.z = apply_act(acc.z, act1); acc.w = apply_act(acc.w, act1);
+        float* part = T_part(ti);
+#pragma unroll
+        for (int ot = 0; ot < OTL; ++ot) {
+            f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 0], acc.x, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 1], acc.y, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 2], acc.z, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 3], acc.w, o, 0, 0, 0);
+            *reinterpret_cast<f32x4*>(part + (((size_t)wave * OTL + ot) * 64 + lane) * 4) = o;
+        }
+    };
+    // epilogue of step t: one thread per (feature, particle); index math is done unconditionally on a clamped
+    // index so that it can be scheduled under the other tile's MFMAs, only the stores are predicated
+    const int ef = min(tid / MLP_TP, S + U - 1), epp = tid % MLP_TP;
+    const bool e_live = tid < MLP_TP * (S + U);
+    const int e_ot = ef >> 4, e_ln = ((ef & 15) >> 2) * 16 + epp, e_rg = ef & 3;
+    const int e_xaddr = tile_addr(ef, epp);
+    auto stage_C = [&](int ti, int t) {
+        float* st = T_st(ti);
+        float* cur = st + (t & 1) * MLP_TP * Sp;
+        float* nxt = st + ((t + 1) & 1) * MLP_TP * Sp;
+        const float* part = T_part(ti) + (((size_t)e_ot) * 64 + e_ln) * 4 + e_rg;
+        float v;
+        if (ef < S) {
+            float acc = lbias[ef];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc = acc + part[(size_t)w * OTL * 256];
+            acc = apply_act(acc, act2);
+            const float dev = normd ? tmean[ef] + acc * tstd[ef] : acc;
+            v = dev + cur[epp * Sp + ef];
+            if (e_live) nxt[epp * Sp + ef] = v;
+        } else {
+            const int tn = (t + 1 < H) ? t + 1 : t;
+            v = T_acts(ti)[(tn * MLP_TP + epp) * U + (ef - S)];
+        }
+        if (e_live) T_xs(ti)[e_xaddr] = (v - nmean[ef]) * ninv[ef];
+    };
+    float total[2] = {0.0f, 0.0f};                 // lanes 0..15 of wave 0: particle `lane` of tile 0 / 1
+    auto reward = [&](int ti, int t) {
+        if (tid < MLP_TP) {
+            const float* st = T_st(ti);
+            const float* cur = st + (t & 1) * MLP_TP * Sp;
+            const float* nxt = st + ((t + 1) & 1) * MLP_TP * Sp;
+            total[ti] = total[ti] + reward_generic(p.reward_kind, p.fix_q1 != 0, cur + tid * Sp,
+                                                   T_acts(ti) + (t * MLP_TP + tid) * U, nxt + tid * Sp, S, U);
+        }
+    };
+
+    // ---- pipelined recurrence: tile 1 runs one stage behind tile 0
+    for (int t = 0; t < H; ++t) {
+        stage_A(0);                       // A_X(t)
+        if (t > 0) stage_C(1, t - 1);     // C_Y(t-1)
+        if (t > 0) reward(0, t - 1);      // state pair (t-1, t) of tile 0 is complete since the previous barrier
+        __syncthreads();
+        stage_B(0);                       // B_X(t)
+        stage_A(1);                       // A_Y(t)
+        if (t > 0) reward(1, t - 1);
+        __syncthreads();
+        stage_C(0, t);                    // C_X(t)
+        stage_B(1);                       // B_Y(t)
+        __syncthreads();
+    }
+    stage_C(1, H - 1);
+    reward(0, H - 1);
+    __syncthreads();
+    reward(1, H - 1);
+
+    // ---- results
+    for (int ti = 0; ti < 2; ++ti) {
+        if (tid < MLP_TP) {
+            const int n = (blockIdx.x * 2 + ti) * MLP_TP + tid;
+            if (n < p.n_pop) {
+                float tot = total[ti];
+                if (tot != tot) tot = -1.0e6f;
+                if (q.pen) {
+                    const float* pens = T_pen(ti);
+                    float pen = 0.0f;
+                    for (int u = 0; u < U; ++u) pen = pen + pens[tid * U + u];
+                    const float nr = sqrtf(pen);
+                    pen = nr * nr;
+                    tot = tot - pen;
+                    if (p.penalty_out) p.penalty_out[(size_t)a * p.Nst + n] = pen;
+                }
+                p.rewards[(size_t)a * p.Nst + n] = tot;
+            }
+        }
+    }
+}
+
+// LDS floats the pair kernel needs
+inline int mlp_pair_lds_floats(int HT, int H, int U, int S) {
+    const int Sp = (S + 3) & ~3;
+    const int tile = 2 * 256 + HT * 256 + HT * 2 * 256 + 2 * MLP_TP * Sp + ((H * MLP_TP * U + 3) & ~3) + ((MLP_TP * U + 63) & ~63);
+    return 2 * tile + (((S + U) * 2 + S * 3 + 63) & ~63);
+}
+
 }  // namespace bbmpc
