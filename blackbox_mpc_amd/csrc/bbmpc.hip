@@ -468,19 +468,21 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     }
     // pair mode (two tiles per workgroup, software-pipelined) when there are more tiles than CUs can hold one each
     const long tiles_total = (long)((ra.n_pop + MLP_TP - 1) / MLP_TP) * A;
-    int pair = (spec == 1 && mlp.tiles[1] == 13 && !per_particle_state && tiles_total > 256) ? 1 : 0;
-    if (const char* ev = getenv("BBMPC_MLP_PAIR")) pair = (atoi(ev) != 0 && spec == 1 && mlp.tiles[1] == 13 && !per_particle_state) ? 1 : 0;
+    const bool pair_ok = spec == 1 && mlp.tiles[1] == 13 && !per_particle_state && mlp.act[0] == BBMPC_ACT_TANH &&
+                         mlp.act[1] == BBMPC_ACT_TANH && mlp.act[2] == BBMPC_ACT_NONE;
+    int pair = (pair_ok && tiles_total > 256) ? 1 : 0;
+    if (const char* ev = getenv("BBMPC_MLP_PAIR")) pair = (atoi(ev) != 0 && pair_ok) ? 1 : 0;
     if (pair) {
         const size_t plds = (size_t)mlp_pair_lds_floats(13, ra.H, U, S) * sizeof(float);
         if (plds <= 159 * 1024) {
             static bool pconf = false;
             if (!pconf) {
-                HIP_CHECK(hipFuncSetAttribute((const void*)k_rollout_mlp_pair<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+                HIP_CHECK(hipFuncSetAttribute((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
                 pconf = true;
             }
             dim3 pgrid((ra.n_pop + 2 * MLP_TP - 1) / (2 * MLP_TP), A), pblock(13 * 64);
             prof_begin();
-            hipLaunchKernelGGL(k_rollout_mlp_pair<13>, pgrid, pblock, plds, stream, q);
+            hipLaunchKernelGGL((k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE>), pgrid, pblock, plds, stream, q);
             HIP_CHECK(hipGetLastError());
             prof_end();
             return;

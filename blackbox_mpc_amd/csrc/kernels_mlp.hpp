@@ -474,7 +474,15 @@ __global__ void k_pack_record(int A, int U, int S, const float* action, const fl
 // (same three barriers per step, but for two tiles), weights are shared in VGPRs.  Tile counts are
 // compile-time so that each interval is straight-line code the scheduler can interleave.
 // Restricted to 2 hidden layers of HT tiles each, S+U <= 32, S <= 32 (BASELINE configs 4-5: HT = 13).
-template <int HT>
+template <int ACT>
+__device__ __forceinline__ float apply_act_ct(float x) {
+    if constexpr (ACT == ACT_TANH) return bb_tanhf(x);
+    else if constexpr (ACT == ACT_RELU) return fmaxf(x, 0.0f);
+    else if constexpr (ACT == ACT_SIGMOID) return 1.0f / (1.0f + expf(-x));
+    else return x;
+}
+
+template <int HT, int A0, int A1, int A2>
 __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutArgs& p = q.r;
@@ -519,8 +527,6 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
             wr_out[ot * 4 + s] = (ot < m.tiles[3]) ? m.wpack[2][(((size_t)ot * HT + wave) * 4 + s) * 64 + lane] : 0.0f;
     const f32x4 bias0 = *reinterpret_cast<const f32x4*>(m.bpack[0] + ((size_t)wave * 64 + lane) * 4);
     const f32x4 bias1 = *reinterpret_cast<const f32x4*>(m.bpack[1] + ((size_t)wave * 64 + lane) * 4);
-    const int act0 = m.act[0], act1 = m.act[1], act2 = m.act[2];
-
     for (int f = tid; f < S + U; f += NT) {
         const float mu = normd ? (f < S ? m.mean_s[f] : m.mean_a[f - S]) : 0.0f;
         const float sd = normd ? (f < S ? m.std_s[f] : m.std_a[f - S]) : 1.0f;
@@ -602,23 +608,29 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 2], b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 3], b.w, acc, 0, 0, 0);
         }
-        acc.x = apply_act(acc.x, act0); acc.y = apply_act(acc.y, act0);
-        acc.z = apply_act(acc.z, act0); acc.w = apply_act(acc.w, act0);
+        acc.x = apply_act_ct<A0>(acc.x); acc.y = apply_act_ct<A0>(acc.y);
+        acc.z = apply_act_ct<A0>(acc.z); acc.w = apply_act_ct<A0>(acc.w);
         *reinterpret_cast<f32x4*>(T_h0(ti) + ((size_t)wave * 64 + lane) * 4) = acc;
     };
-    auto stage_B = [&](int ti) {
+    // Layer 1 + K split of tile `ti`.  When `co` >= 0 the partial-sum reduction of tile `co`'s epilogue
+    // (one LDS read + one add per producing wave) is issued between this tile's dependent MFMA groups, so
+    // it costs no time of its own; `cacc` returns the reduced value.
+    auto stage_B = [&](int ti, int co, const float* cpart, float& cacc) {
         const float* h0 = T_h0(ti);
         f32x4 acc = bias1;
 #pragma unroll
         for (int it = 0; it < HT; ++it) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(h0 + ((size_t)it * 64 + lane) * 4);
+            float pv = 0.0f;
+            if (co >= 0) pv = cpart[(size_t)it * OTL * 256];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 0], b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 1], b.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 2], b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 3], b.w, acc, 0, 0, 0);
+            if (co >= 0) cacc = cacc + pv;
         }
-        acc.x = apply_act(acc.x, act1); acc.y = apply_act(acc.y, act1);
-        acc.z = apply_act(acc.z, act1); acc.w = apply_act(acc.w, act1);
+        acc.x = apply_act_ct<A1>(acc.x); acc.y = apply_act_ct<A1>(acc.y);
+        acc.z = apply_act_ct<A1>(acc.z); acc.w = apply_act_ct<A1>(acc.w);
         float* part = T_part(ti);
 #pragma unroll
         for (int ot = 0; ot < OTL; ++ot) {
@@ -636,17 +648,22 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
     const bool e_live = tid < MLP_TP * (S + U);
     const int e_ot = ef >> 4, e_ln = ((ef & 15) >> 2) * 16 + epp, e_rg = ef & 3;
     const int e_xaddr = tile_addr(ef, epp);
-    auto stage_C = [&](int ti, int t) {
+    auto epi_part = [&](int ti) { return T_part(ti) + (((size_t)e_ot) * 64 + e_ln) * 4 + e_rg; };
+    auto epi_reduce = [&](int ti) {
+        const float* part = epi_part(ti);
+        float acc = lbias[min(ef, S - 1)];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc = acc + part[(size_t)w * OTL * 256];
+        return acc;
+    };
+    // finish the epilogue of step t given the reduced pre-activation `acc`
+    auto epi_finish = [&](int ti, int t, float acc) {
         float* st = T_st(ti);
         float* cur = st + (t & 1) * MLP_TP * Sp;
         float* nxt = st + ((t + 1) & 1) * MLP_TP * Sp;
-        const float* part = T_part(ti) + (((size_t)e_ot) * 64 + e_ln) * 4 + e_rg;
         float v;
         if (ef < S) {
-            float acc = lbias[ef];
-#pragma unroll
-            for (int w = 0; w < NW; ++w) acc = acc + part[(size_t)w * OTL * 256];
-            acc = apply_act(acc, act2);
+            acc = apply_act_ct<A2>(acc);
             const float dev = normd ? tmean[ef] + acc * tstd[ef] : acc;
             v = dev + cur[epp * Sp + ef];
             if (e_live) nxt[epp * Sp + ef] = v;
@@ -668,20 +685,22 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
     };
 
     // ---- pipelined recurrence: tile 1 runs one stage behind tile 0
+    float dummy = 0.0f;
     for (int t = 0; t < H; ++t) {
-        stage_A(0);                       // A_X(t)
-        if (t > 0) stage_C(1, t - 1);     // C_Y(t-1)
-        if (t > 0) reward(0, t - 1);      // state pair (t-1, t) of tile 0 is complete since the previous barrier
+        stage_A(0);                                   // A_X(t)
+        if (t > 0) epi_finish(1, t - 1, epi_reduce(1));   // C_Y(t-1)
+        if (t > 0) reward(0, t - 1);                  // state pair (t-1, t) of tile 0 is complete since the last barrier
         __syncthreads();
-        stage_B(0);                       // B_X(t)
-        stage_A(1);                       // A_Y(t)
+        stage_A(1);                                   // A_Y(t)
+        stage_B(0, -1, nullptr, dummy);               // B_X(t)
         if (t > 0) reward(1, t - 1);
         __syncthreads();
-        stage_C(0, t);                    // C_X(t)
-        stage_B(1);                       // B_Y(t)
+        float cacc = lbias[min(ef, S - 1)];           // C_X(t): reduction rides under B_Y(t)'s MFMA chain
+        stage_B(1, 0, epi_part(0), cacc);
+        epi_finish(0, t, cacc);
         __syncthreads();
     }
-    stage_C(1, H - 1);
+    epi_finish(1, H - 1, epi_reduce(1));
     reward(0, H - 1);
     __syncthreads();
     reward(1, H - 1);

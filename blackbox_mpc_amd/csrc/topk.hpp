@@ -109,6 +109,7 @@ __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int 
         __syncthreads();
         TK(5 + 4 * passno);
         ++passno;
+        (void)passno;
         T |= hist[256] << shift;
         remaining = hist[257];
         const bool whole_bucket = hist[258] == remaining;     // every key of the boundary bucket is a winner:
