@@ -63,22 +63,16 @@ struct MlpRolloutArgs {
     int nw;                   // waves per workgroup
 };
 
-// tanh on the hardware exp/rcp units: 1 - 2/(1 + e^{2|x|}) away from zero, odd Taylor polynomial near it
-// (the rational form cancels there).  |error| <= ~3e-7 absolute (tests/test_gpu_mlp.py sweeps it against
-// float64), i.e. a few ulp -- the class of difference the stated MLP tolerances already cover.
+// tanh on the hardware exp/rcp units: sign(x) * (1 - 2 / (e^{2|x|} + 1)), 7 instructions.  Absolute error
+// <= ~2.5e-7 over the whole range (v_exp_f32 / v_rcp_f32 are ~1 ulp); near zero the RELATIVE error grows
+// (cancellation) but an activation feeds a dot product, where only absolute error matters -- it is the size of
+// one fp32 rounding of an O(1) pre-activation.  fp32-input MFMA executes at the vector rate on the same
+// datapath as VALU work (measured: step time = MFMA time + VALU time, not the max), so every VALU
+// instruction shaved off the activations is matrix time gained.
 __device__ __forceinline__ float bb_tanhf(float x) {
-    const float ax = fabsf(x);
-    const float x2 = x * x;
-    // |x| < 0.3: x - x^3/3 + 2x^5/15 - 17x^7/315 + 62x^9/2835   (next term < 2e-8 relative)
-    float p = 0.021869488536155203f;
-    p = fmaf(p, x2, -0.053968253968253971f);
-    p = fmaf(p, x2, 0.13333333333333333f);
-    p = fmaf(p, x2, -0.33333333333333331f);
-    const float small = fmaf(x * x2, p, x);
-    const float e = __expf(2.0f * ax);                       // inf for large |x| -> 1 - 0
-    const float big = 1.0f - 2.0f * __frcp_rn(1.0f + e);
-    const float r = (ax < 0.3f) ? small : copysignf(big, x);
-    return (x != x) ? x : r;
+    const float e = __expf(2.0f * fabsf(x));                 // +inf for large |x| -> 1 - 0
+    const float r = 1.0f - 2.0f * __frcp_rn(1.0f + e);
+    return copysignf(r, x);                                  // NaN stays NaN (exp(NaN) = NaN)
 }
 
 __device__ __forceinline__ float apply_act(float x, int act) {
@@ -618,9 +612,11 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
     auto stage_B = [&](int ti, int co, const float* cpart, float& cacc) {
         const float* h0 = T_h0(ti);
         f32x4 acc = bias1;
+        f32x4 bn = *reinterpret_cast<const f32x4*>(h0 + (size_t)lane * 4);
 #pragma unroll
         for (int it = 0; it < HT; ++it) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(h0 + ((size_t)it * 64 + lane) * 4);
+            const f32x4 b = bn;                       // operand of this group was loaded during the previous one
+            if (it + 1 < HT) bn = *reinterpret_cast<const f32x4*>(h0 + ((size_t)(it + 1) * 64 + lane) * 4);
             float pv = 0.0f;
             if (co >= 0) pv = cpart[(size_t)it * OTL * 256];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 0], b.x, acc, 0, 0, 0);
@@ -657,6 +653,11 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
         return acc;
     };
     // finish the epilogue of step t given the reduced pre-activation `acc`
+    // cheetah reward (cost_func.py:5-22) needs cur[5..7], cur[17], next[17] and the actions only: the epilogue
+    // thread that produces feature 17 of particle epp has next[17] in hand and evaluates it right there
+    // (its reward accumulator is collected at the end); other rewards go through reward() below.
+    const bool rew_inline = p.reward_kind == REW_CHEETAH && S > 17;
+    float rew_acc[2] = {0.0f, 0.0f};
     auto epi_finish = [&](int ti, int t, float acc) {
         float* st = T_st(ti);
         float* cur = st + (t & 1) * MLP_TP * Sp;
@@ -665,8 +666,22 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
         if (ef < S) {
             acc = apply_act_ct<A2>(acc);
             const float dev = normd ? tmean[ef] + acc * tstd[ef] : acc;
-            v = dev + cur[epp * Sp + ef];
+            const float c17 = cur[epp * Sp + ef];
+            v = dev + c17;
             if (e_live) nxt[epp * Sp + ef] = v;
+            if (rew_inline && ef == 17) {
+                const float c5 = cur[epp * Sp + 5], c6 = cur[epp * Sp + 6], c7 = cur[epp * Sp + 7];
+                const float* ac = T_acts(ti) + (t * MLP_TP + epp) * U;
+                float ss = 0.0f;
+                for (int u = 0; u < U; ++u) ss = ss + ac[u] * ac[u];
+                float r = 0.0f;
+                if (c5 >= 0.2f) r = r + (-10.0f);
+                if (c6 >= 0.0f) r = r + (-10.0f);
+                if (c7 >= 0.0f) r = r + (-10.0f);
+                r = r + (v - c17) / 0.01f;
+                r = r - 0.0f * ss;
+                rew_acc[ti] = rew_acc[ti] + r;
+            }
         } else {
             const int tn = (t + 1 < H) ? t + 1 : t;
             v = T_acts(ti)[(tn * MLP_TP + epp) * U + (ef - S)];
@@ -675,7 +690,7 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
     };
     float total[2] = {0.0f, 0.0f};                 // lanes 0..15 of wave 0: particle `lane` of tile 0 / 1
     auto reward = [&](int ti, int t) {
-        if (tid < MLP_TP) {
+        if (!rew_inline && tid < MLP_TP) {
             const float* st = T_st(ti);
             const float* cur = st + (t & 1) * MLP_TP * Sp;
             const float* nxt = st + ((t + 1) & 1) * MLP_TP * Sp;
@@ -686,19 +701,51 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
 
     // ---- pipelined recurrence: tile 1 runs one stage behind tile 0
     float dummy = 0.0f;
+#ifdef BBMPC_TOPK_DBG
+#define PK(slot) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && t == 3) g_topk_dbg[(slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define PK(slot) do {} while (0)
+#endif
+    // Waves of one SIMD are split into two groups that run the two (independent) stages of an interval in
+    // opposite order: right after a barrier every wave would otherwise reach its activation (VALU) section at
+    // the same time and leave the matrix pipe idle.  Waves w, w+4, w+8, ... share a SIMD, so (w >> 2) & 1
+    // alternates within each SIMD.
+    const bool grp = ((wave >> 2) & 1) != 0;
     for (int t = 0; t < H; ++t) {
-        stage_A(0);                                   // A_X(t)
-        if (t > 0) epi_finish(1, t - 1, epi_reduce(1));   // C_Y(t-1)
+        PK(0);
+        if (!grp) {
+            stage_A(0);                                           // A_X(t)
+            if (t > 0) epi_finish(1, t - 1, epi_reduce(1));       // C_Y(t-1)
+        } else {
+            if (t > 0) epi_finish(1, t - 1, epi_reduce(1));
+            stage_A(0);
+        }
         if (t > 0) reward(0, t - 1);                  // state pair (t-1, t) of tile 0 is complete since the last barrier
+        PK(1);
         __syncthreads();
-        stage_A(1);                                   // A_Y(t)
-        stage_B(0, -1, nullptr, dummy);               // B_X(t)
+        PK(2);
+        if (!grp) {
+            stage_A(1);                                           // A_Y(t)
+            stage_B(0, -1, nullptr, dummy);                       // B_X(t)
+        } else {
+            stage_B(0, -1, nullptr, dummy);
+            stage_A(1);
+        }
         if (t > 0) reward(1, t - 1);
+        PK(5);
         __syncthreads();
-        float cacc = lbias[min(ef, S - 1)];           // C_X(t): reduction rides under B_Y(t)'s MFMA chain
-        stage_B(1, 0, epi_part(0), cacc);
-        epi_finish(0, t, cacc);
+        PK(6);
+        if (!grp) {
+            float cacc = lbias[min(ef, S - 1)];                   // C_X(t): reduction rides under B_Y(t)'s MFMA chain
+            stage_B(1, 0, epi_part(0), cacc);
+            epi_finish(0, t, cacc);
+        } else {
+            epi_finish(0, t, epi_reduce(0));
+            stage_B(1, -1, nullptr, dummy);
+        }
+        PK(8);
         __syncthreads();
+        PK(9);
     }
     epi_finish(1, H - 1, epi_reduce(1));
     reward(0, H - 1);
@@ -706,6 +753,12 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
     reward(1, H - 1);
 
     // ---- results
+    if (rew_inline) {
+        __syncthreads();
+        if (ef == 17 && e_live) { T_part(0)[epp] = rew_acc[0]; T_part(1)[epp] = rew_acc[1]; }
+        __syncthreads();
+        if (tid < MLP_TP) { total[0] = T_part(0)[tid]; total[1] = T_part(1)[tid]; }
+    }
     for (int ti = 0; ti < 2; ++ti) {
         if (tid < MLP_TP) {
             const int n = (blockIdx.x * 2 + ti) * MLP_TP + tid;
