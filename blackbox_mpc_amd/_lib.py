@@ -60,7 +60,7 @@ SYMBOLS = [
     "bbmpc_set_stream", "bbmpc_set_mlp", "bbmpc_reset", "bbmpc_optimize", "bbmpc_optimize_dev", "bbmpc_evaluate",
     "bbmpc_evaluate_dev", "bbmpc_predict_next_state", "bbmpc_evaluate_next_reward", "bbmpc_step_dev",
     "bbmpc_inject_noise", "bbmpc_dump_noise", "bbmpc_set_trace", "bbmpc_get_trace", "bbmpc_get_state",
-    "bbmpc_set_state", "bbmpc_set_profiling", "bbmpc_get_profile", "bbmpc_synchronize",
+    "bbmpc_set_state", "bbmpc_set_profiling", "bbmpc_get_profile", "bbmpc_synchronize", "bbmpc_rollout_episode",
 ]
 
 
@@ -98,6 +98,7 @@ def _load():
     lib.bbmpc_get_profile.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64),
                                       ctypes.POINTER(ctypes.c_char_p)]
     lib.bbmpc_synchronize.argtypes = [vp]
+    lib.bbmpc_rollout_episode.argtypes = [vp, vp, i32, i32, vp]
     return lib
 
 

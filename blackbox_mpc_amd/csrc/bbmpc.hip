@@ -1239,6 +1239,24 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
     API_END
 }
 
+int bbmpc_rollout_episode(bbmpc_handle h, const float* start_state, int32_t num_steps, int32_t noise, float* records_out) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(start_state);
+    CHECK_PTR(records_out);
+    Engine& e = *h->e;
+    if (num_steps < 1) throw HipError(BBMPC_E_INVALID, "num_steps must be >= 1");
+    const size_t ns = (size_t)e.A * e.S, nr = (size_t)e.A * e.rec;
+    if (e.d_step_d.n < 2 * ns + nr * (size_t)num_steps) e.d_step_d.alloc(2 * ns + nr * (size_t)num_steps);
+    float* st[2] = {e.d_step_d.p, e.d_step_d.p + ns};
+    float* recs = e.d_step_d.p + 2 * ns;
+    HIP_CHECK(hipMemcpyAsync(st[0], start_state, ns * 4, hipMemcpyHostToDevice, e.stream));
+    for (int t = 0; t < num_steps; ++t) e.optimize_dev(st[t & 1], noise, recs + nr * t, st[(t + 1) & 1]);
+    HIP_CHECK(hipMemcpyAsync(records_out, recs, nr * (size_t)num_steps * 4, hipMemcpyDeviceToHost, e.stream));
+    HIP_CHECK(hipStreamSynchronize(e.stream));
+    API_END
+}
+
 int bbmpc_evaluate_dev(bbmpc_handle h, const float* d_state, const float* d_seq, int32_t n_pop, float* d_rewards) {
     API_BEGIN
     CHECK_HANDLE(h);

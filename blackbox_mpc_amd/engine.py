@@ -96,6 +96,17 @@ class Engine:
                                      L.ptr(action), L.ptr(nxt), L.ptr(rew)))
         return action, nxt, rew
 
+    def rollout_episode(self, start_state, num_steps, add_exploration_noise=False):
+        """T closed-loop control steps on the device (model = environment); returns
+        (actions [T,A,U], next_states [T,A,S], rewards [T,A])."""
+        s = L.f32c(start_state)
+        if s.shape != (self.A, self.S):
+            raise ValueError("start_state must be [%d, %d]" % (self.A, self.S))
+        rec = np.empty((int(num_steps), self.A, self.U + self.S + 1), np.float32)
+        L.check(L.lib.bbmpc_rollout_episode(self._h, L.ptr(s), int(num_steps), int(bool(add_exploration_noise)),
+                                            L.ptr(rec)))
+        return rec[..., :self.U], rec[..., self.U:self.U + self.S], rec[..., self.U + self.S]
+
     def optimize_dev(self, d_state, d_record, t=0, add_exploration_noise=False, d_next_state=0):
         L.check(L.lib.bbmpc_optimize_dev(self._h, ctypes.c_void_p(d_state), int(t), int(bool(add_exploration_noise)),
                                          ctypes.c_void_p(d_record), ctypes.c_void_p(d_next_state or 0)))

@@ -181,6 +181,13 @@ int bbmpc_evaluate_next_reward(bbmpc_handle h, const float* states, const float*
 int bbmpc_step_dev(bbmpc_handle h, const float* d_states, const float* d_actions, int32_t action_stride,
                    int32_t batch, float* d_next_states, float* d_rewards);
 
+/* Closed-loop episode on the device -- counterpart of utils/rollouts.py:60-139 (_sample) with the engine's own
+ * model as the environment: T control steps, each feeding its predicted next state back as the next observation;
+ * nothing leaves HBM until the end.  records_out is [T][A][U+S+1] (action | next_state | reward) on the host.
+ * Equivalent to T calls of bbmpc_optimize with state_{t+1} = next_state_t (no exploration noise). */
+int bbmpc_rollout_episode(bbmpc_handle h, const float* start_state, int32_t num_steps, int32_t add_exploration_noise,
+                          float* records_out);
+
 /* ---- parity / test hooks ------------------------------------------------ */
 /* Replace the engine's Philox draws of `kind` by caller-supplied standard noise
  * (reference layout, see BBMPC_NOISE_*).  count = number of floats.  data == NULL
