@@ -472,17 +472,30 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
                          mlp.act[1] == BBMPC_ACT_TANH && mlp.act[2] == BBMPC_ACT_NONE;
     int pair = (pair_ok && tiles_total > 256) ? 1 : 0;
     if (const char* ev = getenv("BBMPC_MLP_PAIR")) pair = (atoi(ev) != 0 && pair_ok) ? 1 : 0;
-    if (pair) {
-        const size_t plds = (size_t)mlp_pair_lds_floats(13, ra.H, U, S) * sizeof(float);
+    if (pair_ok && !getenv("BBMPC_MLP_GENERIC")) {
+        // pipelined kernel for the 26-200-200-20 family: two tiles per workgroup when tiles outnumber the CUs,
+        // one tile per workgroup otherwise (more workgroups beat better per-workgroup efficiency then)
+        const int nt = pair ? 2 : 1;
+        const size_t plds = (size_t)mlp_pair_lds_floats(13, ra.H, U, S, nt) * sizeof(float);
         if (plds <= 159 * 1024) {
-            static bool pconf = false;
-            if (!pconf) {
-                HIP_CHECK(hipFuncSetAttribute((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-                pconf = true;
-            }
-            dim3 pgrid((ra.n_pop + 2 * MLP_TP - 1) / (2 * MLP_TP), A), pblock(13 * 64);
+            static bool pconf[3] = {false, false, false};
+            dim3 pgrid((ra.n_pop + nt * MLP_TP - 1) / (nt * MLP_TP), A), pblock(13 * 64);
             prof_begin();
-            hipLaunchKernelGGL((k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE>), pgrid, pblock, plds, stream, q);
+            if (nt == 2) {
+                if (!pconf[2]) {
+                    HIP_CHECK(hipFuncSetAttribute((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+                    pconf[2] = true;
+                }
+                hipLaunchKernelGGL((k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2>), pgrid, pblock, plds, stream, q);
+            } else {
+                if (!pconf[1]) {
+                    HIP_CHECK(hipFuncSetAttribute((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 1>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+                    pconf[1] = true;
+                }
+                hipLaunchKernelGGL((k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 1>), pgrid, pblock, plds, stream, q);
+            }
             HIP_CHECK(hipGetLastError());
             prof_end();
             return;

@@ -476,7 +476,7 @@ __device__ __forceinline__ float apply_act_ct(float x) {
     else return x;
 }
 
-template <int HT, int A0, int A1, int A2>
+template <int HT, int A0, int A1, int A2, int NTILES>
 __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutArgs& p = q.r;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
     const int sz_xs = IT0 * 256, sz_h0 = HT * 256, sz_part = NW * OTL * 256, sz_st = 2 * MLP_TP * Sp,
               sz_acts = (H * MLP_TP * U + 3) & ~3, sz_pen = (MLP_TP * U + 63) & ~63;
     const int tile_sz = sz_xs + sz_h0 + sz_part + sz_st + sz_acts + sz_pen;
-    float* nmean = smem + 2 * tile_sz;
+    float* nmean = smem + NTILES * tile_sz;
     float* ninv = nmean + (S + U);
     float* tmean = ninv + (S + U);
     float* tstd = tmean + S;
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
         }
     }
     // ---- prologue per tile: action block, start state
-    for (int ti = 0; ti < 2; ++ti) {
-        const int n0 = (blockIdx.x * 2 + ti) * MLP_TP;
+    for (int ti = 0; ti < NTILES; ++ti) {
+        const int n0 = (blockIdx.x * NTILES + ti) * MLP_TP;
         float* acts = T_acts(ti);
         float* pens = T_pen(ti);
         float* st = T_st(ti);
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
         for (int i = tid; i < MLP_TP * S; i += NT) st[(i / S) * Sp + (i % S)] = p.state[a * S + (i % S)];
     }
     __syncthreads();
-    for (int ti = 0; ti < 2; ++ti) {
+    for (int ti = 0; ti < NTILES; ++ti) {
         float* xs = T_xs(ti);
         const float* st = T_st(ti);
         const float* acts = T_acts(ti);
@@ -706,62 +706,78 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
 #else
 #define PK(slot) do {} while (0)
 #endif
-    // Waves of one SIMD are split into two groups that run the two (independent) stages of an interval in
-    // opposite order: right after a barrier every wave would otherwise reach its activation (VALU) section at
-    // the same time and leave the matrix pipe idle.  Waves w, w+4, w+8, ... share a SIMD, so (w >> 2) & 1
-    // alternates within each SIMD.
-    const bool grp = ((wave >> 2) & 1) != 0;
-    for (int t = 0; t < H; ++t) {
-        PK(0);
-        if (!grp) {
-            stage_A(0);                                           // A_X(t)
-            if (t > 0) epi_finish(1, t - 1, epi_reduce(1));       // C_Y(t-1)
-        } else {
-            if (t > 0) epi_finish(1, t - 1, epi_reduce(1));
+    if constexpr (NTILES == 1) {
+        // one tile: the three stages back to back (same stage bodies, B-operand prefetch, compile-time activations)
+        for (int t = 0; t < H; ++t) {
             stage_A(0);
-        }
-        if (t > 0) reward(0, t - 1);                  // state pair (t-1, t) of tile 0 is complete since the last barrier
-        PK(1);
-        __syncthreads();
-        PK(2);
-        if (!grp) {
-            stage_A(1);                                           // A_Y(t)
-            stage_B(0, -1, nullptr, dummy);                       // B_X(t)
-        } else {
+            if (t > 0) reward(0, t - 1);
+            __syncthreads();
             stage_B(0, -1, nullptr, dummy);
-            stage_A(1);
-        }
-        if (t > 0) reward(1, t - 1);
-        PK(5);
-        __syncthreads();
-        PK(6);
-        if (!grp) {
-            float cacc = lbias[min(ef, S - 1)];                   // C_X(t): reduction rides under B_Y(t)'s MFMA chain
-            stage_B(1, 0, epi_part(0), cacc);
-            epi_finish(0, t, cacc);
-        } else {
+            __syncthreads();
             epi_finish(0, t, epi_reduce(0));
-            stage_B(1, -1, nullptr, dummy);
+            __syncthreads();
         }
-        PK(8);
+        reward(0, H - 1);
+    } else {
+        // Waves of one SIMD are split into two groups that run the two (independent) stages of an interval in
+        // opposite order: right after a barrier every wave would otherwise reach its activation (VALU) section at
+        // the same time and leave the matrix pipe idle.  Waves w, w+4, w+8, ... share a SIMD, so (w >> 2) & 1
+        // alternates within each SIMD.
+        const bool grp = ((wave >> 2) & 1) != 0;
+        for (int t = 0; t < H; ++t) {
+            PK(0);
+            if (!grp) {
+                stage_A(0);                                           // A_X(t)
+                if (t > 0) epi_finish(1, t - 1, epi_reduce(1));       // C_Y(t-1)
+            } else {
+                if (t > 0) epi_finish(1, t - 1, epi_reduce(1));
+                stage_A(0);
+            }
+            if (t > 0) reward(0, t - 1);                  // state pair (t-1, t) of tile 0 is complete since the last barrier
+            PK(1);
+            __syncthreads();
+            PK(2);
+            if (!grp) {
+                stage_A(1);                                           // A_Y(t)
+                stage_B(0, -1, nullptr, dummy);                       // B_X(t)
+            } else {
+                stage_B(0, -1, nullptr, dummy);
+                stage_A(1);
+            }
+            if (t > 0) reward(1, t - 1);
+            PK(5);
+            __syncthreads();
+            PK(6);
+            if (!grp) {
+                float cacc = lbias[min(ef, S - 1)];                   // C_X(t): reduction rides under B_Y(t)'s MFMA chain
+                stage_B(1, 0, epi_part(0), cacc);
+                epi_finish(0, t, cacc);
+            } else {
+                epi_finish(0, t, epi_reduce(0));
+                stage_B(1, -1, nullptr, dummy);
+            }
+            PK(8);
+            __syncthreads();
+            PK(9);
+        }
+        epi_finish(1, H - 1, epi_reduce(1));
+        reward(0, H - 1);
         __syncthreads();
-        PK(9);
+        reward(1, H - 1);
     }
-    epi_finish(1, H - 1, epi_reduce(1));
-    reward(0, H - 1);
-    __syncthreads();
-    reward(1, H - 1);
 
     // ---- results
     if (rew_inline) {
         __syncthreads();
-        if (ef == 17 && e_live) { T_part(0)[epp] = rew_acc[0]; T_part(1)[epp] = rew_acc[1]; }
+        if (ef == 17 && e_live)
+            for (int ti = 0; ti < NTILES; ++ti) T_part(ti)[epp] = rew_acc[ti];
         __syncthreads();
-        if (tid < MLP_TP) { total[0] = T_part(0)[tid]; total[1] = T_part(1)[tid]; }
+        if (tid < MLP_TP)
+            for (int ti = 0; ti < NTILES; ++ti) total[ti] = T_part(ti)[tid];
     }
-    for (int ti = 0; ti < 2; ++ti) {
+    for (int ti = 0; ti < NTILES; ++ti) {
         if (tid < MLP_TP) {
-            const int n = (blockIdx.x * 2 + ti) * MLP_TP + tid;
+            const int n = (blockIdx.x * NTILES + ti) * MLP_TP + tid;
             if (n < p.n_pop) {
                 float tot = total[ti];
                 if (tot != tot) tot = -1.0e6f;
@@ -781,10 +797,10 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
 }
 
 // LDS floats the pair kernel needs
-inline int mlp_pair_lds_floats(int HT, int H, int U, int S) {
+inline int mlp_pair_lds_floats(int HT, int H, int U, int S, int ntiles) {
     const int Sp = (S + 3) & ~3;
     const int tile = 2 * 256 + HT * 256 + HT * 2 * 256 + 2 * MLP_TP * Sp + ((H * MLP_TP * U + 3) & ~3) + ((MLP_TP * U + 63) & ~63);
-    return 2 * tile + (((S + U) * 2 + S * 3 + 63) & ~63);
+    return ntiles * tile + (((S + U) * 2 + S * 3 + 63) & ~63);
 }
 
 }  // namespace bbmpc
