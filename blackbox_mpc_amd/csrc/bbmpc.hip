@@ -1424,8 +1424,3 @@ int bbmpc_synchronize(bbmpc_handle h) {
 
 }  // extern "C"
 
-#ifdef BBMPC_TOPK_DBG
-extern "C" int bbmpc_debug_topk(long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bbmpc::g_topk_dbg), 32 * sizeof(long long));
-}
-#endif

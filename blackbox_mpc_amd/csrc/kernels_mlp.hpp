@@ -701,11 +701,6 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
 
     // ---- pipelined recurrence: tile 1 runs one stage behind tile 0
     float dummy = 0.0f;
-#ifdef BBMPC_TOPK_DBG
-#define PK(slot) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && t == 3) g_topk_dbg[(slot)] = (long long)wall_clock64(); } while (0)
-#else
-#define PK(slot) do {} while (0)
-#endif
     if constexpr (NTILES == 1) {
         // one tile: the three stages back to back (same stage bodies, B-operand prefetch, compile-time activations)
         for (int t = 0; t < H; ++t) {
@@ -725,7 +720,6 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
         // alternates within each SIMD.
         const bool grp = ((wave >> 2) & 1) != 0;
         for (int t = 0; t < H; ++t) {
-            PK(0);
             if (!grp) {
                 stage_A(0);                                           // A_X(t)
                 if (t > 0) epi_finish(1, t - 1, epi_reduce(1));       // C_Y(t-1)
@@ -734,9 +728,7 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
                 stage_A(0);
             }
             if (t > 0) reward(0, t - 1);                  // state pair (t-1, t) of tile 0 is complete since the last barrier
-            PK(1);
             __syncthreads();
-            PK(2);
             if (!grp) {
                 stage_A(1);                                           // A_Y(t)
                 stage_B(0, -1, nullptr, dummy);                       // B_X(t)
@@ -745,9 +737,7 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
                 stage_A(1);
             }
             if (t > 0) reward(1, t - 1);
-            PK(5);
             __syncthreads();
-            PK(6);
             if (!grp) {
                 float cacc = lbias[min(ef, S - 1)];                   // C_X(t): reduction rides under B_Y(t)'s MFMA chain
                 stage_B(1, 0, epi_part(0), cacc);
@@ -756,9 +746,7 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
                 epi_finish(0, t, epi_reduce(0));
                 stage_B(1, -1, nullptr, dummy);
             }
-            PK(8);
             __syncthreads();
-            PK(9);
         }
         epi_finish(1, H - 1, epi_reduce(1));
         reward(0, H - 1);

@@ -12,15 +12,7 @@
 
 namespace bbmpc {
 
-#ifdef BBMPC_TOPK_DBG
-__device__ long long g_topk_dbg[32];
-#define TK(slot) do { if (tid == 0 && blockIdx.x == 0) g_topk_dbg[(slot)] = (long long)wall_clock64(); } while (0)
-#else
-#define TK(slot) do {} while (0)
-#endif
-
-constexpr int TOPK_HIST_WORDS = 272;   // 256 bins + 16 control words (256.. bucket, 257 wanted, 258 bucket size,
-                                       // 259 compaction cursor, 260/261 key min/max)
+constexpr int TOPK_HIST_WORDS = 528;   // histogram A (256 bins) + 16 control words + histogram B (256 bins)
 
 // smaller key == better (larger reward); equal rewards <=> equal keys (-0 is folded onto +0 first)
 __device__ __forceinline__ uint32_t reward_key(float r) {
@@ -44,14 +36,16 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 }
 
 // vals[N] in LDS (left untouched); eidx[k] out; hist[TOPK_HIST_WORDS] and ekeys[k] are LDS scratch.
-// All threads of the workgroup must call; ends with a barrier (eidx visible to everyone).
+// All threads of the workgroup must call (k <= nthr); ends with a barrier (eidx visible to everyone).
+// Barrier budget: 1 (key range) + 2 per radix pass (usually 2 passes) + 1 (compaction) + 2 (ranking).
 __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int k, int* eidx, uint32_t* hist,
                                                   unsigned long long* ekeys, int tid, int nthr) {
-    const int lane = tid & 63;
-    TK(0);
-    // Key range first: digits are taken from the highest bit where min and max differ.  Rewards of one
-    // population mostly share sign + exponent, so a fixed top-8-bit digit would send a whole wave's
-    // ds_add_u32 to one or two bins (serialised); digits below the common prefix spread over the bins.
+    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    uint32_t* ctrl = hist + 256;                 // [0] bucket [1] wanted [2] bucket size [3] compaction cursor
+    uint32_t* hist2 = hist + 272;                // second histogram: zeroed while the other one is scanned
+    // ---- key range: digits are taken from the highest bit where min and max differ.  Rewards of one
+    // population mostly share sign + exponent, so a fixed top-8-bit digit would send a whole wave's ds_add_u32
+    // to one or two bins (serialised); digits below the common prefix spread over the bins.
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
     for (int n = tid; n < N; n += nthr) {
         const uint32_t key = reward_key(vals[n]);
@@ -63,35 +57,35 @@ __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int 
         kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
         kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
     }
-    if (tid == 0) { hist[260] = 0xFFFFFFFFu; hist[261] = 0u; }
+    // per-wave slots instead of atomics; the min of wave w goes to hist[w] (low bins), the max to hist[16+w],
+    // both are consumed before the first histogram pass touches the bins
+    if (lane == 0) { hist[wave] = kmin; hist[16 + wave] = kmax; }
+    for (int i = tid; i < 256; i += nthr) hist2[i] = 0;          // first pass histograms into hist2
     __syncthreads();
-    if (lane == 0) { atomicMin(&hist[260], kmin); atomicMax(&hist[261], kmax); }
-    __syncthreads();
-    kmin = hist[260];
-    kmax = hist[261];
-    TK(1);
+    kmin = 0xFFFFFFFFu; kmax = 0u;
+    for (int w = 0; w < nw; ++w) { kmin = min(kmin, hist[w]); kmax = max(kmax, hist[16 + w]); }
     const uint32_t diff = kmin ^ kmax;
     int top = diff ? 32 - __clz(diff) : 0;        // number of low bits that are not common to all keys
     uint32_t T = (top >= 32) ? 0u : (kmin >> top) << top;   // common high bits
     uint32_t remaining = (uint32_t)k;
-    if (top == 0 && tid == 0) hist[258] = (uint32_t)N;       // every key equal
-    int passno = 0;
+    uint32_t eq_total = (uint32_t)N;              // top == 0: every key equal
+    int pass = 0;
+    // hist is still being read above by slower waves: the first pass uses hist2 (zeroed before the barrier),
+    // later passes alternate; the array for pass p+1 is zeroed by the idle waves while wave 0 scans pass p.
     while (top > 0) {
-        TK(2 + 4 * passno);
+        uint32_t* h = (pass & 1) ? hist : hist2;
+        uint32_t* hn = (pass & 1) ? hist2 : hist;
         const int width = top >= 8 ? 8 : top;
         const int shift = top - width;
         const uint32_t dmask = (1u << width) - 1u;
-        for (int i = tid; i < 256; i += nthr) hist[i] = 0;
-        __syncthreads();
         for (int n = tid; n < N; n += nthr) {
             const uint32_t key = reward_key(vals[n]);
             const bool in = (top >= 32) || ((key >> top) == (T >> top));
-            if (in) atomicAdd(&hist[(key >> shift) & dmask], 1u);
+            if (in) atomicAdd(&h[(key >> shift) & dmask], 1u);
         }
         __syncthreads();
-        TK(3 + 4 * passno);
         if (tid < 64) {
-            const uint4 c = *reinterpret_cast<const uint4*>(hist + 4 * lane);
+            const uint4 c = *reinterpret_cast<const uint4*>(h + 4 * lane);
             const uint32_t s = c.x + c.y + c.z + c.w;
             const uint32_t incl = wave_incl_scan(s, lane);
             const uint32_t excl = incl - s;
@@ -100,30 +94,31 @@ __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int 
                 if (cum + c.x < remaining) { cum += c.x; b += 1; cnt = c.y;
                     if (cum + c.y < remaining) { cum += c.y; b += 1; cnt = c.z;
                         if (cum + c.z < remaining) { cum += c.z; b += 1; cnt = c.w; } } }
-                hist[256] = b;
-                hist[257] = remaining - cum;     // how many keys of this bucket are still wanted
-                hist[258] = cnt;                 // how many keys the bucket holds
+                ctrl[0] = b;
+                ctrl[1] = remaining - cum;     // how many keys of this bucket are still wanted
+                ctrl[2] = cnt;                 // how many keys the bucket holds
+                ctrl[3] = 0;                   // compaction cursor
             }
+        } else {
+            for (int i = tid - 64; i < 256; i += nthr - 64) hn[i] = 0;
         }
-        TK(4 + 4 * passno);
+        if (nthr == 64)
+            for (int i = tid; i < 256; i += 64) hn[i] = 0;
         __syncthreads();
-        TK(5 + 4 * passno);
-        ++passno;
-        (void)passno;
-        T |= hist[256] << shift;
-        remaining = hist[257];
-        const bool whole_bucket = hist[258] == remaining;     // every key of the boundary bucket is a winner:
-        top = shift;                                            // the undecided low bits no longer matter
+        T |= ctrl[0] << shift;
+        remaining = ctrl[1];
+        eq_total = ctrl[2];
+        top = shift;
+        ++pass;
+        if (eq_total == remaining) break;      // every key of the boundary bucket is a winner: the undecided
+    }                                          // low bits no longer matter
+    if (pass == 0) {                           // all keys equal: no pass ran, nobody reset the cursor
+        if (tid == 0) ctrl[3] = 0;
         __syncthreads();
-        if (whole_bucket) break;
     }
-    // T is now the key of the k-th best
-    TK(20);
-    if (tid == 0) hist[259] = 0;
-    __syncthreads();
-    const uint32_t eq_total = hist[258];         // population members with exactly that key
-    // `top` low bits may be undecided after an early exit; compare on the decided prefix
+    // ---- compaction of the winners (any order); `top` low bits may be undecided after an early exit
     const uint32_t Tp = (top >= 32) ? 0u : (T >> top);
+    for (int e = tid; e < k; e += nthr) eidx[e] = 0;             // rank counters for the next phase
     for (int n = tid; n < N; n += nthr) {
         const uint32_t key = reward_key(vals[n]);
         const uint32_t kp_ = (top >= 32) ? 0u : (key >> top);
@@ -137,16 +132,13 @@ __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int 
             }
         }
         if (take) {
-            const uint32_t slot = atomicAdd(&hist[259], 1u);
+            const uint32_t slot = atomicAdd(&ctrl[3], 1u);
             ekeys[slot] = ((unsigned long long)key << 32) | (uint32_t)n;
         }
     }
     __syncthreads();
-    TK(21);
-    // rank the k winners among themselves with the whole workgroup: thread (e, chunk) counts how many
+    // ---- rank the k winners among themselves with the whole workgroup: thread (e, chunk) counts how many
     // winners in its chunk precede winner e, partial counts meet in LDS (eidx doubles as the counter array).
-    for (int e = tid; e < k; e += nthr) eidx[e] = 0;
-    __syncthreads();
     const int kp64 = (k + 63) & ~63;                 // e runs over full waves so chunk ids are wave-uniform
     const int nchunk = max(1, nthr / kp64);
     const int clen = (k + nchunk - 1) / nchunk;
@@ -164,10 +156,9 @@ __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int 
     __syncthreads();
     int myrank = -1, myidx = 0;
     if (tid < k) { myrank = eidx[tid]; myidx = (int)(uint32_t)(ekeys[tid] & 0xFFFFFFFFull); }
-    __syncthreads();                                 // callers guarantee k <= nthr
+    __syncthreads();
     if (myrank >= 0) eidx[myrank] = myidx;
     __syncthreads();
-    TK(22);
 }
 
 }  // namespace bbmpc
