@@ -52,11 +52,15 @@ __device__ __forceinline__ void block_topk_sorted(const float* vals, int N, int 
         kmin = min(kmin, key);
         kmax = max(kmax, key);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
-        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
-    }
+    // 16-lane DPP rows, then the four row results through readlane (a bpermute shuffle costs ~100 cycles/step)
+#define BB_ROW_U32(op, v, ctrl) v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xf, 0xf, false))
+    BB_ROW_U32(min, kmin, 0xB1); BB_ROW_U32(min, kmin, 0x4E); BB_ROW_U32(min, kmin, 0x141); BB_ROW_U32(min, kmin, 0x140);
+    BB_ROW_U32(max, kmax, 0xB1); BB_ROW_U32(max, kmax, 0x4E); BB_ROW_U32(max, kmax, 0x141); BB_ROW_U32(max, kmax, 0x140);
+#undef BB_ROW_U32
+    kmin = min(min((uint32_t)__builtin_amdgcn_readlane((int)kmin, 0), (uint32_t)__builtin_amdgcn_readlane((int)kmin, 16)),
+               min((uint32_t)__builtin_amdgcn_readlane((int)kmin, 32), (uint32_t)__builtin_amdgcn_readlane((int)kmin, 48)));
+    kmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)kmax, 0), (uint32_t)__builtin_amdgcn_readlane((int)kmax, 16)),
+               max((uint32_t)__builtin_amdgcn_readlane((int)kmax, 32), (uint32_t)__builtin_amdgcn_readlane((int)kmax, 48)));
     // per-wave slots instead of atomics; the min of wave w goes to hist[w] (low bins), the max to hist[16+w],
     // both are consumed before the first histogram pass touches the bins
     if (lane == 0) { hist[wave] = kmin; hist[16 + wave] = kmax; }
