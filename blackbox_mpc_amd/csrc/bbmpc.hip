@@ -610,7 +610,7 @@ bool Engine::use_fused() const {
 
 template <int OPT, bool FASTM, bool INJ, int ILP>
 static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
-    const size_t limit = 159 * 1024;   // 160 KiB per CU minus the kernel's small static LDS
+    const size_t limit = 160 * 1024;   // all of a CU's LDS
     if (lds_base + lds_samples <= limit) {
         auto fn = k_fused_pendulum<OPT, true, FASTM, INJ, ILP>;
         static bool configured = false;
@@ -666,11 +666,13 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
         ensure_trace();
         fa.t_rewards = t_rewards.p; fa.t_mean = t_mean.p; fa.t_var = t_var.p; fa.t_elites = t_elites.p; fa.t_samples = t_samples.p;
     }
+#ifdef BBMPC_KERNEL_DBG
     static long long* dbg_buf = nullptr;
     if (getenv("BBMPC_DBG")) {
         if (!dbg_buf) HIP_CHECK(hipHostMalloc((void**)&dbg_buf, 64 * 8, hipHostMallocDefault));
         fa.dbg = dbg_buf;
     }
+#endif
     fa.key = key(step);
     // two trajectories per lane (one wave per SIMD for N <= 512) unless overridden
     int ilp = 1;                 // measured: 2 waves/SIMD x 1 trajectory beats 1 wave/SIMD x 2 trajectories

@@ -50,7 +50,12 @@ struct FusedArgs {
     RngKey key;
 };
 
+// phase clocks for kernel development: build with -DBBMPC_KERNEL_DBG and run with BBMPC_DBG=1
+#ifdef BBMPC_KERNEL_DBG
 #define BB_DBG(slot) do { if (p.dbg && tid == 0 && a == 0) dbg_lds[(slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define BB_DBG(slot) do {} while (0)
+#endif
 
 __device__ __forceinline__ float block_min(float v, float* red, int tid, int nw) {
     v = wave_min(v);
@@ -91,7 +96,9 @@ __global__ void k_fused_pendulum(FusedArgs p) {
     uint32_t* hist = (uint32_t*)(red + 64);
     unsigned long long* ekeys = (unsigned long long*)(hist + TOPK_HIST_WORDS);
     float* samp = SAMPLES_LDS ? (float*)(ekeys + kp) : (p.samples_g + (size_t)a * p.HU * p.Nst);
+#ifdef BBMPC_KERNEL_DBG
     __shared__ long long dbg_lds[48];
+#endif
     const PendulumModel model{p.fix_q1 != 0};
     const float lo = p.lo[0], hi = p.hi[0];
     const float s0 = p.state[a * 3 + 0], s1 = p.state[a * 3 + 1], s2 = p.state[a * 3 + 2];
@@ -109,7 +116,9 @@ __global__ void k_fused_pendulum(FusedArgs p) {
     float action0 = (OPT == FOPT_RS) ? 0.0f : mean[0];          // iters == 0 -> untouched mean[:,0]
 
     BB_DBG(0);
+#ifdef BBMPC_KERNEL_DBG
     if (p.dbg && tid == 0 && a == 0) dbg_lds[40] = (long long)clock64();
+#endif
     for (int it = 0; it < p.iters; ++it) {
         BB_DBG(1 + it * 4);
         // ---- sample + rollout: one lane per trajectory, state in VGPRs
@@ -194,7 +203,9 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                 if (live[q]) rew[nn[q]] = tot;
             }
         }
+#ifdef BBMPC_KERNEL_DBG
         if (p.dbg && a == 0 && it == 0 && (tid & 63) == 0) dbg_lds[24 + (tid >> 6) % 8] = (long long)wall_clock64();
+#endif
         BB_DBG(2 + it * 4);
         __syncthreads();
         BB_DBG(3 + it * 4);
@@ -299,10 +310,12 @@ __global__ void k_fused_pendulum(FusedArgs p) {
     }
 
     BB_DBG(1 + p.iters * 4);
+#ifdef BBMPC_KERNEL_DBG
     if (p.dbg && tid == 0 && a == 0) {
         dbg_lds[41] = (long long)clock64();
         for (int i = 0; i < 48; ++i) p.dbg[i] = dbg_lds[i];
     }
+#endif
     // ---- state carried to the next control step
     if (OPT != FOPT_RS) {
         for (int j = tid; j < p.HU; j += nthr) {
