@@ -65,7 +65,11 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     from blackbox_mpc_amd import _build
-    _build.build()
+    if local == 0 or os.environ.get("BBMPC_BENCH_ONE_DEVICE"):
+        if rank == 0 or not os.environ.get("BBMPC_BENCH_ONE_DEVICE"):
+            _build.build()                   # one builder per node; the others wait for it
+    if world > 1:
+        dist.barrier()
     from blackbox_mpc_amd import _lib as L
     from blackbox_mpc_amd.engine import Engine
     from oracle import oracle_np as O      # inputs (start states) + the cpu_baseline leg only

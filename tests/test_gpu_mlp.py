@@ -223,3 +223,22 @@ def test_host_api_with_learned_dynamics(L, tmp_path):
     ev = O.Evaluator("cheetah", O.Handler(O.MLP(ws, bs, ["tanh", "tanh", None]), False, True, stats))
     np.testing.assert_allclose(n, ev.predict_next_state(obs, a), rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(pol._trajectory_evaluator.predict_next_state(obs, a), n, rtol=1e-6, atol=1e-6)
+
+
+def test_wide_io_network_generic_kernel(L):
+    # S + U > 32 and S > 32: outside the weights-stationary specialisations -> generic streaming kernel
+    S, U = 40, 9
+    dims, acts = [S + U, 96, 64, S], ["relu", "tanh", None]
+    from blackbox_mpc_amd.engine import Engine
+    ws, bs = O.make_mlp_params(dims, seed=3)
+    stats = _stats(S, U, 5)
+    eng = Engine(L.OPT_NONE, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=2, planning_horizon=6)
+    eng.set_mlp(ws, bs, [ACT[a] for a in acts], stats)
+    ev = O.Evaluator("cheetah", O.Handler(O.MLP(ws, bs, acts), False, True, stats))
+    rng = np.random.default_rng(1)
+    states = rng.normal(0, 0.1, (2, S)).astype(F)
+    seq = rng.uniform(-1, 1, (50, 2, 6, U)).astype(F)
+    np.testing.assert_allclose(eng.evaluate(states, seq), ev(states, seq), rtol=1e-3, atol=6e-3)
+    s1 = rng.normal(0, 0.5, (17, S)).astype(F)
+    a1 = rng.uniform(-1, 1, (17, U)).astype(F)
+    np.testing.assert_allclose(eng.predict_next_state(s1, a1), ev.predict_next_state(s1, a1), rtol=2e-5, atol=2e-5)

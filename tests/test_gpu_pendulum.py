@@ -385,3 +385,49 @@ def test_closed_loop_harness_matches_step_by_step(L):
     np.testing.assert_allclose(o, obs[0], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(r, rews[0], rtol=1e-5, atol=1e-5)
     assert np.all(np.isfinite(r)) and np.all(np.abs(a) <= 2.0)
+
+
+@pytest.mark.parametrize("opt_name", ["CEM", "PI2", "RandomSearch"])
+def test_degenerate_sizes(L, opt_name):
+    # N = 1 particle, k = N, H = 1, and max_iterations = 0 (the reference's while_loop then never runs:
+    # the action is the untouched initial mean's first entry, cem.py:129-136 / pi2.py:90-94)
+    opt = {"CEM": L.OPT_CEM, "PI2": L.OPT_PI2, "RandomSearch": L.OPT_RANDOM_SEARCH}[opt_name]
+    states = O.pendulum_start_states(2)
+    ev = _oracle_eval()
+    eng = _engine(L, opt, 2, 1, N=1, iters=2, k=1)
+    a, n, r = eng.optimize(states)
+    assert a.shape == (2, 1) and np.all(np.isfinite(a)) and np.all(np.abs(a) <= 2.0)
+    np.testing.assert_allclose(n, ev.predict_next_state(states, a), rtol=1e-5, atol=1e-5)
+    if opt_name != "RandomSearch":
+        eng0 = _engine(L, opt, 2, 7, N=33, iters=0, k=33)
+        a0, n0, _ = eng0.optimize(states)
+        np.testing.assert_array_equal(a0, np.zeros((2, 1), F))        # bounds midpoint
+        np.testing.assert_allclose(n0, ev.predict_next_state(states, a0), rtol=1e-5, atol=1e-5)
+    # k == N with an odd population: every particle is an elite
+    if opt_name == "CEM":
+        N, H = 37, 5
+        eng = _engine(L, opt, 1, H, N=N, iters=1, k=N)
+        eng.set_trace(True)
+        rng = np.random.default_rng(8)
+        xi = O.truncated_normal_noise(rng, (N, 1, H, 1))
+        eng.inject_noise(L.NOISE_TRUNC_NORMAL, xi[None])
+        a, _, _ = eng.optimize(states[:1])
+        cem = O.CEM(ev, LO, HI, horizon=H, max_iterations=1, population=N, num_elite=N, num_agents=1)
+        a_o, _, _ = cem.call(states[:1], {"trunc": [xi]})
+        assert sorted(eng.get_trace(0, L.TRACE_ELITES)[0].tolist()) == list(range(N))
+        np.testing.assert_allclose(a, a_o, rtol=0, atol=2e-5)
+
+
+def test_large_population_uses_global_samples(L):
+    # N*H too large for the LDS-resident sample block (fused path falls back to the HBM scratch) and
+    # N > 2048 with few agents (auto mode picks the per-iteration kernels): same answers as the oracle
+    N, A, H, iters, k = 4096, 1, 40, 2, 64
+    eng = _engine(L, L.OPT_CEM, A, H, N=N, iters=iters, k=k)
+    eng.set_trace(True)
+    rng = np.random.default_rng(12)
+    noise = {"trunc": [O.truncated_normal_noise(rng, (N, A, H, 1)) for _ in range(iters)]}
+    eng.inject_noise(L.NOISE_TRUNC_NORMAL, np.stack(noise["trunc"]))
+    states = O.pendulum_start_states(A)
+    act, nxt, rew = eng.optimize(states)
+    cem = _cem_lockstep(L, eng, states, noise, N, A, H, iters, k, 0.25)
+    np.testing.assert_allclose(act, cem.trace[-1]["mean"][:, 0], rtol=0, atol=2e-5)
