@@ -504,12 +504,18 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
     auto T_pen = [&](int ti) { return smem + ti * tile_sz + sz_xs + sz_h0 + sz_part + sz_st + sz_acts; };
 
     // ---- stationary weights (operand order, see set_mlp)
+    // layer-1 and last-layer slabs stay in VGPRs for the whole recurrence; with two tiles in flight the 8
+    // layer-0 operands do not fit the 128-register budget any more and are re-read per stage (L1/L2-resident)
     float wr_in[IT0 * 4], wr_hid[HT * 4], wr_out[OTL * 4];
+    const float* __restrict__ w_in_p = m.wpack[0] + ((size_t)wave * m.tiles[0]) * 256 + lane;
+    const int it0n = m.tiles[0];
+    auto load_w_in = [&]() {
 #pragma unroll
-    for (int it = 0; it < IT0; ++it)
+        for (int it = 0; it < IT0; ++it)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            wr_in[it * 4 + s] = (it < m.tiles[0]) ? m.wpack[0][(((size_t)wave * m.tiles[0] + it) * 4 + s) * 64 + lane] : 0.0f;
+            for (int s = 0; s < 4; ++s) wr_in[it * 4 + s] = (it < it0n) ? w_in_p[(it * 4 + s) * 64] : 0.0f;
+    };
+    if (NTILES == 1) load_w_in();
 #pragma unroll
     for (int it = 0; it < HT; ++it)
 #pragma unroll
@@ -519,8 +525,10 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
 #pragma unroll
         for (int s = 0; s < 4; ++s)
             wr_out[ot * 4 + s] = (ot < m.tiles[3]) ? m.wpack[2][(((size_t)ot * HT + wave) * 4 + s) * 64 + lane] : 0.0f;
-    const f32x4 bias0 = *reinterpret_cast<const f32x4*>(m.bpack[0] + ((size_t)wave * 64 + lane) * 4);
-    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(m.bpack[1] + ((size_t)wave * 64 + lane) * 4);
+    // biases are re-read per stage (one L1-resident 16-byte load each): 8 VGPRs that the 128-register budget
+    // of a 13-wave workgroup cannot spare
+    const float* __restrict__ bias0_p = m.bpack[0] + ((size_t)wave * 64 + lane) * 4;
+    const float* __restrict__ bias1_p = m.bpack[1] + ((size_t)wave * 64 + lane) * 4;
     for (int f = tid; f < S + U; f += NT) {
         const float mu = normd ? (f < S ? m.mean_s[f] : m.mean_a[f - S]) : 0.0f;
         const float sd = normd ? (f < S ? m.std_s[f] : m.std_a[f - S]) : 1.0f;
@@ -593,7 +601,8 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
     // ---- stages
     auto stage_A = [&](int ti) {
         const float* xs = T_xs(ti);
-        f32x4 acc = bias0;
+        if (NTILES == 2) load_w_in();
+        f32x4 acc = *reinterpret_cast<const f32x4*>(bias0_p);
 #pragma unroll
         for (int it = 0; it < IT0; ++it) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(xs + ((size_t)it * 64 + lane) * 4);
@@ -611,7 +620,7 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
     // it costs no time of its own; `cacc` returns the reduced value.
     auto stage_B = [&](int ti, int co, const float* cpart, float& cacc) {
         const float* h0 = T_h0(ti);
-        f32x4 acc = bias1;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(bias1_p);
         f32x4 bn = *reinterpret_cast<const f32x4*>(h0 + (size_t)lane * 4);
 #pragma unroll
         for (int it = 0; it < HT; ++it) {
