@@ -413,6 +413,8 @@ void Engine::set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, con
         }
         upload(d_wpack[l], wp);
         upload(d_bpack[l], bp);
+        upload(d_wraw[l], std::vector<float>(w[l], w[l] + (size_t)K * M));
+        upload(d_braw[l], std::vector<float>(b[l], b[l] + M));
         mlp.wpack[l] = d_wpack[l].p;
         mlp.bpack[l] = d_bpack[l].p;
     }
@@ -448,6 +450,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     q.per_particle_state = per_particle_state ? 1 : 0;
     q.final_state = final_state;
     q.nw = mlp_nw;
+    for (int l = 0; l < mlp.n_layers; ++l) { q.wraw[l] = d_wraw[l].p; q.braw[l] = d_braw[l].p; }
     const MlpLds lay = mlp_lds_layout(mlp, ra.H, U, S, mlp_nw);
     const size_t lds = (size_t)lay.total * sizeof(float);
     REQUIRE(lds <= 159 * 1024, BBMPC_E_UNSUPPORTED, "planning horizon x action dim too large for the LDS action block");
@@ -472,6 +475,30 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
                          mlp.act[1] == BBMPC_ACT_TANH && mlp.act[2] == BBMPC_ACT_NONE;
     int pair = (pair_ok && tiles_total > 256) ? 1 : 0;
     if (const char* ev = getenv("BBMPC_MLP_PAIR")) pair = (atoi(ev) != 0 && pair_ok) ? 1 : 0;
+    // quad mode (4 particles per workgroup, 4x4x1_16b MFMA, all weights in registers) when the population is too
+    // small to give every CU a 16-particle tile
+    {
+        const bool q4_ok = pair_ok && mlp.dims[0] <= 28 && mlp.dims[1] == 200 && mlp.dims[2] == 200 && mlp.dims[3] <= 64;
+        int q4 = (q4_ok && tiles_total <= 256) ? 1 : 0;
+        if (const char* ev = getenv("BBMPC_MLP_Q4")) q4 = (atoi(ev) != 0 && q4_ok) ? 1 : 0;
+        if (q4 && !getenv("BBMPC_MLP_GENERIC")) {
+            const size_t qlds = (size_t)mlp_q4_lds_floats(50, 7, 4, ra.H, U, S) * sizeof(float);
+            if (qlds <= 160 * 1024) {
+                auto fn = k_rollout_mlp_q4<50, 7, 4, ACT_TANH, ACT_TANH, ACT_NONE>;
+                static bool qconf = false;
+                if (!qconf && qlds > 64 * 1024) {
+                    HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    qconf = true;
+                }
+                dim3 qgrid((ra.n_pop + 3) / 4, A), qblock(256);
+                prof_begin();
+                hipLaunchKernelGGL(fn, qgrid, qblock, qlds, stream, q);
+                HIP_CHECK(hipGetLastError());
+                prof_end();
+                return;
+            }
+        }
+    }
     if (pair_ok && !getenv("BBMPC_MLP_GENERIC")) {
         // pipelined kernel for the 26-200-200-20 family: two tiles per workgroup when tiles outnumber the CUs,
         // one tile per workgroup otherwise (more workgroups beat better per-workgroup efficiency then)

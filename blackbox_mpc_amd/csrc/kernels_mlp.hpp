@@ -61,6 +61,8 @@ struct MlpRolloutArgs {
     int per_particle_state;   // state is [n_pop, S] (single-step API) instead of [A, S]
     float* final_state;       // optional [A? n_pop][S] written after the last step (per_particle_state layout)
     int nw;                   // waves per workgroup
+    const float* wraw[MLP_MAX_LAYERS];   // unpacked Dense kernels [in][out] (quad-mode kernel)
+    const float* braw[MLP_MAX_LAYERS];   // unpacked biases [out]
 };
 
 // tanh on the hardware exp/rcp units: sign(x) * (1 - 2 / (e^{2|x|} + 1)), 7 instructions.  Absolute error
@@ -798,6 +800,298 @@ inline int mlp_pair_lds_floats(int HT, int H, int U, int S, int ntiles) {
     const int Sp = (S + 3) & ~3;
     const int tile = 2 * 256 + HT * 256 + HT * 2 * 256 + 2 * MLP_TP * Sp + ((H * MLP_TP * U + 3) & ~3) + ((MLP_TP * U + 63) & ~63);
     return ntiles * tile + (((S + U) * 2 + S * 3 + 63) & ~63);
+}
+
+}  // namespace bbmpc
+
+namespace bbmpc {
+
+// =================================================================================================
+// Quad mode: 4 particles per workgroup on v_mfma_f32_4x4x1_16b_f32.
+//
+// The 16x16x4 tiling needs 16 particles per workgroup, so a population of 1000 (BASELINE config 4) makes
+// only 63 workgroups for 256 CUs.  The 16-block 4x4x1 form computes, per instruction, 16 independent
+// (4 features x 4 particles) outer products: give all 16 blocks the same 4 particles and 64 different features
+// and one wave produces 64 features x 4 particles per k.  A workgroup then needs just 4 particles:
+// 250 workgroups at config 4.  With ceil(hidden/64) = 4 waves per workgroup every wave sits alone on its SIMD,
+// owns the full 512-entry register file and keeps ALL of its A operands stationary (K0 + hidden + hidden/4
+// registers: 26 + 200 + 50 for 26-200-200-20).
+//   A operand, lane l : W[k][64*wave + l]                    (block l>>2, row l&3)
+//   B operand, lane l : x[k][particle l&3]                   (same for every block)
+//   D fragment, lane l: out[64*wave + 4*(l>>2) + r][l&3], r = 0..3
+// Activations travel through LDS as [k/4][particle][4] so that a lane fetches 4 consecutive k of its particle
+// with one ds_read_b128.  Last layer: K split over the waves, partial sums reduced in the epilogue.
+// Two hidden layers of equal width; HG = hidden/4 groups, K0G = ceil((S+U)/4) groups, NWQ waves.
+template <int HG, int K0G, int NWQ, int A0, int A1, int A2>
+__global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const RolloutArgs& p = q.r;
+    const MlpDesc& m = q.m;
+    constexpr int NT = NWQ * 64, QP = 4;                 // threads, particles per workgroup
+    constexpr int HK = HG * 4;                           // hidden width (multiple of 4)
+    constexpr int KS = (HG + NWQ - 1) / NWQ;             // k groups per wave in the K-split last layer
+    const int a = blockIdx.y, n0 = blockIdx.x * QP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = p.S, U = p.U, H = p.H;
+    const int Sp = (S + 3) & ~3;
+    const bool normd = m.normalized != 0;
+    // ---- LDS: xs[K0G][4][4] | h0[HG][4][4] | h1[HG][4][4] | part[NWQ][64][4] | st[2][4][Sp] | acts[H][4][U] | pen[4*U] | norm
+    float* xs = smem;
+    float* h0 = xs + K0G * 16;
+    float* h1 = h0 + HG * 16;
+    float* part = h1 + HG * 16;
+    float* st = part + NWQ * 256;
+    float* acts = st + 2 * QP * Sp;
+    float* pens = acts + ((H * QP * U + 3) & ~3);
+    float* nmean = pens + ((QP * U + 3) & ~3);
+    float* ninv = nmean + (S + U);
+    float* tmean = ninv + (S + U);
+    float* tstd = tmean + S;
+    float* lbias = tstd + S;
+
+    // ---- stationary A operands.  W_l is [in][out] row-major (dims from the descriptor, unpacked copy wraw)
+    const int M1 = m.dims[1], M3 = m.dims[3];
+    const float* __restrict__ W0 = q.wraw[0];
+    const float* __restrict__ W1 = q.wraw[1];
+    const float* __restrict__ W2 = q.wraw[2];
+    const int f = wave * 64 + lane;                      // hidden feature this lane's A operands belong to
+    float wA0[K0G * 4], wA1[HK], wA2[KS * 4];
+#pragma unroll
+    for (int k = 0; k < K0G * 4; ++k) wA0[k] = (k < m.dims[0] && f < M1) ? W0[(size_t)k * M1 + f] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < HK; ++k) wA1[k] = (f < M1) ? W1[(size_t)k * M1 + f] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < KS * 4; ++k) {                    // last layer: my k range, output feature = lane
+        const int kk = wave * KS * 4 + k;
+        wA2[k] = (kk < HK && lane < M3) ? W2[(size_t)kk * M3 + lane] : 0.0f;
+    }
+    // bias of my 4 D rows: features 64*wave + 4*(lane>>2) + r
+    f32x4 b0, b1;
+    {
+        const int fb = wave * 64 + 4 * (lane >> 2);
+        b0.x = fb + 0 < M1 ? q.braw[0][fb + 0] : 0.0f; b0.y = fb + 1 < M1 ? q.braw[0][fb + 1] : 0.0f;
+        b0.z = fb + 2 < M1 ? q.braw[0][fb + 2] : 0.0f; b0.w = fb + 3 < M1 ? q.braw[0][fb + 3] : 0.0f;
+        b1.x = fb + 0 < M1 ? q.braw[1][fb + 0] : 0.0f; b1.y = fb + 1 < M1 ? q.braw[1][fb + 1] : 0.0f;
+        b1.z = fb + 2 < M1 ? q.braw[1][fb + 2] : 0.0f; b1.w = fb + 3 < M1 ? q.braw[1][fb + 3] : 0.0f;
+    }
+    for (int i = tid; i < S + U; i += NT) {
+        const float mu = normd ? (i < S ? m.mean_s[i] : m.mean_a[i - S]) : 0.0f;
+        const float sd = normd ? (i < S ? m.std_s[i] : m.std_a[i - S]) : 1.0f;
+        nmean[i] = mu;
+        ninv[i] = normd ? 1.0f / (sd + 1e-7f) : 1.0f;
+        if (i < S) {
+            tmean[i] = normd ? m.mean_t[i] : 0.0f;
+            tstd[i] = normd ? (m.std_t[i] + 1e-7f) : 1.0f;
+            lbias[i] = q.braw[2][i];
+        }
+    }
+    // ---- prologue: the 4 particles' action block + start state
+    for (int i = tid; i < QP * U; i += NT) {
+        const int pp = i / U, u = i % U;
+        const int n = n0 + pp;
+        const bool live = n < p.n_pop;
+        const float lo = p.lo[u], hi = p.hi[u];
+        float pen_part = 0.0f;
+        for (int t = 0; t < H; ++t) {
+            const int j = t * U + u;
+            float x = 0.0f;
+            if (live) {
+                if (q.mode == SRC_REF) x = p.seq[((size_t)n * p.A + a) * p.HU + j];
+                else if (q.mode == SRC_BUF) x = p.cand[((size_t)a * p.HU + j) * p.Nst + n];
+                else {
+                    float xi;
+                    if (p.inj) xi = p.inj[((size_t)a * p.HU + j) * p.Nst + n];
+                    else {
+                        const U4 blk = rng_block(p.key, p.stream, p.iter, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)j);
+                        const uint32_t w = pick_word(blk, (uint32_t)j);
+                        xi = (q.mode == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
+                    }
+                    if (q.mode == SRC_UNIFORM) x = xi * (hi - lo) + lo;
+                    else x = xi * p.sigma[a * p.HU + j] + p.mean[a * p.HU + j];
+                }
+                if (q.pen) {
+                    const float xf = clipf(x, lo, hi);
+                    const float d = x - xf;
+                    pen_part = pen_part + d * d;
+                    x = xf;
+                }
+                if (p.samples) p.samples[((size_t)a * p.HU + j) * p.Nst + n] = x;
+            }
+            acts[(t * QP + pp) * U + u] = x;
+        }
+        pens[i] = pen_part;
+    }
+    for (int i = tid; i < K0G * 16; i += NT) xs[i] = 0.0f;
+    for (int i = tid; i < QP * S; i += NT) st[(i / S) * Sp + (i % S)] = p.state[a * S + (i % S)];
+    __syncthreads();
+    // vector layout [k/4][p][4]
+    auto vaddr = [](int k, int pp) { return ((k >> 2) * 4 + pp) * 4 + (k & 3); };
+    for (int i = tid; i < QP * (S + U); i += NT) {
+        const int k = i / QP, pp = i % QP;
+        const float v = (k < S) ? st[pp * Sp + k] : acts[pp * U + (k - S)];
+        xs[vaddr(k, pp)] = (v - nmean[k]) * ninv[k];
+    }
+    __syncthreads();
+
+    const int pl = lane & 3;                              // my particle
+    const int my_row = (wave * 16 + (lane >> 2)) * 16 + pl * 4;     // where my D fragment goes in h0/h1 (floats)
+    const bool own_rows = (wave * 64 + 4 * (lane >> 2)) < HK;
+    // HalfCheetah reward (cost_func.py:5-22) needs only cur[5..7], cur[17], nxt[17] and the action: the epilogue
+    // thread of output feature 17 accumulates it in place (same operation order as reward_generic); any other
+    // reward goes through reward_generic on threads 0..3.
+    const bool rew_inline = (p.reward_kind != REW_PENDULUM) && S > 17;
+    float total = 0.0f;                                   // rew_inline: thread (feature 17, particle pp); else threads 0..3
+    for (int t = 0; t < H; ++t) {
+        float* cur = st + (t & 1) * QP * Sp;
+        float* nxt = st + ((t + 1) & 1) * QP * Sp;
+        // ---- layer 0
+        {
+            f32x4 acc0 = b0, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 bq[K0G];                                  // all B operands in flight before the first MFMA
+#pragma unroll
+            for (int g = 0; g < K0G; ++g) bq[g] = *reinterpret_cast<const f32x4*>(xs + (g * 4 + pl) * 4);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < K0G; ++g) {
+                const f32x4 b = bq[g];
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA0[g * 4 + 0], b.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA0[g * 4 + 1], b.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA0[g * 4 + 2], b.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA0[g * 4 + 3], b.w, acc1, 0, 0, 0);
+            }
+            f32x4 o;
+            o.x = apply_act_ct<A0>(acc0.x + acc1.x); o.y = apply_act_ct<A0>(acc0.y + acc1.y);
+            o.z = apply_act_ct<A0>(acc0.z + acc1.z); o.w = apply_act_ct<A0>(acc0.w + acc1.w);
+            if (own_rows) *reinterpret_cast<f32x4*>(h0 + my_row) = o;
+        }
+        if (!rew_inline && t > 0 && tid < QP) {            // reward of step t-1 (both states complete)
+            const float* c0 = st + ((t - 1) & 1) * QP * Sp;
+            total = total + reward_generic(p.reward_kind, p.fix_q1 != 0, c0 + tid * Sp, acts + ((t - 1) * QP + tid) * U,
+                                           cur + tid * Sp, S, U);
+        }
+        __syncthreads();
+        // ---- layer 1: 4 independent accumulator chains
+        {
+            f32x4 c0 = b1, c1 = {0.0f, 0.0f, 0.0f, 0.0f}, c2 = c1, c3 = c1;
+            // B operands are fetched one chunk ahead of the MFMAs that consume them: this wave is alone on its SIMD,
+            // nothing else hides the LDS latency
+            constexpr int CH = 10, NCH = (HG + CH - 1) / CH;
+            f32x4 bq[2][CH];
+#pragma unroll
+            for (int g = 0; g < CH; ++g) bq[0][g] = *reinterpret_cast<const f32x4*>(h0 + (min(g, HG - 1) * 4 + pl) * 4);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c + 1 < NCH) {
+#pragma unroll
+                    for (int g = 0; g < CH; ++g)
+                        bq[(c + 1) & 1][g] = *reinterpret_cast<const f32x4*>(h0 + (min((c + 1) * CH + g, HG - 1) * 4 + pl) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < CH; ++g) {
+                    const int gg = c * CH + g;
+                    if (gg < HG) {
+                        const f32x4 b = bq[c & 1][g];
+                        c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA1[gg * 4 + 0], b.x, c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA1[gg * 4 + 1], b.y, c1, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA1[gg * 4 + 2], b.z, c2, 0, 0, 0);
+                        c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA1[gg * 4 + 3], b.w, c3, 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x4 o;
+            o.x = apply_act_ct<A1>((c0.x + c1.x) + (c2.x + c3.x)); o.y = apply_act_ct<A1>((c0.y + c1.y) + (c2.y + c3.y));
+            o.z = apply_act_ct<A1>((c0.z + c1.z) + (c2.z + c3.z)); o.w = apply_act_ct<A1>((c0.w + c1.w) + (c2.w + c3.w));
+            if (own_rows) *reinterpret_cast<f32x4*>(h1 + my_row) = o;
+        }
+        __syncthreads();
+        // ---- last layer, K split: my k range, output feature = 4*(lane>>2)+r ... only features < S matter
+        {
+            f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = c0;
+            f32x4 bq[KS];
+#pragma unroll
+            for (int g = 0; g < KS; ++g) {
+                const int gg = min(wave * KS + g, HG - 1);               // clamped; out-of-range k has zero weights
+                bq[g] = *reinterpret_cast<const f32x4*>(h1 + (gg * 4 + pl) * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < KS; ++g) {
+                const f32x4 b = bq[g];
+                c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA2[g * 4 + 0], b.x, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA2[g * 4 + 1], b.y, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA2[g * 4 + 2], b.z, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA2[g * 4 + 3], b.w, c1, 0, 0, 0);
+            }
+            f32x4 o = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
+            *reinterpret_cast<f32x4*>(part + ((size_t)wave * 64 + lane) * 4) = o;
+        }
+        __syncthreads();
+        // ---- epilogue: thread (feature k, particle pp)
+        for (int i = tid; i < QP * (S + U); i += NT) {
+            const int k = i / QP, pp = i % QP;
+            float v;
+            if (k < S) {
+                // D fragment of output feature k: lane (k>>2)*4 + pp, register k&3
+                const int ln = (k >> 2) * 4 + pp, rg = k & 3;
+                float acc = lbias[k];
+#pragma unroll
+                for (int w = 0; w < NWQ; ++w) acc = acc + part[((size_t)w * 64 + ln) * 4 + rg];
+                acc = apply_act_ct<A2>(acc);
+                const float dev = normd ? tmean[k] + acc * tstd[k] : acc;
+                const float ck = cur[pp * Sp + k];
+                v = dev + ck;
+                nxt[pp * Sp + k] = v;
+                if (rew_inline && k == 17) {
+                    const float c5 = cur[pp * Sp + 5], c6 = cur[pp * Sp + 6], c7 = cur[pp * Sp + 7];
+                    const float* ac = acts + (t * QP + pp) * U;
+                    float ss = 0.0f;
+                    for (int u = 0; u < U; ++u) ss = ss + ac[u] * ac[u];
+                    float r = 0.0f;
+                    if (c5 >= 0.2f) r = r + (-10.0f);
+                    if (c6 >= 0.0f) r = r + (-10.0f);
+                    if (c7 >= 0.0f) r = r + (-10.0f);
+                    r = r + (v - ck) / 0.01f;
+                    r = r - 0.0f * ss;
+                    total = total + r;
+                }
+            } else {
+                const int tn = (t + 1 < H) ? t + 1 : t;
+                v = acts[(tn * QP + pp) * U + (k - S)];
+            }
+            xs[vaddr(k, pp)] = (v - nmean[k]) * ninv[k];
+        }
+        __syncthreads();
+    }
+    const int rt = rew_inline ? tid - 17 * QP : tid;      // particle whose total this thread holds
+    if (rt >= 0 && rt < QP) {
+        if (!rew_inline) {
+            const float* c0 = st + ((H - 1) & 1) * QP * Sp;
+            const float* n1 = st + (H & 1) * QP * Sp;
+            total = total + reward_generic(p.reward_kind, p.fix_q1 != 0, c0 + rt * Sp, acts + ((H - 1) * QP + rt) * U,
+                                           n1 + rt * Sp, S, U);
+        }
+        const int n = n0 + rt;
+        if (n < p.n_pop) {
+            if (total != total) total = -1.0e6f;
+            if (q.pen) {
+                float pen = 0.0f;
+                for (int u = 0; u < U; ++u) pen = pen + pens[rt * U + u];
+                const float nr = sqrtf(pen);
+                pen = nr * nr;
+                total = total - pen;
+                if (p.penalty_out) p.penalty_out[(size_t)a * p.Nst + n] = pen;
+            }
+            p.rewards[(size_t)a * p.Nst + n] = total;
+        }
+    }
+}
+
+inline int mlp_q4_lds_floats(int HG, int K0G, int NWQ, int H, int U, int S) {
+    const int Sp = (S + 3) & ~3;
+    return K0G * 16 + 2 * HG * 16 + NWQ * 256 + 2 * 4 * Sp + ((H * 4 * U + 3) & ~3) + ((4 * U + 3) & ~3) + 2 * (S + U) + 3 * S + 16;
 }
 
 }  // namespace bbmpc
