@@ -69,6 +69,13 @@ def _load():
         raise ImportError(
             "blackbox_mpc_amd: %s is missing. Build it with `python -m blackbox_mpc_amd._build` "
             "(needs hipcc). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm carries its own libamdhip64 and must be the first to load it --
+    # libbbmpc.so then binds to that same runtime (shared device pointers / streams with torch tensors).  Loaded the
+    # other way round, torch comes up with a second runtime and reports no devices.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     if lib.bbmpc_abi_version() != ABI_VERSION:
         raise ImportError("blackbox_mpc_amd: libbbmpc.so ABI %d != expected %d; rebuild"

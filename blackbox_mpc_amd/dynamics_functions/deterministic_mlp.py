@@ -1,8 +1,9 @@
 """Learned deterministic MLP dynamics (reference dynamics_functions/deterministic_mlp.py:5-51).
 
 A weights container: Dense kernels [in,out] + biases, Keras default init
-(Glorot-uniform / zeros).  The forward pass runs on the GPU inside the fused
-rollout kernel (MFMA path); training is out of scope of this engine."""
+(Glorot-uniform / zeros).  The planning-time forward pass runs on the GPU inside the fused
+rollout kernels (MFMA path); training (SystemDynamicsHandler.train) runs through
+dynamics_functions/_train_torch.py on the same device."""
 import numpy as np
 
 from .. import _lib as L
@@ -68,3 +69,13 @@ class DeterministicMLP:
     def __call__(self, x, train=False):
         raise NotImplementedError("DeterministicMLP.forward runs fused inside the engine's rollout kernels; use "
                                   "DeterministicTrajectoryEvaluator.predict_next_state")
+
+    # -- losses (deterministic_mlp.py:53-92: both are loss_fn = Keras MeanSquaredError unless overridden) ----------
+    def get_loss(self, expected_output, predictions):
+        if self.loss_fn is not None:
+            return self.loss_fn(expected_output, predictions)
+        d = np.asarray(expected_output, np.float32) - np.asarray(predictions, np.float32)
+        return np.float32(np.mean(d * d))
+
+    def get_validation_loss(self, expected_output, predictions):
+        return self.get_loss(expected_output, predictions)

@@ -1,7 +1,10 @@
-"""Inference half of the reference's SystemDynamicsHandler
-(dynamics_handlers/system_dynamics_handler.py:7-161): which dynamics function, whether it is the
-true model, and the six normalisation statistics.  process_input / process_output are fused into
-the rollout kernels (GEMM-1 prologue / GEMM-3 epilogue); training + SavedModel I/O are out of scope."""
+"""Counterpart of the reference's SystemDynamicsHandler (dynamics_handlers/system_dynamics_handler.py).
+
+Inference half (:7-161): which dynamics function, whether it is the true model, and the six normalisation
+statistics; process_input / process_output are fused into the rollout kernels (GEMM-1 prologue / GEMM-3 epilogue).
+Training half (:163-349): dataset assembly, train/validation split, freeze-after-first
+normalisation, shuffled drop-remainder batches, MSE + Keras-Adam on the GPU (dynamics_functions/_train_torch.py);
+the SavedModel checkpoint is replaced by `mlp.npz` + the reference's six `.npy` statistics files."""
 import os
 
 import numpy as np
@@ -26,8 +29,19 @@ class SystemDynamicsHandler:
         self._save_model_frequency, self._saved_model_dir = save_model_frequency, saved_model_dir
         self._stats = None
         self._version = 0
+        # training state (:50-56)
+        self._model_training_in = np.zeros((0, self._dim_U + self._dim_S), np.float32)
+        self._model_validation_in = np.zeros((0, self._dim_U + self._dim_S), np.float32)
+        self._model_training_out = np.zeros((0, self._dim_S), np.float32)
+        self._model_validation_out = np.zeros((0, self._dim_S), np.float32)
+        self._training_iter = 0
+        self._refining_model_iter = 0
+        self._first_time = True
+        self.training_loss = None
+        self.validation_loss = None
         if saved_model_dir is not None:
             self.load(saved_model_dir)
+            self._first_time = False                     # :61 a loaded model keeps its statistics
 
     # -- normalisation statistics (system_dynamics_handler.py:84-95, 340-349) -----------------------
     def set_normalization_stats(self, mean_states, std_states, mean_actions, std_actions, mean_targets, std_targets):
@@ -66,5 +80,88 @@ class SystemDynamicsHandler:
             for n, v in zip(_STATS, self._stats):
                 np.save(os.path.join(log_dir, n + ".npy"), v)
 
-    def train(self, *args, **kwargs):
-        raise NotImplementedError("dynamics-model training is outside the rollout engine (SURVEY.md 8 f-3)")
+    # -- training (system_dynamics_handler.py:163-349) ---------------------------------------------------------------
+    def _append_to_training_dataset(self, observations_trajectories, actions_trajectories, rewards_trajectories,
+                                    validation_split=0.2, split_mask=None):
+        """:292-331.  Episodes: observations [T+1, A, S], actions [T, A, U]; rows are (s_t, a_t) -> s_{t+1} - s_t,
+        episode-major, then agent, then t.  Each row goes to the training set with probability 1 - validation_split
+        (np.random.choice, :311-313); `split_mask` injects that draw (True = training row)."""
+        acs_all = np.array(actions_trajectories)
+        num_agents = acs_all.shape[2]
+        d_in, d_out = [], []
+        for obs, acs in zip(observations_trajectories, acs_all):
+            obs = np.asarray(obs)
+            for agent in range(num_agents):
+                states = obs[:-1, agent]
+                d_in.append(np.concatenate([states, acs[:, agent]], axis=-1))
+                d_out.append(obs[1:, agent] - states)                      # default_transform_targets
+        d_in = np.array(d_in, dtype=np.float32).reshape(-1, self._dim_U + self._dim_S)
+        d_out = np.array(d_out, dtype=np.float32).reshape(-1, self._dim_S)
+        if split_mask is None:
+            split_mask = np.random.choice([False, True], size=d_in.shape[0], p=[validation_split, 1.0 - validation_split])
+        split_mask = np.asarray(split_mask, bool)
+        if split_mask.shape[0] != d_in.shape[0]:
+            raise ValueError("split_mask needs one entry per transition (%d)" % d_in.shape[0])
+        self._model_training_in = np.concatenate([self._model_training_in, d_in[split_mask]], axis=0)
+        self._model_training_out = np.concatenate([self._model_training_out, d_out[split_mask]], axis=0)
+        self._model_validation_in = np.concatenate([self._model_validation_in, d_in[~split_mask]], axis=0)
+        self._model_validation_out = np.concatenate([self._model_validation_out, d_out[~split_mask]], axis=0)
+
+    def _recompute_normalization(self):
+        """:340-349 -- statistics of the TRAINING rows (population std)."""
+        S = self._dim_S
+        tin, tout = self._model_training_in, self._model_training_out
+        self.set_normalization_stats(np.mean(tin[:, :S], axis=0), np.std(tin[:, :S], axis=0),
+                                     np.mean(tin[:, S:], axis=0), np.std(tin[:, S:], axis=0),
+                                     np.mean(tout, axis=0), np.std(tout, axis=0))
+
+    def _normalize_data(self, data_in, data_out):
+        """:333-338; un-normalised handlers train on the raw rows."""
+        if not self._is_normalized:
+            return data_in, data_out
+        ms, ss, ma, sa, mt, st = self._stats
+        S = self._dim_S
+        s = (data_in[:, :S] - ms) / (ss + 1e-7)
+        a = (data_in[:, S:] - ma) / (sa + 1e-7)
+        t = (data_out - mt) / (st + 1e-7)
+        return np.concatenate([s, a], axis=1).astype(np.float32), t.astype(np.float32)
+
+    def train(self, observations_trajectories, actions_trajectories, rewards_trajectories, validation_split=0.2,
+              batch_size=128, learning_rate=1e-3, epochs=30, nn_optimizer=None, *, device=None, seed=None,
+              split_mask=None, permutations=None):
+        """Reference signature (:163-166); `nn_optimizer` must be None/"Adam" (tf.keras.optimizers.Adam is the only
+        optimizer the reference's callers use).  Keyword-only extras: `device` (default: the GPU -- training on the
+        host has to be asked for explicitly with device="cpu"), and the injected random draws `split_mask`,
+        `permutations` (one per epoch) / `seed` for reproducible runs."""
+        if self._is_true_model:
+            raise Exception("the true model has nothing to train")
+        if nn_optimizer is not None and getattr(nn_optimizer, "__name__", str(nn_optimizer)).lower() != "adam":
+            raise NotImplementedError("only Adam (the reference's default nn_optimizer) is built")
+        fn = self._dynamics_function
+        if fn is None or not hasattr(fn, "weights"):
+            raise Exception("train() needs a DeterministicMLP dynamics function")
+        import torch
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("SystemDynamicsHandler.train runs on the GPU and none is visible "
+                                   "(pass device='cpu' explicitly to train on the host)")
+            device = "cuda"
+        self._append_to_training_dataset(observations_trajectories, actions_trajectories, rewards_trajectories,
+                                         validation_split=validation_split, split_mask=split_mask)
+        if self._first_time:                                               # :193-198 statistics are frozen after the first call
+            if self._is_normalized:
+                self._recompute_normalization()
+            self._first_time = False
+        tin, tout = self._normalize_data(self._model_training_in, self._model_training_out)
+        vin, vout = self._normalize_data(self._model_validation_in, self._model_validation_out)
+        from ..dynamics_functions._train_torch import DenseTrainer
+        trainer = DenseTrainer(fn.weights, fn.biases, fn.activation_codes, device, learning_rate=learning_rate)  # fresh Adam per call (:258)
+        self.training_loss, self.validation_loss = trainer.fit(tin, tout, vin, vout, epochs, batch_size,
+                                                               permutations=permutations, generator_seed=seed)
+        fn.set_weights(*trainer.numpy_params())                            # bumps the version: evaluators re-upload
+        self._version += 1
+        self._refining_model_iter += 1                                     # :290
+        self._training_iter += 1
+        if self._training_iter % self._save_model_frequency == 0 and self._log_dir is not None:   # :212-241
+            self.save(os.path.join(self._log_dir, "saved_model_%d" % self._refining_model_iter))
+        return

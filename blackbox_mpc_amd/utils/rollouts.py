@@ -20,6 +20,9 @@ class ModelEnvironment:
         self._ev = trajectory_evaluator
         self._start = np.asarray(start_states, np.float32)
         self._state = self._start.copy()
+        h = getattr(trajectory_evaluator, "_system_dynamics_handler", None)
+        self.action_space = getattr(h, "_env_action_space", None)
+        self.observation_space = getattr(h, "_env_observation_space", None)
 
     def reset(self):
         self._state = self._start.copy()
@@ -34,11 +37,15 @@ class ModelEnvironment:
 
 
 def _sample(env, horizon, policy, episode_step, exploration_noise=False, tf_writer=None):
+    from ..policies.model_free_base_policy import ModelFreeBasePolicy
     policy.reset()
     observations, actions, rewards, times, reward_sum = [env.reset()], [], [], [], 0
     for t in range(horizon):
         start = time.time()
-        action, expected_obs, expected_reward = policy.act(observations[t], t, exploration_noise)
+        if isinstance(policy, ModelFreeBasePolicy):              # rollouts.py:93-101
+            action = np.asarray(policy.act(observations[t], t))
+        else:
+            action, expected_obs, expected_reward = policy.act(observations[t], t, exploration_noise)
         times.append(time.time() - start)
         actions.append(action)
         obs, reward, done, info = env.step(action)

@@ -1,0 +1,173 @@
+"""Dynamics-model training row on the host: the product trainer (PyTorch, here with
+device="cpu" asked for explicitly) against the NumPy oracle (oracle/oracle_train.py) with every random draw injected.
+
+Tolerance: the oracle is float64, the product float32; after a few hundred Adam steps the weights agree to
+~1e-4 absolute (Adam's m/(sqrt(v)+eps) is scale free, so fp32 rounding enters at relative 1e-7 per step)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as O
+from oracle import oracle_train as OT
+
+F = np.float32
+
+
+def _episodes(n_eps, T, A, seed):
+    """pendulum episodes under random torques, generated with the hot-path oracle's true model"""
+    rng = np.random.default_rng(seed)
+    ev = O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))
+    obs_l, acs_l, rew_l = [], [], []
+    for e in range(n_eps):
+        s = O.pendulum_start_states(A, agent_offset=e * A)
+        obs, acs, rews = [s], [], []
+        for t in range(T):
+            a = rng.uniform(-2, 2, (A, 1)).astype(F)
+            n = ev.predict_next_state(s, a)
+            rews.append(ev.evaluate_next_reward(s, n, a))
+            obs.append(n)
+            acs.append(a)
+            s = n
+        obs_l.append(np.array(obs))
+        acs_l.append(np.array(acs))
+        rew_l.append(np.array(rews))
+    return obs_l, acs_l, rew_l
+
+
+def _handler(layers=(4, 16, 16, 3), acts=("tanh", "relu", None), normalized=True, seed=0, **kw):
+    from blackbox_mpc_amd import Box
+    from blackbox_mpc_amd.dynamics_functions.deterministic_mlp import DeterministicMLP
+    from blackbox_mpc_amd.dynamics_handlers.system_dynamics_handler import SystemDynamicsHandler
+    fn = DeterministicMLP(list(layers), list(acts), seed=seed)
+    h = SystemDynamicsHandler(Box(low=[-2.0], high=[2.0]), Box(low=[-1, -1, -8], high=[1, 1, 8]),
+                              dynamics_function=fn, is_normalized=normalized, **kw)
+    return h, fn
+
+
+def test_dataset_assembly_split_and_frozen_statistics():
+    obs, acs, rews = _episodes(3, 20, 2, 0)
+    h, fn = _handler()
+    d_in, d_out = OT.assemble_dataset(obs, acs)
+    assert d_in.shape == (3 * 2 * 20, 4) and d_out.shape == (120, 3)
+    np.testing.assert_array_equal(d_in[:20, :3], obs[0][:-1, 0])            # episode 0, agent 0, t = 0..19
+    np.testing.assert_array_equal(d_in[20:40, 3:], acs[0][:, 1])             # then agent 1
+    np.testing.assert_array_equal(d_out[40:60], obs[1][1:, 0] - obs[1][:-1, 0])
+    mask = np.random.default_rng(1).random(120) > 0.2
+    h.train(obs, acs, rews, epochs=1, batch_size=16, device="cpu", split_mask=mask,
+            permutations=[np.arange(mask.sum())])
+    np.testing.assert_array_equal(h._model_training_in, d_in[mask])
+    np.testing.assert_array_equal(h._model_validation_out, d_out[~mask])
+    want = OT.normalization_stats(d_in[mask], d_out[mask], 3)
+    for got, w in zip(h.normalization_stats(), want):
+        np.testing.assert_allclose(got, w, rtol=1e-6, atol=1e-7)
+    # second call: data appended, statistics frozen (system_dynamics_handler.py:193-198)
+    frozen = [v.copy() for v in h.normalization_stats()]
+    obs2, acs2, rews2 = _episodes(1, 20, 2, 5)
+    h.train(obs2, acs2, rews2, epochs=1, batch_size=16, device="cpu", seed=0)
+    assert h._model_training_in.shape[0] + h._model_validation_in.shape[0] == 160
+    for got, w in zip(h.normalization_stats(), frozen):
+        np.testing.assert_array_equal(got, w)
+
+
+@pytest.mark.parametrize("normalized", [True, False])
+def test_training_matches_numpy_oracle(normalized):
+    obs, acs, rews = _episodes(4, 40, 2, 2)
+    h, fn = _handler(normalized=normalized, seed=3)
+    w0, b0 = [w.copy() for w in fn.weights], [b.copy() for b in fn.biases]
+    d_in, d_out = OT.assemble_dataset(obs, acs)
+    rng = np.random.default_rng(4)
+    mask = rng.random(d_in.shape[0]) > 0.25
+    epochs, B = 6, 32
+    perms = [rng.permutation(int(mask.sum())) for _ in range(epochs)]
+    v0 = fn._version
+    h.train(obs, acs, rews, validation_split=0.25, batch_size=B, learning_rate=2e-3, epochs=epochs, device="cpu",
+            split_mask=mask, permutations=perms)
+    assert fn._version > v0                                                  # evaluators will re-upload the model
+    tin, tout, vin, vout = d_in[mask], d_out[mask], d_in[~mask], d_out[~mask]
+    if normalized:
+        stats = OT.normalization_stats(tin, tout, 3)
+        (tin, tout), (vin, vout) = OT.normalize(tin, tout, stats, 3), OT.normalize(vin, vout, stats, 3)
+    w, b, tl, vl = OT.train(w0, b0, ["tanh", "relu", None], tin, tout, vin, vout, perms, batch_size=B, learning_rate=2e-3)
+    for got, want in zip(fn.weights + fn.biases, w + b):
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-4)
+    np.testing.assert_allclose(h.training_loss, tl, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(h.validation_loss, vl, rtol=1e-4, atol=1e-6)
+    assert tl[-1] < tl[0]
+
+
+def test_drop_remainder_with_too_few_rows_leaves_the_model_untouched():
+    obs, acs, rews = _episodes(1, 10, 1, 7)
+    h, fn = _handler()
+    w0 = [w.copy() for w in fn.weights]
+    h.train(obs, acs, rews, batch_size=128, epochs=2, device="cpu", split_mask=np.ones(10, bool))
+    for a, b in zip(fn.weights, w0):
+        np.testing.assert_array_equal(a, b)
+    assert np.all(np.isnan(h.training_loss))
+
+
+def test_checkpoint_every_save_model_frequency(tmp_path):
+    from blackbox_mpc_amd import Box
+    from blackbox_mpc_amd.dynamics_handlers.system_dynamics_handler import SystemDynamicsHandler
+    obs, acs, rews = _episodes(2, 20, 1, 8)
+    h, fn = _handler(log_dir=str(tmp_path), save_model_frequency=2)
+    h.train(obs, acs, rews, batch_size=8, epochs=1, device="cpu", seed=1)
+    assert not os.path.exists(tmp_path / "saved_model_1")
+    h.train(obs, acs, rews, batch_size=8, epochs=1, device="cpu", seed=1)
+    d = tmp_path / "saved_model_2"
+    for n in ("mean_states", "std_states", "mean_actions", "std_actions", "mean_targets", "std_targets"):
+        assert os.path.exists(d / (n + ".npy"))                              # the reference's file names (:219-241)
+    h2 = SystemDynamicsHandler(Box(low=[-2.0], high=[2.0]), Box(low=[-1, -1, -8], high=[1, 1, 8]),
+                               saved_model_dir=str(d))
+    for a, b in zip(h2._dynamics_function.weights, fn.weights):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(h2.normalization_stats(), h.normalization_stats()):
+        np.testing.assert_array_equal(a, b)
+    assert h2._first_time is False
+
+
+def test_train_refuses_silent_host_fallback_and_true_model():
+    import torch
+    obs, acs, rews = _episodes(1, 10, 1, 9)
+    h, fn = _handler()
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="GPU"):
+            h.train(obs, acs, rews)
+    from blackbox_mpc_amd import Box
+    from blackbox_mpc_amd.dynamics_handlers.system_dynamics_handler import SystemDynamicsHandler
+    ht = SystemDynamicsHandler(Box(low=[-2.0], high=[2.0]), Box(low=[-1, -1, -8], high=[1, 1, 8]), true_model=True)
+    with pytest.raises(Exception):
+        ht.train(obs, acs, rews, device="cpu")
+
+
+def test_random_policy_and_learn_dynamics_from_policy_on_a_host_env():
+    from blackbox_mpc_amd import Box
+    from blackbox_mpc_amd.dynamics_functions.deterministic_mlp import DeterministicMLP
+    from blackbox_mpc_amd.policies import RandomPolicy
+    from blackbox_mpc_amd.utils.dynamics_learning import learn_dynamics_from_policy
+
+    class Env:                                      # vector env over the oracle's true pendulum
+        action_space = Box(low=[-2.0], high=[2.0])
+        observation_space = Box(low=[-1, -1, -8], high=[1, 1, 8])
+
+        def __init__(self, A):
+            self.A, self.ev = A, O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))
+
+        def reset(self):
+            self.s = O.pendulum_start_states(self.A)
+            return self.s.copy()
+
+        def step(self, a):
+            n = self.ev.predict_next_state(self.s, a)
+            r = self.ev.evaluate_next_reward(self.s, n, a)
+            self.s = n
+            return n.copy(), r, False, {}
+
+    pol = RandomPolicy(3, Env.action_space, seed=0)
+    a = np.stack([pol.act(None, t) for t in range(200)])
+    assert a.shape == (200, 3, 1) and a.min() >= -2.0 and a.max() <= 2.0 and a.std() > 1.0
+    h = learn_dynamics_from_policy(Env(3), pol, number_of_rollouts=4, task_horizon=50,
+                                   dynamics_function=DeterministicMLP([4, 32, 32, 3], ["tanh", "tanh", None], seed=1),
+                                   epochs=25, batch_size=32, learning_rate=3e-3, device="cpu", seed=0)
+    assert h.training_loss[-1] < 0.25 * h.training_loss[0]
+    assert h.validation_loss[-1] < h.validation_loss[0]
