@@ -180,7 +180,8 @@ def main():
             roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None, "traffic": None,
                     "algorithmic_flops_per_launch": launch_traj * flops_per_traj,
-                    "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32); peak = dense fp32 matrix rate"}
+                    "note": "fp32-in/fp32-acc MFMA (%s); peak = dense fp32 matrix rate"
+                            % ("v_mfma_f32_4x4x1_16b_f32" if kname.endswith("_q4") else "v_mfma_f32_16x16x4_f32")}
         else:
             achieved = launch_traj * bytes_per_traj / (avg_ms * 1e-3) / 1e9 if roll_n else None
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

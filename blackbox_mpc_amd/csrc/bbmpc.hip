@@ -491,6 +491,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
                     qconf = true;
                 }
                 dim3 qgrid((ra.n_pop + 3) / 4, A), qblock(256);
+                dominant_kernel = "k_rollout_mlp_q4";
                 prof_begin();
                 hipLaunchKernelGGL(fn, qgrid, qblock, qlds, stream, q);
                 HIP_CHECK(hipGetLastError());
@@ -507,6 +508,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
         if (plds <= 159 * 1024) {
             static bool pconf[3] = {false, false, false};
             dim3 pgrid((ra.n_pop + nt * MLP_TP - 1) / (nt * MLP_TP), A), pblock(13 * 64);
+            dominant_kernel = "k_rollout_mlp_pair";
             prof_begin();
             if (nt == 2) {
                 if (!pconf[2]) {
