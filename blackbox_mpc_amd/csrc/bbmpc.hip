@@ -639,7 +639,11 @@ bool Engine::use_fused() const {
 
 template <int OPT, bool FASTM, bool INJ, int ILP>
 static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
+#ifdef BBMPC_KERNEL_DBG
+    const size_t limit = 158 * 1024;   // the debug clocks live in static LDS
+#else
     const size_t limit = 160 * 1024;   // all of a CU's LDS
+#endif
     if (lds_base + lds_samples <= limit) {
         auto fn = k_fused_pendulum<OPT, true, FASTM, INJ, ILP>;
         static bool configured = false;
@@ -726,6 +730,9 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
             fprintf(stderr, "\n[dbg] iter0 per-wave rollout end:");
             for (int i = 24; i < 32; ++i) fprintf(stderr, " %lld", fa.dbg[i] - fa.dbg[0]);
             fprintf(stderr, "  gather-done %lld stats-done %lld", fa.dbg[32] - fa.dbg[0], fa.dbg[33] - fa.dbg[0]);
+            fprintf(stderr, "\n[dbg] iter1 top-k select marks rel. to rollout end:");
+            for (int i = 0; i < 10; ++i) fprintf(stderr, " %lld", fa.dbg[48 + i] - fa.dbg[3 + 4]);
+            fprintf(stderr, "  (iter1 marks: start %lld rollout-end %lld barrier %lld topk-end %lld)", fa.dbg[5] - fa.dbg[0], fa.dbg[6] - fa.dbg[0], fa.dbg[7] - fa.dbg[0], fa.dbg[8] - fa.dbg[0]);
             fprintf(stderr, "\n[dbg] shader clocks: %lld over %lld wall ticks => %.1f MHz\n", fa.dbg[41] - fa.dbg[40], fa.dbg[1 + iters * 4] - fa.dbg[0], (double)(fa.dbg[41] - fa.dbg[40]) / ((double)(fa.dbg[1 + iters * 4] - fa.dbg[0]) * 0.01));
         }
     }

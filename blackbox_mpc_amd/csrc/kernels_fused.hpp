@@ -220,26 +220,59 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         // ---- refit
         if (OPT == FOPT_CEM) {
             // exact sorted top-k (tf.nn.top_k, cem.py:97-99): LDS radix select, see topk.hpp
-            block_topk_sorted(rew, p.N, p.k, eidx, hist, ekeys, tid, nthr);
-            BB_DBG(4 + it * 4);
-            if (p.t_elites)
+            // The refit needs the elite SET only, so the winners are listed in ascending index order (no ranking);
+            // the sorted list tf.nn.top_k returns is produced only for the parity trace.  The statistics below always
+            // run over the index-ordered list, so results do not depend on tracing.
+            const TopkSel sel = block_topk_select(rew, p.N, p.k, hist, tid, nthr);
+            if (p.t_elites) {
+                block_topk_finish_sorted(rew, p.N, p.k, eidx, hist, ekeys, sel, tid, nthr);
                 for (int e = tid; e < p.k; e += nthr) p.t_elites[((size_t)it * p.A + a) * p.k + e] = eidx[e];
+                __syncthreads();
+            }
+            block_topk_finish_indexed(rew, p.N, p.k, eidx, hist, sel, tid, nthr);
+            BB_DBG(4 + it * 4);
+#ifdef BBMPC_KERNEL_DBG
+            if (p.dbg && tid == 0 && a == 0 && it == 1) for (int i = 0; i < 12; ++i) p.dbg[48 + i] = g_topk_dbg[i];
+#endif
             // elite statistics (cem.py:112-125): one 16-lane DPP row per (h,u) element -- 4 elements per wave,
             // every element of the horizon at once for H*U <= 4*waves; mean and biased variance two-pass,
             // as the reference computes them.
             const float kf = (float)p.k;
             const int sub = tid & 15;
+            // up to 64 elites: a lane's (<= 4) elite indices and sample values stay in registers -- every LDS read of
+            // a phase is issued before the first use (a dependent eidx -> row read per element costs two LDS
+            // latencies each, 16 in a row for k = 50)
+            constexpr int EC = 4;
+            const bool small_k = p.k <= 16 * EC;
+            int ei[EC];
+#pragma unroll
+            for (int i = 0; i < EC; ++i) ei[i] = (small_k && sub + 16 * i < p.k) ? eidx[sub + 16 * i] : -1;
             for (int j = tid >> 4; j < ((p.HU + 3) & ~3); j += nthr >> 4) {       // all 16 lanes of a row share j
                 const bool live = j < p.HU;
                 const float* row = samp + (size_t)(live ? j : 0) * p.Nst;
-                float sum = 0.0f;
-                for (int e = sub; e < p.k; e += 16) sum += row[eidx[e]];
-                sum = row16_sum(sum);
-                const float em = sum / kf;                                       // cem.py:112
-                float vs = 0.0f;
-                for (int e = sub; e < p.k; e += 16) {
-                    const float d = row[eidx[e]] - em;
-                    vs += d * d;
+                float sum = 0.0f, vs = 0.0f, em;
+                if (small_k) {
+                    float x[EC];
+#pragma unroll
+                    for (int i = 0; i < EC; ++i) x[i] = row[ei[i] >= 0 ? ei[i] : 0];
+#pragma unroll
+                    for (int i = 0; i < EC; ++i) if (ei[i] >= 0) sum += x[i];
+                    sum = row16_sum(sum);
+                    em = sum / kf;                                               // cem.py:112
+#pragma unroll
+                    for (int i = 0; i < EC; ++i)
+                        if (ei[i] >= 0) {
+                            const float d = x[i] - em;
+                            vs += d * d;
+                        }
+                } else {
+                    for (int e = sub; e < p.k; e += 16) sum += row[eidx[e]];
+                    sum = row16_sum(sum);
+                    em = sum / kf;
+                    for (int e = sub; e < p.k; e += 16) {
+                        const float d = row[eidx[e]] - em;
+                        vs += d * d;
+                    }
                 }
                 vs = row16_sum(vs);
                 if (live && sub == 0) {

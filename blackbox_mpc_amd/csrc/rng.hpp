@@ -44,7 +44,10 @@ __host__ __device__ __forceinline__ void mulhilo(uint32_t a, uint32_t b, uint32_
 
 __host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+#ifndef BBMPC_PHILOX_ROUNDS
+#define BBMPC_PHILOX_ROUNDS 10
+#endif
+    for (int r = 0; r < BBMPC_PHILOX_ROUNDS; ++r) {
         uint32_t hi0, lo0, hi1, lo1;
         mulhilo(0xD2511F53u, c.x, hi0, lo0);
         mulhilo(0xCD9E8D57u, c.z, hi1, lo1);
