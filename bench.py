@@ -140,7 +140,10 @@ def main():
     for _ in range(args.warmup):
         control_step()
     fence()
-    eng.set_profiling(True)          # HIP events on the launch stream around every rollout-kernel launch
+    # HIP events on the launch stream around every 8th launch of the dominant kernel: an event pair costs ~8 us of
+    # stream time, a sixth of a config-2 control step, so bracketing every launch would distort `value`
+    PROF_EVERY = 8
+    eng.set_profiling(True, every=PROF_EVERY)
     eng.get_profile()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -189,7 +192,8 @@ def main():
                     "algorithmic_bytes_per_launch": launch_traj * bytes_per_traj,
                     "note": "the fused kernel keeps the H-step recurrence in registers/LDS: the path is VALU-issue "
                             "bound, the HBM fraction is nominal (DESIGN.md)"}
-        roof.update({"kernel": kname, "avg_launch_us": avg_ms * 1e3, "launches": roll_n})
+        roof.update({"kernel": kname, "avg_launch_us": avg_ms * 1e3, "launches": roll_n,
+                     "launches_note": "HIP-event pairs around every %dth launch in the timed region" % PROF_EVERY})
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
         # collected separately, (2*FETCH + WRITE)*1024 -- tools/profile_round.sh, profiles/*_hbm_traffic.json)
         try:

@@ -154,6 +154,13 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
 
 Engine::~Engine() {
     if (own_stream) (void)hipStreamSynchronize(own_stream);
+    if (pf_stream) {
+        (void)hipStreamSynchronize(pf_stream);
+        (void)hipStreamDestroy(pf_stream);
+        for (int b = 0; b < 2; ++b)
+            if (pf_done[b]) (void)hipEventDestroy(pf_done[b]);
+        if (pf_free) (void)hipEventDestroy(pf_free);
+    }
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     if (h_pin) (void)hipHostFree(h_pin);
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -342,7 +349,8 @@ void Engine::from_internal(const float* in, int n_pop, float* ref) const {
 // profiling (HIP events on the launch stream around the dominant kernel)
 // ------------------------------------------------------------------------------------------------
 void Engine::prof_begin() {
-    if (!profiling) return;
+    prof_this = profiling && (prof_seq++ % (uint64_t)prof_every) == 0;
+    if (!prof_this) return;
     if (ev_used + 2 > ev_pool.size()) {
         for (int i = 0; i < 2; ++i) {
             hipEvent_t e;
@@ -353,7 +361,7 @@ void Engine::prof_begin() {
     HIP_CHECK(hipEventRecord(ev_pool[ev_used], stream));
 }
 void Engine::prof_end() {
-    if (!profiling) return;
+    if (!prof_this) return;
     HIP_CHECK(hipEventRecord(ev_pool[ev_used + 1], stream));
     ev_used += 2;
 }
@@ -637,7 +645,7 @@ bool Engine::use_fused() const {
     return (long)N <= 2048 || A >= 64;
 }
 
-template <int OPT, bool FASTM, bool INJ, int ILP>
+template <int OPT, bool FASTM, int INJ, int ILP>
 static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
 #ifdef BBMPC_KERNEL_DBG
     const size_t limit = 158 * 1024;   // the debug clocks live in static LDS
@@ -660,19 +668,49 @@ static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base
 }
 
 template <int OPT>
-static void launch_fused(Engine& e, FusedArgs& fa, int ilp, int threads, size_t lds_base, size_t lds_samples) {
+static void launch_fused(Engine& e, FusedArgs& fa, int ilp, int threads, size_t lds_base, size_t lds_samples, int inj_layout) {
     const bool fastm = !e.fix(BBMPC_STRICT_MATH);
-    const bool inj = fa.inj != nullptr;
+    const int inj = fa.inj == nullptr ? 0 : inj_layout;     // 0 in-kernel Philox, 1 caller-injected, 2 prefetched float4
 #define LF(F, I)                                                                              \
     do {                                                                                      \
         if (ilp == 2) launch_fused4<OPT, F, I, 2>(e, fa, threads, lds_base, lds_samples);    \
         else launch_fused4<OPT, F, I, 1>(e, fa, threads, lds_base, lds_samples);             \
     } while (0)
-    if (fastm && !inj) LF(true, false);
-    else if (fastm && inj) LF(true, true);
-    else if (!fastm && !inj) LF(false, false);
-    else LF(false, true);
+    if (inj == 2) {                                         // ILP = 1 only
+        if (fastm) launch_fused4<OPT, true, 2, 1>(e, fa, threads, lds_base, lds_samples);
+        else launch_fused4<OPT, false, 2, 1>(e, fa, threads, lds_base, lds_samples);
+    } else if (fastm && !inj) LF(true, 0);
+    else if (fastm && inj) LF(true, 1);
+    else if (!fastm && !inj) LF(false, 0);
+    else LF(false, 1);
 #undef LF
+}
+
+// Standard draws for a chunk of control steps in the layout the persistent kernel's INJ=2 path reads:
+// [step][iter][A][Nst][Q] float4, one float4 = the 4 words of Philox block q of particle n.  Same counters and
+// transforms as the in-kernel generator (rng.hpp), so the values are bit-identical.  thread = (n, q), coalesced.
+__global__ void k_noise_fill(RngKey key, uint32_t rstream, int uniform, int n_it, int N, int Nst, int A, int Q,
+                             int agent_offset, float4* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * Q) return;
+    const int n = idx / Q, q = idx % Q;
+    const int z = blockIdx.y;
+    const int a = z % A, it = (z / A) % n_it, s = z / (A * n_it);
+    key.step += (uint32_t)s;
+    const U4 w = rng_block(key, rstream, (uint32_t)it, (uint32_t)n, (uint32_t)(agent_offset + a), (uint32_t)(4 * q));
+    float4 v;
+    if (uniform) v = make_float4(word_to_uniform(w.x), word_to_uniform(w.y), word_to_uniform(w.z), word_to_uniform(w.w));
+    else v = make_float4(word_to_trunc_normal(w.x), word_to_trunc_normal(w.y), word_to_trunc_normal(w.z), word_to_trunc_normal(w.w));
+    out[(((size_t)s * n_it + it) * A + a) * Nst * Q + (size_t)n * Q + q] = v;
+}
+
+void Engine::launch_noise_fill(int64_t chunk, int buf, hipStream_t on) {
+    const bool rs = cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH;
+    const int n_it = rs ? 1 : iters, Q = (HU + 3) / 4;
+    dim3 grid((N * Q + 255) / 256, A * n_it * pf_steps), block(256);
+    hipLaunchKernelGGL(k_noise_fill, grid, block, 0, on, key((uint32_t)(chunk * pf_steps)), rs ? 2u : 1u, rs ? 1 : 0, n_it,
+                       N, Nst, A, Q, cfg.agent_offset, reinterpret_cast<float4*>(d_noise_pf[buf].p));
+    HIP_CHECK(hipGetLastError());
 }
 
 void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step) {
@@ -707,9 +745,51 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     }
 #endif
     fa.key = key(step);
+    // ---- noise prefetch (see engine.hpp): unless the caller injected its own draws.  One fill launch covers a
+    // chunk of pf_steps control steps (the host adds one launch + three event calls per chunk, not per step).
+    const int pf_nit = cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH ? 1 : iters;
+    if (pf_mode < 0) {
+        const char* ev = getenv("BBMPC_NOISE_PREFETCH");
+        pf_step_floats = (size_t)pf_nit * A * Nst * ((HU + 3) / 4) * 4;
+        const size_t budget = (size_t)128 << 20;     // bytes per chunk buffer
+        pf_steps = pf_step_floats ? (int)std::min<size_t>(8, budget / (pf_step_floats * 4)) : 0;
+        pf_mode = ((ev ? atoi(ev) != 0 : true) && pf_steps >= 1 && U == 1) ? 1 : 0;
+        if (pf_mode) {
+            HIP_CHECK(hipStreamCreateWithFlags(&pf_stream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&pf_free, hipEventDisableTiming));
+            for (int b = 0; b < 2; ++b) {
+                d_noise_pf[b].alloc(pf_step_floats * pf_steps);
+                HIP_CHECK(hipEventCreateWithFlags(&pf_done[b], hipEventDisableTiming));
+            }
+        }
+    }
+    const bool use_pf = pf_mode == 1 && fa.inj == nullptr && pf_nit > 0;
+    if (use_pf) {
+        const int64_t c = (int64_t)step / pf_steps;
+        const int pb = (int)(c & 1), nb = pb ^ 1;
+        if (pf_chunk[pb] != c) {                   // not prefetched (first step, or steps did not advance by one): in line
+            if (pf_inflight[pb]) HIP_CHECK(hipStreamWaitEvent(stream, pf_done[pb], 0));   // stale fill still running
+            launch_noise_fill(c, pb, stream);
+            pf_chunk[pb] = c; pf_waited[pb] = true; pf_inflight[pb] = false;
+        } else if (!pf_waited[pb]) {
+            HIP_CHECK(hipStreamWaitEvent(stream, pf_done[pb], 0));
+            pf_waited[pb] = true; pf_inflight[pb] = false;
+        }
+        fa.inj = d_noise_pf[pb].p + (size_t)((int64_t)step - c * pf_steps) * pf_step_floats;
+        if (pf_chunk[nb] != c + 1) {
+            // the other buffer was last read by kernels already enqueued on `stream`: the side stream fills it for
+            // the next chunk while this chunk's control steps run
+            HIP_CHECK(hipEventRecord(pf_free, stream));
+            HIP_CHECK(hipStreamWaitEvent(pf_stream, pf_free, 0));
+            launch_noise_fill(c + 1, nb, pf_stream);
+            HIP_CHECK(hipEventRecord(pf_done[nb], pf_stream));
+            pf_chunk[nb] = c + 1; pf_waited[nb] = false; pf_inflight[nb] = true;
+        }
+    }
     // two trajectories per lane (one wave per SIMD for N <= 512) unless overridden
     int ilp = 1;                 // measured: 2 waves/SIMD x 1 trajectory beats 1 wave/SIMD x 2 trajectories
     if (const char* e_ilp = getenv("BBMPC_ILP")) ilp = atoi(e_ilp) == 2 ? 2 : 1;
+    if (use_pf) ilp = 1;
     const int per = (N + ilp - 1) / ilp;
     const int threads = std::min(1024, std::max(((per + 63) / 64) * 64, ((std::max(k, 1) + 63) / 64) * 64));   // top-k needs k <= threads
     const int HUp = (HU + 3) & ~3, kp = (std::max(k, 1) + 3) & ~3;
@@ -717,9 +797,9 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     const size_t lds_samples = (size_t)HU * Nst * 4;
     prof_begin();
     switch (cfg.optimizer) {
-        case BBMPC_OPT_RANDOM_SEARCH: launch_fused<FOPT_RS>(*this, fa, ilp, threads, lds_base, lds_samples); break;
-        case BBMPC_OPT_CEM: launch_fused<FOPT_CEM>(*this, fa, ilp, threads, lds_base, lds_samples); break;
-        default: launch_fused<FOPT_PI2>(*this, fa, ilp, threads, lds_base, lds_samples); break;
+        case BBMPC_OPT_RANDOM_SEARCH: launch_fused<FOPT_RS>(*this, fa, ilp, threads, lds_base, lds_samples, use_pf ? 2 : 1); break;
+        case BBMPC_OPT_CEM: launch_fused<FOPT_CEM>(*this, fa, ilp, threads, lds_base, lds_samples, use_pf ? 2 : 1); break;
+        default: launch_fused<FOPT_PI2>(*this, fa, ilp, threads, lds_base, lds_samples, use_pf ? 2 : 1); break;
     }
     prof_end();
     if (fa.dbg) {
@@ -1440,6 +1520,8 @@ int bbmpc_set_profiling(bbmpc_handle h, int32_t enabled) {
     API_BEGIN
     CHECK_HANDLE(h);
     h->e->profiling = enabled != 0;
+    h->e->prof_every = enabled > 1 ? enabled : 1;
+    h->e->prof_seq = 0;
     API_END
 }
 

@@ -36,7 +36,8 @@ struct FusedArgs {
     float* mean_out;         // [A][HU] last mean (get_state)
     float* var_out;          // [A][HU]
     float* samples_g;        // [A][HU][Nst] global scratch when the samples do not fit in LDS
-    const float* inj;        // injected standard noise [iters][A][HU][Nst] or null
+    const float* inj;        // standard noise or null: INJ=1 caller-injected [iters][A][HU][Nst];
+                             // INJ=2 prefetched by k_noise_fill, [iters][A][Nst][Q] float4 (particle-major Philox blocks)
     const float* inj_expl;   // injected exploration noise [A,U] or null
     float* record;           // [A][U+S+1]
     float* next_state;       // optional contiguous [A,S]
@@ -78,7 +79,7 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nw)
 
 // LDS carve (4-byte words): rewards[Nst] | mean[HUp] | var[HUp] | sigma[HUp] | eidx[kp] | red[64] | hist[272] |
 //                            ekeys[2*kp] | samples[HU][Nst]      (every piece a multiple of 16 B)
-template <int OPT, bool SAMPLES_LDS, bool FASTM, bool INJ, int ILP>
+template <int OPT, bool SAMPLES_LDS, bool FASTM, int INJ, int ILP>
 __global__ void k_fused_pendulum(FusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int a = blockIdx.x;
@@ -125,11 +126,58 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         // The 4 candidate actions of Philox block b+1 are generated while the recurrence steps through
         // block b: their instructions carry no dependence on the state, so they fill the latency
         // shadows of the sequential theta/thdot chain (all straight-line code inside a block).
-        const float* inj = INJ ? p.inj + ((size_t)it * p.A + a) * p.HU * p.Nst : nullptr;
+        const float* inj = (INJ == 1) ? p.inj + ((size_t)it * p.A + a) * p.HU * p.Nst : nullptr;
         const int nblk = p.H >> 2, rem = p.H & 3;
         const uint32_t rstream = (OPT == FOPT_RS) ? 2u : 1u;
         // ILP independent trajectories per lane: with half as many waves each SIMD runs a single wave whose two
         // recurrences interleave in program order, instead of two waves fighting over issue slots.
+        if constexpr (INJ == 2) {
+            // Draws prefetched by idle CUs (k_noise_fill): one float4 = one Philox block = 4 steps of this trajectory.
+            // Loads run TWO blocks (8 steps, ~2 us) ahead of their use so that L2/HBM latency never reaches the
+            // recurrence; the Philox rounds (a quarter of this kernel's VALU work) are gone from the critical path.
+            const int Q = (p.HU + 3) >> 2;
+            const float4* inj4 = reinterpret_cast<const float4*>(p.inj) + ((size_t)it * p.A + a) * p.Nst * Q;
+            for (int n = tid; n < p.N; n += nthr) {
+                Roller<FASTM> roll;
+                roll.init(p.fix_q1 != 0, s0, s1, s2);
+                float total = 0.0f, pen = 0.0f;
+                const float4* mine = inj4 + (size_t)n * Q;
+                auto ld = [&](int b) { return mine[min(b, Q - 1)]; };
+                auto step1 = [&](int t, float xi) {
+                    float x = (OPT == FOPT_RS) ? xi * (hi - lo) + lo : xi * sigma[t] + mean[t];
+                    if (OPT == FOPT_PI2) {
+                        const float xf = clipf(x, lo, hi);
+                        const float d = x - xf;
+                        pen = pen + d * d;
+                        x = xf;
+                    }
+                    samp[(size_t)t * p.Nst + n] = x;
+                    total = total + roll.step(x);
+                };
+                auto block4 = [&](const float4& z, int b) {
+                    step1(4 * b + 0, z.x); step1(4 * b + 1, z.y); step1(4 * b + 2, z.z); step1(4 * b + 3, z.w);
+                };
+                float4 c0 = ld(0), c1 = ld(1);
+                int b = 0;
+                for (; b + 1 < nblk; b += 2) {
+                    const float4 n0 = ld(b + 2), n1 = ld(b + 3);
+                    block4(c0, b);
+                    block4(c1, b + 1);
+                    c0 = n0; c1 = n1;
+                }
+                if (b < nblk) { block4(c0, b); c0 = c1; ++b; }
+                if (rem > 0) step1(4 * b + 0, c0.x);
+                if (rem > 1) step1(4 * b + 1, c0.y);
+                if (rem > 2) step1(4 * b + 2, c0.z);
+                float tot = total;
+                if (tot != tot) tot = -1.0e6f;                                   // deterministic.py:75-77
+                if (OPT == FOPT_PI2) {
+                    const float nr = sqrtf(pen);
+                    tot = tot - nr * nr;
+                }
+                rew[n] = tot;
+            }
+        } else
         for (int n0 = tid; n0 < p.N; n0 += ILP * nthr) {
             int nn[ILP];
             bool live[ILP];

@@ -199,8 +199,9 @@ class Engine:
         L.check(L.lib.bbmpc_set_state(self._h, name.encode(), L.ptr(d), d.size))
 
     # -- measurement -----------------------------------------------------------------------
-    def set_profiling(self, enabled=True):
-        L.check(L.lib.bbmpc_set_profiling(self._h, int(bool(enabled))))
+    def set_profiling(self, enabled=True, every=1):
+        """HIP events around every `every`-th launch of the dominant kernel (see include/bbmpc.h)."""
+        L.check(L.lib.bbmpc_set_profiling(self._h, (max(int(every), 1) if enabled else 0)))
 
     def get_profile(self):
         ms, n, name = ctypes.c_double(), ctypes.c_int64(), ctypes.c_char_p()

@@ -207,9 +207,10 @@ int bbmpc_get_state(bbmpc_handle h, const char* name, float* out, int64_t count)
 int bbmpc_set_state(bbmpc_handle h, const char* name, const float* data, int64_t count);
 
 /* ---- measurement -------------------------------------------------------- */
-/* When enabled the handle brackets every launch of its dominant (rollout) kernel with HIP events on
- * the launch stream; bbmpc_get_profile returns the accumulated device time and launch count since
- * the last call and resets them. */
+/* When enabled the handle brackets launches of its dominant (rollout) kernel with HIP events on the launch
+ * stream: enabled = 1 every launch, enabled = n > 1 every n-th launch (an event pair costs a few microseconds
+ * of stream time, which matters when the whole control step is ~50 us); bbmpc_get_profile returns the
+ * accumulated device time and the number of bracketed launches since the last call and resets them. */
 int bbmpc_set_profiling(bbmpc_handle h, int32_t enabled);
 int bbmpc_get_profile(bbmpc_handle h, double* rollout_ms_total, int64_t* rollout_launches,
                       const char** kernel_name);

@@ -431,3 +431,23 @@ def test_large_population_uses_global_samples(L):
     act, nxt, rew = eng.optimize(states)
     cem = _cem_lockstep(L, eng, states, noise, N, A, H, iters, k, 0.25)
     np.testing.assert_allclose(act, cem.trace[-1]["mean"][:, 0], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("opt_name,N,A,H", [("CEM", 500, 1, 30), ("PI2", 300, 3, 17), ("RandomSearch", 200, 2, 20)])
+def test_noise_prefetch_is_bit_identical_to_in_kernel_draws(L, monkeypatch, opt_name, N, A, H):
+    # The persistent kernel reads draws that idle CUs generated one control step ahead (side stream); they come from
+    # the same Philox counters, so switching the prefetch off must not change a single bit -- also across reset().
+    opt = {"CEM": L.OPT_CEM, "PI2": L.OPT_PI2, "RandomSearch": L.OPT_RANDOM_SEARCH}[opt_name]
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("BBMPC_NOISE_PREFETCH", mode)
+        eng = _engine(L, opt, A, H, N=N, iters=3, k=max(N // 10, 1), seed=11)
+        s = O.pendulum_start_states(A)
+        out = []
+        for t in range(7):
+            if t == 4:
+                eng.reset()
+            a, s, r = eng.optimize(s)
+            out.append(np.concatenate([a.ravel(), s.ravel(), r.ravel()]))
+        runs[mode] = np.stack(out)
+    np.testing.assert_array_equal(runs["0"], runs["1"])
