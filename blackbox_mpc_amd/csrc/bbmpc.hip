@@ -423,6 +423,13 @@ void Engine::set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, con
         upload(d_bpack[l], bp);
         upload(d_wraw[l], std::vector<float>(w[l], w[l] + (size_t)K * M));
         upload(d_braw[l], std::vector<float>(b[l], b[l] + M));
+        {   // quad-mode operand order [k/4][Mp][4]
+            const int Mp = (M + 63) & ~63, KG = (K + 3) / 4;
+            std::vector<float> wq((size_t)KG * Mp * 4, 0.0f);
+            for (int kk = 0; kk < K; ++kk)
+                for (int o = 0; o < M; ++o) wq[((size_t)(kk >> 2) * Mp + o) * 4 + (kk & 3)] = w[l][(size_t)kk * M + o];
+            upload(d_wq4[l], wq);
+        }
         mlp.wpack[l] = d_wpack[l].p;
         mlp.bpack[l] = d_bpack[l].p;
     }
@@ -458,7 +465,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     q.per_particle_state = per_particle_state ? 1 : 0;
     q.final_state = final_state;
     q.nw = mlp_nw;
-    for (int l = 0; l < mlp.n_layers; ++l) { q.wraw[l] = d_wraw[l].p; q.braw[l] = d_braw[l].p; }
+    for (int l = 0; l < mlp.n_layers; ++l) { q.wraw[l] = d_wraw[l].p; q.braw[l] = d_braw[l].p; q.wq4[l] = d_wq4[l].p; }
     const MlpLds lay = mlp_lds_layout(mlp, ra.H, U, S, mlp_nw);
     const size_t lds = (size_t)lay.total * sizeof(float);
     REQUIRE(lds <= 159 * 1024, BBMPC_E_UNSUPPORTED, "planning horizon x action dim too large for the LDS action block");

@@ -63,6 +63,7 @@ struct MlpRolloutArgs {
     int nw;                   // waves per workgroup
     const float* wraw[MLP_MAX_LAYERS];   // unpacked Dense kernels [in][out] (quad-mode kernel)
     const float* braw[MLP_MAX_LAYERS];   // unpacked biases [out]
+    const float* wq4[MLP_MAX_LAYERS];    // quad-mode operands [ceil(in/4)][Mp][4], Mp = out rounded up to 64, zero padded
 };
 
 // tanh on the hardware exp/rcp units: sign(x) * (1 - 2 / (e^{2|x|} + 1)), 7 instructions.  Absolute error
@@ -175,6 +176,63 @@ __device__ __forceinline__ int tile_addr(int f, int p) {
 //   SPEC 1: 2 hidden layers of equal width <= 256 (one output tile per wave, nw == hidden tiles),
 //           S+U <= 32, S <= 32            e.g. 26-200-200-20 (BASELINE configs 4-5): 68 weight VGPRs
 //   SPEC 2: 3 hidden layers of equal width <= 64, S+U <= 32, S <= 32   e.g. 4-32-32-32-3 (low-level tutorial)
+// The workgroup's action block acts[t][particle][u] (candidate -> clip/penalty -> store), shared by the rollout
+// kernels.  Every element is independent (its own Philox block / table lookup / mean-sigma read), so the work is
+// spread over ALL threads: one thread per (particle,u) walking t serially pays one global-memory latency per step
+// (H x ~1 us -- a fifth of the quad kernel's run time at config 4).  The squared bound violation is summed per
+// (particle,u) in t order afterwards, from LDS.  Contains a barrier when q.pen is set (uniform).
+template <int TP>
+__device__ __forceinline__ void mlp_fill_actions(const MlpRolloutArgs& q, int a, int n0, int tid, int nthr,
+                                                 float* acts, float* pens) {
+    const RolloutArgs& p = q.r;
+    const int U = p.U, H = p.H;
+    const int total = H * TP * U;                       // element e = (t*TP + pp)*U + u is also its index in acts
+    for (int e = tid; e < total; e += nthr) {
+        const int u = e % U, pp = (e / U) % TP, t = e / (U * TP);
+        const int n = n0 + pp;
+        const int j = t * U + u;
+        float x = 0.0f;
+        if (n < p.n_pop) {
+            if (q.mode == SRC_REF) x = p.seq[((size_t)n * p.A + a) * p.HU + j];
+            else if (q.mode == SRC_BUF) x = p.cand[((size_t)a * p.HU + j) * p.Nst + n];
+            else {
+                float xi;
+                if (p.inj) xi = p.inj[((size_t)a * p.HU + j) * p.Nst + n];
+                else {
+                    const U4 blk = rng_block(p.key, p.stream, p.iter, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)j);
+                    const uint32_t w = pick_word(blk, (uint32_t)j);
+                    xi = (q.mode == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
+                }
+                if (q.mode == SRC_UNIFORM) x = xi * (p.hi[u] - p.lo[u]) + p.lo[u];
+                else x = xi * p.sigma[a * p.HU + j] + p.mean[a * p.HU + j];
+            }
+            if (!q.pen && p.samples) p.samples[((size_t)a * p.HU + j) * p.Nst + n] = x;
+        }
+        acts[e] = x;                                    // unclipped when q.pen: clipped in place below
+    }
+    if (q.pen) {
+        __syncthreads();
+        for (int i = tid; i < TP * U; i += nthr) {
+            const int pp = i / U, u = i % U;
+            const int n = n0 + pp;
+            const float lo = p.lo[u], hi = p.hi[u];
+            float pen_part = 0.0f;
+            if (n < p.n_pop)
+                for (int t = 0; t < H; ++t) {
+                    const float x = acts[(t * TP + pp) * U + u];
+                    const float xf = clipf(x, lo, hi);
+                    const float d = x - xf;
+                    pen_part = pen_part + d * d;
+                    acts[(t * TP + pp) * U + u] = xf;
+                    if (p.samples) p.samples[((size_t)a * p.HU + t * U + u) * p.Nst + n] = xf;
+                }
+            pens[i] = pen_part;
+        }
+    } else {
+        for (int i = tid; i < TP * U; i += nthr) pens[i] = 0.0f;
+    }
+}
+
 template <int SPEC>
 __device__ __forceinline__ void rollout_mlp_body(const MlpRolloutArgs& q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -231,45 +289,7 @@ __device__ __forceinline__ void rollout_mlp_body(const MlpRolloutArgs& q) {
     }
 
     // ---- prologue 1: the tile's whole action block [H][16][U] (candidate -> clip/penalty -> store)
-    float pen_part = 0.0f;                         // penalty share of one (particle,u) pair
-    for (int i = tid; i < MLP_TP * U; i += nthr) {
-        const int pp = i / U, u = i % U;           // consecutive threads: consecutive u of one particle
-        const int n = n0 + pp;
-        const bool live = n < p.n_pop;
-        U4 blk = {0, 0, 0, 0};
-        const float lo = p.lo[u], hi = p.hi[u];
-        for (int t = 0; t < H; ++t) {
-            const int j = t * U + u;
-            float x = 0.0f;
-            if (live) {
-                if (q.mode == SRC_REF) {
-                    x = p.seq[((size_t)n * p.A + a) * p.HU + j];
-                } else if (q.mode == SRC_BUF) {
-                    x = p.cand[((size_t)a * p.HU + j) * p.Nst + n];
-                } else {
-                    float xi;
-                    if (p.inj) xi = p.inj[((size_t)a * p.HU + j) * p.Nst + n];
-                    else {
-                        blk = rng_block(p.key, p.stream, p.iter, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)j);
-                        const uint32_t w = pick_word(blk, (uint32_t)j);
-                        xi = (q.mode == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
-                    }
-                    if (q.mode == SRC_UNIFORM) x = xi * (hi - lo) + lo;
-                    else x = xi * p.sigma[a * p.HU + j] + p.mean[a * p.HU + j];
-                }
-                if (q.pen) {
-                    const float xf = clipf(x, lo, hi);
-                    const float d = x - xf;
-                    pen_part = pen_part + d * d;
-                    x = xf;
-                }
-                if (p.samples) p.samples[((size_t)a * p.HU + j) * p.Nst + n] = x;
-            }
-            acts[(t * MLP_TP + pp) * U + u] = x;
-        }
-        misc[i] = pen_part;
-        pen_part = 0.0f;
-    }
+    mlp_fill_actions<MLP_TP>(q, a, n0, tid, nthr, acts, misc);
     for (int f = tid; f < S + U; f += nthr) {
         const float mu = normd ? (f < S ? m.mean_s[f] : m.mean_a[f - S]) : 0.0f;
         const float sd = normd ? (f < S ? m.std_s[f] : m.std_a[f - S]) : 1.0f;
@@ -549,41 +569,7 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
         float* pens = T_pen(ti);
         float* st = T_st(ti);
         float* xs = T_xs(ti);
-        for (int i = tid; i < MLP_TP * U; i += NT) {
-            const int pp = i / U, u = i % U;
-            const int n = n0 + pp;
-            const bool live = n < p.n_pop;
-            const float lo = p.lo[u], hi = p.hi[u];
-            float pen_part = 0.0f;
-            for (int t = 0; t < H; ++t) {
-                const int j = t * U + u;
-                float x = 0.0f;
-                if (live) {
-                    if (q.mode == SRC_REF) x = p.seq[((size_t)n * p.A + a) * p.HU + j];
-                    else if (q.mode == SRC_BUF) x = p.cand[((size_t)a * p.HU + j) * p.Nst + n];
-                    else {
-                        float xi;
-                        if (p.inj) xi = p.inj[((size_t)a * p.HU + j) * p.Nst + n];
-                        else {
-                            const U4 blk = rng_block(p.key, p.stream, p.iter, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)j);
-                            const uint32_t w = pick_word(blk, (uint32_t)j);
-                            xi = (q.mode == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
-                        }
-                        if (q.mode == SRC_UNIFORM) x = xi * (hi - lo) + lo;
-                        else x = xi * p.sigma[a * p.HU + j] + p.mean[a * p.HU + j];
-                    }
-                    if (q.pen) {
-                        const float xf = clipf(x, lo, hi);
-                        const float d = x - xf;
-                        pen_part = pen_part + d * d;
-                        x = xf;
-                    }
-                    if (p.samples) p.samples[((size_t)a * p.HU + j) * p.Nst + n] = x;
-                }
-                acts[(t * MLP_TP + pp) * U + u] = x;
-            }
-            pens[i] = pen_part;
-        }
+        mlp_fill_actions<MLP_TP>(q, a, n0, tid, NT, acts, pens);
         for (int i = tid; i < sz_xs; i += NT) xs[i] = 0.0f;
         for (int i = tid; i < MLP_TP * S; i += NT) st[(i / S) * Sp + (i % S)] = p.state[a * S + (i % S)];
     }
@@ -850,20 +836,32 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
     float* lbias = tstd + S;
 
     // ---- stationary A operands.  W_l is [in][out] row-major (dims from the descriptor, unpacked copy wraw)
+    // Packed by bbmpc_set_mlp as [k/4][Mp][4] (zero padded): a lane's four consecutive-k operands are one 16-byte
+    // load, a wave's load is 1 KB contiguous -- 70 loads per lane instead of 278 dword loads (the prologue was a
+    // fifth of the kernel).
     const int M1 = m.dims[1], M3 = m.dims[3];
-    const float* __restrict__ W0 = q.wraw[0];
-    const float* __restrict__ W1 = q.wraw[1];
-    const float* __restrict__ W2 = q.wraw[2];
-    const int f = wave * 64 + lane;                      // hidden feature this lane's A operands belong to
+    const int Mp1 = (M1 + 63) & ~63, Mp3 = (M3 + 63) & ~63;
+    const float4* __restrict__ Q0 = reinterpret_cast<const float4*>(q.wq4[0]);
+    const float4* __restrict__ Q1 = reinterpret_cast<const float4*>(q.wq4[1]);
+    const float4* __restrict__ Q2 = reinterpret_cast<const float4*>(q.wq4[2]);
+    const int f = wave * 64 + lane;                      // hidden feature this lane's A operands belong to (< Mp1)
     float wA0[K0G * 4], wA1[HK], wA2[KS * 4];
 #pragma unroll
-    for (int k = 0; k < K0G * 4; ++k) wA0[k] = (k < m.dims[0] && f < M1) ? W0[(size_t)k * M1 + f] : 0.0f;
+    for (int g = 0; g < K0G; ++g) {
+        const float4 v = Q0[(size_t)g * Mp1 + f];
+        wA0[4 * g + 0] = v.x; wA0[4 * g + 1] = v.y; wA0[4 * g + 2] = v.z; wA0[4 * g + 3] = v.w;
+    }
 #pragma unroll
-    for (int k = 0; k < HK; ++k) wA1[k] = (f < M1) ? W1[(size_t)k * M1 + f] : 0.0f;
+    for (int g = 0; g < HG; ++g) {
+        const float4 v = Q1[(size_t)g * Mp1 + f];
+        wA1[4 * g + 0] = v.x; wA1[4 * g + 1] = v.y; wA1[4 * g + 2] = v.z; wA1[4 * g + 3] = v.w;
+    }
 #pragma unroll
-    for (int k = 0; k < KS * 4; ++k) {                    // last layer: my k range, output feature = lane
-        const int kk = wave * KS * 4 + k;
-        wA2[k] = (kk < HK && lane < M3) ? W2[(size_t)kk * M3 + lane] : 0.0f;
+    for (int g = 0; g < KS; ++g) {                       // last layer: my k range, output feature = lane
+        const int gg = wave * KS + g;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (gg < HG) v = Q2[(size_t)gg * Mp3 + lane];
+        wA2[4 * g + 0] = v.x; wA2[4 * g + 1] = v.y; wA2[4 * g + 2] = v.z; wA2[4 * g + 3] = v.w;
     }
     // bias of my 4 D rows: features 64*wave + 4*(lane>>2) + r
     f32x4 b0, b1;
@@ -886,41 +884,7 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
         }
     }
     // ---- prologue: the 4 particles' action block + start state
-    for (int i = tid; i < QP * U; i += NT) {
-        const int pp = i / U, u = i % U;
-        const int n = n0 + pp;
-        const bool live = n < p.n_pop;
-        const float lo = p.lo[u], hi = p.hi[u];
-        float pen_part = 0.0f;
-        for (int t = 0; t < H; ++t) {
-            const int j = t * U + u;
-            float x = 0.0f;
-            if (live) {
-                if (q.mode == SRC_REF) x = p.seq[((size_t)n * p.A + a) * p.HU + j];
-                else if (q.mode == SRC_BUF) x = p.cand[((size_t)a * p.HU + j) * p.Nst + n];
-                else {
-                    float xi;
-                    if (p.inj) xi = p.inj[((size_t)a * p.HU + j) * p.Nst + n];
-                    else {
-                        const U4 blk = rng_block(p.key, p.stream, p.iter, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)j);
-                        const uint32_t w = pick_word(blk, (uint32_t)j);
-                        xi = (q.mode == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
-                    }
-                    if (q.mode == SRC_UNIFORM) x = xi * (hi - lo) + lo;
-                    else x = xi * p.sigma[a * p.HU + j] + p.mean[a * p.HU + j];
-                }
-                if (q.pen) {
-                    const float xf = clipf(x, lo, hi);
-                    const float d = x - xf;
-                    pen_part = pen_part + d * d;
-                    x = xf;
-                }
-                if (p.samples) p.samples[((size_t)a * p.HU + j) * p.Nst + n] = x;
-            }
-            acts[(t * QP + pp) * U + u] = x;
-        }
-        pens[i] = pen_part;
-    }
+    mlp_fill_actions<QP>(q, a, n0, tid, NT, acts, pens);
     for (int i = tid; i < K0G * 16; i += NT) xs[i] = 0.0f;
     for (int i = tid; i < QP * S; i += NT) st[(i / S) * Sp + (i % S)] = p.state[a * S + (i % S)];
     __syncthreads();
@@ -941,6 +905,14 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
     // reward goes through reward_generic on threads 0..3.
     const bool rew_inline = (p.reward_kind != REW_PENDULUM) && S > 17;
     float total = 0.0f;                                   // rew_inline: thread (feature 17, particle pp); else threads 0..3
+#ifdef BBMPC_KERNEL_DBG
+    long long dbg_acc[6] = {0, 0, 0, 0, 0, 0}, dbg_t0 = 0;
+#define Q4_MARK(i) do { const long long now_ = (long long)wall_clock64(); dbg_acc[i] += now_ - dbg_t0; dbg_t0 = now_; } while (0)
+    dbg_t0 = (long long)wall_clock64();
+    const long long dbg_start = dbg_t0;
+#else
+#define Q4_MARK(i) do {} while (0)
+#endif
     for (int t = 0; t < H; ++t) {
         float* cur = st + (t & 1) * QP * Sp;
         float* nxt = st + ((t + 1) & 1) * QP * Sp;
@@ -964,12 +936,14 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
             o.z = apply_act_ct<A0>(acc0.z + acc1.z); o.w = apply_act_ct<A0>(acc0.w + acc1.w);
             if (own_rows) *reinterpret_cast<f32x4*>(h0 + my_row) = o;
         }
+        Q4_MARK(0);
         if (!rew_inline && t > 0 && tid < QP) {            // reward of step t-1 (both states complete)
             const float* c0 = st + ((t - 1) & 1) * QP * Sp;
             total = total + reward_generic(p.reward_kind, p.fix_q1 != 0, c0 + tid * Sp, acts + ((t - 1) * QP + tid) * U,
                                            cur + tid * Sp, S, U);
         }
         __syncthreads();
+        Q4_MARK(1);
         // ---- layer 1: 4 independent accumulator chains
         {
             f32x4 c0 = b1, c1 = {0.0f, 0.0f, 0.0f, 0.0f}, c2 = c1, c3 = c1;
@@ -1006,7 +980,9 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
             o.z = apply_act_ct<A1>((c0.z + c1.z) + (c2.z + c3.z)); o.w = apply_act_ct<A1>((c0.w + c1.w) + (c2.w + c3.w));
             if (own_rows) *reinterpret_cast<f32x4*>(h1 + my_row) = o;
         }
+        Q4_MARK(2);
         __syncthreads();
+        Q4_MARK(3);
         // ---- last layer, K split: my k range, output feature = 4*(lane>>2)+r ... only features < S matter
         {
             f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = c0;
@@ -1029,6 +1005,7 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
             *reinterpret_cast<f32x4*>(part + ((size_t)wave * 64 + lane) * 4) = o;
         }
         __syncthreads();
+        Q4_MARK(4);
         // ---- epilogue: thread (feature k, particle pp)
         for (int i = tid; i < QP * (S + U); i += NT) {
             const int k = i / QP, pp = i % QP;
@@ -1064,7 +1041,13 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
             xs[vaddr(k, pp)] = (v - nmean[k]) * ninv[k];
         }
         __syncthreads();
+        Q4_MARK(5);
     }
+#ifdef BBMPC_KERNEL_DBG
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+        printf("[q4dbg] H=%d total %lld | layer0 %lld bar %lld layer1 %lld bar %lld last+bar %lld epi+bar %lld (10ns units, summed over steps)\n",
+               H, (long long)wall_clock64() - dbg_start, dbg_acc[0], dbg_acc[1], dbg_acc[2], dbg_acc[3], dbg_acc[4], dbg_acc[5]);
+#endif
     const int rt = rew_inline ? tid - 17 * QP : tid;      // particle whose total this thread holds
     if (rt >= 0 && rt < QP) {
         if (!rew_inline) {
