@@ -834,6 +834,8 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
     float* tmean = ninv + (S + U);
     float* tstd = tmean + S;
     float* lbias = tstd + S;
+    float* xa = smem + (((int)(lbias - smem) + S + 3) & ~3);   // [H][K0G - S/4][4][4] normalised action groups (fast epilogue), 16-byte aligned
+    float* zs = xa + H * K0G * 16;                         // [H][4]   0 * sum(a^2) of cost_func.py:21
 
     // ---- stationary A operands.  W_l is [in][out] row-major (dims from the descriptor, unpacked copy wraw)
     // Packed by bbmpc_set_mlp as [k/4][Mp][4] (zero padded): a lane's four consecutive-k operands are one 16-byte
@@ -894,6 +896,37 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
         const int k = i / QP, pp = i % QP;
         const float v = (k < S) ? st[pp * Sp + k] : acts[pp * U + (k - S)];
         xs[vaddr(k, pp)] = (v - nmean[k]) * ninv[k];
+    }
+    __syncthreads();
+
+    // ---- fast epilogue (cheetah reward, S a multiple of 4): wave 0 keeps the state in D-fragment layout in
+    // registers -- lane g*4+pp owns features 4g..4g+3 of particle pp, exactly the float4 the next step's layer-0 B
+    // operand wants -- so a step's epilogue is four 16-byte partial reads, ~40 VALU and one 16-byte write instead of
+    // 104 threads doing scalar LDS gathers.  The action part of the next input is pre-normalised once.
+    const bool rew_inline0 = (p.reward_kind != REW_PENDULUM) && S > 17;
+    const bool fast_epi = rew_inline0 && (S & 3) == 0 && S <= 64 && (S + U) <= K0G * 4;
+    const int SG = S >> 2, AG = K0G - SG;
+    if (fast_epi) {
+        for (int e = tid; e < H * AG * 16; e += NT) {
+            const int c = e & 3, pp = (e >> 2) & 3, ga = (e >> 4) % AG, t = e / (16 * AG);
+            const int k = S + ga * 4 + c;
+            xa[e] = (k < S + U) ? (acts[(t * QP + pp) * U + (k - S)] - nmean[k]) * ninv[k] : 0.0f;
+        }
+        for (int e = tid; e < H * QP; e += NT) {
+            const float* ac = acts + e * U;                // e = t*QP + pp
+            float ss = 0.0f;
+            for (int u = 0; u < U; ++u) ss = ss + ac[u] * ac[u];
+            zs[e] = 0.0f * ss;
+        }
+    }
+    f32x4 cur4 = {0.0f, 0.0f, 0.0f, 0.0f}, e_bias = cur4, e_tm = cur4, e_ts = {1.0f, 1.0f, 1.0f, 1.0f}, e_nm = cur4, e_ni = e_ts;
+    if (fast_epi && wave == 0 && lane < S) {
+        const int k0 = (lane >> 2) * 4;
+        for (int r = 0; r < 4; ++r) {
+            cur4[r] = p.state[a * S + k0 + r];
+            e_bias[r] = lbias[k0 + r]; e_tm[r] = tmean[k0 + r]; e_ts[r] = tstd[k0 + r];
+            e_nm[r] = nmean[k0 + r]; e_ni[r] = ninv[k0 + r];
+        }
     }
     __syncthreads();
 
@@ -1006,6 +1039,48 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
         }
         __syncthreads();
         Q4_MARK(4);
+        if (fast_epi) {
+            if (wave == 0) {
+                if (lane < S) {
+                    f32x4 pr[NWQ];
+#pragma unroll
+                    for (int w = 0; w < NWQ; ++w) pr[w] = *reinterpret_cast<const f32x4*>(part + ((size_t)w * 64 + lane) * 4);
+                    f32x4 v4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float acc = e_bias[r];
+#pragma unroll
+                        for (int w = 0; w < NWQ; ++w) acc = acc + pr[w][r];
+                        acc = apply_act_ct<A2>(acc);
+                        const float dev = normd ? e_tm[r] + acc * e_ts[r] : acc;
+                        v4[r] = dev + cur4[r];
+                    }
+                    // reward: flags live in the lanes of features 4..7, the progress term in those of 16..19
+                    float fl = 0.0f;
+                    if (cur4.y >= 0.2f) fl = fl + (-10.0f);            // cur[5]
+                    if (cur4.z >= 0.0f) fl = fl + (-10.0f);            // cur[6]
+                    if (cur4.w >= 0.0f) fl = fl + (-10.0f);            // cur[7]
+                    const float f0 = __builtin_amdgcn_readlane(fl, 4), f1 = __builtin_amdgcn_readlane(fl, 5),
+                                f2 = __builtin_amdgcn_readlane(fl, 6), f3 = __builtin_amdgcn_readlane(fl, 7);
+                    if ((lane >> 2) == 4) {
+                        float r = (pl == 0) ? f0 : (pl == 1) ? f1 : (pl == 2) ? f2 : f3;
+                        r = r + (v4.y - cur4.y) / 0.01f;               // (nxt[17] - cur[17]) / 0.01
+                        r = r - zs[t * QP + pl];
+                        total = total + r;
+                    }
+                    cur4 = v4;
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (v4[r] - e_nm[r]) * e_ni[r];
+                    *reinterpret_cast<f32x4*>(xs + (size_t)lane * 4) = o;          // lane = g*4 + pp
+                } else if (lane < K0G * 4) {
+                    const int tn = (t + 1 < H) ? t + 1 : t;
+                    const int ga = (lane >> 2) - SG;
+                    *reinterpret_cast<f32x4*>(xs + (size_t)lane * 4) =
+                        *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + ga) * 4 + pl) * 4);
+                }
+            }
+        } else
         // ---- epilogue: thread (feature k, particle pp)
         for (int i = tid; i < QP * (S + U); i += NT) {
             const int k = i / QP, pp = i % QP;
@@ -1048,7 +1123,7 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
         printf("[q4dbg] H=%d total %lld | layer0 %lld bar %lld layer1 %lld bar %lld last+bar %lld epi+bar %lld (10ns units, summed over steps)\n",
                H, (long long)wall_clock64() - dbg_start, dbg_acc[0], dbg_acc[1], dbg_acc[2], dbg_acc[3], dbg_acc[4], dbg_acc[5]);
 #endif
-    const int rt = rew_inline ? tid - 17 * QP : tid;      // particle whose total this thread holds
+    const int rt = fast_epi ? tid - 16 : (rew_inline ? tid - 17 * QP : tid);      // particle whose total this thread holds
     if (rt >= 0 && rt < QP) {
         if (!rew_inline) {
             const float* c0 = st + ((H - 1) & 1) * QP * Sp;
@@ -1074,7 +1149,8 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
 
 inline int mlp_q4_lds_floats(int HG, int K0G, int NWQ, int H, int U, int S) {
     const int Sp = (S + 3) & ~3;
-    return K0G * 16 + 2 * HG * 16 + NWQ * 256 + 2 * 4 * Sp + ((H * 4 * U + 3) & ~3) + ((4 * U + 3) & ~3) + 2 * (S + U) + 3 * S + 16;
+    return K0G * 16 + 2 * HG * 16 + NWQ * 256 + 2 * 4 * Sp + ((H * 4 * U + 3) & ~3) + ((4 * U + 3) & ~3) + 2 * (S + U) + 3 * S + 16 +
+           H * K0G * 16 + H * 4 + 8;
 }
 
 }  // namespace bbmpc
