@@ -886,7 +886,14 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                 ra.stream = BBMPC_NOISE_TRUNC_NORMAL; ra.iter = (uint32_t)it;
                 ra.inj = inj_t ? inj_t + inj_stride * it : nullptr;
                 launch_rollout(SRC_TRUNC, false, ra);
-                hipLaunchKernelGGL(k_refit_cem, dim3(A), dim3(REFIT_THREADS), lds, stream, rf, JC);
+                if (k <= 64 && !getenv("BBMPC_REFIT_V1")) {
+                    const int rthreads = N > 512 ? 1024 : (N > 256 ? 512 : 256);
+                    RefitArgs rf2 = rf;
+                    if (!trace_on) rf2.elites = nullptr;          // the sorted elite list is only needed by the parity trace
+                    hipLaunchKernelGGL(k_refit_cem_v2, dim3(A), dim3(rthreads), (size_t)fixed * 4, stream, rf2);
+                } else {
+                    hipLaunchKernelGGL(k_refit_cem, dim3(A), dim3(REFIT_THREADS), lds, stream, rf, JC);
+                }
                 HIP_CHECK(hipGetLastError());
                 capture_trace(it);
             }

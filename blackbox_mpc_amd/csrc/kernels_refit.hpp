@@ -154,6 +154,76 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_refit_cem(RefitArgs p, int JC
     }
 }
 
+// CEM refit for k <= 64 elites, latency-lean version of the kernel above (same results as the persistent kernel's
+// refit: elite SET from the radix select, listed in ascending index order; statistics over 16-lane rows).
+// blockDim up to 1024: the gathers are 4 independent global loads per lane with up to four rows in flight, the
+// elite statistics a 16-lane DPP reduction -- no LDS tile, no serial 50-element loops.
+// LDS: rewards[Nst] | elite idx[kpad] | hist[TOPK_HIST_WORDS] | ekeys[2*kpad]
+__global__ __launch_bounds__(1024) void k_refit_cem_v2(RefitArgs p) {
+    extern __shared__ float smem[];
+    const int a = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    float* r = smem;
+    int* eidx = (int*)(smem + p.Nst);
+    const int kpad = (p.k + 3) & ~3;
+    uint32_t* hist = (uint32_t*)(eidx + kpad);
+    unsigned long long* ekeys = (unsigned long long*)(hist + TOPK_HIST_WORDS);
+
+    for (int n = tid; n < p.N; n += nthr) r[n] = p.rewards[(size_t)a * p.Nst + n];
+    __syncthreads();
+    const TopkSel sel = block_topk_select(r, p.N, p.k, hist, tid, nthr);
+    if (p.elites) {                                   // parity trace wants tf.nn.top_k's sorted order
+        block_topk_finish_sorted(r, p.N, p.k, eidx, hist, ekeys, sel, tid, nthr);
+        for (int e = tid; e < p.k; e += nthr) p.elites[a * p.k + e] = eidx[e];
+        __syncthreads();
+    }
+    block_topk_finish_indexed(r, p.N, p.k, eidx, hist, sel, tid, nthr);
+
+    constexpr int EC = 4, RC = 4;                     // elites per lane, rows in flight per 16-lane group
+    const int sub = tid & 15, grp = tid >> 4, ngrp = nthr >> 4;
+    int ei[EC];
+#pragma unroll
+    for (int i = 0; i < EC; ++i) ei[i] = (sub + 16 * i < p.k) ? eidx[sub + 16 * i] : -1;
+    const float kf = (float)p.k, one_m = 1.0f - p.alpha;
+    const float* __restrict__ samples = p.samples + (size_t)a * p.HU * p.Nst;
+    for (int j0 = 0; j0 < p.HU; j0 += RC * ngrp) {
+        float x[RC][EC];
+#pragma unroll
+        for (int rr = 0; rr < RC; ++rr) {
+            const int j = j0 + rr * ngrp + grp;
+            const float* row = samples + (size_t)(j < p.HU ? j : 0) * p.Nst;
+#pragma unroll
+            for (int i = 0; i < EC; ++i) x[rr][i] = row[ei[i] >= 0 ? ei[i] : 0];
+        }
+#pragma unroll
+        for (int rr = 0; rr < RC; ++rr) {
+            const int j = j0 + rr * ngrp + grp;
+            float sum = 0.0f, vs = 0.0f;
+#pragma unroll
+            for (int i = 0; i < EC; ++i) if (ei[i] >= 0) sum += x[rr][i];
+            sum = row16_sum(sum);
+            const float em = sum / kf;                                     // cem.py:112
+#pragma unroll
+            for (int i = 0; i < EC; ++i)
+                if (ei[i] >= 0) {
+                    const float d = x[rr][i] - em;
+                    vs += d * d;
+                }
+            vs = row16_sum(vs);
+            if (j < p.HU && sub == 0) {
+                const float ev = vs / kf;                                  // cem.py:113-119
+                const int aj = a * p.HU + j;
+                const float m = p.alpha * p.mean[aj] + one_m * em;         // cem.py:121-122
+                const float v = p.alpha * p.var[aj] + one_m * ev;          // cem.py:123-125
+                p.mean[aj] = m;
+                p.var[aj] = v;
+                const int u = j % p.U;
+                p.sigma[aj] = cem_sigma(m, v, p.lo[u], p.hi[u]);
+                if (j < p.U) p.action[a * p.U + j] = m;                    // mean[:, 0]  cem.py:135
+            }
+        }
+    }
+}
+
 // PI2 refit  pi2.py:78-87: softmin weights over the population, weighted mean of the (feasible) samples.
 // LDS: omega[Nst] | scratch[32]
 __global__ __launch_bounds__(REFIT_THREADS) void k_refit_pi2(RefitArgs p) {
