@@ -106,6 +106,29 @@ class COracle:
         lib().bbo_predict_next_state(ctypes.byref(self.P), s.shape[0], _p(s), _p(a), _p(out))
         return out
 
+    def evaluate_next_reward(self, cur, nxt, act):
+        cur, nxt, act = [np.ascontiguousarray(v, np.float32) for v in (cur, nxt, act)]
+        out = np.empty((cur.shape[0],), np.float32)
+        lib().bbo_evaluate_next_reward(ctypes.byref(self.P), cur.shape[0], _p(cur), _p(nxt), _p(act), _p(out))
+        return out
+
+    def as_evaluator(self):
+        """Adapter with oracle_np.Evaluator's interface, so that the NumPy optimizers (PSO, SPSA, CMA-ES) can run
+        BASELINE-size problems with this library doing the rollouts."""
+        co = self
+
+        class _Ev:
+            def __call__(self, states, seq, return_final_state=False):
+                assert not return_final_state
+                return co.evaluate(states, seq)
+
+            def predict_next_state(self, s, a):
+                return co.predict_next_state(s, a)
+
+            def evaluate_next_reward(self, cur, nxt, act):
+                return co.evaluate_next_reward(cur, nxt, act)
+        return _Ev()
+
     def optimize(self, opt, state, noise=None, seed=0, forced_elites=None, trace=False):
         """One OptimizerBase.__call__ (exploration noise off).  noise: [iters][N,A,H,U] standard draws or None."""
         state = np.ascontiguousarray(state, np.float32)

@@ -507,7 +507,10 @@ class PSO(OptimizerBase):
         self.pbest_r = np.full((self.N, self.A), -np.inf, F)
         self.gbest_r = np.full((self.A,), -np.inf, F)
 
-    def _optimize(self, state, noise):
+    def _optimize(self, state, noise, rewards_override=None):
+        """`rewards_override`: optional callable (iteration, rewards[N,A]) -> rewards[N,A] used by full-size parity
+        tests for lock-step: it checks the oracle's rewards against the device's within tolerance and returns the
+        device's, so that the exact comparisons below (pbest update, argmax) see identical values."""
         self.trace = []
         ar = np.arange(self.A)
         for it in range(self.iters):
@@ -515,6 +518,8 @@ class PSO(OptimizerBase):
             pen = self._penalty(self.pos, feas)                                # :78-79
             self.pos = feas                                                    # :80
             rewards = (self.ev(state, self.pos) - pen).astype(F)               # :82
+            if rewards_override is not None:
+                rewards = f32(rewards_override(it, rewards))
             cond = self.pbest_r < rewards                                      # :84
             self.pbest = np.where(cond[:, :, None, None], self.pos, self.pbest)    # :86-88
             self.pbest_r = np.where(cond, rewards, self.pbest_r).astype(F)     # :89-91

@@ -125,3 +125,91 @@ def test_config5_evaluator_per_gpu_share(L):
     np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3 * H)
     # tighter statistical statement: typical error is far below the bound
     assert np.median(np.abs(got - want)) < 2e-3
+
+
+def test_config5_pso_lockstep_per_gpu_share(L):
+    # BASELINE config 5 (PSO leg) on 8 GPUs: N=2000, A=4 of 32, H=50, 5 iterations, learned 26-200-200-20 model.
+    # NumPy PSO oracle with the C library doing the rollouts; lock-step on the rewards (checked within tolerance each
+    # iteration, then the device's values are carried on so that pbest / argmax comparisons see identical numbers).
+    N, A, H, iters, U = 2000, 4, 50, 5, 6
+    eng, co = _cheetah(L, L.OPT_PSO, N, A, H, iters)
+    eng.set_trace(True)
+    lo, hi = [-1.0] * U, [1.0] * U
+    pso = O.PSO(co.as_evaluator(), lo, hi, horizon=H, max_iterations=iters, population=N, num_agents=A)
+    rng = np.random.default_rng(505)
+    rn = {"uniform_pos": rng.random((N, A, H, U)).astype(F), "uniform_vel": rng.random((N, A, H, U)).astype(F)}
+    eng.inject_noise(L.NOISE_PSO_RESET_POS, rn["uniform_pos"])
+    eng.inject_noise(L.NOISE_PSO_RESET_VEL, rn["uniform_vel"])
+    eng.reset()
+    pso.reset(rn)
+    states = O.cheetah_start_states(A, 20, agent_offset=8)
+    noise = {"normal2": rng.standard_normal((iters, 2)).astype(F), "trunc": O.truncated_normal_noise(rng, (N, A, H, U)),
+             "uniform": rng.random((N, A, H, U)).astype(F)}
+    eng.inject_noise(L.NOISE_PSO_SCALARS, noise["normal2"])
+    eng.inject_noise(L.NOISE_PSO_RESEED_TRUNC, noise["trunc"])
+    eng.inject_noise(L.NOISE_PSO_RESEED_UNIFORM, noise["uniform"])
+    act, nxt, rew = eng.optimize(states)
+    hip_r = [eng.get_trace(it, L.TRACE_REWARDS) for it in range(iters)]
+
+    def lock(it, r_o):
+        np.testing.assert_allclose(hip_r[it], r_o, rtol=1e-3, atol=1e-3 * H)
+        return hip_r[it]
+    act_o = pso._optimize(states, noise, rewards_override=lock)
+    for it in range(iters):
+        np.testing.assert_array_equal(eng.get_trace(it, L.TRACE_ELITES), pso.trace[it]["gbest_idx"])
+        np.testing.assert_allclose(eng.get_trace(it, L.TRACE_MEAN), pso.trace[it]["gbest"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(act, act_o, rtol=0, atol=2e-5)
+    shp = (N, A, H, U)
+    np.testing.assert_allclose(eng.get_state("pos", shp), pso.pos, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(eng.get_state("vel", shp), pso.vel, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(nxt, co.predict_next_state(states, act_o), rtol=2e-5, atol=2e-4)
+
+
+def test_config5_cmaes_coupled_single_agent_full_dimension(L):
+    # BASELINE config 5 (CMA-ES leg): N=2000, H=50, U=6 => n = 300 search dimensions, k=50, A=1 (the coupled reference
+    # behaviour; with one agent it coincides with the per-agent mode that shards).  Two control steps, one
+    # iteration each; the oracle takes the engine's eigen-decomposition (library-specific signs) after checking its
+    # invariants, and near-tied ranks may swap.
+    from blackbox_mpc_amd.engine import Engine
+    N, A, H, U, k = 2000, 1, 50, 6, 50
+    n = A * H * U
+    S = 20
+    ws, bs = O.make_mlp_params(MLP_DIMS, seed=42)
+    stats = _cheetah_stats(S, U)
+    lo, hi = [-1.0] * U, [1.0] * U
+    eng = Engine(L.OPT_CMAES, L.DYN_MLP, L.REW_CHEETAH, lo, hi, dim_s=S, num_agents=A, planning_horizon=H,
+                 population_size=N, max_iterations=1, num_elite=k)
+    eng.set_mlp(ws, bs, [1, 1, 0], stats)
+    eng.set_trace(True)
+    co = OC.COracle("mlp", "cheetah", lo, hi, N, A, H, S, mlp=(ws, bs, MLP_ACTS), stats=stats)
+    cma = O.CMAES(co.as_evaluator(), lo, hi, horizon=H, max_iterations=1, population=N, num_elite=k, num_agents=A)
+    rng = np.random.default_rng(77)
+    states = O.cheetah_start_states(A, S)
+    RT, AT = 1e-3, 1e-3 * H
+    for step in range(2):
+        z = rng.standard_normal((1, N, n)).astype(F)
+        eng.inject_noise(L.NOISE_NORMAL, z.reshape(1, N, A, H, U))
+        act, nxt, rew = eng.optimize(states)
+        g = lambda name, shape: eng.get_state(name, shape)
+        D, B, C = g("D", (n,)), g("B", (1, n, n))[0], g("C", (1, n, n))[0]
+        hip_r = eng.get_trace(0, L.TRACE_REWARDS)
+        hip_order = eng.get_trace(0, L.TRACE_ELITES)[0]
+
+        def order(it, rsum, own):
+            np.testing.assert_allclose(hip_r.sum(axis=1), rsum, rtol=RT, atol=AT)
+            np.testing.assert_array_equal(hip_order, O.topk_desc(hip_r.sum(axis=1, dtype=np.float32), k))
+            for a_, b_ in zip(own[:k], hip_order):
+                assert a_ == b_ or abs(rsum[a_] - rsum[b_]) <= AT + RT * abs(rsum[a_])
+            return hip_order
+        cma._optimize(states, {"normal": [z[0]]}, eig=[((D.astype(np.float64) ** 2).astype(F), B)], forced_order=order)
+        tr = cma.trace[0]
+        np.testing.assert_allclose(eng.get_trace(0, L.TRACE_SAMPLES), tr["samples"], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(g("m", (n,)), tr["m"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(g("sigma", (n,)), tr["sigma"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(g("p_sigma", (n,)), tr["p_sigma"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(C, tr["C"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(act, tr["m"].reshape(A, H, U)[:, 0], rtol=0, atol=1e-4)
+        B64, D64, C64 = B.astype(np.float64), D.astype(np.float64), C.astype(np.float64)
+        np.testing.assert_allclose(B64 @ np.diag(D64 ** 2) @ B64.T, C64, rtol=0, atol=1e-4 * max(1.0, np.abs(C64).max()))
+        np.testing.assert_allclose(B64.T @ B64, np.eye(n), rtol=0, atol=1e-4)
+        assert np.all(D64[:-1] >= D64[1:] - 1e-6) and np.all(D64 > 0)
