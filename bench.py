@@ -29,6 +29,9 @@ CONFIGS = {
     "cfg4": dict(env="cheetah", opt="CEM", N=1000, A=1, H=30, iters=5, k=50),
     "cfg5cem": dict(env="cheetah", opt="CEM", N=2000, A=4, H=50, iters=5, k=50),     # config-5 shape per GPU, CEM
     "cfg5full": dict(env="cheetah", opt="CEM", N=2000, A=32, H=50, iters=5, k=50),   # all 32 agents on one GPU
+    # BASELINE config 5 proper (its two optimizers), one GPU's share of the 32 agents
+    "cfg5pso": dict(env="cheetah", opt="PSO", N=2000, A=4, H=50, iters=5, k=0),
+    "cfg5cma": dict(env="cheetah", opt="CMA-ES", N=2000, A=4, H=50, iters=5, k=50),  # per-agent CMA-ES (n = 300 each)
 }
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
@@ -75,14 +78,16 @@ def main():
     from oracle import oracle_np as O      # inputs (start states) + the cpu_baseline leg only
 
     c = CONFIGS[args.config]
-    opt = {"RandomSearch": L.OPT_RANDOM_SEARCH, "CEM": L.OPT_CEM, "PI2": L.OPT_PI2}[c["opt"]]
+    opt = {"RandomSearch": L.OPT_RANDOM_SEARCH, "CEM": L.OPT_CEM, "PI2": L.OPT_PI2, "PSO": L.OPT_PSO,
+           "CMA-ES": L.OPT_CMAES}[c["opt"]]
+    quirks = L.CMAES_PER_AGENT if c["opt"] == "CMA-ES" else 0     # the shardable CMA-ES mode
     N, A, H, iters, k = c["N"], c["A"], c["H"], c["iters"], c["k"]
     mlp = c["env"] == "cheetah"
     if mlp:
         U, S = 6, 20
         eng = Engine(opt, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=A, planning_horizon=H,
                      population_size=N, max_iterations=iters, num_elite=k, seed=0, agent_offset=rank * A,
-                     num_agents_global=world * A, device=local)
+                     num_agents_global=world * A, device=local, quirks=quirks)
         ws, bs = O.make_mlp_params(MLP_DIMS, seed=42)          # Glorot-uniform / zero bias, last layer x0.1
         eng.set_mlp(ws, bs, [L.ACT_TANH, L.ACT_TANH, L.ACT_NONE], cheetah_stats(S, U))
         start = O.cheetah_start_states(A, S, agent_offset=rank * A)
@@ -92,6 +97,7 @@ def main():
                      population_size=N, max_iterations=iters, num_elite=k, seed=0, agent_offset=rank * A,
                      num_agents_global=world * A, device=local)
         start = O.pendulum_start_states(A, agent_offset=rank * A)
+    eng.reset()                      # episode start, as utils/rollouts.py:_sample does (PSO draws its swarm here)
     rec = U + S + 1
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
@@ -230,7 +236,7 @@ def main():
             "ms_per_step_uninstrumented": (t3 - t2) / args.steps * 1e3,
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and c["opt"] in ("RandomSearch", "CEM", "PI2"):
             out["cpu_baseline"] = cpu_baseline(O, c, H, N, A, iters, k)
         print(json.dumps(out))
     if world > 1:

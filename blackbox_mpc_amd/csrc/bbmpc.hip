@@ -227,6 +227,7 @@ void Engine::cma_init() {
     c_Ye.alloc((size_t)G * k * n);
     c_eidx.alloc((size_t)G * k);
     c_info.alloc(gn);           // SVD: column permutation
+    c_sync.alloc((size_t)G * 32);
     // C = B = D = I, paths = 0 (cma_es.py:98-117)
     std::vector<float> eye(gnn, 0.0f), ones(gn, 1.0f);
     for (int g = 0; g < G; ++g)
@@ -291,7 +292,15 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
         hipLaunchKernelGGL(k_cma_paths, dim3(G), dim3(REFIT_THREADS), 0, stream, q);
         hipLaunchKernelGGL(k_cma_cov, dim3((n + 15) / 16, (n + 15) / 16, G), dim3(16, 16), 0, stream, q);
         HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(k_cma_svd, dim3(G), dim3(REFIT_THREADS), 0, stream, q, c_evec.p, c_eval.p, c_info.p, 15);
+        if (n <= 512 && !getenv("BBMPC_CMA_SVD_V1")) {
+            // warm-started Jacobi, one 1024-thread workgroup per instance (kernels_cma.hpp)
+            HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * 32 * sizeof(unsigned), stream));
+            hipLaunchKernelGGL(k_cma_warm, dim3((unsigned)((n * n + 255) / 256), G), dim3(256), 0, stream, q, c_evec.p);
+            hipLaunchKernelGGL(k_cma_svd_rounds, dim3(1, G), dim3(1024), 0, stream, q, c_evec.p, c_sync.p, 15);
+            hipLaunchKernelGGL(k_cma_svd_finish, dim3(G), dim3(REFIT_THREADS), 0, stream, q, c_evec.p, c_eval.p, c_info.p);
+        } else {
+            hipLaunchKernelGGL(k_cma_svd, dim3(G), dim3(REFIT_THREADS), 0, stream, q, c_evec.p, c_eval.p, c_info.p, 15);
+        }
         HIP_CHECK(hipGetLastError());
         if (trace_on) {
             ensure_trace();

@@ -291,4 +291,144 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_cma_svd(CmaArgs p, float* At_
     for (int c = tid; c < n; c += REFIT_THREADS) p.Dd[(size_t)g * n + c] = sqrtf(norms[perm[c]]);   // D = diag(sqrt(s))
 }
 
+// ---- Multi-workgroup, warm-started version of the Jacobi SVD above (n = H*U = 300 at BASELINE config 5: one
+// workgroup per instance needed 50 ms).
+//  * Warm start: C changes by a small rank-(k+1) update per iteration, so the previous eigenvectors B0 nearly
+//    diagonalise it.  Run the one-sided Jacobi on A = C*B0 (columns ~ lambda_j b_j, already almost orthogonal):
+//    A V = U S with C = U S (B0 V)^T, i.e. the same left singular vectors / values, reached in 2-3 sweeps instead of 8+.
+//  * 16 waves per instance, a pair's two columns held in registers between the dot products and the rotation (one
+//    global round trip per pair instead of two).
+//  * The kernel can also spread an instance over WPG workgroups with a global-atomic barrier per round.  Measured:
+//    42 us per round -- an agent-scope release/acquire on this multi-XCD part writes back / invalidates L2 -- against
+//    ~10 us for the whole round in one workgroup, so WPG = 1 is what the engine launches.
+// k_cma_warm: At[j][:] = C * B0[:, j] (C symmetric => coalesced along the column);  k_cma_svd_rounds: the sweeps;
+// k_cma_svd_finish: norms, descending order, B and D.
+__global__ void k_cma_warm(CmaArgs p, float* At_all) {
+    const int g = blockIdx.y, n = p.n;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    const int j = idx / n, e = idx % n;
+    const float* C = p.C + (size_t)g * n * n;
+    const float* B = p.B + (size_t)g * n * n;
+    float acc = 0.0f;
+    for (int k = 0; k < n; ++k) acc = fmaf(C[(size_t)k * n + e], B[(size_t)k * n + j], acc);
+    At_all[(size_t)g * n * n + idx] = acc;
+}
+
+__device__ __forceinline__ void cma_instance_barrier(unsigned* ctr, unsigned target) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(ctr, 1u);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        __threadfence();
+    }
+    __syncthreads();
+}
+
+// sync: [G][32] unsigned: [0] barrier counter, [1 + sweep] "some pair rotated in this sweep"
+__global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
+    const int g = blockIdx.y, WPG = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
+    const int NW = blockDim.x >> 6;
+    // rotation threshold on the cosine between two columns: the fp32 dot-product noise floor grows with n
+    const float tol = fminf(fmaxf(3.0e-8f * (float)n, 2.0e-6f), 1.0e-5f);
+    float* At = At_all + (size_t)g * n * n;
+    unsigned* sync = sync_all + (size_t)g * 32;
+    const int gw = blockIdx.x * NW + wv, nwaves = WPG * NW;
+    const int m = (n + 1) & ~1;                 // players of the round-robin (one dummy when n is odd)
+    unsigned bar = 0;
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        for (int r = 0; r < m - 1; ++r) {
+            // two pairs per wave in flight: the loads of the second pair overlap the reductions of the first
+            for (int i0 = gw; i0 < m / 2; i0 += 2 * nwaves) {
+                float xv[2][8], yv[2][8];
+                float* xp[2];
+                float* yp[2];
+                bool act[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int i = i0 + q * nwaves;
+                    int pa = 0, pb = 0;
+                    if (i == 0) { pa = m - 1; pb = r; }
+                    else if (i < m / 2) { pa = (r + i) % (m - 1); pb = (r - i + (m - 1)) % (m - 1); }
+                    act[q] = i < m / 2 && pa < n && pb < n;              // dummy player sits out
+                    xp[q] = At + (size_t)(act[q] ? pa : 0) * n;
+                    yp[q] = At + (size_t)(act[q] ? pb : 0) * n;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int e = lane + 64 * c;
+                        xv[q][c] = (act[q] && e < n) ? xp[q][e] : 0.0f;
+                        yv[q][c] = (act[q] && e < n) ? yp[q][e] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float al = 0.0f, be = 0.0f, ga = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        al = fmaf(xv[q][c], xv[q][c], al); be = fmaf(yv[q][c], yv[q][c], be); ga = fmaf(xv[q][c], yv[q][c], ga);
+                    }
+                    al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
+                    if (!act[q] || fabsf(ga) <= tol * sqrtf(al * be) || ga == 0.0f) continue;
+                    const float zeta = (be - al) / (2.0f * ga);
+                    const float t = copysignf(1.0f, zeta) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
+                    const float cs = 1.0f / sqrtf(1.0f + t * t), sn = cs * t;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int e = lane + 64 * c;
+                        if (e < n) {
+                            xp[q][e] = cs * xv[q][c] - sn * yv[q][c];
+                            yp[q][e] = sn * xv[q][c] + cs * yv[q][c];
+                        }
+                    }
+#ifdef BBMPC_KERNEL_DBG
+                    if (lane == 0) atomicAdd(&sync[1 + sweep], 1u);
+#else
+                    if (lane == 0) sync[1 + sweep] = 1u;
+#endif
+                }
+            }
+            ++bar;
+            if (WPG > 1) cma_instance_barrier(sync, bar * (unsigned)WPG);
+            else __syncthreads();
+        }
+        if (WPG == 1) __syncthreads();
+        if (__hip_atomic_load(sync + 1 + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
+#ifdef BBMPC_KERNEL_DBG
+        if (g == 0 && blockIdx.x == 0 && tid == 0) printf("[svd] sweep %d done at %lld rotations %u\n", sweep, (long long)wall_clock64(), sync[1 + sweep]);
+#endif
+    }
+}
+
+__global__ __launch_bounds__(REFIT_THREADS) void k_cma_svd_finish(CmaArgs p, const float* At_all, float* norms_all, int* perm_all) {
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
+    constexpr int NW = REFIT_THREADS / 64;
+    const size_t nn = (size_t)n * n;
+    const float* At = At_all + (size_t)g * nn;
+    float* norms = norms_all + (size_t)g * n;
+    int* perm = perm_all + (size_t)g * n;
+    for (int j = wv; j < n; j += NW) {
+        float al = 0.0f;
+        for (int e = lane; e < n; e += 64) { const float v = At[(size_t)j * n + e]; al = fmaf(v, v, al); }
+        al = wave_sum(al);
+        if (lane == 0) norms[j] = sqrtf(al);
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += REFIT_THREADS) {
+        const float nj = norms[j];
+        int rank = 0;
+        for (int o = 0; o < n; ++o) rank += (norms[o] > nj || (norms[o] == nj && o < j)) ? 1 : 0;
+        perm[rank] = j;
+    }
+    __syncthreads();
+    float* B = p.B + (size_t)g * nn;
+    for (size_t i = tid; i < nn; i += REFIT_THREADS) {
+        const int r = (int)(i / n), c = (int)(i % n);
+        const int src = perm[c];
+        const float sv = norms[src];
+        B[i] = (sv > 0.0f) ? At[(size_t)src * n + r] / sv : ((r == c) ? 1.0f : 0.0f);
+    }
+    for (int c = tid; c < n; c += REFIT_THREADS) p.Dd[(size_t)g * n + c] = sqrtf(norms[perm[c]]);   // D = diag(sqrt(s))
+}
+
 }  // namespace bbmpc
