@@ -837,8 +837,7 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
     float* xa = smem + (((int)(lbias - smem) + S + 3) & ~3);   // [H][K0G - S/4][4][4] normalised action groups (fast epilogue), 16-byte aligned
     float* zs = xa + H * K0G * 16;                         // [H][4]   0 * sum(a^2) of cost_func.py:21
 
-    // ---- stationary A operands.  W_l is [in][out] row-major (dims from the descriptor, unpacked copy wraw)
-    // Packed by bbmpc_set_mlp as [k/4][Mp][4] (zero padded): a lane's four consecutive-k operands are one 16-byte
+    // ---- stationary A operands.  Packed by bbmpc_set_mlp as [k/4][Mp][4] (zero padded): a lane's four consecutive-k operands are one 16-byte
     // load, a wave's load is 1 KB contiguous -- 70 loads per lane instead of 278 dword loads (the prologue was a
     // fifth of the kernel).
     const int M1 = m.dims[1], M3 = m.dims[3];
