@@ -738,6 +738,7 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     fa.fix_q7 = fix(BBMPC_FIX_Q7_EXPL_NOISE_ZERO_MEAN);
     fa.add_noise = add_noise;
     fa.warm_start = fix(BBMPC_FIX_Q2_CEM_WARM_START);
+    { const char* ev = getenv("BBMPC_BALANCE"); fa.balance = ev ? atoi(ev) : 1; }
     fa.alpha = cfg.alpha;
     fa.inv_lamda = 1.0f / cfg.lamda;
     fa.state = d_state_in;

@@ -27,6 +27,7 @@ struct FusedArgs {
     int agent_offset;
     int fix_q1, fix_q7, add_noise;
     int warm_start;          // CEM: BBMPC_FIX_Q2 (keep the mean across control steps)
+    int balance;             // progress-balanced wave priorities in the rollout (BBMPC_BALANCE, default on)
     float alpha, inv_lamda;
     const float* state;      // [A,3]
     const float* lo;
@@ -137,6 +138,9 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             // recurrence; the Philox rounds (a quarter of this kernel's VALU work) are gone from the critical path.
             const int Q = (p.HU + 3) >> 2;
             const float4* inj4 = reinterpret_cast<const float4*>(p.inj) + ((size_t)it * p.A + a) * p.Nst * Q;
+            int* prog = (int*)red;                             // per-wave progress (red[] is idle during the rollout)
+            const int wave = tid >> 6, lane = tid & 63;
+            const bool balance = p.balance != 0 && nw > 4 && nw <= 64 && p.N <= nthr;
             for (int n = tid; n < p.N; n += nthr) {
                 Roller<FASTM> roll;
                 roll.init(p.fix_q1 != 0, s0, s1, s2);
@@ -159,11 +163,27 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                 };
                 float4 c0 = ld(0), c1 = ld(1);
                 int b = 0;
+                // Waves that share a SIMD (wave ids equal mod 4) run the same instruction stream, and the arbiter
+                // favours the older one: it finishes early and the younger one then runs alone at a lone wave's
+                // issue rate (measured: 4.5 us vs 6.0 us for the two halves of a 500-particle population).  Each
+                // wave publishes its block counter in LDS and lowers its priority while it is ahead of a SIMD mate.
+                if (balance && lane == 0) prog[wave] = 0;
                 for (; b + 1 < nblk; b += 2) {
                     const float4 n0 = ld(b + 2), n1 = ld(b + 3);
+                    if (balance) {
+                        if (lane == 0) prog[wave] = b;
+                        int behind = b;
+                        for (int w2 = wave & 3; w2 < nw; w2 += 4) behind = min(behind, prog[w2]);
+                        if (behind < b) __builtin_amdgcn_s_setprio(0);
+                        else __builtin_amdgcn_s_setprio(2);
+                    }
                     block4(c0, b);
                     block4(c1, b + 1);
                     c0 = n0; c1 = n1;
+                }
+                if (balance) {
+                    if (lane == 0) prog[wave] = 1 << 30;
+                    __builtin_amdgcn_s_setprio(0);
                 }
                 if (b < nblk) { block4(c0, b); c0 = c1; ++b; }
                 if (rem > 0) step1(4 * b + 0, c0.x);
