@@ -444,8 +444,8 @@ def test_noise_prefetch_is_bit_identical_to_in_kernel_draws(L, monkeypatch, opt_
         eng = _engine(L, opt, A, H, N=N, iters=3, k=max(N // 10, 1), seed=11)
         s = O.pendulum_start_states(A)
         out = []
-        for t in range(7):
-            if t == 4:
+        for t in range(21):                # crosses two 8-step prefetch chunks
+            if t == 11:
                 eng.reset()
             a, s, r = eng.optimize(s)
             out.append(np.concatenate([a.ravel(), s.ravel(), r.ravel()]))
