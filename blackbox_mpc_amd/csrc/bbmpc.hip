@@ -296,7 +296,19 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             // warm-started Jacobi, one 1024-thread workgroup per instance (kernels_cma.hpp)
             HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * 32 * sizeof(unsigned), stream));
             hipLaunchKernelGGL(k_cma_warm, dim3((unsigned)((n * n + 255) / 256), G), dim3(256), 0, stream, q, c_evec.p);
-            hipLaunchKernelGGL(k_cma_svd_rounds, dim3(1, G), dim3(1024), 0, stream, q, c_evec.p, c_sync.p, 15);
+            const int bsz = (n + 7) / 8;
+            const size_t blds = (size_t)2 * bsz * n * sizeof(float);
+            if (n >= 128 && blds <= 160 * 1024 && G * 4 <= 256 && !getenv("BBMPC_CMA_SVD_ROUNDS")) {
+                // block Jacobi: 4 workgroups per instance, block pairs resident in LDS, 7 instance barriers per sweep
+                static bool bconf = false;
+                if (!bconf) {
+                    HIP_CHECK(hipFuncSetAttribute((const void*)k_cma_svd_block, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    bconf = true;
+                }
+                hipLaunchKernelGGL(k_cma_svd_block, dim3(4, G), dim3(1024), blds, stream, q, c_evec.p, c_sync.p, 15);
+            } else {
+                hipLaunchKernelGGL(k_cma_svd_rounds, dim3(1, G), dim3(1024), 0, stream, q, c_evec.p, c_sync.p, 15);
+            }
             hipLaunchKernelGGL(k_cma_svd_finish, dim3(G), dim3(REFIT_THREADS), 0, stream, q, c_evec.p, c_eval.p, c_info.p);
         } else {
             hipLaunchKernelGGL(k_cma_svd, dim3(G), dim3(REFIT_THREADS), 0, stream, q, c_evec.p, c_eval.p, c_info.p, 15);

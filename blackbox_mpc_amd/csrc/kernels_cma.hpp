@@ -431,4 +431,107 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_cma_svd_finish(CmaArgs p, con
     for (int c = tid; c < n; c += REFIT_THREADS) p.Dd[(size_t)g * n + c] = sqrtf(norms[perm[c]]);   // D = diag(sqrt(s))
 }
 
+// ---- Block Jacobi: the columns are cut into 8 blocks; 4 workgroups per instance each hold one PAIR of blocks in
+// LDS and orthogonalise every column pair inside it without touching global memory; the block pairs follow a
+// round-robin tournament (7 block rounds per sweep), so an instance needs 7 instance-wide barriers per sweep instead
+// of n-1, and the one-CU memory path that bounds k_cma_svd_rounds (67 GB/s, 3.2 ms per sweep at n = 300) is out of
+// the picture.  Same rotation, threshold and convergence rule as above.
+// LDS: 2*bs columns of n floats.  sync: [G][32] as above.
+__global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
+    extern __shared__ __attribute__((aligned(16))) float cols[];
+    constexpr int NB = 8;                                   // blocks; gridDim.x == NB / 2 workgroups per instance
+    const int g = blockIdx.y, wg = blockIdx.x, WPG = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
+    const int NW = blockDim.x >> 6;
+    const int bs = (n + NB - 1) / NB;                       // columns per block (the last block may be short)
+    float* At = At_all + (size_t)g * n * n;
+    unsigned* sync = sync_all + (size_t)g * 32;
+    const float tol = fminf(fmaxf(3.0e-8f * (float)n, 2.0e-6f), 1.0e-5f);
+    unsigned bar = 0;
+
+    // one column pair (LDS columns ia, ib; global column ids ca, cb < n guaranteed by the caller)
+    auto rotate = [&](int ia, int ib) -> bool {
+        float* x = cols + (size_t)ia * n;
+        float* y = cols + (size_t)ib * n;
+        float xv[8], yv[8];
+        float al = 0.0f, be = 0.0f, ga = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int e = lane + 64 * c;
+            xv[c] = (e < n) ? x[e] : 0.0f;
+            yv[c] = (e < n) ? y[e] : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { al = fmaf(xv[c], xv[c], al); be = fmaf(yv[c], yv[c], be); ga = fmaf(xv[c], yv[c], ga); }
+        al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
+        if (fabsf(ga) <= tol * sqrtf(al * be) || ga == 0.0f) return false;
+        const float zeta = (be - al) / (2.0f * ga);
+        const float t = copysignf(1.0f, zeta) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
+        const float cs = 1.0f / sqrtf(1.0f + t * t), sn = cs * t;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int e = lane + 64 * c;
+            if (e < n) {
+                x[e] = cs * xv[c] - sn * yv[c];
+                y[e] = sn * xv[c] + cs * yv[c];
+            }
+        }
+        return true;
+    };
+
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        bool rotated = false;
+        for (int R = 0; R < NB - 1; ++R) {
+            // tournament: workgroup 0 plays (NB-1, R), workgroup i plays ((R+i) % (NB-1), (R-i) mod (NB-1))
+            int bx, by;
+            if (wg == 0) { bx = NB - 1; by = R; }
+            else { bx = (R + wg) % (NB - 1); by = (R - wg + (NB - 1)) % (NB - 1); }
+            const int x0 = bx * bs, y0 = by * bs;
+            const int nx = max(0, min(bs, n - x0)), ny = max(0, min(bs, n - y0));
+            // ---- load the two blocks (columns are rows of At: contiguous)
+            for (int i = tid; i < (nx + ny) * n; i += blockDim.x) {
+                const int c = i / n, e = i % n;
+                cols[(size_t)c * n + e] = At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e];
+            }
+            __syncthreads();
+            // ---- pairs inside each block, once per sweep (block round 0 has every block in some workgroup)
+            if (R == 0) {
+                for (int blk = 0; blk < 2; ++blk) {
+                    const int base = blk ? nx : 0, cnt = blk ? ny : nx;
+                    const int m = (cnt + 1) & ~1;
+                    for (int r = 0; r < m - 1; ++r) {
+                        for (int i = wv; i < m / 2; i += NW) {
+                            int pa, pb;
+                            if (i == 0) { pa = m - 1; pb = r; }
+                            else { pa = (r + i) % (m - 1); pb = (r - i + (m - 1)) % (m - 1); }
+                            if (pa < cnt && pb < cnt) rotated |= rotate(base + pa, base + pb);
+                        }
+                        __syncthreads();
+                    }
+                }
+            }
+            // ---- pairs across the two blocks: round r pairs x-column i with y-column (i + r) % mm: disjoint
+            const int mm = max(nx, ny);
+            for (int r = 0; r < mm; ++r) {
+                for (int i = wv; i < mm; i += NW) {
+                    const int j = (i + r) % mm;
+                    if (i < nx && j < ny) rotated |= rotate(i, nx + j);
+                }
+                __syncthreads();
+            }
+            // ---- write back
+            for (int i = tid; i < (nx + ny) * n; i += blockDim.x) {
+                const int c = i / n, e = i % n;
+                At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e] = cols[(size_t)c * n + e];
+            }
+            if (R == NB - 2 && rotated && lane == 0) sync[1 + sweep] = 1u;
+            ++bar;
+            cma_instance_barrier(sync, bar * (unsigned)WPG);
+        }
+        if (__hip_atomic_load(sync + 1 + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
+#ifdef BBMPC_KERNEL_DBG
+        if (g == 0 && blockIdx.x == 0 && tid == 0) printf("[svdb] sweep %d done at %lld\n", sweep, (long long)wall_clock64());
+#endif
+    }
+}
+
 }  // namespace bbmpc
