@@ -1392,10 +1392,19 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
     const size_t ns = (size_t)e.A * e.S, nr = (size_t)e.A * e.rec;
     float* pin = e.pinned(ns + nr);
     memcpy(pin, state, ns * 4);
-    HIP_CHECK(hipMemcpyAsync(e.d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e.stream));
     (void)t;  // the reference evaluator accepts and ignores time_step (deterministic.py:26)
-    e.optimize_dev(e.d_state.p, noise, e.d_record.p, nullptr);
-    HIP_CHECK(hipMemcpyAsync(pin + ns, e.d_record.p, nr * 4, hipMemcpyDeviceToHost, e.stream));
+    static const bool zero_copy = !getenv("BBMPC_NO_ZERO_COPY");
+    if (zero_copy && e.use_fused()) {
+        // the persistent kernel reads the [A,S] state and writes the packed record straight from / to the pinned,
+        // device-mapped host buffer (a few PCIe transactions) -- no copy-engine round trips around a ~50 us kernel
+        float* dpin = nullptr;
+        HIP_CHECK(hipHostGetDevicePointer((void**)&dpin, pin, 0));
+        e.optimize_dev(dpin, noise, dpin + ns, nullptr);
+    } else {
+        HIP_CHECK(hipMemcpyAsync(e.d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e.stream));
+        e.optimize_dev(e.d_state.p, noise, e.d_record.p, nullptr);
+        HIP_CHECK(hipMemcpyAsync(pin + ns, e.d_record.p, nr * 4, hipMemcpyDeviceToHost, e.stream));
+    }
     HIP_CHECK(hipStreamSynchronize(e.stream));
     const float* r = pin + ns;
     for (int a = 0; a < e.A; ++a) {

@@ -43,17 +43,18 @@ class OptimizerBase:
             if type(self)._engine_optimizer == L.OPT_NONE:
                 raise Exception("__call__ function is not implemented yet")
             raise Exception("trajectory evaluator is not set; call set_trajectory_evaluator first")
-        from ..trajectory_evaluators.deterministic import configure_dynamics, dynamics_stale
+        eng = self._engine
         h = self._trajectory_evaluator._system_dynamics_handler
-        if dynamics_stale(self._engine, h):
-            configure_dynamics(self._engine, h)
-        return self._engine
+        # inline staleness test (a learned model that was refitted / reloaded is re-uploaded before the next step)
+        if eng.__dict__.get("_dyn_version") != (getattr(h._dynamics_function, "_version", 0), h._version):
+            from ..trajectory_evaluators.deterministic import configure_dynamics
+            configure_dynamics(eng, h)
+        return eng
 
     def __call__(self, current_state, time_step=0, add_exploration_noise=False):
         """(current_state[A,S], time_step, add_exploration_noise) ->
         (action[A,U], next_state[A,S], rewards_of_next_state[A])   optimizer_base.py:55-95"""
-        eng = self._require_engine()
-        return eng.optimize(np.asarray(current_state, np.float32), int(time_step), bool(add_exploration_noise))
+        return self._require_engine().optimize(current_state, time_step, add_exploration_noise)
 
     def reset(self):
         if type(self)._engine_optimizer == L.OPT_NONE:

@@ -49,8 +49,7 @@ class MPCPolicy(ModelBasedBasePolicy):
         batched = observations
         if observations.ndim == 1:
             batched = np.tile(observations[None], (self._optimizer._num_agents, 1))
-        action, next_observations, rewards = self._optimizer(batched.astype(np.float32), int(t),
-                                                             bool(exploration_noise))
+        action, next_observations, rewards = self._optimizer(batched, t, exploration_noise)
         self._act_call_counter += 1
         if observations.ndim == 1:
             return action[0], next_observations[0], rewards[0]
