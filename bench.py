@@ -41,11 +41,16 @@ MLP_DIMS = [26, 200, 200, 20]
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed control steps (default: per config, ~0.1-2 s of GPU time)")
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"cfg1": 2000, "cfg2": 2000, "cfg3": 2000, "cfg3full": 300, "cfg4": 400, "cfg5cem": 60, "cfg5pso": 60,
+                      "cfg5full": 10, "cfg5cma": 20}.get(args.config, 200)
+    if args.warmup is None:
+        args.warmup = max(2, args.steps // 20)
 
     import torch
     import torch.distributed as dist
