@@ -326,6 +326,26 @@ __device__ __forceinline__ void cma_instance_barrier(unsigned* ctr, unsigned tar
     __syncthreads();
 }
 
+// Cache-bypassing accessors for data that workgroups on different XCDs exchange inside one kernel: relaxed atomics at
+// system scope compile to plain loads/stores with the sc0 sc1 bits (no fence).  With them the instance barrier does not
+// need __threadfence(), whose agent-scope release/acquire walks the XCD's L2 (measured ~60 us per barrier).
+__device__ __forceinline__ float coh_load(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__device__ __forceinline__ void coh_store(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// all data exchanged through coh_load / coh_store: the barrier only has to wait for this workgroup's stores
+__device__ __forceinline__ void cma_instance_barrier_light(unsigned* ctr, unsigned target) {
+    __builtin_amdgcn_s_waitcnt(0);                       // vmcnt/lgkmcnt = 0: my stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+
 // sync: [G][32] unsigned: [0] barrier counter, [1 + sweep] "some pair rotated in this sweep"
 __global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
     const int g = blockIdx.y, WPG = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
@@ -478,6 +498,12 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
         return true;
     };
 
+#ifdef BBMPC_KERNEL_DBG
+    long long tacc[5] = {0, 0, 0, 0, 0}, tl = (long long)wall_clock64();
+#define SVDB_MARK(i) do { const long long now_ = (long long)wall_clock64(); tacc[i] += now_ - tl; tl = now_; } while (0)
+#else
+#define SVDB_MARK(i) do {} while (0)
+#endif
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         bool rotated = false;
         for (int R = 0; R < NB - 1; ++R) {
@@ -488,11 +514,25 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             const int x0 = bx * bs, y0 = by * bs;
             const int nx = max(0, min(bs, n - x0)), ny = max(0, min(bs, n - y0));
             // ---- load the two blocks (columns are rows of At: contiguous)
-            for (int i = tid; i < (nx + ny) * n; i += blockDim.x) {
-                const int c = i / n, e = i % n;
-                cols[(size_t)c * n + e] = At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e];
+            {   // eight cache-bypassing loads in flight per thread (one at a time costs a memory latency each)
+                const int total = (nx + ny) * n, nthr = blockDim.x;
+                for (int i0 = tid; i0 < total; i0 += 8 * nthr) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * nthr;
+                        const int c = i / n, e = i % n;
+                        v[u] = (i < total) ? coh_load(&At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e]) : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * nthr;
+                        if (i < total) cols[i] = v[u];          // cols index == c * n + e == i
+                    }
+                }
             }
             __syncthreads();
+            SVDB_MARK(0);
             // ---- pairs inside each block, once per sweep (block round 0 has every block in some workgroup)
             if (R == 0) {
                 for (int blk = 0; blk < 2; ++blk) {
@@ -509,6 +549,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                     }
                 }
             }
+            SVDB_MARK(1);
             // ---- pairs across the two blocks: round r pairs x-column i with y-column (i + r) % mm: disjoint
             const int mm = max(nx, ny);
             for (int r = 0; r < mm; ++r) {
@@ -518,18 +559,21 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                 }
                 __syncthreads();
             }
+            SVDB_MARK(2);
             // ---- write back
             for (int i = tid; i < (nx + ny) * n; i += blockDim.x) {
                 const int c = i / n, e = i % n;
-                At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e] = cols[(size_t)c * n + e];
+                coh_store(&At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e], cols[(size_t)c * n + e]);
             }
-            if (R == NB - 2 && rotated && lane == 0) sync[1 + sweep] = 1u;
+            if (R == NB - 2 && rotated && lane == 0) __hip_atomic_store(sync + 1 + sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            SVDB_MARK(3);
             ++bar;
-            cma_instance_barrier(sync, bar * (unsigned)WPG);
+            cma_instance_barrier_light(sync, bar * (unsigned)WPG);
+            SVDB_MARK(4);
         }
-        if (__hip_atomic_load(sync + 1 + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
+        if (__hip_atomic_load(sync + 1 + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) break;
 #ifdef BBMPC_KERNEL_DBG
-        if (g == 0 && blockIdx.x == 0 && tid == 0) printf("[svdb] sweep %d done at %lld\n", sweep, (long long)wall_clock64());
+        if (g == 0 && blockIdx.x == 0 && tid == 0) printf("[svdb] sweep %d: load %lld intra %lld cross %lld store %lld barrier %lld (10ns, cumulative)\n", sweep, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
 #endif
     }
 }
