@@ -298,14 +298,14 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             hipLaunchKernelGGL(k_cma_warm, dim3((unsigned)((n * n + 255) / 256), G), dim3(256), 0, stream, q, c_evec.p);
             const int bsz = (n + 7) / 8;
             const size_t blds = (size_t)2 * bsz * n * sizeof(float);
-            if (n >= 128 && blds <= 160 * 1024 && G * 4 <= 256 && !getenv("BBMPC_CMA_SVD_ROUNDS")) {
+            if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 160 * 1024 && G * 4 <= 256 && !getenv("BBMPC_CMA_SVD_ROUNDS")) {
                 // block Jacobi: 4 workgroups per instance, block pairs resident in LDS, 7 instance barriers per sweep
                 static bool bconf = false;
                 if (!bconf) {
                     HIP_CHECK(hipFuncSetAttribute((const void*)k_cma_svd_block, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     bconf = true;
                 }
-                hipLaunchKernelGGL(k_cma_svd_block, dim3(4, G), dim3(1024), blds, stream, q, c_evec.p, c_sync.p, 15);
+                { const char* ex = getenv("BBMPC_SVD_EXP"); hipLaunchKernelGGL(k_cma_svd_block, dim3(4, G), dim3(1024), blds, stream, q, c_evec.p, c_sync.p, 15, ex ? atoi(ex) : 0); }
             } else {
                 hipLaunchKernelGGL(k_cma_svd_rounds, dim3(1, G), dim3(1024), 0, stream, q, c_evec.p, c_sync.p, 15);
             }

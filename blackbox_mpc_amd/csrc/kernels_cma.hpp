@@ -457,7 +457,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_cma_svd_finish(CmaArgs p, con
 // of n-1, and the one-CU memory path that bounds k_cma_svd_rounds (67 GB/s, 3.2 ms per sweep at n = 300) is out of
 // the picture.  Same rotation, threshold and convergence rule as above.
 // LDS: 2*bs columns of n floats.  sync: [G][32] as above.
-__global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
+__global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps, int exp) {
     extern __shared__ __attribute__((aligned(16))) float cols[];
     constexpr int NB = 8;                                   // blocks; gridDim.x == NB / 2 workgroups per instance
     const int g = blockIdx.y, wg = blockIdx.x, WPG = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                     for (int u = 0; u < 8; ++u) {
                         const int i = i0 + u * nthr;
                         const int c = i / n, e = i % n;
-                        v[u] = (i < total) ? coh_load(&At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e]) : 0.0f;
+                        v[u] = (i < total) ? ((exp & 4) ? At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e] : coh_load(&At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e])) : 0.0f;
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             __syncthreads();
             SVDB_MARK(0);
             // ---- pairs inside each block, once per sweep (block round 0 has every block in some workgroup)
-            if (R == 0) {
+            if (R == 0 && !(exp & 2)) {
                 for (int blk = 0; blk < 2; ++blk) {
                     const int base = blk ? nx : 0, cnt = blk ? ny : nx;
                     const int m = (cnt + 1) & ~1;
@@ -550,12 +550,74 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                 }
             }
             SVDB_MARK(1);
-            // ---- pairs across the two blocks: round r pairs x-column i with y-column (i + r) % mm: disjoint
+            // ---- pairs across the two blocks: round r pairs x-column i with y-column (i + r) % mm: disjoint.
+            // One 16-lane DPP row per pair (four pairs per wave instruction stream, reductions = 4 DPP steps); a row
+            // keeps its x-column in registers for all mm rounds, only the y-columns travel through LDS, as 16-byte
+            // accesses (n % 4 == 0).  Waves whose rows hold no x-column only take part in the barriers, and the
+            // rotation scalars use the hardware rcp / rsq (+ one Newton step where orthogonality depends on it):
+            // the round is instruction-issue bound, IEEE divide / sqrt expansions were half of it.
             const int mm = max(nx, ny);
-            for (int r = 0; r < mm; ++r) {
-                for (int i = wv; i < mm; i += NW) {
-                    const int j = (i + r) % mm;
-                    if (i < nx && j < ny) rotated |= rotate(i, nx + j);
+            {
+                constexpr int EC = 8;                                // float4 chunks per lane: n <= 512
+                const int sub = lane & 15, row = wv * 4 + (lane >> 4), nc = (n + 63) >> 6;
+                const bool has_x = row < nx, wave_on = wv * 4 < nx;
+                float4 xr[EC];
+#pragma unroll
+                for (int c = 0; c < EC; ++c) {
+                    const int e = 4 * (sub + 16 * c);
+                    xr[c] = (c < nc && has_x && e < n) ? *reinterpret_cast<const float4*>(cols + (size_t)row * n + e)
+                                                       : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                for (int r = 0; r < ((exp & 1) ? 0 : mm); ++r) {
+                    if (wave_on) {
+                        const int j = (row + r) % mm;
+                        const bool act = has_x && j < ny;
+                        float* y = cols + (size_t)(nx + (act ? j : 0)) * n;
+                        float4 yv[EC];
+                        float al = 0.0f, be = 0.0f, ga = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < EC; ++c) {
+                            if (c < nc) {
+                                const int e = 4 * (sub + 16 * c);
+                                yv[c] = (act && e < n) ? *reinterpret_cast<const float4*>(y + e) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                                al = fmaf(xr[c].x, xr[c].x, al); al = fmaf(xr[c].y, xr[c].y, al); al = fmaf(xr[c].z, xr[c].z, al); al = fmaf(xr[c].w, xr[c].w, al);
+                                be = fmaf(yv[c].x, yv[c].x, be); be = fmaf(yv[c].y, yv[c].y, be); be = fmaf(yv[c].z, yv[c].z, be); be = fmaf(yv[c].w, yv[c].w, be);
+                                ga = fmaf(xr[c].x, yv[c].x, ga); ga = fmaf(xr[c].y, yv[c].y, ga); ga = fmaf(xr[c].z, yv[c].z, ga); ga = fmaf(xr[c].w, yv[c].w, ga);
+                            }
+                        }
+                        al = row16_sum(al); be = row16_sum(be); ga = row16_sum(ga);
+                        // |ga| <= tol * sqrt(al*be)  <=>  ga^2 <= tol^2 * al * be  (no sqrt)
+                        const bool rot = act && ga != 0.0f && (ga * ga > (tol * tol) * (al * be));
+                        if (rot) {
+                            const float zeta = (be - al) * __builtin_amdgcn_rcpf(2.0f * ga);
+                            const float az = fabsf(zeta);
+                            const float t = copysignf(__builtin_amdgcn_rcpf(az + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.0f))), zeta);
+                            const float w = fmaf(t, t, 1.0f);
+                            float cs = __builtin_amdgcn_rsqf(w);
+                            cs = cs * fmaf(-0.5f * w * cs, cs, 1.5f);           // Newton step: cs^2 * (1 + t^2) = 1 to fp32
+                            const float sn = cs * t;
+#pragma unroll
+                            for (int c = 0; c < EC; ++c) {
+                                if (c < nc) {
+                                    const int e = 4 * (sub + 16 * c);
+                                    float4 xn, yn;
+                                    xn.x = cs * xr[c].x - sn * yv[c].x; yn.x = sn * xr[c].x + cs * yv[c].x;
+                                    xn.y = cs * xr[c].y - sn * yv[c].y; yn.y = sn * xr[c].y + cs * yv[c].y;
+                                    xn.z = cs * xr[c].z - sn * yv[c].z; yn.z = sn * xr[c].z + cs * yv[c].z;
+                                    xn.w = cs * xr[c].w - sn * yv[c].w; yn.w = sn * xr[c].w + cs * yv[c].w;
+                                    xr[c] = xn;
+                                    if (e < n) *reinterpret_cast<float4*>(y + e) = yn;
+                                }
+                            }
+                            rotated = true;
+                        }
+                    }
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int c = 0; c < EC; ++c) {
+                    const int e = 4 * (sub + 16 * c);
+                    if (c < nc && has_x && e < n) *reinterpret_cast<float4*>(cols + (size_t)row * n + e) = xr[c];
                 }
                 __syncthreads();
             }
@@ -568,7 +630,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             if (R == NB - 2 && rotated && lane == 0) __hip_atomic_store(sync + 1 + sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             SVDB_MARK(3);
             ++bar;
-            cma_instance_barrier_light(sync, bar * (unsigned)WPG);
+            if (!(exp & 8)) cma_instance_barrier_light(sync, bar * (unsigned)WPG);
             SVDB_MARK(4);
         }
         if (__hip_atomic_load(sync + 1 + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) break;
