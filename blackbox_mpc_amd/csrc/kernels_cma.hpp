@@ -514,6 +514,16 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             const int x0 = bx * bs, y0 = by * bs;
             const int nx = max(0, min(bs, n - x0)), ny = max(0, min(bs, n - y0));
             // ---- load the two blocks (columns are rows of At: contiguous)
+            if (exp & 4) {
+                // experiment: ordinary 16-byte loads after an explicit agent-scope cache invalidate
+                asm volatile("buffer_inv sc1" ::: "memory");
+                const int total4 = ((nx + ny) * n) >> 2;
+                for (int i = tid; i < total4; i += blockDim.x) {
+                    const int c = (4 * i) / n, e = (4 * i) % n;
+                    *reinterpret_cast<float4*>(cols + 4 * (size_t)i) =
+                        *reinterpret_cast<const float4*>(At + (size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e);
+                }
+            } else
             {   // eight cache-bypassing loads in flight per thread (one at a time costs a memory latency each)
                 const int total = (nx + ny) * n, nthr = blockDim.x;
                 for (int i0 = tid; i0 < total; i0 += 8 * nthr) {
