@@ -305,7 +305,7 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                     HIP_CHECK(hipFuncSetAttribute((const void*)k_cma_svd_block, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     bconf = true;
                 }
-                { const char* ex = getenv("BBMPC_SVD_EXP"); hipLaunchKernelGGL(k_cma_svd_block, dim3(4, G), dim3(1024), blds, stream, q, c_evec.p, c_sync.p, 15, ex ? atoi(ex) : 0); }
+                hipLaunchKernelGGL(k_cma_svd_block, dim3(4, G), dim3(1024), blds, stream, q, c_evec.p, c_sync.p, 15);
             } else {
                 hipLaunchKernelGGL(k_cma_svd_rounds, dim3(1, G), dim3(1024), 0, stream, q, c_evec.p, c_sync.p, 15);
             }

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_cma_svd_finish(CmaArgs p, con
 // of n-1, and the one-CU memory path that bounds k_cma_svd_rounds (67 GB/s, 3.2 ms per sweep at n = 300) is out of
 // the picture.  Same rotation, threshold and convergence rule as above.
 // LDS: 2*bs columns of n floats.  sync: [G][32] as above.
-__global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps, int exp) {
+__global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
     extern __shared__ __attribute__((aligned(16))) float cols[];
     constexpr int NB = 8;                                   // blocks; gridDim.x == NB / 2 workgroups per instance
     const int g = blockIdx.y, wg = blockIdx.x, WPG = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
@@ -514,16 +514,6 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             const int x0 = bx * bs, y0 = by * bs;
             const int nx = max(0, min(bs, n - x0)), ny = max(0, min(bs, n - y0));
             // ---- load the two blocks (columns are rows of At: contiguous)
-            if (exp & 4) {
-                // experiment: ordinary 16-byte loads after an explicit agent-scope cache invalidate
-                asm volatile("buffer_inv sc1" ::: "memory");
-                const int total4 = ((nx + ny) * n) >> 2;
-                for (int i = tid; i < total4; i += blockDim.x) {
-                    const int c = (4 * i) / n, e = (4 * i) % n;
-                    *reinterpret_cast<float4*>(cols + 4 * (size_t)i) =
-                        *reinterpret_cast<const float4*>(At + (size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e);
-                }
-            } else
             {   // eight cache-bypassing loads in flight per thread (one at a time costs a memory latency each)
                 const int total = (nx + ny) * n, nthr = blockDim.x;
                 for (int i0 = tid; i0 < total; i0 += 8 * nthr) {
@@ -532,7 +522,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                     for (int u = 0; u < 8; ++u) {
                         const int i = i0 + u * nthr;
                         const int c = i / n, e = i % n;
-                        v[u] = (i < total) ? ((exp & 4) ? At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e] : coh_load(&At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e])) : 0.0f;
+                        v[u] = (i < total) ? coh_load(&At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e]) : 0.0f;
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -544,7 +534,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             __syncthreads();
             SVDB_MARK(0);
             // ---- pairs inside each block, once per sweep (block round 0 has every block in some workgroup)
-            if (R == 0 && !(exp & 2)) {
+            if (R == 0) {
                 for (int blk = 0; blk < 2; ++blk) {
                     const int base = blk ? nx : 0, cnt = blk ? ny : nx;
                     const int m = (cnt + 1) & ~1;
@@ -578,7 +568,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                     xr[c] = (c < nc && has_x && e < n) ? *reinterpret_cast<const float4*>(cols + (size_t)row * n + e)
                                                        : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
-                for (int r = 0; r < ((exp & 1) ? 0 : mm); ++r) {
+                for (int r = 0; r < mm; ++r) {
                     if (wave_on) {
                         const int j = (row + r) % mm;
                         const bool act = has_x && j < ny;
@@ -640,7 +630,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             if (R == NB - 2 && rotated && lane == 0) __hip_atomic_store(sync + 1 + sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             SVDB_MARK(3);
             ++bar;
-            if (!(exp & 8)) cma_instance_barrier_light(sync, bar * (unsigned)WPG);
+            cma_instance_barrier_light(sync, bar * (unsigned)WPG);
             SVDB_MARK(4);
         }
         if (__hip_atomic_load(sync + 1 + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) break;
