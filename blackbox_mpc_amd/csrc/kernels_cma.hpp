@@ -514,20 +514,26 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             const int x0 = bx * bs, y0 = by * bs;
             const int nx = max(0, min(bs, n - x0)), ny = max(0, min(bs, n - y0));
             // ---- load the two blocks (columns are rows of At: contiguous)
-            {   // eight cache-bypassing loads in flight per thread (one at a time costs a memory latency each)
-                const int total = (nx + ny) * n, nthr = blockDim.x;
-                for (int i0 = tid; i0 < total; i0 += 8 * nthr) {
-                    float v[8];
+            // whole columns per wave (no index divisions), all of a wave's loads issued before the first LDS write
+            for (int c0 = wv; c0 < nx + ny; c0 += 4 * NW) {
+                float v[4][8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int i = i0 + u * nthr;
-                        const int c = i / n, e = i % n;
-                        v[u] = (i < total) ? coh_load(&At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e]) : 0.0f;
+                for (int q = 0; q < 4; ++q) {
+                    const int c = c0 + q * NW;
+                    const float* src = At + (size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int e = lane + 64 * k;
+                        v[q][k] = (c < nx + ny && e < n) ? coh_load(src + e) : 0.0f;
                     }
+                }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int i = i0 + u * nthr;
-                        if (i < total) cols[i] = v[u];          // cols index == c * n + e == i
+                for (int q = 0; q < 4; ++q) {
+                    const int c = c0 + q * NW;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int e = lane + 64 * k;
+                        if (c < nx + ny && e < n) cols[(size_t)c * n + e] = v[q][k];
                     }
                 }
             }
@@ -623,9 +629,9 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             }
             SVDB_MARK(2);
             // ---- write back
-            for (int i = tid; i < (nx + ny) * n; i += blockDim.x) {
-                const int c = i / n, e = i % n;
-                coh_store(&At[(size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n + e], cols[(size_t)c * n + e]);
+            for (int c = wv; c < nx + ny; c += NW) {
+                float* dst = At + (size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n;
+                for (int e = lane; e < n; e += 64) coh_store(dst + e, cols[(size_t)c * n + e]);
             }
             if (R == NB - 2 && rotated && lane == 0) __hip_atomic_store(sync + 1 + sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             SVDB_MARK(3);
