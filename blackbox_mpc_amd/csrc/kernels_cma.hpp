@@ -327,21 +327,21 @@ __device__ __forceinline__ void cma_instance_barrier(unsigned* ctr, unsigned tar
 }
 
 // Cache-bypassing accessors for data that workgroups on different XCDs exchange inside one kernel: relaxed atomics at
-// system scope compile to plain loads/stores with the sc0 sc1 bits (no fence).  With them the instance barrier does not
+// agent scope compile to plain loads/stores with the sc1 bit (no fence).  With them the instance barrier does not
 // need __threadfence(), whose agent-scope release/acquire walks the XCD's L2 (measured ~60 us per barrier).
 __device__ __forceinline__ float coh_load(const float* p) {
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 __device__ __forceinline__ void coh_store(float* p, float v) {
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // all data exchanged through coh_load / coh_store: the barrier only has to wait for this workgroup's stores
 __device__ __forceinline__ void cma_instance_barrier_light(unsigned* ctr, unsigned target) {
     __builtin_amdgcn_s_waitcnt(0);                       // vmcnt/lgkmcnt = 0: my stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) __builtin_amdgcn_s_sleep(1);
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
     }
     __syncthreads();
 }
@@ -633,13 +633,13 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                 float* dst = At + (size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n;
                 for (int e = lane; e < n; e += 64) coh_store(dst + e, cols[(size_t)c * n + e]);
             }
-            if (R == NB - 2 && rotated && lane == 0) __hip_atomic_store(sync + 1 + sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (R == NB - 2 && rotated && lane == 0) __hip_atomic_store(sync + 1 + sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             SVDB_MARK(3);
             ++bar;
             cma_instance_barrier_light(sync, bar * (unsigned)WPG);
             SVDB_MARK(4);
         }
-        if (__hip_atomic_load(sync + 1 + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) break;
+        if (__hip_atomic_load(sync + 1 + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
 #ifdef BBMPC_KERNEL_DBG
         if (g == 0 && blockIdx.x == 0 && tid == 0) printf("[svdb] sweep %d: load %lld intra %lld cross %lld store %lld barrier %lld (10ns, cumulative)\n", sweep, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
 #endif
