@@ -29,6 +29,11 @@ CONFIGS = {
     "cfg4": dict(env="cheetah", opt="CEM", N=1000, A=1, H=30, iters=5, k=50),
     "cfg5cem": dict(env="cheetah", opt="CEM", N=2000, A=4, H=50, iters=5, k=50),     # config-5 shape per GPU, CEM
     "cfg5full": dict(env="cheetah", opt="CEM", N=2000, A=32, H=50, iters=5, k=50),   # all 32 agents on one GPU
+    # the other three optimizers at config 2's size (Pendulum, N=500, H=30, 5 iterations)
+    "cfg2pso": dict(env="pendulum", opt="PSO", N=500, A=1, H=30, iters=5, k=0),
+    "cfg2spsa": dict(env="pendulum", opt="SPSA", N=500, A=1, H=30, iters=5, k=0),
+    "cfg2cma": dict(env="pendulum", opt="CMA-ES", N=500, A=1, H=30, iters=5, k=50),
+    "cfg2pi2": dict(env="pendulum", opt="PI2", N=500, A=1, H=30, iters=5, k=0),
     # BASELINE config 5 proper (its two optimizers), one GPU's share of the 32 agents
     "cfg5pso": dict(env="cheetah", opt="PSO", N=2000, A=4, H=50, iters=5, k=0),
     "cfg5cma": dict(env="cheetah", opt="CMA-ES", N=2000, A=4, H=50, iters=5, k=50),  # per-agent CMA-ES (n = 300 each)
@@ -84,7 +89,7 @@ def main():
 
     c = CONFIGS[args.config]
     opt = {"RandomSearch": L.OPT_RANDOM_SEARCH, "CEM": L.OPT_CEM, "PI2": L.OPT_PI2, "PSO": L.OPT_PSO,
-           "CMA-ES": L.OPT_CMAES}[c["opt"]]
+           "CMA-ES": L.OPT_CMAES, "SPSA": L.OPT_SPSA}[c["opt"]]
     quirks = L.CMAES_PER_AGENT if c["opt"] == "CMA-ES" else 0     # the shardable CMA-ES mode
     N, A, H, iters, k = c["N"], c["A"], c["H"], c["iters"], c["k"]
     mlp = c["env"] == "cheetah"
@@ -100,7 +105,7 @@ def main():
         U, S = 1, 3
         eng = Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=S, num_agents=A, planning_horizon=H,
                      population_size=N, max_iterations=iters, num_elite=k, seed=0, agent_offset=rank * A,
-                     num_agents_global=world * A, device=local)
+                     num_agents_global=world * A, device=local, quirks=quirks)
         start = O.pendulum_start_states(A, agent_offset=rank * A)
     eng.reset()                      # episode start, as utils/rollouts.py:_sample does (PSO draws its swarm here)
     rec = U + S + 1

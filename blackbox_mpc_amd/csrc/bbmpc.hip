@@ -307,7 +307,17 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                 }
                 hipLaunchKernelGGL(k_cma_svd_block, dim3(4, G), dim3(1024), blds, stream, q, c_evec.p, c_sync.p, 15);
             } else {
-                hipLaunchKernelGGL(k_cma_svd_rounds, dim3(1, G), dim3(1024), 0, stream, q, c_evec.p, c_sync.p, 15);
+                if (n <= 64 && !getenv("BBMPC_CMA_SVD_GENERAL")) {
+                    const int pairs = (n + 1) / 2;
+                    hipLaunchKernelGGL(k_cma_svd_small, dim3(G), dim3(64 * ((pairs + 3) / 4)), (size_t)n * n * sizeof(float), stream,
+                                       q, c_evec.p, c_sync.p, 15);
+                } else {
+                // small n: the matrix fits LDS; a workgroup sized to the number of pairs
+                const size_t rl = (size_t)n * n * sizeof(float) <= 64 * 1024 ? (size_t)n * n * sizeof(float) : 0;
+                const int rthreads = std::min(1024, std::max(64, 64 * ((n + 1) / 2)));
+                hipLaunchKernelGGL(k_cma_svd_rounds, dim3(1, G), dim3(rthreads), rl, stream, q, c_evec.p, c_sync.p, 15,
+                                   (int)(rl / sizeof(float)));
+                }
             }
             hipLaunchKernelGGL(k_cma_svd_finish, dim3(G), dim3(REFIT_THREADS), 0, stream, q, c_evec.p, c_eval.p, c_info.p);
         } else {

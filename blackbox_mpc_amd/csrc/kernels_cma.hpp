@@ -347,12 +347,21 @@ __device__ __forceinline__ void cma_instance_barrier_light(unsigned* ctr, unsign
 }
 
 // sync: [G][32] unsigned: [0] barrier counter, [1 + sweep] "some pair rotated in this sweep"
-__global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
+__global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps, int lds_floats) {
     const int g = blockIdx.y, WPG = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
     const int NW = blockDim.x >> 6;
     // rotation threshold on the cosine between two columns: the fp32 dot-product noise floor grows with n
     const float tol = fminf(fmaxf(3.0e-8f * (float)n, 2.0e-6f), 1.0e-5f);
-    float* At = At_all + (size_t)g * n * n;
+    float* At_g = At_all + (size_t)g * n * n;
+    // small instances (n*n floats fit the dynamic LDS the launch provides, WPG == 1): the whole matrix lives in LDS
+    // for the sweeps -- a round then costs LDS latency instead of L2 latency (n = 30: 437 -> ~100 us per iteration)
+    extern __shared__ __attribute__((aligned(16))) float at_lds[];
+    const bool in_lds = lds_floats >= n * n && WPG == 1;
+    float* At = in_lds ? at_lds : At_g;
+    if (in_lds) {
+        for (int i = tid; i < n * n; i += blockDim.x) at_lds[i] = At_g[i];
+        __syncthreads();
+    }
     unsigned* sync = sync_all + (size_t)g * 32;
     const int gw = blockIdx.x * NW + wv, nwaves = WPG * NW;
     const int m = (n + 1) & ~1;                 // players of the round-robin (one dummy when n is odd)
@@ -417,6 +426,10 @@ __global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_al
 #ifdef BBMPC_KERNEL_DBG
         if (g == 0 && blockIdx.x == 0 && tid == 0) printf("[svd] sweep %d done at %lld rotations %u\n", sweep, (long long)wall_clock64(), sync[1 + sweep]);
 #endif
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int i = tid; i < n * n; i += blockDim.x) At_g[i] = at_lds[i];
     }
 }
 
@@ -644,6 +657,69 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
         if (g == 0 && blockIdx.x == 0 && tid == 0) printf("[svdb] sweep %d: load %lld intra %lld cross %lld store %lld barrier %lld (10ns, cumulative)\n", sweep, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
 #endif
     }
+}
+
+// ---- Small instances (n <= 64, e.g. the pendulum's n = H*U = 30): the whole matrix in LDS, one 16-lane DPP row per
+// column pair (four elements per lane), rcp / rsq rotation scalars as in the block kernel.  A round is ~40
+// instructions per wave + one barrier; the general kernels above spend ~1 us per round on predicated 512-wide code.
+// LDS: n*n floats.  blockDim = 64 * ceil(pairs / 4).  sync: [G][32] as above (sweep flags only).
+__global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
+    extern __shared__ __attribute__((aligned(16))) float at_s[];
+    __shared__ int s_rot;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
+    float* At_g = At_all + (size_t)g * n * n;
+    const float tol = 2.0e-6f;
+    for (int i = tid; i < n * n; i += blockDim.x) at_s[i] = At_g[i];
+    const int m = (n + 1) & ~1;
+    const int sub = lane & 15, slot = wv * 4 + (lane >> 4);     // pair slot of this 16-lane row
+    __syncthreads();
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (tid == 0) s_rot = 0;
+        __syncthreads();
+        for (int r = 0; r < m - 1; ++r) {
+            int pa = 0, pb = 0;
+            bool act = slot < m / 2;
+            if (act) {
+                if (slot == 0) { pa = m - 1; pb = r; }
+                else { pa = (r + slot) % (m - 1); pb = (r - slot + (m - 1)) % (m - 1); }
+                act = pa < n && pb < n;
+            }
+            float* x = at_s + (size_t)(act ? pa : 0) * n;
+            float* y = at_s + (size_t)(act ? pb : 0) * n;
+            float xv[4], yv[4], al = 0.0f, be = 0.0f, ga = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int e = sub + 16 * c;
+                xv[c] = (act && e < n) ? x[e] : 0.0f;
+                yv[c] = (act && e < n) ? y[e] : 0.0f;
+                al = fmaf(xv[c], xv[c], al); be = fmaf(yv[c], yv[c], be); ga = fmaf(xv[c], yv[c], ga);
+            }
+            al = row16_sum(al); be = row16_sum(be); ga = row16_sum(ga);
+            if (act && ga != 0.0f && ga * ga > (tol * tol) * (al * be)) {
+                const float zeta = (be - al) * __builtin_amdgcn_rcpf(2.0f * ga);
+                const float t = copysignf(__builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.0f))), zeta);
+                const float w = fmaf(t, t, 1.0f);
+                float cs = __builtin_amdgcn_rsqf(w);
+                cs = cs * fmaf(-0.5f * w * cs, cs, 1.5f);
+                const float sn = cs * t;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int e = sub + 16 * c;
+                    if (e < n) {
+                        x[e] = cs * xv[c] - sn * yv[c];
+                        y[e] = sn * xv[c] + cs * yv[c];
+                    }
+                }
+                if (sub == 0) s_rot = 1;
+            }
+            __syncthreads();
+        }
+        if (!s_rot) break;
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int i = tid; i < n * n; i += blockDim.x) At_g[i] = at_s[i];
+    (void)sync_all;
 }
 
 }  // namespace bbmpc
