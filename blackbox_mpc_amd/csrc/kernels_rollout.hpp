@@ -118,6 +118,30 @@ __global__ void k_rollout_pendulum(RolloutArgs p) {
         }
         const float lo0 = p.lo[0], hi0 = p.hi[0];
         if (active) {
+            if constexpr (MODE == SRC_BUF && U == 1) {
+                // candidates come from a buffer (PSO / SPSA / CMA-ES; may alias p.samples, which is written below):
+                // eight loads in flight per lane instead of one L2 latency per step inside the recurrence
+                for (int t0 = 0; t0 < p.H; t0 += 8) {
+                    float xb[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        xb[i] = (t0 + i < p.H) ? p.cand[((size_t)a * p.HU + t0 + i) * p.Nst + n] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (t0 + i < p.H) {
+                            float x = xb[i];
+                            if constexpr (PEN) {
+                                const float xf = clipf(x, lo0, hi0);
+                                const float d = x - xf;
+                                pen = pen + d * d;
+                                x = xf;
+                            }
+                            if (p.samples) p.samples[(size_t)(a * p.HU + t0 + i) * p.Nst + n] = x;
+                            total = total + roll.step(x);
+                        }
+                    }
+                }
+            } else
             for (int t = 0; t < p.H; ++t) {
                 float act[U];
 #pragma unroll
