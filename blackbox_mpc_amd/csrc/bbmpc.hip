@@ -675,7 +675,11 @@ void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_ou
 
 bool Engine::use_fused() const {
     if (cfg.dynamics != BBMPC_DYN_PENDULUM) return false;
-    if (cfg.optimizer != BBMPC_OPT_RANDOM_SEARCH && cfg.optimizer != BBMPC_OPT_CEM && cfg.optimizer != BBMPC_OPT_PI2) return false;
+    if (cfg.optimizer == BBMPC_OPT_SPSA) {
+        if (iters > FUSED_MAX_SPSA_ITERS) return false;
+    } else if (cfg.optimizer != BBMPC_OPT_RANDOM_SEARCH && cfg.optimizer != BBMPC_OPT_CEM && cfg.optimizer != BBMPC_OPT_PI2) {
+        return false;
+    }
     if (fused_mode == 0) return false;
     if (fused_mode == 1) return true;
     // auto: one workgroup per agent keeps a whole control step in one launch.  When a handful of agents
@@ -768,13 +772,26 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     fa.prev_mean = d_prev_mean.p; fa.var0 = d_var0.p;
     fa.mean_out = d_mean.p; fa.var_out = d_var.p;
     fa.samples_g = d_samples.p;
-    fa.inj = injected(cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH ? BBMPC_NOISE_UNIFORM : BBMPC_NOISE_TRUNC_NORMAL);
+    fa.inj = injected(cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH ? BBMPC_NOISE_UNIFORM
+                      : cfg.optimizer == BBMPC_OPT_SPSA ? BBMPC_NOISE_RADEMACHER : BBMPC_NOISE_TRUNC_NORMAL);
     fa.inj_expl = injected(BBMPC_NOISE_EXPLORATION);
+    if (cfg.optimizer == BBMPC_OPT_SPSA) {                                   // gain sequences spsa.py:56,69-70
+        const float big_a = (float)iters / 10.0f;
+        for (int it = 0; it < iters && it < FUSED_MAX_SPSA_ITERS; ++it) {
+            const float tf = (float)it;
+            fa.spsa_ak[it] = cfg.spsa_a / (float)pow((double)((tf + 1.0f) + big_a), (double)cfg.spsa_alpha);
+            fa.spsa_ck[it] = cfg.spsa_c / (float)pow((double)(tf + 1.0f), (double)cfg.spsa_gamma);
+        }
+    }
     fa.record = d_record_out;
     fa.next_state = d_next_out;
     if (trace_on) {
         ensure_trace();
         fa.t_rewards = t_rewards.p; fa.t_mean = t_mean.p; fa.t_var = t_var.p; fa.t_elites = t_elites.p; fa.t_samples = t_samples.p;
+        if (cfg.optimizer == BBMPC_OPT_SPSA) {
+            if (!t_rewards2.p) t_rewards2.alloc((size_t)A * Nst * std::max(iters, 1));
+            fa.t_rewards2 = t_rewards2.p;
+        }
     }
 #ifdef BBMPC_KERNEL_DBG
     static long long* dbg_buf = nullptr;
@@ -792,7 +809,7 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
         pf_step_floats = (size_t)pf_nit * A * Nst * ((HU + 3) / 4) * 4;
         const size_t budget = (size_t)128 << 20;     // bytes per chunk buffer
         pf_steps = pf_step_floats ? (int)std::min<size_t>(8, budget / (pf_step_floats * 4)) : 0;
-        pf_mode = ((ev ? atoi(ev) != 0 : true) && pf_steps >= 1 && U == 1) ? 1 : 0;
+        pf_mode = ((ev ? atoi(ev) != 0 : true) && pf_steps >= 1 && U == 1 && cfg.optimizer != BBMPC_OPT_SPSA) ? 1 : 0;
         if (pf_mode) {
             HIP_CHECK(hipStreamCreateWithFlags(&pf_stream, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&pf_free, hipEventDisableTiming));
@@ -802,7 +819,7 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
             }
         }
     }
-    const bool use_pf = pf_mode == 1 && fa.inj == nullptr && pf_nit > 0;
+    const bool use_pf = pf_mode == 1 && fa.inj == nullptr && pf_nit > 0 && cfg.optimizer != BBMPC_OPT_SPSA;
     if (use_pf) {
         const int64_t c = (int64_t)step / pf_steps;
         const int pb = (int)(c & 1), nb = pb ^ 1;
@@ -838,6 +855,17 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     switch (cfg.optimizer) {
         case BBMPC_OPT_RANDOM_SEARCH: launch_fused<FOPT_RS>(*this, fa, ilp, threads, lds_base, lds_samples, use_pf ? 2 : 1); break;
         case BBMPC_OPT_CEM: launch_fused<FOPT_CEM>(*this, fa, ilp, threads, lds_base, lds_samples, use_pf ? 2 : 1); break;
+        case BBMPC_OPT_SPSA: {
+            const bool fastm = !fix(BBMPC_STRICT_MATH);
+            if (fa.inj) {
+                if (fastm) launch_fused4<FOPT_SPSA, true, 1, 1>(*this, fa, threads, lds_base, lds_samples);
+                else launch_fused4<FOPT_SPSA, false, 1, 1>(*this, fa, threads, lds_base, lds_samples);
+            } else {
+                if (fastm) launch_fused4<FOPT_SPSA, true, 0, 1>(*this, fa, threads, lds_base, lds_samples);
+                else launch_fused4<FOPT_SPSA, false, 0, 1>(*this, fa, threads, lds_base, lds_samples);
+            }
+            break;
+        }
         default: launch_fused<FOPT_PI2>(*this, fa, ilp, threads, lds_base, lds_samples, use_pf ? 2 : 1); break;
     }
     prof_end();

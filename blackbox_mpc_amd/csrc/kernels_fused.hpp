@@ -21,6 +21,8 @@ namespace bbmpc {
 constexpr int FOPT_RS = 1;
 constexpr int FOPT_CEM = 2;
 constexpr int FOPT_PI2 = 3;
+constexpr int FOPT_SPSA = 4;
+constexpr int FUSED_MAX_SPSA_ITERS = 16;
 
 struct FusedArgs {
     int N, A, H, U, HU, Nst, k, iters;
@@ -43,6 +45,8 @@ struct FusedArgs {
     float* record;           // [A][U+S+1]
     float* next_state;       // optional contiguous [A,S]
     // traces (null when disabled): [iters][A][Nst], [iters][A][HU], [iters][A][HU], [iters][A][k], [iters][A][HU][Nst]
+    float spsa_ak[FUSED_MAX_SPSA_ITERS], spsa_ck[FUSED_MAX_SPSA_ITERS];   // SPSA gain sequences (spsa.py:69-70), per iteration
+    float* t_rewards2;       // SPSA trace: rewards of the minus candidates [iters][A][Nst]
     float* t_rewards;
     float* t_mean;
     float* t_var;
@@ -111,7 +115,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         const float v = p.var0[a * p.HU + j];
         mean[j] = m;
         var[j] = v;
-        sigma[j] = (OPT == FOPT_CEM) ? cem_sigma(m, v, lo, hi) : sqrtf(v);
+        sigma[j] = (OPT == FOPT_CEM) ? cem_sigma(m, v, lo, hi) : ((OPT == FOPT_SPSA) ? 0.0f : sqrtf(v));
     }
     __syncthreads();
 
@@ -132,7 +136,54 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         const uint32_t rstream = (OPT == FOPT_RS) ? 2u : 1u;
         // ILP independent trajectories per lane: with half as many waves each SIMD runs a single wave whose two
         // recurrences interleave in program order, instead of two waves fighting over issue slots.
-        if constexpr (INJ == 2) {
+        if constexpr (OPT == FOPT_SPSA) {
+            // SPSA (spsa.py:61-107): theta +- c_k * delta with delta in {-1,+1}; both candidates of a particle are
+            // rolled out by the same lane (two independent recurrences: four chains per SIMD at N = 500).  The
+            // Rademacher draws stay in LDS (samp) for the gradient estimate.
+            const float ck = p.spsa_ck[it];
+            const int nb4 = (p.H + 3) >> 2;
+            for (int n = tid; n < p.N; n += nthr) {
+                Roller<FASTM> rp, rm;
+                rp.init(p.fix_q1 != 0, s0, s1, s2);
+                rm.init(p.fix_q1 != 0, s0, s1, s2);
+                float tp = 0.0f, tm = 0.0f, pp = 0.0f, pm = 0.0f;
+                for (int b = 0; b < nb4; ++b) {
+                    float d[4];
+                    if (INJ == 1) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) d[i] = (4 * b + i < p.H) ? inj[(size_t)(4 * b + i) * p.Nst + n] : 1.0f;
+                    } else {
+                        const U4 w = rng_block(p.key, 3u, (uint32_t)it, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)(4 * b));
+                        d[0] = word_to_rademacher(w.x); d[1] = word_to_rademacher(w.y);
+                        d[2] = word_to_rademacher(w.z); d[3] = word_to_rademacher(w.w);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int t = 4 * b + i;
+                        if (t < p.H) {
+                            const float th = mean[t], stp = ck * d[i];
+                            const float xp = th + stp, xm = th - stp;                      // spsa.py:76-77
+                            const float xpf = clipf(xp, lo, hi), xmf = clipf(xm, lo, hi);  // :78-81
+                            const float dp = xp - xpf, dm = xm - xmf;
+                            pp = pp + dp * dp;
+                            pm = pm + dm * dm;
+                            samp[(size_t)t * p.Nst + n] = d[i];
+                            tp = tp + rp.step(xpf);
+                            tm = tm + rm.step(xmf);
+                        }
+                    }
+                }
+                if (tp != tp) tp = -1.0e6f;                                                // deterministic.py:75-77
+                if (tm != tm) tm = -1.0e6f;
+                const float np_ = sqrtf(pp), nm_ = sqrtf(pm);                              // tf.norm(...)**2  spsa.py:82-89
+                const float r_p = tp - np_ * np_, r_m = tm - nm_ * nm_;                    // :98-99
+                if (p.t_rewards) {
+                    p.t_rewards[((size_t)it * p.A + a) * p.Nst + n] = r_p;
+                    p.t_rewards2[((size_t)it * p.A + a) * p.Nst + n] = r_m;
+                }
+                rew[n] = r_p - r_m;
+            }
+        } else if constexpr (INJ == 2) {
             // Draws prefetched by idle CUs (k_noise_fill): one float4 = one Philox block = 4 steps of this trajectory.
             // Loads run TWO blocks (8 steps, ~2 us) ahead of their use so that L2/HBM latency never reaches the
             // recurrence; the Philox rounds (a quarter of this kernel's VALU work) are gone from the critical path.
@@ -278,7 +329,8 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         __syncthreads();
         BB_DBG(3 + it * 4);
         if (p.t_rewards) {
-            for (int n = tid; n < p.N; n += nthr) p.t_rewards[((size_t)it * p.A + a) * p.Nst + n] = rew[n];
+            if (OPT != FOPT_SPSA)
+                for (int n = tid; n < p.N; n += nthr) p.t_rewards[((size_t)it * p.A + a) * p.Nst + n] = rew[n];
             for (int i = tid; i < p.HU * p.Nst; i += nthr) {
                 const int j = i / p.Nst, n = i % p.Nst;
                 if (n < p.N) p.t_samples[(((size_t)it * p.A + a) * p.HU + j) * p.Nst + n] = samp[(size_t)j * p.Nst + n];
@@ -384,6 +436,18 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             }
             __syncthreads();
             action0 = mean[0];                                                   // pi2.py:94
+        } else if (OPT == FOPT_SPSA) {
+            // ghat[j] = mean_n (r+ - r-)[n] / (2 c_k delta[j][n]);  theta = clip(theta + a_k ghat)   (spsa.py:101-107)
+            const float two_ck = 2.0f * p.spsa_ck[it], ak = p.spsa_ak[it];
+            for (int j = tid >> 6; j < p.HU; j += nw) {
+                const float* row = samp + (size_t)j * p.Nst;
+                float acc = 0.0f;
+                for (int n = tid & 63; n < p.N; n += 64) acc += rew[n] / (two_ck * row[n]);
+                acc = wave_sum(acc);
+                if ((tid & 63) == 0) mean[j] = clipf(mean[j] + ak * (acc / (float)p.N), lo, hi);
+            }
+            __syncthreads();
+            action0 = mean[0];                                                   // spsa.py:117
         } else {  // RandomSearch: argmax, first maximum (random_search.py:43-47)
             float bv = -INFINITY;
             int bi = 0x7fffffff;
@@ -422,7 +486,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         for (int j = tid; j < p.HU; j += nthr) {
             p.mean_out[a * p.HU + j] = mean[j];
             p.var_out[a * p.HU + j] = var[j];
-            if (OPT == FOPT_PI2) {                                               // shift-left warm start pi2.py:92-93
+            if (OPT == FOPT_PI2 || OPT == FOPT_SPSA) {                           // shift-left warm start pi2.py:92-93 / spsa.py:114-115
                 const int js = (j + 1 < p.HU) ? j + 1 : p.HU - 1;
                 p.prev_mean[a * p.HU + j] = mean[js];
             } else if (p.warm_start) {

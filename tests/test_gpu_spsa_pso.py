@@ -29,8 +29,11 @@ def _engine(L, opt, A, H, N, iters, **kw):
                   population_size=N, max_iterations=iters, **kw)
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("N,A,H,iters", [(500, 1, 30, 5), (130, 3, 7, 3)])
-def test_spsa_injected_noise(L, N, A, H, iters):
+def test_spsa_injected_noise(L, monkeypatch, N, A, H, iters, fused):
+    # both device paths: the persistent one-launch kernel (two candidates per lane) and the per-iteration kernels
+    monkeypatch.setenv("BBMPC_FUSED", fused)
     eng = _engine(L, L.OPT_SPSA, A, H, N, iters)
     eng.set_trace(True)
     rng = np.random.default_rng(N)
@@ -50,6 +53,25 @@ def test_spsa_injected_noise(L, N, A, H, iters):
         np.testing.assert_allclose(eng.get_state("prev_mean"), sp.params, rtol=0, atol=1e-4)
         np.testing.assert_allclose(nxt, nxt_o, rtol=1e-4, atol=1e-4)
     assert np.all(np.abs(eng.get_state("prev_mean")) <= 2.0)
+
+
+def test_spsa_fused_equals_per_iteration_with_engine_draws(L, monkeypatch):
+    # production (Philox) draws: the persistent kernel and the per-iteration kernels agree bit for bit over several
+    # control steps, including the shift-left warm start and a reset
+    N, A, H, iters = 300, 2, 17, 4
+    runs = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("BBMPC_FUSED", fused)
+        eng = _engine(L, L.OPT_SPSA, A, H, N, iters, seed=21)
+        s = O.pendulum_start_states(A)
+        out = []
+        for t in range(6):
+            if t == 4:
+                eng.reset()
+            a, s, r = eng.optimize(s)
+            out.append(np.concatenate([a.ravel(), s.ravel(), r.ravel(), eng.get_state("prev_mean").ravel()]))
+        runs[fused] = np.stack(out)
+    np.testing.assert_array_equal(runs["0"], runs["1"])
 
 
 def test_spsa_engine_rademacher_draws(L):
