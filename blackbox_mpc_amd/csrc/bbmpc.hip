@@ -4,6 +4,9 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace bbmpc {
 
@@ -51,6 +54,20 @@ static void init_tnq_table() {
 static void upload(DevBuf<float>& b, const std::vector<float>& v) {
     b.alloc(v.size());
     HIP_CHECK(hipMemcpy(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (device, kernel)
+// -- a process may hold handles on several devices (bbmpc_config.device).
+static void ensure_max_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.find({dev, fn}) == done.end()) {
+        HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        done.insert({dev, fn});
+    }
 }
 
 Engine::Engine(const bbmpc_config& c) : cfg(c) {
@@ -300,11 +317,7 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             const size_t blds = (size_t)2 * bsz * n * sizeof(float);
             if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 160 * 1024 && G * 4 <= 256 && !getenv("BBMPC_CMA_SVD_ROUNDS")) {
                 // block Jacobi: 4 workgroups per instance, block pairs resident in LDS, 7 instance barriers per sweep
-                static bool bconf = false;
-                if (!bconf) {
-                    HIP_CHECK(hipFuncSetAttribute((const void*)k_cma_svd_block, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    bconf = true;
-                }
+                ensure_max_lds((const void*)k_cma_svd_block, 160 * 1024);
                 hipLaunchKernelGGL(k_cma_svd_block, dim3(4, G), dim3(1024), blds, stream, q, c_evec.p, c_sync.p, 15);
             } else {
                 if (n <= 64 && !getenv("BBMPC_CMA_SVD_GENERAL")) {
@@ -510,11 +523,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     const bool single_step = per_particle_state && ra.H == 1;
     if (single_step) spec = 3;
     const void* fn = spec == 3 ? (const void*)k_step_mlp : spec == 1 ? (const void*)k_rollout_mlp<1> : (spec == 2 ? (const void*)k_rollout_mlp<2> : (const void*)k_rollout_mlp<0>);
-    static bool configured[4] = {false, false, false, false};
-    if (lds > 64 * 1024 && !configured[spec]) {
-        HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        configured[spec] = true;
-    }
+    if (lds > 64 * 1024) ensure_max_lds(fn, 159 * 1024);
     // pair mode (two tiles per workgroup, software-pipelined) when there are more tiles than CUs can hold one each
     const long tiles_total = (long)((ra.n_pop + MLP_TP - 1) / MLP_TP) * A;
     const bool pair_ok = spec == 1 && mlp.tiles[1] == 13 && !per_particle_state && mlp.act[0] == BBMPC_ACT_TANH &&
@@ -531,11 +540,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
             const size_t qlds = (size_t)mlp_q4_lds_floats(50, 7, 4, ra.H, U, S) * sizeof(float);
             if (qlds <= 160 * 1024) {
                 auto fn = k_rollout_mlp_q4<50, 7, 4, ACT_TANH, ACT_TANH, ACT_NONE>;
-                static bool qconf = false;
-                if (!qconf && qlds > 64 * 1024) {
-                    HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    qconf = true;
-                }
+                if (qlds > 64 * 1024) ensure_max_lds((const void*)fn, 160 * 1024);
                 dim3 qgrid((ra.n_pop + 3) / 4, A), qblock(256);
                 dominant_kernel = "k_rollout_mlp_q4";
                 prof_begin();
@@ -552,23 +557,14 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
         const int nt = pair ? 2 : 1;
         const size_t plds = (size_t)mlp_pair_lds_floats(13, ra.H, U, S, nt) * sizeof(float);
         if (plds <= 159 * 1024) {
-            static bool pconf[3] = {false, false, false};
             dim3 pgrid((ra.n_pop + nt * MLP_TP - 1) / (nt * MLP_TP), A), pblock(13 * 64);
             dominant_kernel = "k_rollout_mlp_pair";
             prof_begin();
             if (nt == 2) {
-                if (!pconf[2]) {
-                    HIP_CHECK(hipFuncSetAttribute((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-                    pconf[2] = true;
-                }
+                ensure_max_lds((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2>), 159 * 1024);
                 hipLaunchKernelGGL((k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2>), pgrid, pblock, plds, stream, q);
             } else {
-                if (!pconf[1]) {
-                    HIP_CHECK(hipFuncSetAttribute((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 1>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-                    pconf[1] = true;
-                }
+                ensure_max_lds((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 1>), 159 * 1024);
                 hipLaunchKernelGGL((k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 1>), pgrid, pblock, plds, stream, q);
             }
             HIP_CHECK(hipGetLastError());
@@ -696,11 +692,7 @@ static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base
 #endif
     if (lds_base + lds_samples <= limit) {
         auto fn = k_fused_pendulum<OPT, true, FASTM, INJ, ILP>;
-        static bool configured = false;
-        if (!configured) {
-            HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limit));
-            configured = true;
-        }
+        ensure_max_lds((const void*)fn, (int)limit);
         hipLaunchKernelGGL(fn, dim3(e.A), dim3(threads), lds_base + lds_samples, e.stream, fa);
     } else {
         auto fn = k_fused_pendulum<OPT, false, FASTM, INJ, ILP>;
