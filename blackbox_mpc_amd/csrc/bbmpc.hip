@@ -118,6 +118,19 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
     init_tnq_table();
 
     if (const char* fm = getenv("BBMPC_FUSED")) fused_mode = atoi(fm);
+    {
+        auto flag = [](const char* n) { return getenv(n) != nullptr; };
+        auto ival = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
+        sw.cma_svd_v1 = flag("BBMPC_CMA_SVD_V1"); sw.cma_svd_rounds = flag("BBMPC_CMA_SVD_ROUNDS");
+        sw.cma_svd_general = flag("BBMPC_CMA_SVD_GENERAL");
+        sw.mlp_generic = flag("BBMPC_MLP_GENERIC");
+        sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1);
+        sw.balance = ival("BBMPC_BALANCE", 1);
+        sw.ilp = ival("BBMPC_ILP", 1) == 2 ? 2 : 1;
+        sw.refit_v1 = flag("BBMPC_REFIT_V1");
+        sw.zero_copy = !flag("BBMPC_NO_ZERO_COPY");
+        sw.dbg = flag("BBMPC_DBG");
+    }
     HU = H * U;
     Nst = ((std::max(N, 1) + 63) / 64) * 64;
     rec = U + S + 1;
@@ -309,18 +322,18 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
         hipLaunchKernelGGL(k_cma_paths, dim3(G), dim3(REFIT_THREADS), 0, stream, q);
         hipLaunchKernelGGL(k_cma_cov, dim3((n + 15) / 16, (n + 15) / 16, G), dim3(16, 16), 0, stream, q);
         HIP_CHECK(hipGetLastError());
-        if (n <= 512 && !getenv("BBMPC_CMA_SVD_V1")) {
+        if (n <= 512 && !sw.cma_svd_v1) {
             // warm-started Jacobi, one 1024-thread workgroup per instance (kernels_cma.hpp)
             HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * 32 * sizeof(unsigned), stream));
             hipLaunchKernelGGL(k_cma_warm, dim3((unsigned)((n * n + 255) / 256), G), dim3(256), 0, stream, q, c_evec.p);
             const int bsz = (n + 7) / 8;
             const size_t blds = (size_t)2 * bsz * n * sizeof(float);
-            if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 160 * 1024 && G * 4 <= 256 && !getenv("BBMPC_CMA_SVD_ROUNDS")) {
+            if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 160 * 1024 && G * 4 <= 256 && !sw.cma_svd_rounds) {
                 // block Jacobi: 4 workgroups per instance, block pairs resident in LDS, 7 instance barriers per sweep
                 ensure_max_lds((const void*)k_cma_svd_block, 160 * 1024);
                 hipLaunchKernelGGL(k_cma_svd_block, dim3(4, G), dim3(1024), blds, stream, q, c_evec.p, c_sync.p, 15);
             } else {
-                if (n <= 64 && !getenv("BBMPC_CMA_SVD_GENERAL")) {
+                if (n <= 64 && !sw.cma_svd_general) {
                     const int pairs = (n + 1) / 2;
                     hipLaunchKernelGGL(k_cma_svd_small, dim3(G), dim3(64 * ((pairs + 3) / 4)), (size_t)n * n * sizeof(float), stream,
                                        q, c_evec.p, c_sync.p, 15);
@@ -519,7 +532,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     if (small_io && mlp.n_layers == 3 && mlp.tiles[1] == mlp.tiles[2] && mlp.tiles[1] <= 16 && mlp_nw == mlp.tiles[1]) spec = 1;
     if (small_io && mlp.n_layers == 4 && mlp.tiles[1] == mlp.tiles[2] && mlp.tiles[2] == mlp.tiles[3] && mlp.tiles[1] <= 4 &&
         mlp_nw == mlp.tiles[1]) spec = 2;
-    if (getenv("BBMPC_MLP_GENERIC")) spec = 0;
+    if (sw.mlp_generic) spec = 0;
     const bool single_step = per_particle_state && ra.H == 1;
     if (single_step) spec = 3;
     const void* fn = spec == 3 ? (const void*)k_step_mlp : spec == 1 ? (const void*)k_rollout_mlp<1> : (spec == 2 ? (const void*)k_rollout_mlp<2> : (const void*)k_rollout_mlp<0>);
@@ -529,14 +542,14 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     const bool pair_ok = spec == 1 && mlp.tiles[1] == 13 && !per_particle_state && mlp.act[0] == BBMPC_ACT_TANH &&
                          mlp.act[1] == BBMPC_ACT_TANH && mlp.act[2] == BBMPC_ACT_NONE;
     int pair = (pair_ok && tiles_total > 256) ? 1 : 0;
-    if (const char* ev = getenv("BBMPC_MLP_PAIR")) pair = (atoi(ev) != 0 && pair_ok) ? 1 : 0;
+    if (sw.mlp_pair >= 0) pair = (sw.mlp_pair != 0 && pair_ok) ? 1 : 0;
     // quad mode (4 particles per workgroup, 4x4x1_16b MFMA, all weights in registers) when the population is too
     // small to give every CU a 16-particle tile
     {
         const bool q4_ok = pair_ok && mlp.dims[0] <= 28 && mlp.dims[1] == 200 && mlp.dims[2] == 200 && mlp.dims[3] <= 64;
         int q4 = (q4_ok && tiles_total <= 256) ? 1 : 0;
-        if (const char* ev = getenv("BBMPC_MLP_Q4")) q4 = (atoi(ev) != 0 && q4_ok) ? 1 : 0;
-        if (q4 && !getenv("BBMPC_MLP_GENERIC")) {
+        if (sw.mlp_q4 >= 0) q4 = (sw.mlp_q4 != 0 && q4_ok) ? 1 : 0;
+        if (q4 && !sw.mlp_generic) {
             const size_t qlds = (size_t)mlp_q4_lds_floats(50, 7, 4, ra.H, U, S) * sizeof(float);
             if (qlds <= 160 * 1024) {
                 auto fn = k_rollout_mlp_q4<50, 7, 4, ACT_TANH, ACT_TANH, ACT_NONE>;
@@ -551,7 +564,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
             }
         }
     }
-    if (pair_ok && !getenv("BBMPC_MLP_GENERIC")) {
+    if (pair_ok && !sw.mlp_generic) {
         // pipelined kernel for the 26-200-200-20 family: two tiles per workgroup when tiles outnumber the CUs,
         // one tile per workgroup otherwise (more workgroups beat better per-workgroup efficiency then)
         const int nt = pair ? 2 : 1;
@@ -756,7 +769,7 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     fa.fix_q7 = fix(BBMPC_FIX_Q7_EXPL_NOISE_ZERO_MEAN);
     fa.add_noise = add_noise;
     fa.warm_start = fix(BBMPC_FIX_Q2_CEM_WARM_START);
-    { const char* ev = getenv("BBMPC_BALANCE"); fa.balance = ev ? atoi(ev) : 1; }
+    fa.balance = sw.balance;
     fa.alpha = cfg.alpha;
     fa.inv_lamda = 1.0f / cfg.lamda;
     fa.state = d_state_in;
@@ -787,7 +800,7 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     }
 #ifdef BBMPC_KERNEL_DBG
     static long long* dbg_buf = nullptr;
-    if (getenv("BBMPC_DBG")) {
+    if (sw.dbg) {
         if (!dbg_buf) HIP_CHECK(hipHostMalloc((void**)&dbg_buf, 64 * 8, hipHostMallocDefault));
         fa.dbg = dbg_buf;
     }
@@ -836,7 +849,7 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     }
     // two trajectories per lane (one wave per SIMD for N <= 512) unless overridden
     int ilp = 1;                 // measured: 2 waves/SIMD x 1 trajectory beats 1 wave/SIMD x 2 trajectories
-    if (const char* e_ilp = getenv("BBMPC_ILP")) ilp = atoi(e_ilp) == 2 ? 2 : 1;
+    ilp = sw.ilp;
     if (use_pf) ilp = 1;
     const int per = (N + ilp - 1) / ilp;
     const int threads = std::min(1024, std::max(((per + 63) / 64) * 64, ((std::max(k, 1) + 63) / 64) * 64));   // top-k needs k <= threads
@@ -938,7 +951,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                 ra.stream = BBMPC_NOISE_TRUNC_NORMAL; ra.iter = (uint32_t)it;
                 ra.inj = inj_t ? inj_t + inj_stride * it : nullptr;
                 launch_rollout(SRC_TRUNC, false, ra);
-                if (k <= 64 && !getenv("BBMPC_REFIT_V1")) {
+                if (k <= 64 && !sw.refit_v1) {
                     const int rthreads = N > 512 ? 1024 : (N > 256 ? 512 : 256);
                     RefitArgs rf2 = rf;
                     if (!trace_on) rf2.elites = nullptr;          // the sorted elite list is only needed by the parity trace
@@ -1423,8 +1436,7 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
     float* pin = e.pinned(ns + nr);
     memcpy(pin, state, ns * 4);
     (void)t;  // the reference evaluator accepts and ignores time_step (deterministic.py:26)
-    static const bool zero_copy = !getenv("BBMPC_NO_ZERO_COPY");
-    if (zero_copy && e.use_fused()) {
+    if (e.sw.zero_copy && e.use_fused()) {
         // the persistent kernel reads the [A,S] state and writes the packed record straight from / to the pinned,
         // device-mapped host buffer (a few PCIe transactions) -- no copy-engine round trips around a ~50 us kernel
         float* dpin = nullptr;
