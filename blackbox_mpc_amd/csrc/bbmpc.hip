@@ -331,7 +331,15 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 160 * 1024 && G * 4 <= 256 && !sw.cma_svd_rounds) {
                 // block Jacobi: 4 workgroups per instance, block pairs resident in LDS, 7 instance barriers per sweep
                 ensure_max_lds((const void*)k_cma_svd_block, 160 * 1024);
-                hipLaunchKernelGGL(k_cma_svd_block, dim3(4, G), dim3(1024), blds, stream, q, c_evec.p, c_sync.p, 15);
+                // cooperative launch: the instance barrier spins, so every workgroup of the grid must be resident at
+                // once -- the runtime checks that and orders the launch against other cooperative grids
+                {
+                    float* evp = c_evec.p;
+                    unsigned* syp = c_sync.p;
+                    int sweeps = 15;
+                    void* kargs[] = {(void*)&q, (void*)&evp, (void*)&syp, (void*)&sweeps};
+                    HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_cma_svd_block, dim3(4, G), dim3(1024), kargs, blds, stream));
+                }
             } else {
                 if (n <= 64 && !sw.cma_svd_general) {
                     const int pairs = (n + 1) / 2;
