@@ -906,6 +906,11 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
         optimize_fused(d_state_in, add_noise, d_record_out, d_next_out, step);
         return;
     }
+    if (use_fused_pso()) {
+        dominant_kernel = "k_fused_pso_pendulum";
+        optimize_fused_pso(d_state_in, add_noise, d_record_out, d_next_out, step);
+        return;
+    }
     dominant_kernel = "k_rollout_pendulum";
     RolloutArgs ra;
     memset(&ra, 0, sizeof(ra));
@@ -1041,6 +1046,58 @@ void Engine::optimize_spsa(RolloutArgs& ra, uint32_t step) {
         }
     }
     hipLaunchKernelGGL(k_shift_left, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, H, U, d_mean.p, d_prev_mean.p);  // :114-115
+    HIP_CHECK(hipGetLastError());
+}
+
+// PSO on the true pendulum model in one launch per control step (kernels_fused_pso.hpp) when the swarm's positions
+// and velocities fit one CU's LDS
+static size_t fused_pso_lds(int H, int Nst) { return ((size_t)2 * H * Nst + ((H + 3) & ~3) + 16 + 16 + 4) * sizeof(float); }
+
+bool Engine::use_fused_pso() const {
+    if (cfg.dynamics != BBMPC_DYN_PENDULUM || cfg.optimizer != BBMPC_OPT_PSO || U != 1) return false;
+    if (fused_mode == 0) return false;
+    return N <= 1024 && fused_pso_lds(H, Nst) <= 160 * 1024;
+}
+
+void Engine::optimize_fused_pso(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step) {
+    FusedPsoArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.N = N; fa.A = A; fa.H = H; fa.Nst = Nst; fa.iters = iters;
+    fa.agent_offset = cfg.agent_offset;
+    fa.fix_q1 = fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
+    fa.fix_q7 = fix(BBMPC_FIX_Q7_EXPL_NOISE_ZERO_MEAN);
+    fa.add_noise = add_noise;
+    fa.w = cfg.pso_w; fa.c1 = cfg.pso_c1; fa.c2 = cfg.pso_c2; fa.v0frac = cfg.pso_v0_fraction;
+    fa.state = d_state_in;
+    fa.lo = d_lo.p; fa.hi = d_hi.p; fa.var0 = d_var0.p;
+    fa.s = pso_state();
+    fa.inj2 = injected(BBMPC_NOISE_PSO_SCALARS);
+    fa.inj_pos = injected(BBMPC_NOISE_PSO_RESEED_TRUNC);
+    fa.inj_vel = injected(BBMPC_NOISE_PSO_RESEED_UNIFORM);
+    fa.inj_expl = injected(BBMPC_NOISE_EXPLORATION);
+    fa.record = d_record_out;
+    fa.next_state = d_next_out;
+    if (trace_on) {
+        ensure_trace();
+        fa.t_rewards = t_rewards.p; fa.t_mean = t_mean.p; fa.t_elites = t_elites.p;
+        fa.t_elite_stride = std::max(k, 1);
+    }
+    fa.key = key(step);
+    const size_t lds = fused_pso_lds(H, Nst);
+    const int threads = std::max(64, ((N + 63) / 64) * 64);
+    prof_begin();
+    if (!fix(BBMPC_STRICT_MATH)) {
+        ensure_max_lds((const void*)k_fused_pso_pendulum<true>, 160 * 1024);
+        hipLaunchKernelGGL(k_fused_pso_pendulum<true>, dim3(A), dim3(threads), lds, stream, fa);
+    } else {
+        ensure_max_lds((const void*)k_fused_pso_pendulum<false>, 160 * 1024);
+        hipLaunchKernelGGL(k_fused_pso_pendulum<false>, dim3(A), dim3(threads), lds, stream, fa);
+    }
+    HIP_CHECK(hipGetLastError());
+    prof_end();
+    const OptArgs oa = opt_args(step, 0u);
+    hipLaunchKernelGGL(k_pso_seed, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, fa.s, d_var0.p, cfg.pso_v0_fraction, 0,
+                       fa.inj_pos, fa.inj_vel);                                                                         // :116-138
     HIP_CHECK(hipGetLastError());
 }
 

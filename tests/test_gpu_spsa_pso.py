@@ -103,8 +103,11 @@ def _check_pso_state(L, eng, pso, N, A, H):
     np.testing.assert_array_equal(eng.get_state("gbest_r", (A,)), pso.gbest_r)
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("with_reset", [True, False])
-def test_pso_injected_noise(L, with_reset):
+def test_pso_injected_noise(L, monkeypatch, with_reset, fused):
+    # both device paths: the persistent kernel (swarm positions / velocities in LDS) and the per-iteration kernels
+    monkeypatch.setenv("BBMPC_FUSED", fused)
     N, A, H, iters = 160, 2, 9, 4
     eng = _engine(L, L.OPT_PSO, A, H, N, iters)
     eng.set_trace(True)
@@ -132,6 +135,27 @@ def test_pso_injected_noise(L, with_reset):
         np.testing.assert_allclose(nxt, nxt_o, rtol=1e-4, atol=1e-4)
         _check_pso_state(L, eng, pso, N, A, H)
         np.testing.assert_allclose(eng.get_state("gbest"), pso.gbest, rtol=0, atol=2e-5)
+
+
+def test_pso_fused_equals_per_iteration_with_engine_draws(L, monkeypatch):
+    # production (Philox) draws, config-2 size: the two device paths agree bit for bit over several control steps
+    # (actions, predictions and the whole swarm state), with and without a reset in between
+    N, A, H, iters = 500, 2, 30, 5
+    runs = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("BBMPC_FUSED", fused)
+        eng = _engine(L, L.OPT_PSO, A, H, N, iters, seed=31)
+        eng.reset()
+        s = O.pendulum_start_states(A)
+        out = []
+        for t in range(5):
+            if t == 3:
+                eng.reset()
+            a, s, r = eng.optimize(s)
+            out.append(np.concatenate([a.ravel(), s.ravel(), r.ravel(), eng.get_state("pos", (N, A, H, 1)).ravel(),
+                                       eng.get_state("vel", (N, A, H, 1)).ravel(), eng.get_state("gbest").ravel()]))
+        runs[fused] = np.stack(out)
+    np.testing.assert_array_equal(runs["0"], runs["1"])
 
 
 def test_pso_production_noise_is_shard_invariant(L):
