@@ -744,7 +744,7 @@ static void launch_fused(Engine& e, FusedArgs& fa, int ilp, int threads, size_t 
 // Standard draws for a chunk of control steps in the layout the persistent kernel's INJ=2 path reads:
 // [step][iter][A][Nst][Q] float4, one float4 = the 4 words of Philox block q of particle n.  Same counters and
 // transforms as the in-kernel generator (rng.hpp), so the values are bit-identical.  thread = (n, q), coalesced.
-__global__ void k_noise_fill(RngKey key, uint32_t rstream, int uniform, int n_it, int N, int Nst, int A, int Q,
+__global__ void k_noise_fill(RngKey key, uint32_t rstream, int kind /* 0 trunc normal, 1 uniform, 2 rademacher */, int n_it, int N, int Nst, int A, int Q,
                              int agent_offset, float4* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * Q) return;
@@ -754,16 +754,17 @@ __global__ void k_noise_fill(RngKey key, uint32_t rstream, int uniform, int n_it
     key.step += (uint32_t)s;
     const U4 w = rng_block(key, rstream, (uint32_t)it, (uint32_t)n, (uint32_t)(agent_offset + a), (uint32_t)(4 * q));
     float4 v;
-    if (uniform) v = make_float4(word_to_uniform(w.x), word_to_uniform(w.y), word_to_uniform(w.z), word_to_uniform(w.w));
+    if (kind == 1) v = make_float4(word_to_uniform(w.x), word_to_uniform(w.y), word_to_uniform(w.z), word_to_uniform(w.w));
+    else if (kind == 2) v = make_float4(word_to_rademacher(w.x), word_to_rademacher(w.y), word_to_rademacher(w.z), word_to_rademacher(w.w));
     else v = make_float4(word_to_trunc_normal(w.x), word_to_trunc_normal(w.y), word_to_trunc_normal(w.z), word_to_trunc_normal(w.w));
     out[(((size_t)s * n_it + it) * A + a) * Nst * Q + (size_t)n * Q + q] = v;
 }
 
 void Engine::launch_noise_fill(int64_t chunk, int buf, hipStream_t on) {
-    const bool rs = cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH;
+    const bool rs = cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH, sp = cfg.optimizer == BBMPC_OPT_SPSA;
     const int n_it = rs ? 1 : iters, Q = (HU + 3) / 4;
     dim3 grid((N * Q + 255) / 256, A * n_it * pf_steps), block(256);
-    hipLaunchKernelGGL(k_noise_fill, grid, block, 0, on, key((uint32_t)(chunk * pf_steps)), rs ? 2u : 1u, rs ? 1 : 0, n_it,
+    hipLaunchKernelGGL(k_noise_fill, grid, block, 0, on, key((uint32_t)(chunk * pf_steps)), rs ? 2u : (sp ? 3u : 1u), rs ? 1 : (sp ? 2 : 0), n_it,
                        N, Nst, A, Q, cfg.agent_offset, reinterpret_cast<float4*>(d_noise_pf[buf].p));
     HIP_CHECK(hipGetLastError());
 }
@@ -822,7 +823,7 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
         pf_step_floats = (size_t)pf_nit * A * Nst * ((HU + 3) / 4) * 4;
         const size_t budget = (size_t)128 << 20;     // bytes per chunk buffer
         pf_steps = pf_step_floats ? (int)std::min<size_t>(8, budget / (pf_step_floats * 4)) : 0;
-        pf_mode = ((ev ? atoi(ev) != 0 : true) && pf_steps >= 1 && U == 1 && cfg.optimizer != BBMPC_OPT_SPSA) ? 1 : 0;
+        pf_mode = ((ev ? atoi(ev) != 0 : true) && pf_steps >= 1 && U == 1) ? 1 : 0;
         if (pf_mode) {
             HIP_CHECK(hipStreamCreateWithFlags(&pf_stream, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&pf_free, hipEventDisableTiming));
@@ -832,7 +833,7 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
             }
         }
     }
-    const bool use_pf = pf_mode == 1 && fa.inj == nullptr && pf_nit > 0 && cfg.optimizer != BBMPC_OPT_SPSA;
+    const bool use_pf = pf_mode == 1 && fa.inj == nullptr && pf_nit > 0;
     if (use_pf) {
         const int64_t c = (int64_t)step / pf_steps;
         const int pb = (int)(c & 1), nb = pb ^ 1;
@@ -870,7 +871,10 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
         case BBMPC_OPT_CEM: launch_fused<FOPT_CEM>(*this, fa, ilp, threads, lds_base, lds_samples, use_pf ? 2 : 1); break;
         case BBMPC_OPT_SPSA: {
             const bool fastm = !fix(BBMPC_STRICT_MATH);
-            if (fa.inj) {
+            if (use_pf) {
+                if (fastm) launch_fused4<FOPT_SPSA, true, 2, 1>(*this, fa, threads, lds_base, lds_samples);
+                else launch_fused4<FOPT_SPSA, false, 2, 1>(*this, fa, threads, lds_base, lds_samples);
+            } else if (fa.inj) {
                 if (fastm) launch_fused4<FOPT_SPSA, true, 1, 1>(*this, fa, threads, lds_base, lds_samples);
                 else launch_fused4<FOPT_SPSA, false, 1, 1>(*this, fa, threads, lds_base, lds_samples);
             } else {

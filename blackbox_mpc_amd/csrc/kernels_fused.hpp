@@ -147,9 +147,19 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                 rp.init(p.fix_q1 != 0, s0, s1, s2);
                 rm.init(p.fix_q1 != 0, s0, s1, s2);
                 float tp = 0.0f, tm = 0.0f, pp = 0.0f, pm = 0.0f;
+                [[maybe_unused]] const float4* mine4 = nullptr;
+                [[maybe_unused]] float4 cur4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                if constexpr (INJ == 2) {            // draws prefetched by k_noise_fill, one float4 per 4 steps
+                    mine4 = reinterpret_cast<const float4*>(p.inj) + (((size_t)it * p.A + a) * p.Nst + n) * nb4;
+                    cur4 = mine4[0];
+                }
                 for (int b = 0; b < nb4; ++b) {
                     float d[4];
-                    if (INJ == 1) {
+                    if constexpr (INJ == 2) {
+                        const float4 nxt4 = mine4[min(b + 1, nb4 - 1)];
+                        d[0] = cur4.x; d[1] = cur4.y; d[2] = cur4.z; d[3] = cur4.w;
+                        cur4 = nxt4;
+                    } else if (INJ == 1) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) d[i] = (4 * b + i < p.H) ? inj[(size_t)(4 * b + i) * p.Nst + n] : 1.0f;
                     } else {
