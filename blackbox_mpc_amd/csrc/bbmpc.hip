@@ -124,6 +124,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.cma_svd_v1 = flag("BBMPC_CMA_SVD_V1"); sw.cma_svd_rounds = flag("BBMPC_CMA_SVD_ROUNDS");
         sw.cma_svd_general = flag("BBMPC_CMA_SVD_GENERAL");
         sw.mlp_generic = flag("BBMPC_MLP_GENERIC");
+        { const int b = ival("BBMPC_MLP_BF16", 0); sw.mlp_bf16 = (b == 1 || b == 3) ? b : 0; }
         sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1);
         sw.balance = ival("BBMPC_BALANCE", 1);
         sw.ilp = ival("BBMPC_ILP", 1) == 2 ? 2 : 1;
@@ -495,6 +496,29 @@ void Engine::set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, con
                 for (int o = 0; o < M; ++o) wq[((size_t)(kk >> 2) * Mp + o) * 4 + (kk & 3)] = w[l][(size_t)kk * M + o];
             upload(d_wq4[l], wq);
         }
+        {   // optional bf16 mode operands: [OT][IT][64] x (4 bf16 hi | 4 bf16 lo), k = 16*it + 4*(lane>>4) + r, row = 16*ot + (lane&15)
+            auto bf16_rne = [](float x) -> uint16_t {
+                uint32_t u; memcpy(&u, &x, 4);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                return (uint16_t)(u >> 16);
+            };
+            auto bf16_f = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+            const int IT = (K + 15) / 16, OT = (M + 15) / 16;
+            std::vector<float> wb((size_t)OT * IT * 64 * 4, 0.0f);          // 16 bytes per lane, kept in a float buffer
+            uint16_t* hw = reinterpret_cast<uint16_t*>(wb.data());
+            for (int ot = 0; ot < OT; ++ot)
+                for (int it = 0; it < IT; ++it)
+                    for (int ln = 0; ln < 64; ++ln)
+                        for (int r = 0; r < 4; ++r) {
+                            const int kk = 16 * it + 4 * (ln >> 4) + r, o = 16 * ot + (ln & 15);
+                            const float v = (kk < K && o < M) ? w[l][(size_t)kk * M + o] : 0.0f;
+                            const uint16_t h = bf16_rne(v), lo = bf16_rne(v - bf16_f(h));
+                            uint16_t* d = hw + (((size_t)ot * IT + it) * 64 + ln) * 8;
+                            d[r] = h;
+                            d[4 + r] = lo;
+                        }
+            upload(d_wbf[l], wb);
+        }
         mlp.wpack[l] = d_wpack[l].p;
         mlp.bpack[l] = d_bpack[l].p;
     }
@@ -530,7 +554,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     q.per_particle_state = per_particle_state ? 1 : 0;
     q.final_state = final_state;
     q.nw = mlp_nw;
-    for (int l = 0; l < mlp.n_layers; ++l) { q.wraw[l] = d_wraw[l].p; q.braw[l] = d_braw[l].p; q.wq4[l] = d_wq4[l].p; }
+    for (int l = 0; l < mlp.n_layers; ++l) { q.wraw[l] = d_wraw[l].p; q.braw[l] = d_braw[l].p; q.wq4[l] = d_wq4[l].p; q.wbf[l] = reinterpret_cast<const uint4*>(d_wbf[l].p); }
     const MlpLds lay = mlp_lds_layout(mlp, ra.H, U, S, mlp_nw);
     const size_t lds = (size_t)lay.total * sizeof(float);
     REQUIRE(lds <= 159 * 1024, BBMPC_E_UNSUPPORTED, "planning horizon x action dim too large for the LDS action block");
@@ -543,6 +567,19 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     if (sw.mlp_generic) spec = 0;
     const bool single_step = per_particle_state && ra.H == 1;
     if (single_step) spec = 3;
+    if (sw.mlp_bf16 && spec == 1 && !per_particle_state && !final_state) {
+        // opt-in reduced-precision mode (kernels_mlp.hpp): never selected automatically
+        dim3 bgrid((ra.n_pop + MLP_TP - 1) / MLP_TP, A), bblock(mlp_nw * 64);
+        dominant_kernel = sw.mlp_bf16 == 3 ? "k_rollout_mlp_bf16<3>" : "k_rollout_mlp_bf16<1>";
+        const void* bfn = sw.mlp_bf16 == 3 ? (const void*)k_rollout_mlp_bf16<3> : (const void*)k_rollout_mlp_bf16<1>;
+        if (lds > 64 * 1024) ensure_max_lds(bfn, 159 * 1024);
+        prof_begin();
+        if (sw.mlp_bf16 == 3) hipLaunchKernelGGL(k_rollout_mlp_bf16<3>, bgrid, bblock, lds, stream, q);
+        else hipLaunchKernelGGL(k_rollout_mlp_bf16<1>, bgrid, bblock, lds, stream, q);
+        HIP_CHECK(hipGetLastError());
+        prof_end();
+        return;
+    }
     const void* fn = spec == 3 ? (const void*)k_step_mlp : spec == 1 ? (const void*)k_rollout_mlp<1> : (spec == 2 ? (const void*)k_rollout_mlp<2> : (const void*)k_rollout_mlp<0>);
     if (lds > 64 * 1024) ensure_max_lds(fn, 159 * 1024);
     // pair mode (two tiles per workgroup, software-pipelined) when there are more tiles than CUs can hold one each

@@ -79,6 +79,7 @@ struct Engine {
     struct Switches {
         bool cma_svd_v1 = false, cma_svd_rounds = false, cma_svd_general = false;   // BBMPC_CMA_SVD_V1 / _ROUNDS / _GENERAL
         bool mlp_generic = false;      // BBMPC_MLP_GENERIC
+        int mlp_bf16 = 0;              // BBMPC_MLP_BF16: 0 off (default, fp32), 1 plain bf16 inputs, 3 split bf16 (hi+lo, three products)
         int mlp_pair = -1, mlp_q4 = -1;   // BBMPC_MLP_PAIR / BBMPC_MLP_Q4: -1 automatic, 0 / 1 forced
         int balance = 1;               // BBMPC_BALANCE
         int ilp = 1;                   // BBMPC_ILP
@@ -96,7 +97,7 @@ struct Engine {
     bool mlp_ready = false;
     MlpDesc mlp;
     int mlp_nw = 1;
-    DevBuf<float> d_wpack[MLP_MAX_LAYERS], d_bpack[MLP_MAX_LAYERS], d_wraw[MLP_MAX_LAYERS], d_braw[MLP_MAX_LAYERS], d_wq4[MLP_MAX_LAYERS], d_stats;
+    DevBuf<float> d_wpack[MLP_MAX_LAYERS], d_bpack[MLP_MAX_LAYERS], d_wraw[MLP_MAX_LAYERS], d_braw[MLP_MAX_LAYERS], d_wq4[MLP_MAX_LAYERS], d_wbf[MLP_MAX_LAYERS], d_stats;
     DevBuf<float> d_fin_next, d_fin_rew, d_step_act;
     // SPSA / PSO state (internal layout)
     DevBuf<float> d_cand_a, d_cand_b, d_rewards2, d_vel, d_pbest, d_pbest_r, d_gbest, d_gbest_r, d_cond;

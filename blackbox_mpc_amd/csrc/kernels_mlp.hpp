@@ -64,6 +64,7 @@ struct MlpRolloutArgs {
     const float* wraw[MLP_MAX_LAYERS];   // unpacked Dense kernels [in][out] (quad-mode kernel)
     const float* braw[MLP_MAX_LAYERS];   // unpacked biases [out]
     const float* wq4[MLP_MAX_LAYERS];    // quad-mode operands [ceil(in/4)][Mp][4], Mp = out rounded up to 64, zero padded
+    const uint4* wbf[MLP_MAX_LAYERS];    // bf16 mode operands [OT][IT][64] x (4 bf16 hi | 4 bf16 lo), k = 16*it + 4*(lane>>4) + r
 };
 
 // tanh on the hardware exp/rcp units: sign(x) * (1 - 2 / (e^{2|x|} + 1)), 7 instructions.  Absolute error
@@ -1150,6 +1151,209 @@ inline int mlp_q4_lds_floats(int HG, int K0G, int NWQ, int H, int U, int S) {
     const int Sp = (S + 3) & ~3;
     return K0G * 16 + 2 * HG * 16 + NWQ * 256 + 2 * 4 * Sp + ((H * 4 * U + 3) & ~3) + ((4 * U + 3) & ~3) + 2 * (S + U) + 3 * S + 16 +
            H * K0G * 16 + H * 4 + 8;
+}
+
+// =================================================================================================
+// OPTIONAL bf16-input mode (BBMPC_MLP_BF16 = 1 | 3; never the default: the parity path is fp32 in / fp32 accumulate).
+// v_mfma_f32_16x16x16_bf16 moves 4x the K per instruction in half the time of v_mfma_f32_16x16x4_f32
+// (tools/microbench/mfma_valu_overlap.hip), so even the split form -- every operand x = hi + lo with hi, lo bf16,
+// products hi*hi + hi*lo + lo*hi accumulated in fp32, i.e. ~16 mantissa bits per factor -- needs 24 ns of matrix time per
+// 16-deep K tile instead of 61 ns.  NPROD = 1 drops the lo parts (plain bf16 inputs, ~8 mantissa bits).
+// Same decomposition as SPEC 1 of rollout_mlp_body (2 hidden layers of equal width <= 256, one output tile per wave,
+// weights stationary in VGPRs, last layer K-split): the D fragment of an output tile (rows 4g..4g+3 of column p) is,
+// converted in place, exactly the 4-bf16 B operand of the next layer's K tile.  LDS tiles hold (hi | lo) = 16 bytes per
+// lane, the size of the fp32 float4 they replace.  Tolerances are stated in tests/test_gpu_mlp.py.
+typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+
+struct BfSplit { bf16x4_t hi, lo; };
+
+__device__ __forceinline__ BfSplit bf_split4(const f32x4& v) {
+    BfSplit o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t u = __float_as_uint(v[r]);
+        const uint32_t h = u & 0xffff0000u;                                  // hi: truncated to bf16
+        const float rem = v[r] - __uint_as_float(h);                         // exact
+        const uint32_t l = __float_as_uint(rem) + 0x8000u;                   // lo: rounded to bf16
+        o.hi[r] = (short)(h >> 16);
+        o.lo[r] = (short)(l >> 16);
+    }
+    return o;
+}
+
+template <int NPROD>
+__device__ __forceinline__ f32x4 bf_mma(const BfSplit& a, const BfSplit& b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.hi, b.hi, acc, 0, 0, 0);
+    if (NPROD == 3) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.hi, b.lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.lo, b.hi, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ BfSplit bf_from_u4(const uint4& w) {
+    BfSplit o;
+    o.hi[0] = (short)(w.x & 0xffffu); o.hi[1] = (short)(w.x >> 16); o.hi[2] = (short)(w.y & 0xffffu); o.hi[3] = (short)(w.y >> 16);
+    o.lo[0] = (short)(w.z & 0xffffu); o.lo[1] = (short)(w.z >> 16); o.lo[2] = (short)(w.w & 0xffffu); o.lo[3] = (short)(w.w >> 16);
+    return o;
+}
+__device__ __forceinline__ uint4 bf_to_u4(const BfSplit& s) {
+    uint4 w;
+    w.x = ((uint32_t)(unsigned short)s.hi[0]) | ((uint32_t)(unsigned short)s.hi[1] << 16);
+    w.y = ((uint32_t)(unsigned short)s.hi[2]) | ((uint32_t)(unsigned short)s.hi[3] << 16);
+    w.z = ((uint32_t)(unsigned short)s.lo[0]) | ((uint32_t)(unsigned short)s.lo[1] << 16);
+    w.w = ((uint32_t)(unsigned short)s.lo[2]) | ((uint32_t)(unsigned short)s.lo[3] << 16);
+    return w;
+}
+
+template <int NPROD>
+__global__ void k_rollout_mlp_bf16(MlpRolloutArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const RolloutArgs& p = q.r;
+    const MlpDesc& m = q.m;
+    const int a = blockIdx.y;
+    const int n0 = blockIdx.x * MLP_TP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = q.nw, nthr = nw * 64;
+    const int S = p.S, U = p.U, H = p.H, L = m.n_layers;
+    const int Sp = (S + 3) & ~3;
+    const MlpLds lay = mlp_lds_layout(m, H, U, S, nw);
+    uint4* xs = reinterpret_cast<uint4*>(smem + lay.xs);          // [IT0][64] (hi|lo)
+    uint4* hbuf = reinterpret_cast<uint4*>(smem + lay.actA);      // [HT][64]  (hi|lo)
+    float* part = smem + lay.part;
+    float* st = smem + lay.st;
+    float* acts = smem + lay.acts;
+    float* misc = smem + lay.misc;
+    const bool normd = m.normalized != 0;
+    float* nmean = smem + lay.norm;
+    float* ninv = nmean + (S + U);
+    float* tmean = ninv + (S + U);
+    float* tstd = tmean + S;
+    float* lbias = tstd + S;
+
+    constexpr int HTM = 16, IT0M = 2, OTLM = 2;
+    const int HT = m.tiles[1], IT0 = m.tiles[0], OTl = m.tiles[L];
+    BfSplit w_in[IT0M], w_hid[HTM], w_out[OTLM];
+#pragma unroll
+    for (int it = 0; it < IT0M; ++it) w_in[it] = bf_from_u4(it < IT0 ? q.wbf[0][((size_t)wave * IT0 + it) * 64 + lane] : make_uint4(0, 0, 0, 0));
+#pragma unroll
+    for (int it = 0; it < HTM; ++it) w_hid[it] = bf_from_u4(it < HT ? q.wbf[1][((size_t)wave * HT + it) * 64 + lane] : make_uint4(0, 0, 0, 0));
+#pragma unroll
+    for (int ot = 0; ot < OTLM; ++ot) w_out[ot] = bf_from_u4(ot < OTl ? q.wbf[2][((size_t)ot * HT + wave) * 64 + lane] : make_uint4(0, 0, 0, 0));
+    const f32x4 bias0 = *reinterpret_cast<const f32x4*>(m.bpack[0] + ((size_t)wave * 64 + lane) * 4);
+    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(m.bpack[1] + ((size_t)wave * 64 + lane) * 4);
+
+    mlp_fill_actions<MLP_TP>(q, a, n0, tid, nthr, acts, misc);
+    for (int f = tid; f < S + U; f += nthr) {
+        const float mu = normd ? (f < S ? m.mean_s[f] : m.mean_a[f - S]) : 0.0f;
+        const float sd = normd ? (f < S ? m.std_s[f] : m.std_a[f - S]) : 1.0f;
+        nmean[f] = mu;
+        ninv[f] = normd ? 1.0f / (sd + 1e-7f) : 1.0f;
+        if (f < S) {
+            tmean[f] = normd ? m.mean_t[f] : 0.0f;
+            tstd[f] = normd ? (m.std_t[f] + 1e-7f) : 1.0f;
+            lbias[f] = m.bpack[L - 1][((size_t)(f >> 4) * 64 + ((f & 15) >> 2) * 16) * 4 + (f & 3)];
+        }
+    }
+    for (int i = tid; i < IT0 * 64; i += nthr) xs[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < MLP_TP * S; i += nthr) {
+        const int pp = i / S, s = i % S;
+        st[pp * Sp + s] = p.state[a * S + s];
+    }
+    __syncthreads();
+    // element (feature f, particle pp) of an input tile: lane ((f&15)>>2)*16 + pp, bf16 slot f&3 of the hi / lo quads
+    auto put_x = [&](int f, int pp, float v) {
+        const uint32_t u = __float_as_uint(v);
+        const uint32_t h = u & 0xffff0000u;
+        const uint32_t l = __float_as_uint(v - __uint_as_float(h)) + 0x8000u;
+        unsigned short* base = reinterpret_cast<unsigned short*>(xs + ((size_t)(f >> 4) * 64 + ((f & 15) >> 2) * 16 + pp));
+        base[f & 3] = (unsigned short)(h >> 16);
+        base[4 + (f & 3)] = (unsigned short)(l >> 16);
+    };
+    for (int i = tid; i < MLP_TP * (S + U); i += nthr) {
+        const int f = i / MLP_TP, pp = i % MLP_TP;
+        const float v = (f < S) ? st[pp * Sp + f] : acts[(0 * MLP_TP + pp) * U + (f - S)];
+        put_x(f, pp, (v - nmean[f]) * ninv[f]);
+    }
+    __syncthreads();
+
+    float total = 0.0f;
+    for (int t = 0; t < H; ++t) {
+        float* cur = st + (t & 1) * MLP_TP * Sp;
+        float* nxt = st + ((t + 1) & 1) * MLP_TP * Sp;
+        // ---- layer 0
+        f32x4 acc = bias0;
+#pragma unroll
+        for (int it = 0; it < IT0M; ++it)
+            if (it < IT0) acc = bf_mma<NPROD>(w_in[it], bf_from_u4(xs[(size_t)it * 64 + lane]), acc);
+        acc.x = apply_act(acc.x, m.act[0]); acc.y = apply_act(acc.y, m.act[0]);
+        acc.z = apply_act(acc.z, m.act[0]); acc.w = apply_act(acc.w, m.act[0]);
+        hbuf[(size_t)wave * 64 + lane] = bf_to_u4(bf_split4(acc));               // all-gather through LDS
+        __syncthreads();
+        // ---- layer 1
+        acc = bias1;
+#pragma unroll
+        for (int it = 0; it < HTM; ++it)
+            if (it < HT) acc = bf_mma<NPROD>(w_hid[it], bf_from_u4(hbuf[(size_t)it * 64 + lane]), acc);
+        acc.x = apply_act(acc.x, m.act[1]); acc.y = apply_act(acc.y, m.act[1]);
+        acc.z = apply_act(acc.z, m.act[1]); acc.w = apply_act(acc.w, m.act[1]);
+        // ---- last layer, K split: my own hidden tile (converted in registers) times my slab of W_last
+        {
+            const BfSplit hb = bf_split4(acc);
+#pragma unroll
+            for (int ot = 0; ot < OTLM; ++ot) {
+                if (ot < OTl) {
+                    f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+                    o = bf_mma<NPROD>(w_out[ot], hb, o);
+                    *reinterpret_cast<f32x4*>(part + (((size_t)wave * OTl + ot) * 64 + lane) * 4) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- epilogue (fp32): reduce partials, bias, last activation, de-normalise, residual; stage step t+1's input
+        const int nwp = min(nw, HT);
+        for (int i = tid; i < MLP_TP * (S + U); i += nthr) {
+            const int f = i / MLP_TP, pp = i % MLP_TP;
+            float v;
+            if (f < S) {
+                const int ot = f >> 4, ln = ((f & 15) >> 2) * 16 + pp, rg = f & 3;
+                const float* pp0 = part + (((size_t)ot) * 64 + ln) * 4 + rg;
+                float s_ = lbias[f];
+#pragma unroll 4
+                for (int w = 0; w < nwp; ++w) s_ = s_ + pp0[(size_t)w * OTl * 256];
+                s_ = apply_act(s_, m.act[L - 1]);
+                const float dev = normd ? tmean[f] + s_ * tstd[f] : s_;
+                const float ns = dev + cur[pp * Sp + f];
+                nxt[pp * Sp + f] = ns;
+                v = ns;
+            } else {
+                const int tn = (t + 1 < H) ? t + 1 : t;
+                v = acts[(tn * MLP_TP + pp) * U + (f - S)];
+            }
+            put_x(f, pp, (v - nmean[f]) * ninv[f]);
+        }
+        __syncthreads();
+        if (tid < MLP_TP) {
+            const float r = reward_generic(p.reward_kind, p.fix_q1 != 0, cur + tid * Sp, acts + (t * MLP_TP + tid) * U,
+                                           nxt + tid * Sp, S, U);
+            total = total + r;
+        }
+    }
+    __syncthreads();
+    if (tid < MLP_TP) {
+        const int n = n0 + tid;
+        if (n < p.n_pop) {
+            if (total != total) total = -1.0e6f;
+            if (q.pen) {
+                float pen = 0.0f;
+                for (int u = 0; u < U; ++u) pen = pen + misc[tid * U + u];
+                const float nr = sqrtf(pen);
+                pen = nr * nr;
+                total = total - pen;
+                if (p.penalty_out) p.penalty_out[(size_t)a * p.Nst + n] = pen;
+            }
+            p.rewards[(size_t)a * p.Nst + n] = total;
+        }
+    }
 }
 
 }  // namespace bbmpc

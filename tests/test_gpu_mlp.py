@@ -246,3 +246,36 @@ def test_wide_io_network_generic_kernel(L):
     s1 = rng.normal(0, 0.5, (17, S)).astype(F)
     a1 = rng.uniform(-1, 1, (17, U)).astype(F)
     np.testing.assert_allclose(eng.predict_next_state(s1, a1), ev.predict_next_state(s1, a1), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("mode,q99,frac_flip", [("3", 1e-3, 0.005), ("1", 15.0, 0.1)])
+def test_optional_bf16_modes_against_oracle(L, monkeypatch, mode, q99, frac_flip):
+    # BBMPC_MLP_BF16 = 3: every MFMA operand split into bf16 hi + lo, three products per K tile (~16 mantissa bits per
+    # factor, fp32 accumulate); = 1: plain bf16 inputs.  Opt-in modes with their OWN tolerance (never the default path):
+    #   split : 99 % of the H=50 rollout rewards within 1e-3 of the oracle (median ~3e-5);
+    #   plain : median error below 0.1 on rewards of spread ~200.
+    # The cheetah reward has three indicator terms (cur[5] >= 0.2 etc., -10 each): a state that sits on a threshold can
+    # flip one of them under ANY rounding change, so a small fraction of trajectories may differ by a multiple of 10.
+    from oracle import oracle_c as OC
+    monkeypatch.setenv("BBMPC_MLP_BF16", mode)
+    dims, acts, S, U, reward = CHEETAH
+    N, A, H = 2000, 2, 50
+    eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, True, A=A, H=H)
+    assert eng is not None
+    ws, bs = O.make_mlp_params(dims, seed=42)
+    rng = np.random.default_rng(43)
+    bs = [rng.normal(0, 0.05, b.shape).astype(F) for b in bs]
+    co = OC.COracle("mlp", "cheetah", lo, hi, N, A, H, S, mlp=(ws, bs, acts), stats=_stats(S, U, 44))
+    rng = np.random.default_rng(9)
+    states = O.cheetah_start_states(A, S)
+    seq = rng.uniform(-1, 1, (N, A, H, U)).astype(F)
+    got, want = eng.evaluate(states, seq), co.evaluate(states, seq)
+    err = np.abs(got - want)
+    assert np.quantile(err, 0.99) < q99
+    big = err > (0.05 if mode == "3" else 5.0)
+    assert big.mean() < frac_flip
+    if mode == "3":
+        np.testing.assert_allclose(err[big] / 10.0, np.round(err[big] / 10.0), atol=0.02)     # flips are multiples of 10
+        assert np.median(err) < 2e-4
+    else:
+        assert np.median(err) < 0.1
