@@ -342,8 +342,9 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                     HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_cma_svd_block, dim3(4, G), dim3(1024), kargs, blds, stream));
                 }
             } else {
-                if (n <= 64 && !sw.cma_svd_general) {
+                if (n <= 128 && !sw.cma_svd_general) {
                     const int pairs = (n + 1) / 2;
+                    if ((size_t)n * n * sizeof(float) > 48 * 1024) ensure_max_lds((const void*)k_cma_svd_small, 96 * 1024);
                     hipLaunchKernelGGL(k_cma_svd_small, dim3(G), dim3(64 * ((pairs + 3) / 4)), (size_t)n * n * sizeof(float), stream,
                                        q, c_evec.p, c_sync.p, 15);
                 } else {

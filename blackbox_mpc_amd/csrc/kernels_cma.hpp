@@ -659,8 +659,8 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
     }
 }
 
-// ---- Small instances (n <= 64, e.g. the pendulum's n = H*U = 30): the whole matrix in LDS, one 16-lane DPP row per
-// column pair (four elements per lane), rcp / rsq rotation scalars as in the block kernel.  A round is ~40
+// ---- Small instances (n <= 128, e.g. the pendulum's n = H*U = 30): the whole matrix in LDS, one 16-lane DPP row per
+// column pair (up to eight elements per lane), rcp / rsq rotation scalars as in the block kernel.  A round is ~40
 // instructions per wave + one barrier; the general kernels above spend ~1 us per round on predicated 512-wide code.
 // LDS: n*n floats.  blockDim = 64 * ceil(pairs / 4).  sync: [G][32] as above (sweep flags only).
 __global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
@@ -668,7 +668,8 @@ __global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all
     __shared__ int s_rot;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
     float* At_g = At_all + (size_t)g * n * n;
-    const float tol = 2.0e-6f;
+    const float tol = fminf(fmaxf(3.0e-8f * (float)n, 2.0e-6f), 1.0e-5f);
+    const int nc = (n + 15) >> 4;                              // elements per lane (<= 8: n <= 128)
     for (int i = tid; i < n * n; i += blockDim.x) at_s[i] = At_g[i];
     const int m = (n + 1) & ~1;
     const int sub = lane & 15, slot = wv * 4 + (lane >> 4);     // pair slot of this 16-lane row
@@ -686,13 +687,15 @@ __global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all
             }
             float* x = at_s + (size_t)(act ? pa : 0) * n;
             float* y = at_s + (size_t)(act ? pb : 0) * n;
-            float xv[4], yv[4], al = 0.0f, be = 0.0f, ga = 0.0f;
+            float xv[8], yv[8], al = 0.0f, be = 0.0f, ga = 0.0f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int e = sub + 16 * c;
-                xv[c] = (act && e < n) ? x[e] : 0.0f;
-                yv[c] = (act && e < n) ? y[e] : 0.0f;
-                al = fmaf(xv[c], xv[c], al); be = fmaf(yv[c], yv[c], be); ga = fmaf(xv[c], yv[c], ga);
+            for (int c = 0; c < 8; ++c) {
+                if (c < nc) {
+                    const int e = sub + 16 * c;
+                    xv[c] = (act && e < n) ? x[e] : 0.0f;
+                    yv[c] = (act && e < n) ? y[e] : 0.0f;
+                    al = fmaf(xv[c], xv[c], al); be = fmaf(yv[c], yv[c], be); ga = fmaf(xv[c], yv[c], ga);
+                }
             }
             al = row16_sum(al); be = row16_sum(be); ga = row16_sum(ga);
             if (act && ga != 0.0f && ga * ga > (tol * tol) * (al * be)) {
@@ -703,9 +706,9 @@ __global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all
                 cs = cs * fmaf(-0.5f * w * cs, cs, 1.5f);
                 const float sn = cs * t;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < 8; ++c) {
                     const int e = sub + 16 * c;
-                    if (e < n) {
+                    if (c < nc && e < n) {
                         x[e] = cs * xv[c] - sn * yv[c];
                         y[e] = sn * xv[c] + cs * yv[c];
                     }

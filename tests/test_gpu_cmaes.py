@@ -138,8 +138,9 @@ def test_cmaes_with_learned_dynamics_runs(L):
         assert act.shape == (A, U) and np.all(np.isfinite(act)) and np.all(np.isfinite(nxt)) and np.all(np.isfinite(rew))
 
 
-@pytest.mark.parametrize("H", [132, 148])
+@pytest.mark.parametrize("H", [96, 132, 148])
 def test_block_jacobi_path_uneven_blocks_and_sharding(L, monkeypatch, H):
+    # n = 96 takes the LDS-resident single-workgroup kernel with eight elements per lane (64 < n <= 128);
     # n = H*U >= 128 takes the block-Jacobi decomposition (8 column blocks over 4 workgroups per instance); sizes
     # that do not divide into equal blocks (132 = 7*17 + 13, 148 = 7*19 + 15), two instances at once (per-agent
     # mode), its invariants, shard-vs-full bit equality.
