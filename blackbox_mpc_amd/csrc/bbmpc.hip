@@ -320,13 +320,13 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
         const int kp = (k + 3) & ~3;
         const size_t lds = (size_t)(Nst + TOPK_HIST_WORDS + 2 * kp) * 4;
         hipLaunchKernelGGL(k_cma_select, dim3(G), dim3(REFIT_THREADS), lds, stream, q);
-        hipLaunchKernelGGL(k_cma_paths, dim3(G), dim3(REFIT_THREADS), 0, stream, q);
+        hipLaunchKernelGGL(k_cma_paths, dim3(G), dim3(n > 128 ? 1024 : REFIT_THREADS), 0, stream, q);
         hipLaunchKernelGGL(k_cma_cov, dim3((n + 15) / 16, (n + 15) / 16, G), dim3(16, 16), 0, stream, q);
         HIP_CHECK(hipGetLastError());
         if (n <= 512 && !sw.cma_svd_v1) {
             // warm-started Jacobi, one 1024-thread workgroup per instance (kernels_cma.hpp)
             HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * 32 * sizeof(unsigned), stream));
-            hipLaunchKernelGGL(k_cma_warm, dim3((unsigned)((n * n + 255) / 256), G), dim3(256), 0, stream, q, c_evec.p);
+            hipLaunchKernelGGL(k_cma_warm, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(256), 0, stream, q, c_evec.p);
             const int bsz = (n + 7) / 8;
             const size_t blds = (size_t)2 * bsz * n * sizeof(float);
             if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 160 * 1024 && G * 4 <= 256 && !sw.cma_svd_rounds) {
@@ -344,9 +344,14 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             } else {
                 if (n <= 128 && !sw.cma_svd_general) {
                     const int pairs = (n + 1) / 2;
-                    if ((size_t)n * n * sizeof(float) > 48 * 1024) ensure_max_lds((const void*)k_cma_svd_small, 96 * 1024);
-                    hipLaunchKernelGGL(k_cma_svd_small, dim3(G), dim3(64 * ((pairs + 3) / 4)), (size_t)n * n * sizeof(float), stream,
-                                       q, c_evec.p, c_sync.p, 15);
+                    if (n <= 64) {
+                        hipLaunchKernelGGL(k_cma_svd_small<4>, dim3(G), dim3(64 * ((pairs + 3) / 4)), (size_t)n * n * sizeof(float), stream,
+                                           q, c_evec.p, c_sync.p, 15);
+                    } else {
+                        if ((size_t)n * n * sizeof(float) > 48 * 1024) ensure_max_lds((const void*)k_cma_svd_small<8>, 96 * 1024);
+                        hipLaunchKernelGGL(k_cma_svd_small<8>, dim3(G), dim3(64 * ((pairs + 3) / 4)), (size_t)n * n * sizeof(float), stream,
+                                           q, c_evec.p, c_sync.p, 15);
+                    }
                 } else {
                 // small n: the matrix fits LDS; a workgroup sized to the number of pairs
                 const size_t rl = (size_t)n * n * sizeof(float) <= 64 * 1024 ? (size_t)n * n * sizeof(float) : 0;
@@ -355,7 +360,7 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                                    (int)(rl / sizeof(float)));
                 }
             }
-            hipLaunchKernelGGL(k_cma_svd_finish, dim3(G), dim3(REFIT_THREADS), 0, stream, q, c_evec.p, c_eval.p, c_info.p);
+            hipLaunchKernelGGL(k_cma_svd_finish, dim3(G), dim3(n > 256 ? 1024 : 256), 0, stream, q, c_evec.p, c_eval.p, c_info.p);
         } else {
             hipLaunchKernelGGL(k_cma_svd, dim3(G), dim3(REFIT_THREADS), 0, stream, q, c_evec.p, c_eval.p, c_info.p, 15);
         }

@@ -137,22 +137,35 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_cma_select(CmaArgs p) {
 
 // per group: elite deviations, weighted mean step, evolution paths, step size, new mean
 // (cma_es.py:161-177).  One workgroup per group; threads stride the n coordinates.
-__global__ __launch_bounds__(REFIT_THREADS) void k_cma_paths(CmaArgs p) {
-    __shared__ float red[REFIT_THREADS / 64];
+__global__ __launch_bounds__(1024) void k_cma_paths(CmaArgs p) {
+    // blockDim: any multiple of 64 up to 1024.  The loops keep several independent loads in flight and the row-wise
+    // product runs one wave per row (coalesced), instead of one L2 latency per term of an n-term sum.
+    __shared__ float red[16];
     __shared__ float s_norm;
-    const int g = blockIdx.x, tid = threadIdx.x, n = p.n;
+    __shared__ int s_el[REFIT_THREADS];
+    __shared__ float s_w[REFIT_THREADS];
+    const int g = blockIdx.x, tid = threadIdx.x, n = p.n, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, NW = nthr >> 6;
     const size_t off = (size_t)g * n;
-    const float* X = p.cand + off * p.Nst;
-    const int* el = p.eidx + g * p.k;
-    float* Ye = p.Ye + (size_t)g * p.k * n;
+    const float* __restrict__ X = p.cand + off * p.Nst;
+    float* __restrict__ Ye = p.Ye + (size_t)g * p.k * n;
+    for (int i = tid; i < p.k; i += nthr) { s_el[i] = p.eidx[g * p.k + i]; s_w[i] = p.weights[i]; }
+    __syncthreads();
     // x_diff, x_mean, y_mean, Ye
-    for (int c = tid; c < n; c += REFIT_THREADS) {
+    for (int c = tid; c < n; c += nthr) {
         const float mc = p.m[off + c], sc = p.sigma[off + c];
         float xm = 0.0f;
-        for (int i = 0; i < p.k; ++i) {
-            const float xd = X[(size_t)c * p.Nst + el[i]] - mc;           // :161
-            xm = xm + xd * p.weights[i];                                   // :162
-            Ye[(size_t)i * n + c] = xd / sc;                               // :180
+        for (int i0 = 0; i0 < p.k; i0 += 8) {
+            float xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xv[q] = (i0 + q < p.k) ? X[(size_t)c * p.Nst + s_el[i0 + q]] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (i0 + q < p.k) {
+                    const float xd = xv[q] - mc;                                 // :161
+                    xm = xm + xd * s_w[i0 + q];                                  // :162
+                    Ye[(size_t)(i0 + q) * n + c] = xd / sc;                      // :180
+                }
+            }
         }
         p.xmean[off + c] = xm;
         p.ymean[off + c] = xm / sc;                                        // :167
@@ -160,36 +173,50 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_cma_paths(CmaArgs p) {
     __syncthreads();
     // t1 = B^T y_mean ; t2 = t1 / diag(D)   (C^{-1/2} y = B D^{-1} B^T y, :168-169)
     float* t2 = p.BD + (size_t)g * n * n;      // BD scratch is free after the sampling GEMM
-    const float* B = p.B + (size_t)g * n * n;
-    for (int j = tid; j < n; j += REFIT_THREADS) {
+    const float* __restrict__ B = p.B + (size_t)g * n * n;
+    const float* __restrict__ ym = p.ymean + off;
+    for (int j = tid; j < n; j += nthr) {
         float s = 0.0f;
-        for (int i = 0; i < n; ++i) s = fmaf(B[(size_t)i * n + j], p.ymean[off + i], s);
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            float bv[8], yv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = min(i0 + q, n - 1);
+                bv[q] = B[(size_t)i * n + j];
+                yv[q] = ym[i];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (i0 + q < n) s = fmaf(bv[q], yv[q], s);
+        }
         t2[j] = s * (1.0f / p.Dd[off + j]);
     }
     __syncthreads();
     const float cs = p.c.c_sigma, cc = p.c.cc;
     const float coef_s = sqrtf((cs * (2.0f - cs)) * p.c.mu_eff);
     const float coef_c = p.c.h_sigma * sqrtf((cc * (2.0f - cc)) * p.c.mu_eff);
+    // s_i = sum_j B[i][j] t2[j]: one wave per row i, lanes along j (64-lane partial sums in j order, then the wave reduction)
     float part = 0.0f;
-    for (int i = tid; i < n; i += REFIT_THREADS) {
+    for (int i = wv; i < n; i += NW) {
         float s = 0.0f;
-        for (int j = 0; j < n; ++j) s = fmaf(B[(size_t)i * n + j], t2[j], s);
-        const float ps = (1.0f - cs) * p.p_sigma[off + i] + coef_s * s;    // :170-171
-        p.p_sigma[off + i] = ps;
-        part += ps * ps;
-        p.p_C[off + i] = (1.0f - cc) * p.p_C[off + i] + coef_c * p.ymean[off + i];   // :177
+        for (int j = lane; j < n; j += 64) s = fmaf(B[(size_t)i * n + j], t2[j], s);
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float ps = (1.0f - cs) * p.p_sigma[off + i] + coef_s * s;    // :170-171
+            p.p_sigma[off + i] = ps;
+            part += ps * ps;
+            p.p_C[off + i] = (1.0f - cc) * p.p_C[off + i] + coef_c * ym[i];    // :177
+        }
     }
-    part = wave_sum(part);
-    if ((tid & 63) == 0) red[tid >> 6] = part;
+    if (lane == 0) red[wv] = part;
     __syncthreads();
     if (tid == 0) {
         float s = 0.0f;
-        for (int w = 0; w < REFIT_THREADS / 64; ++w) s += red[w];
+        for (int w = 0; w < NW; ++w) s += red[w];
         s_norm = sqrtf(s);
     }
     __syncthreads();
     const float fac = expf((cs / p.c.d_sigma) * (s_norm / p.c.e_norm - 1.0f));   // :172-173
-    for (int c = tid; c < n; c += REFIT_THREADS) {
+    for (int c = tid; c < n; c += nthr) {
         p.sigma[off + c] = p.sigma[off + c] * fac;
         p.m[off + c] = p.m[off + c] + p.xmean[off + c];                    // :163
     }
@@ -303,16 +330,40 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_cma_svd(CmaArgs p, float* At_
 //    ~10 us for the whole round in one workgroup, so WPG = 1 is what the engine launches.
 // k_cma_warm: At[j][:] = C * B0[:, j] (C symmetric => coalesced along the column);  k_cma_svd_rounds: the sweeps;
 // k_cma_svd_finish: norms, descending order, B and D.
-__global__ void k_cma_warm(CmaArgs p, float* At_all) {
-    const int g = blockIdx.y, n = p.n;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * n) return;
-    const int j = idx / n, e = idx % n;
+__global__ __launch_bounds__(256) void k_cma_warm(CmaArgs p, float* At_all) {
+    // At[j][e] = sum_k C[k][e] * B[k][j]: 32x32 output tile per workgroup, K staged through LDS in slabs of 32,
+    // each thread owns a 2x2 micro tile.  grid (ceil(n/32), ceil(n/32), G), block 256 = 16 x 16
+    __shared__ float sC[32][33], sB[32][33];
+    const int g = blockIdx.z, n = p.n;
+    const int e0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const float* C = p.C + (size_t)g * n * n;
     const float* B = p.B + (size_t)g * n * n;
-    float acc = 0.0f;
-    for (int k = 0; k < n; ++k) acc = fmaf(C[(size_t)k * n + e], B[(size_t)k * n + j], acc);
-    At_all[(size_t)g * n * n + idx] = acc;
+    float acc[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+    for (int k0 = 0; k0 < n; k0 += 32) {
+        for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+            const int kk = i >> 5, c = i & 31;
+            sC[kk][c] = (k0 + kk < n && e0 + c < n) ? C[(size_t)(k0 + kk) * n + e0 + c] : 0.0f;
+            sB[kk][c] = (k0 + kk < n && j0 + c < n) ? B[(size_t)(k0 + kk) * n + j0 + c] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            const float c0 = sC[kk][tx], c1 = sC[kk][tx + 16];
+            const float b0 = sB[kk][ty], b1 = sB[kk][ty + 16];
+            acc[0][0] = fmaf(c0, b0, acc[0][0]); acc[0][1] = fmaf(c1, b0, acc[0][1]);
+            acc[1][0] = fmaf(c0, b1, acc[1][0]); acc[1][1] = fmaf(c1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+    float* At = At_all + (size_t)g * n * n;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int ee = 0; ee < 2; ++ee) {
+            const int j = j0 + ty + 16 * jj, e = e0 + tx + 16 * ee;
+            if (j < n && e < n) At[(size_t)j * n + e] = acc[jj][ee];
+        }
 }
 
 __device__ __forceinline__ void cma_instance_barrier(unsigned* ctr, unsigned target) {
@@ -433,9 +484,11 @@ __global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_al
     }
 }
 
-__global__ __launch_bounds__(REFIT_THREADS) void k_cma_svd_finish(CmaArgs p, const float* At_all, float* norms_all, int* perm_all) {
-    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
-    constexpr int NW = REFIT_THREADS / 64;
+__global__ __launch_bounds__(1024) void k_cma_svd_finish(CmaArgs p, const float* At_all, float* norms_all, int* perm_all) {
+    // column norms = singular values; ranks by counting over an LDS copy of the norms (n <= 2048); B, D.  blockDim any multiple of 64
+    __shared__ float s_norm[2048];
+    __shared__ int s_perm[2048];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n, nthr = blockDim.x, NW = nthr >> 6;
     const size_t nn = (size_t)n * n;
     const float* At = At_all + (size_t)g * nn;
     float* norms = norms_all + (size_t)g * n;
@@ -444,24 +497,25 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_cma_svd_finish(CmaArgs p, con
         float al = 0.0f;
         for (int e = lane; e < n; e += 64) { const float v = At[(size_t)j * n + e]; al = fmaf(v, v, al); }
         al = wave_sum(al);
-        if (lane == 0) norms[j] = sqrtf(al);
+        if (lane == 0) { const float nj = sqrtf(al); s_norm[j] = nj; norms[j] = nj; }
     }
     __syncthreads();
-    for (int j = tid; j < n; j += REFIT_THREADS) {
-        const float nj = norms[j];
+    for (int j = tid; j < n; j += nthr) {
+        const float nj = s_norm[j];
         int rank = 0;
-        for (int o = 0; o < n; ++o) rank += (norms[o] > nj || (norms[o] == nj && o < j)) ? 1 : 0;
+        for (int o = 0; o < n; ++o) { const float no = s_norm[o]; rank += (no > nj || (no == nj && o < j)) ? 1 : 0; }
+        s_perm[rank] = j;
         perm[rank] = j;
     }
     __syncthreads();
     float* B = p.B + (size_t)g * nn;
-    for (size_t i = tid; i < nn; i += REFIT_THREADS) {
+    for (size_t i = tid; i < nn; i += nthr) {
         const int r = (int)(i / n), c = (int)(i % n);
-        const int src = perm[c];
-        const float sv = norms[src];
+        const int src = s_perm[c];
+        const float sv = s_norm[src];
         B[i] = (sv > 0.0f) ? At[(size_t)src * n + r] / sv : ((r == c) ? 1.0f : 0.0f);
     }
-    for (int c = tid; c < n; c += REFIT_THREADS) p.Dd[(size_t)g * n + c] = sqrtf(norms[perm[c]]);   // D = diag(sqrt(s))
+    for (int c = tid; c < n; c += nthr) p.Dd[(size_t)g * n + c] = sqrtf(s_norm[s_perm[c]]);   // D = diag(sqrt(s))
 }
 
 // ---- Block Jacobi: the columns are cut into 8 blocks; 4 workgroups per instance each hold one PAIR of blocks in
@@ -663,6 +717,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
 // column pair (up to eight elements per lane), rcp / rsq rotation scalars as in the block kernel.  A round is ~40
 // instructions per wave + one barrier; the general kernels above spend ~1 us per round on predicated 512-wide code.
 // LDS: n*n floats.  blockDim = 64 * ceil(pairs / 4).  sync: [G][32] as above (sweep flags only).
+template <int EC>   // elements per lane: 4 (n <= 64) or 8 (n <= 128)
 __global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
     extern __shared__ __attribute__((aligned(16))) float at_s[];
     __shared__ int s_rot;
@@ -687,9 +742,9 @@ __global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all
             }
             float* x = at_s + (size_t)(act ? pa : 0) * n;
             float* y = at_s + (size_t)(act ? pb : 0) * n;
-            float xv[8], yv[8], al = 0.0f, be = 0.0f, ga = 0.0f;
+            float xv[EC], yv[EC], al = 0.0f, be = 0.0f, ga = 0.0f;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < EC; ++c) {
                 if (c < nc) {
                     const int e = sub + 16 * c;
                     xv[c] = (act && e < n) ? x[e] : 0.0f;
@@ -706,7 +761,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all
                 cs = cs * fmaf(-0.5f * w * cs, cs, 1.5f);
                 const float sn = cs * t;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
+                for (int c = 0; c < EC; ++c) {
                     const int e = sub + 16 * c;
                     if (c < nc && e < n) {
                         x[e] = cs * xv[c] - sn * yv[c];
