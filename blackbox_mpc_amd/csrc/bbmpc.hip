@@ -258,7 +258,7 @@ void Engine::cma_init() {
     c_Ye.alloc((size_t)G * k * n);
     c_eidx.alloc((size_t)G * k);
     c_info.alloc(gn);           // SVD: column permutation
-    c_sync.alloc((size_t)G * 32);
+    c_sync.alloc((size_t)G * CMA_SYNC_WORDS);
     // C = B = D = I, paths = 0 (cma_es.py:98-117)
     std::vector<float> eye(gnn, 0.0f), ones(gn, 1.0f);
     for (int g = 0; g < G; ++g)
@@ -325,13 +325,13 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
         HIP_CHECK(hipGetLastError());
         if (n <= 512 && !sw.cma_svd_v1) {
             // warm-started Jacobi, one 1024-thread workgroup per instance (kernels_cma.hpp)
-            HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * 32 * sizeof(unsigned), stream));
+            HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * CMA_SYNC_WORDS * sizeof(unsigned), stream));
             hipLaunchKernelGGL(k_cma_warm, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(256), 0, stream, q, c_evec.p);
             const int bsz = (n + 7) / 8;
             const size_t blds = (size_t)2 * bsz * n * sizeof(float);
-            if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 160 * 1024 && G * 4 <= 256 && !sw.cma_svd_rounds) {
+            if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 159 * 1024 && G * 4 <= 256 && !sw.cma_svd_rounds) {
                 // block Jacobi: 4 workgroups per instance, block pairs resident in LDS, 7 instance barriers per sweep
-                ensure_max_lds((const void*)k_cma_svd_block, 160 * 1024);
+                ensure_max_lds((const void*)k_cma_svd_block, 159 * 1024);     // + a few static words
                 // cooperative launch: the instance barrier spins, so every workgroup of the grid must be resident at
                 // once -- the runtime checks that and orders the launch against other cooperative grids
                 {

@@ -397,7 +397,9 @@ __device__ __forceinline__ void cma_instance_barrier_light(unsigned* ctr, unsign
     __syncthreads();
 }
 
-// sync: [G][32] unsigned: [0] barrier counter, [1 + sweep] "some pair rotated in this sweep"
+constexpr int CMA_SYNC_WORDS = 128;
+// sync: [G][CMA_SYNC_WORDS] unsigned: [0] barrier counter, [1 + sweep] "some pair rotated in this sweep"; the block kernel keeps
+// its block-pair bookkeeping in words 32..111
 __global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps, int lds_floats) {
     const int g = blockIdx.y, WPG = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
     const int NW = blockDim.x >> 6;
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_al
         for (int i = tid; i < n * n; i += blockDim.x) at_lds[i] = At_g[i];
         __syncthreads();
     }
-    unsigned* sync = sync_all + (size_t)g * 32;
+    unsigned* sync = sync_all + (size_t)g * CMA_SYNC_WORDS;
     const int gw = blockIdx.x * NW + wv, nwaves = WPG * NW;
     const int m = (n + 1) & ~1;                 // players of the round-robin (one dummy when n is odd)
     unsigned bar = 0;
@@ -531,7 +533,15 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
     const int NW = blockDim.x >> 6;
     const int bs = (n + NB - 1) / NB;                       // columns per block (the last block may be short)
     float* At = At_all + (size_t)g * n * n;
-    unsigned* sync = sync_all + (size_t)g * 32;
+    unsigned* sync = sync_all + (size_t)g * CMA_SYNC_WORDS;
+    // Block-pair bookkeeping (all zero at launch): a pair of blocks that was checked without a single rotation stays
+    // clean until one of its blocks changes, so late sweeps -- and the final verification sweep entirely -- skip it.
+    //   ver[b] + 1 = version of block b; iseen[b] = version at which block b's inner pairs were last found clean;
+    //   pseen[min*8+max] = (version of the lower block << 16 | version of the higher block) at the last clean check
+    unsigned* ver = sync + 32;
+    unsigned* iseen = sync + 40;
+    unsigned* pseen = sync + 48;
+    __shared__ int s_skip[3], s_rotf[3];          // [0] cross pairs, [1] inner pairs of block x, [2] of block y
     const float tol = fminf(fmaxf(3.0e-8f * (float)n, 2.0e-6f), 1.0e-5f);
     unsigned bar = 0;
 
@@ -580,6 +590,20 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             else { bx = (R + wg) % (NB - 1); by = (R - wg + (NB - 1)) % (NB - 1); }
             const int x0 = bx * bs, y0 = by * bs;
             const int nx = max(0, min(bs, n - x0)), ny = max(0, min(bs, n - y0));
+            const int blo = min(bx, by), bhi = max(bx, by);
+            unsigned vx = 0, vy = 0;
+            if (tid == 0) {
+                vx = __hip_atomic_load(ver + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                vy = __hip_atomic_load(ver + by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                const unsigned packed = ((bx < by ? vx : vy) << 16) | (bx < by ? vy : vx);
+                s_skip[0] = __hip_atomic_load(pseen + blo * 8 + bhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == packed;
+                s_skip[1] = R != 0 || __hip_atomic_load(iseen + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == vx;
+                s_skip[2] = R != 0 || __hip_atomic_load(iseen + by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == vy;
+                s_rotf[0] = s_rotf[1] = s_rotf[2] = 0;
+            }
+            __syncthreads();
+            const bool skip_cross = s_skip[0] != 0, skip_ix = s_skip[1] != 0, skip_iy = s_skip[2] != 0;
+            if (!(skip_cross && skip_ix && skip_iy)) {
             // ---- load the two blocks (columns are rows of At: contiguous)
             // whole columns per wave (no index divisions), all of a wave's loads issued before the first LDS write
             for (int c0 = wv; c0 < nx + ny; c0 += 4 * NW) {
@@ -609,17 +633,21 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             // ---- pairs inside each block, once per sweep (block round 0 has every block in some workgroup)
             if (R == 0) {
                 for (int blk = 0; blk < 2; ++blk) {
+                    if (blk ? skip_iy : skip_ix) continue;
                     const int base = blk ? nx : 0, cnt = blk ? ny : nx;
                     const int m = (cnt + 1) & ~1;
+                    bool rot_here = false;
                     for (int r = 0; r < m - 1; ++r) {
                         for (int i = wv; i < m / 2; i += NW) {
                             int pa, pb;
                             if (i == 0) { pa = m - 1; pb = r; }
                             else { pa = (r + i) % (m - 1); pb = (r - i + (m - 1)) % (m - 1); }
-                            if (pa < cnt && pb < cnt) rotated |= rotate(base + pa, base + pb);
+                            if (pa < cnt && pb < cnt) rot_here |= rotate(base + pa, base + pb);
                         }
                         __syncthreads();
                     }
+                    if (rot_here && lane == 0) s_rotf[1 + blk] = 1;
+                    rotated |= rot_here;
                 }
             }
             SVDB_MARK(1);
@@ -630,7 +658,8 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             // rotation scalars use the hardware rcp / rsq (+ one Newton step where orthogonality depends on it):
             // the round is instruction-issue bound, IEEE divide / sqrt expansions were half of it.
             const int mm = max(nx, ny);
-            {
+            if (!skip_cross) {
+                bool rot_cross = false;
                 constexpr int EC = 8;                                // float4 chunks per lane: n <= 512
                 const int sub = lane & 15, row = wv * 4 + (lane >> 4), nc = (n + 63) >> 6;
                 const bool has_x = row < nx, wave_on = wv * 4 < nx;
@@ -682,7 +711,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                                     if (e < n) *reinterpret_cast<float4*>(y + e) = yn;
                                 }
                             }
-                            rotated = true;
+                            rot_cross = true;
                         }
                     }
                     __syncthreads();
@@ -692,14 +721,32 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                     const int e = 4 * (sub + 16 * c);
                     if (c < nc && has_x && e < n) *reinterpret_cast<float4*>(cols + (size_t)row * n + e) = xr[c];
                 }
+                if (rot_cross && sub == 0) s_rotf[0] = 1;
+                rotated |= rot_cross;
                 __syncthreads();
             }
             SVDB_MARK(2);
-            // ---- write back
-            for (int c = wv; c < nx + ny; c += NW) {
-                float* dst = At + (size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n;
-                for (int e = lane; e < n; e += 64) coh_store(dst + e, cols[(size_t)c * n + e]);
+            __syncthreads();
+            const bool rc = s_rotf[0] != 0, rix = s_rotf[1] != 0, riy = s_rotf[2] != 0;
+            // ---- write back what changed
+            if (rc || rix || riy) {
+                for (int c = wv; c < nx + ny; c += NW) {
+                    if (c < nx ? !(rc || rix) : !(rc || riy)) continue;
+                    float* dst = At + (size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n;
+                    for (int e = lane; e < n; e += 64) coh_store(dst + e, cols[(size_t)c * n + e]);
+                }
             }
+            if (tid == 0) {
+                const unsigned nvx = vx + ((rc || rix) ? 1u : 0u), nvy = vy + ((rc || riy) ? 1u : 0u);
+                if (rc || rix) __hip_atomic_store(ver + bx, nvx - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (rc || riy) __hip_atomic_store(ver + by, nvy - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!skip_ix && !rix && !rc) __hip_atomic_store(iseen + bx, nvx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!skip_iy && !riy && !rc) __hip_atomic_store(iseen + by, nvy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!skip_cross && !rc)
+                    __hip_atomic_store(pseen + blo * 8 + bhi, ((bx < by ? nvx : nvy) << 16) | (bx < by ? nvy : nvx), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            }   // not everything skipped
             if (R == NB - 2 && rotated && lane == 0) __hip_atomic_store(sync + 1 + sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             SVDB_MARK(3);
             ++bar;
