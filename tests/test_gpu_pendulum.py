@@ -201,7 +201,8 @@ def _cem_lockstep(L, eng, states, noise, N, A, H, iters, k, alpha):
     return cem
 
 
-@pytest.mark.parametrize("N,A,H,iters,k", [(500, 1, 30, 5, 50), (200, 3, 12, 3, 20), (64, 2, 5, 2, 64)])
+@pytest.mark.parametrize("N,A,H,iters,k", [(500, 1, 30, 5, 50), (200, 3, 12, 3, 20), (64, 2, 5, 2, 64), (300, 2, 9, 3, 100),
+                                           (1500, 1, 6, 2, 70)])
 def test_cem_injected_noise_lockstep(L, N, A, H, iters, k):
     alpha = 0.25
     eng = _engine(L, L.OPT_CEM, A, H, N=N, iters=iters, k=k, alpha=alpha)
