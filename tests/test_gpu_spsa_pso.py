@@ -30,7 +30,7 @@ def _engine(L, opt, A, H, N, iters, **kw):
 
 
 @pytest.mark.parametrize("fused", ["1", "0"])
-@pytest.mark.parametrize("N,A,H,iters", [(500, 1, 30, 5), (130, 3, 7, 3)])
+@pytest.mark.parametrize("N,A,H,iters", [(500, 1, 30, 5), (130, 3, 7, 3), (64, 1, 5, 17)])     # 17 iterations: beyond the persistent kernel's table
 def test_spsa_injected_noise(L, monkeypatch, N, A, H, iters, fused):
     # both device paths: the persistent one-launch kernel (two candidates per lane) and the per-iteration kernels
     monkeypatch.setenv("BBMPC_FUSED", fused)
