@@ -419,28 +419,36 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             __syncthreads();
             action0 = mean[0];                                                   // cem.py:135
         } else if (OPT == FOPT_PI2) {
+            // pi2.py:78-87.  Cross-wave reductions use their own LDS slots (no second barrier to recycle them) and the
+            // per-wave slots are combined by every wave with one LDS round trip + a DPP reduction.
             float lmin = INFINITY;
             for (int n = tid; n < p.N; n += nthr) {
                 const float c = -rew[n];                                         // pi2.py:78
                 rew[n] = c;
                 lmin = fminf(lmin, c);
             }
-            const float beta = block_min(lmin, red, tid, nw);                    // pi2.py:81
+            lmin = wave_min(lmin);
+            if ((tid & 63) == 0) red[tid >> 6] = lmin;
+            __syncthreads();
+            float beta = ((tid & 63) < nw) ? red[tid & 63] : INFINITY;
+            beta = wave_min(beta);                                               // pi2.py:81
             float lsum = 0.0f;
             for (int n = tid; n < p.N; n += nthr) {
                 const float pr = expf((-p.inv_lamda) * (rew[n] - beta));         // pi2.py:82
                 rew[n] = pr;
                 lsum += pr;
             }
-            const float eta = block_sum(lsum, red, tid, nw);                     // pi2.py:83
-            const float inv_eta = 1.0f / eta;
-            for (int n = tid; n < p.N; n += nthr) rew[n] = inv_eta * rew[n];      // pi2.py:85
+            lsum = wave_sum(lsum);
+            if ((tid & 63) == 0) red[32 + (tid >> 6)] = lsum;
             __syncthreads();
-            // new_mean[j] = sum_n x[j][n] * omega[n]   (pi2.py:86-87): one wave per j
+            float eta = ((tid & 63) < nw) ? red[32 + (tid & 63)] : 0.0f;
+            eta = wave_sum(eta);                                                 // pi2.py:83
+            const float inv_eta = 1.0f / eta;
+            // new_mean[j] = sum_n x[j][n] * omega[n],  omega = inv_eta * prob   (pi2.py:85-87): one wave per j
             for (int j = tid >> 6; j < p.HU; j += nw) {
                 const float* row = samp + (size_t)j * p.Nst;
                 float acc = 0.0f;
-                for (int n = tid & 63; n < p.N; n += 64) acc += row[n] * rew[n];
+                for (int n = tid & 63; n < p.N; n += 64) acc += row[n] * (inv_eta * rew[n]);
                 acc = wave_sum(acc);
                 if ((tid & 63) == 0) mean[j] = acc;
             }
