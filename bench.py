@@ -69,8 +69,14 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # BBMPC_BENCH_FORCE_DIST=1: run the per-step all-gather path in a one-rank group (what it costs on a 1-GPU box)
+    use_dist = world > 1 or bool(os.environ.get("BBMPC_BENCH_FORCE_DIST"))
+    # how the per-step record all-gather is issued under the nccl backend: "native" = the engine's own RCCL
+    # communicator and stream (bbmpc_gather_records_dev); "async" / "events" = torch.distributed, for comparison
+    gather_mode = os.environ.get("BBMPC_BENCH_GATHER", "native")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -81,7 +87,7 @@ def main():
     if local == 0 or os.environ.get("BBMPC_BENCH_ONE_DEVICE"):
         if rank == 0 or not os.environ.get("BBMPC_BENCH_ONE_DEVICE"):
             _build.build()                   # one builder per node; the others wait for it
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from blackbox_mpc_amd import _lib as L
     from blackbox_mpc_amd.engine import Engine
@@ -108,6 +114,23 @@ def main():
                      num_agents_global=world * A, device=local, quirks=quirks)
         start = O.pendulum_start_states(A, agent_offset=rank * A)
     eng.reset()                      # episode start, as utils/rollouts.py:_sample does (PSO draws its swarm here)
+    native_gather = use_dist and backend == "nccl" and gather_mode == "native"
+    if native_gather:
+        # the engine's own RCCL communicator + stream; every rank must agree on whether it came up
+        from blackbox_mpc_amd.parallel import attach_record_comm
+        ok = torch.ones(1, device=dev)
+        try:
+            attach_record_comm(eng, device=dev)
+        except Exception as ex:                       # e.g. librccl not loadable: use torch.distributed's collective
+            print("bench: native record gather unavailable (%s); using torch.distributed" % ex, file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
+            native_gather, gather_mode = False, "async"
+            try:
+                eng.comm_destroy()
+            except Exception:
+                pass
     rec = U + S + 1
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
@@ -117,9 +140,12 @@ def main():
     # records / gathered results are double buffered: the all-gather of control step t runs on its own stream
     # while step t+1 computes (the local optimizer never needs the other ranks' records)
     records = [torch.zeros((A, rec), device=dev, dtype=torch.float32) for _ in range(2)]
-    gathered = [torch.zeros((world * A, rec), device=dev, dtype=torch.float32) for _ in range(2)] if world > 1 else None
-    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    gathered = [torch.zeros((world * A, rec), device=dev, dtype=torch.float32) for _ in range(2)] if use_dist else None
+    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
     comm_done = [None, None]
+    ready_ev = [torch.cuda.Event(), torch.cuda.Event()] if use_dist else None
+    done_ev = [torch.cuda.Event(), torch.cuda.Event()] if use_dist else None
+    works = [None, None]
     tick = [0]
 
     def control_step():
@@ -127,29 +153,46 @@ def main():
         b = tick[0] & 1
         tick[0] += 1
         record = records[b]
+        if native_gather:
+            # control step + hand-off of its records to the all-gather on the engine's communication stream; the
+            # wait is for the gather that last used this slot's buffers, two steps ago (normally a host-side check)
+            eng.gather_wait(b)
+            eng.optimize_gather_dev(state.data_ptr(), record.data_ptr(), gathered[b].data_ptr(), b,
+                                    d_next_state=nxt.data_ptr())
+            state, nxt = nxt, state
+            return
+        if works[b] is not None:
+            works[b].wait()                          # stream-level: the gather that last read this buffer has finished
+            works[b] = None
         if comm_done[b] is not None:
-            stream.wait_event(comm_done[b])          # the gather that last read this buffer has finished
+            stream.wait_event(comm_done[b])
         # closed loop: the environment is the engine's own model, so the predicted next state
         # the control step already produced IS the next observation -- it never leaves HBM.
         eng.optimize_dev(state.data_ptr(), record.data_ptr(), d_next_state=nxt.data_ptr())
-        if world > 1:
-            ready = torch.cuda.Event()
-            ready.record(stream)
-            comm_stream.wait_event(ready)
-            with torch.cuda.stream(comm_stream):
-                if backend == "nccl":
-                    dist.all_gather_into_tensor(gathered[b], record)
-                else:
-                    out = torch.empty((world * A, rec), dtype=torch.float32)
-                    dist.all_gather_into_tensor(out, record.cpu())
-                    gathered[b].copy_(out)
-                comm_done[b] = torch.cuda.Event()
-                comm_done[b].record(comm_stream)
+        if use_dist:
+            if backend == "nccl" and gather_mode == "async":
+                # the process group's own stream waits for this stream, runs the collective, and is only joined
+                # again (works[b].wait()) when this record buffer is about to be overwritten two steps later
+                works[b] = dist.all_gather_into_tensor(gathered[b], record, async_op=True)
+            else:
+                ready_ev[b].record(stream)
+                comm_stream.wait_event(ready_ev[b])
+                with torch.cuda.stream(comm_stream):
+                    if backend == "nccl":
+                        dist.all_gather_into_tensor(gathered[b], record)
+                    else:
+                        out = torch.empty((world * A, rec), dtype=torch.float32)
+                        dist.all_gather_into_tensor(out, record.cpu())
+                        gathered[b].copy_(out)
+                    done_ev[b].record(comm_stream)
+                    comm_done[b] = done_ev[b]
         state, nxt = nxt, state
 
     def fence():
+        if native_gather:
+            eng.synchronize()                        # launch stream + the engine's communication stream
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -170,7 +213,7 @@ def main():
     eng.set_profiling(False)
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
@@ -181,6 +224,13 @@ def main():
         control_step()
     fence()
     t3 = time.perf_counter()
+
+    if use_dist:
+        # the gathered rows of this rank's own agents must be the records it produced
+        for b in range(2):
+            mine = gathered[b][rank * A:(rank + 1) * A]
+            assert torch.equal(mine.view(torch.int32), records[b].view(torch.int32)), \
+                "all-gather returned different records for the local agents: %r vs %r" % (mine, records[b])
 
     if rank == 0:
         total_agents = world * A
@@ -239,8 +289,10 @@ def main():
                                    "device" % (args.config, "HalfCheetah(mod) S=20 U=6 learned MLP dynamics" if mlp
                                                else "Pendulum-v0 true dynamics", c["opt"], A, N, H, iters,
                                                (", k=%d" % k) if k else ""),
-                       "parallelism": "agents sharded %d/GPU, 1 RCCL all-gather of [A,%d] per control step" % (A, rec)
-                       if world > 1 else "single GPU"},
+                       "parallelism": "agents sharded %d/GPU, 1 RCCL all-gather of [A,%d] per control step (%s)"
+                                      % (A, rec, "engine-owned communicator + stream" if native_gather
+                                         else "torch.distributed " + gather_mode)
+                       if use_dist else "single GPU"},
             "candidate_trajectories_per_sec": steps_per_s * N * iters,
             "dyn_steps_per_sec": steps_per_s * N * iters * H,
             "ms_per_step_uninstrumented": (t3 - t2) / args.steps * 1e3,
@@ -249,7 +301,10 @@ def main():
         if not args.no_cpu_baseline and world == 1 and c["opt"] in ("RandomSearch", "CEM", "PI2"):
             out["cpu_baseline"] = cpu_baseline(O, c, H, N, A, iters, k)
         print(json.dumps(out))
-    if world > 1:
+    if native_gather:
+        eng.synchronize()
+        eng.comm_destroy()
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -61,7 +61,10 @@ SYMBOLS = [
     "bbmpc_evaluate_dev", "bbmpc_predict_next_state", "bbmpc_evaluate_next_reward", "bbmpc_step_dev",
     "bbmpc_inject_noise", "bbmpc_dump_noise", "bbmpc_set_trace", "bbmpc_get_trace", "bbmpc_get_state",
     "bbmpc_set_state", "bbmpc_set_profiling", "bbmpc_get_profile", "bbmpc_synchronize", "bbmpc_rollout_episode",
+    "bbmpc_comm_unique_id", "bbmpc_comm_init", "bbmpc_gather_records_dev", "bbmpc_gather_wait", "bbmpc_comm_destroy",
+    "bbmpc_optimize_gather_dev",
 ]
+COMM_ID_BYTES = 128
 
 
 def _load():
@@ -106,6 +109,12 @@ def _load():
                                       ctypes.POINTER(ctypes.c_char_p)]
     lib.bbmpc_synchronize.argtypes = [vp]
     lib.bbmpc_rollout_episode.argtypes = [vp, vp, i32, i32, vp]
+    lib.bbmpc_comm_unique_id.argtypes = [vp, i64]
+    lib.bbmpc_comm_init.argtypes = [vp, vp, i32, i32]
+    lib.bbmpc_gather_records_dev.argtypes = [vp, vp, vp, i64, i32]
+    lib.bbmpc_gather_wait.argtypes = [vp, i32, i32]
+    lib.bbmpc_optimize_gather_dev.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32]
+    lib.bbmpc_comm_destroy.argtypes = [vp]
     return lib
 
 

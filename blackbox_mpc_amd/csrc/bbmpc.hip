@@ -4,8 +4,10 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <chrono>
 #include <mutex>
 #include <set>
+#include <thread>
 #include <utility>
 
 namespace bbmpc {
@@ -113,6 +115,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         REQUIRE(c.device < ndev, BBMPC_E_NO_DEVICE, "bbmpc_config.device out of range");
         HIP_CHECK(hipSetDevice(c.device));
     }
+    HIP_CHECK(hipGetDevice(&device));
     HIP_CHECK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
     stream = own_stream;
     init_tnq_table();
@@ -185,6 +188,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
 
 Engine::~Engine() {
     if (own_stream) (void)hipStreamSynchronize(own_stream);
+    rc.destroy();
     if (pf_stream) {
         (void)hipStreamSynchronize(pf_stream);
         (void)hipStreamDestroy(pf_stream);
@@ -747,6 +751,19 @@ bool Engine::use_fused() const {
     return (long)N <= 2048 || A >= 64;
 }
 
+// Launch the last kernel of a control step.  When the caller asked for a completion event (the record all-gather
+// waits on it from its own stream) the event rides on the kernel's own dispatch packet: a separate
+// hipEventRecord costs the launch stream ~5 us per control step (tools/gather_overhead.py).
+template <class F, class Args>
+static void launch_with_tail(Engine& e, F fn, dim3 grid, dim3 block, size_t lds, const Args& args) {
+    if (e.tail_event) {
+        hipExtLaunchKernelGGL(fn, grid, block, lds, e.stream, nullptr, e.tail_event, 0, args);
+        e.tail_attached = true;
+    } else {
+        hipLaunchKernelGGL(fn, grid, block, lds, e.stream, args);
+    }
+}
+
 template <int OPT, bool FASTM, int INJ, int ILP>
 static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
 #ifdef BBMPC_KERNEL_DBG
@@ -757,10 +774,10 @@ static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base
     if (lds_base + lds_samples <= limit) {
         auto fn = k_fused_pendulum<OPT, true, FASTM, INJ, ILP>;
         ensure_max_lds((const void*)fn, (int)limit);
-        hipLaunchKernelGGL(fn, dim3(e.A), dim3(threads), lds_base + lds_samples, e.stream, fa);
+        launch_with_tail(e, fn, dim3(e.A), dim3(threads), lds_base + lds_samples, fa);
     } else {
         auto fn = k_fused_pendulum<OPT, false, FASTM, INJ, ILP>;
-        hipLaunchKernelGGL(fn, dim3(e.A), dim3(threads), lds_base, e.stream, fa);
+        launch_with_tail(e, fn, dim3(e.A), dim3(threads), lds_base, fa);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -822,6 +839,10 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     fa.add_noise = add_noise;
     fa.warm_start = fix(BBMPC_FIX_Q2_CEM_WARM_START);
     fa.balance = sw.balance;
+    if (tail_flag) {
+        fa.done_flag = tail_flag; fa.done_count = rc.count; fa.done_value = tail_value;
+        tail_attached = true;
+    }
     fa.alpha = cfg.alpha;
     fa.inv_lamda = 1.0f / cfg.lamda;
     fa.state = d_state_in;
@@ -1115,6 +1136,10 @@ void Engine::optimize_fused_pso(const float* d_state_in, int add_noise, float* d
     fa.fix_q7 = fix(BBMPC_FIX_Q7_EXPL_NOISE_ZERO_MEAN);
     fa.add_noise = add_noise;
     fa.w = cfg.pso_w; fa.c1 = cfg.pso_c1; fa.c2 = cfg.pso_c2; fa.v0frac = cfg.pso_v0_fraction;
+    if (tail_flag) {             // the records are complete when this kernel ends (k_pso_seed only re-seeds the swarm)
+        fa.done_flag = tail_flag; fa.done_count = rc.count; fa.done_value = tail_value;
+        tail_attached = true;
+    }
     fa.state = d_state_in;
     fa.lo = d_lo.p; fa.hi = d_hi.p; fa.var0 = d_var0.p;
     fa.s = pso_state();
@@ -1446,6 +1471,8 @@ void Engine::set_state(const std::string& name, const float* data, int64_t count
 // ================================================================================================
 using bbmpc::Engine;
 using bbmpc::HipError;
+using bbmpc::Rccl;
+using bbmpc::RecordComm;
 
 struct bbmpc_handle_s {
     Engine* e;
@@ -1738,6 +1765,208 @@ int bbmpc_synchronize(bbmpc_handle h) {
     API_BEGIN
     CHECK_HANDLE(h);
     HIP_CHECK(hipStreamSynchronize(h->e->stream));
+    if (h->e->rc.stream) HIP_CHECK(hipStreamSynchronize(h->e->rc.stream));
+    API_END
+}
+
+int bbmpc_comm_unique_id(void* out, int64_t bytes) {
+    API_BEGIN
+    CHECK_PTR(out);
+    if (bytes < (int64_t)sizeof(Rccl::UniqueId)) throw HipError(BBMPC_E_INVALID, "bbmpc_comm_unique_id: buffer smaller than BBMPC_COMM_ID_BYTES");
+    const Rccl& r = Rccl::get();
+    Rccl::UniqueId id;
+    r.check(r.GetUniqueId(&id), "ncclGetUniqueId");
+    memcpy(out, &id, sizeof(id));
+    API_END
+}
+
+int bbmpc_comm_init(bbmpc_handle h, const void* unique_id, int32_t nranks, int32_t rank) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(unique_id);
+    Engine* e = h->e;
+    if (nranks < 1 || rank < 0 || rank >= nranks) throw HipError(BBMPC_E_INVALID, "bbmpc_comm_init: rank / nranks out of range");
+    if (e->rc.comm) throw HipError(BBMPC_E_STATE, "bbmpc_comm_init: the handle already has a communicator");
+    HIP_CHECK(hipSetDevice(e->device));
+    const Rccl& r = Rccl::get();
+    Rccl::UniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    RecordComm& c = e->rc;
+    HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    for (int s = 0; s < RecordComm::kSlots; ++s) {
+        HIP_CHECK(hipEventCreateWithFlags(&c.ready[s], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&c.done[s], hipEventDisableTiming));
+    }
+    r.check(r.CommInitRank(&c.comm, nranks, id, rank), "ncclCommInitRank");
+    c.nranks = nranks;
+    c.rank = rank;
+    // BBMPC_COMM_SYNC=event: events only; default: flags in signal memory where the device supports stream wait-value
+    int can_wait = 0;
+    (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, e->device);
+    const char* sm = getenv("BBMPC_COMM_SYNC");
+    c.sync_mode = can_wait ? 1 : 0;
+    if (sm && !strcmp(sm, "event")) c.sync_mode = 0;
+    if (c.sync_mode != 0) {
+        // signal memory comes in 8-byte units, lives in host memory and can be polled by the host
+        bool ok = hipExtMallocWithFlags((void**)&c.flag, 8, hipMallocSignalMemory) == hipSuccess;
+        for (int s = 0; ok && s < RecordComm::kSlots; ++s)
+            ok = hipExtMallocWithFlags((void**)&c.done_flag[s], 8, hipMallocSignalMemory) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            c.sync_mode = 0;
+        } else {
+            HIP_CHECK(hipMalloc((void**)&c.count, 8));
+            HIP_CHECK(hipMemset(c.count, 0, 8));
+            HIP_CHECK(hipMemset(c.flag, 0, 8));
+            for (int s = 0; s < RecordComm::kSlots; ++s) HIP_CHECK(hipMemset(c.done_flag[s], 0, 8));
+        }
+    }
+    API_END
+}
+
+// sequence number of the next hand-off (flag modes)
+static uint32_t next_comm_seq(Engine* e) {
+    RecordComm& c = e->rc;
+    if (c.seq >= 0x7fffffffu) {                                        // wrap: once per 2^31 control steps
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        HIP_CHECK(hipStreamSynchronize(c.stream));
+        HIP_CHECK(hipMemset(c.flag, 0, 8));
+        for (int s = 0; s < RecordComm::kSlots; ++s) {
+            HIP_CHECK(hipMemset(c.done_flag[s], 0, 8));
+            c.done_seq[s] = 0;
+            c.pending[s] = false;
+        }
+        c.seq = 0;
+    }
+    return ++c.seq;
+}
+
+// Enqueue the all-gather of `count` floats per rank behind everything the launch stream holds so far.
+//
+// Hand-off launch stream -> communication stream, two forms:
+//  * `published`: the control step was one persistent kernel and its last workgroup publishes sequence number `v` in
+//    signal memory (kernels_fused.hpp); the communication stream waits for the value.  Nothing is added to the
+//    launch stream: +2 us per control step against no gather at all (tools/gather_overhead.py).
+//  * otherwise an event (`event_attached`: it already rides on the last kernel's dispatch packet).  A cross-stream
+//    event costs the launch stream 5-9 us per control step -- the runtime adds a barrier packet and a completion
+//    signal between two back-to-back kernels -- which only matters for ~50 us control steps, and those are the
+//    single-kernel ones.  (A wait-value that sits in the queue across many launches is worse: the command processor
+//    polls it between the other queue's dispatches; measured +77 us on a 25-launch control step.)
+// Completion (sync_mode 1) goes to a second flag that the host polls in bbmpc_gather_wait: an event recorded on the
+// communication stream and queried from the host was measured to cost the launch stream another 4 us per step.
+static void gather_records(Engine* e, const float* d_records, float* d_gathered, size_t count, int slot, bool event_attached,
+                           bool published, uint32_t v) {
+    RecordComm& c = e->rc;
+    const Rccl& r = Rccl::get();
+    if (published) {
+        HIP_CHECK(hipStreamWaitValue32(c.stream, c.flag, v, hipStreamWaitValueGte, 0xffffffffu));
+    } else {
+        if (!event_attached) HIP_CHECK(hipEventRecord(c.ready[slot], e->stream));
+        HIP_CHECK(hipStreamWaitEvent(c.stream, c.ready[slot], 0));
+    }
+    r.check(r.AllGather(d_records, d_gathered, count, Rccl::kFloat32, c.comm, c.stream), "ncclAllGather");
+    if (c.sync_mode == 1) {
+        HIP_CHECK(hipStreamWriteValue32(c.stream, c.done_flag[slot], v, 0));
+        c.done_seq[slot] = v;
+    } else {
+        HIP_CHECK(hipEventRecord(c.done[slot], c.stream));
+    }
+    c.pending[slot] = true;
+}
+
+int bbmpc_gather_records_dev(bbmpc_handle h, const float* d_records, float* d_gathered, int64_t count, int32_t slot) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(d_records);
+    CHECK_PTR(d_gathered);
+    Engine* e = h->e;
+    RecordComm& c = e->rc;
+    if (!c.comm) throw HipError(BBMPC_E_STATE, "bbmpc_gather_records_dev: call bbmpc_comm_init first");
+    if (slot < 0 || slot >= RecordComm::kSlots) throw HipError(BBMPC_E_INVALID, "bbmpc_gather_records_dev: slot must be 0 or 1");
+    if (count <= 0) throw HipError(BBMPC_E_INVALID, "bbmpc_gather_records_dev: count must be positive");
+    if (c.pending[slot]) throw HipError(BBMPC_E_STATE, "bbmpc_gather_records_dev: slot still pending (call bbmpc_gather_wait)");
+    gather_records(e, d_records, d_gathered, (size_t)count, slot, false, false, c.sync_mode ? next_comm_seq(e) : 0u);
+    API_END
+}
+
+int bbmpc_optimize_gather_dev(bbmpc_handle h, const float* d_state, int32_t, int32_t noise, float* d_records,
+                              float* d_next_state, float* d_gathered, int32_t slot) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(d_state);
+    CHECK_PTR(d_records);
+    CHECK_PTR(d_gathered);
+    if (d_next_state == d_state) throw HipError(BBMPC_E_INVALID, "d_next_state must not alias d_state");
+    Engine* e = h->e;
+    RecordComm& c = e->rc;
+    if (!c.comm) throw HipError(BBMPC_E_STATE, "bbmpc_optimize_gather_dev: call bbmpc_comm_init first");
+    if (slot < 0 || slot >= RecordComm::kSlots) throw HipError(BBMPC_E_INVALID, "bbmpc_optimize_gather_dev: slot must be 0 or 1");
+    if (c.pending[slot]) throw HipError(BBMPC_E_STATE, "bbmpc_optimize_gather_dev: slot still pending (call bbmpc_gather_wait)");
+    // single-launch control steps carry the hand-off themselves: the sequence number published by the kernel's last
+    // workgroup, or (BBMPC_COMM_SYNC=event) the ready event on the kernel's dispatch packet
+    uint32_t v = 0;
+    if (c.sync_mode == 1) {
+        v = next_comm_seq(e);
+        e->tail_flag = c.flag;
+        e->tail_value = v;
+    } else {
+        e->tail_event = c.ready[slot];
+    }
+    e->tail_attached = false;
+    try {
+        e->optimize_dev(d_state, noise, d_records, d_next_state);
+    } catch (...) {
+        e->tail_event = nullptr;
+        e->tail_flag = nullptr;
+        throw;
+    }
+    e->tail_event = nullptr;
+    e->tail_flag = nullptr;
+    const bool published = c.sync_mode == 1 && e->tail_attached;
+    gather_records(e, d_records, d_gathered, (size_t)e->A * e->rec, slot, c.sync_mode == 0 && e->tail_attached, published, v);
+    API_END
+}
+
+int bbmpc_gather_wait(bbmpc_handle h, int32_t slot, int32_t host_block) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    Engine* e = h->e;
+    RecordComm& c = e->rc;
+    if (slot < 0 || slot >= RecordComm::kSlots) throw HipError(BBMPC_E_INVALID, "bbmpc_gather_wait: slot must be 0 or 1");
+    if (c.pending[slot]) {
+        if (c.sync_mode == 0) {
+            if (host_block) {
+                HIP_CHECK(hipEventSynchronize(c.done[slot]));
+            } else {
+                const hipError_t q = hipEventQuery(c.done[slot]);
+                if (q == hipErrorNotReady) HIP_CHECK(hipStreamWaitEvent(e->stream, c.done[slot], 0));
+                else HIP_CHECK(q);
+            }
+        } else {
+            // normally long finished (it is a control step old): then the launch stream needs no dependency at all
+            volatile const uint32_t* f = c.done_flag[slot];
+            const uint32_t want = c.done_seq[slot];
+            if (host_block) {
+                // the collective needs every rank: a dead peer shows up as a timeout, not as a hang
+                const auto t0 = std::chrono::steady_clock::now();
+                while (*f < want) {
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                        throw HipError(BBMPC_E_HIP, "bbmpc_gather_wait: record all-gather did not finish within 120 s");
+                    std::this_thread::yield();
+                }
+            } else if (*f < want) {
+                HIP_CHECK(hipStreamWaitValue32(e->stream, c.done_flag[slot], want, hipStreamWaitValueGte, 0xffffffffu));
+            }
+        }
+        c.pending[slot] = false;
+    }
+    API_END
+}
+
+int bbmpc_comm_destroy(bbmpc_handle h) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    h->e->rc.destroy();
     API_END
 }
 

@@ -2,6 +2,7 @@
 // counter, injected-noise buffers and traces, and enqueues the per-control-step
 // kernel sequence of each optimizer.
 #pragma once
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -12,6 +13,7 @@
 #include <vector>
 
 #include "../../include/bbmpc.h"
+#include "comm.hpp"
 #include "kernels_cma.hpp"
 #include "kernels_fused.hpp"
 #include "kernels_fused_pso.hpp"
@@ -69,6 +71,7 @@ struct Engine {
     int rec;                 // record width U+S+1
     std::vector<float> lo, hi;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    int device = 0;          // the device the handle lives on (cfg.device, or the caller's current device when that is < 0)
     uint32_t step_counter = 0;
     bool trace_on = false, profiling = false;
     int prof_every = 1;      // events around every prof_every-th launch of the dominant kernel
@@ -123,6 +126,11 @@ struct Engine {
     // noise prefetch for the persistent kernel: the standard draws of control step t+1 are generated by otherwise
     // idle CUs on a side stream while step t's kernel runs (same Philox counters => bit-identical to in-kernel draws)
     DevBuf<float> d_noise_pf[2];      // two chunks of pf_steps control steps each
+    RecordComm rc;           // multi-GPU record all-gather (comm.hpp); unused until bbmpc_comm_init
+    hipEvent_t tail_event = nullptr;   // completion event wanted on the control step's last kernel (launch_with_tail)
+    bool tail_attached = false;
+    uint32_t* tail_flag = nullptr;     // or: sequence number the last kernel should publish itself (RecordComm::flag)
+    uint32_t tail_value = 0;
     hipStream_t pf_stream = nullptr;
     hipEvent_t pf_done[2] = {nullptr, nullptr}, pf_free = nullptr;
     int64_t pf_chunk[2] = {-1, -1};   // chunk id (control step / pf_steps) a buffer holds

@@ -12,6 +12,7 @@
 //   (cem.py:74-136, pi2.py:58-96, random_search.py:38-48) -> DeterministicTrajectoryEvaluator.__call__
 //   (deterministic.py:26-77) -> PendulumTrueModel / pendulum_reward_function (utils/pendulum.py).
 #pragma once
+#include "kernels_opt.hpp"
 #include "kernels_refit.hpp"
 #include "kernels_rollout.hpp"
 #include "topk.hpp"
@@ -30,6 +31,9 @@ struct FusedArgs {
     int fix_q1, fix_q7, add_noise;
     int warm_start;          // CEM: BBMPC_FIX_Q2 (keep the mean across control steps)
     int balance;             // progress-balanced wave priorities in the rollout (BBMPC_BALANCE, default on)
+    unsigned* done_flag;     // optional completion counter in signal memory (see the kernel's tail), else null
+    unsigned* done_count;
+    unsigned done_value;
     float alpha, inv_lamda;
     const float* state;      // [A,3]
     const float* lo;
@@ -539,6 +543,10 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             p.next_state[a * 3 + 1] = s[1];
             p.next_state[a * 3 + 2] = s[2];
         }
+        // "records ready" for the all-gather that waits on another stream (comm.hpp): the last agent's workgroup
+        // publishes the sequence number once every agent's record is in HBM.  No event, no extra packet on the
+        // launch stream.
+        publish_records_done(p.done_flag, p.done_count, p.done_value, (unsigned)p.A);
     }
 }
 

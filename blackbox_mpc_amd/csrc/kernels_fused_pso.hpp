@@ -34,6 +34,9 @@ struct FusedPsoArgs {
     float* t_mean;
     int* t_elites;
     int t_elite_stride;
+    unsigned* done_flag;     // optional: see publish_records_done (kernels_opt.hpp)
+    unsigned* done_count;
+    unsigned done_value;
     RngKey key;
 };
 
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(1024) void k_fused_pso_pendulum(FusedPsoArgs p) {
             p.next_state[a * 3 + 1] = s[1];
             p.next_state[a * 3 + 2] = s[2];
         }
+        publish_records_done(p.done_flag, p.done_count, p.done_value, (unsigned)p.A);
     }
 }
 

@@ -12,6 +12,19 @@
 
 namespace bbmpc {
 
+// "records ready" for an all-gather that waits on another stream (comm.hpp, gather_records in bbmpc.hip): called by
+// one thread per workgroup after its record stores; the last of `nwg` workgroups publishes the sequence number in
+// signal memory.  No event and no extra packet on the launch stream.
+__device__ __forceinline__ void publish_records_done(unsigned* flag, unsigned* count, unsigned value, unsigned nwg) {
+    if (!flag) return;
+    const unsigned old = __hip_atomic_fetch_add(count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == nwg - 1u) {
+        __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+
 struct OptArgs {
     int N, A, H, U, HU, Nst;
     int agent_offset;

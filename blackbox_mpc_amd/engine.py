@@ -84,6 +84,36 @@ class Engine:
     def synchronize(self):
         L.check(L.lib.bbmpc_synchronize(self._h))
 
+    # -- multi-GPU: one all-gather of the per-agent records per control step (include/bbmpc.h) ------
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes from rank 0 that every rank passes to comm_init (ship them over any side channel)."""
+        buf = ctypes.create_string_buffer(L.COMM_ID_BYTES)
+        L.check(L.lib.bbmpc_comm_unique_id(buf, L.COMM_ID_BYTES))
+        return buf.raw
+
+    def comm_init(self, unique_id, nranks, rank):
+        if len(unique_id) != L.COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % L.COMM_ID_BYTES)
+        L.check(L.lib.bbmpc_comm_init(self._h, ctypes.c_char_p(bytes(unique_id)), int(nranks), int(rank)))
+
+    def gather_records_dev(self, d_records, d_gathered, count_per_rank, slot):
+        L.check(L.lib.bbmpc_gather_records_dev(self._h, ctypes.c_void_p(d_records), ctypes.c_void_p(d_gathered),
+                                               int(count_per_rank), int(slot)))
+
+    def optimize_gather_dev(self, d_state, d_records, d_gathered, slot, t=0, add_exploration_noise=False,
+                            d_next_state=0):
+        L.check(L.lib.bbmpc_optimize_gather_dev(self._h, ctypes.c_void_p(d_state), int(t),
+                                                int(bool(add_exploration_noise)), ctypes.c_void_p(d_records),
+                                                ctypes.c_void_p(d_next_state or 0), ctypes.c_void_p(d_gathered),
+                                                int(slot)))
+
+    def gather_wait(self, slot, host_block=False):
+        L.check(L.lib.bbmpc_gather_wait(self._h, int(slot), int(bool(host_block))))
+
+    def comm_destroy(self):
+        L.check(L.lib.bbmpc_comm_destroy(self._h))
+
     # -- hot path --------------------------------------------------------------------------
     def optimize(self, state, t=0, add_exploration_noise=False):
         # persistent I/O buffers with cached ctypes pointers: building four `ndarray.ctypes` views per call costs more

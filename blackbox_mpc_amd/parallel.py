@@ -41,6 +41,27 @@ def gather_records(local_record, num_agents_global, group=None):
     return torch.cat([out[r * cap:r * cap + counts[r]] for r in range(world)], dim=0)
 
 
+def attach_record_comm(engine, group=None, device=None):
+    """Give `engine` (blackbox_mpc_amd.engine.Engine) its own RCCL communicator over the ranks of `group`, for the
+    device-side record all-gather (Engine.gather_records_dev / gather_wait; include/bbmpc.h "multi-GPU").
+
+    torch.distributed is only the side channel that ships rank 0's 128-byte unique id; the per-control-step
+    collective is then enqueued by the engine itself on its communication stream (c10d spends ~30 us of host time
+    per asynchronous collective, most of a ~50 us control step -- tools/gather_overhead.py).  `device`: where the
+    broadcast tensor lives (a torch.device for the nccl backend, None = CPU for gloo)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    raw = engine.comm_unique_id() if rank == 0 else bytes(128)
+    buf = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
+    if device is not None:
+        buf = buf.to(device)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast(buf, src=src, group=group)
+    engine.comm_init(bytes(buf.cpu().numpy().tobytes()), world, rank)
+    return world, rank
+
+
 class ShardedMPCPolicy:
     """MPCPolicy over all agents with the agents sharded across the ranks of a process group.
 

@@ -214,8 +214,37 @@ int bbmpc_set_state(bbmpc_handle h, const char* name, const float* data, int64_t
 int bbmpc_set_profiling(bbmpc_handle h, int32_t enabled);
 int bbmpc_get_profile(bbmpc_handle h, double* rollout_ms_total, int64_t* rollout_launches,
                       const char** kernel_name);
-/* Block until everything enqueued on the handle's stream has finished. */
+/* Block until everything enqueued on the handle's stream (and its communication stream) has finished. */
 int bbmpc_synchronize(bbmpc_handle h);
+
+/* ---- multi-GPU: the agent-sharded path's one exchange ------------------------
+ * One process per GPU, each handle owning agents [agent_offset, agent_offset + num_agents) of num_agents_global
+ * (bbmpc_config).  Nothing on the optimisation path crosses GPUs; per control step the packed records
+ * [num_agents, dim_u + dim_s + 1] are all-gathered (RCCL over xGMI) so every rank holds every agent's action /
+ * predicted next state / predicted reward.  The reference has no counterpart: its agents are a batch dimension of a
+ * single process (optimizers/optimizer_base.py:59-94 returns all agents' results at once); the gathered array is
+ * exactly that return value, reassembled.
+ *
+ *   rank 0: bbmpc_comm_unique_id(id)  -> ship the BBMPC_COMM_ID_BYTES to every rank (any side channel)
+ *   all   : bbmpc_comm_init(h, id, nranks, rank)              (collective; librccl is bound at run time)
+ *   step t: bbmpc_gather_wait(h, t & 1, 0);                    the gather that last used this slot's buffers is done
+ *           bbmpc_optimize_dev(h, ..., d_records[t & 1], ...);
+ *           bbmpc_gather_records_dev(h, d_records[t & 1], d_gathered[t & 1], num_agents * record_width, t & 1);
+ * The collective runs on the handle's own stream and overlaps the next control step; rows of d_gathered are in
+ * global agent order when every rank has the same num_agents.  bbmpc_gather_wait with host_block != 0 blocks the
+ * calling thread until the slot's gathered array can be read. */
+#define BBMPC_COMM_ID_BYTES 128
+int bbmpc_comm_unique_id(void* out, int64_t bytes);
+int bbmpc_comm_init(bbmpc_handle h, const void* unique_id, int32_t nranks, int32_t rank);
+int bbmpc_gather_records_dev(bbmpc_handle h, const float* d_records, float* d_gathered, int64_t count_per_rank,
+                             int32_t slot);
+/* bbmpc_optimize_dev + bbmpc_gather_records_dev in one call (count = num_agents * record width): lets a control
+ * step that is a single kernel launch carry the "records ready" event on its own dispatch packet instead of a
+ * separate event record on the launch stream. */
+int bbmpc_optimize_gather_dev(bbmpc_handle h, const float* d_state, int32_t time_step, int32_t add_exploration_noise,
+                              float* d_records, float* d_next_state, float* d_gathered, int32_t slot);
+int bbmpc_gather_wait(bbmpc_handle h, int32_t slot, int32_t host_block);
+int bbmpc_comm_destroy(bbmpc_handle h);
 
 #ifdef __cplusplus
 }
