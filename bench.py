@@ -300,7 +300,15 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1 and c["opt"] in ("RandomSearch", "CEM", "PI2"):
             out["cpu_baseline"] = cpu_baseline(O, c, H, N, A, iters, k)
-        print(json.dumps(out))
+        # RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would otherwise
+        # come out after this line at exit: push it out first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if native_gather:
         eng.synchronize()
         eng.comm_destroy()
