@@ -17,6 +17,7 @@ import time
 
 import numpy as np
 
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -132,8 +133,18 @@ def main():
             except Exception:
                 pass
     rec = U + S + 1
-    stream = torch.cuda.current_stream()
-    eng.set_stream(stream.cuda_stream)
+    # The engine launches on its own (non-blocking) stream.  Only the torch.distributed gather modes put torch work
+    # into the loop (events, collectives): they run the loop on a torch side stream that the engine is told to use,
+    # so that this work is ordered with its kernels.  (PyTorch's default stream has the NULL handle, which
+    # bbmpc_set_stream reads as "the handle's own stream".)
+    torch_loop_stream = (use_dist and not native_gather) or bool(os.environ.get("BBMPC_BENCH_TORCH_STREAM"))
+    if torch_loop_stream:
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        eng.set_torch_stream(stream)
+    else:
+        stream = None
+        eng.set_stream(None)
 
     state = torch.from_numpy(start).to(dev)
     nxt = torch.empty_like(state)
@@ -141,10 +152,10 @@ def main():
     # while step t+1 computes (the local optimizer never needs the other ranks' records)
     records = [torch.zeros((A, rec), device=dev, dtype=torch.float32) for _ in range(2)]
     gathered = [torch.zeros((world * A, rec), device=dev, dtype=torch.float32) for _ in range(2)] if use_dist else None
-    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
+    comm_stream = torch.cuda.Stream(device=dev) if (use_dist and torch_loop_stream) else None
     comm_done = [None, None]
-    ready_ev = [torch.cuda.Event(), torch.cuda.Event()] if use_dist else None
-    done_ev = [torch.cuda.Event(), torch.cuda.Event()] if use_dist else None
+    ready_ev = [torch.cuda.Event(), torch.cuda.Event()] if comm_stream is not None else None
+    done_ev = [torch.cuda.Event(), torch.cuda.Event()] if comm_stream is not None else None
     works = [None, None]
     tick = [0]
 

@@ -57,7 +57,15 @@ class Engine:
             pass
 
     def set_stream(self, stream_ptr):
+        """Launch on the given hipStream_t handle; 0 / None = the handle's own stream (include/bbmpc.h)."""
         L.check(L.lib.bbmpc_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def set_torch_stream(self, stream):
+        """Launch on a torch.cuda.Stream so that torch work on that stream (events, collectives, copies) is ordered
+        with the engine's kernels.  PyTorch's default stream has the NULL handle, which bbmpc_set_stream reads as
+        "the handle's own stream": it is mapped to hipStreamLegacy here."""
+        ptr = int(stream.cuda_stream)
+        self.set_stream(ptr if ptr != 0 else 1)
 
     def set_mlp(self, weights, biases, activations, stats=None):
         n = len(weights)

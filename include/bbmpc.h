@@ -136,7 +136,9 @@ int         bbmpc_device_count(void);
  * (policies/mpc_policy.py:58-122; optimizer_base.py:105-115). */
 int bbmpc_create(const bbmpc_config* cfg, bbmpc_handle* out);
 int bbmpc_destroy(bbmpc_handle h);
-/* Launch on a caller-provided hipStream_t (e.g. torch's current stream); NULL = handle's own. */
+/* Launch on a caller-provided hipStream_t; NULL = the handle's own (non-blocking) stream.  Note that the legacy
+ * default stream's handle IS NULL (PyTorch's current stream, unless the caller entered a side stream): to launch
+ * there pass hipStreamLegacy ((hipStream_t)1) explicitly -- or, better, run the control loop on a side stream. */
 int bbmpc_set_stream(bbmpc_handle h, void* hip_stream);
 
 /* DeterministicMLP weights + SystemDynamicsHandler normalisation stats

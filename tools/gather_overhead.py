@@ -7,6 +7,7 @@ import os
 import sys
 import time
 
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
@@ -26,8 +27,9 @@ def main():
     eng = Engine(L.OPT_CEM, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=1, planning_horizon=30,
                  population_size=500, max_iterations=5, num_elite=50, seed=0, device=0)
     eng.reset()
-    stream = torch.cuda.current_stream()
-    eng.set_stream(stream.cuda_stream)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    eng.set_torch_stream(stream)
     state = torch.from_numpy(O.pendulum_start_states(1)).to(dev)
     nxt = torch.empty_like(state)
     records = [torch.zeros((1, 5), device=dev) for _ in range(2)]
