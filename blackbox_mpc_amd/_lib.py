@@ -62,7 +62,7 @@ SYMBOLS = [
     "bbmpc_inject_noise", "bbmpc_dump_noise", "bbmpc_set_trace", "bbmpc_get_trace", "bbmpc_get_state",
     "bbmpc_set_state", "bbmpc_set_profiling", "bbmpc_get_profile", "bbmpc_synchronize", "bbmpc_rollout_episode",
     "bbmpc_comm_unique_id", "bbmpc_comm_init", "bbmpc_gather_records_dev", "bbmpc_gather_wait", "bbmpc_comm_destroy",
-    "bbmpc_optimize_gather_dev",
+    "bbmpc_optimize_gather_dev", "bbmpc_set_stream_default",
 ]
 COMM_ID_BYTES = 128
 
@@ -88,6 +88,7 @@ def _load():
     lib.bbmpc_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
     lib.bbmpc_destroy.argtypes = [vp]
     lib.bbmpc_set_stream.argtypes = [vp, vp]
+    lib.bbmpc_set_stream_default.argtypes = [vp]
     lib.bbmpc_set_mlp.argtypes = [vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(vp),
                                   ctypes.POINTER(vp), i32, ctypes.POINTER(vp)]
     lib.bbmpc_reset.argtypes = [vp]

@@ -1558,6 +1558,14 @@ int bbmpc_set_stream(bbmpc_handle h, void* s) {
     API_END
 }
 
+int bbmpc_set_stream_default(bbmpc_handle h) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    HIP_CHECK(hipStreamSynchronize(h->e->stream));
+    h->e->stream = nullptr;
+    API_END
+}
+
 int bbmpc_set_mlp(bbmpc_handle h, int32_t n_layers, const int32_t* dims, const int32_t* acts, const float* const* w,
                   const float* const* b, int32_t is_normalized, const float* const* stats) {
     API_BEGIN

@@ -63,9 +63,12 @@ class Engine:
     def set_torch_stream(self, stream):
         """Launch on a torch.cuda.Stream so that torch work on that stream (events, collectives, copies) is ordered
         with the engine's kernels.  PyTorch's default stream has the NULL handle, which bbmpc_set_stream reads as
-        "the handle's own stream": it is mapped to hipStreamLegacy here."""
+        "the handle's own stream": it goes through bbmpc_set_stream_default."""
         ptr = int(stream.cuda_stream)
-        self.set_stream(ptr if ptr != 0 else 1)
+        if ptr != 0:
+            self.set_stream(ptr)
+        else:
+            L.check(L.lib.bbmpc_set_stream_default(self._h))
 
     def set_mlp(self, weights, biases, activations, stats=None):
         n = len(weights)

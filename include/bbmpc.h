@@ -137,9 +137,10 @@ int         bbmpc_device_count(void);
 int bbmpc_create(const bbmpc_config* cfg, bbmpc_handle* out);
 int bbmpc_destroy(bbmpc_handle h);
 /* Launch on a caller-provided hipStream_t; NULL = the handle's own (non-blocking) stream.  Note that the legacy
- * default stream's handle IS NULL (PyTorch's current stream, unless the caller entered a side stream): to launch
- * there pass hipStreamLegacy ((hipStream_t)1) explicitly -- or, better, run the control loop on a side stream. */
+ * default stream's handle IS NULL (PyTorch's current stream, unless the caller entered a side stream): use
+ * bbmpc_set_stream_default to launch there -- or, better, run the control loop on a side stream. */
 int bbmpc_set_stream(bbmpc_handle h, void* hip_stream);
+int bbmpc_set_stream_default(bbmpc_handle h);   /* the legacy default (NULL) stream */
 
 /* DeterministicMLP weights + SystemDynamicsHandler normalisation stats
  * (deterministic_mlp.py:5-25 Dense kernels [in,out] row-major, biases [out];

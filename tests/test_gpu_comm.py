@@ -150,3 +150,30 @@ def test_comm_call_sequence_errors(L):
     eng.gather_wait(1, host_block=True)
     eng.comm_destroy()
     eng.comm_destroy()                                           # idempotent
+
+
+@pytest.mark.parametrize("which", ["default", "side"])
+def test_set_torch_stream_orders_torch_work_with_the_kernels(L, which):
+    # PyTorch's default stream has the NULL handle, which bbmpc_set_stream reads as "the handle's own stream";
+    # set_torch_stream maps it to hipStreamLegacy.  Torch work issued right before / after a ~50 us control step, with
+    # no synchronisation, must be ordered with it.
+    import torch
+    dev = torch.device("cuda", 0)
+    eng = _pendulum_engine(L, L.OPT_CEM, A=1, N=500, H=30, iters=5)
+    eng.reset()
+    s = torch.cuda.default_stream(dev) if which == "default" else torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        eng.set_torch_stream(s)
+        state = torch.from_numpy(O.pendulum_start_states(1)).to(dev)
+        nxt = torch.empty_like(state)
+        rec = torch.zeros((1, 5), device=dev)
+        snaps = []
+        for t in range(30):
+            rec.fill_(-100.0)                                    # ordered before the kernel's record store
+            eng.optimize_dev(state.data_ptr(), rec.data_ptr(), d_next_state=nxt.data_ptr())
+            snaps.append(rec.clone())                            # ordered after it
+            state, nxt = nxt, state
+        torch.cuda.synchronize()
+    eng.set_stream(None)
+    for snap in snaps:
+        assert (snap != -100.0).all() and torch.isfinite(snap).all()
