@@ -64,9 +64,9 @@ def _closed_loop(eng, start, steps, gather):
 
 
 @pytest.mark.parametrize("sync", ["flags", "event"])
-@pytest.mark.parametrize("kind", ["cem", "pso", "cmaes", "mlp"])
+@pytest.mark.parametrize("kind", ["cem", "pi2", "spsa", "rs", "pso", "cmaes", "mlp"])
 def test_one_rank_gather_delivers_the_records(L, monkeypatch, kind, sync):
-    # cem / pso: one persistent kernel per control step (it publishes the hand-off itself in flags mode);
+    # cem / pi2 / spsa / rs / pso: one persistent kernel per control step (it publishes the hand-off itself in flags mode);
     # cmaes / mlp: many launches per control step (event hand-off)
     from blackbox_mpc_amd.engine import Engine
     monkeypatch.setenv("BBMPC_COMM_SYNC", sync)
@@ -74,7 +74,8 @@ def test_one_rank_gather_delivers_the_records(L, monkeypatch, kind, sync):
     def make():
         if kind == "mlp":
             return _mlp_engine(L), O.cheetah_start_states(2, 20)
-        opt = {"cem": L.OPT_CEM, "pso": L.OPT_PSO, "cmaes": L.OPT_CMAES}[kind]
+        opt = {"cem": L.OPT_CEM, "pi2": L.OPT_PI2, "spsa": L.OPT_SPSA, "rs": L.OPT_RANDOM_SEARCH, "pso": L.OPT_PSO,
+               "cmaes": L.OPT_CMAES}[kind]
         return _pendulum_engine(L, opt), O.pendulum_start_states(2)
 
     ref_eng, start = make()
