@@ -643,7 +643,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
         const int nt = pair ? 2 : 1;
         const size_t plds = (size_t)mlp_pair_lds_floats(13, ra.H, U, S, nt) * sizeof(float);
         if (plds <= 159 * 1024) {
-            dim3 pgrid((ra.n_pop + nt * MLP_TP - 1) / (nt * MLP_TP), A), pblock(13 * 64);
+            dim3 pgrid((ra.n_pop + nt * MLP_TP - 1) / (nt * MLP_TP), A), pblock(mlp_pair_waves(13, nt) * 64);
             dominant_kernel = "k_rollout_mlp_pair";
             prof_begin();
             if (nt == 2) {

@@ -499,14 +499,24 @@ __device__ __forceinline__ float apply_act_ct(float x) {
     else return x;
 }
 
+// Two-tile mode runs HT + 1 waves: feature tile HT-1 (the 13th, half-empty one for 200 hidden units) is served by TWO
+// waves, wave HT-1 for particle tile 0 and wave HT for particle tile 1.  Waves land on SIMD (wave & 3), so with HT = 13
+// SIMD 0 used to carry four waves x two tile-jobs = 8 jobs against 6 on the others; split like this the load is
+// 7 / 7 / 6 / 6 (tile-jobs per SIMD) and the critical SIMD's matrix time drops by an eighth.
+constexpr int mlp_pair_waves(int HT, int NTILES) { return HT + (NTILES == 2 ? 1 : 0); }
+
 template <int HT, int A0, int A1, int A2, int NTILES>
-__global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) {
+__global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutArgs& p = q.r;
     const MlpDesc& m = q.m;
-    constexpr int NW = HT, NT = HT * 64, IT0 = 2, OTL = 2;
+    constexpr int NW = HT, NT = mlp_pair_waves(HT, NTILES) * 64, IT0 = 2, OTL = 2;   // NW: feature tiles = partial-sum slots
     const int a = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wave = wid < HT ? wid : HT - 1;                 // the feature tile this wave serves
+    // which particle tiles this wave works on (everything else -- barriers, epilogue threads -- is common)
+    const bool serves0 = NTILES == 1 || wid != HT;
+    const bool serves1 = NTILES == 2 && wid != HT - 1;
     const int S = p.S, U = p.U, H = p.H;
     const int Sp = (S + 3) & ~3;
     const bool normd = m.normalized != 0;
@@ -589,6 +599,7 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
 
     // ---- stages
     auto stage_A = [&](int ti) {
+        if (!(ti == 0 ? serves0 : serves1)) return;
         const float* xs = T_xs(ti);
         if (NTILES == 2) load_w_in();
         f32x4 acc = *reinterpret_cast<const f32x4*>(bias0_p);
@@ -608,6 +619,7 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
     // (one LDS read + one add per producing wave) is issued between this tile's dependent MFMA groups, so
     // it costs no time of its own; `cacc` returns the reduced value.
     auto stage_B = [&](int ti, int co, const float* cpart, float& cacc) {
+        if (!(ti == 0 ? serves0 : serves1)) return;       // only waves HT-1 / HT skip; they own no epilogue thread
         const float* h0 = T_h0(ti);
         f32x4 acc = *reinterpret_cast<const f32x4*>(bias1_p);
         f32x4 bn = *reinterpret_cast<const f32x4*>(h0 + (size_t)lane * 4);
@@ -716,7 +728,7 @@ __global__ __launch_bounds__(HT * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) 
         // opposite order: right after a barrier every wave would otherwise reach its activation (VALU) section at
         // the same time and leave the matrix pipe idle.  Waves w, w+4, w+8, ... share a SIMD, so (w >> 2) & 1
         // alternates within each SIMD.
-        const bool grp = ((wave >> 2) & 1) != 0;
+        const bool grp = ((wid >> 2) & 1) != 0;
         for (int t = 0; t < H; ++t) {
             if (!grp) {
                 stage_A(0);                                           // A_X(t)
