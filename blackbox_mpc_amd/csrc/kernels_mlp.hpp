@@ -619,7 +619,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     // (one LDS read + one add per producing wave) is issued between this tile's dependent MFMA groups, so
     // it costs no time of its own; `cacc` returns the reduced value.
     auto stage_B = [&](int ti, int co, const float* cpart, float& cacc) {
-        if (!(ti == 0 ? serves0 : serves1)) return;       // only waves HT-1 / HT skip; they own no epilogue thread
+        if (!(ti == 0 ? serves0 : serves1)) return;       // only waves HT-1 / HT skip: no epilogue threads, never the `co` form
         const float* h0 = T_h0(ti);
         f32x4 acc = *reinterpret_cast<const f32x4*>(bias1_p);
         f32x4 bn = *reinterpret_cast<const f32x4*>(h0 + (size_t)lane * 4);
