@@ -821,6 +821,27 @@ namespace bbmpc {
 // Activations travel through LDS as [k/4][particle][4] so that a lane fetches 4 consecutive k of its particle
 // with one ds_read_b128.  Last layer: K split over the waves, partial sums reduced in the epilogue.
 // Two hidden layers of equal width; HG = hidden/4 groups, K0G = ceil((S+U)/4) groups, NWQ waves.
+//
+// The 200 layer-1 A operands of a lane do not fit next to everything else in the 256 architectural VGPRs, and left to
+// itself the compiler parks them in AccVGPRs and copies each one back with v_accvgpr_read before the MFMA that uses it
+// (112-144 copies per step, on the same issue port as the MFMAs).  MFMA can read SrcA straight from an AccVGPR, so
+// layer 1 issues its MFMAs through inline asm with an "a" constraint on the weight: the weights live in AccVGPRs for
+// the whole recurrence and nothing is copied.  The hazard recogniser does not look inside inline asm:
+//  * the four accumulator chains are independent and interleaved, so a dependent MFMA is 4 issues (32 cycles) behind
+//    its producer (the 4x4x1 form needs 12);
+//  * mfma_operands_settled() separates the VALU writes that initialise the accumulators from the first MFMA;
+//  * before the first VALU use of the results mfma_results_ready() spends the wait states the compiler would have
+//    inserted (2-pass XDL write -> VALU read) and ties the accumulators to it.
+__device__ __forceinline__ void mfma4x4_agpr_a(f32x4& acc, float w_in_agpr, float b) {
+    asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(w_in_agpr), "v"(b));
+}
+__device__ __forceinline__ void mfma_operands_settled(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3) {
+    asm volatile("s_nop 3" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));     // VALU-initialised accumulators -> first MFMA
+}
+__device__ __forceinline__ void mfma_results_ready(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3) {
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+}
+
 template <int HG, int K0G, int NWQ, int A0, int A1, int A2>
 __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -999,6 +1020,7 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
 #pragma unroll
             for (int g = 0; g < CH; ++g) bq[0][g] = *reinterpret_cast<const f32x4*>(h0 + (min(g, HG - 1) * 4 + pl) * 4);
             __builtin_amdgcn_sched_barrier(0);
+            mfma_operands_settled(c0, c1, c2, c3);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 if (c + 1 < NCH) {
@@ -1012,14 +1034,15 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
                     const int gg = c * CH + g;
                     if (gg < HG) {
                         const f32x4 b = bq[c & 1][g];
-                        c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA1[gg * 4 + 0], b.x, c0, 0, 0, 0);
-                        c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA1[gg * 4 + 1], b.y, c1, 0, 0, 0);
-                        c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA1[gg * 4 + 2], b.z, c2, 0, 0, 0);
-                        c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA1[gg * 4 + 3], b.w, c3, 0, 0, 0);
+                        mfma4x4_agpr_a(c0, wA1[gg * 4 + 0], b.x);
+                        mfma4x4_agpr_a(c1, wA1[gg * 4 + 1], b.y);
+                        mfma4x4_agpr_a(c2, wA1[gg * 4 + 2], b.z);
+                        mfma4x4_agpr_a(c3, wA1[gg * 4 + 3], b.w);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            mfma_results_ready(c0, c1, c2, c3);
             f32x4 o;
             o.x = apply_act_ct<A1>((c0.x + c1.x) + (c2.x + c3.x)); o.y = apply_act_ct<A1>((c0.y + c1.y) + (c2.y + c3.y));
             o.z = apply_act_ct<A1>((c0.z + c1.z) + (c2.z + c3.z)); o.w = apply_act_ct<A1>((c0.w + c1.w) + (c2.w + c3.w));
