@@ -14,6 +14,9 @@ HEADERS = ["engine.hpp", "kernels_rollout.hpp", "kernels_refit.hpp", "models.hpp
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          # one rounding per reference op: never contract a*b+c behind the source's back
          "-ffp-contract=off",
+         # no SLP vectorisation: on gfx950 a packed v_pk_mul/add_f32 takes two issue slots (tools/microbench/pk_fp32.hip),
+         # so pairing scalar fp32 ops buys nothing and costs the v_movs that assemble the register pairs
+         "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function"]
 
 
@@ -28,7 +31,10 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "bbmpc.h")]
+    # every file under csrc/ (headers are all included by the one translation unit), the public header, and this
+    # file itself (the compiler flags live here)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "bbmpc.h"),
+                                                                os.path.abspath(__file__)]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
