@@ -17,7 +17,11 @@ namespace bbmpc {
 // signal memory.  No event and no extra packet on the launch stream.
 __device__ __forceinline__ void publish_records_done(unsigned* flag, unsigned* count, unsigned value, unsigned nwg) {
     if (!flag) return;
-    const unsigned old = __hip_atomic_fetch_add(count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    // release only: this workgroup's record stores are written back before its arrival is counted, so when the last
+    // arrival is seen every record is in memory.  Nobody in this kernel reads the other workgroups' records (the
+    // consumer is a later kernel, which starts with its own acquire), so no acquire here -- at agent scope that
+    // would invalidate the XCD's L2 under the workgroups still running.
+    const unsigned old = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (old == nwg - 1u) {
         __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
