@@ -75,7 +75,9 @@ struct MlpRolloutArgs {
 // instruction shaved off the activations is matrix time gained.
 __device__ __forceinline__ float bb_tanhf(float x) {
     const float e = __expf(2.0f * fabsf(x));                 // +inf for large |x| -> 1 - 0
-    const float r = 1.0f - 2.0f * __frcp_rn(1.0f + e);
+    // v_rcp_f32 (1 ulp).  __frcp_rn is the correctly rounded reciprocal, i.e. a full IEEE division: ten instructions
+    // (v_div_scale x2, v_rcp, four fmas, v_div_fmas, v_div_fixup) per activation value, on the MFMAs' issue port.
+    const float r = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
     return copysignf(r, x);                                  // NaN stays NaN (exp(NaN) = NaN)
 }
 
