@@ -282,8 +282,8 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_cma_svd(CmaArgs p, float* At_
                 const float cs = 1.0f / sqrtf(1.0f + t * t), sn = cs * t;
                 for (int e = lane; e < n; e += 64) {
                     const float xv = x[e], yv = y[e];
-                    x[e] = cs * xv - sn * yv;
-                    y[e] = sn * xv + cs * yv;
+                    x[e] = fmaf(cs, xv, -(sn * yv));
+                    y[e] = fmaf(sn, xv, cs * yv);
                 }
                 if (lane == 0) s_rotated = 1;
             }
@@ -459,8 +459,8 @@ __global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_al
                     for (int c = 0; c < 8; ++c) {
                         const int e = lane + 64 * c;
                         if (e < n) {
-                            xp[q][e] = cs * xv[q][c] - sn * yv[q][c];
-                            yp[q][e] = sn * xv[q][c] + cs * yv[q][c];
+                            xp[q][e] = fmaf(cs, xv[q][c], -(sn * yv[q][c]));
+                            yp[q][e] = fmaf(sn, xv[q][c], cs * yv[q][c]);
                         }
                     }
 #ifdef BBMPC_KERNEL_DBG
@@ -568,8 +568,8 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
         for (int c = 0; c < 8; ++c) {
             const int e = lane + 64 * c;
             if (e < n) {
-                x[e] = cs * xv[c] - sn * yv[c];
-                y[e] = sn * xv[c] + cs * yv[c];
+                x[e] = fmaf(cs, xv[c], -(sn * yv[c]));
+                y[e] = fmaf(sn, xv[c], cs * yv[c]);
             }
         }
         return true;
@@ -703,10 +703,10 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                                 if (c < nc) {
                                     const int e = 4 * (sub + 16 * c);
                                     float4 xn, yn;
-                                    xn.x = cs * xr[c].x - sn * yv[c].x; yn.x = sn * xr[c].x + cs * yv[c].x;
-                                    xn.y = cs * xr[c].y - sn * yv[c].y; yn.y = sn * xr[c].y + cs * yv[c].y;
-                                    xn.z = cs * xr[c].z - sn * yv[c].z; yn.z = sn * xr[c].z + cs * yv[c].z;
-                                    xn.w = cs * xr[c].w - sn * yv[c].w; yn.w = sn * xr[c].w + cs * yv[c].w;
+                                    xn.x = fmaf(cs, xr[c].x, -(sn * yv[c].x)); yn.x = fmaf(sn, xr[c].x, cs * yv[c].x);
+                                    xn.y = fmaf(cs, xr[c].y, -(sn * yv[c].y)); yn.y = fmaf(sn, xr[c].y, cs * yv[c].y);
+                                    xn.z = fmaf(cs, xr[c].z, -(sn * yv[c].z)); yn.z = fmaf(sn, xr[c].z, cs * yv[c].z);
+                                    xn.w = fmaf(cs, xr[c].w, -(sn * yv[c].w)); yn.w = fmaf(sn, xr[c].w, cs * yv[c].w);
                                     xr[c] = xn;
                                     if (e < n) *reinterpret_cast<float4*>(y + e) = yn;
                                 }
@@ -811,8 +811,8 @@ __global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all
                 for (int c = 0; c < EC; ++c) {
                     const int e = sub + 16 * c;
                     if (c < nc && e < n) {
-                        x[e] = cs * xv[c] - sn * yv[c];
-                        y[e] = sn * xv[c] + cs * yv[c];
+                        x[e] = fmaf(cs, xv[c], -(sn * yv[c]));
+                        y[e] = fmaf(sn, xv[c], cs * yv[c]);
                     }
                 }
                 if (sub == 0) s_rot = 1;
