@@ -1846,6 +1846,15 @@ int bbmpc_comm_init(bbmpc_handle h, const void* unique_id, int32_t nranks, int32
             HIP_CHECK(hipMemset(c.count, 0, 8));
             HIP_CHECK(hipMemset(c.flag, 0, 8));
             for (int s = 0; s < RecordComm::kSlots; ++s) HIP_CHECK(hipMemset(c.done_flag[s], 0, 8));
+            // test hook: start the sequence numbers just below the wrap (tests/test_gpu_comm.py)
+            if (const char* s0 = getenv("BBMPC_COMM_SEQ_START")) {
+                c.seq = (uint32_t)strtoul(s0, nullptr, 0);
+                HIP_CHECK(hipMemcpy(c.flag, &c.seq, 4, hipMemcpyHostToDevice));
+                for (int s = 0; s < RecordComm::kSlots; ++s) {
+                    HIP_CHECK(hipMemcpy(c.done_flag[s], &c.seq, 4, hipMemcpyHostToDevice));
+                    c.done_seq[s] = c.seq;
+                }
+            }
         }
     }
     API_END

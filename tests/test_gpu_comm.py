@@ -178,3 +178,24 @@ def test_set_torch_stream_orders_torch_work_with_the_kernels(L, which):
     eng.set_stream(None)
     for snap in snaps:
         assert (snap != -100.0).all() and torch.isfinite(snap).all()
+
+
+def test_sequence_number_wrap(L, monkeypatch):
+    # the hand-off's sequence numbers are reset (both streams drained, flags zeroed) before they reach 2^31
+    import torch
+    from blackbox_mpc_amd.engine import Engine
+    monkeypatch.setenv("BBMPC_COMM_SEQ_START", str(0x7FFFFFFF - 5))
+    dev = torch.device("cuda", 0)
+
+    def run(gather):
+        eng = _pendulum_engine(L, L.OPT_CEM, A=2, N=200, H=12, iters=3)
+        eng.reset()
+        if gather:
+            eng.comm_init(Engine.comm_unique_id(), 1, 0)
+        return _closed_loop(eng, O.pendulum_start_states(2), 14, gather=gather)
+
+    ref, _ = run(False)
+    got, got_g = run(True)
+    for t in range(14):
+        np.testing.assert_array_equal(got[t].view(np.int32), ref[t].view(np.int32))
+        np.testing.assert_array_equal(got_g[t].view(np.int32), got[t].view(np.int32))
