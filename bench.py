@@ -282,6 +282,23 @@ def main():
                 roof["traffic_source"] = "profiles/ (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes)"
         except Exception:
             pass
+        # A bound that means something for the persistent pendulum kernels (their HBM fraction is nominal): VALU issue.
+        # Wave-instructions per launch come from the committed rocprofv3 PMC pass (SQ_INSTS_VALU); the kernel occupies
+        # one CU per agent, each CU issues at most one VALU instruction per SIMD per 1.07 ns (measured,
+        # tools/microbench/pk_fp32.hip); the duration is this run's.
+        try:
+            if not mlp and roll_n and world == 1:
+                sqc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))[-1]))
+                hit = [v for kn, v in sqc.get(args.config, {}).items() if kname in kn and "noise" not in kn]
+                if hit:
+                    insts = hit[0]["SQ_INSTS_VALU"]
+                    peak = A * 4 / 1.07e-9
+                    ach = insts / (avg_ms * 1e-3)
+                    roof["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "wave-instructions/s", "frac": ach / peak,
+                                          "insts_per_launch": insts, "cus": A,
+                                          "source": "profiles/*_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+        except Exception:
+            pass
         out = {
             "metric": "MPC control-steps/sec (agent-control-steps; %s, %s N=%d H=%d)"
                       % ("HalfCheetah learned MLP 26-200-200-20" if mlp else "Pendulum true model", c["opt"], N, H),

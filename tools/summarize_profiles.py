@@ -16,6 +16,7 @@ def short(name):
 
 
 traffic = {}
+sq = {}
 for cfg_dir in sorted(glob.glob(os.path.join(src, "cfg*"))):
     if not os.path.isdir(cfg_dir):
         continue
@@ -60,7 +61,10 @@ for cfg_dir in sorted(glob.glob(os.path.join(src, "cfg*"))):
                 hbm = (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
                 lines.append("  * HBM traffic per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 = %.0f bytes" % hbm)
                 traffic.setdefault(cfg, {})[k] = hbm
+            if "SQ_INSTS_VALU" in d:
+                sq.setdefault(cfg, {})[k] = {c: d[c] for c in d if c.startswith("SQ_")}
         lines.append("")
     open(os.path.join(dst, "%s_%s.md" % (tag, cfg)), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(dst, "%s_hbm_traffic.json" % tag), "w"), indent=1, sort_keys=True)
+json.dump(sq, open(os.path.join(dst, "%s_sq_counters.json" % tag), "w"), indent=1, sort_keys=True)
 print("wrote", os.listdir(dst))
