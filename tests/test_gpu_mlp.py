@@ -1,7 +1,8 @@
 """GPU parity tests for the learned-dynamics (MFMA) path, through the C ABI.
 
 Tolerances (fp32): the oracle's Dense layers accumulate in float64 and round once; the kernel accumulates in
-fp32 on the matrix cores (exact fp32 products, k-ordered), and tanh is the device libm's.  Stated bounds:
+fp32 on the matrix cores (exact fp32 products, k-ordered), and tanh is sign(x)(1 - 2/(e^{2|x|}+1)) on the hardware
+exp / rcp units (v_exp_f32, v_rcp_f32: absolute error <= ~3e-7, csrc/kernels_mlp.hpp bb_tanhf).  Stated bounds:
   single model step  : rtol 2e-5 + atol 2e-5 on the next state
   H-step rewards     : rtol 1e-3 + atol 1e-3 * H   ('rtol 1e-3 (MLP fp32-MFMA)')
   refit mean/var     : atol 1e-4 given the same elite set (elite near-ties handled as in the pendulum tests)
