@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <set>
@@ -133,6 +134,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.ilp = ival("BBMPC_ILP", 1) == 2 ? 2 : 1;
         sw.refit_v1 = flag("BBMPC_REFIT_V1");
         sw.zero_copy = !flag("BBMPC_NO_ZERO_COPY");
+        sw.host_poll = !flag("BBMPC_NO_HOST_POLL");
         sw.dbg = flag("BBMPC_DBG");
     }
     HU = H * U;
@@ -187,6 +189,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
 }
 
 Engine::~Engine() {
+    if (lazy_sync && stream) (void)hipStreamSynchronize(stream);
     if (own_stream) (void)hipStreamSynchronize(own_stream);
     rc.destroy();
     if (pf_stream) {
@@ -198,7 +201,16 @@ Engine::~Engine() {
     }
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     if (h_pin) (void)hipHostFree(h_pin);
+    if (host_done) (void)hipHostFree(host_done);
+    if (host_count) (void)hipFree(host_count);
     if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+void Engine::settle() {
+    if (lazy_sync) {
+        lazy_sync = false;
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
 }
 
 float* Engine::pinned(size_t count) {
@@ -858,7 +870,7 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
     fa.warm_start = fix(BBMPC_FIX_Q2_CEM_WARM_START);
     fa.balance = sw.balance;
     if (tail_flag) {
-        fa.done_flag = tail_flag; fa.done_count = rc.count; fa.done_value = tail_value;
+        fa.done_flag = tail_flag; fa.done_count = tail_count; fa.done_value = tail_value;
         tail_attached = true;
     }
     fa.alpha = cfg.alpha;
@@ -1155,7 +1167,7 @@ void Engine::optimize_fused_pso(const float* d_state_in, int add_noise, float* d
     fa.add_noise = add_noise;
     fa.w = cfg.pso_w; fa.c1 = cfg.pso_c1; fa.c2 = cfg.pso_c2; fa.v0frac = cfg.pso_v0_fraction;
     if (tail_flag) {             // the records are complete when this kernel ends (k_pso_seed only re-seeds the swarm)
-        fa.done_flag = tail_flag; fa.done_count = rc.count; fa.done_value = tail_value;
+        fa.done_flag = tail_flag; fa.done_count = tail_count; fa.done_value = tail_value;
         tail_attached = true;
     }
     fa.state = d_state_in;
@@ -1510,8 +1522,11 @@ struct bbmpc_handle_s {
     }                                             \
     return BBMPC_OK;
 
-#define CHECK_HANDLE(h) \
+#define CHECK_HANDLE_NOSETTLE(h) \
     if (!(h) || !(h)->e) throw HipError(BBMPC_E_INVALID, "null handle")
+#define CHECK_HANDLE(h)        \
+    CHECK_HANDLE_NOSETTLE(h);  \
+    (h)->e->settle()
 #define CHECK_PTR(p) \
     if (!(p)) throw HipError(BBMPC_E_INVALID, "null pointer argument: " #p)
 
@@ -1595,25 +1610,67 @@ int bbmpc_optimize_dev(bbmpc_handle h, const float* d_state, int32_t, int32_t no
 int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise, float* action, float* next_state,
                    float* reward) {
     API_BEGIN
-    CHECK_HANDLE(h);
+    CHECK_HANDLE_NOSETTLE(h);            // consecutive calls are ordered by the stream; everything else settles first
     CHECK_PTR(state);
     Engine& e = *h->e;
     const size_t ns = (size_t)e.A * e.S, nr = (size_t)e.A * e.rec;
     float* pin = e.pinned(ns + nr);
     memcpy(pin, state, ns * 4);
     (void)t;  // the reference evaluator accepts and ignores time_step (deterministic.py:26)
+    bool published = false;
     if (e.sw.zero_copy && e.use_fused()) {
         // the persistent kernel reads the [A,S] state and writes the packed record straight from / to the pinned,
         // device-mapped host buffer (a few PCIe transactions) -- no copy-engine round trips around a ~50 us kernel
         float* dpin = nullptr;
         HIP_CHECK(hipHostGetDevicePointer((void**)&dpin, pin, 0));
-        e.optimize_dev(dpin, noise, dpin + ns, nullptr);
+        if (e.sw.host_poll && !e.trace_on) {
+            // ... and its last workgroup publishes a sequence number into a pinned host word right after the record
+            // stores (publish_records_done): the call returns when the host sees it, ~10 us earlier than
+            // hipStreamSynchronize notices the kernel's completion; the stream itself is joined lazily (settle)
+            if (!e.host_done) {
+                HIP_CHECK(hipHostMalloc((void**)&e.host_done, 64, hipHostMallocDefault));
+                memset(e.host_done, 0, 64);
+                HIP_CHECK(hipHostGetDevicePointer((void**)&e.host_done_dev, e.host_done, 0));
+                HIP_CHECK(hipMalloc((void**)&e.host_count, 8));
+                HIP_CHECK(hipMemset(e.host_count, 0, 8));
+            }
+            if (++e.host_seq == 0) e.host_seq = 1;
+            e.tail_flag = e.host_done_dev;
+            e.tail_count = e.host_count;
+            e.tail_value = e.host_seq;
+            e.tail_attached = false;
+        }
+        try {
+            e.optimize_dev(dpin, noise, dpin + ns, nullptr);
+        } catch (...) {
+            e.tail_flag = nullptr;
+            throw;
+        }
+        published = e.tail_flag != nullptr && e.tail_attached;
+        e.tail_flag = nullptr;
     } else {
         HIP_CHECK(hipMemcpyAsync(e.d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e.stream));
         e.optimize_dev(e.d_state.p, noise, e.d_record.p, nullptr);
         HIP_CHECK(hipMemcpyAsync(pin + ns, e.d_record.p, nr * 4, hipMemcpyDeviceToHost, e.stream));
     }
-    HIP_CHECK(hipStreamSynchronize(e.stream));
+    if (published) {
+        volatile const uint32_t* f = e.host_done;
+        const uint32_t want = e.host_seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t spins = 0;
+        while (*f != want) {
+            if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                HIP_CHECK(hipStreamSynchronize(e.stream));       // a fault surfaces here; otherwise the word must be there
+                if (*f != want) throw HipError(BBMPC_E_HIP, "bbmpc_optimize: the control step finished without publishing its records");
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        e.lazy_sync = true;
+    } else {
+        HIP_CHECK(hipStreamSynchronize(e.stream));
+        e.lazy_sync = false;
+    }
     const float* r = pin + ns;
     for (int a = 0; a < e.A; ++a) {
         if (action) memcpy(action + (size_t)a * e.U, r + (size_t)a * e.rec, e.U * 4);
@@ -1944,6 +2001,7 @@ int bbmpc_optimize_gather_dev(bbmpc_handle h, const float* d_state, int32_t, int
     if (c.sync_mode == 1) {
         v = next_comm_seq(e);
         e->tail_flag = c.flag;
+        e->tail_count = c.count;
         e->tail_value = v;
     } else {
         e->tail_event = c.ready[slot];

@@ -88,6 +88,7 @@ struct Engine {
         int ilp = 1;                   // BBMPC_ILP
         bool refit_v1 = false;         // BBMPC_REFIT_V1
         bool zero_copy = true;         // !BBMPC_NO_ZERO_COPY
+        bool host_poll = true;         // !BBMPC_NO_HOST_POLL: host calls return on the kernel's own completion word
         bool dbg = false;              // BBMPC_DBG
     } sw;
 
@@ -129,8 +130,17 @@ struct Engine {
     RecordComm rc;           // multi-GPU record all-gather (comm.hpp); unused until bbmpc_comm_init
     hipEvent_t tail_event = nullptr;   // completion event wanted on the control step's last kernel (launch_with_tail)
     bool tail_attached = false;
-    uint32_t* tail_flag = nullptr;     // or: sequence number the last kernel should publish itself (RecordComm::flag)
+    uint32_t* tail_flag = nullptr;     // or: sequence number the last kernel should publish itself (RecordComm::flag / host_done)
     uint32_t tail_value = 0;
+    uint32_t* tail_count = nullptr;    // arrival counter that goes with tail_flag (device memory)
+    // host-in/host-out calls of a single-kernel control step return as soon as the kernel has published its records
+    // into host memory; the stream is joined lazily by the next call that needs it (settle)
+    uint32_t* host_done = nullptr;     // pinned host word the kernel publishes to
+    uint32_t* host_done_dev = nullptr; // its device address
+    uint32_t* host_count = nullptr;    // device memory arrival counter
+    uint32_t host_seq = 0;
+    bool lazy_sync = false;
+    void settle();
     hipStream_t pf_stream = nullptr;
     hipEvent_t pf_done[2] = {nullptr, nullptr}, pf_free = nullptr;
     int64_t pf_chunk[2] = {-1, -1};   // chunk id (control step / pf_steps) a buffer holds
