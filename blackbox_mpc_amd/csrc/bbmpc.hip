@@ -220,6 +220,7 @@ float* Engine::pinned(size_t count) {
         h_pin_n = 0;
         HIP_CHECK(hipHostMalloc((void**)&h_pin, count * sizeof(float), hipHostMallocDefault));
         h_pin_n = count;
+        HIP_CHECK(hipHostGetDevicePointer((void**)&h_pin_dev, h_pin, 0));
     }
     return h_pin;
 }
@@ -1621,8 +1622,7 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
     if (e.sw.zero_copy && e.use_fused()) {
         // the persistent kernel reads the [A,S] state and writes the packed record straight from / to the pinned,
         // device-mapped host buffer (a few PCIe transactions) -- no copy-engine round trips around a ~50 us kernel
-        float* dpin = nullptr;
-        HIP_CHECK(hipHostGetDevicePointer((void**)&dpin, pin, 0));
+        float* dpin = e.h_pin_dev;
         if (e.sw.host_poll && !e.trace_on) {
             // ... and its last workgroup publishes a sequence number into a pinned host word right after the record
             // stores (publish_records_done): the call returns when the host sees it, ~10 us earlier than

@@ -123,6 +123,7 @@ struct Engine {
     DevBuf<int> t_elites;
     // pinned staging
     float* h_pin = nullptr;
+    float* h_pin_dev = nullptr;   // device address of h_pin (looked up once per allocation)
     size_t h_pin_n = 0;
     // noise prefetch for the persistent kernel: the standard draws of control step t+1 are generated by otherwise
     // idle CUs on a side stream while step t's kernel runs (same Philox counters => bit-identical to in-kernel draws)
