@@ -1881,7 +1881,12 @@ int bbmpc_comm_init(bbmpc_handle h, const void* unique_id, int32_t nranks, int32
         HIP_CHECK(hipEventCreateWithFlags(&c.ready[s], hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&c.done[s], hipEventDisableTiming));
     }
-    r.check(r.CommInitRank(&c.comm, nranks, id, rank), "ncclCommInitRank");
+    const int irc = r.CommInitRank(&c.comm, nranks, id, rank);
+    if (irc != 0) {
+        c.comm = nullptr;
+        c.destroy();                     // stream + events created above
+        r.check(irc, "ncclCommInitRank");
+    }
     c.nranks = nranks;
     c.rank = rank;
     // BBMPC_COMM_SYNC=event: events only; default: flags in signal memory where the device supports stream wait-value
