@@ -236,6 +236,21 @@ def main():
     fence()
     t3 = time.perf_counter()
 
+    # PCIe-inclusive rate (never `value`): the same closed loop driven through the host-in/host-out entry point that
+    # MPCPolicy.act uses (NumPy state in, NumPy action / next state / reward out, SURVEY 8d's "wall time of one act")
+    host_rate = None
+    if world == 1 and not use_dist:
+        n_host = max(50, min(1000, int(0.25 / max((t3 - t2) / args.steps, 1e-6))))
+        st_h = np.ascontiguousarray(state.cpu().numpy())
+        for _ in range(20):
+            _, st_h, _ = eng.optimize(st_h)
+        th0 = time.perf_counter()
+        for _ in range(n_host):
+            _, st_h, _ = eng.optimize(st_h)
+        th1 = time.perf_counter()
+        eng.synchronize()
+        host_rate = n_host * A / (th1 - th0)
+
     if use_dist:
         # the gathered rows of this rank's own agents must be the records it produced
         for b in range(2):
@@ -324,6 +339,7 @@ def main():
             "candidate_trajectories_per_sec": steps_per_s * N * iters,
             "dyn_steps_per_sec": steps_per_s * N * iters * H,
             "ms_per_step_uninstrumented": (t3 - t2) / args.steps * 1e3,
+            "host_in_host_out_control_steps_per_sec": host_rate,
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1 and c["opt"] in ("RandomSearch", "CEM", "PI2"):
