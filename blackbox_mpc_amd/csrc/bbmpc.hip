@@ -135,6 +135,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.refit_v1 = flag("BBMPC_REFIT_V1");
         sw.zero_copy = !flag("BBMPC_NO_ZERO_COPY");
         sw.host_poll = !flag("BBMPC_NO_HOST_POLL");
+        sw.mlp_no_half_tail = flag("BBMPC_MLP_NO_HALF_TAIL");
         sw.dbg = flag("BBMPC_DBG");
     }
     HU = H * U;
@@ -507,23 +508,40 @@ void Engine::set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, con
     REQUIRE(hidden_tiles <= 16 * MLP_TMAX, BBMPC_E_UNSUPPORTED, "hidden width > 512 not supported");
     REQUIRE(mlp.tiles[0] <= 8 && mlp.tiles[n_layers] <= 4, BBMPC_E_UNSUPPORTED, "dim_S+dim_U <= 128 and dim_S <= 64 supported");
     mlp_nw = std::min(16, hidden_tiles);
+    for (int l = 1; l < n_layers; ++l) {
+        const int tail = dims[l] - 16 * (mlp.tiles[l] - 1);
+        mlp.half_tail[l] = (tail <= 8 && !sw.mlp_no_half_tail) ? 1 : 0;
+    }
     for (int l = 0; l < n_layers; ++l) {
         REQUIRE(acts[l] >= BBMPC_ACT_NONE && acts[l] <= BBMPC_ACT_SIGMOID, BBMPC_E_INVALID, "unknown activation");
         REQUIRE(w[l] && b[l], BBMPC_E_INVALID, "null weight/bias pointer");
         mlp.act[l] = acts[l];
         const int K = dims[l], M = dims[l + 1], IT = mlp.tiles[l], OT = mlp.tiles[l + 1];
         std::vector<float> wp((size_t)OT * IT * 256, 0.0f), bp((size_t)OT * 256, 0.0f);
+        // Hidden features are internal, so their order inside a tile is free.  When the last tile of a hidden layer
+        // holds <= 8 features (200 units = 12 tiles + 8) they are put into the slots 4g + {0, 1}: as the next layer's
+        // K tile that leaves MFMAs 2 and 3 (k = 4g + 2, 4g + 3) with nothing but zeros, and the pipelined kernel
+        // skips them.  slot -> feature (or -1 = padding); inputs (layer 0) and outputs (last layer) keep their order.
+        auto feature_of_slot = [&](int layer_of_feature, int slot) -> int {
+            const int width = dims[layer_of_feature], tiles = (width + 15) / 16, t = slot >> 4, q = slot & 15;
+            if (layer_of_feature >= 1 && layer_of_feature < n_layers && t == tiles - 1 && mlp.half_tail[layer_of_feature]) {
+                if ((q & 3) >= 2) return -1;
+                const int f = 16 * t + 2 * (q >> 2) + (q & 3);
+                return f < width ? f : -1;
+            }
+            return slot < width ? slot : -1;
+        };
         for (int ot = 0; ot < OT; ++ot) {
             for (int it = 0; it < IT; ++it)
                 for (int s = 0; s < 4; ++s)
                     for (int ln = 0; ln < 64; ++ln) {
-                        const int k = it * 16 + 4 * (ln >> 4) + s, o = ot * 16 + (ln & 15);
-                        if (k < K && o < M) wp[(((size_t)ot * IT + it) * 4 + s) * 64 + ln] = w[l][(size_t)k * M + o];
+                        const int k = feature_of_slot(l, it * 16 + 4 * (ln >> 4) + s), o = feature_of_slot(l + 1, ot * 16 + (ln & 15));
+                        if (k >= 0 && o >= 0) wp[(((size_t)ot * IT + it) * 4 + s) * 64 + ln] = w[l][(size_t)k * M + o];
                     }
             for (int ln = 0; ln < 64; ++ln)
                 for (int r = 0; r < 4; ++r) {
-                    const int o = ot * 16 + (ln >> 4) * 4 + r;
-                    if (o < M) bp[((size_t)ot * 64 + ln) * 4 + r] = b[l][o];
+                    const int o = feature_of_slot(l + 1, ot * 16 + (ln >> 4) * 4 + r);
+                    if (o >= 0) bp[((size_t)ot * 64 + ln) * 4 + r] = b[l][o];
                 }
         }
         upload(d_wpack[l], wp);
@@ -551,8 +569,9 @@ void Engine::set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, con
                 for (int it = 0; it < IT; ++it)
                     for (int ln = 0; ln < 64; ++ln)
                         for (int r = 0; r < 4; ++r) {
-                            const int kk = 16 * it + 4 * (ln >> 4) + r, o = 16 * ot + (ln & 15);
-                            const float v = (kk < K && o < M) ? w[l][(size_t)kk * M + o] : 0.0f;
+                            // same slot -> feature map as the fp32 operands (the biases come from bpack)
+                            const int kk = feature_of_slot(l, 16 * it + 4 * (ln >> 4) + r), o = feature_of_slot(l + 1, 16 * ot + (ln & 15));
+                            const float v = (kk >= 0 && o >= 0) ? w[l][(size_t)kk * M + o] : 0.0f;
                             const uint16_t h = bf16_rne(v), lo = bf16_rne(v - bf16_f(h));
                             uint16_t* d = hw + (((size_t)ot * IT + it) * 64 + ln) * 8;
                             d[r] = h;

@@ -88,6 +88,7 @@ struct Engine {
         int ilp = 1;                   // BBMPC_ILP
         bool refit_v1 = false;         // BBMPC_REFIT_V1
         bool zero_copy = true;         // !BBMPC_NO_ZERO_COPY
+        bool mlp_no_half_tail = false; // BBMPC_MLP_NO_HALF_TAIL: keep hidden features in index order (no skipped MFMAs)
         bool host_poll = true;         // !BBMPC_NO_HOST_POLL: host calls return on the kernel's own completion word
         bool dbg = false;              // BBMPC_DBG
     } sw;

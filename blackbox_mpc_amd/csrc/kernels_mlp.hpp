@@ -44,6 +44,8 @@ struct MlpDesc {
     int act[MLP_MAX_LAYERS];
     const float* wpack[MLP_MAX_LAYERS];  // [OT][IT][4][64]
     const float* bpack[MLP_MAX_LAYERS];  // [OT][64][4]
+    int half_tail[MLP_MAX_LAYERS + 1];   // hidden layer whose last 16-feature tile holds <= 8 features: they sit in the
+                                         // slots 4g+{0,1} (set_mlp), so MFMAs 2 and 3 of that K tile multiply zeros
     int normalized;
     const float* mean_s;                 // [S]
     const float* std_s;                  // [S]
@@ -522,6 +524,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     const int S = p.S, U = p.U, H = p.H;
     const int Sp = (S + 3) & ~3;
     const bool normd = m.normalized != 0;
+    const bool half1 = m.half_tail[1] != 0, half2 = m.half_tail[2] != 0;   // inputs of layer 1 / of the last layer
     // ---- LDS carve
     const int sz_xs = IT0 * 256, sz_h0 = HT * 256, sz_part = NW * OTL * 256, sz_st = 2 * MLP_TP * Sp,
               sz_acts = (H * MLP_TP * U + 3) & ~3, sz_pen = (MLP_TP * U + 63) & ~63;
@@ -633,8 +636,10 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             if (co >= 0) pv = cpart[(size_t)it * OTL * 256];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 0], b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 1], b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 2], b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 3], b.w, acc, 0, 0, 0);
+            if (it + 1 < HT || !half1) {               // the padded half of the last K tile multiplies zeros
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 2], b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 3], b.w, acc, 0, 0, 0);
+            }
             if (co >= 0) cacc = cacc + pv;
         }
         acc.x = apply_act_ct<A1>(acc.x); acc.y = apply_act_ct<A1>(acc.y);
@@ -645,8 +650,10 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
             o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 0], acc.x, o, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 1], acc.y, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 2], acc.z, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 3], acc.w, o, 0, 0, 0);
+            if (wave + 1 < HT || !half2) {             // this wave's K slice is the half-empty tile
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 2], acc.z, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 3], acc.w, o, 0, 0, 0);
+            }
             *reinterpret_cast<f32x4*>(part + (((size_t)wave * OTL + ot) * 64 + lane) * 4) = o;
         }
     };
