@@ -56,7 +56,11 @@ PEND_MLP = ([4, 32, 32, 32, 3], ["tanh", "tanh", "tanh", None], 3, 1, "pendulum"
 @pytest.mark.parametrize("spec,normalized", [(CHEETAH, True), (CHEETAH, False), (PEND_MLP, True),
                                              (([26, 500, 500, 500, 20], ["tanh", "relu", "sigmoid", None], 20, 6, "cheetah"), True),
                                              (([26, 20], [None], 20, 6, "cheetah"), True),
-                                             (([23, 40, 18], ["tanh", None], 18, 5, "cheetah"), True)])
+                                             (([23, 40, 18], ["tanh", None], 18, 5, "cheetah"), True),
+                                             # hidden widths whose last 16-feature tile is half empty (permuted operand
+                                             # packing, csrc set_mlp): a single 8-wide tile, 5 of 16, and sigmoid padding
+                                             (([4, 8, 3], ["tanh", None], 3, 1, "pendulum"), True),
+                                             (([4, 21, 24, 3], ["sigmoid", "tanh", None], 3, 1, "pendulum"), False)])
 def test_single_step_matches_oracle(L, spec, normalized):
     dims, acts, S, U, reward = spec
     eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, normalized)
