@@ -1069,8 +1069,9 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
         case BBMPC_OPT_CEM: {
             hipLaunchKernelGGL(k_dist_init, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, HU, U, d_lo.p, d_hi.p,
                                d_prev_mean.p, d_var0.p, d_mean.p, d_var.p, d_sigma.p, 1);
-            // iters == 0: action = mean[:,0] of the untouched distribution
-            HIP_CHECK(hipMemcpy2DAsync(d_action.p, U * 4, d_prev_mean.p, HU * 4, U * 4, A, hipMemcpyDeviceToDevice, stream));
+            // iters == 0: action = mean[:,0] of the untouched distribution (otherwise the last refit writes it)
+            if (iters == 0)
+                HIP_CHECK(hipMemcpy2DAsync(d_action.p, U * 4, d_prev_mean.p, HU * 4, U * 4, A, hipMemcpyDeviceToDevice, stream));
             const float* inj_t = injected(BBMPC_NOISE_TRUNC_NORMAL);
             // LDS budget for the refit: rewards + elite idx + elite tile
             const int kpad = (k + 3) & ~3;
@@ -1100,7 +1101,8 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
         case BBMPC_OPT_PI2: {
             hipLaunchKernelGGL(k_dist_init, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, HU, U, d_lo.p, d_hi.p,
                                d_prev_mean.p, d_var0.p, d_mean.p, d_var.p, d_sigma.p, 0);
-            HIP_CHECK(hipMemcpy2DAsync(d_action.p, U * 4, d_prev_mean.p, HU * 4, U * 4, A, hipMemcpyDeviceToDevice, stream));
+            if (iters == 0)              // otherwise the last refit writes the action
+                HIP_CHECK(hipMemcpy2DAsync(d_action.p, U * 4, d_prev_mean.p, HU * 4, U * 4, A, hipMemcpyDeviceToDevice, stream));
             const float* inj_t = injected(BBMPC_NOISE_TRUNC_NORMAL);
             const size_t lds = (size_t)(Nst + 64) * 4;
             for (int it = 0; it < iters; ++it) {
