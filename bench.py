@@ -1,13 +1,24 @@
 #!/usr/bin/env python
 """Headline benchmark: MPC control steps / second (and candidate trajectories / second).
 
-A "step" is ONE control step of the hot path (all optimizer iterations: sample -> rollout -> reduce ->
-refit, plus the action/next-state tail) for every agent this process owns, closed-loop on the device:
-the state stays resident in HBM and the engine's own pendulum step plays the environment, so warm-starts
-are exercised.  Default workload = BASELINE.json configs[1]: Pendulum-v0 true dynamics, CEM,
-num_agents=1 per GPU, N=500, H=30, 5 iterations, k=50.  With --gpus N every rank owns its own agents
-(weak scaling, independent agents, RNG keyed by global agent id) and one RCCL all-gather per control
-step collects the packed (action | next_state | reward) records -- the only exchange the path has.
+A "step" is ONE control step of the hot path (all optimizer iterations: sample -> rollout -> reduce -> refit, plus the
+action / next-state tail) for every agent this process owns, closed loop: the engine's own model plays the environment
+(SURVEY.md 8d), so warm starts are exercised.
+
+`value` is the metric as SURVEY.md 8(d) / BASELINE.md define it: 1 / MEDIAN wall time of one `MPCPolicy.act(obs, t)`
+-- NumPy observation in, all optimizer iterations on the GPU, NumPy action / next observation / reward out, the same
+bracket as the reference's utils/rollouts.py:92-101 -- times the agents the job owns, with p10 / p90.  The
+device-resident rate of the same closed loop (state never leaves HBM, launches never synchronised) is reported next
+to it as `device_resident_control_steps_per_sec`, and the dominant kernel's roofline is measured on that loop with HIP
+events on the launch stream.
+
+Default workload = BASELINE.json configs[1]: Pendulum-v0 true dynamics, CEM, num_agents=1 per GPU, N=500, H=30,
+5 iterations, k=50.  At one GPU the same JSON line carries a `secondary` block for the north star's second target --
+HalfCheetah learned MLP (26-200-200-20), PI2, N=1000, H=30 -- with its own MFMA roofline and CPU baseline.
+
+With --gpus N every rank owns its own agents (weak scaling, independent agents, RNG keyed by global agent id); the
+only exchange the path has is one RCCL all-gather of the packed (action | next_state | reward) records per control
+step, issued by the engine on its own communicator and stream and overlapped with the next control step.
 """
 import argparse
 import json
@@ -28,9 +39,11 @@ CONFIGS = {
     "cfg3": dict(env="pendulum", opt="PI2", N=1000, A=8, H=30, iters=5, k=0),      # 64 agents over 8 GPUs
     "cfg3full": dict(env="pendulum", opt="PI2", N=1000, A=64, H=30, iters=5, k=0),  # all 64 agents on one GPU
     "cfg4": dict(env="cheetah", opt="CEM", N=1000, A=1, H=30, iters=5, k=50),
+    # north_star target 2: HalfCheetah learned MLP, PI2, N=1000, H=30
+    "cfg4pi2": dict(env="cheetah", opt="PI2", N=1000, A=1, H=30, iters=5, k=0),
     "cfg5cem": dict(env="cheetah", opt="CEM", N=2000, A=4, H=50, iters=5, k=50),     # config-5 shape per GPU, CEM
     "cfg5full": dict(env="cheetah", opt="CEM", N=2000, A=32, H=50, iters=5, k=50),   # all 32 agents on one GPU
-    # the other three optimizers at config 2's size (Pendulum, N=500, H=30, 5 iterations)
+    # the other optimizers at config 2's size (Pendulum, N=500, H=30, 5 iterations)
     "cfg2pso": dict(env="pendulum", opt="PSO", N=500, A=1, H=30, iters=5, k=0),
     "cfg2spsa": dict(env="pendulum", opt="SPSA", N=500, A=1, H=30, iters=5, k=0),
     "cfg2cma": dict(env="pendulum", opt="CMA-ES", N=500, A=1, H=30, iters=5, k=50),
@@ -39,9 +52,449 @@ CONFIGS = {
     "cfg5pso": dict(env="cheetah", opt="PSO", N=2000, A=4, H=50, iters=5, k=0),
     "cfg5cma": dict(env="cheetah", opt="CMA-ES", N=2000, A=4, H=50, iters=5, k=50),  # per-agent CMA-ES (n = 300 each)
 }
+DEFAULT_STEPS = {"cfg1": 2000, "cfg2": 2000, "cfg3": 2000, "cfg3full": 300, "cfg4": 400, "cfg4pi2": 400, "cfg5cem": 60,
+                 "cfg5pso": 60, "cfg5full": 10, "cfg5cma": 30}
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
 MLP_DIMS = [26, 200, 200, 20]
+SECONDARY = "cfg4pi2"
+
+
+def _pct(xs, q):
+    return float(np.percentile(np.asarray(xs, np.float64), q))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the workload: a rank's agents behind the reference's own API (MPCPolicy), plus the device-resident loop
+# ------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """One rank's share of a configuration on the GPU.  `act_step` = what the metric brackets (MPCPolicy.act);
+    `dev_step` = the same control step with the state resident in HBM."""
+
+    def __init__(self, name, rank, world, local, dev, use_dist, backend, gather_mode):
+        import torch
+        import torch.distributed as dist
+        from blackbox_mpc_amd import _lib as L
+        from blackbox_mpc_amd.dynamics_functions import DeterministicMLP
+        from blackbox_mpc_amd.dynamics_handlers import SystemDynamicsHandler
+        from blackbox_mpc_amd.policies import MPCPolicy
+        from blackbox_mpc_amd.spaces import Box
+        from blackbox_mpc_amd.utils import synthetic as SY
+        self.torch, self.dist, self.L = torch, dist, L
+        self.name, self.rank, self.world, self.dev, self.use_dist, self.backend = name, rank, world, dev, use_dist, backend
+        c = self.c = CONFIGS[name]
+        N, A, H, iters, k = c["N"], c["A"], c["H"], c["iters"], c["k"]
+        self.mlp = c["env"] == "cheetah"
+        quirks = L.CMAES_PER_AGENT if c["opt"] == "CMA-ES" else 0   # the shardable CMA-ES mode (DESIGN.md section 6)
+        opt_args = dict(planning_horizon=H, population_size=N, seed=0, quirks=quirks, agent_offset=rank * A,
+                        num_agents_global=world * A, device=local)
+        if c["opt"] != "RandomSearch":
+            opt_args["max_iterations"] = iters
+        if k:
+            opt_args["num_elite"] = k
+        if self.mlp:
+            from blackbox_mpc_amd.utils.cheetah import reward_function
+            self.U, self.S = 6, 20
+            act_space, obs_space = Box([-1.0] * self.U, [1.0] * self.U), Box([-10.0] * self.S, [10.0] * self.S)
+            net = DeterministicMLP(layers=MLP_DIMS, activation_functions=SY.CHEETAH_ACTIVATIONS, seed=1)
+            net.set_weights(*SY.make_mlp_params(MLP_DIMS, seed=42))      # Glorot-uniform / zero bias, last layer x0.1
+            handler = SystemDynamicsHandler(act_space, obs_space, dynamics_function=net, true_model=False,
+                                            is_normalized=True)
+            handler.set_normalization_stats(*SY.cheetah_stats(self.S, self.U))
+            self.policy = MPCPolicy(reward_function=reward_function, env_action_space=act_space,
+                                    env_observation_space=obs_space, dynamics_handler=handler,
+                                    optimizer_name=c["opt"], num_agents=A, **opt_args)
+            self.start = SY.cheetah_start_states(A, self.S, agent_offset=rank * A)
+        else:
+            from blackbox_mpc_amd.utils.pendulum import PendulumTrueModel, pendulum_reward_function
+            self.U, self.S = 1, 3
+            self.policy = MPCPolicy(reward_function=pendulum_reward_function, env_action_space=Box([-2.0], [2.0]),
+                                    env_observation_space=Box([-1, -1, -8], [1, 1, 8]), true_model=True,
+                                    dynamics_function=PendulumTrueModel(), optimizer_name=c["opt"], num_agents=A,
+                                    **opt_args)
+            self.start = SY.pendulum_start_states(A, agent_offset=rank * A)
+        self.eng = self.policy._optimizer._require_engine()
+        self.policy.reset()              # episode start, as utils/rollouts.py:_sample does (PSO draws its swarm here)
+        self.rec = self.U + self.S + 1
+        self.A = A
+        # ---- the one exchange: all-gather of the records, on the engine's own RCCL communicator + stream -------------
+        self.gather_mode = "none"
+        self.fallback_reason = None
+        self.native = False
+        self.comm_info = None
+        if use_dist:
+            self.gather_mode = gather_mode
+            if backend == "nccl" and gather_mode == "native":
+                from blackbox_mpc_amd.parallel import attach_record_comm
+                ok = torch.ones(1, device=dev)
+                why = ""
+                try:
+                    attach_record_comm(self.eng, device=dev)
+                    self.comm_info = self.eng.comm_info()
+                    if self.comm_info[0] != world:
+                        raise RuntimeError("ncclCommCount = %d, expected %d" % (self.comm_info[0], world))
+                except Exception as ex:                       # e.g. librccl not loadable
+                    why = "%s: %s" % (type(ex).__name__, ex)
+                    print("bench[rank %d]: engine-owned record gather unavailable (%s)" % (rank, why), file=sys.stderr)
+                    ok.zero_()
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if ok.item() == 0:
+                    # every rank agrees to use torch.distributed's collective instead -- reported, never silent
+                    self.gather_mode, self.fallback_reason = "async", (why or "another rank could not create its communicator")
+                    try:
+                        self.eng.comm_destroy()
+                    except Exception:
+                        pass
+                else:
+                    self.native = True
+            elif backend != "nccl":
+                self.gather_mode = "host(%s)" % backend
+        # The engine launches on its own (non-blocking) stream.  Only the torch.distributed gather modes put torch work
+        # into the loop (events, collectives): they run the loop on a torch side stream that the engine is told to use.
+        self.torch_loop = (use_dist and not self.native) or bool(os.environ.get("BBMPC_BENCH_TORCH_STREAM"))
+        if self.torch_loop:
+            self.stream = torch.cuda.Stream(device=dev)
+            torch.cuda.set_stream(self.stream)
+            self.eng.set_torch_stream(self.stream)
+        else:
+            self.stream = None
+            self.eng.set_stream(None)
+        self.state = torch.from_numpy(self.start).to(dev)
+        self.nxt = torch.empty_like(self.state)
+        # records / gathered results are double buffered: the all-gather of control step t runs on its own stream
+        # while step t+1 computes (the local optimizer never needs the other ranks' records)
+        self.records = [torch.zeros((A, self.rec), device=dev, dtype=torch.float32) for _ in range(2)]
+        self.gathered = [torch.zeros((world * A, self.rec), device=dev, dtype=torch.float32) for _ in range(2)] if use_dist else None
+        self.comm_stream = torch.cuda.Stream(device=dev) if (use_dist and self.torch_loop) else None
+        self.comm_done = [None, None]
+        self.ready_ev = [torch.cuda.Event(), torch.cuda.Event()] if self.comm_stream is not None else None
+        self.done_ev = [torch.cuda.Event(), torch.cuda.Event()] if self.comm_stream is not None else None
+        self.works = [None, None]
+        self.tick = 0
+        self.obs = self.start.copy()
+        self.last_host_record = [None, None]
+
+    # -- what `value` is measured on: MPCPolicy.act, NumPy in / NumPy out ---------------------------------------------
+    def act_step(self, t):
+        b = self.tick & 1
+        self.tick += 1
+        if self.native:
+            # this rank's act + the all-gather of its records enqueued behind it on the communication stream
+            self.eng.gather_wait(b)
+            a, n, r = self.eng.optimize_gather(self.obs, self.gathered[b].data_ptr(), b, t)
+        else:
+            a, n, r = self.policy.act(self.obs, t)
+            if self.use_dist:
+                self._torch_gather_host(b, a, n, r)
+        self.obs = n                      # closed loop: the model is the environment
+        self.last_host_record[b] = np.concatenate([a, n, np.asarray(r, np.float32).reshape(-1, 1)], axis=1)
+
+    def _torch_gather_host(self, b, a, n, r):
+        torch, dist = self.torch, self.dist
+        rec = torch.from_numpy(np.concatenate([a, n, np.asarray(r, np.float32).reshape(-1, 1)], axis=1).astype(np.float32))
+        if self.backend == "nccl":
+            if self.works[b] is not None:
+                self.works[b].wait()
+            self.records[b].copy_(rec, non_blocking=True)
+            self.works[b] = dist.all_gather_into_tensor(self.gathered[b], self.records[b], async_op=True)
+        else:
+            out = torch.empty((self.world * self.A, self.rec), dtype=torch.float32)
+            dist.all_gather_into_tensor(out, rec)
+            self.gathered[b].copy_(out)
+            self.records[b].copy_(rec)
+
+    # -- the same control step with the state resident in HBM ---------------------------------------------------------
+    def dev_step(self):
+        torch, dist, eng = self.torch, self.dist, self.eng
+        b = self.tick & 1
+        self.tick += 1
+        record = self.records[b]
+        if self.native:
+            eng.gather_wait(b)
+            eng.optimize_gather_dev(self.state.data_ptr(), record.data_ptr(), self.gathered[b].data_ptr(), b,
+                                    d_next_state=self.nxt.data_ptr())
+            self.state, self.nxt = self.nxt, self.state
+            return
+        if self.works[b] is not None:
+            self.works[b].wait()                     # stream-level: the gather that last read this buffer has finished
+            self.works[b] = None
+        if self.comm_done[b] is not None:
+            self.stream.wait_event(self.comm_done[b])
+        eng.optimize_dev(self.state.data_ptr(), record.data_ptr(), d_next_state=self.nxt.data_ptr())
+        if self.use_dist:
+            if self.backend == "nccl" and self.gather_mode == "async":
+                self.works[b] = dist.all_gather_into_tensor(self.gathered[b], record, async_op=True)
+            else:
+                self.ready_ev[b].record(self.stream)
+                self.comm_stream.wait_event(self.ready_ev[b])
+                with torch.cuda.stream(self.comm_stream):
+                    if self.backend == "nccl":
+                        dist.all_gather_into_tensor(self.gathered[b], record)
+                    else:
+                        out = torch.empty((self.world * self.A, self.rec), dtype=torch.float32)
+                        dist.all_gather_into_tensor(out, record.cpu())
+                        self.gathered[b].copy_(out)
+                    self.done_ev[b].record(self.comm_stream)
+                    self.comm_done[b] = self.done_ev[b]
+        self.state, self.nxt = self.nxt, self.state
+
+    def fence(self):
+        for b in range(2):
+            if self.works[b] is not None:
+                self.works[b].wait()
+                self.works[b] = None
+        if self.native:
+            for b in range(2):
+                self.eng.gather_wait(b, host_block=True)
+        self.eng.synchronize()                       # launch stream + the engine's communication stream
+        self.torch.cuda.synchronize()
+        if self.use_dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def set_profiling(self, on, every=1):
+        self.eng.set_profiling(on, every=every)
+
+    def get_profile(self):
+        return self.eng.get_profile()
+
+    def check_gather(self, host_records):
+        """The gathered rows of this rank's own agents must be the records it produced (bit for bit), and the row
+        blocks of the other ranks must be populated.  Returns the number of rows checked."""
+        if not self.use_dist:
+            return 0
+        torch = self.torch
+        rows = 0
+        for b in range(2):
+            mine = self.gathered[b][self.rank * self.A:(self.rank + 1) * self.A]
+            ref = torch.from_numpy(host_records[b]).to(mine.device) if host_records and host_records[b] is not None else self.records[b]
+            if not torch.equal(mine.view(torch.int32), ref.contiguous().view(torch.int32)):
+                raise RuntimeError("all-gather returned different records for the local agents: %r vs %r" % (mine, ref))
+            if not bool(torch.isfinite(self.gathered[b]).all()):
+                raise RuntimeError("gathered records contain non-finite rows")
+            rows += int(self.gathered[b].shape[0])
+        return rows
+
+    def close(self):
+        if self.native:
+            self.eng.synchronize()
+            self.eng.comm_destroy()
+
+
+class StubWorkload:
+    """BBMPC_BENCH_STUB=1: the same interface without a GPU, so that bench.py's rank logic (environment variables,
+    process group, barriers, max-over-ranks timing, the gathered-rows check, the JSON line) runs under the gloo
+    backend in the CPU test suite (tests/test_bench_ranks_cpu.py).  It computes nothing worth timing and its numbers
+    mean nothing; it is refused outside BBMPC_BENCH_BACKEND=gloo."""
+
+    def __init__(self, name, rank, world, local, dev, use_dist, backend, gather_mode):
+        import torch
+        import torch.distributed as dist
+        assert backend == "gloo", "the stub workload only exists for the gloo rank-logic test"
+        self.torch, self.dist = torch, dist
+        c = self.c = CONFIGS[name]
+        self.name, self.rank, self.world, self.use_dist, self.backend = name, rank, world, use_dist, backend
+        self.mlp = c["env"] == "cheetah"
+        self.U, self.S = (6, 20) if self.mlp else (1, 3)
+        self.A, self.rec = c["A"], self.U + self.S + 1
+        self.gather_mode, self.fallback_reason, self.native, self.comm_info = "host(gloo)", None, False, None
+        self.records = [torch.zeros((self.A, self.rec)) for _ in range(2)]
+        self.gathered = [torch.zeros((world * self.A, self.rec)) for _ in range(2)] if use_dist else None
+        self.tick = 0
+        self.last_host_record = [None, None]
+        self.obs = np.full((self.A, self.S), 0.01 * (rank + 1), np.float32)
+
+    def _step(self):
+        b = self.tick & 1
+        self.tick += 1
+        ga = self.rank * self.A + np.arange(self.A, dtype=np.float32)
+        rec = np.zeros((self.A, self.rec), np.float32)
+        rec[:, 0] = ga + 0.001 * self.tick                          # "action" keyed by global agent id and step
+        rec[:, self.U:self.U + self.S] = self.obs * 0.5
+        rec[:, -1] = -ga
+        self.obs = rec[:, self.U:self.U + self.S].copy()
+        self.records[b] = self.torch.from_numpy(rec)
+        self.last_host_record[b] = rec
+        if self.use_dist:
+            self.dist.all_gather_into_tensor(self.gathered[b], self.records[b])
+
+    def act_step(self, t):
+        self._step()
+
+    def dev_step(self):
+        self._step()
+
+    def fence(self):
+        if self.use_dist:
+            self.dist.barrier()
+
+    def set_profiling(self, on, every=1):
+        pass
+
+    def get_profile(self):
+        return 0.0, 0, "stub"
+
+    check_gather = Workload.check_gather
+
+    def close(self):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def measure(W, steps, warmup, dist, use_dist, red_dev):
+    """Times `steps` control steps twice: through MPCPolicy.act (the metric) and device-resident (the roofline).
+    Both regions are bracketed by barrier + synchronize on both sides; elapsed = MAX over ranks."""
+    torch = W.torch
+
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- (1) the metric: wall time of MPCPolicy.act, host in / host out ------------------------------------------
+    for t in range(warmup):
+        W.act_step(t)
+    W.fence()
+    # exactly `steps` calls inside the barrier-to-barrier bracket (ms_per_step); the percentiles want >= 30 samples, so a
+    # shorter run appends the missing calls AFTER the bracket and only their per-call wall times join the sample
+    n_samples = max(steps, 30)
+    walls = np.empty(n_samples, np.float64)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        s0 = time.perf_counter()
+        W.act_step(warmup + i)
+        walls[i] = time.perf_counter() - s0
+    W.fence()
+    t1 = time.perf_counter()
+    for i in range(steps, n_samples):
+        s0 = time.perf_counter()
+        W.act_step(warmup + i)
+        walls[i] = time.perf_counter() - s0
+    W.fence()
+    host_records = list(W.last_host_record)
+    rows_act = W.check_gather(host_records)
+    act_elapsed = reduce_max(t1 - t0)
+    med, p10, p90 = (reduce_max(_pct(walls, q)) for q in (50, 10, 90))
+
+    # ---- (2) device-resident closed loop + HIP events around the dominant kernel ----------------------------------
+    for _ in range(max(2, min(warmup, 20))):
+        W.dev_step()
+    W.fence()
+    # an event pair costs a few microseconds of stream time (a sixth of a config-2 control step): every launch is
+    # bracketed when the run is short, every 8th otherwise; the un-instrumented repeat below gives the rate
+    every = 1 if steps <= 64 else 8
+    W.set_profiling(True, every=every)
+    W.get_profile()
+    t2 = time.perf_counter()
+    for _ in range(steps):
+        W.dev_step()
+    W.fence()
+    t3 = time.perf_counter()
+    roll_ms, roll_n, kname = W.get_profile()
+    W.set_profiling(False)
+    W.fence()
+    t4 = time.perf_counter()
+    for _ in range(steps):
+        W.dev_step()
+    W.fence()
+    t5 = time.perf_counter()
+    rows_dev = W.check_gather(None)
+    dev_elapsed = reduce_max(t5 - t4)
+    return dict(walls=walls, act_elapsed=act_elapsed, median=med, p10=p10, p90=p90, dev_elapsed=dev_elapsed,
+                dev_elapsed_instrumented=reduce_max(t3 - t2), roll_ms=roll_ms, roll_n=roll_n, kname=kname,
+                prof_every=every, gather_rows_checked=rows_act + rows_dev, n_samples=n_samples)
+
+
+def roofline(W, m, name, world):
+    c = CONFIGS[name]
+    N, A, H, iters = c["N"], c["A"], c["H"], c["iters"]
+    U, S, mlp, kname = W.U, W.S, W.mlp, m["kname"]
+    bytes_per_traj = 4.0 * (H * U + 1) + 4.0 * S / N        # SURVEY 8d / BASELINE.md
+    avg_ms = m["roll_ms"] / max(m["roll_n"], 1)
+    fused = kname.startswith("k_fused")
+    # trajectories one launch of the dominant kernel processes: the persistent kernel runs every iteration of every
+    # local agent in one launch, the per-iteration kernels one iteration (SPSA: two launches of N per iteration)
+    launch_traj = N * A * (iters if fused else 1)
+    if mlp:
+        flops_per_traj = H * 2.0 * sum(MLP_DIMS[i] * MLP_DIMS[i + 1] for i in range(len(MLP_DIMS) - 1))
+        achieved = launch_traj * flops_per_traj / (avg_ms * 1e-3) / 1e12 if m["roll_n"] else None
+        roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None, "traffic": None,
+                "algorithmic_flops_per_launch": launch_traj * flops_per_traj,
+                "note": "fp32-in/fp32-acc MFMA (%s); peak = dense fp32 matrix rate"
+                        % ("v_mfma_f32_4x4x1_16b_f32" if "_q4" in kname else "v_mfma_f32_16x16x4_f32")}
+    else:
+        achieved = launch_traj * bytes_per_traj / (avg_ms * 1e-3) / 1e9 if m["roll_n"] else None
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                "algorithmic_bytes_per_launch": launch_traj * bytes_per_traj,
+                "note": "the fused kernel keeps the H-step recurrence in registers/LDS: the path is VALU-issue "
+                        "bound, the HBM fraction is nominal (DESIGN.md)"}
+    roof.update({"kernel": kname, "avg_launch_us": avg_ms * 1e3, "launches": m["roll_n"],
+                 "launches_note": "HIP-event pairs on the launch stream around %s launch of the kernel in the "
+                                  "device-resident timed region" % ("every" if m["prof_every"] == 1 else "every %dth" % m["prof_every"])})
+    # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    # collected separately, (2*FETCH + WRITE)*1024 -- tools/profile_round.sh, profiles/*_hbm_traffic.json)
+    import glob
+    try:
+        tr = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]))
+        hit = [v for kn, v in tr.get(name, {}).items() if kname in kn]
+        if hit and world == 1:
+            roof["traffic"] = hit[0]
+            roof["traffic_source"] = "profiles/ (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes)"
+    except Exception:
+        pass
+    # A bound that means something for the persistent pendulum kernels (their HBM fraction is nominal): VALU issue.
+    # Wave-instructions per launch come from the committed rocprofv3 PMC pass (SQ_INSTS_VALU); the kernel occupies
+    # one CU per agent, each CU issues at most one VALU instruction per SIMD per 1.07 ns (tools/microbench/pk_fp32.hip)
+    try:
+        if not mlp and m["roll_n"] and world == 1:
+            sqc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))[-1]))
+            hit = [v for kn, v in sqc.get(name, {}).items() if kname in kn and "noise" not in kn]
+            if hit:
+                insts = hit[0]["SQ_INSTS_VALU"]
+                peak = A * 4 / 1.07e-9
+                ach = insts / (avg_ms * 1e-3)
+                roof["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "wave-instructions/s", "frac": ach / peak,
+                                      "insts_per_launch": insts, "cus": A,
+                                      "source": "profiles/*_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+    except Exception:
+        pass
+    return roof
+
+
+def describe(name, W, world):
+    c = CONFIGS[name]
+    return ("BASELINE %s: %s, %s, num_agents=%d/GPU, N=%d, H=%d, %d iters%s, closed loop (the model is the environment)"
+            % (name, "HalfCheetah(mod) S=20 U=6 learned MLP 26-200-200-20 dynamics" if W.mlp else "Pendulum-v0 true dynamics",
+               c["opt"], c["A"], c["N"], c["H"], c["iters"], (", k=%d" % c["k"]) if c["k"] else ""))
+
+
+def result_block(name, W, m, world, steps, warmup):
+    c = CONFIGS[name]
+    total_agents = world * c["A"]
+    value = total_agents / m["median"]
+    dev_rate = steps * total_agents / m["dev_elapsed"]
+    traj = c["N"] * c["iters"] * (2 if c["opt"] == "SPSA" else 1)
+    return {
+        "metric": "MPC control-steps/sec (agent-control-steps; %s, %s N=%d H=%d)"
+                  % ("HalfCheetah learned MLP 26-200-200-20" if W.mlp else "Pendulum true model", c["opt"], c["N"], c["H"]),
+        "value": value,
+        "unit": "control-steps/s",
+        "value_definition": "agents / median wall time of MPCPolicy.act(obs, t): NumPy observation in, all optimizer "
+                            "iterations on the GPU, NumPy action / next observation / reward out (rollouts.py:92-101 bracket)",
+        "median_ms": m["median"] * 1e3, "p10_ms": m["p10"] * 1e3, "p90_ms": m["p90"] * 1e3,
+        "percentile_samples": m["n_samples"],
+        "steps": steps, "warmup": warmup,
+        "ms_per_step": m["act_elapsed"] / steps * 1e3,
+        "candidate_trajectories_per_sec": value * traj,
+        "dyn_steps_per_sec": value * traj * c["H"],
+        "device_resident_control_steps_per_sec": dev_rate,
+        "device_resident_ms_per_step": m["dev_elapsed"] / steps * 1e3,
+        "device_resident_ms_per_step_with_events": m["dev_elapsed_instrumented"] / steps * 1e3,
+        "roofline": roofline(W, m, name, world),
+    }
 
 
 def main():
@@ -51,12 +504,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the MLP (north-star target 2) block at --gpus 1")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"cfg1": 2000, "cfg2": 2000, "cfg3": 2000, "cfg3full": 300, "cfg4": 400, "cfg5cem": 60, "cfg5pso": 60,
-                      "cfg5full": 10, "cfg5cma": 20}.get(args.config, 200)
+        args.steps = DEFAULT_STEPS.get(args.config, 200)
     if args.warmup is None:
-        args.warmup = max(2, args.steps // 20)
+        args.warmup = max(5, args.steps // 20)
 
     import torch
     import torch.distributed as dist
@@ -64,16 +517,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # BBMPC_BENCH_BACKEND=gloo + BBMPC_BENCH_ONE_DEVICE=1: rank-logic smoke test on a 1-GPU box (all ranks share
-    # device 0, records gathered through host memory); the real runs use nccl (= RCCL), one rank per GPU.
+    # device 0, records gathered through host memory); + BBMPC_BENCH_STUB=1: the same without any GPU (CPU test suite);
+    # the real runs use nccl (= RCCL), one rank per GPU.
     backend = os.environ.get("BBMPC_BENCH_BACKEND", "nccl")
+    stub = bool(os.environ.get("BBMPC_BENCH_STUB"))
+    if stub and backend != "gloo":
+        raise SystemExit("BBMPC_BENCH_STUB is only valid with BBMPC_BENCH_BACKEND=gloo (rank-logic test)")
     if os.environ.get("BBMPC_BENCH_ONE_DEVICE"):
         local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = None
+    if not stub:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     # BBMPC_BENCH_FORCE_DIST=1: run the per-step all-gather path in a one-rank group (what it costs on a 1-GPU box)
     use_dist = world > 1 or bool(os.environ.get("BBMPC_BENCH_FORCE_DIST"))
     # how the per-step record all-gather is issued under the nccl backend: "native" = the engine's own RCCL
-    # communicator and stream (bbmpc_gather_records_dev); "async" / "events" = torch.distributed, for comparison
+    # communicator and stream; "async" / "events" = torch.distributed, for comparison
     gather_mode = os.environ.get("BBMPC_BENCH_GATHER", "native")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -84,266 +543,67 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
-    from blackbox_mpc_amd import _build
-    if local == 0 or os.environ.get("BBMPC_BENCH_ONE_DEVICE"):
-        if rank == 0 or not os.environ.get("BBMPC_BENCH_ONE_DEVICE"):
-            _build.build()                   # one builder per node; the others wait for it
+    if not stub:
+        from blackbox_mpc_amd import _build
+        if local == 0 or os.environ.get("BBMPC_BENCH_ONE_DEVICE"):
+            if rank == 0 or not os.environ.get("BBMPC_BENCH_ONE_DEVICE"):
+                _build.build()                   # one builder per node; the others wait for it
     if use_dist:
         dist.barrier()
-    from blackbox_mpc_amd import _lib as L
-    from blackbox_mpc_amd.engine import Engine
-    from oracle import oracle_np as O      # inputs (start states) + the cpu_baseline leg only
+    red_dev = dev if (backend == "nccl" and not stub) else "cpu"
+    cls = StubWorkload if stub else Workload
 
-    c = CONFIGS[args.config]
-    opt = {"RandomSearch": L.OPT_RANDOM_SEARCH, "CEM": L.OPT_CEM, "PI2": L.OPT_PI2, "PSO": L.OPT_PSO,
-           "CMA-ES": L.OPT_CMAES, "SPSA": L.OPT_SPSA}[c["opt"]]
-    quirks = L.CMAES_PER_AGENT if c["opt"] == "CMA-ES" else 0     # the shardable CMA-ES mode
-    N, A, H, iters, k = c["N"], c["A"], c["H"], c["iters"], c["k"]
-    mlp = c["env"] == "cheetah"
-    if mlp:
-        U, S = 6, 20
-        eng = Engine(opt, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=A, planning_horizon=H,
-                     population_size=N, max_iterations=iters, num_elite=k, seed=0, agent_offset=rank * A,
-                     num_agents_global=world * A, device=local, quirks=quirks)
-        ws, bs = O.make_mlp_params(MLP_DIMS, seed=42)          # Glorot-uniform / zero bias, last layer x0.1
-        eng.set_mlp(ws, bs, [L.ACT_TANH, L.ACT_TANH, L.ACT_NONE], cheetah_stats(S, U))
-        start = O.cheetah_start_states(A, S, agent_offset=rank * A)
-    else:
-        U, S = 1, 3
-        eng = Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=S, num_agents=A, planning_horizon=H,
-                     population_size=N, max_iterations=iters, num_elite=k, seed=0, agent_offset=rank * A,
-                     num_agents_global=world * A, device=local, quirks=quirks)
-        start = O.pendulum_start_states(A, agent_offset=rank * A)
-    eng.reset()                      # episode start, as utils/rollouts.py:_sample does (PSO draws its swarm here)
-    native_gather = use_dist and backend == "nccl" and gather_mode == "native"
-    if native_gather:
-        # the engine's own RCCL communicator + stream; every rank must agree on whether it came up
-        from blackbox_mpc_amd.parallel import attach_record_comm
-        ok = torch.ones(1, device=dev)
-        try:
-            attach_record_comm(eng, device=dev)
-        except Exception as ex:                       # e.g. librccl not loadable: use torch.distributed's collective
-            print("bench: native record gather unavailable (%s); using torch.distributed" % ex, file=sys.stderr)
-            ok.zero_()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if ok.item() == 0:
-            native_gather, gather_mode = False, "async"
-            try:
-                eng.comm_destroy()
-            except Exception:
-                pass
-    rec = U + S + 1
-    # The engine launches on its own (non-blocking) stream.  Only the torch.distributed gather modes put torch work
-    # into the loop (events, collectives): they run the loop on a torch side stream that the engine is told to use,
-    # so that this work is ordered with its kernels.  (PyTorch's default stream has the NULL handle, which
-    # bbmpc_set_stream reads as "the handle's own stream".)
-    torch_loop_stream = (use_dist and not native_gather) or bool(os.environ.get("BBMPC_BENCH_TORCH_STREAM"))
-    if torch_loop_stream:
-        stream = torch.cuda.Stream(device=dev)
-        torch.cuda.set_stream(stream)
-        eng.set_torch_stream(stream)
-    else:
-        stream = None
-        eng.set_stream(None)
-
-    state = torch.from_numpy(start).to(dev)
-    nxt = torch.empty_like(state)
-    # records / gathered results are double buffered: the all-gather of control step t runs on its own stream
-    # while step t+1 computes (the local optimizer never needs the other ranks' records)
-    records = [torch.zeros((A, rec), device=dev, dtype=torch.float32) for _ in range(2)]
-    gathered = [torch.zeros((world * A, rec), device=dev, dtype=torch.float32) for _ in range(2)] if use_dist else None
-    comm_stream = torch.cuda.Stream(device=dev) if (use_dist and torch_loop_stream) else None
-    comm_done = [None, None]
-    ready_ev = [torch.cuda.Event(), torch.cuda.Event()] if comm_stream is not None else None
-    done_ev = [torch.cuda.Event(), torch.cuda.Event()] if comm_stream is not None else None
-    works = [None, None]
-    tick = [0]
-
-    def control_step():
-        nonlocal state, nxt
-        b = tick[0] & 1
-        tick[0] += 1
-        record = records[b]
-        if native_gather:
-            # control step + hand-off of its records to the all-gather on the engine's communication stream; the
-            # wait is for the gather that last used this slot's buffers, two steps ago (normally a host-side check)
-            eng.gather_wait(b)
-            eng.optimize_gather_dev(state.data_ptr(), record.data_ptr(), gathered[b].data_ptr(), b,
-                                    d_next_state=nxt.data_ptr())
-            state, nxt = nxt, state
-            return
-        if works[b] is not None:
-            works[b].wait()                          # stream-level: the gather that last read this buffer has finished
-            works[b] = None
-        if comm_done[b] is not None:
-            stream.wait_event(comm_done[b])
-        # closed loop: the environment is the engine's own model, so the predicted next state
-        # the control step already produced IS the next observation -- it never leaves HBM.
-        eng.optimize_dev(state.data_ptr(), record.data_ptr(), d_next_state=nxt.data_ptr())
-        if use_dist:
-            if backend == "nccl" and gather_mode == "async":
-                # the process group's own stream waits for this stream, runs the collective, and is only joined
-                # again (works[b].wait()) when this record buffer is about to be overwritten two steps later
-                works[b] = dist.all_gather_into_tensor(gathered[b], record, async_op=True)
-            else:
-                ready_ev[b].record(stream)
-                comm_stream.wait_event(ready_ev[b])
-                with torch.cuda.stream(comm_stream):
-                    if backend == "nccl":
-                        dist.all_gather_into_tensor(gathered[b], record)
-                    else:
-                        out = torch.empty((world * A, rec), dtype=torch.float32)
-                        dist.all_gather_into_tensor(out, record.cpu())
-                        gathered[b].copy_(out)
-                    done_ev[b].record(comm_stream)
-                    comm_done[b] = done_ev[b]
-        state, nxt = nxt, state
-
-    def fence():
-        if native_gather:
-            eng.synchronize()                        # launch stream + the engine's communication stream
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        control_step()
-    fence()
-    # HIP events on the launch stream around every 8th launch of the dominant kernel: an event pair costs ~8 us of
-    # stream time, a sixth of a config-2 control step, so bracketing every launch would distort `value`
-    PROF_EVERY = 8
-    eng.set_profiling(True, every=PROF_EVERY)
-    eng.get_profile()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        control_step()
-    fence()
-    t1 = time.perf_counter()
-    roll_ms, roll_n, kname = eng.get_profile()
-    eng.set_profiling(False)
-
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if use_dist:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
-
-    # un-instrumented repeat of the same K steps (events off) for the overhead of the instrumentation
-    fence()
-    t2 = time.perf_counter()
-    for _ in range(args.steps):
-        control_step()
-    fence()
-    t3 = time.perf_counter()
-
-    # PCIe-inclusive rate (never `value`): the same closed loop driven through the host-in/host-out entry point that
-    # MPCPolicy.act uses (NumPy state in, NumPy action / next state / reward out, SURVEY 8d's "wall time of one act")
-    host_rate = None
-    if world == 1 and not use_dist:
-        n_host = max(50, min(1000, int(0.25 / max((t3 - t2) / args.steps, 1e-6))))
-        st_h = np.ascontiguousarray(state.cpu().numpy())
-        for _ in range(20):
-            _, st_h, _ = eng.optimize(st_h)
-        th0 = time.perf_counter()
-        for _ in range(n_host):
-            _, st_h, _ = eng.optimize(st_h)
-        th1 = time.perf_counter()
-        eng.synchronize()
-        host_rate = n_host * A / (th1 - th0)
-
-    if use_dist:
-        # the gathered rows of this rank's own agents must be the records it produced
-        for b in range(2):
-            mine = gathered[b][rank * A:(rank + 1) * A]
-            assert torch.equal(mine.view(torch.int32), records[b].view(torch.int32)), \
-                "all-gather returned different records for the local agents: %r vs %r" % (mine, records[b])
-
+    W = cls(args.config, rank, world, local, dev, use_dist, backend, gather_mode)
+    m = measure(W, args.steps, args.warmup, dist, use_dist, red_dev)
+    out = None
     if rank == 0:
-        total_agents = world * A
-        steps_per_s = args.steps * total_agents / elapsed
-        traj_per_step = N * iters * total_agents
-        # algorithmic bytes per trajectory: 4*(H*U + 1) + 4*S/N   (SURVEY 8d / BASELINE.md)
-        bytes_per_traj = 4.0 * (H * U + 1) + 4.0 * S / N
-        avg_ms = roll_ms / max(roll_n, 1)
-        fused = kname.startswith("k_fused")
-        # trajectories one launch of the dominant kernel processes: the persistent kernel runs every
-        # iteration of every local agent in one launch, the per-iteration kernels one iteration
-        launch_traj = N * A * (iters if fused else 1)
-        if mlp:
-            flops_per_traj = H * 2.0 * sum(MLP_DIMS[i] * MLP_DIMS[i + 1] for i in range(len(MLP_DIMS) - 1))
-            achieved = launch_traj * flops_per_traj / (avg_ms * 1e-3) / 1e12 if roll_n else None
-            roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None, "traffic": None,
-                    "algorithmic_flops_per_launch": launch_traj * flops_per_traj,
-                    "note": "fp32-in/fp32-acc MFMA (%s); peak = dense fp32 matrix rate"
-                            % ("v_mfma_f32_4x4x1_16b_f32" if kname.endswith("_q4") else "v_mfma_f32_16x16x4_f32")}
-        else:
-            achieved = launch_traj * bytes_per_traj / (avg_ms * 1e-3) / 1e9 if roll_n else None
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                    "algorithmic_bytes_per_launch": launch_traj * bytes_per_traj,
-                    "note": "the fused kernel keeps the H-step recurrence in registers/LDS: the path is VALU-issue "
-                            "bound, the HBM fraction is nominal (DESIGN.md)"}
-        roof.update({"kernel": kname, "avg_launch_us": avg_ms * 1e3, "launches": roll_n,
-                     "launches_note": "HIP-event pairs around every %dth launch in the timed region" % PROF_EVERY})
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-        # collected separately, (2*FETCH + WRITE)*1024 -- tools/profile_round.sh, profiles/*_hbm_traffic.json)
-        try:
-            import glob
-            tr = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]))
-            hit = [v for kn, v in tr.get(args.config, {}).items() if kname in kn]
-            if hit and world == 1:
-                roof["traffic"] = hit[0]
-                roof["traffic_source"] = "profiles/ (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes)"
-        except Exception:
-            pass
-        # A bound that means something for the persistent pendulum kernels (their HBM fraction is nominal): VALU issue.
-        # Wave-instructions per launch come from the committed rocprofv3 PMC pass (SQ_INSTS_VALU); the kernel occupies
-        # one CU per agent, each CU issues at most one VALU instruction per SIMD per 1.07 ns (measured,
-        # tools/microbench/pk_fp32.hip); the duration is this run's.
-        try:
-            if not mlp and roll_n and world == 1:
-                sqc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))[-1]))
-                hit = [v for kn, v in sqc.get(args.config, {}).items() if kname in kn and "noise" not in kn]
-                if hit:
-                    insts = hit[0]["SQ_INSTS_VALU"]
-                    peak = A * 4 / 1.07e-9
-                    ach = insts / (avg_ms * 1e-3)
-                    roof["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "wave-instructions/s", "frac": ach / peak,
-                                          "insts_per_launch": insts, "cus": A,
-                                          "source": "profiles/*_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
-        except Exception:
-            pass
-        out = {
-            "metric": "MPC control-steps/sec (agent-control-steps; %s, %s N=%d H=%d)"
-                      % ("HalfCheetah learned MLP 26-200-200-20" if mlp else "Pendulum true model", c["opt"], N, H),
-            "value": steps_per_s,
-            "unit": "control-steps/s",
+        out = result_block(args.config, W, m, world, args.steps, args.warmup)
+        rec = W.rec
+        out.update({
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE %s: %s, %s, num_agents=%d/GPU, N=%d, H=%d, %d iters%s, closed loop on "
-                                   "device" % (args.config, "HalfCheetah(mod) S=20 U=6 learned MLP dynamics" if mlp
-                                               else "Pendulum-v0 true dynamics", c["opt"], A, N, H, iters,
-                                               (", k=%d" % k) if k else ""),
-                       "parallelism": "agents sharded %d/GPU, 1 RCCL all-gather of [A,%d] per control step (%s)"
-                                      % (A, rec, "engine-owned communicator + stream" if native_gather
-                                         else "torch.distributed " + gather_mode)
-                       if use_dist else "single GPU"},
-            "candidate_trajectories_per_sec": steps_per_s * N * iters,
-            "dyn_steps_per_sec": steps_per_s * N * iters * H,
-            "ms_per_step_uninstrumented": (t3 - t2) / args.steps * 1e3,
-            "host_in_host_out_control_steps_per_sec": host_rate,
-            "roofline": roof,
-        }
-        if not args.no_cpu_baseline and world == 1 and c["opt"] in ("RandomSearch", "CEM", "PI2"):
-            out["cpu_baseline"] = cpu_baseline(O, c, H, N, A, iters, k)
+            "config": {"workload": describe(args.config, W, world),
+                       "parallelism": ("agents sharded %d/GPU, no data-path collective; 1 all-gather of [A,%d] records "
+                                       "per control step" % (W.A, rec)) if use_dist else "single GPU"},
+        })
+        if use_dist:
+            out["multi_gpu"] = {
+                "ranks": world,
+                "rccl_ranks": W.comm_info[0] if W.comm_info else None,             # ncclCommCount of the engine's communicator
+                "rccl_rank0": W.comm_info[1] if W.comm_info else None,
+                "gather_mode": ("engine-owned RCCL communicator + stream (%s hand-off)"
+                                % ("signal-memory sequence number" if W.comm_info and W.comm_info[2] == 1 else "event"))
+                               if W.native else "torch.distributed " + W.gather_mode,
+                "fallback_reason": W.fallback_reason,
+                "gathered_rows_checked": m["gather_rows_checked"],
+                "gathered_rows_check": "rows of the local agents bit-equal to the records produced, all rows finite",
+            }
+    W.close()
+    del W
+
+    # ---- north star target 2 in the same line: HalfCheetah learned MLP, PI2, N=1000, H=30 (MFMA path) -------------
+    if world == 1 and not use_dist and not stub and args.config == "cfg2" and not args.no_secondary:
+        s_steps = max(30, min(DEFAULT_STEPS[SECONDARY], args.steps))
+        s_warm = 5
+        W2 = Workload(SECONDARY, rank, world, local, dev, False, backend, gather_mode)
+        m2 = measure(W2, s_steps, s_warm, dist, False, red_dev)
+        sec = result_block(SECONDARY, W2, m2, world, s_steps, s_warm)
+        sec["config"] = {"workload": describe(SECONDARY, W2, world), "parallelism": "single GPU"}
+        sec["dtype"] = "f32"
+        if not args.no_cpu_baseline:
+            sec["cpu_baseline"] = cpu_baseline(CONFIGS[SECONDARY], budget_s=10.0)
+        out["secondary"] = sec
+        W2.close()
+        del W2
+
+    if rank == 0:
+        c = CONFIGS[args.config]
+        if not args.no_cpu_baseline and world == 1 and not stub and c["opt"] in ("RandomSearch", "CEM", "PI2"):
+            out["cpu_baseline"] = cpu_baseline(c)
         # RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would otherwise
         # come out after this line at exit: push it out first so that the JSON line is the last line of stdout
         try:
@@ -353,40 +613,34 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
-    if native_gather:
-        eng.synchronize()
-        eng.comm_destroy()
     if use_dist:
         dist.destroy_process_group()
 
 
-def cheetah_stats(S, U):
-    """mu = 0, sigma = 1 for states/actions, targets mu = 0, sigma = 0.1"""
-    z, o = np.zeros, np.ones
-    return [z(S, np.float32), o(S, np.float32), z(U, np.float32), o(U, np.float32), z(S, np.float32),
-            np.full(S, 0.1, np.float32)]
-
-
-def cpu_baseline(O, c, H, N, A, iters, k, budget_s=12.0):
+def cpu_baseline(c, budget_s=12.0):
     """The CPU restatement of the same hot path timed on this host: oracle/oracle_c.c (plain C, OpenMP over candidate
-    trajectories -- the axis the reference's TF-CPU executor parallelises), all host cores, closed loop, noise drawn
-    inside the timed region as the reference's graph does.  Also reported for context: the same C path on one core
-    and the NumPy op-for-op oracle (Python-overhead bound, like an eager TF run)."""
+    trajectories -- the axis the reference's TF-CPU executor parallelises), closed loop, noise drawn inside the timed
+    region as the reference's graph does.  Also reported for context: the same C path on one core and (pendulum only)
+    the NumPy op-for-op oracle (Python-overhead bound, like an eager TF run).  This is the ONLY place bench.py touches
+    oracle/."""
     os.environ.setdefault("OMP_WAIT_POLICY", "ACTIVE")
     from oracle import oracle_c as OC
+    from oracle import oracle_np as O
+    from blackbox_mpc_amd.utils import synthetic as SY
+    N, A, H, iters, k = c["N"], c["A"], c["H"], c["iters"], c["k"]
     mlp = c["env"] == "cheetah"
     if mlp:
         S, U = 20, 6
-        ws, bs = O.make_mlp_params(MLP_DIMS, seed=42)
-        acts, stats = ["tanh", "tanh", None], cheetah_stats(S, U)
+        ws, bs = SY.make_mlp_params(MLP_DIMS, seed=42)
+        acts, stats = SY.CHEETAH_ACTIVATIONS, SY.cheetah_stats(S, U)
         lo, hi = [-1.0] * U, [1.0] * U
-        start = O.cheetah_start_states(A, S)
+        start = SY.cheetah_start_states(A, S)
         co = OC.COracle("mlp", "cheetah", lo, hi, N, A, H, S, iters=iters, k=max(k, 1), mlp=(ws, bs, acts), stats=stats)
-        ev = O.Evaluator("cheetah", O.Handler(O.MLP(ws, bs, acts), False, True, stats))
+        ev = None
     else:
         S, U = 3, 1
         lo, hi = [-2.0], [2.0]
-        start = O.pendulum_start_states(A)
+        start = SY.pendulum_start_states(A)
         co = OC.COracle("pendulum", "pendulum", lo, hi, N, A, H, S, iters=iters, k=max(k, 1))
         ev = O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))
 
@@ -405,47 +659,48 @@ def cpu_baseline(O, c, H, N, A, iters, k, budget_s=12.0):
     # cost outgrows the work), so probe a ladder of team sizes briefly and keep the fastest
     max_t = OC.num_threads()
     run_c(0.3, 3)                                   # warm the thread pool / page in
-    ladder = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, max_t) if t <= max_t})
+    ladder = sorted({t for t in ((16, 32, 64, max_t) if mlp else (1, 2, 4, 8, 16, 32, 64, max_t)) if t <= max_t})
     probe = {}
     for t in ladder:
         OC.set_num_threads(t)
-        probe[t] = run_c(0.4, 400)[1]
+        probe[t] = run_c(1.0 if mlp else 0.4, 400)[1]
     cores = max(probe, key=probe.get)
     OC.set_num_threads(cores)
     n_all, v_all = run_c(budget_s, 40000)
     OC.set_num_threads(1)
     n_one, v_one = run_c(3.0, 400)
     OC.set_num_threads(max_t)
-
-    # NumPy op-for-op oracle, a short sample (noise generation excluded)
-    rng = np.random.default_rng(0)
-    if c["opt"] == "CEM":
-        opt = O.CEM(ev, lo, hi, horizon=H, max_iterations=iters, population=N, num_elite=k, num_agents=A)
-        mk = lambda: {"trunc": [O.truncated_normal_noise(rng, (N, A, H, U)) for _ in range(iters)]}
-    elif c["opt"] == "PI2":
-        opt = O.PI2(ev, lo, hi, horizon=H, max_iterations=iters, population=N, num_agents=A)
-        mk = lambda: {"trunc": [O.truncated_normal_noise(rng, (N, A, H, U)) for _ in range(iters)]}
-    else:
-        opt = O.RandomSearch(ev, lo, hi, horizon=H, population=N, num_agents=A)
-        mk = lambda: {"uniform": rng.random((N, A, H, U)).astype(np.float32)}
-    state, n_np, t_np = start, 0, 0.0
-    while t_np < 3.0 and n_np < 50:
-        noise = mk()
-        t0 = time.perf_counter()
-        _, nxt, _ = opt.call(state, noise)
-        t_np += time.perf_counter() - t0
-        state = nxt
-        n_np += 1
-    return {"value": v_all, "unit": "control-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d closed-loop control steps of the same workload with the C restatement oracle/oracle_c.c "
-                      "(OpenMP over trajectories, best of a thread-count ladder = %d of %d threads, noise drawn in the "
-                      "timed region)" % (n_all, cores, max_t),
-            "thread_ladder": {str(t): round(v, 1) for t, v in probe.items()},
-            "single_core_value": v_one,
-            "numpy_oracle_value": n_np * A / t_np,
-            "note": "no TF-CPU number exists for the reference (TensorFlow absent, reference publishes none); "
-                    "single_core_value = same C path on 1 thread (%d steps), numpy_oracle_value = op-for-op NumPy "
-                    "oracle (%d steps, noise excluded)" % (n_one, n_np)}
+    res = {"value": v_all, "unit": "control-steps/s", "cores": cores, "kind": "port",
+           "sample": "%d closed-loop control steps of the same workload with the C restatement oracle/oracle_c.c "
+                     "(OpenMP over trajectories, best of a thread-count ladder = %d of %d threads, noise drawn in the "
+                     "timed region)" % (n_all, cores, max_t),
+           "thread_ladder": {str(t): round(v, 2) for t, v in probe.items()},
+           "single_core_value": v_one,
+           "note": "no TF-CPU number exists for the reference (TensorFlow absent, reference publishes none); "
+                   "single_core_value = same C path on 1 thread (%d steps)" % n_one}
+    if ev is not None:
+        # NumPy op-for-op oracle, a short sample (noise generation excluded)
+        rng = np.random.default_rng(0)
+        if c["opt"] == "CEM":
+            opt = O.CEM(ev, lo, hi, horizon=H, max_iterations=iters, population=N, num_elite=k, num_agents=A)
+            mk = lambda: {"trunc": [O.truncated_normal_noise(rng, (N, A, H, U)) for _ in range(iters)]}
+        elif c["opt"] == "PI2":
+            opt = O.PI2(ev, lo, hi, horizon=H, max_iterations=iters, population=N, num_agents=A)
+            mk = lambda: {"trunc": [O.truncated_normal_noise(rng, (N, A, H, U)) for _ in range(iters)]}
+        else:
+            opt = O.RandomSearch(ev, lo, hi, horizon=H, population=N, num_agents=A)
+            mk = lambda: {"uniform": rng.random((N, A, H, U)).astype(np.float32)}
+        state, n_np, t_np = start, 0, 0.0
+        while t_np < 3.0 and n_np < 50:
+            noise = mk()
+            t0 = time.perf_counter()
+            _, nxt, _ = opt.call(state, noise)
+            t_np += time.perf_counter() - t0
+            state = nxt
+            n_np += 1
+        res["numpy_oracle_value"] = n_np * A / t_np
+        res["note"] += "; numpy_oracle_value = op-for-op NumPy oracle (%d steps, noise excluded)" % n_np
+    return res
 
 
 if __name__ == "__main__":

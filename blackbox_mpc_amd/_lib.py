@@ -24,6 +24,7 @@ NOISE_TRUNC_NORMAL, NOISE_UNIFORM, NOISE_RADEMACHER, NOISE_NORMAL, NOISE_PSO_SCA
 NOISE_PSO_RESEED_TRUNC, NOISE_PSO_RESEED_UNIFORM, NOISE_PSO_RESET_POS, NOISE_PSO_RESET_VEL = 6, 7, 8, 9
 NOISE_EXPLORATION = 10
 TRACE_REWARDS, TRACE_MEAN, TRACE_VAR, TRACE_ELITES, TRACE_SAMPLES = 1, 2, 3, 4, 5
+TRACE_CMA_B, TRACE_CMA_C, TRACE_CMA_D = 6, 7, 8
 
 E_INVALID, E_NO_DEVICE, E_HIP, E_STATE, E_UNSUPPORTED = -1, -2, -3, -4, -5
 
@@ -62,7 +63,7 @@ SYMBOLS = [
     "bbmpc_inject_noise", "bbmpc_dump_noise", "bbmpc_set_trace", "bbmpc_get_trace", "bbmpc_get_state",
     "bbmpc_set_state", "bbmpc_set_profiling", "bbmpc_get_profile", "bbmpc_synchronize", "bbmpc_rollout_episode",
     "bbmpc_comm_unique_id", "bbmpc_comm_init", "bbmpc_gather_records_dev", "bbmpc_gather_wait", "bbmpc_comm_destroy",
-    "bbmpc_optimize_gather_dev", "bbmpc_set_stream_default",
+    "bbmpc_optimize_gather_dev", "bbmpc_set_stream_default", "bbmpc_optimize_gather", "bbmpc_comm_info",
 ]
 COMM_ID_BYTES = 128
 
@@ -116,6 +117,8 @@ def _load():
     lib.bbmpc_gather_wait.argtypes = [vp, i32, i32]
     lib.bbmpc_optimize_gather_dev.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32]
     lib.bbmpc_comm_destroy.argtypes = [vp]
+    lib.bbmpc_optimize_gather.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i32]
+    lib.bbmpc_comm_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     return lib
 
 

@@ -39,10 +39,13 @@ static double erfinv_d(double y) {
 }
 
 static void init_tnq_table() {
-    static std::map<int, bool> done;
+    // per-device symbol, uploaded once; handles may be created from several threads (a thread-per-GPU driver)
+    static std::mutex mu;
+    static std::set<int> done;
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
-    if (done[dev]) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count(dev)) return;
     std::vector<float> q(TNQ_SIZE + 1);
     const double p2 = erf(sqrt(2.0));                       // P(|z| < 2)
     for (int i = 0; i <= TNQ_SIZE; ++i) q[i] = (float)(sqrt(2.0) * erfinv_d((2.0 * i / TNQ_SIZE - 1.0) * p2));
@@ -51,7 +54,7 @@ static void init_tnq_table() {
     std::vector<float2> tab(TNQ_SIZE);
     for (int i = 0; i < TNQ_SIZE; ++i) tab[i] = make_float2(q[i], q[i + 1] - q[i]);
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tnq), tab.data(), sizeof(float2) * TNQ_SIZE));
-    done[dev] = true;
+    done.insert(dev);                                       // only after the upload succeeded
 }
 
 static void upload(DevBuf<float>& b, const std::vector<float>& v) {
@@ -114,7 +117,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         throw HipError(BBMPC_E_NO_DEVICE, "no HIP device available: this library has no CPU fallback");
     if (c.device >= 0) {
         REQUIRE(c.device < ndev, BBMPC_E_NO_DEVICE, "bbmpc_config.device out of range");
-        HIP_CHECK(hipSetDevice(c.device));
+        HIP_CHECK(hipSetDevice(c.device));        // bbmpc_create restores the caller's device (DeviceGuard)
     }
     HIP_CHECK(hipGetDevice(&device));
     HIP_CHECK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
@@ -219,7 +222,7 @@ float* Engine::pinned(size_t count) {
         if (h_pin) (void)hipHostFree(h_pin);
         h_pin = nullptr;
         h_pin_n = 0;
-        HIP_CHECK(hipHostMalloc((void**)&h_pin, count * sizeof(float), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&h_pin, count * sizeof(float), hipHostMallocCoherent | hipHostMallocMapped));
         h_pin_n = count;
         HIP_CHECK(hipHostGetDevicePointer((void**)&h_pin_dev, h_pin, 0));
     }
@@ -391,6 +394,16 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             HIP_CHECK(hipMemcpyAsync(t_samples.p + ns * it, d_cand_a.p, ns * 4, hipMemcpyDeviceToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(t_elites.p + (size_t)A * std::max(k, 1) * it, c_eidx.p, (size_t)G * k * 4,
                                      hipMemcpyDeviceToDevice, stream));
+            // the eigen-system this iteration produced (B, D) and the covariance it factorises: parity tests feed the
+            // oracle the engine's own (D^2, B) every iteration and check the factorisation's invariants
+            if (!t_cma_B.p) {
+                t_cma_B.alloc(gnn * std::max(iters, 1));
+                t_cma_C.alloc(gnn * std::max(iters, 1));
+                t_cma_D.alloc((size_t)G * n * std::max(iters, 1));
+            }
+            HIP_CHECK(hipMemcpyAsync(t_cma_B.p + gnn * it, c_B.p, gnn * 4, hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(t_cma_C.p + gnn * it, c_C.p, gnn * 4, hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(t_cma_D.p + (size_t)G * n * it, c_Dd.p, (size_t)G * n * 4, hipMemcpyDeviceToDevice, stream));
         }
     }
     hipLaunchKernelGGL(k_take_first, dim3((A * U + 63) / 64), dim3(64), 0, stream, A, HU, U, c_m.p, d_action.p);   // :211-212
@@ -1386,9 +1399,27 @@ __global__ void k_dump_noise(RngKey key, uint32_t stream, uint32_t iter, int N, 
     out[idx] = v;
 }
 
+// the two scalar N(0,1) draws of PSO iteration `iter` (quirk Q3), same counter as pso_scalars (kernels_opt.hpp)
+__global__ void k_dump_pso_scalars(OptArgs p, float* out) {
+    float r1, r2;
+    pso_scalars(p, nullptr, r1, r2);
+    out[0] = r1;
+    out[1] = r2;
+}
+
 void Engine::dump_noise(int kind, int control_step, int iteration, float* out, int64_t count) {
     int n = N, a = A, hu = HU;
     RngKey kk = key((uint32_t)control_step);
+    if (kind == BBMPC_NOISE_PSO_SCALARS) {
+        REQUIRE(count == 2, BBMPC_E_INVALID, "dump_noise: PSO scalars are [2] per (control step, iteration)");
+        DevBuf<float> tmp;
+        tmp.alloc(2);
+        hipLaunchKernelGGL(k_dump_pso_scalars, dim3(1), dim3(1), 0, stream, opt_args((uint32_t)control_step, (uint32_t)iteration), tmp.p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out, tmp.p, 8, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return;
+    }
     if (kind == BBMPC_NOISE_EXPLORATION) {
         n = 1; hu = U;
         kk.q_per_agent = (uint32_t)((U + 3) / 4);
@@ -1440,6 +1471,17 @@ void Engine::get_trace(int it, int item, void* out, int64_t bytes) {
             std::vector<float> tmp(ns);
             HIP_CHECK(hipMemcpy(tmp.data(), t_samples.p + ns * it, ns * 4, hipMemcpyDeviceToHost));
             from_internal(tmp.data(), N, (float*)out);
+            break;
+        }
+        case BBMPC_TRACE_CMA_B:
+        case BBMPC_TRACE_CMA_C:
+        case BBMPC_TRACE_CMA_D: {
+            REQUIRE(cfg.optimizer == BBMPC_OPT_CMAES && t_cma_B.p, BBMPC_E_STATE, "CMA-ES trace items need a traced CMA-ES control step");
+            const size_t gn = (size_t)cma_G * cma_n, gnn = gn * cma_n;
+            const size_t cnt = item == BBMPC_TRACE_CMA_D ? gn : gnn;
+            REQUIRE(bytes == (int64_t)cnt * 4, BBMPC_E_INVALID, "CMA-ES trace item: wrong size");
+            const float* src = item == BBMPC_TRACE_CMA_B ? t_cma_B.p : (item == BBMPC_TRACE_CMA_C ? t_cma_C.p : t_cma_D.p);
+            HIP_CHECK(hipMemcpy(out, src + cnt * it, cnt * 4, hipMemcpyDeviceToHost));
             break;
         }
         default:
@@ -1544,8 +1586,28 @@ struct bbmpc_handle_s {
     }                                             \
     return BBMPC_OK;
 
-#define CHECK_HANDLE_NOSETTLE(h) \
-    if (!(h) || !(h)->e) throw HipError(BBMPC_E_INVALID, "null handle")
+// Every entry point runs with the handle's device current and leaves the caller's current device as it found it: a
+// process may hold handles on several GPUs (bbmpc_config.device) next to a PyTorch caller with its own idea of the
+// current device; lazy allocations, stream / event creation, hipFuncSetAttribute and launches all bind to "current".
+struct DeviceGuard {
+    int prev = -1;
+    bool restore = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev && dev >= 0) {
+            HIP_CHECK(hipSetDevice(dev));
+            restore = true;
+        }
+    }
+    ~DeviceGuard() {
+        if (restore) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+#define CHECK_HANDLE_NOSETTLE(h)                                            \
+    if (!(h) || !(h)->e) throw HipError(BBMPC_E_INVALID, "null handle");    \
+    DeviceGuard _device_guard((h)->e->device)
 #define CHECK_HANDLE(h)        \
     CHECK_HANDLE_NOSETTLE(h);  \
     (h)->e->settle()
@@ -1573,6 +1635,12 @@ int bbmpc_create(const bbmpc_config* cfg, bbmpc_handle* out) {
     CHECK_PTR(cfg);
     CHECK_PTR(out);
     *out = nullptr;
+    int caller_dev = -1;
+    (void)hipGetDevice(&caller_dev);
+    struct Restore {
+        int d;
+        ~Restore() { if (d >= 0) (void)hipSetDevice(d); }
+    } restore{caller_dev};                       // the constructor selects cfg->device; the caller's device comes back
     Engine* e = new Engine(*cfg);
     *out = new bbmpc_handle_s{e};
     API_END
@@ -1581,7 +1649,10 @@ int bbmpc_create(const bbmpc_config* cfg, bbmpc_handle* out) {
 int bbmpc_destroy(bbmpc_handle h) {
     API_BEGIN
     if (h) {
-        delete h->e;
+        if (h->e) {
+            DeviceGuard g(h->e->device);
+            delete h->e;
+        }
         delete h;
     }
     API_END
@@ -1649,7 +1720,7 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
             // stores (publish_records_done): the call returns when the host sees it, ~10 us earlier than
             // hipStreamSynchronize notices the kernel's completion; the stream itself is joined lazily (settle)
             if (!e.host_done) {
-                HIP_CHECK(hipHostMalloc((void**)&e.host_done, 64, hipHostMallocDefault));
+                HIP_CHECK(hipHostMalloc((void**)&e.host_done, 64, hipHostMallocCoherent | hipHostMallocMapped));
                 memset(e.host_done, 0, 64);
                 HIP_CHECK(hipHostGetDevicePointer((void**)&e.host_done_dev, e.host_done, 0));
                 HIP_CHECK(hipMalloc((void**)&e.host_count, 8));
@@ -1892,8 +1963,7 @@ int bbmpc_comm_init(bbmpc_handle h, const void* unique_id, int32_t nranks, int32
     Engine* e = h->e;
     if (nranks < 1 || rank < 0 || rank >= nranks) throw HipError(BBMPC_E_INVALID, "bbmpc_comm_init: rank / nranks out of range");
     if (e->rc.comm) throw HipError(BBMPC_E_STATE, "bbmpc_comm_init: the handle already has a communicator");
-    HIP_CHECK(hipSetDevice(e->device));
-    const Rccl& r = Rccl::get();
+    const Rccl& r = Rccl::get();            // (the handle's device is current: CHECK_HANDLE)
     Rccl::UniqueId id;
     memcpy(&id, unique_id, sizeof(id));
     RecordComm& c = e->rc;
@@ -2044,6 +2114,79 @@ int bbmpc_optimize_gather_dev(bbmpc_handle h, const float* d_state, int32_t, int
     e->tail_flag = nullptr;
     const bool published = c.sync_mode == 1 && e->tail_attached;
     gather_records(e, d_records, d_gathered, (size_t)e->A * e->rec, slot, c.sync_mode == 0 && e->tail_attached, published, v);
+    API_END
+}
+
+// MPCPolicy.act of one rank of an agent-sharded run: host state in, host action / next state / reward out for the
+// LOCAL agents (synchronous), plus the all-gather of their records enqueued on the communication stream, where it
+// overlaps the caller's next control step (bbmpc_gather_wait(slot) before the slot is reused).
+int bbmpc_optimize_gather(bbmpc_handle h, const float* state, int32_t, int32_t noise, float* action, float* next_state,
+                          float* reward, float* d_gathered, int32_t slot) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(state);
+    CHECK_PTR(d_gathered);
+    Engine* e = h->e;
+    RecordComm& c = e->rc;
+    if (!c.comm) throw HipError(BBMPC_E_STATE, "bbmpc_optimize_gather: call bbmpc_comm_init first");
+    if (slot < 0 || slot >= RecordComm::kSlots) throw HipError(BBMPC_E_INVALID, "bbmpc_optimize_gather: slot must be 0 or 1");
+    if (c.pending[slot]) throw HipError(BBMPC_E_STATE, "bbmpc_optimize_gather: slot still pending (call bbmpc_gather_wait)");
+    const size_t ns = (size_t)e->A * e->S, nr = (size_t)e->A * e->rec;
+    if (!e->d_record_slot[slot].p) e->d_record_slot[slot].alloc(nr);
+    float* d_rec = e->d_record_slot[slot].p;
+    float* pin = e->pinned(ns + nr);
+    memcpy(pin, state, ns * 4);
+    uint32_t v = 0;
+    if (c.sync_mode == 1) {
+        v = next_comm_seq(e);
+        e->tail_flag = c.flag;
+        e->tail_count = c.count;
+        e->tail_value = v;
+    } else {
+        e->tail_event = c.ready[slot];
+    }
+    e->tail_attached = false;
+    try {
+        if (e->sw.zero_copy && e->use_fused()) {
+            e->optimize_dev(e->h_pin_dev, noise, d_rec, nullptr);        // the kernel reads the state from pinned host memory
+        } else {
+            HIP_CHECK(hipMemcpyAsync(e->d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e->stream));
+            e->optimize_dev(e->d_state.p, noise, d_rec, nullptr);
+        }
+    } catch (...) {
+        e->tail_event = nullptr;
+        e->tail_flag = nullptr;
+        throw;
+    }
+    e->tail_event = nullptr;
+    e->tail_flag = nullptr;
+    const bool published = c.sync_mode == 1 && e->tail_attached;
+    gather_records(e, d_rec, d_gathered, nr, slot, c.sync_mode == 0 && e->tail_attached, published, v);
+    HIP_CHECK(hipMemcpyAsync(pin + ns, d_rec, nr * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    const float* r = pin + ns;
+    for (int a = 0; a < e->A; ++a) {
+        if (action) memcpy(action + (size_t)a * e->U, r + (size_t)a * e->rec, e->U * 4);
+        if (next_state) memcpy(next_state + (size_t)a * e->S, r + (size_t)a * e->rec + e->U, e->S * 4);
+        if (reward) reward[a] = r[(size_t)a * e->rec + e->U + e->S];
+    }
+    API_END
+}
+
+// What the communicator itself reports (ncclCommCount / ncclCommUserRank) + the hand-off mode in use:
+// sync_mode 1 = sequence numbers in signal memory, 0 = events.
+int bbmpc_comm_info(bbmpc_handle h, int32_t* nranks, int32_t* rank, int32_t* sync_mode) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    RecordComm& c = h->e->rc;
+    if (!c.comm) throw HipError(BBMPC_E_STATE, "bbmpc_comm_info: no communicator (bbmpc_comm_init)");
+    const Rccl& r = Rccl::get();
+    int n = 0, me = 0;
+    r.check(r.CommCount(c.comm, &n), "ncclCommCount");
+    r.check(r.CommUserRank(c.comm, &me), "ncclCommUserRank");
+    if (nranks) *nranks = n;
+    if (rank) *rank = me;
+    if (sync_mode) *sync_mode = c.sync_mode;
     API_END
 }
 

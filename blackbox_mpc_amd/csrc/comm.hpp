@@ -28,6 +28,8 @@ struct Rccl {
     int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
+    int (*CommCount)(Comm, int*) = nullptr;
+    int (*CommUserRank)(Comm, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 
     static const Rccl& get() {
@@ -59,6 +61,8 @@ private:
         a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
         a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+        a.CommCount = reinterpret_cast<decltype(a.CommCount)>(sym("ncclCommCount"));
+        a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(sym("ncclCommUserRank"));
         return a;
     }
 };

@@ -122,6 +122,7 @@ struct Engine {
     // traces
     DevBuf<float> t_rewards, t_mean, t_var, t_samples;
     DevBuf<int> t_elites;
+    DevBuf<float> t_cma_B, t_cma_C, t_cma_D;   // CMA-ES: eigenvectors / covariance / sqrt eigenvalues after each iteration
     // pinned staging
     float* h_pin = nullptr;
     float* h_pin_dev = nullptr;   // device address of h_pin (looked up once per allocation)
@@ -130,6 +131,7 @@ struct Engine {
     // idle CUs on a side stream while step t's kernel runs (same Philox counters => bit-identical to in-kernel draws)
     DevBuf<float> d_noise_pf[2];      // two chunks of pf_steps control steps each
     RecordComm rc;           // multi-GPU record all-gather (comm.hpp); unused until bbmpc_comm_init
+    DevBuf<float> d_record_slot[RecordComm::kSlots];   // bbmpc_optimize_gather: the all-gather of step t reads its records while step t+1 runs
     hipEvent_t tail_event = nullptr;   // completion event wanted on the control step's last kernel (launch_with_tail)
     bool tail_attached = false;
     uint32_t* tail_flag = nullptr;     // or: sequence number the last kernel should publish itself (RecordComm::flag / host_done)

@@ -119,6 +119,25 @@ class Engine:
                                                 ctypes.c_void_p(d_next_state or 0), ctypes.c_void_p(d_gathered),
                                                 int(slot)))
 
+    def comm_info(self):
+        """(nranks, rank, sync_mode) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r, m = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        L.check(L.lib.bbmpc_comm_info(self._h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(m)))
+        return n.value, r.value, m.value
+
+    def optimize_gather(self, state, d_gathered, slot, t=0, add_exploration_noise=False):
+        """`optimize` for this rank's agents (NumPy in / out) + the device all-gather of their records into
+        d_gathered (device address of [num_agents_global, U+S+1] floats), overlapped with the next control step."""
+        io = self._io_buffers()
+        st, action, nxt, rew, p_st, p_act, p_nxt, p_rew = io
+        state = np.asarray(state)
+        if state.shape != (self.A, self.S):
+            raise ValueError("state must be [num_agents, dim_S] = [%d, %d], got %s" % (self.A, self.S, state.shape))
+        np.copyto(st, state, casting="unsafe")
+        L.check(L.lib.bbmpc_optimize_gather(self._h, p_st, int(t), 1 if add_exploration_noise else 0, p_act, p_nxt,
+                                            p_rew, ctypes.c_void_p(d_gathered), int(slot)))
+        return action.copy(), nxt.copy(), rew.copy()
+
     def gather_wait(self, slot, host_block=False):
         L.check(L.lib.bbmpc_gather_wait(self._h, int(slot), int(bool(host_block))))
 
@@ -129,12 +148,7 @@ class Engine:
     def optimize(self, state, t=0, add_exploration_noise=False):
         # persistent I/O buffers with cached ctypes pointers: building four `ndarray.ctypes` views per call costs more
         # host time (~15 us) than the H2D/D2H traffic of a control step
-        io = self.__dict__.get("_io")
-        if io is None:
-            bufs = (np.empty((self.A, self.S), np.float32), np.empty((self.A, self.U), np.float32),
-                    np.empty((self.A, self.S), np.float32), np.empty((self.A,), np.float32))
-            io = self._io = bufs + tuple(L.ptr(b) for b in bufs)
-        st, action, nxt, rew, p_st, p_act, p_nxt, p_rew = io
+        st, action, nxt, rew, p_st, p_act, p_nxt, p_rew = self._io_buffers()
         state = np.asarray(state)
         if state.shape != (self.A, self.S):
             raise ValueError("state must be [num_agents, dim_S] = [%d, %d], got %s" % (self.A, self.S, state.shape))
@@ -143,6 +157,14 @@ class Engine:
         if code != 0:
             L.check(code)
         return action.copy(), nxt.copy(), rew.copy()
+
+    def _io_buffers(self):
+        io = self.__dict__.get("_io")
+        if io is None:
+            bufs = (np.empty((self.A, self.S), np.float32), np.empty((self.A, self.U), np.float32),
+                    np.empty((self.A, self.S), np.float32), np.empty((self.A,), np.float32))
+            io = self._io = bufs + tuple(L.ptr(b) for b in bufs)
+        return io
 
     def rollout_episode(self, start_state, num_steps, add_exploration_noise=False):
         """T closed-loop control steps on the device (model = environment); returns
@@ -189,7 +211,11 @@ class Engine:
 
     def evaluate_next_reward(self, states, next_states, actions):
         states, next_states, actions = L.f32c(states), L.f32c(next_states), L.f32c(actions)
-        b = states.shape[0]
+        b = states.shape[0] if states.ndim == 2 else -1
+        # the C side copies b*S / b*S / b*U floats from these buffers: a wrong shape must not become an out-of-bounds read
+        if states.shape != (b, self.S) or next_states.shape != (b, self.S) or actions.shape != (b, self.U):
+            raise ValueError("states / next_states [B,%d] and actions [B,%d] expected, got %s, %s, %s"
+                             % (self.S, self.U, states.shape, next_states.shape, actions.shape))
         out = np.empty((b,), np.float32)
         if b:
             L.check(L.lib.bbmpc_evaluate_next_reward(self._h, L.ptr(states), L.ptr(next_states), L.ptr(actions), b,
@@ -232,6 +258,11 @@ class Engine:
                 out = np.empty((self.A,), np.int32)
         elif item == L.TRACE_SAMPLES:
             out = np.empty((self.N, self.A, self.H, self.U), np.float32)
+        elif item in (L.TRACE_CMA_B, L.TRACE_CMA_C, L.TRACE_CMA_D):
+            per_agent = bool(self.cfg.quirks & L.CMAES_PER_AGENT)
+            groups = self.A if per_agent else 1
+            n = self.H * self.U * (1 if per_agent else self.A)
+            out = np.empty((groups, n) if item == L.TRACE_CMA_D else (groups, n, n), np.float32)
         else:
             raise ValueError(item)
         L.check(L.lib.bbmpc_get_trace(self._h, int(iteration), int(item), L.ptr(out), out.nbytes))

@@ -76,6 +76,11 @@ class ShardedMPCPolicy:
         self._world = dist.get_world_size(group)
         self._rank = dist.get_rank(group)
         self._A = int(num_agents_global)
+        # every rank needs at least one agent: a rank without agents has no record layout to split the gathered rows
+        # with, and finding that out inside act() -- after it joined the collectives -- would leave the ranks out of step
+        if self._world > self._A:
+            raise ValueError("ShardedMPCPolicy: world_size %d > num_agents_global %d (give every rank >= 1 agent; "
+                             "single-agent problems run as independent replicas)" % (self._world, self._A))
         self._offset, self._count = agent_shard(self._A, self._world, self._rank)
         self._device = device
         self._policy = policy_factory(self._offset, self._count, self._A) if self._count > 0 else None

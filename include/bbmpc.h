@@ -92,6 +92,9 @@ extern "C" {
 #define BBMPC_TRACE_VAR     3   /* [A,H,U] (CEM)                             */
 #define BBMPC_TRACE_ELITES  4   /* int32 [A,k] (CEM), [A] best index (RandomSearch/PSO) */
 #define BBMPC_TRACE_SAMPLES 5   /* [N,A,H,U] action sequences that were rolled out */
+#define BBMPC_TRACE_CMA_B   6   /* CMA-ES [G,n,n] eigenvectors B after the iteration (cma_es.py:195-198,204)   */
+#define BBMPC_TRACE_CMA_C   7   /* CMA-ES [G,n,n] covariance C after the iteration (cma_es.py:183-190,202)     */
+#define BBMPC_TRACE_CMA_D   8   /* CMA-ES [G,n]   diag(D) = sqrt(eigenvalues) after the iteration (:197,205)   */
 
 typedef struct bbmpc_handle_s* bbmpc_handle;
 
@@ -246,6 +249,14 @@ int bbmpc_gather_records_dev(bbmpc_handle h, const float* d_records, float* d_ga
  * separate event record on the launch stream. */
 int bbmpc_optimize_gather_dev(bbmpc_handle h, const float* d_state, int32_t time_step, int32_t add_exploration_noise,
                               float* d_records, float* d_next_state, float* d_gathered, int32_t slot);
+/* MPCPolicy.act (policies/mpc_policy.py:124-172) of ONE RANK of an agent-sharded run: bbmpc_optimize for the local
+ * agents (host buffers, synchronous) + the all-gather of their records into d_gathered [num_agents_global, U+S+1]
+ * (device memory), enqueued on the communication stream and overlapped with the caller's next control step. */
+int bbmpc_optimize_gather(bbmpc_handle h, const float* state, int32_t time_step, int32_t add_exploration_noise,
+                          float* action, float* next_state, float* reward, float* d_gathered, int32_t slot);
+/* ncclCommCount / ncclCommUserRank of the handle's communicator and the hand-off mode in use
+ * (1 = sequence numbers in signal memory, 0 = events); any out pointer may be NULL. */
+int bbmpc_comm_info(bbmpc_handle h, int32_t* nranks, int32_t* rank, int32_t* sync_mode);
 int bbmpc_gather_wait(bbmpc_handle h, int32_t slot, int32_t host_block);
 int bbmpc_comm_destroy(bbmpc_handle h);
 

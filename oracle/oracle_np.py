@@ -411,7 +411,10 @@ class PI2(OptimizerBase):
     def reset(self):                                               # :98-105
         self.prev = self._init_mean()
 
-    def _optimize(self, state, noise):
+    def _optimize(self, state, noise, rewards_override=None):
+        """`rewards_override`: optional callable (iteration, rewards[N,A]) -> rewards[N,A] for lock-step parity tests
+        (same contract as PSO._optimize): it checks this oracle's rewards against the device's within the stated
+        tolerance and returns the device's, so the exp-weighted mean that follows is compared on identical inputs."""
         mean = self.prev.copy()
         self.trace = []
         for it in range(self.iters):
@@ -420,6 +423,8 @@ class PI2(OptimizerBase):
             feas = self._clip_h(samples)                                       # :70-71
             pen = self._penalty(samples, feas)                                 # :72-75
             rewards = (self.ev(state, feas) - pen).astype(F)                   # :77
+            if rewards_override is not None:
+                rewards = f32(rewards_override(it, rewards))
             costs = (-rewards).T                                               # :78-79 [A,N]
             beta = costs.min(axis=1)                                           # :81
             inv = (F(1) / self.lamda).astype(F)
@@ -525,7 +530,10 @@ class PSO(OptimizerBase):
             self.pbest_r = np.where(cond, rewards, self.pbest_r).astype(F)     # :89-91
             gi = argmax_first(self.pbest_r, axis=0)                            # :94
             self.gbest = self.pbest[gi, ar]                                    # :95-98
-            self.gbest_r = self.pbest_r[gi, ar]                                # :99-100
+            # :99-103 as executed (quirk Q10): the reward is gathered from pbest_r [N,A] flattened N-major with the
+            # index gi[a] + a*N that was built for the [A,N]-major position tensor -- the intended pbest_r[gi[a], a]
+            # only when A == 1.  The Variable is re-filled with -inf after the loop (:137-138) and never read.
+            self.gbest_r = self.pbest_r.reshape(-1)[gi + ar * self.N]
             r1, r2 = F(noise["normal2"][it][0]), F(noise["normal2"][it][1])
             t1 = (self.vel * self.w).astype(F)                                 # :104
             t2 = (((self.pbest - self.pos).astype(F) * self.c1).astype(F) * r1).astype(F)          # :105

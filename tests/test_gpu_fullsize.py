@@ -213,3 +213,100 @@ def test_config5_cmaes_coupled_single_agent_full_dimension(L):
         np.testing.assert_allclose(B64 @ np.diag(D64 ** 2) @ B64.T, C64, rtol=0, atol=1e-4 * max(1.0, np.abs(C64).max()))
         np.testing.assert_allclose(B64.T @ B64, np.eye(n), rtol=0, atol=1e-4)
         assert np.all(D64[:-1] >= D64[1:] - 1e-6) and np.all(D64 > 0)
+
+
+def test_northstar_mlp_pi2_lockstep_full_size(L):
+    # BASELINE north_star target 2: HalfCheetah learned MLP (26-200-200-20), PI2, N=1000, A=1, H=30, 5 iterations,
+    # lambda=1 (pi2.py:58-96).  The NumPy PI2 restatement runs with the C library doing the 1000 x 30-step rollouts.
+    # Lock-step: every iteration's rewards are compared within the MLP tolerance, then the device's values are carried
+    # on, so the exp-weighted means are compared on identical inputs (cheetah rewards spread over ~100 at lambda=1:
+    # the soft-min is sharply peaked, a 1e-2 reward difference is a 1 % weight difference); a free-running oracle is
+    # compared as well, with the tolerance that follows from the reward tolerance.
+    N, A, H, iters, U = 1000, 1, 30, 5, 6
+    lo, hi = [-1.0] * U, [1.0] * U
+    eng, co = _cheetah(L, L.OPT_PI2, N, A, H, iters, lamda=1.0)
+    eng.set_trace(True)
+    rng = np.random.default_rng(1030)
+    noise = {"trunc": [O.truncated_normal_noise(rng, (N, A, H, U)) for _ in range(iters)]}
+    eng.inject_noise(L.NOISE_TRUNC_NORMAL, np.stack(noise["trunc"]))
+    states = O.cheetah_start_states(A, 20)
+    RT, AT = 1e-3, 1e-3 * H
+    for step in range(2):                           # second control step: shifted warm start (pi2.py:92-93)
+        act, nxt, rew = eng.optimize(states)
+        hip_r = [eng.get_trace(it, L.TRACE_REWARDS) for it in range(iters)]
+        if step == 0:
+            pi2 = O.PI2(co.as_evaluator(), lo, hi, horizon=H, max_iterations=iters, population=N, num_agents=A, lamda=1.0)
+            free = O.PI2(co.as_evaluator(), lo, hi, horizon=H, max_iterations=iters, population=N, num_agents=A, lamda=1.0)
+
+        def lock(it, r_o):
+            np.testing.assert_allclose(hip_r[it], r_o, rtol=RT, atol=AT)
+            return hip_r[it]
+        act_o = pi2._optimize(states, noise, rewards_override=lock)
+        for it in range(iters):
+            np.testing.assert_allclose(eng.get_trace(it, L.TRACE_SAMPLES), pi2.trace[it]["samples"], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(eng.get_trace(it, L.TRACE_MEAN), pi2.trace[it]["mean"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(act, act_o, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(eng.get_state("prev_mean"), pi2.prev, rtol=0, atol=2e-5)
+        nxt_o = co.predict_next_state(states, act_o)
+        np.testing.assert_allclose(nxt, nxt_o, rtol=2e-5, atol=2e-4)
+        np.testing.assert_allclose(rew, co.evaluate_next_reward(states, nxt_o, act_o), rtol=1e-4, atol=2e-2)
+        # free-running: no values carried over; a reward error e moves a weight by ~e (lambda = 1)
+        act_f = free._optimize(states, noise)
+        np.testing.assert_allclose(act, act_f, rtol=0, atol=2e-2)
+        assert np.median(np.abs(hip_r[-1] - free.trace[-1]["rewards"])) < 5e-3
+        states = nxt
+
+
+def test_config5_cmaes_per_agent_full_size(L):
+    # BASELINE config 5, CMA-ES leg, one GPU's share in the sharding mode: BBMPC_CMAES_PER_AGENT, A=4 of 32, N=2000,
+    # H=50, U=6 (n = 300 per agent), k=50, 5 iterations.  Each agent is an independent CMA-ES (cma_es.py:129-213 with
+    # num_agents=1); the oracle is given the engine's own eigen-system (D^2, B) after every iteration -- eigenvector
+    # signs are library specific -- once its invariants hold, and ranks are kept in lock-step (near-ties may swap).
+    from blackbox_mpc_amd.engine import Engine
+    N, A, H, U, k, iters, S = 2000, 4, 50, 6, 50, 5, 20
+    n = H * U
+    ws, bs = O.make_mlp_params(MLP_DIMS, seed=42)
+    stats = _cheetah_stats(S, U)
+    lo, hi = [-1.0] * U, [1.0] * U
+    eng = Engine(L.OPT_CMAES, L.DYN_MLP, L.REW_CHEETAH, lo, hi, dim_s=S, num_agents=A, planning_horizon=H,
+                 population_size=N, max_iterations=iters, num_elite=k, quirks=L.CMAES_PER_AGENT, agent_offset=8,
+                 num_agents_global=32)
+    eng.set_mlp(ws, bs, [1, 1, 0], stats)
+    eng.set_trace(True)
+    co = OC.COracle("mlp", "cheetah", lo, hi, N, 1, H, S, mlp=(ws, bs, MLP_ACTS), stats=stats)
+    rng = np.random.default_rng(532)
+    z = rng.standard_normal((iters, N, A, H, U)).astype(F)
+    eng.inject_noise(L.NOISE_NORMAL, z)
+    states = O.cheetah_start_states(A, S, agent_offset=8)
+    act, nxt, rew = eng.optimize(states)
+    RT, AT = 1e-3, 1e-3 * H
+    Bs = [eng.get_trace(it, L.TRACE_CMA_B) for it in range(iters)]
+    Ds = [eng.get_trace(it, L.TRACE_CMA_D) for it in range(iters)]
+    Cs = [eng.get_trace(it, L.TRACE_CMA_C) for it in range(iters)]
+    hip_r = [eng.get_trace(it, L.TRACE_REWARDS) for it in range(iters)]
+    hip_e = [eng.get_trace(it, L.TRACE_ELITES) for it in range(iters)]
+    hip_s = [eng.get_trace(it, L.TRACE_SAMPLES) for it in range(iters)]
+    for g in range(A):
+        cma = O.CMAES(co.as_evaluator(), lo, hi, horizon=H, max_iterations=iters, population=N, num_elite=k, num_agents=1)
+
+        def order(it, rsum, own, g=g):
+            np.testing.assert_allclose(hip_r[it][:, g], rsum, rtol=RT, atol=AT)
+            np.testing.assert_array_equal(hip_e[it][g], O.topk_desc(hip_r[it][:, g], k))
+            for a_, b_ in zip(own[:k], hip_e[it][g]):
+                assert a_ == b_ or abs(rsum[a_] - rsum[b_]) <= AT + RT * abs(rsum[a_])
+            return hip_e[it][g]
+        eig = [((Ds[it][g].astype(np.float64) ** 2).astype(F), Bs[it][g]) for it in range(iters)]
+        cma._optimize(states[g:g + 1], {"normal": [z[it][:, g].reshape(N, n) for it in range(iters)]}, eig=eig,
+                      forced_order=order)
+        for it in range(iters):
+            tr = cma.trace[it]
+            np.testing.assert_allclose(hip_s[it][:, g:g + 1], tr["samples"], rtol=0, atol=1e-4)
+            np.testing.assert_allclose(Cs[it][g], tr["C"], rtol=1e-3, atol=1e-4)
+            B64, D64, C64 = Bs[it][g].astype(np.float64), Ds[it][g].astype(np.float64), Cs[it][g].astype(np.float64)
+            np.testing.assert_allclose(B64 @ np.diag(D64 ** 2) @ B64.T, C64, rtol=0, atol=1e-4 * max(1.0, np.abs(C64).max()))
+            np.testing.assert_allclose(B64.T @ B64, np.eye(n), rtol=0, atol=1e-4)
+            assert np.all(D64[:-1] >= D64[1:] - 1e-6) and np.all(D64 > 0)
+        np.testing.assert_allclose(eng.get_state("m", (A * n,)).reshape(A, n)[g], cma.m, rtol=0, atol=2e-4)
+        np.testing.assert_allclose(eng.get_state("sigma", (A * n,)).reshape(A, n)[g], cma.sigma, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(eng.get_state("p_sigma", (A * n,)).reshape(A, n)[g], cma.p_sigma, rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(act[g], cma.m.reshape(H, U)[0], rtol=0, atol=2e-4)
