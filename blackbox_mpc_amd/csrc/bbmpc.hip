@@ -765,6 +765,19 @@ void Engine::capture_trace(int it) {
     HIP_CHECK(hipMemcpyAsync(t_elites.p + ne * it, d_elites.p, ne * 4, hipMemcpyDeviceToDevice, stream));
 }
 
+// Launch the last kernel of a control step.  When the caller asked for a completion event (the record all-gather
+// waits on it from its own stream) the event rides on the kernel's own dispatch packet: a separate
+// hipEventRecord costs the launch stream ~5 us per control step (tools/gather_overhead.py).
+template <class F, class Args>
+static void launch_with_tail(Engine& e, F fn, dim3 grid, dim3 block, size_t lds, const Args& args) {
+    if (e.tail_event) {
+        hipExtLaunchKernelGGL(fn, grid, block, lds, e.stream, nullptr, e.tail_event, 0, args);
+        e.tail_attached = true;
+    } else {
+        hipLaunchKernelGGL(fn, grid, block, lds, e.stream, args);
+    }
+}
+
 void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step) {
     FinalArgs fa;
     fa.A = A; fa.U = U; fa.S = S;
@@ -785,19 +798,33 @@ void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_ou
         HIP_CHECK(hipGetLastError());
         return;
     }
-    // learned dynamics: exploration noise, one model step on the [A] rows, pack the record
-    if (add_noise) {
-        hipLaunchKernelGGL(k_explore, dim3((A * U + 63) / 64), dim3(64), 0, stream, fa, d_action.p);
-        HIP_CHECK(hipGetLastError());
+    // learned dynamics: exploration noise, one model step on the [A] rows, reward, packed record and the warm start of
+    // the next control step in ONE launch (kernels_tail.hpp; was k_explore + k_step_mlp + k_pack_record + k_shift_left)
+    REQUIRE(mlp_ready, BBMPC_E_STATE, "learned dynamics: call bbmpc_set_mlp before computing");
+    TailArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.f = fa;
+    ta.net = row_mlp();
+    ta.reward_kind = cfg.reward;
+    ta.warm_mode = pending_warm;
+    ta.H = H; ta.HU = HU;
+    ta.mean = d_mean.p;
+    ta.prev_mean = d_prev_mean.p;
+    pending_warm = 0;
+    if (tail_flag) {             // the record is complete when this kernel ends: it publishes the sequence number itself
+        ta.done_flag = tail_flag; ta.done_count = tail_count; ta.done_value = tail_value;
+        tail_attached = true;
     }
-    if (!d_fin_next.p) {
-        d_fin_next.alloc((size_t)A * S);
-        d_fin_rew.alloc((size_t)((A + 63) / 64) * 64);
-    }
-    step_dev(d_state_in, d_action.p, U, A, d_fin_next.p, d_fin_rew.p);
-    hipLaunchKernelGGL(k_pack_record, dim3((A * rec + 63) / 64), dim3(64), 0, stream, A, U, S, d_action.p, d_fin_next.p,
-                       d_fin_rew.p, d_record_out, d_next_out);
+    launch_with_tail(*this, k_tail_mlp, dim3(A), dim3(TAIL_THREADS), 0, ta);
     HIP_CHECK(hipGetLastError());
+}
+
+RowMlp Engine::row_mlp() const {
+    RowMlp r;
+    memset(&r, 0, sizeof(r));
+    r.m = mlp;
+    for (int l = 0; l < mlp.n_layers; ++l) { r.wraw[l] = d_wraw[l].p; r.braw[l] = d_braw[l].p; }
+    return r;
 }
 
 bool Engine::use_fused() const {
@@ -812,19 +839,6 @@ bool Engine::use_fused() const {
     // auto: one workgroup per agent keeps a whole control step in one launch.  When a handful of agents
     // own very large populations the per-iteration kernels spread the rollouts over more CUs instead.
     return (long)N <= 2048 || A >= 64;
-}
-
-// Launch the last kernel of a control step.  When the caller asked for a completion event (the record all-gather
-// waits on it from its own stream) the event rides on the kernel's own dispatch packet: a separate
-// hipEventRecord costs the launch stream ~5 us per control step (tools/gather_overhead.py).
-template <class F, class Args>
-static void launch_with_tail(Engine& e, F fn, dim3 grid, dim3 block, size_t lds, const Args& args) {
-    if (e.tail_event) {
-        hipExtLaunchKernelGGL(fn, grid, block, lds, e.stream, nullptr, e.tail_event, 0, args);
-        e.tail_attached = true;
-    } else {
-        hipLaunchKernelGGL(fn, grid, block, lds, e.stream, args);
-    }
 }
 
 template <int OPT, bool FASTM, int INJ, int ILP>
@@ -1107,8 +1121,10 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                 HIP_CHECK(hipGetLastError());
                 capture_trace(it);
             }
-            if (fix(BBMPC_FIX_Q2_CEM_WARM_START))
-                HIP_CHECK(hipMemcpyAsync(d_prev_mean.p, d_mean.p, (size_t)nelem * 4, hipMemcpyDeviceToDevice, stream));
+            if (fix(BBMPC_FIX_Q2_CEM_WARM_START)) {
+                if (cfg.dynamics == BBMPC_DYN_MLP) pending_warm = 2;      // prev = mean, in k_tail_mlp
+                else HIP_CHECK(hipMemcpyAsync(d_prev_mean.p, d_mean.p, (size_t)nelem * 4, hipMemcpyDeviceToDevice, stream));
+            }
             break;
         }
         case BBMPC_OPT_PI2: {
@@ -1122,12 +1138,17 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                 ra.stream = BBMPC_NOISE_TRUNC_NORMAL; ra.iter = (uint32_t)it;
                 ra.inj = inj_t ? inj_t + inj_stride * it : nullptr;
                 launch_rollout(SRC_TRUNC, true, ra);
-                hipLaunchKernelGGL(k_refit_pi2, dim3(A), dim3(REFIT_THREADS), lds, stream, rf);
+                if (sw.refit_v1) hipLaunchKernelGGL(k_refit_pi2, dim3(A), dim3(REFIT_THREADS), lds, stream, rf);
+                else hipLaunchKernelGGL(k_refit_pi2_mw, dim3((HU + PI2_ROWS - 1) / PI2_ROWS, A), dim3(64 * PI2_ROWS), lds, stream, rf);
                 HIP_CHECK(hipGetLastError());
                 capture_trace(it);
             }
-            hipLaunchKernelGGL(k_shift_left, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, H, U, d_mean.p, d_prev_mean.p);
-            HIP_CHECK(hipGetLastError());
+            if (cfg.dynamics == BBMPC_DYN_MLP) {
+                pending_warm = 1;                      // prev = shift_left(mean) (pi2.py:92-93) happens in k_tail_mlp
+            } else {
+                hipLaunchKernelGGL(k_shift_left, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, H, U, d_mean.p, d_prev_mean.p);
+                HIP_CHECK(hipGetLastError());
+            }
             break;
         }
         case BBMPC_OPT_SPSA:
@@ -1178,8 +1199,12 @@ void Engine::optimize_spsa(RolloutArgs& ra, uint32_t step) {
                                      hipMemcpyDeviceToDevice, stream));
         }
     }
-    hipLaunchKernelGGL(k_shift_left, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, H, U, d_mean.p, d_prev_mean.p);  // :114-115
-    HIP_CHECK(hipGetLastError());
+    if (cfg.dynamics == BBMPC_DYN_MLP) {
+        pending_warm = 1;                              // :114-115, in k_tail_mlp
+    } else {
+        hipLaunchKernelGGL(k_shift_left, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, H, U, d_mean.p, d_prev_mean.p);  // :114-115
+        HIP_CHECK(hipGetLastError());
+    }
 }
 
 // PSO on the true pendulum model in one launch per control step (kernels_fused_pso.hpp) when the swarm's positions
@@ -1290,6 +1315,15 @@ void Engine::evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop
 
 void Engine::step_dev(const float* d_states, const float* d_actions, int astride, int batch, float* d_next, float* d_rew) {
     REQUIRE(batch >= 1, BBMPC_E_INVALID, "batch must be >= 1");
+    if (cfg.dynamics == BBMPC_DYN_MLP && batch <= 32 && !sw.mlp_generic) {
+        // a handful of rows: one workgroup per row on plain FMAs -- the same per-row code as the control step's tail,
+        // so act()'s predicted next state and evaluator.predict_next_state(obs, action) agree bit for bit
+        REQUIRE(mlp_ready, BBMPC_E_STATE, "learned dynamics: call bbmpc_set_mlp before computing");
+        hipLaunchKernelGGL(k_rows_mlp, dim3(batch), dim3(TAIL_THREADS), 0, stream, row_mlp(), S, U, cfg.reward,
+                           (int)fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER), d_states, d_actions, astride, d_next, d_rew);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (cfg.dynamics == BBMPC_DYN_MLP) {
         // one-step rollout of `batch` independent rows: per-particle start states, H = 1, actions as a
         // [batch,1,1,U] sequence (gathered to a contiguous block first when they come strided)
@@ -1711,7 +1745,11 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
     memcpy(pin, state, ns * 4);
     (void)t;  // the reference evaluator accepts and ignores time_step (deterministic.py:26)
     bool published = false;
-    if (e.sw.zero_copy && e.use_fused()) {
+    // single-kernel control steps read the state straight from the pinned, device-mapped host buffer; those and the
+    // learned-dynamics path (whose last kernel, k_tail_mlp, owns the record) write the packed record straight into it
+    const bool fused_step = e.sw.zero_copy && e.use_fused();
+    const bool mlp_tail = e.sw.zero_copy && !fused_step && e.cfg.dynamics == BBMPC_DYN_MLP && e.cfg.optimizer != BBMPC_OPT_NONE;
+    if (fused_step || mlp_tail) {
         // the persistent kernel reads the [A,S] state and writes the packed record straight from / to the pinned,
         // device-mapped host buffer (a few PCIe transactions) -- no copy-engine round trips around a ~50 us kernel
         float* dpin = e.h_pin_dev;
@@ -1733,7 +1771,13 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
             e.tail_attached = false;
         }
         try {
-            e.optimize_dev(dpin, noise, dpin + ns, nullptr);
+            if (fused_step) {
+                e.optimize_dev(dpin, noise, dpin + ns, nullptr);
+            } else {
+                // hundreds of rollout workgroups read the state: it goes to HBM once, the record comes back on its own
+                HIP_CHECK(hipMemcpyAsync(e.d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e.stream));
+                e.optimize_dev(e.d_state.p, noise, dpin + ns, nullptr);
+            }
         } catch (...) {
             e.tail_flag = nullptr;
             throw;

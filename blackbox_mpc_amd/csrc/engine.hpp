@@ -21,6 +21,7 @@
 #include "kernels_opt.hpp"
 #include "kernels_refit.hpp"
 #include "kernels_rollout.hpp"
+#include "kernels_tail.hpp"
 
 namespace bbmpc {
 
@@ -170,6 +171,8 @@ struct Engine {
         return kk;
     }
     bool fix(uint32_t bit) const { return (cfg.quirks & bit) != 0; }
+    int pending_warm = 0;    // learned-dynamics path: warm start the tail kernel performs (kernels_tail.hpp TailArgs::warm_mode)
+    RowMlp row_mlp() const;
     const float* injected(int kind) const {
         auto it = inj.find(kind);
         return (it == inj.end() || !it->second.p) ? nullptr : it->second.p;

@@ -1,0 +1,227 @@
+// Small-batch kernels around the per-iteration rollouts of the learned-dynamics path:
+//
+//   k_refit_pi2_mw   PI2 refit (pi2.py:78-87) spread over many workgroups: the soft-min weighted mean is a
+//                    [HU x N] matrix-vector product, one wave per row of the particle-minor sample matrix.
+//   k_tail_mlp       the tail of OptimizerBase.__call__ (optimizer_base.py:82-94) for a learned model in ONE launch:
+//                    exploration noise, one model step on the agent's row, reward, packed record, and the warm start
+//                    of the next control step (pi2.py:92-93 / spsa.py:114-115 shift-left).
+//   k_rows_mlp       predict_next_state / evaluate_next_reward for a handful of rows (deterministic.py:79-127) with the
+//                    same per-row code as the tail, so that `policy.act`'s predicted next state and a later
+//                    `evaluator.predict_next_state(obs, action)` agree bit for bit.
+//
+// A single row through a 26-200-200-20 network is 49 k multiply-adds behind 198 KB of weights: nothing for the matrix
+// cores to chew on (an MFMA tile would be 1/16 full) and latency bound either way, so these use plain fp32 FMAs:
+// one workgroup per row, every Dense layer split over (K-slices x outputs) threads with coalesced reads of the
+// reference-layout kernel W[in][out], partial sums combined in a fixed order through LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_mlp.hpp"
+#include "kernels_opt.hpp"
+#include "kernels_refit.hpp"
+
+namespace bbmpc {
+
+constexpr int TAIL_THREADS = 1024;
+constexpr int TAIL_MAXW = 512;                 // widest layer (set_mlp enforces hidden <= 512, S+U <= 128, S <= 64)
+
+struct RowMlp {
+    MlpDesc m;
+    const float* wraw[MLP_MAX_LAYERS];         // Dense kernels [in][out] (reference layout)
+    const float* braw[MLP_MAX_LAYERS];         // biases [out]
+};
+
+// One Dense stack on the row held in `x` (LDS, dims[0] values, already normalised).  Returns a pointer (LDS) to the
+// raw network output dims[L].  bufA/bufB: TAIL_MAXW floats each; part: [splits][TAIL_MAXW].
+__device__ __forceinline__ const float* row_mlp_forward(const RowMlp& q, const float* x, float* bufA, float* bufB,
+                                                        float* part, int tid, int nthr) {
+    const float* in = x;
+    for (int l = 0; l < q.m.n_layers; ++l) {
+        const int K = q.m.dims[l], M = q.m.dims[l + 1];
+        const int Mr = (M + 63) & ~63;                           // outputs per K-slice, wave aligned
+        const int G = max(1, min(nthr / Mr, (K + 7) / 8));       // K-slices (>= 8 terms each)
+        const int Kc = (K + G - 1) / G;
+        const float* __restrict__ W = q.wraw[l];
+        for (int t = tid; t < G * Mr; t += nthr) {
+            const int g = t / Mr, o = t - g * Mr;
+            if (o < M) {
+                const int k0 = g * Kc, k1 = min(K, k0 + Kc);
+                float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+                int k = k0;
+                for (; k + 3 < k1; k += 4) {
+                    acc0 = fmaf(in[k], W[(size_t)k * M + o], acc0);
+                    acc1 = fmaf(in[k + 1], W[(size_t)(k + 1) * M + o], acc1);
+                    acc2 = fmaf(in[k + 2], W[(size_t)(k + 2) * M + o], acc2);
+                    acc3 = fmaf(in[k + 3], W[(size_t)(k + 3) * M + o], acc3);
+                }
+                for (; k < k1; ++k) acc0 = fmaf(in[k], W[(size_t)k * M + o], acc0);
+                part[g * TAIL_MAXW + o] = (acc0 + acc1) + (acc2 + acc3);
+            }
+        }
+        __syncthreads();
+        float* out = (l & 1) ? bufB : bufA;
+        for (int o = tid; o < M; o += nthr) {
+            float acc = q.braw[l][o];
+            for (int g = 0; g < G; ++g) acc = acc + part[g * TAIL_MAXW + o];
+            out[o] = apply_act(acc, q.m.act[l]);
+        }
+        __syncthreads();
+        in = out;
+    }
+    return in;
+}
+
+// process_input -> Dense stack -> process_output -> reward for the row (cur[S] | act[U]) staged in LDS.
+// nxt (LDS, S floats) receives the next state; returns the reward (valid in every thread).
+__device__ __forceinline__ float row_model_step(const RowMlp& q, int S, int U, int reward_kind, bool fix_q1, const float* cur,
+                                                const float* act, float* nxt, float* x, float* bufA, float* bufB, float* part,
+                                                int tid, int nthr) {
+    const bool normd = q.m.normalized != 0;
+    for (int f = tid; f < S + U; f += nthr) {                    // system_dynamics_handler.py:97-126
+        const float v = f < S ? cur[f] : act[f - S];
+        const float mu = normd ? (f < S ? q.m.mean_s[f] : q.m.mean_a[f - S]) : 0.0f;
+        const float sd = normd ? (f < S ? q.m.std_s[f] : q.m.std_a[f - S]) : 1.0f;
+        const float inv = normd ? 1.0f / (sd + 1e-7f) : 1.0f;    // same form as the rollout kernels' prologue
+        x[f] = (v - mu) * inv;
+    }
+    __syncthreads();
+    const float* raw = row_mlp_forward(q, x, bufA, bufB, part, tid, nthr);
+    for (int f = tid; f < S; f += nthr) {                        // :128-161 + transforms.py:20-34
+        const float dev = normd ? q.m.mean_t[f] + raw[f] * (q.m.std_t[f] + 1e-7f) : raw[f];
+        nxt[f] = dev + cur[f];
+    }
+    __syncthreads();
+    return reward_generic(reward_kind, fix_q1, cur, act, nxt, S, U);
+}
+
+struct TailArgs {
+    FinalArgs f;            // A, U, S, exploration noise, state [A,S], action [A,U] (in: the optimizer's solution), record, next_state
+    RowMlp net;
+    int reward_kind;
+    // warm start of the next control step: 0 none, 1 prev = shift_left(mean) (pi2.py:92-93, spsa.py:114-115),
+    // 2 prev = mean (CEM with BBMPC_FIX_Q2_CEM_WARM_START)
+    int warm_mode, H, HU;
+    const float* mean;      // [A][HU]
+    float* prev_mean;       // [A][HU]
+    unsigned* done_flag;    // publish_records_done (kernels_opt.hpp) or null
+    unsigned* done_count;
+    unsigned done_value;
+};
+
+// grid A, block TAIL_THREADS
+__global__ __launch_bounds__(TAIL_THREADS) void k_tail_mlp(TailArgs p) {
+    __shared__ float cur[64], act[128], nxt[64], x[192];
+    __shared__ float bufA[TAIL_MAXW], bufB[TAIL_MAXW], part[(TAIL_THREADS / 64) * TAIL_MAXW];
+    const int a = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int S = p.f.S, U = p.f.U;
+    if (tid < S) cur[tid] = p.f.state[a * S + tid];
+    if (tid >= 64 && tid < 64 + U) {
+        const int u = tid - 64;
+        act[u] = exploration_action(p.f, a, u, p.f.action[a * U + u]);       // optimizer_base.py:82-90
+    }
+    // warm start (independent of the model step; before it so the loads overlap)
+    if (p.warm_mode) {
+        for (int j = tid; j < p.HU; j += nthr) {
+            int src = j;
+            if (p.warm_mode == 1) {
+                const int u = j % U, h = j / U;
+                src = ((h + 1 < p.H) ? h + 1 : p.H - 1) * U + u;
+            }
+            p.prev_mean[a * p.HU + j] = p.mean[a * p.HU + src];
+        }
+    }
+    __syncthreads();
+    const float r = row_model_step(p.net, S, U, p.reward_kind, p.f.fix_q1 != 0, cur, act, nxt, x, bufA, bufB, part, tid, nthr);
+    const int rec = U + S + 1;
+    float* out = p.f.record + (size_t)a * rec;
+    if (tid < U) out[tid] = act[tid];
+    if (tid >= 64 && tid < 64 + S) {
+        const float v = nxt[tid - 64];
+        out[U + tid - 64] = v;
+        if (p.f.next_state) p.f.next_state[a * S + tid - 64] = v;
+    }
+    if (tid == 128) out[U + S] = r;
+    if (p.done_flag) {
+        __syncthreads();
+        if (tid == 0) publish_records_done(p.done_flag, p.done_count, p.done_value, gridDim.x);
+    }
+}
+
+// grid = rows, block TAIL_THREADS.  next_states and/or rewards may be null.
+__global__ __launch_bounds__(TAIL_THREADS) void k_rows_mlp(RowMlp net, int S, int U, int reward_kind, int fix_q1,
+                                                           const float* states, const float* actions, int action_stride,
+                                                           float* next_states, float* rewards) {
+    __shared__ float cur[64], act[128], nxt[64], x[192];
+    __shared__ float bufA[TAIL_MAXW], bufB[TAIL_MAXW], part[(TAIL_THREADS / 64) * TAIL_MAXW];
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    if (tid < S) cur[tid] = states[(size_t)b * S + tid];
+    if (tid >= 64 && tid < 64 + U) act[tid - 64] = actions[(size_t)b * action_stride + tid - 64];
+    __syncthreads();
+    const float r = row_model_step(net, S, U, reward_kind, fix_q1 != 0, cur, act, nxt, x, bufA, bufB, part, tid, nthr);
+    if (next_states && tid < S) next_states[(size_t)b * S + tid] = nxt[tid];
+    if (rewards && tid == 64) rewards[b] = r;
+}
+
+// ---- PI2 refit over many workgroups ---------------------------------------------------------------------------
+// new_mean[j] = sum_n omega[n] * samples[j][n], omega = softmin(cost / lamda)   (pi2.py:78-87).
+// Every workgroup recomputes beta = min cost, eta = sum exp(-(cost - beta)/lamda) and omega for the agent's whole
+// population (N <= 8192 values: a few loads per thread and two block reductions -- cheaper than a launch that would
+// produce them once), then each of its waves takes one row j of the particle-minor sample matrix with all of a
+// lane's loads in flight.  One 1024-thread workgroup walking all HU rows (the previous kernel) needed 58 us at
+// N = 1000, HU = 180: 11 rows per wave, each a 16-deep chain of dependent L2 round trips.
+// grid (ceil(HU / PI2_ROWS), A), block 64 * PI2_ROWS.   LDS: omega[Nst] | red[PI2_ROWS]
+constexpr int PI2_ROWS = 4;
+__global__ __launch_bounds__(64 * PI2_ROWS) void k_refit_pi2_mw(RefitArgs p) {
+    extern __shared__ float smem[];
+    float* om = smem;
+    float* red = smem + p.Nst;
+    const int a = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = PI2_ROWS, NT = 64 * PI2_ROWS;
+    float lmin = INFINITY;
+    for (int n = tid; n < p.N; n += NT) {
+        const float c = -p.rewards[(size_t)a * p.Nst + n];               // costs = -rewards   pi2.py:78-79
+        om[n] = c;
+        lmin = fminf(lmin, c);
+    }
+    lmin = wave_min(lmin);
+    if (lane == 0) red[wv] = lmin;
+    __syncthreads();
+    float beta = red[lane < NW ? lane : 0];
+    beta = wave_min(beta);                                               // pi2.py:81
+    __syncthreads();
+    float lsum = 0.0f;
+    for (int n = tid; n < p.N; n += NT) {
+        const float pr = expf((-p.inv_lamda) * (om[n] - beta));          // pi2.py:82
+        om[n] = pr;
+        lsum += pr;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[wv] = lsum;
+    __syncthreads();
+    float eta = (lane < NW) ? red[lane] : 0.0f;
+    eta = wave_sum(eta);                                                 // pi2.py:83
+    const float inv_eta = 1.0f / eta;
+    __syncthreads();
+    for (int n = tid; n < p.N; n += NT) om[n] = inv_eta * om[n];         // pi2.py:85
+    __syncthreads();
+    const int j = blockIdx.x * PI2_ROWS + wv;
+    if (j >= p.HU) return;
+    const float* __restrict__ row = p.samples + (size_t)(a * p.HU + j) * p.Nst;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int n = lane;
+    for (; n + 192 < p.N; n += 256) {                                    // four independent loads per trip
+        const float x0 = row[n], x1 = row[n + 64], x2 = row[n + 128], x3 = row[n + 192];
+        acc[0] = fmaf(x0, om[n], acc[0]);
+        acc[1] = fmaf(x1, om[n + 64], acc[1]);
+        acc[2] = fmaf(x2, om[n + 128], acc[2]);
+        acc[3] = fmaf(x3, om[n + 192], acc[3]);
+    }
+    for (; n < p.N; n += 64) acc[0] = fmaf(row[n], om[n], acc[0]);
+    const float s = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    if (lane == 0) {
+        p.mean[a * p.HU + j] = s;                                        // pi2.py:86-87
+        if (j < p.U) p.action[a * p.U + j] = s;                          // new_mean[:, 0]
+    }
+}
+
+}  // namespace bbmpc
