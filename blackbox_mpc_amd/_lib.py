@@ -12,8 +12,9 @@ ABI_VERSION = 1
 
 # enums (bbmpc.h)
 OPT_NONE, OPT_RANDOM_SEARCH, OPT_CEM, OPT_PI2, OPT_PSO, OPT_CMAES, OPT_SPSA = range(7)
-DYN_PENDULUM, DYN_MLP = 1, 2
-REW_PENDULUM, REW_CHEETAH = 1, 2
+DYN_PENDULUM, DYN_MLP, DYN_USER = 1, 2, 3
+REW_PENDULUM, REW_CHEETAH, REW_USER = 1, 2, 3
+USER_KIND_REWARD, USER_KIND_DYNAMICS = 1, 2
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = range(4)
 FIX_Q1_REWARD_ARG_ORDER = 1 << 0
 FIX_Q2_CEM_WARM_START = 1 << 1
@@ -64,6 +65,8 @@ SYMBOLS = [
     "bbmpc_set_state", "bbmpc_set_profiling", "bbmpc_get_profile", "bbmpc_synchronize", "bbmpc_rollout_episode",
     "bbmpc_comm_unique_id", "bbmpc_comm_init", "bbmpc_gather_records_dev", "bbmpc_gather_wait", "bbmpc_comm_destroy",
     "bbmpc_optimize_gather_dev", "bbmpc_set_stream_default", "bbmpc_optimize_gather", "bbmpc_comm_info",
+    "bbmpc_set_reward_source", "bbmpc_set_dynamics_source", "bbmpc_check_user_source", "bbmpc_mlp_forward",
+    "bbmpc_process_input", "bbmpc_process_output",
 ]
 COMM_ID_BYTES = 128
 
@@ -119,6 +122,12 @@ def _load():
     lib.bbmpc_comm_destroy.argtypes = [vp]
     lib.bbmpc_optimize_gather.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i32]
     lib.bbmpc_comm_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    lib.bbmpc_set_reward_source.argtypes = [vp, ctypes.c_char_p]
+    lib.bbmpc_set_dynamics_source.argtypes = [vp, ctypes.c_char_p]
+    lib.bbmpc_check_user_source.argtypes = [i32, ctypes.c_char_p, i32, i32]
+    lib.bbmpc_mlp_forward.argtypes = [vp, vp, i32, vp]
+    lib.bbmpc_process_input.argtypes = [vp, vp, vp, i32, ctypes.POINTER(vp), vp]
+    lib.bbmpc_process_output.argtypes = [vp, vp, vp, i32, ctypes.POINTER(vp), vp]
     return lib
 
 

@@ -85,8 +85,10 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
     REQUIRE(A >= 1 && H >= 1 && U >= 1 && S >= 1, BBMPC_E_INVALID, "num_agents, planning_horizon, dim_u, dim_s must be >= 1");
     REQUIRE(c.action_low && c.action_high, BBMPC_E_INVALID, "action_low/action_high are required");
     REQUIRE(c.optimizer >= BBMPC_OPT_NONE && c.optimizer <= BBMPC_OPT_SPSA, BBMPC_E_INVALID, "unknown optimizer");
-    REQUIRE(c.dynamics == BBMPC_DYN_PENDULUM || c.dynamics == BBMPC_DYN_MLP, BBMPC_E_INVALID, "unknown dynamics kind");
-    REQUIRE(c.reward == BBMPC_REW_PENDULUM || c.reward == BBMPC_REW_CHEETAH, BBMPC_E_INVALID, "unknown reward kind");
+    REQUIRE(c.dynamics == BBMPC_DYN_PENDULUM || c.dynamics == BBMPC_DYN_MLP || c.dynamics == BBMPC_DYN_USER, BBMPC_E_INVALID, "unknown dynamics kind");
+    REQUIRE(c.reward == BBMPC_REW_PENDULUM || c.reward == BBMPC_REW_CHEETAH || c.reward == BBMPC_REW_USER, BBMPC_E_INVALID, "unknown reward kind");
+    if (c.dynamics == BBMPC_DYN_USER || c.reward == BBMPC_REW_USER)
+        REQUIRE(S <= 256 && U <= 256, BBMPC_E_UNSUPPORTED, "user device functions: dim_s, dim_u <= 256 (per-row arrays live in registers)");
     if (c.dynamics == BBMPC_DYN_PENDULUM)
         REQUIRE(S == 3 && U == 1, BBMPC_E_INVALID, "PendulumTrueModel needs dim_s == 3 and dim_u == 1");
     if (c.reward == BBMPC_REW_PENDULUM) REQUIRE(S >= 3, BBMPC_E_INVALID, "pendulum reward needs dim_s >= 3");
@@ -204,6 +206,8 @@ Engine::~Engine() {
         if (pf_free) (void)hipEventDestroy(pf_free);
     }
     for (auto e : ev_pool) (void)hipEventDestroy(e);
+    user_reward.release();
+    user_dynamics.release();
     if (h_pin) (void)hipHostFree(h_pin);
     if (host_done) (void)hipHostFree(host_done);
     if (host_count) (void)hipFree(host_count);
@@ -713,7 +717,125 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     prof_end();
 }
 
+// ------------------------------------------------------------------------------------------------
+// user device functions (rtc.hpp) + the step-wise evaluator (kernels_user.hpp)
+// ------------------------------------------------------------------------------------------------
+void Engine::set_user_source(int kind, const char* src) {
+    REQUIRE(src && *src, BBMPC_E_INVALID, "empty HIP source");
+    if (kind == USER_KIND_REWARD) REQUIRE(cfg.reward == BBMPC_REW_USER, BBMPC_E_STATE, "handle was not created with BBMPC_REW_USER");
+    else REQUIRE(cfg.dynamics == BBMPC_DYN_USER, BBMPC_E_STATE, "handle was not created with BBMPC_DYN_USER");
+    std::vector<char> code;
+    try {
+        code = compile_user_program(src, kind, S, U);
+    } catch (const std::exception& ex) {
+        throw HipError(BBMPC_E_INVALID, ex.what());
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+    UserFunction& f = kind == USER_KIND_REWARD ? user_reward : user_dynamics;
+    f.release();
+    HIP_CHECK(hipModuleLoadData(&f.module, code.data()));
+    HIP_CHECK(hipModuleGetFunction(&f.fn, f.module, kind == USER_KIND_REWARD ? "bbmpc_user_reward_rows" : "bbmpc_user_dynamics_rows"));
+    f.source = src;
+}
+
+// next = process_output(state, dynamics(process_input(state, action)))  on [batch] rows   deterministic.py:79-103
+void Engine::dynamics_rows(const float* d_states, const float* d_actions, int astride, int batch, float* d_next) {
+    if (cfg.dynamics == BBMPC_DYN_USER) {
+        REQUIRE(user_dynamics.fn, BBMPC_E_STATE, "user dynamics: call bbmpc_set_dynamics_source before computing");
+        void* args[] = {(void*)&d_states, (void*)&d_actions, (void*)&astride, (void*)&batch, (void*)&d_next};
+        HIP_CHECK(hipModuleLaunchKernel(user_dynamics.fn, (unsigned)((batch + 255) / 256), 1, 1, 256, 1, 1, 0, stream, args, nullptr));
+        return;
+    }
+    if (cfg.dynamics == BBMPC_DYN_PENDULUM) {
+        hipLaunchKernelGGL(k_step_pendulum, dim3((batch + 63) / 64), dim3(64), 0, stream, d_states, d_actions, astride, batch,
+                           (int)fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER), d_next, (float*)nullptr);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    step_dev(d_states, d_actions, astride, batch, d_next, nullptr);        // learned model (its built-in reward kind is REW_NONE here)
+}
+
+// total (+)= reward_function(cur, actions, next) on [batch] rows   deterministic.py:65-66, 105-127
+void Engine::reward_rows(const float* d_cur, const float* d_next, const float* d_actions, int astride, int batch, float* d_total,
+                         int accumulate) {
+    if (cfg.reward == BBMPC_REW_USER) {
+        REQUIRE(user_reward.fn, BBMPC_E_STATE, "user reward: call bbmpc_set_reward_source before computing");
+        void* args[] = {(void*)&d_cur, (void*)&d_next, (void*)&d_actions, (void*)&astride, (void*)&batch, (void*)&d_total, (void*)&accumulate};
+        HIP_CHECK(hipModuleLaunchKernel(user_reward.fn, (unsigned)((batch + 255) / 256), 1, 1, 256, 1, 1, 0, stream, args, nullptr));
+        return;
+    }
+    hipLaunchKernelGGL(k_reward_rows_acc, dim3((batch + 255) / 256), dim3(256), 0, stream, d_cur, d_next, d_actions, astride, batch, S, U,
+                       (int)cfg.reward, (int)fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER), d_total, accumulate);
+    HIP_CHECK(hipGetLastError());
+}
+
+// DeterministicTrajectoryEvaluator.__call__ one planning step at a time (kernels_user.hpp)
+void Engine::rollout_stepwise(int mode, bool pen, RolloutArgs& ra) {
+    const int n_pop = ra.n_pop, Hh = ra.H, HUh = ra.HU;
+    const size_t B = (size_t)A * n_pop;
+    if (u_rows.n < (size_t)Hh * B * U) u_rows.alloc((size_t)Hh * B * U);
+    if (u_x0.n < B * S) { u_x0.alloc(B * S); u_x1.alloc(B * S); }
+    if (u_total.n < B) { u_total.alloc(B); u_pen.alloc(B); }
+    dim3 grid((n_pop + 255) / 256, A), block(256);
+    if (mode == SRC_UNIFORM || mode == SRC_TRUNC) {
+        // the draws the fused kernels make on the fly: candidates of this iteration into the sample buffer
+        REQUIRE(ra.samples, BBMPC_E_STATE, "step-wise rollout: no sample buffer");
+        if (mode == SRC_UNIFORM) hipLaunchKernelGGL(k_gen_candidates<SRC_UNIFORM>, grid, block, 0, stream, ra);
+        else hipLaunchKernelGGL(k_gen_candidates<SRC_TRUNC>, grid, block, (size_t)2 * HUh * sizeof(float), stream, ra);
+        HIP_CHECK(hipGetLastError());
+    }
+    RowsArgs rw;
+    memset(&rw, 0, sizeof(rw));
+    rw.n_pop = n_pop; rw.A = A; rw.H = Hh; rw.U = U; rw.S = S; rw.HU = HUh; rw.Nst = ra.Nst;
+    rw.from_ref = mode == SRC_REF ? 1 : 0;
+    rw.pen = pen ? 1 : 0;
+    rw.seq = ra.seq;
+    rw.cand = mode == SRC_BUF ? ra.cand : ra.samples;
+    rw.samples = (mode == SRC_BUF && pen) ? ra.samples : nullptr;       // the feasible candidates go back (PSO / SPSA / CMA-ES / PI2)
+    if (mode == SRC_TRUNC && pen) rw.samples = ra.samples;
+    rw.lo = ra.lo; rw.hi = ra.hi;
+    rw.state = ra.state;
+    rw.rows = u_rows.p; rw.x0 = u_x0.p; rw.penalty = u_pen.p;
+    prof_begin();
+    hipLaunchKernelGGL(k_rows_prepare, grid, block, 0, stream, rw);
+    HIP_CHECK(hipGetLastError());
+    float* cur = u_x0.p;
+    float* nxt = u_x1.p;
+    for (int t = 0; t < Hh; ++t) {
+        const float* acts = u_rows.p + (size_t)t * B * U;
+        dynamics_rows(cur, acts, U, (int)B, nxt);
+        reward_rows(cur, nxt, acts, U, (int)B, u_total.p, t > 0 ? 1 : 0);
+        std::swap(cur, nxt);
+    }
+    hipLaunchKernelGGL(k_rows_finish, grid, block, 0, stream, n_pop, A, ra.Nst, pen ? 1 : 0, u_total.p, u_pen.p, ra.rewards, ra.penalty_out);
+    HIP_CHECK(hipGetLastError());
+    prof_end();
+}
+
+// DeterministicMLP.__call__ on already-processed rows (deterministic_mlp.py:27-51)
+__global__ __launch_bounds__(TAIL_THREADS) void k_rows_mlp_raw(RowMlp net, const float* x_in, float* out) {
+    __shared__ float x[192];
+    __shared__ float bufA[TAIL_MAXW], bufB[TAIL_MAXW], part[(TAIL_THREADS / 64) * TAIL_MAXW];
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int K = net.m.dims[0], M = net.m.dims[net.m.n_layers];
+    for (int i = tid; i < K; i += nthr) x[i] = x_in[(size_t)b * K + i];
+    __syncthreads();
+    const float* raw = row_mlp_forward(net, x, bufA, bufB, part, tid, nthr);
+    for (int i = tid; i < M; i += nthr) out[(size_t)b * M + i] = raw[i];
+}
+
+void Engine::mlp_forward_rows(const float* d_x, int batch, float* d_out) {
+    REQUIRE(cfg.dynamics == BBMPC_DYN_MLP && mlp_ready, BBMPC_E_STATE, "bbmpc_mlp_forward: needs a learned-dynamics handle with weights set");
+    hipLaunchKernelGGL(k_rows_mlp_raw, dim3(batch), dim3(TAIL_THREADS), 0, stream, row_mlp(), d_x, d_out);
+    HIP_CHECK(hipGetLastError());
+}
+
 void Engine::launch_rollout(int mode, bool pen, RolloutArgs& ra) {
+    if (user_path()) {
+        dominant_kernel = "stepwise(user device function)";
+        rollout_stepwise(mode, pen, ra);
+        return;
+    }
     if (cfg.dynamics == BBMPC_DYN_MLP) {
         dominant_kernel = "k_rollout_mlp";
         launch_rollout_mlp(mode, pen, ra, false, nullptr);
@@ -793,9 +915,29 @@ void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_ou
     fa.next_state = d_next_out;
     fa.key = key(step);
     fa.key.q_per_agent = (uint32_t)((U + 3) / 4);
-    if (cfg.dynamics == BBMPC_DYN_PENDULUM) {
+    if (cfg.dynamics == BBMPC_DYN_PENDULUM && !user_path()) {
         hipLaunchKernelGGL(k_finalize_pendulum, dim3((A + 63) / 64), dim3(64), 0, stream, fa);
         HIP_CHECK(hipGetLastError());
+        return;
+    }
+    if (user_path()) {
+        // a user device function is involved: exploration noise, one batched model step + reward on the [A] rows, pack
+        if (add_noise) {
+            hipLaunchKernelGGL(k_explore, dim3((A * U + 63) / 64), dim3(64), 0, stream, fa, d_action.p);
+            HIP_CHECK(hipGetLastError());
+        }
+        if (!d_fin_next.p) {
+            d_fin_next.alloc((size_t)A * S);
+            d_fin_rew.alloc((size_t)((A + 63) / 64) * 64);
+        }
+        step_dev(d_state_in, d_action.p, U, A, d_fin_next.p, d_fin_rew.p);
+        hipLaunchKernelGGL(k_pack_record, dim3((A * rec + 63) / 64), dim3(64), 0, stream, A, U, S, d_action.p, d_fin_next.p,
+                           d_fin_rew.p, d_record_out, d_next_out);
+        HIP_CHECK(hipGetLastError());
+        if (pending_warm == 1) hipLaunchKernelGGL(k_shift_left, dim3((A * HU + 255) / 256), dim3(256), 0, stream, A, H, U, d_mean.p, d_prev_mean.p);
+        else if (pending_warm == 2) HIP_CHECK(hipMemcpyAsync(d_prev_mean.p, d_mean.p, (size_t)A * HU * 4, hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipGetLastError());
+        pending_warm = 0;
         return;
     }
     // learned dynamics: exploration noise, one model step on the [A] rows, reward, packed record and the warm start of
@@ -805,7 +947,7 @@ void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_ou
     memset(&ta, 0, sizeof(ta));
     ta.f = fa;
     ta.net = row_mlp();
-    ta.reward_kind = cfg.reward;
+    ta.reward_kind = builtin_reward_kind();
     ta.warm_mode = pending_warm;
     ta.H = H; ta.HU = HU;
     ta.mean = d_mean.p;
@@ -828,7 +970,7 @@ RowMlp Engine::row_mlp() const {
 }
 
 bool Engine::use_fused() const {
-    if (cfg.dynamics != BBMPC_DYN_PENDULUM) return false;
+    if (cfg.dynamics != BBMPC_DYN_PENDULUM || cfg.reward != BBMPC_REW_PENDULUM) return false;
     if (cfg.optimizer == BBMPC_OPT_SPSA) {
         if (iters > FUSED_MAX_SPSA_ITERS) return false;
     } else if (cfg.optimizer != BBMPC_OPT_RANDOM_SEARCH && cfg.optimizer != BBMPC_OPT_CEM && cfg.optimizer != BBMPC_OPT_PI2) {
@@ -1062,7 +1204,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
     ra.n_pop = N; ra.A = A; ra.H = H; ra.U = U; ra.S = S; ra.HU = HU; ra.Nst = Nst;
     ra.agent_offset = cfg.agent_offset;
     ra.fix_q1 = fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
-    ra.reward_kind = cfg.reward;
+    ra.reward_kind = builtin_reward_kind();
     ra.state = d_state_in;
     ra.mean = d_mean.p; ra.sigma = d_sigma.p;
     ra.lo = d_lo.p; ra.hi = d_hi.p;
@@ -1122,7 +1264,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                 capture_trace(it);
             }
             if (fix(BBMPC_FIX_Q2_CEM_WARM_START)) {
-                if (cfg.dynamics == BBMPC_DYN_MLP) pending_warm = 2;      // prev = mean, in k_tail_mlp
+                if (cfg.dynamics == BBMPC_DYN_MLP || user_path()) pending_warm = 2;      // prev = mean, in k_tail_mlp
                 else HIP_CHECK(hipMemcpyAsync(d_prev_mean.p, d_mean.p, (size_t)nelem * 4, hipMemcpyDeviceToDevice, stream));
             }
             break;
@@ -1143,7 +1285,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                 HIP_CHECK(hipGetLastError());
                 capture_trace(it);
             }
-            if (cfg.dynamics == BBMPC_DYN_MLP) {
+            if (cfg.dynamics == BBMPC_DYN_MLP || user_path()) {
                 pending_warm = 1;                      // prev = shift_left(mean) (pi2.py:92-93) happens in k_tail_mlp
             } else {
                 hipLaunchKernelGGL(k_shift_left, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, H, U, d_mean.p, d_prev_mean.p);
@@ -1199,7 +1341,7 @@ void Engine::optimize_spsa(RolloutArgs& ra, uint32_t step) {
                                      hipMemcpyDeviceToDevice, stream));
         }
     }
-    if (cfg.dynamics == BBMPC_DYN_MLP) {
+    if (cfg.dynamics == BBMPC_DYN_MLP || user_path()) {
         pending_warm = 1;                              // :114-115, in k_tail_mlp
     } else {
         hipLaunchKernelGGL(k_shift_left, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, H, U, d_mean.p, d_prev_mean.p);  // :114-115
@@ -1212,7 +1354,7 @@ void Engine::optimize_spsa(RolloutArgs& ra, uint32_t step) {
 static size_t fused_pso_lds(int H, int Nst) { return ((size_t)2 * H * Nst + ((H + 3) & ~3) + 16 + 16 + 4) * sizeof(float); }
 
 bool Engine::use_fused_pso() const {
-    if (cfg.dynamics != BBMPC_DYN_PENDULUM || cfg.optimizer != BBMPC_OPT_PSO || U != 1) return false;
+    if (cfg.dynamics != BBMPC_DYN_PENDULUM || cfg.reward != BBMPC_REW_PENDULUM || cfg.optimizer != BBMPC_OPT_PSO || U != 1) return false;
     if (fused_mode == 0) return false;
     return N <= 1024 && fused_pso_lds(H, Nst) <= 160 * 1024;
 }
@@ -1301,7 +1443,7 @@ void Engine::evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop
     ra.n_pop = n_pop; ra.A = A; ra.H = H; ra.U = U; ra.S = S; ra.HU = HU; ra.Nst = st;
     ra.agent_offset = cfg.agent_offset;
     ra.fix_q1 = fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
-    ra.reward_kind = cfg.reward;
+    ra.reward_kind = builtin_reward_kind();
     ra.state = d_state_in;
     ra.seq = d_seq;
     ra.lo = d_lo.p; ra.hi = d_hi.p;
@@ -1315,11 +1457,23 @@ void Engine::evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop
 
 void Engine::step_dev(const float* d_states, const float* d_actions, int astride, int batch, float* d_next, float* d_rew) {
     REQUIRE(batch >= 1, BBMPC_E_INVALID, "batch must be >= 1");
+    if (user_path() && (cfg.dynamics == BBMPC_DYN_USER || d_rew)) {
+        // user dynamics, or a reward the built-in step kernels cannot evaluate: dynamics rows, then reward rows
+        float* nx = d_next;
+        if (!nx) {
+            if (u_next.n < (size_t)batch * S) u_next.alloc((size_t)batch * S);
+            nx = u_next.p;
+        }
+        if (cfg.dynamics == BBMPC_DYN_USER) dynamics_rows(d_states, d_actions, astride, batch, nx);
+        else step_dev(d_states, d_actions, astride, batch, nx, nullptr);
+        if (d_rew) reward_rows(d_states, nx, d_actions, astride, batch, d_rew, 0);
+        return;
+    }
     if (cfg.dynamics == BBMPC_DYN_MLP && batch <= 32 && !sw.mlp_generic) {
         // a handful of rows: one workgroup per row on plain FMAs -- the same per-row code as the control step's tail,
         // so act()'s predicted next state and evaluator.predict_next_state(obs, action) agree bit for bit
         REQUIRE(mlp_ready, BBMPC_E_STATE, "learned dynamics: call bbmpc_set_mlp before computing");
-        hipLaunchKernelGGL(k_rows_mlp, dim3(batch), dim3(TAIL_THREADS), 0, stream, row_mlp(), S, U, cfg.reward,
+        hipLaunchKernelGGL(k_rows_mlp, dim3(batch), dim3(TAIL_THREADS), 0, stream, row_mlp(), S, U, builtin_reward_kind(),
                            (int)fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER), d_states, d_actions, astride, d_next, d_rew);
         HIP_CHECK(hipGetLastError());
         return;
@@ -1344,7 +1498,7 @@ void Engine::step_dev(const float* d_states, const float* d_actions, int astride
         memset(&ra, 0, sizeof(ra));
         ra.n_pop = batch; ra.A = 1; ra.H = 1; ra.U = U; ra.S = S; ra.HU = U; ra.Nst = st_;
         ra.fix_q1 = fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
-        ra.reward_kind = cfg.reward;
+        ra.reward_kind = builtin_reward_kind();
         ra.state = d_states;
         ra.seq = acts_c;
         ra.lo = d_lo.p; ra.hi = d_hi.p;
@@ -1361,6 +1515,10 @@ void Engine::step_dev(const float* d_states, const float* d_actions, int astride
 }
 
 void Engine::reward_dev(const float* d_cur, const float* d_next, const float* d_act, int batch, float* d_rew) {
+    if (cfg.reward == BBMPC_REW_USER) {
+        reward_rows(d_cur, d_next, d_act, U, batch, d_rew, 0);
+        return;
+    }
     hipLaunchKernelGGL(k_reward_only, dim3((batch + 63) / 64), dim3(64), 0, stream, d_cur, d_next, d_act, batch, S, U,
                        cfg.reward, (int)fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER), d_rew);
     HIP_CHECK(hipGetLastError());
@@ -1713,6 +1871,98 @@ int bbmpc_set_mlp(bbmpc_handle h, int32_t n_layers, const int32_t* dims, const i
     API_BEGIN
     CHECK_HANDLE(h);
     h->e->set_mlp(n_layers, dims, acts, w, b, is_normalized, stats);
+    API_END
+}
+
+int bbmpc_set_reward_source(bbmpc_handle h, const char* src) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(src);
+    h->e->set_user_source(bbmpc::USER_KIND_REWARD, src);
+    API_END
+}
+
+int bbmpc_set_dynamics_source(bbmpc_handle h, const char* src) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(src);
+    h->e->set_user_source(bbmpc::USER_KIND_DYNAMICS, src);
+    API_END
+}
+
+int bbmpc_check_user_source(int32_t kind, const char* src, int32_t dim_s, int32_t dim_u) {
+    API_BEGIN
+    CHECK_PTR(src);
+    if (kind != bbmpc::USER_KIND_REWARD && kind != bbmpc::USER_KIND_DYNAMICS) throw HipError(BBMPC_E_INVALID, "kind must be 1 (reward) or 2 (dynamics)");
+    if (dim_s < 1 || dim_u < 1 || dim_s > 256 || dim_u > 256) throw HipError(BBMPC_E_INVALID, "dim_s / dim_u must be in [1, 256]");
+    try {
+        (void)bbmpc::compile_user_program(src, kind, dim_s, dim_u);
+    } catch (const std::exception& ex) {
+        throw HipError(BBMPC_E_INVALID, ex.what());
+    }
+    API_END
+}
+
+int bbmpc_mlp_forward(bbmpc_handle h, const float* x, int32_t batch, float* out) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(x);
+    CHECK_PTR(out);
+    Engine& e = *h->e;
+    if (batch < 1) throw HipError(BBMPC_E_INVALID, "batch must be >= 1");
+    if (e.cfg.dynamics != BBMPC_DYN_MLP || !e.mlp_ready) throw HipError(BBMPC_E_STATE, "bbmpc_mlp_forward: needs a learned-dynamics handle with weights set");
+    const size_t nin = (size_t)batch * e.mlp.dims[0], nout = (size_t)batch * e.mlp.dims[e.mlp.n_layers];
+    if (e.d_step_a.n < nin + nout) e.d_step_a.alloc(nin + nout);
+    HIP_CHECK(hipMemcpyAsync(e.d_step_a.p, x, nin * 4, hipMemcpyHostToDevice, e.stream));
+    e.mlp_forward_rows(e.d_step_a.p, batch, e.d_step_a.p + nin);
+    HIP_CHECK(hipMemcpyAsync(out, e.d_step_a.p + nin, nout * 4, hipMemcpyDeviceToHost, e.stream));
+    HIP_CHECK(hipStreamSynchronize(e.stream));
+    API_END
+}
+
+// which = 0: process_input(states[B,S], actions[B,U]) -> [B,S+U];  1: process_output(states[B,S], raw[B,S]) -> [B,S]
+static void process_io(Engine& e, int which, const float* a, const float* b, int batch, const float* const* stats, float* out) {
+    if (batch < 1) throw HipError(BBMPC_E_INVALID, "batch must be >= 1");
+    const int S = e.S, U = e.U;
+    const size_t na = (size_t)batch * S, nb = (size_t)batch * (which == 0 ? U : S), no = (size_t)batch * (which == 0 ? S + U : S);
+    const size_t nst = stats ? (size_t)4 * S + 2 * U : 0;
+    if (e.d_step_b.n < na + nb + no + nst) e.d_step_b.alloc(na + nb + no + nst);
+    float* da = e.d_step_b.p; float* db = da + na; float* dout = db + nb; float* dst = dout + no;
+    HIP_CHECK(hipMemcpyAsync(da, a, na * 4, hipMemcpyHostToDevice, e.stream));
+    HIP_CHECK(hipMemcpyAsync(db, b, nb * 4, hipMemcpyHostToDevice, e.stream));
+    if (stats) {
+        std::vector<float> st;
+        const int lens[6] = {S, S, U, U, S, S};
+        for (int i = 0; i < 6; ++i) {
+            if (!stats[i]) throw HipError(BBMPC_E_INVALID, "null statistics vector");
+            st.insert(st.end(), stats[i], stats[i] + lens[i]);
+        }
+        HIP_CHECK(hipMemcpy(dst, st.data(), nst * 4, hipMemcpyHostToDevice));
+    }
+    if (which == 0) hipLaunchKernelGGL(bbmpc::k_process_input, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, e.stream, da, db, batch, S, U, stats ? dst : nullptr, dout);
+    else hipLaunchKernelGGL(bbmpc::k_process_output, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, e.stream, da, db, batch, S, U, stats ? dst : nullptr, dout);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(out, dout, no * 4, hipMemcpyDeviceToHost, e.stream));
+    HIP_CHECK(hipStreamSynchronize(e.stream));
+}
+
+int bbmpc_process_input(bbmpc_handle h, const float* states, const float* actions, int32_t batch, const float* const* stats, float* out) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(states);
+    CHECK_PTR(actions);
+    CHECK_PTR(out);
+    process_io(*h->e, 0, states, actions, batch, stats, out);
+    API_END
+}
+
+int bbmpc_process_output(bbmpc_handle h, const float* states, const float* raw_output, int32_t batch, const float* const* stats, float* out) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(states);
+    CHECK_PTR(raw_output);
+    CHECK_PTR(out);
+    process_io(*h->e, 1, states, raw_output, batch, stats, out);
     API_END
 }
 

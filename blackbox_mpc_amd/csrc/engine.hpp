@@ -22,6 +22,8 @@
 #include "kernels_refit.hpp"
 #include "kernels_rollout.hpp"
 #include "kernels_tail.hpp"
+#include "kernels_user.hpp"
+#include "rtc.hpp"
 
 namespace bbmpc {
 
@@ -171,6 +173,16 @@ struct Engine {
         return kk;
     }
     bool fix(uint32_t bit) const { return (cfg.quirks & bit) != 0; }
+    // user-supplied reward / dynamics device functions (rtc.hpp) and the step-wise evaluator that calls them
+    UserFunction user_reward, user_dynamics;
+    DevBuf<float> u_rows, u_x0, u_x1, u_total, u_pen, u_next;
+    bool user_path() const { return cfg.reward == BBMPC_REW_USER || cfg.dynamics == BBMPC_DYN_USER; }
+    int builtin_reward_kind() const { return cfg.reward == BBMPC_REW_USER ? REW_NONE : cfg.reward; }
+    void set_user_source(int kind, const char* src);
+    void rollout_stepwise(int mode, bool pen, RolloutArgs& ra);
+    void dynamics_rows(const float* d_states, const float* d_actions, int astride, int batch, float* d_next);
+    void reward_rows(const float* d_cur, const float* d_next, const float* d_actions, int astride, int batch, float* d_total, int accumulate);
+    void mlp_forward_rows(const float* d_x, int batch, float* d_out);
     int pending_warm = 0;    // learned-dynamics path: warm start the tail kernel performs (kernels_tail.hpp TailArgs::warm_mode)
     RowMlp row_mlp() const;
     const float* injected(int kind) const {

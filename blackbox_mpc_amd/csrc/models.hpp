@@ -25,6 +25,7 @@ __device__ __forceinline__ float floormodf(float x, float y) {
 }
 
 // reward kinds (bbmpc.h)
+constexpr int REW_NONE = 0;       // the reward is somebody else's business (a user device function evaluates it, kernels_user.hpp)
 constexpr int REW_PENDULUM = 1;
 constexpr int REW_CHEETAH = 2;
 
@@ -41,6 +42,7 @@ __device__ __forceinline__ float pendulum_reward_from_theta(float theta, float t
 // cur/nxt have S entries, act has U entries.
 __device__ __forceinline__ float reward_generic(int kind, bool fix_q1, const float* cur, const float* act,
                                                 const float* nxt, int S, int U) {
+    if (kind == REW_NONE) return 0.0f;
     if (kind == REW_PENDULUM) {
         float theta = bb_atan2f(cur[1], cur[0]);
         float ss = 0.0f;

@@ -1,0 +1,157 @@
+// User-supplied reward / dynamics functions as DEVICE code compiled at run time (hiprtc).
+//
+// The reference accepts any callable as `reward_function` / `dynamics_function`
+// (trajectory_evaluators/deterministic.py:13-18, called at :65-66 and :99-100; plugin contracts in SURVEY.md 1-L1):
+//     reward  r(current_state[B,S], actions[B,U], next_state[B,S]) -> [B]
+//     dynamics f(x[B,S+U], train) -> delta[B,S]           (true model: next = delta + state, transforms.py:34)
+// Python callables cannot run inside a kernel, so the counterpart here is a HIP source string that defines
+//     __device__ float bbmpc_user_reward(const float* cur, const float* act, const float* nxt, int S, int U);
+//     __device__ void  bbmpc_user_dynamics(const float* x /*[S+U]*/, float* delta /*[S]*/, int S, int U);
+// per row.  bbmpc_set_reward_source / bbmpc_set_dynamics_source compile it together with the two row kernels below and
+// the engine calls them once per planning step from its step-wise evaluator (kernels_user.hpp).  libhiprtc is bound at
+// run time, next to the HIP runtime the process already uses; compiling needs no GPU.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace bbmpc {
+
+struct Hiprtc {
+    typedef void* Program;
+    int (*CreateProgram)(Program*, const char*, const char*, int, const char**, const char**) = nullptr;
+    int (*CompileProgram)(Program, int, const char**) = nullptr;
+    int (*GetProgramLogSize)(Program, size_t*) = nullptr;
+    int (*GetProgramLog)(Program, char*) = nullptr;
+    int (*GetCodeSize)(Program, size_t*) = nullptr;
+    int (*GetCode)(Program, char*) = nullptr;
+    int (*DestroyProgram)(Program*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+
+    static const Hiprtc& get() {
+        static const Hiprtc api = load();
+        return api;
+    }
+
+private:
+    static Hiprtc load() {
+        void* lib = dlopen("libhiprtc.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!lib) {
+            // the copy that ships with the HIP runtime this process runs on (PyTorch bundles its own pair)
+            Dl_info info;
+            if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+                std::string p(info.dli_fname);
+                const size_t slash = p.rfind('/');
+                if (slash != std::string::npos) lib = dlopen((p.substr(0, slash + 1) + "libhiprtc.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
+            }
+        }
+        const char* names[] = {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+        for (int i = 0; !lib && i < 3; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) throw std::runtime_error("libhiprtc.so not found (needed to compile user reward / dynamics device functions)");
+        Hiprtc a;
+        auto sym = [&](const char* s) {
+            void* p = dlsym(lib, s);
+            if (!p) throw std::runtime_error(std::string("libhiprtc: missing symbol ") + s);
+            return p;
+        };
+        a.CreateProgram = reinterpret_cast<decltype(a.CreateProgram)>(sym("hiprtcCreateProgram"));
+        a.CompileProgram = reinterpret_cast<decltype(a.CompileProgram)>(sym("hiprtcCompileProgram"));
+        a.GetProgramLogSize = reinterpret_cast<decltype(a.GetProgramLogSize)>(sym("hiprtcGetProgramLogSize"));
+        a.GetProgramLog = reinterpret_cast<decltype(a.GetProgramLog)>(sym("hiprtcGetProgramLog"));
+        a.GetCodeSize = reinterpret_cast<decltype(a.GetCodeSize)>(sym("hiprtcGetCodeSize"));
+        a.GetCode = reinterpret_cast<decltype(a.GetCode)>(sym("hiprtcGetCode"));
+        a.DestroyProgram = reinterpret_cast<decltype(a.DestroyProgram)>(sym("hiprtcDestroyProgram"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("hiprtcGetErrorString"));
+        return a;
+    }
+};
+
+constexpr int USER_KIND_REWARD = 1, USER_KIND_DYNAMICS = 2;
+
+// The row kernels the engine launches around the user's function.  BBMPC_S / BBMPC_U are compile-time so the per-row
+// arrays live in registers; rows are [batch, S] / [batch, astride] row-major.
+inline std::string user_program_source(const std::string& user_src, int kind) {
+    std::string s;
+    s += "// ---- user source ------------------------------------------------------------------\n";
+    s += user_src;
+    s += "\n// ---- row kernels (blackbox_mpc_amd/csrc/rtc.hpp) ------------------------------------\n";
+    if (kind == USER_KIND_REWARD) {
+        s += R"RTC(
+extern "C" __global__ void bbmpc_user_reward_rows(const float* __restrict__ cur, const float* __restrict__ nxt,
+                                                  const float* __restrict__ act, int astride, int batch,
+                                                  float* __restrict__ total, int accumulate) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    float c[BBMPC_S], n[BBMPC_S], a[BBMPC_U];
+    for (int i = 0; i < BBMPC_S; ++i) { c[i] = cur[(size_t)b * BBMPC_S + i]; n[i] = nxt[(size_t)b * BBMPC_S + i]; }
+    for (int i = 0; i < BBMPC_U; ++i) a[i] = act[(size_t)b * astride + i];
+    // reward_function(current_state, actions, next_state): the argument order of the CALL (deterministic.py:65-66)
+    const float r = bbmpc_user_reward(c, a, n, BBMPC_S, BBMPC_U);
+    total[b] = accumulate ? total[b] + r : r;
+}
+)RTC";
+    } else {
+        s += R"RTC(
+extern "C" __global__ void bbmpc_user_dynamics_rows(const float* __restrict__ states, const float* __restrict__ act,
+                                                    int astride, int batch, float* __restrict__ next_states) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    float x[BBMPC_S + BBMPC_U], d[BBMPC_S];
+    for (int i = 0; i < BBMPC_S; ++i) x[i] = states[(size_t)b * BBMPC_S + i];                    // process_input: concat
+    for (int i = 0; i < BBMPC_U; ++i) x[BBMPC_S + i] = act[(size_t)b * astride + i];
+    bbmpc_user_dynamics(x, d, BBMPC_S, BBMPC_U);                                                // f(x, train=False) -> delta
+    for (int i = 0; i < BBMPC_S; ++i) next_states[(size_t)b * BBMPC_S + i] = d[i] + x[i];        // transforms.py:34
+}
+)RTC";
+    }
+    return s;
+}
+
+// Compile for gfx950; returns the code object.  Throws std::runtime_error with the compiler log on failure.
+inline std::vector<char> compile_user_program(const std::string& user_src, int kind, int S, int U) {
+    const Hiprtc& r = Hiprtc::get();
+    const std::string src = user_program_source(user_src, kind);
+    Hiprtc::Program prog = nullptr;
+    int rc = r.CreateProgram(&prog, src.c_str(), kind == USER_KIND_REWARD ? "bbmpc_user_reward.hip" : "bbmpc_user_dynamics.hip", 0, nullptr, nullptr);
+    if (rc != 0) throw std::runtime_error(std::string("hiprtcCreateProgram: ") + r.GetErrorString(rc));
+    const std::string ds = "-DBBMPC_S=" + std::to_string(S), du = "-DBBMPC_U=" + std::to_string(U);
+    // one rounding per source operation, as everywhere in the engine (and as the reference's TF ops round)
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", ds.c_str(), du.c_str()};
+    rc = r.CompileProgram(prog, 5, opts);
+    std::string log;
+    size_t n = 0;
+    if (r.GetProgramLogSize(prog, &n) == 0 && n > 1) {
+        log.resize(n);
+        (void)r.GetProgramLog(prog, &log[0]);
+    }
+    if (rc != 0) {
+        (void)r.DestroyProgram(&prog);
+        throw std::runtime_error(std::string("user device function failed to compile (") + r.GetErrorString(rc) + "):\n" + log);
+    }
+    std::vector<char> code;
+    if (r.GetCodeSize(prog, &n) != 0 || n == 0) {
+        (void)r.DestroyProgram(&prog);
+        throw std::runtime_error("hiprtcGetCodeSize failed");
+    }
+    code.resize(n);
+    rc = r.GetCode(prog, code.data());
+    (void)r.DestroyProgram(&prog);
+    if (rc != 0) throw std::runtime_error(std::string("hiprtcGetCode: ") + r.GetErrorString(rc));
+    return code;
+}
+
+struct UserFunction {
+    std::string source;
+    hipModule_t module = nullptr;
+    hipFunction_t fn = nullptr;
+    void release() {
+        if (module) (void)hipModuleUnload(module);
+        module = nullptr;
+        fn = nullptr;
+    }
+};
+
+}  // namespace bbmpc

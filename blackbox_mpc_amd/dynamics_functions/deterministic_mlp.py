@@ -67,8 +67,25 @@ class DeterministicMLP:
         return m
 
     def __call__(self, x, train=False):
-        raise NotImplementedError("DeterministicMLP.forward runs fused inside the engine's rollout kernels; use "
-                                  "DeterministicTrajectoryEvaluator.predict_next_state")
+        """x [B, layers[0]] -> [B, layers[-1]]: the Dense stack (deterministic_mlp.py:27-51; `train` is accepted and
+        ignored, as there).  Runs on the GPU through bbmpc_mlp_forward -- the per-row code the control step's tail
+        uses; inside rollouts the same weights run fused on the matrix cores."""
+        x = np.asarray(x, np.float32)
+        eng = self.__dict__.get("_fwd_engine")
+        if eng is None or self.__dict__.get("_fwd_version") != self._version:
+            from ..engine import Engine
+            dim_s = self.layer_sizes[-1]
+            dim_u = self.layer_sizes[0] - dim_s
+            if dim_u < 1:
+                raise ValueError("DeterministicMLP maps [state | action] -> state delta: layers[0] must exceed layers[-1]")
+            if eng is None:
+                # the reward kind is irrelevant for a forward pass; REW_USER puts no constraint on dim_S
+                eng = Engine(L.OPT_NONE, L.DYN_MLP, L.REW_USER, [-1.0] * dim_u, [1.0] * dim_u, dim_s=dim_s, num_agents=1,
+                             planning_horizon=1)
+                self._fwd_engine = eng
+            eng.set_mlp(self.weights, self.biases, self.activation_codes, None)
+            self._fwd_version = self._version
+        return eng.mlp_forward(x)
 
     # -- losses (deterministic_mlp.py:53-92: both are loss_fn = Keras MeanSquaredError unless overridden) ----------
     def get_loss(self, expected_output, predictions):

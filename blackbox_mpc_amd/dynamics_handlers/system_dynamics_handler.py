@@ -62,6 +62,25 @@ class SystemDynamicsHandler:
                             "(set_normalization_stats / load)")
         return self._stats
 
+    # -- process_input / process_output (system_dynamics_handler.py:97-161) as stand-alone calls: inside rollouts the same
+    # arithmetic is fused into the kernels; called directly they run the device code through the C ABI
+    def _io_engine(self):
+        eng = self.__dict__.get("_io_eng")
+        if eng is None:
+            from .. import _lib as L
+            from ..engine import Engine
+            eng = self._io_eng = Engine(L.OPT_NONE, L.DYN_USER, L.REW_USER, self._env_action_space.low,
+                                        self._env_action_space.high, dim_s=self._dim_S, num_agents=1, planning_horizon=1)
+        return eng
+
+    def process_input(self, states, actions):
+        """states [B,S], actions [B,U] -> [B,S+U]: concat (true / un-normalised model) or z-scored concat."""
+        return self._io_engine().process_input(states, actions, self.normalization_stats())
+
+    def process_output(self, inputs_states, raw_output):
+        """inputs_states [B,S], raw_output [B,S] -> absolute next states (de-normalise, then state + delta)."""
+        return self._io_engine().process_output(inputs_states, raw_output, self.normalization_stats())
+
     def load(self, saved_model_dir):
         """Counterpart of the reference's checkpoint load (:78-95): the six `.npy` statistics are read as
         written by the reference; the SavedModel graph is replaced by `mlp.npz` (DeterministicMLP.save)."""

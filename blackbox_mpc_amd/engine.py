@@ -89,6 +89,45 @@ class Engine:
         else:
             L.check(L.lib.bbmpc_set_mlp(self._h, n, dims_a, acts_a, wp, bp, 0, None))
 
+    def set_reward_source(self, hip_source):
+        """HIP source defining `__device__ float bbmpc_user_reward(cur, act, nxt, S, U)` (include/bbmpc.h)."""
+        L.check(L.lib.bbmpc_set_reward_source(self._h, hip_source.encode()))
+
+    def set_dynamics_source(self, hip_source):
+        """HIP source defining `__device__ void bbmpc_user_dynamics(x, delta, S, U)` (include/bbmpc.h)."""
+        L.check(L.lib.bbmpc_set_dynamics_source(self._h, hip_source.encode()))
+
+    def mlp_forward(self, x):
+        """DeterministicMLP.__call__ on the device: raw Dense stack on processed inputs [B, S+U] -> [B, S]."""
+        x = L.f32c(x)
+        if x.ndim != 2 or x.shape[1] != self.S + self.U:
+            raise ValueError("x must be [B, dim_S + dim_U] = [B, %d], got %s" % (self.S + self.U, x.shape))
+        out = np.empty((x.shape[0], self.S), np.float32)
+        if x.shape[0]:
+            L.check(L.lib.bbmpc_mlp_forward(self._h, L.ptr(x), x.shape[0], L.ptr(out)))
+        return out
+
+    def _process(self, fn, first, second, width_second, width_out, stats):
+        first, second = L.f32c(first), L.f32c(second)
+        b = first.shape[0] if first.ndim == 2 else -1
+        if first.shape != (b, self.S) or second.shape != (b, width_second):
+            raise ValueError("expected [B,%d] and [B,%d], got %s and %s" % (self.S, width_second, first.shape, second.shape))
+        out = np.empty((b, width_out), np.float32)
+        if b:
+            if stats is not None:
+                st = [L.f32c(np.asarray(v).reshape(-1)) for v in stats]
+                sp = (ctypes.c_void_p * 6)(*[v.ctypes.data for v in st])
+            else:
+                sp = None
+            L.check(fn(self._h, L.ptr(first), L.ptr(second), b, sp, L.ptr(out)))
+        return out
+
+    def process_input(self, states, actions, stats=None):
+        return self._process(L.lib.bbmpc_process_input, states, actions, self.U, self.S + self.U, stats)
+
+    def process_output(self, states, raw_output, stats=None):
+        return self._process(L.lib.bbmpc_process_output, states, raw_output, self.S, self.S, stats)
+
     def reset(self):
         L.check(L.lib.bbmpc_reset(self._h))
 

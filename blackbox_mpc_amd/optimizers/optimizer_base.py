@@ -63,7 +63,7 @@ class OptimizerBase:
             self._engine.reset()
 
     def set_trajectory_evaluator(self, trajectory_evaluator):
-        from ..trajectory_evaluators.deterministic import configure_dynamics, plugin_kinds
+        from ..trajectory_evaluators.deterministic import configure_dynamics, configure_reward, plugin_kinds
         self._trajectory_evaluator = trajectory_evaluator
         if type(self)._engine_optimizer == L.OPT_NONE:
             return
@@ -78,4 +78,5 @@ class OptimizerBase:
                               agent_offset=self._agent_offset, num_agents_global=self._num_agents_global,
                               device=self._device, **self._engine_kwargs())
         configure_dynamics(self._engine, h)
+        configure_reward(self._engine, trajectory_evaluator._reward_function)
         return

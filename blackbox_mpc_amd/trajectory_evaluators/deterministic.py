@@ -11,17 +11,25 @@ def plugin_kinds(reward_function, handler):
     """Map the user-supplied callables to device functors (fused kernels need
     device code, arbitrary Python callables cannot run there)."""
     rk = getattr(reward_function, "_bbmpc_reward_kind", None)
+    if rk is None and isinstance(getattr(reward_function, "hip_source", None), str):
+        rk = L.REW_USER                       # any object that carries HIP source for bbmpc_user_reward
     if rk is None:
         raise NotImplementedError(
-            "reward_function %r has no device functor. Built-ins: blackbox_mpc_amd.utils.pendulum."
-            "pendulum_reward_function, blackbox_mpc_amd.utils.cheetah.reward_function" % (reward_function,))
+            "reward_function %r is a host callable: rollouts run inside GPU kernels, so a custom reward must be device "
+            "code -- wrap HIP source in blackbox_mpc_amd.utils.device_functions.HipRewardFunction (or give the object a "
+            "`hip_source` attribute).  Built-ins: blackbox_mpc_amd.utils.pendulum.pendulum_reward_function, "
+            "blackbox_mpc_amd.utils.cheetah.reward_function" % (reward_function,))
     dyn = handler._dynamics_function
     dk = getattr(dyn, "_bbmpc_dynamics_kind", None)
+    if dk is None and isinstance(getattr(dyn, "hip_source", None), str):
+        dk = L.DYN_USER
     if dk is None:
         raise NotImplementedError(
-            "dynamics_function %r has no device functor. Built-ins: PendulumTrueModel, DeterministicMLP" % (dyn,))
-    if dk == L.DYN_PENDULUM and not handler._is_true_model:
-        raise Exception("PendulumTrueModel must be used with true_model=True")
+            "dynamics_function %r is a host callable: a custom model must be device code -- wrap HIP source in "
+            "blackbox_mpc_amd.utils.device_functions.HipDynamicsFunction.  Built-ins: PendulumTrueModel, "
+            "DeterministicMLP" % (dyn,))
+    if dk in (L.DYN_PENDULUM, L.DYN_USER) and not handler._is_true_model:
+        raise Exception("%s must be used with true_model=True" % type(dyn).__name__)
     return dk, rk
 
 
@@ -30,7 +38,17 @@ def configure_dynamics(engine, handler):
     dyn = handler._dynamics_function
     if getattr(dyn, "_bbmpc_dynamics_kind", None) == L.DYN_MLP:
         engine.set_mlp(dyn.weights, dyn.biases, dyn.activation_codes, handler.normalization_stats())
+    elif engine.cfg.dynamics == L.DYN_USER and getattr(engine, "_dyn_source", None) is not dyn.hip_source:
+        engine.set_dynamics_source(dyn.hip_source)
+        engine._dyn_source = dyn.hip_source
     engine._dyn_version = (getattr(dyn, "_version", 0), handler._version)
+
+
+def configure_reward(engine, reward_function):
+    """Compile + attach the user's reward device function, once per engine."""
+    if engine.cfg.reward == L.REW_USER and getattr(engine, "_rew_source", None) is not reward_function.hip_source:
+        engine.set_reward_source(reward_function.hip_source)
+        engine._rew_source = reward_function.hip_source
 
 
 def dynamics_stale(engine, handler):
@@ -53,6 +71,7 @@ class DeterministicTrajectoryEvaluator(EvaluatorBase):
             space = h._env_action_space
             eng = Engine(L.OPT_NONE, dk, rk, space.low, space.high, dim_s=h._dim_S, num_agents=key[0],
                          planning_horizon=key[1], quirks=self._quirks)
+            configure_reward(eng, self._reward_function)
             self._engines[key] = eng
         if dynamics_stale(eng, h):
             configure_dynamics(eng, h)

@@ -54,10 +54,12 @@ extern "C" {
 /* dynamics plugin: utils/pendulum.py:38-92 | dynamics_functions/deterministic_mlp.py:5-51 */
 #define BBMPC_DYN_PENDULUM 1
 #define BBMPC_DYN_MLP      2
+#define BBMPC_DYN_USER     3   /* device function given as HIP source: bbmpc_set_dynamics_source */
 
 /* reward plugin: utils/pendulum.py:10-35 | tutorials/mujoco/cost_func.py:5-22 */
 #define BBMPC_REW_PENDULUM 1
 #define BBMPC_REW_CHEETAH  2
+#define BBMPC_REW_USER     3   /* device function given as HIP source: bbmpc_set_reward_source */
 
 /* Dense activations (tutorials use tf.math.tanh and None) */
 #define BBMPC_ACT_NONE    0
@@ -154,6 +156,34 @@ int bbmpc_set_stream_default(bbmpc_handle h);   /* the legacy default (NULL) str
 int bbmpc_set_mlp(bbmpc_handle h, int32_t n_layers, const int32_t* dims, const int32_t* activations,
                   const float* const* weights, const float* const* biases,
                   int32_t is_normalized, const float* const* stats);
+
+/* User-supplied plug-ins.  The reference takes ANY callable as reward_function / dynamics_function
+ * (trajectory_evaluators/deterministic.py:13-18; called at :65-66 as reward(current_state, actions, next_state) and at
+ * :99-100 as dynamics(x[B,S+U], train=False) -> delta[B,S]).  A Python callable cannot run inside a kernel; the
+ * counterpart is HIP source, compiled at run time (hiprtc, gfx950), that defines per row
+ *     __device__ float bbmpc_user_reward(const float* cur, const float* act, const float* nxt, int S, int U);
+ *     __device__ void  bbmpc_user_dynamics(const float* x, float* delta, int S, int U);     (x = [state | action])
+ * for a handle created with BBMPC_REW_USER / BBMPC_DYN_USER (user dynamics are a true model: next = state + delta,
+ * utils/transforms.py:34).  Any combination with the built-in plug-ins works; evaluation then runs step by step
+ * (one batched dynamics and one batched reward launch per planning step, as the reference's own graph does) instead
+ * of through the fused whole-horizon kernels.  Compile errors come back as BBMPC_E_INVALID with the compiler log in
+ * bbmpc_last_error().  bbmpc_check_user_source only compiles (needs no GPU): kind 1 = reward, 2 = dynamics. */
+int bbmpc_set_reward_source(bbmpc_handle h, const char* hip_source);
+int bbmpc_set_dynamics_source(bbmpc_handle h, const char* hip_source);
+int bbmpc_check_user_source(int32_t kind, const char* hip_source, int32_t dim_s, int32_t dim_u);
+/* DeterministicMLP.__call__(x[B, S+U], train) -> [B, S]: the raw Dense stack on already-processed inputs
+ * (dynamics_functions/deterministic_mlp.py:27-51), no normalisation, no residual. */
+int bbmpc_mlp_forward(bbmpc_handle h, const float* x, int32_t batch, float* out);
+
+/* SystemDynamicsHandler.process_input(states[B,S], actions[B,U]) -> [B,S+U] and .process_output(states[B,S],
+ * raw_output[B,S]) -> next_states[B,S] as stand-alone calls (dynamics_handlers/system_dynamics_handler.py:97-161 +
+ * utils/transforms.py:20-34).  stats = the six statistics vectors in bbmpc_set_mlp's order for a normalised learned
+ * model, NULL for a true model / un-normalised handler (plain concat; next = raw + state).  Inside rollouts the same
+ * arithmetic is fused into the kernels (prologue / epilogue). */
+int bbmpc_process_input(bbmpc_handle h, const float* states, const float* actions, int32_t batch,
+                        const float* const* stats, float* out);
+int bbmpc_process_output(bbmpc_handle h, const float* states, const float* raw_output, int32_t batch,
+                         const float* const* stats, float* out);
 
 /* Optimizer.reset()  (cem.py:138-149, pi2.py:98-105, pso.py:143-160, cma_es.py:215-227, spsa.py:119-127) */
 int bbmpc_reset(bbmpc_handle h);

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "bbmpc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)           # comments mention names that are not entry points
     return sorted(set(re.findall(r"\b(bbmpc_[a-z_0-9]+)\s*\(", text)))
 
 
