@@ -8,7 +8,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbbmpc.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enums (bbmpc.h)
 OPT_NONE, OPT_RANDOM_SEARCH, OPT_CEM, OPT_PI2, OPT_PSO, OPT_CMAES, OPT_SPSA = range(7)
@@ -47,6 +47,7 @@ class Config(ctypes.Structure):
         ("spsa_c", ctypes.c_float),
         ("cma_alpha_cov", ctypes.c_float), ("cma_h_sigma", ctypes.c_float),
         ("action_low", c_float_p), ("action_high", c_float_p),
+        ("population_offset", ctypes.c_int32), ("population_global", ctypes.c_int32),
     ]
 
 

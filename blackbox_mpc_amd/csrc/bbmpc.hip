@@ -114,6 +114,13 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         REQUIRE(k <= 1024, BBMPC_E_UNSUPPORTED, "num_elite > 1024 not supported");
     }
 
+    if (c.population_global != 0 || c.population_offset != 0) {
+        REQUIRE(c.population_global >= N && c.population_offset >= 0 && c.population_offset + N <= c.population_global, BBMPC_E_INVALID,
+                "population_offset / population_global: this handle's particles must lie inside the global population");
+        if (c.population_global > N)
+            REQUIRE(c.optimizer == BBMPC_OPT_PI2, BBMPC_E_UNSUPPORTED,
+                    "population sharding is built for PI2 (min / sum reductions, pi2.py:80-87); CEM needs a top-k merge");
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         throw HipError(BBMPC_E_NO_DEVICE, "no HIP device available: this library has no CPU fallback");
@@ -142,6 +149,10 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.host_poll = !flag("BBMPC_NO_HOST_POLL");
         sw.mlp_no_half_tail = flag("BBMPC_MLP_NO_HALF_TAIL");
         sw.dbg = flag("BBMPC_DBG");
+        if (c.optimizer == BBMPC_OPT_PI2) {
+            ps_loopback = ival("BBMPC_POPSHARD_LOOPBACK", 0);
+            ps_force = flag("BBMPC_POPSHARD_FORCE");
+        }
     }
     HU = H * U;
     Nst = ((std::max(N, 1) + 63) / 64) * 64;
@@ -669,7 +680,11 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     // small to give every CU a 16-particle tile
     {
         const bool q4_ok = pair_ok && mlp.dims[0] <= 28 && mlp.dims[1] == 200 && mlp.dims[2] == 200 && mlp.dims[3] <= 64;
-        int q4 = (q4_ok && tiles_total <= 256) ? 1 : 0;
+        // measured on MI355X (tools/q4_sweep.py, PI2, H = 30, us per control step): a "wave" of 256 quad workgroups (one
+        // per CU, 1024 particles) costs ~400 us, the 16-particle tiling ~850 us for anything up to 4096 particles:
+        // quads win up to two waves (N*A <= 2048: 810 vs 860), lose from the third on (2500: 1177 vs 868)
+        const long quads_total = (long)((ra.n_pop + 3) / 4) * A;
+        int q4 = (q4_ok && quads_total <= 512) ? 1 : 0;
         if (sw.mlp_q4 >= 0) q4 = (sw.mlp_q4 != 0 && q4_ok) ? 1 : 0;
         if (q4 && !sw.mlp_generic) {
             const size_t qlds = (size_t)mlp_q4_lds_floats(50, 7, 4, ra.H, U, S) * sizeof(float);
@@ -971,6 +986,7 @@ RowMlp Engine::row_mlp() const {
 
 bool Engine::use_fused() const {
     if (cfg.dynamics != BBMPC_DYN_PENDULUM || cfg.reward != BBMPC_REW_PENDULUM) return false;
+    if (pop_sharded()) return false;            // the refit is split around a collective: per-iteration kernels
     if (cfg.optimizer == BBMPC_OPT_SPSA) {
         if (iters > FUSED_MAX_SPSA_ITERS) return false;
     } else if (cfg.optimizer != BBMPC_OPT_RANDOM_SEARCH && cfg.optimizer != BBMPC_OPT_CEM && cfg.optimizer != BBMPC_OPT_PI2) {
@@ -1212,6 +1228,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
     ra.rewards = d_rewards.p;
     ra.penalty_out = d_penalty.p;
     ra.key = key(step);
+    ra.pop_offset = cfg.population_offset;
 
     RefitArgs rf;
     memset(&rf, 0, sizeof(rf));
@@ -1279,6 +1296,39 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
             for (int it = 0; it < iters; ++it) {
                 ra.stream = BBMPC_NOISE_TRUNC_NORMAL; ra.iter = (uint32_t)it;
                 ra.inj = inj_t ? inj_t + inj_stride * it : nullptr;
+                if (pop_sharded()) {
+                    // population sharded over ranks: partial sums here, one exchange, merge in rank order
+                    const int G = ps_loopback > 1 ? ps_loopback : std::max(1, rc.comm ? rc.nranks : 1);
+                    const size_t pw = (size_t)A * (HU + 2);
+                    if (!ps_part.p) { ps_part.alloc(pw); }
+                    if (ps_all.n < pw * G) ps_all.alloc(pw * G);
+                    dim3 pgrid((HU + PI2_ROWS - 1) / PI2_ROWS, A), pblock(64 * PI2_ROWS);
+                    if (ps_loopback > 1) {
+                        // one handle plays every shard in turn (test / measurement hook): shard r = particles [r*N, (r+1)*N)
+                        for (int r = 0; r < G; ++r) {
+                            ra.pop_offset = r * N;
+                            launch_rollout(SRC_TRUNC, true, ra);
+                            hipLaunchKernelGGL(k_refit_pi2_partial, pgrid, pblock, lds, stream, rf, ps_all.p + pw * r);
+                        }
+                        ra.pop_offset = cfg.population_offset;
+                    } else {
+                        launch_rollout(SRC_TRUNC, true, ra);
+                        hipLaunchKernelGGL(k_refit_pi2_partial, pgrid, pblock, lds, stream, rf, ps_part.p);
+                        if (rc.comm) {
+                            // the exchange sits ON the launch stream: the merge needs it, nothing can overlap it
+                            const Rccl& r = Rccl::get();
+                            r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (PI2 partials)");
+                        } else {
+                            REQUIRE(cfg.population_global <= N, BBMPC_E_STATE, "population sharding needs a communicator: call bbmpc_comm_init first");
+                            HIP_CHECK(hipMemcpyAsync(ps_all.p, ps_part.p, pw * 4, hipMemcpyDeviceToDevice, stream));
+                        }
+                    }
+                    HIP_CHECK(hipGetLastError());
+                    hipLaunchKernelGGL(k_refit_pi2_merge, dim3((HU + 255) / 256, A), dim3(256), 0, stream, rf, ps_all.p, G);
+                    HIP_CHECK(hipGetLastError());
+                    capture_trace(it);
+                    continue;
+                }
                 launch_rollout(SRC_TRUNC, true, ra);
                 if (sw.refit_v1) hipLaunchKernelGGL(k_refit_pi2, dim3(A), dim3(REFIT_THREADS), lds, stream, rf);
                 else hipLaunchKernelGGL(k_refit_pi2_mw, dim3((HU + PI2_ROWS - 1) / PI2_ROWS, A), dim3(64 * PI2_ROWS), lds, stream, rf);

@@ -183,6 +183,11 @@ struct Engine {
     void dynamics_rows(const float* d_states, const float* d_actions, int astride, int batch, float* d_next);
     void reward_rows(const float* d_cur, const float* d_next, const float* d_actions, int astride, int batch, float* d_total, int accumulate);
     void mlp_forward_rows(const float* d_x, int batch, float* d_out);
+    // population sharding (PI2): per-iteration partials of this rank and the gathered partials of all ranks
+    DevBuf<float> ps_part, ps_all;
+    int ps_loopback = 0;     // BBMPC_POPSHARD_LOOPBACK=G: one handle plays all G shards in turn (single-GPU test / measurement hook)
+    bool ps_force = false;   // BBMPC_POPSHARD_FORCE: take the sharded code path (incl. the collective) even with one shard
+    bool pop_sharded() const { return cfg.population_global > N || ps_loopback > 1 || ps_force; }
     int pending_warm = 0;    // learned-dynamics path: warm start the tail kernel performs (kernels_tail.hpp TailArgs::warm_mode)
     RowMlp row_mlp() const;
     const float* injected(int kind) const {

@@ -204,7 +204,7 @@ __device__ __forceinline__ void mlp_fill_actions(const MlpRolloutArgs& q, int a,
                 float xi;
                 if (p.inj) xi = p.inj[((size_t)a * p.HU + j) * p.Nst + n];
                 else {
-                    const U4 blk = rng_block(p.key, p.stream, p.iter, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)j);
+                    const U4 blk = rng_block(p.key, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j);
                     const uint32_t w = pick_word(blk, (uint32_t)j);
                     xi = (q.mode == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
                 }

@@ -44,6 +44,7 @@ struct RolloutArgs {
     RngKey key;
     uint32_t stream;
     uint32_t iter;
+    int pop_offset;       // global index of local particle 0 (population sharding): the RNG is keyed by the GLOBAL particle
 };
 
 // Candidate element j of particle n, agent a.  `blk` caches the Philox block across calls.
@@ -59,7 +60,7 @@ __device__ __forceinline__ float candidate(const RolloutArgs& p, int n, int a, i
         if (p.inj) {
             xi = p.inj[(size_t)aj * p.Nst + n];
         } else {
-            if ((j & 3) == 0 || j == 0) blk = rng_block(p.key, p.stream, p.iter, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)j);
+            if ((j & 3) == 0 || j == 0) blk = rng_block(p.key, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j);
             const uint32_t w = pick_word(blk, (uint32_t)j);
             xi = (MODE == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
         }

@@ -224,4 +224,83 @@ __global__ __launch_bounds__(64 * PI2_ROWS) void k_refit_pi2_mw(RefitArgs p) {
     }
 }
 
+// ---- PI2 refit with the population sharded over ranks --------------------------------------------
+// Each rank holds N_local particles of the SAME agents.  pi2.py:80-87 split:
+//   partial (this rank) : beta_r = min cost, p_n = exp(-(cost_n - beta_r)/lamda), eta_r = sum p_n, S_r[j] = sum p_n x[j][n]
+//   exchange            : all ranks see every rank's (beta_r, eta_r, S_r[HU]) per agent  (one collective per iteration)
+//   merge (every rank)  : beta = min_r beta_r, s_r = exp(-(beta_r - beta)/lamda), eta = sum_r s_r eta_r,
+//                         mean[j] = (sum_r s_r S_r[j]) / eta        -- in rank order, so all ranks get the same bits
+// The only difference to the un-sharded refit is the order of the fp32 sums (tolerance stated in the tests: 2e-5).
+// part layout per agent: [0] beta_r, [1] eta_r, [2 .. 2+HU) S_r.
+// k_refit_pi2_partial: grid (ceil(HU / PI2_ROWS), A), block 64 * PI2_ROWS, LDS pr[Nst] | red[PI2_ROWS]
+__global__ __launch_bounds__(64 * PI2_ROWS) void k_refit_pi2_partial(RefitArgs p, float* part) {
+    extern __shared__ float smem[];
+    float* pr = smem;
+    float* red = smem + p.Nst;
+    const int a = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = PI2_ROWS, NT = 64 * PI2_ROWS;
+    float* out = part + (size_t)a * (p.HU + 2);
+    float lmin = INFINITY;
+    for (int n = tid; n < p.N; n += NT) {
+        const float c = -p.rewards[(size_t)a * p.Nst + n];
+        pr[n] = c;
+        lmin = fminf(lmin, c);
+    }
+    lmin = wave_min(lmin);
+    if (lane == 0) red[wv] = lmin;
+    __syncthreads();
+    float beta = red[lane < NW ? lane : 0];
+    beta = wave_min(beta);
+    __syncthreads();
+    float lsum = 0.0f;
+    for (int n = tid; n < p.N; n += NT) {
+        const float w = expf((-p.inv_lamda) * (pr[n] - beta));
+        pr[n] = w;
+        lsum += w;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[wv] = lsum;
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) {
+        float eta = 0.0f;
+        for (int w = 0; w < NW; ++w) eta += red[w];
+        out[0] = beta;
+        out[1] = eta;
+    }
+    const int j = blockIdx.x * PI2_ROWS + wv;
+    if (j >= p.HU) return;
+    const float* __restrict__ row = p.samples + (size_t)(a * p.HU + j) * p.Nst;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int n = lane;
+    for (; n + 192 < p.N; n += 256) {
+        const float x0 = row[n], x1 = row[n + 64], x2 = row[n + 128], x3 = row[n + 192];
+        acc[0] = fmaf(x0, pr[n], acc[0]);
+        acc[1] = fmaf(x1, pr[n + 64], acc[1]);
+        acc[2] = fmaf(x2, pr[n + 128], acc[2]);
+        acc[3] = fmaf(x3, pr[n + 192], acc[3]);
+    }
+    for (; n < p.N; n += 64) acc[0] = fmaf(row[n], pr[n], acc[0]);
+    const float s = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    if (lane == 0) out[2 + j] = s;
+}
+
+// gathered: [G][A][HU+2].  grid (ceil(HU/256), A), block 256
+__global__ void k_refit_pi2_merge(RefitArgs p, const float* gathered, int G) {
+    const int a = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= p.HU) return;
+    const size_t stride = (size_t)p.A * (p.HU + 2);
+    float beta = INFINITY;
+    for (int r = 0; r < G; ++r) beta = fminf(beta, gathered[r * stride + (size_t)a * (p.HU + 2)]);
+    float eta = 0.0f, acc = 0.0f;
+    for (int r = 0; r < G; ++r) {
+        const float* g = gathered + r * stride + (size_t)a * (p.HU + 2);
+        const float sc = expf((-p.inv_lamda) * (g[0] - beta));
+        eta = fmaf(sc, g[1], eta);
+        acc = fmaf(sc, g[2 + j], acc);
+    }
+    const float m = acc * (1.0f / eta);
+    p.mean[a * p.HU + j] = m;
+    if (j < p.U) p.action[a * p.U + j] = m;
+}
+
 }  // namespace bbmpc

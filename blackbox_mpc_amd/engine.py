@@ -13,7 +13,7 @@ class Engine:
                  agent_offset=0, num_agents_global=None, device=-1, alpha=0.25, lamda=1.0,
                  pso_c1=0.3, pso_c2=0.5, pso_w=0.2, pso_v0_fraction=0.01,
                  spsa_alpha=0.602, spsa_gamma=0.101, spsa_a=0.01, spsa_c=0.3,
-                 cma_alpha_cov=2.0, cma_h_sigma=1.0):
+                 cma_alpha_cov=2.0, cma_h_sigma=1.0, population_offset=0, population_global=0):
         self._h = ctypes.c_void_p()
         self._lo = L.f32c(np.asarray(action_low).reshape(-1))
         self._hi = L.f32c(np.asarray(action_high).reshape(-1))
@@ -35,6 +35,7 @@ class Engine:
         c.pso_c1, c.pso_c2, c.pso_w, c.pso_v0_fraction = float(pso_c1), float(pso_c2), float(pso_w), float(pso_v0_fraction)
         c.spsa_alpha, c.spsa_gamma, c.spsa_a, c.spsa_c = float(spsa_alpha), float(spsa_gamma), float(spsa_a), float(spsa_c)
         c.cma_alpha_cov, c.cma_h_sigma = float(cma_alpha_cov), float(cma_h_sigma)
+        c.population_offset, c.population_global = int(population_offset), int(population_global or 0)
         c.action_low = self._lo.ctypes.data_as(L.c_float_p)
         c.action_high = self._hi.ctypes.data_as(L.c_float_p)
         self.cfg = c

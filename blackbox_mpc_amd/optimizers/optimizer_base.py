@@ -13,7 +13,8 @@ class OptimizerBase:
     _engine_optimizer = L.OPT_NONE
 
     def __init__(self, name, planning_horizon, max_iterations, num_agents, env_action_space,
-                 env_observation_space, seed=0, quirks=0, agent_offset=0, num_agents_global=None, device=-1):
+                 env_observation_space, seed=0, quirks=0, agent_offset=0, num_agents_global=None, device=-1,
+                 population_offset=0, population_global=0):
         self.name = name
         self._planning_horizon = int(planning_horizon)
         self._env_action_space = env_action_space
@@ -29,6 +30,7 @@ class OptimizerBase:
         self._exploration_mean = (self._action_upper_bound + self._action_lower_bound) / 2
         self._seed, self._quirks = int(seed), int(quirks)
         self._agent_offset, self._num_agents_global, self._device = int(agent_offset), num_agents_global, int(device)
+        self._population_offset, self._population_global = int(population_offset), int(population_global or 0)
         self._engine = None
 
     # hyper-parameters forwarded to bbmpc_config; overridden by subclasses
@@ -76,7 +78,8 @@ class OptimizerBase:
                               dim_s=self._dim_S, num_agents=self._num_agents, planning_horizon=self._planning_horizon,
                               max_iterations=self._max_iterations or 0, seed=self._seed, quirks=quirks,
                               agent_offset=self._agent_offset, num_agents_global=self._num_agents_global,
-                              device=self._device, **self._engine_kwargs())
+                              device=self._device, population_offset=self._population_offset,
+                              population_global=self._population_global, **self._engine_kwargs())
         configure_dynamics(self._engine, h)
         configure_reward(self._engine, trajectory_evaluator._reward_function)
         return

@@ -19,6 +19,16 @@ def agent_shard(num_agents_global, world_size, rank):
     return offset, count
 
 
+def population_shard(population_global, world_size, rank):
+    """Population sharding for num_agents < n_gpus: the contiguous block of particles
+    (offset, count) rank `rank` rolls out.  Every shard must have the same size (the engine all-gathers fixed-size
+    partials and keys its RNG by global particle index), so the population must divide evenly."""
+    if population_global % world_size:
+        raise ValueError("population_size %d does not divide over %d ranks" % (population_global, world_size))
+    count = population_global // world_size
+    return rank * count, count
+
+
 def gather_records(local_record, num_agents_global, group=None):
     """All-gather the per-agent records of every rank into global agent order.
 
