@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbbmpc.so")
+LIB_PATH = os.environ.get("BBMPC_LIB") or os.path.join(HERE, "libbbmpc.so")   # BBMPC_LIB: a debug build (tools/)
 
 ABI_VERSION = 2
 

@@ -139,6 +139,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         auto ival = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
         sw.cma_svd_v1 = flag("BBMPC_CMA_SVD_V1"); sw.cma_svd_rounds = flag("BBMPC_CMA_SVD_ROUNDS");
         sw.cma_svd_general = flag("BBMPC_CMA_SVD_GENERAL");
+        sw.cma_svd_gram = flag("BBMPC_CMA_SVD_GRAM");
         sw.mlp_generic = flag("BBMPC_MLP_GENERIC");
         { const int b = ival("BBMPC_MLP_BF16", 0); sw.mlp_bf16 = (b == 1 || b == 3) ? b : 0; }
         sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1);
@@ -365,7 +366,16 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             hipLaunchKernelGGL(k_cma_warm, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(256), 0, stream, q, c_evec.p);
             const int bsz = (n + 7) / 8;
             const size_t blds = (size_t)2 * bsz * n * sizeof(float);
-            if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 159 * 1024 && G * 4 <= 256 && !sw.cma_svd_rounds) {
+            if (n >= 128 && (n & 3) == 0 && bsz <= 64 && cma_gram_lds_bytes(n) <= 159 * 1024 && cma_gram_wp(n) <= 128 && G * 4 <= 256 &&
+                !sw.cma_svd_rounds && sw.cma_svd_gram) {
+                // block Jacobi in the Gram domain: Gram matrix / column update on the matrix cores, rotations on 2bs x 2bs data
+                ensure_max_lds((const void*)k_cma_svd_gram, 159 * 1024);     // + a few static words
+                float* evp = c_evec.p;
+                unsigned* syp = c_sync.p;
+                int sweeps = 15;
+                void* kargs[] = {(void*)&q, (void*)&evp, (void*)&syp, (void*)&sweeps};
+                HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_cma_svd_gram, dim3(4, G), dim3(1024), kargs, cma_gram_lds_bytes(n), stream));
+            } else if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 159 * 1024 && G * 4 <= 256 && !sw.cma_svd_rounds) {
                 // block Jacobi: 4 workgroups per instance, block pairs resident in LDS, 7 instance barriers per sweep
                 ensure_max_lds((const void*)k_cma_svd_block, 159 * 1024);     // + a few static words
                 // cooperative launch: the instance barrier spins, so every workgroup of the grid must be resident at

@@ -520,6 +520,28 @@ __global__ __launch_bounds__(1024) void k_cma_svd_finish(CmaArgs p, const float*
     for (int c = tid; c < n; c += nthr) p.Dd[(size_t)g * n + c] = sqrtf(s_norm[s_perm[c]]);   // D = diag(sqrt(s))
 }
 
+// 16-byte write-through (sc0 sc1) accesses for blocks that travel between workgroups: the 4-byte scalar form costs ~6x
+// per byte on the fabric (MI355X_MICROARCH.md, inter-workgroup visibility) -- the load phase was a quarter of the block
+// kernel's run time with it.
+typedef float cma_f32x4 __attribute__((ext_vector_type(4)));
+// four 16-byte loads and the wait for them in ONE asm statement: the compiler cannot see that an asm load's result
+// register is still in flight, so nothing (a copy, a select) may sit between the loads and the s_waitcnt
+__device__ __forceinline__ void coh_load16x4(const float* p0, const float* p1, const float* p2, const float* p3, cma_f32x4& v0,
+                                             cma_f32x4& v1, cma_f32x4& v2, cma_f32x4& v3) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+        "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+        "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+        "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+        : "memory");
+}
+__device__ __forceinline__ void coh_store16(float* p, cma_f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+
 // ---- Block Jacobi: the columns are cut into 8 blocks; 4 workgroups per instance each hold one PAIR of blocks in
 // LDS and orthogonalise every column pair inside it without touching global memory; the block pairs follow a
 // round-robin tournament (7 block rounds per sweep), so an instance needs 7 instance-wide barriers per sweep instead
@@ -606,25 +628,25 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             if (!(skip_cross && skip_ix && skip_iy)) {
             // ---- load the two blocks (columns are rows of At: contiguous)
             // whole columns per wave (no index divisions), all of a wave's loads issued before the first LDS write
-            for (int c0 = wv; c0 < nx + ny; c0 += 4 * NW) {
-                float v[4][8];
+            {
+                const int n4 = n >> 2;                                   // n % 4 == 0 on this path
+                for (int c0 = wv; c0 < nx + ny; c0 += 4 * NW) {
+                    const float* src[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = c0 + q * NW;
-                    const float* src = At + (size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int e = lane + 64 * k;
-                        v[q][k] = (c < nx + ny && e < n) ? coh_load(src + e) : 0.0f;
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = min(c0 + q * NW, nx + ny - 1);         // clamped: a duplicate load instead of a branch
+                        src[q] = At + (size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n;
                     }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = c0 + q * NW;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int e = lane + 64 * k;
-                        if (c < nx + ny && e < n) cols[(size_t)c * n + e] = v[q][k];
+                    for (int h0 = 0; h0 < n4; h0 += 64) {
+                        const int e4 = min(h0 + lane, n4 - 1);
+                        cma_f32x4 v0, v1, v2, v3;
+                        coh_load16x4(src[0] + 4 * e4, src[1] + 4 * e4, src[2] + 4 * e4, src[3] + 4 * e4, v0, v1, v2, v3);
+                        if (h0 + lane < n4) {
+                            if (c0 < nx + ny) *reinterpret_cast<cma_f32x4*>(cols + (size_t)c0 * n + 4 * e4) = v0;
+                            if (c0 + NW < nx + ny) *reinterpret_cast<cma_f32x4*>(cols + (size_t)(c0 + NW) * n + 4 * e4) = v1;
+                            if (c0 + 2 * NW < nx + ny) *reinterpret_cast<cma_f32x4*>(cols + (size_t)(c0 + 2 * NW) * n + 4 * e4) = v2;
+                            if (c0 + 3 * NW < nx + ny) *reinterpret_cast<cma_f32x4*>(cols + (size_t)(c0 + 3 * NW) * n + 4 * e4) = v3;
+                        }
                     }
                 }
             }
@@ -733,7 +755,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                 for (int c = wv; c < nx + ny; c += NW) {
                     if (c < nx ? !(rc || rix) : !(rc || riy)) continue;
                     float* dst = At + (size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n;
-                    for (int e = lane; e < n; e += 64) coh_store(dst + e, cols[(size_t)c * n + e]);
+                    for (int q4 = lane; q4 < (n >> 2); q4 += 64) coh_store16(dst + 4 * q4, *reinterpret_cast<const cma_f32x4*>(cols + (size_t)c * n + 4 * q4));
                 }
             }
             if (tid == 0) {
@@ -757,6 +779,252 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
 #ifdef BBMPC_KERNEL_DBG
         if (g == 0 && blockIdx.x == 0 && tid == 0) printf("[svdb] sweep %d: load %lld intra %lld cross %lld store %lld barrier %lld (10ns, cumulative)\n", sweep, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
 #endif
+    }
+}
+
+// ---- Block Jacobi in the Gram domain (replaces the loop above as the default for n = H*U = 300) ---------------------
+// Same decomposition as k_cma_svd_block -- 8 column blocks, 4 workgroups per instance each holding a PAIR of blocks in
+// LDS, round-robin tournament of block pairs, the same rotation / threshold / clean-pair bookkeeping -- but the work
+// on a block pair no longer walks 300-long columns once per rotation:
+//   1. G = [X Y]^T [X Y]  (2bs x 2bs Gram matrix of the 2bs resident columns) on the matrix cores, once per visit
+//   2. the cyclic sweep (intra-block pairs in block round 0, then the bs cross rounds) runs on G alone: a pair's
+//      (|x|^2, |y|^2, x.y) are three entries of G, a rotation is a two-sided 2x2 update of G's rows and columns, and the
+//      rotations are accumulated in V (2bs x 2bs).  A round is ~12 k element updates spread over 1024 threads and two
+//      barriers, with no cross-lane reductions -- against 38 column pairs x 300 elements x (3 dot products + rotation)
+//   3. [X Y] <- [X Y] V  on the matrix cores, once per visit
+// The rotations are the same function of the same three numbers as in the one-sided form, so convergence, threshold
+// and the final invariants are unchanged; G is rebuilt from the columns at every visit, so its rounding drift never
+// outlives 75 rounds.  Blocks travel between workgroups as 16-byte write-through (sc0 sc1) stores and loads: the
+// 4-byte scalar form the kernel above uses costs ~6x per byte (a quarter of its run time was the load phase).
+// LDS: cols [Wp][n] | G [Wp][Wp+1] | V [Wp][Wp+1] | pair tables, Wp = 2*bs + 2 rounded up to 16 (two zero columns for
+// the sit-out players of odd blocks).
+inline int cma_gram_wp(int n) { const int bs = (n + 7) / 8; return ((2 * bs + 2 + 15) / 16) * 16; }
+inline size_t cma_gram_lds_bytes(int n) {
+    const int Wp = cma_gram_wp(n);
+    return ((size_t)Wp * n + 2 * (size_t)Wp * (Wp + 1) + 4 * 64 + 16) * sizeof(float);
+}
+
+__global__ __launch_bounds__(1024) void k_cma_svd_gram(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    constexpr int NB = 8;
+    const int g = blockIdx.y, wg = blockIdx.x, WPG = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
+    const int NW = blockDim.x >> 6, nthr = blockDim.x;
+    const int bs = (n + NB - 1) / NB, W = 2 * bs;
+    const int Wp = ((W + 2 + 15) / 16) * 16, WT = Wp / 16, Gs = Wp + 1, n4 = n >> 2;
+    float* cols = gsm;                                   // [Wp][n]  column c of the pair = cols + c*n
+    float* Gm = cols + (size_t)Wp * n;                   // [Wp][Gs]
+    float* Vm = Gm + (size_t)Wp * Gs;                    // [Wp][Gs]
+    int* tp = (int*)(Vm + (size_t)Wp * Gs);              // [64] first column of pair slot i
+    int* tq = tp + 64;                                   // [64] second column
+    float* tc = (float*)(tq + 64);                       // [64] cosine   (1 when the pair does not rotate)
+    float* tsn = tc + 64;                                // [64] sine     (0 when the pair does not rotate)
+    float* At = At_all + (size_t)g * n * n;
+    unsigned* sync = sync_all + (size_t)g * CMA_SYNC_WORDS;
+    unsigned* ver = sync + 32;
+    unsigned* iseen = sync + 40;
+    unsigned* pseen = sync + 48;
+    __shared__ int s_skip[3], s_rotf[3];
+    const float tol = fminf(fmaxf(3.0e-8f * (float)n, 2.0e-6f), 1.0e-5f);
+    const float tol2 = tol * tol;
+    unsigned bar = 0;
+    const int mi = (bs + 1) & ~1;                        // players of the intra-block tournament (a dummy when bs is odd)
+    const int P = max(bs, mi);                           // pair slots per round: bs cross pairs | 2 * mi/2 intra pairs
+    // the padding columns never change
+    for (int i = tid; i < (Wp - W) * n; i += nthr) cols[(size_t)W * n + i] = 0.0f;
+
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        bool rotated = false;
+        for (int R = 0; R < NB - 1; ++R) {
+            int bx, by;
+            if (wg == 0) { bx = NB - 1; by = R; }
+            else { bx = (R + wg) % (NB - 1); by = (R - wg + (NB - 1)) % (NB - 1); }
+            const int x0 = bx * bs, y0 = by * bs;
+            const int nx = max(0, min(bs, n - x0)), ny = max(0, min(bs, n - y0));
+            const int blo = min(bx, by), bhi = max(bx, by);
+            unsigned vx = 0, vy = 0;
+            if (tid == 0) {
+                vx = __hip_atomic_load(ver + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                vy = __hip_atomic_load(ver + by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                const unsigned packed = ((bx < by ? vx : vy) << 16) | (bx < by ? vy : vx);
+                s_skip[0] = __hip_atomic_load(pseen + blo * 8 + bhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == packed;
+                s_skip[1] = R != 0 || __hip_atomic_load(iseen + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == vx;
+                s_skip[2] = R != 0 || __hip_atomic_load(iseen + by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == vy;
+                s_rotf[0] = s_rotf[1] = s_rotf[2] = 0;
+            }
+            __syncthreads();
+            const bool skip_cross = s_skip[0] != 0, skip_ix = s_skip[1] != 0, skip_iy = s_skip[2] != 0;
+            if (!(skip_cross && skip_ix && skip_iy)) {
+                // ---- load the two blocks: one column per wave at a time, a lane's 16-byte loads all in flight
+                for (int c = wv; c < W; c += NW) {
+                    const bool isx = c < bs;
+                    const int ci = isx ? c : c - bs;
+                    const bool present = isx ? ci < nx : ci < ny;
+                    float* dst = cols + (size_t)c * n;
+                    if (present) {
+                        const float* src = At + (size_t)((isx ? x0 : y0) + ci) * n;
+                        cma_f32x4 v0, v1, v2, v3;                               // addresses clamped: every lane loads something valid
+                        coh_load16x4(src + 4 * min(lane, n4 - 1), src + 4 * min(lane + 64, n4 - 1), src + 4 * min(lane + 128, n4 - 1),
+                                     src + 4 * min(lane + 192, n4 - 1), v0, v1, v2, v3);                       // n <= 1024
+                        if (lane < n4) *reinterpret_cast<cma_f32x4*>(dst + 4 * lane) = v0;
+                        if (lane + 64 < n4) *reinterpret_cast<cma_f32x4*>(dst + 4 * (lane + 64)) = v1;
+                        if (lane + 128 < n4) *reinterpret_cast<cma_f32x4*>(dst + 4 * (lane + 128)) = v2;
+                        if (lane + 192 < n4) *reinterpret_cast<cma_f32x4*>(dst + 4 * (lane + 192)) = v3;
+                    } else {
+                        for (int e = lane; e < n; e += 64) dst[e] = 0.0f;               // short last block: zero columns never rotate
+                    }
+                }
+                // V = I
+                for (int i = tid; i < Wp * Gs; i += nthr) Vm[i] = ((i / Gs) == (i % Gs)) ? 1.0f : 0.0f;
+                __syncthreads();
+                // ---- 1. Gram matrix on the matrix cores: upper tiles, mirrored.  A = 16 columns x 4 elements, B likewise
+                {
+                    const int ntile = WT * (WT + 1) / 2;
+                    for (int t = wv; t < ntile; t += NW) {
+                        int ti = 0, rem = t;
+                        while (rem >= WT - ti) { rem -= WT - ti; ++ti; }
+                        const int tj = ti + rem;
+                        const float* ap = cols + (size_t)(ti * 16 + (lane & 15)) * n + (lane >> 4);
+                        const float* bp = cols + (size_t)(tj * 16 + (lane & 15)) * n + (lane >> 4);
+                        cma_f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0;
+                        int k0 = 0;
+                        for (; k0 + 8 <= n; k0 += 8) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k0], bp[k0], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k0 + 4], bp[k0 + 4], acc1, 0, 0, 0);
+                        }
+                        for (; k0 < n; k0 += 4) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k0], bp[k0], acc0, 0, 0, 0);
+                        const int cj = tj * 16 + (lane & 15);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ci = ti * 16 + 4 * (lane >> 4) + r;
+                            const float v = acc0[r] + acc1[r];
+                            Gm[ci * Gs + cj] = v;
+                            Gm[cj * Gs + ci] = v;
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---- 2. the sweep over this block pair, on G.  Rounds: [intra-block tournament (block round 0)] + cross
+                const int n_intra = (R == 0 && !(skip_ix && skip_iy)) ? mi - 1 : 0;
+                const int n_cross = skip_cross ? 0 : bs;
+                bool rot_any = false;
+                for (int rr = 0; rr < n_intra + n_cross; ++rr) {
+                    const bool intra = rr < n_intra;
+                    const int np = intra ? mi : bs;                                    // pair slots in use this round
+                    if (tid < np) {
+                        int pa, pb, kind;
+                        if (intra) {
+                            const int half = mi / 2, blk = tid >= half ? 1 : 0, i = tid - blk * half, r = rr;
+                            int a, b;
+                            if (i == 0) { a = mi - 1; b = r; }
+                            else { a = (r + i) % (mi - 1); b = (r - i + (mi - 1)) % (mi - 1); }
+                            // player -> column: a real column of the block, or (odd bs) the block's zero column
+                            pa = a < bs ? blk * bs + a : W + blk;
+                            pb = b < bs ? blk * bs + b : W + blk;
+                            kind = 1 + blk;
+                            if (blk ? skip_iy : skip_ix) kind = -1;
+                        } else {
+                            const int r = rr - n_intra;
+                            pa = tid;
+                            pb = bs + (tid + r) % bs;
+                            kind = 0;
+                        }
+                        const float al = Gm[pa * Gs + pa], be = Gm[pb * Gs + pb], ga = Gm[pa * Gs + pb];
+                        float cs = 1.0f, sn = 0.0f;
+                        if (kind >= 0 && ga != 0.0f && ga * ga > tol2 * (al * be)) {
+                            const float zeta = (be - al) * __builtin_amdgcn_rcpf(2.0f * ga);
+                            const float t = copysignf(__builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.0f))), zeta);
+                            const float w = fmaf(t, t, 1.0f);
+                            cs = __builtin_amdgcn_rsqf(w);
+                            cs = cs * fmaf(-0.5f * w * cs, cs, 1.5f);                   // Newton step: cs^2 (1 + t^2) = 1 to fp32
+                            sn = cs * t;
+                            s_rotf[kind] = 1;
+                        }
+                        tp[tid] = pa; tq[tid] = pb; tc[tid] = cs; tsn[tid] = sn;
+                    }
+                    __syncthreads();
+                    // two-sided update of G: the np x np blocks of pair slots (a, b) partition the touched rows / columns
+                    for (int t = tid; t < np * np; t += nthr) {
+                        const int a = t / np, b = t - a * np;
+                        const float sa = tsn[a], sb = tsn[b];
+                        if (sa == 0.0f && sb == 0.0f) continue;
+                        const float ca = tc[a], cb = tc[b];
+                        const int pa = tp[a], qa = tq[a], pb = tp[b], qb = tq[b];
+                        const float m00 = Gm[pa * Gs + pb], m01 = Gm[pa * Gs + qb], m10 = Gm[qa * Gs + pb], m11 = Gm[qa * Gs + qb];
+                        const float r00 = fmaf(ca, m00, -(sa * m10)), r01 = fmaf(ca, m01, -(sa * m11));
+                        const float r10 = fmaf(sa, m00, ca * m10), r11 = fmaf(sa, m01, ca * m11);
+                        Gm[pa * Gs + pb] = fmaf(cb, r00, -(sb * r01));
+                        Gm[pa * Gs + qb] = fmaf(sb, r00, cb * r01);
+                        Gm[qa * Gs + pb] = fmaf(cb, r10, -(sb * r11));
+                        Gm[qa * Gs + qb] = fmaf(sb, r10, cb * r11);
+                    }
+                    // V <- V J
+                    for (int t = tid; t < Wp * np; t += nthr) {
+                        const int k = t / np, b = t - k * np;
+                        const float sb = tsn[b];
+                        if (sb == 0.0f) continue;
+                        const float cb = tc[b];
+                        const int pb = tp[b], qb = tq[b];
+                        const float v0 = Vm[k * Gs + pb], v1 = Vm[k * Gs + qb];
+                        Vm[k * Gs + pb] = fmaf(cb, v0, -(sb * v1));
+                        Vm[k * Gs + qb] = fmaf(sb, v0, cb * v1);
+                    }
+                    __syncthreads();
+                }
+                const bool rc = s_rotf[0] != 0, rix = s_rotf[1] != 0, riy = s_rotf[2] != 0;
+                rot_any = rc || rix || riy;
+                rotated |= rot_any;
+                // ---- 3. [X Y] <- [X Y] V on the matrix cores: a wave owns 16 rows (elements) of every column
+                if (rot_any) {
+                    const int ET = (n + 15) / 16;
+                    for (int et = wv; et < ET; et += NW) {
+                        cma_f32x4 acc[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) acc[c] = cma_f32x4{0, 0, 0, 0};
+                        const float* ap = cols + (size_t)(lane >> 4) * n + et * 16 + (lane & 15);
+                        const float* bp = Vm + (size_t)(lane >> 4) * Gs + (lane & 15);
+                        for (int k0 = 0; k0 < W; k0 += 4) {
+                            const float a = ap[(size_t)k0 * n];
+#pragma unroll
+                            for (int c = 0; c < 8; ++c)
+                                if (c < WT) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[(size_t)k0 * Gs + c * 16], acc[c], 0, 0, 0);
+                        }
+                        const int e = et * 16 + 4 * (lane >> 4);
+                        if (e < n) {
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                const int col = c * 16 + (lane & 15);
+                                if (c < WT && col < W) *reinterpret_cast<cma_f32x4*>(cols + (size_t)col * n + e) = acc[c];
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    // ---- write back what changed, 16-byte write-through stores
+                    for (int c = wv; c < W; c += NW) {
+                        const bool isx = c < bs;
+                        const int ci = isx ? c : c - bs;
+                        if (!(isx ? ci < nx : ci < ny)) continue;
+                        if (isx ? !(rc || rix) : !(rc || riy)) continue;
+                        float* dst = At + (size_t)((isx ? x0 : y0) + ci) * n;
+                        const float* src = cols + (size_t)c * n;
+                        for (int q = lane; q < n4; q += 64) coh_store16(dst + 4 * q, *reinterpret_cast<const cma_f32x4*>(src + 4 * q));
+                    }
+                }
+                if (tid == 0) {
+                    const unsigned nvx = vx + ((rc || rix) ? 1u : 0u), nvy = vy + ((rc || riy) ? 1u : 0u);
+                    if (rc || rix) __hip_atomic_store(ver + bx, nvx - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (rc || riy) __hip_atomic_store(ver + by, nvy - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!skip_ix && !rix && !rc) __hip_atomic_store(iseen + bx, nvx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!skip_iy && !riy && !rc) __hip_atomic_store(iseen + by, nvy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!skip_cross && !rc)
+                        __hip_atomic_store(pseen + blo * 8 + bhi, ((bx < by ? nvx : nvy) << 16) | (bx < by ? nvy : nvx), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (R == NB - 2 && rotated && lane == 0) __hip_atomic_store(sync + 1 + sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ++bar;
+            cma_instance_barrier_light(sync, bar * (unsigned)WPG);
+        }
+        if (__hip_atomic_load(sync + 1 + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
     }
 }
 

@@ -29,7 +29,10 @@ for cfg_dir in sorted(glob.glob(os.path.join(src, "cfg*"))):
         except Exception:
             pass
     st = glob.glob(os.path.join(cfg_dir, "*trace_kernel_stats.csv"))
+    avg_ns = {}
     if st:
+        for r in csv.DictReader(open(st[0])):
+            avg_ns[short(r["Name"])] = float(r["AverageNs"])
         lines += ["## kernel stats (rocprofv3 --kernel-trace --stats)", "", "| kernel | calls | total ns | avg ns | % |",
                   "|---|---|---|---|---|"]
         for r in csv.DictReader(open(st[0])):
@@ -63,6 +66,13 @@ for cfg_dir in sorted(glob.glob(os.path.join(src, "cfg*"))):
                 traffic.setdefault(cfg, {})[k] = hbm
             if "SQ_INSTS_VALU" in d:
                 sq.setdefault(cfg, {})[k] = {c: d[c] for c in d if c.startswith("SQ_")}
+            if d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and k in avg_ns:
+                # matrix-pipe utilisation: busy cycles summed over every SIMD of the part / (kernel duration x clock x
+                # 256 CUs x 4 SIMDs); 2.13 GHz is the clock measured under matrix load, 2.4 GHz the peak
+                dur = avg_ns[k] * 1e-9
+                for clk in (2.13e9, 2.4e9):
+                    lines.append("  * MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (%.2f us x %.2f GHz x 256 CUs x 4 SIMDs) = %.3f"
+                                 % (avg_ns[k] * 1e-3, clk * 1e-9, d["SQ_VALU_MFMA_BUSY_CYCLES"] / (dur * clk * 256 * 4)))
         lines.append("")
     open(os.path.join(dst, "%s_%s.md" % (tag, cfg)), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(dst, "%s_hbm_traffic.json" % tag), "w"), indent=1, sort_keys=True)
