@@ -38,7 +38,14 @@ def _act_grad(code, y, g):
 
 class DenseTrainer:
     def __init__(self, weights, biases, act_codes, device, learning_rate=1e-3, beta_1=0.9, beta_2=0.999,
-                 epsilon=1e-7):
+                 epsilon=1e-7, rule="adam", rho=0.9):
+        """rule: "adam" | "sgd" | "rmsprop" -- tf.keras.optimizers.{Adam, SGD, RMSprop}(learning_rate=lr) with their
+        TF-2.0 defaults, which is how the reference instantiates `nn_optimizer` (system_dynamics_handler.py:261):
+          sgd      w -= lr * g                                              (momentum 0)
+          rmsprop  v = rho*v + (1-rho)*g^2 ;  w -= lr * g / (sqrt(v) + eps)   (rho 0.9, momentum 0, eps 1e-7, not centered)"""
+        if rule not in ("adam", "sgd", "rmsprop"):
+            raise ValueError("unknown optimizer rule %r" % (rule,))
+        self.rule, self.rho = rule, float(rho)
         import torch
         self.torch = torch
         self.dev = torch.device(device)
@@ -76,6 +83,17 @@ class DenseTrainer:
             grads[n + l] = g.sum(dim=0)
             if l:
                 g = g @ self.w[l].t()
+        if self.rule == "sgd":
+            torch._foreach_add_(self.params, grads, alpha=-self.lr)
+            return
+        if self.rule == "rmsprop":
+            torch._foreach_mul_(self.v, self.rho)
+            torch._foreach_addcmul_(self.v, grads, grads, value=1.0 - self.rho)
+            den = torch._foreach_sqrt(self.v)
+            torch._foreach_add_(den, self.eps)
+            upd = torch._foreach_div(grads, den)
+            torch._foreach_add_(self.params, upd, alpha=-self.lr)
+            return
         self.b1t *= self.b1
         self.b2t *= self.b2
         lr_t = (self.lr * torch.sqrt(1.0 - self.b2t) / (1.0 - self.b1t)).to(torch.float32)

@@ -148,14 +148,17 @@ class SystemDynamicsHandler:
     def train(self, observations_trajectories, actions_trajectories, rewards_trajectories, validation_split=0.2,
               batch_size=128, learning_rate=1e-3, epochs=30, nn_optimizer=None, *, device=None, seed=None,
               split_mask=None, permutations=None):
-        """Reference signature (:163-166); `nn_optimizer` must be None/"Adam" (tf.keras.optimizers.Adam is the only
-        optimizer the reference's callers use).  Keyword-only extras: `device` (default: the GPU -- training on the
+        """Reference signature (:163-166); `nn_optimizer`: None / "Adam" / "SGD" / "RMSprop" or a class of that name
+        (the reference's callers only ever pass tf.keras.optimizers.Adam).  Keyword-only extras: `device` (default: the GPU -- training on the
         host has to be asked for explicitly with device="cpu"), and the injected random draws `split_mask`,
         `permutations` (one per epoch) / `seed` for reproducible runs."""
         if self._is_true_model:
             raise Exception("the true model has nothing to train")
-        if nn_optimizer is not None and getattr(nn_optimizer, "__name__", str(nn_optimizer)).lower() != "adam":
-            raise NotImplementedError("only Adam (the reference's default nn_optimizer) is built")
+        # the reference instantiates `nn_optimizer(learning_rate=learning_rate)` (:261): a Keras optimizer CLASS (or its
+        # name); Adam / SGD / RMSprop with their TF-2.0 defaults are built
+        rule = "adam" if nn_optimizer is None else getattr(nn_optimizer, "__name__", str(nn_optimizer)).lower()
+        if rule not in ("adam", "sgd", "rmsprop"):
+            raise NotImplementedError("nn_optimizer %r: Adam, SGD and RMSprop (Keras defaults) are built" % (nn_optimizer,))
         fn = self._dynamics_function
         if fn is None or not hasattr(fn, "weights"):
             raise Exception("train() needs a DeterministicMLP dynamics function")
@@ -174,7 +177,7 @@ class SystemDynamicsHandler:
         tin, tout = self._normalize_data(self._model_training_in, self._model_training_out)
         vin, vout = self._normalize_data(self._model_validation_in, self._model_validation_out)
         from ..dynamics_functions._train_torch import DenseTrainer
-        trainer = DenseTrainer(fn.weights, fn.biases, fn.activation_codes, device, learning_rate=learning_rate)  # fresh Adam per call (:258)
+        trainer = DenseTrainer(fn.weights, fn.biases, fn.activation_codes, device, learning_rate=learning_rate, rule=rule)  # fresh optimizer per call (:258)
         self.training_loss, self.validation_loss = trainer.fit(tin, tout, vin, vout, epochs, batch_size,
                                                                permutations=permutations, generator_seed=seed)
         fn.set_weights(*trainer.numpy_params())                            # bumps the version: evaluators re-upload

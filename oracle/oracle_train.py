@@ -97,15 +97,42 @@ class KerasAdam:
             p -= lr_t * self.m[i] / (np.sqrt(self.v[i]) + self.eps)
 
 
+class KerasSGD:
+    """tf.keras.optimizers.SGD(learning_rate) with TF-2.0 defaults: momentum 0."""
+
+    def __init__(self, params, learning_rate=1e-2):
+        self.lr = learning_rate
+
+    def step(self, params, grads):
+        for p, g in zip(params, grads):
+            p -= self.lr * g
+
+
+class KerasRMSprop:
+    """tf.keras.optimizers.RMSprop(learning_rate) with TF-2.0 defaults: rho 0.9, momentum 0, epsilon 1e-7, not centered."""
+
+    def __init__(self, params, learning_rate=1e-3, rho=0.9, epsilon=1e-7):
+        self.lr, self.rho, self.eps = learning_rate, rho, epsilon
+        self.v = [np.zeros_like(p) for p in params]
+
+    def step(self, params, grads):
+        for i, (p, g) in enumerate(zip(params, grads)):
+            self.v[i] = self.rho * self.v[i] + (1.0 - self.rho) * g * g
+            p -= self.lr * g / (np.sqrt(self.v[i]) + self.eps)
+
+
+OPTIMIZERS = {"adam": KerasAdam, "sgd": KerasSGD, "rmsprop": KerasRMSprop}
+
+
 def train(weights, biases, acts, train_in, train_out, val_in, val_out, permutations, batch_size=128,
-          learning_rate=1e-3):
+          learning_rate=1e-3, rule="adam"):
     """_training_algorithm :243-290.  Inputs are already normalised.  permutations: one index permutation of the
     training rows per epoch (tf.data shuffle(buffer = all rows) reshuffles every epoch); batches drop the remainder.
     A fresh Adam is created per call, as the reference does (:258).  Returns (weights, biases, train_loss[epochs],
     val_loss[epochs])."""
     w = [np.array(x, np.float64) for x in weights]
     b = [np.array(x, np.float64) for x in biases]
-    opt = KerasAdam(w + b, learning_rate)
+    opt = OPTIMIZERS[rule](w + b, learning_rate)
     tl, vl = [], []
     for perm in permutations:
         nb, acc = 0, 0.0

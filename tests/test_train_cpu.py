@@ -96,6 +96,32 @@ def test_training_matches_numpy_oracle(normalized):
     assert tl[-1] < tl[0]
 
 
+@pytest.mark.parametrize("rule", ["SGD", "RMSprop"])
+def test_other_keras_optimizers_match_the_oracle(rule):
+    # the reference instantiates nn_optimizer(learning_rate=...) (system_dynamics_handler.py:261): a class or its name
+    obs, acs, rews = _episodes(3, 30, 2, 5)
+    h, fn = _handler(normalized=True, seed=8)
+    w0, b0 = [w.copy() for w in fn.weights], [b.copy() for b in fn.biases]
+    d_in, d_out = OT.assemble_dataset(obs, acs)
+    rng = np.random.default_rng(6)
+    mask = rng.random(d_in.shape[0]) > 0.2
+    epochs, B, lr = 4, 16, 5e-3
+    perms = [rng.permutation(int(mask.sum())) for _ in range(epochs)]
+    opt_cls = type(rule, (), {})                                             # a class named like the Keras one
+    h.train(obs, acs, rews, validation_split=0.2, batch_size=B, learning_rate=lr, epochs=epochs, nn_optimizer=opt_cls,
+            device="cpu", split_mask=mask, permutations=perms)
+    tin, tout, vin, vout = d_in[mask], d_out[mask], d_in[~mask], d_out[~mask]
+    stats = OT.normalization_stats(tin, tout, 3)
+    (tin, tout), (vin, vout) = OT.normalize(tin, tout, stats, 3), OT.normalize(vin, vout, stats, 3)
+    w, b, tl, vl = OT.train(w0, b0, ["tanh", "relu", None], tin, tout, vin, vout, perms, batch_size=B, learning_rate=lr,
+                            rule=rule.lower())
+    for got, want in zip(fn.weights + fn.biases, w + b):
+        np.testing.assert_allclose(got, want, rtol=0, atol=3e-4)
+    np.testing.assert_allclose(h.training_loss, tl, rtol=2e-4, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        h.train(obs, acs, rews, nn_optimizer="Nadam", device="cpu")
+
+
 def test_drop_remainder_with_too_few_rows_leaves_the_model_untouched():
     obs, acs, rews = _episodes(1, 10, 1, 7)
     h, fn = _handler()
