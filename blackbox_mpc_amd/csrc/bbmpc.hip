@@ -76,6 +76,15 @@ static void ensure_max_lds(const void* fn, int bytes) {
     }
 }
 
+// kernels whose dynamic LDS grows with the population (an agent's rewards, Nst floats): past the 64 KB default they need
+// the attribute raised
+static void want_lds(const void* fn, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        REQUIRE(bytes <= 159 * 1024, BBMPC_E_UNSUPPORTED, "population too large for one CU's LDS");
+        ensure_max_lds(fn, 159 * 1024);
+    }
+}
+
 Engine::Engine(const bbmpc_config& c) : cfg(c) {
     REQUIRE(c.abi_version == BBMPC_ABI_VERSION, BBMPC_E_INVALID, "bbmpc_config.abi_version mismatch");
     N = c.population_size; A = c.num_agents; H = c.planning_horizon; U = c.dim_u; S = c.dim_s;
@@ -96,7 +105,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
     if (c.optimizer != BBMPC_OPT_NONE) {
         REQUIRE(N >= 1, BBMPC_E_INVALID, "population_size must be >= 1");
         REQUIRE(iters >= 0, BBMPC_E_INVALID, "max_iterations must be >= 0");
-        REQUIRE(N <= 8192, BBMPC_E_UNSUPPORTED, "population_size > 8192 not supported by the refit kernels yet");
+        REQUIRE(N <= 32768, BBMPC_E_UNSUPPORTED, "population_size > 32768: the refit kernels keep an agent's rewards in one CU's LDS");
     } else {
         N = 0;
     }
@@ -356,6 +365,7 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
         launch_rollout(SRC_BUF, true, ra);                          // clip + penalty (cma_es.py:147-157)
         const int kp = (k + 3) & ~3;
         const size_t lds = (size_t)(Nst + TOPK_HIST_WORDS + 2 * kp) * 4;
+        want_lds((const void*)k_cma_select, lds);
         hipLaunchKernelGGL(k_cma_select, dim3(G), dim3(REFIT_THREADS), lds, stream, q);
         hipLaunchKernelGGL(k_cma_paths, dim3(G), dim3(n > 128 ? 1024 : REFIT_THREADS), 0, stream, q);
         hipLaunchKernelGGL(k_cma_cov, dim3((n + 15) / 16, (n + 15) / 16, G), dim3(16, 16), 0, stream, q);
@@ -1272,9 +1282,12 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
             // LDS budget for the refit: rewards + elite idx + elite tile
             const int kpad = (k + 3) & ~3;
             const int fixed = Nst + kpad + TOPK_HIST_WORDS + 2 * kpad;
-            int JC = (int)((size_t)(62 * 1024 / 4 - fixed) / (size_t)k);
+            const int budget = fixed * 4 > 48 * 1024 ? 158 * 1024 / 4 : 62 * 1024 / 4;     // floats; big populations take the whole LDS
+            int JC = (int)((size_t)std::max(budget - fixed, k) / (size_t)k);
             JC = std::max(1, std::min(JC, HU));
             const size_t lds = (size_t)(fixed + (size_t)k * JC) * 4;
+            want_lds((const void*)k_refit_cem_v2, (size_t)fixed * 4);
+            want_lds((const void*)k_refit_cem, lds);
             for (int it = 0; it < iters; ++it) {
                 ra.stream = BBMPC_NOISE_TRUNC_NORMAL; ra.iter = (uint32_t)it;
                 ra.inj = inj_t ? inj_t + inj_stride * it : nullptr;
@@ -1303,6 +1316,9 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                 HIP_CHECK(hipMemcpy2DAsync(d_action.p, U * 4, d_prev_mean.p, HU * 4, U * 4, A, hipMemcpyDeviceToDevice, stream));
             const float* inj_t = injected(BBMPC_NOISE_TRUNC_NORMAL);
             const size_t lds = (size_t)(Nst + 64) * 4;
+            want_lds((const void*)k_refit_pi2_mw, lds);
+            want_lds((const void*)k_refit_pi2, lds);
+            want_lds((const void*)k_refit_pi2_partial, lds);
             for (int it = 0; it < iters; ++it) {
                 ra.stream = BBMPC_NOISE_TRUNC_NORMAL; ra.iter = (uint32_t)it;
                 ra.inj = inj_t ? inj_t + inj_stride * it : nullptr;
@@ -1391,6 +1407,7 @@ void Engine::optimize_spsa(RolloutArgs& ra, uint32_t step) {
         launch_rollout(SRC_BUF, true, ra);
         ra.cand = d_cand_b.p; ra.samples = d_cand_b.p; ra.rewards = d_rewards2.p;
         launch_rollout(SRC_BUF, true, ra);
+        want_lds((const void*)k_refit_spsa, (size_t)Nst * 4);
         hipLaunchKernelGGL(k_refit_spsa, dim3(A), dim3(REFIT_THREADS), (size_t)Nst * 4, stream, oa, d_rewards.p, d_rewards2.p,
                            d_samples.p, ak, ck, d_mean.p, d_action.p);
         HIP_CHECK(hipGetLastError());

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_rows_mlp(RowMlp net, int S, in
 // ---- PI2 refit over many workgroups ---------------------------------------------------------------------------
 // new_mean[j] = sum_n omega[n] * samples[j][n], omega = softmin(cost / lamda)   (pi2.py:78-87).
 // Every workgroup recomputes beta = min cost, eta = sum exp(-(cost - beta)/lamda) and omega for the agent's whole
-// population (N <= 8192 values: a few loads per thread and two block reductions -- cheaper than a launch that would
+// population (N <= 32768 values: a few loads per thread and two block reductions -- cheaper than a launch that would
 // produce them once), then each of its waves takes one row j of the particle-minor sample matrix with all of a
 // lane's loads in flight.  One 1024-thread workgroup walking all HU rows (the previous kernel) needed 58 us at
 // N = 1000, HU = 180: 11 rows per wave, each a 16-deep chain of dependent L2 round trips.

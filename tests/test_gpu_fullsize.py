@@ -310,3 +310,41 @@ def test_config5_cmaes_per_agent_full_size(L):
         np.testing.assert_allclose(eng.get_state("sigma", (A * n,)).reshape(A, n)[g], cma.sigma, rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(eng.get_state("p_sigma", (A * n,)).reshape(A, n)[g], cma.p_sigma, rtol=1e-3, atol=2e-4)
         np.testing.assert_allclose(act[g], cma.m.reshape(H, U)[0], rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("opt_name", ["CEM", "PI2", "RandomSearch"])
+def test_large_population_beyond_one_lds_default(L, monkeypatch, opt_name):
+    # N = 20000 particles per agent (the refit kernels keep an agent's rewards in LDS: 80 KB here, past the 64 KB default
+    # allocation; limit 32768).  Pendulum, per-iteration kernels; engine-drawn noise replayed through the C oracle.
+    from blackbox_mpc_amd.engine import Engine
+    N, A, H, iters, k = 20000, 2, 12, 2, 64
+    opt = {"CEM": L.OPT_CEM, "PI2": L.OPT_PI2, "RandomSearch": L.OPT_RANDOM_SEARCH}[opt_name]
+    eng = Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=A, planning_horizon=H,
+                 population_size=N, max_iterations=iters, num_elite=k, seed=12)
+    eng.set_trace(True)
+    states = O.pendulum_start_states(A)
+    act, nxt, rew = eng.optimize(states)
+    co = OC.COracle("pendulum", "pendulum", [-2.0], [2.0], N, A, H, 3, iters=iters, k=k)
+    n_it = 1 if opt_name == "RandomSearch" else iters
+    for it in range(n_it):
+        s, r = eng.get_trace(it, L.TRACE_SAMPLES), eng.get_trace(it, L.TRACE_REWARDS)
+        free = co.evaluate(states, s)
+        if opt_name == "PI2" and it > 0:          # traced rewards are R - penalty; only iteration 0 (mean 0, |xi| < 2) is penalty free
+            assert np.all(r <= free + 2e-3 + 2e-4 * np.abs(free))
+        else:
+            np.testing.assert_allclose(r, free, rtol=2e-4, atol=2e-3)
+        if opt_name == "CEM":
+            e = eng.get_trace(it, L.TRACE_ELITES)
+            for a in range(A):
+                np.testing.assert_array_equal(e[a], O.topk_desc(r[:, a], k))
+    if opt_name == "RandomSearch":
+        best = eng.get_trace(0, L.TRACE_ELITES)
+        np.testing.assert_array_equal(best, np.argmax(eng.get_trace(0, L.TRACE_REWARDS), axis=0))
+    kind = L.NOISE_UNIFORM if opt_name == "RandomSearch" else L.NOISE_TRUNC_NORMAL
+    noise = [eng.dump_noise(kind, 0, it, (N, A, H, 1)) for it in range(n_it)]
+    if opt_name == "PI2":
+        a_c, _, _ = co.optimize("PI2", states, noise=noise)
+        np.testing.assert_allclose(act, a_c, rtol=0, atol=5e-3)
+    with pytest.raises(L.BBMPCError):
+        Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=1, planning_horizon=4,
+               population_size=40000, max_iterations=1, num_elite=8)
