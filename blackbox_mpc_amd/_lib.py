@@ -67,7 +67,7 @@ SYMBOLS = [
     "bbmpc_comm_unique_id", "bbmpc_comm_init", "bbmpc_gather_records_dev", "bbmpc_gather_wait", "bbmpc_comm_destroy",
     "bbmpc_optimize_gather_dev", "bbmpc_set_stream_default", "bbmpc_optimize_gather", "bbmpc_comm_info",
     "bbmpc_set_reward_source", "bbmpc_set_dynamics_source", "bbmpc_check_user_source", "bbmpc_mlp_forward",
-    "bbmpc_process_input", "bbmpc_process_output",
+    "bbmpc_process_input", "bbmpc_process_output", "bbmpc_check_user_rollout",
 ]
 COMM_ID_BYTES = 128
 
@@ -127,6 +127,7 @@ def _load():
     lib.bbmpc_set_dynamics_source.argtypes = [vp, ctypes.c_char_p]
     lib.bbmpc_check_user_source.argtypes = [i32, ctypes.c_char_p, i32, i32]
     lib.bbmpc_mlp_forward.argtypes = [vp, vp, i32, vp]
+    lib.bbmpc_check_user_rollout.argtypes = [i32, i32, ctypes.c_char_p, ctypes.c_char_p, i32, i32]
     lib.bbmpc_process_input.argtypes = [vp, vp, vp, i32, ctypes.POINTER(vp), vp]
     lib.bbmpc_process_output.argtypes = [vp, vp, vp, i32, ctypes.POINTER(vp), vp]
     return lib

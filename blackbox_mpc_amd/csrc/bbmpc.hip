@@ -159,6 +159,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.host_poll = !flag("BBMPC_NO_HOST_POLL");
         sw.mlp_no_half_tail = flag("BBMPC_MLP_NO_HALF_TAIL");
         sw.dbg = flag("BBMPC_DBG");
+        user_stepwise_only = flag("BBMPC_USER_STEPWISE");
         if (c.optimizer == BBMPC_OPT_PI2) {
             ps_loopback = ival("BBMPC_POPSHARD_LOOPBACK", 0);
             ps_force = flag("BBMPC_POPSHARD_FORCE");
@@ -229,6 +230,7 @@ Engine::~Engine() {
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     user_reward.release();
     user_dynamics.release();
+    user_rollout.release();
     if (h_pin) (void)hipHostFree(h_pin);
     if (host_done) (void)hipHostFree(host_done);
     if (host_count) (void)hipFree(host_count);
@@ -771,6 +773,7 @@ void Engine::set_user_source(int kind, const char* src) {
     HIP_CHECK(hipModuleLoadData(&f.module, code.data()));
     HIP_CHECK(hipModuleGetFunction(&f.fn, f.module, kind == USER_KIND_REWARD ? "bbmpc_user_reward_rows" : "bbmpc_user_dynamics_rows"));
     f.source = src;
+    user_rollout_stale = true;
 }
 
 // next = process_output(state, dynamics(process_input(state, action)))  on [batch] rows   deterministic.py:79-103
@@ -847,6 +850,49 @@ void Engine::rollout_stepwise(int mode, bool pen, RolloutArgs& ra) {
     prof_end();
 }
 
+// The fused form for analytic models: one lane per trajectory, user function(s) inlined next to the engine's own
+// model / rewards (rtc.hpp user_rollout_source).  Compiled on first use, after both sources are known.
+void Engine::rollout_user_fused(int mode, bool pen, RolloutArgs& ra) {
+    if (user_rollout_stale || !user_rollout.fn) {
+        if (cfg.reward == BBMPC_REW_USER) REQUIRE(user_reward.fn, BBMPC_E_STATE, "user reward: call bbmpc_set_reward_source before computing");
+        if (cfg.dynamics == BBMPC_DYN_USER) REQUIRE(user_dynamics.fn, BBMPC_E_STATE, "user dynamics: call bbmpc_set_dynamics_source before computing");
+        std::vector<char> code;
+        try {
+            code = compile_user_rollout(cfg.reward == BBMPC_REW_USER ? user_reward.source : std::string(),
+                                        cfg.dynamics == BBMPC_DYN_USER ? user_dynamics.source : std::string(), cfg.dynamics, cfg.reward, S, U);
+        } catch (const std::exception& ex) {
+            throw HipError(BBMPC_E_INVALID, ex.what());
+        }
+        user_rollout.release();
+        HIP_CHECK(hipModuleLoadData(&user_rollout.module, code.data()));
+        HIP_CHECK(hipModuleGetFunction(&user_rollout.fn, user_rollout.module, "bbmpc_user_rollout"));
+        user_rollout_stale = false;
+    }
+    int n_pop = ra.n_pop, Aa = A, Hh = ra.H, Nst_ = ra.Nst;
+    dim3 ggrid((n_pop + 255) / 256, A), gblock(256);
+    if (mode == SRC_UNIFORM || mode == SRC_TRUNC) {
+        REQUIRE(ra.samples, BBMPC_E_STATE, "user rollout: no sample buffer");
+        if (mode == SRC_UNIFORM) hipLaunchKernelGGL(k_gen_candidates<SRC_UNIFORM>, ggrid, gblock, 0, stream, ra);
+        else hipLaunchKernelGGL(k_gen_candidates<SRC_TRUNC>, ggrid, gblock, (size_t)2 * ra.HU * sizeof(float), stream, ra);
+        HIP_CHECK(hipGetLastError());
+    }
+    int from_ref = mode == SRC_REF ? 1 : 0, ipen = pen ? 1 : 0, fq1 = (int)fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
+    const float* state = ra.state;
+    const float* seq = ra.seq;
+    const float* cand = mode == SRC_BUF ? ra.cand : ra.samples;
+    float* samples = (pen && mode != SRC_REF) ? ra.samples : nullptr;          // the feasible candidates go back
+    const float* lo_ = ra.lo;
+    const float* hi_ = ra.hi;
+    float* rewards = ra.rewards;
+    float* penalty_out = ra.penalty_out;
+    void* args[] = {&n_pop, &Aa, &Hh, &Nst_, &from_ref, &ipen, &fq1, &state, &seq, &cand, &samples, &lo_, &hi_, &rewards, &penalty_out};
+    // few trajectories -> one wave per workgroup (latency); many -> 256-thread workgroups
+    const unsigned bs = ((long)n_pop * A <= 16384) ? 64 : 256;
+    prof_begin();
+    HIP_CHECK(hipModuleLaunchKernel(user_rollout.fn, (unsigned)((n_pop + bs - 1) / bs), (unsigned)A, 1, bs, 1, 1, 0, stream, args, nullptr));
+    prof_end();
+}
+
 // DeterministicMLP.__call__ on already-processed rows (deterministic_mlp.py:27-51)
 __global__ __launch_bounds__(TAIL_THREADS) void k_rows_mlp_raw(RowMlp net, const float* x_in, float* out) {
     __shared__ float x[192];
@@ -867,8 +913,13 @@ void Engine::mlp_forward_rows(const float* d_x, int batch, float* d_out) {
 
 void Engine::launch_rollout(int mode, bool pen, RolloutArgs& ra) {
     if (user_path()) {
-        dominant_kernel = "stepwise(user device function)";
-        rollout_stepwise(mode, pen, ra);
+        if (cfg.dynamics != BBMPC_DYN_MLP && !user_stepwise_only) {
+            dominant_kernel = "bbmpc_user_rollout(hiprtc)";
+            rollout_user_fused(mode, pen, ra);
+        } else {
+            dominant_kernel = "stepwise(user device function)";
+            rollout_stepwise(mode, pen, ra);
+        }
         return;
     }
     if (cfg.dynamics == BBMPC_DYN_MLP) {
@@ -1974,6 +2025,20 @@ int bbmpc_check_user_source(int32_t kind, const char* src, int32_t dim_s, int32_
     if (dim_s < 1 || dim_u < 1 || dim_s > 256 || dim_u > 256) throw HipError(BBMPC_E_INVALID, "dim_s / dim_u must be in [1, 256]");
     try {
         (void)bbmpc::compile_user_program(src, kind, dim_s, dim_u);
+    } catch (const std::exception& ex) {
+        throw HipError(BBMPC_E_INVALID, ex.what());
+    }
+    API_END
+}
+
+int bbmpc_check_user_rollout(int32_t dynamics, int32_t reward, const char* dyn_src, const char* rew_src, int32_t dim_s, int32_t dim_u) {
+    API_BEGIN
+    if (dynamics != BBMPC_DYN_PENDULUM && dynamics != BBMPC_DYN_USER) throw HipError(BBMPC_E_INVALID, "fused user rollouts exist for analytic dynamics (pendulum / user)");
+    if (reward < BBMPC_REW_PENDULUM || reward > BBMPC_REW_USER) throw HipError(BBMPC_E_INVALID, "unknown reward kind");
+    if ((dynamics == BBMPC_DYN_USER && !dyn_src) || (reward == BBMPC_REW_USER && !rew_src)) throw HipError(BBMPC_E_INVALID, "missing source");
+    if (dim_s < 1 || dim_u < 1 || dim_s > 256 || dim_u > 256) throw HipError(BBMPC_E_INVALID, "dim_s / dim_u must be in [1, 256]");
+    try {
+        (void)bbmpc::compile_user_rollout(reward == BBMPC_REW_USER ? rew_src : "", dynamics == BBMPC_DYN_USER ? dyn_src : "", dynamics, reward, dim_s, dim_u);
     } catch (const std::exception& ex) {
         throw HipError(BBMPC_E_INVALID, ex.what());
     }

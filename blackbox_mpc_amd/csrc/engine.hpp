@@ -174,7 +174,10 @@ struct Engine {
     }
     bool fix(uint32_t bit) const { return (cfg.quirks & bit) != 0; }
     // user-supplied reward / dynamics device functions (rtc.hpp) and the step-wise evaluator that calls them
-    UserFunction user_reward, user_dynamics;
+    UserFunction user_reward, user_dynamics, user_rollout;   // user_rollout: the fused lane-per-trajectory kernel (rtc.hpp), built lazily
+    bool user_rollout_stale = true;
+    bool user_stepwise_only = false;   // BBMPC_USER_STEPWISE: never fuse (test / comparison hook)
+    void rollout_user_fused(int mode, bool pen, RolloutArgs& ra);
     DevBuf<float> u_rows, u_x0, u_x1, u_total, u_pen, u_next;
     bool user_path() const { return cfg.reward == BBMPC_REW_USER || cfg.dynamics == BBMPC_DYN_USER; }
     int builtin_reward_kind() const { return cfg.reward == BBMPC_REW_USER ? REW_NONE : cfg.reward; }

@@ -110,17 +110,93 @@ extern "C" __global__ void bbmpc_user_dynamics_rows(const float* __restrict__ st
     return s;
 }
 
+#include "_embed.inc"      // k_embed_fastmath, k_embed_models: the leaf-math headers as text (generated by _build.py)
+
+// The FUSED form: one lane per candidate trajectory, the whole H-step recurrence in registers, with the user's
+// function(s) inlined next to the built-in model / rewards (the engine's own models.hpp, compiled from the same text
+// with the same flags).  Used whenever the dynamics is not the learned MLP (whose rollouts live on the matrix cores);
+// the step-wise evaluator (kernels_user.hpp) stays for MLP + user reward.
+//   BBMPC_DYN_KIND 1 = PendulumTrueModel (op-for-op form), 3 = bbmpc_user_dynamics
+//   BBMPC_REW_KIND 1 / 2 = built-in pendulum / cheetah reward, 3 = bbmpc_user_reward
+inline std::string user_rollout_source(const std::string& reward_src, const std::string& dynamics_src) {
+    std::string s = "#include \"models.hpp\"\n";
+    s += "// ---- user reward --------------------------------------------------------------------\n" + reward_src + "\n";
+    s += "// ---- user dynamics ------------------------------------------------------------------\n" + dynamics_src + "\n";
+    s += R"RTC(
+extern "C" __global__ void bbmpc_user_rollout(int n_pop, int A, int H, int Nst, int from_ref, int pen, int fix_q1,
+                                              const float* __restrict__ state, const float* __restrict__ seq,
+                                              const float* cand, float* samples, const float* __restrict__ lo,
+                                              const float* __restrict__ hi, float* __restrict__ rewards,
+                                              float* __restrict__ penalty_out) {
+    constexpr int S = BBMPC_S, U = BBMPC_U;
+    const int a = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_pop) return;
+    const int HU = H * U;
+    float x[S + U], nx[S];
+    for (int i = 0; i < S; ++i) x[i] = state[a * S + i];                       // tf.tile(current_states, [nopt, 1])
+    float total = 0.0f, pen_acc = 0.0f;
+    for (int t = 0; t < H; ++t) {
+        for (int u = 0; u < U; ++u) {
+            const int j = t * U + u;
+            float v = from_ref ? seq[((size_t)n * A + a) * HU + j] : cand[((size_t)a * HU + j) * Nst + n];
+            if (pen) {
+                const float xf = bbmpc::clipf(v, lo[u], hi[u]);
+                const float d = v - xf;
+                pen_acc = pen_acc + d * d;
+                v = xf;
+            }
+            if (samples) samples[((size_t)a * HU + j) * Nst + n] = v;
+            x[S + u] = v;
+        }
+#if BBMPC_DYN_KIND == 3
+        {
+            float d[S];
+            bbmpc_user_dynamics(x, d, S, U);                                   // f(x, train=False) -> delta
+            for (int i = 0; i < S; ++i) nx[i] = d[i] + x[i];                     // transforms.py:34
+        }
+#else
+        {
+            float ss[3] = {x[0], x[1], x[2]};
+            const float ac[1] = {x[3]};
+            const bbmpc::PendulumModel model{fix_q1 != 0};
+            (void)model.step(ss, ac);
+            nx[0] = ss[0]; nx[1] = ss[1]; nx[2] = ss[2];
+        }
+#endif
+#if BBMPC_REW_KIND == 3
+        total = total + bbmpc_user_reward(x, x + S, nx, S, U);                   // (current_state, actions, next_state)
+#else
+        total = total + bbmpc::reward_generic(BBMPC_REW_KIND, fix_q1 != 0, x, x + S, nx, S, U);
+#endif
+        for (int i = 0; i < S; ++i) x[i] = nx[i];
+    }
+    if (total != total) total = -1.0e6f;                                         // deterministic.py:75-77
+    if (pen) {
+        const float nr = sqrtf(pen_acc);                                         // tf.norm(...)**2  pi2.py:72-75
+        const float pv = nr * nr;
+        total = total - pv;
+        if (penalty_out) penalty_out[(size_t)a * Nst + n] = pv;
+    }
+    rewards[(size_t)a * Nst + n] = total;
+}
+)RTC";
+    return s;
+}
+
 // Compile for gfx950; returns the code object.  Throws std::runtime_error with the compiler log on failure.
-inline std::vector<char> compile_user_program(const std::string& user_src, int kind, int S, int U) {
+inline std::vector<char> compile_rtc(const std::string& src, const char* name, const std::vector<std::string>& defines,
+                                     bool with_engine_headers) {
     const Hiprtc& r = Hiprtc::get();
-    const std::string src = user_program_source(user_src, kind);
     Hiprtc::Program prog = nullptr;
-    int rc = r.CreateProgram(&prog, src.c_str(), kind == USER_KIND_REWARD ? "bbmpc_user_reward.hip" : "bbmpc_user_dynamics.hip", 0, nullptr, nullptr);
+    const char* hdr_text[] = {k_embed_fastmath, k_embed_models};
+    const char* hdr_name[] = {"fastmath.hpp", "models.hpp"};
+    int rc = r.CreateProgram(&prog, src.c_str(), name, with_engine_headers ? 2 : 0, with_engine_headers ? hdr_text : nullptr,
+                             with_engine_headers ? hdr_name : nullptr);
     if (rc != 0) throw std::runtime_error(std::string("hiprtcCreateProgram: ") + r.GetErrorString(rc));
-    const std::string ds = "-DBBMPC_S=" + std::to_string(S), du = "-DBBMPC_U=" + std::to_string(U);
     // one rounding per source operation, as everywhere in the engine (and as the reference's TF ops round)
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", ds.c_str(), du.c_str()};
-    rc = r.CompileProgram(prog, 5, opts);
+    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off"};
+    for (const std::string& d : defines) opts.push_back(d.c_str());
+    rc = r.CompileProgram(prog, (int)opts.size(), opts.data());
     std::string log;
     size_t n = 0;
     if (r.GetProgramLogSize(prog, &n) == 0 && n > 1) {
@@ -141,6 +217,18 @@ inline std::vector<char> compile_user_program(const std::string& user_src, int k
     (void)r.DestroyProgram(&prog);
     if (rc != 0) throw std::runtime_error(std::string("hiprtcGetCode: ") + r.GetErrorString(rc));
     return code;
+}
+
+inline std::vector<char> compile_user_program(const std::string& user_src, int kind, int S, int U) {
+    return compile_rtc(user_program_source(user_src, kind), kind == USER_KIND_REWARD ? "bbmpc_user_reward.hip" : "bbmpc_user_dynamics.hip",
+                       {"-DBBMPC_S=" + std::to_string(S), "-DBBMPC_U=" + std::to_string(U)}, false);
+}
+
+inline std::vector<char> compile_user_rollout(const std::string& reward_src, const std::string& dynamics_src, int dyn_kind, int rew_kind,
+                                              int S, int U) {
+    return compile_rtc(user_rollout_source(reward_src, dynamics_src), "bbmpc_user_rollout.hip",
+                       {"-DBBMPC_S=" + std::to_string(S), "-DBBMPC_U=" + std::to_string(U), "-DBBMPC_DYN_KIND=" + std::to_string(dyn_kind),
+                        "-DBBMPC_REW_KIND=" + std::to_string(rew_kind)}, true);
 }
 
 struct UserFunction {

@@ -173,11 +173,17 @@ int bbmpc_set_mlp(bbmpc_handle h, int32_t n_layers, const int32_t* dims, const i
  * for a handle created with BBMPC_REW_USER / BBMPC_DYN_USER (user dynamics are a true model: next = state + delta,
  * utils/transforms.py:34).  Any combination with the built-in plug-ins works; evaluation then runs step by step
  * (one batched dynamics and one batched reward launch per planning step, as the reference's own graph does) instead
- * of through the fused whole-horizon kernels.  Compile errors come back as BBMPC_E_INVALID with the compiler log in
+ * of through the built-in pairs' fused kernels -- unless the dynamics is analytic (user or PendulumTrueModel): then the
+ * engine compiles ONE fused lane-per-trajectory rollout kernel with the user function(s) inlined.  Compile errors come back as BBMPC_E_INVALID with the compiler log in
  * bbmpc_last_error().  bbmpc_check_user_source only compiles (needs no GPU): kind 1 = reward, 2 = dynamics. */
 int bbmpc_set_reward_source(bbmpc_handle h, const char* hip_source);
 int bbmpc_set_dynamics_source(bbmpc_handle h, const char* hip_source);
 int bbmpc_check_user_source(int32_t kind, const char* hip_source, int32_t dim_s, int32_t dim_u);
+/* Compile-only check of the FUSED rollout kernel the engine builds for analytic models (one lane per trajectory, the
+ * user function(s) inlined next to the built-in PendulumTrueModel / rewards): dynamics / reward = BBMPC_DYN_* /
+ * BBMPC_REW_* kinds, sources NULL for built-ins.  Needs no GPU. */
+int bbmpc_check_user_rollout(int32_t dynamics, int32_t reward, const char* dynamics_source, const char* reward_source,
+                             int32_t dim_s, int32_t dim_u);
 /* DeterministicMLP.__call__(x[B, S+U], train) -> [B, S]: the raw Dense stack on already-processed inputs
  * (dynamics_functions/deterministic_mlp.py:27-51), no normalisation, no residual. */
 int bbmpc_mlp_forward(bbmpc_handle h, const float* x, int32_t batch, float* out);

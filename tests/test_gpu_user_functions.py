@@ -73,6 +73,15 @@ def L():
     return _lib
 
 
+@pytest.fixture(params=["fused", "stepwise"], autouse=True)
+def user_rollout_form(request, monkeypatch):
+    """every test runs on both forms of the user-function evaluator: the hiprtc-compiled fused lane-per-trajectory
+    kernel (analytic dynamics; the default) and the step-wise evaluator (always used for MLP + user reward)"""
+    if request.param == "stepwise":
+        monkeypatch.setenv("BBMPC_USER_STEPWISE", "1")
+    yield request.param
+
+
 def _intended(cur, act, nxt):
     return O.pendulum_reward(cur, act, nxt, as_executed=False)
 

@@ -28,6 +28,21 @@ def test_sources_compile_without_a_gpu(built_lib):
     check_source(L.USER_KIND_DYNAMICS, GOOD_DYNAMICS, 4, 2)
 
 
+def test_fused_rollout_kernel_compiles_with_the_engine_headers(built_lib):
+    # analytic dynamics: the engine builds ONE lane-per-trajectory kernel with the user function(s) inlined next to its own
+    # PendulumTrueModel / rewards (models.hpp handed to hiprtc as text) -- every combination must compile
+    chk = lambda d, r, ds, rs, S, U: L.check(L.lib.bbmpc_check_user_rollout(d, r, ds.encode() if ds else None,
+                                                                            rs.encode() if rs else None, S, U))
+    chk(L.DYN_USER, L.REW_USER, GOOD_DYNAMICS, GOOD_REWARD, 4, 2)
+    chk(L.DYN_PENDULUM, L.REW_USER, None, GOOD_REWARD, 3, 1)
+    chk(L.DYN_USER, L.REW_PENDULUM, GOOD_DYNAMICS, None, 3, 1)
+    chk(L.DYN_USER, L.REW_CHEETAH, GOOD_DYNAMICS, None, 20, 6)
+    with pytest.raises(L.BBMPCError):                        # the learned MLP's rollouts live on the matrix cores
+        chk(L.DYN_MLP, L.REW_USER, None, GOOD_REWARD, 20, 6)
+    with pytest.raises(L.BBMPCError):
+        chk(L.DYN_USER, L.REW_USER, None, GOOD_REWARD, 3, 1)
+
+
 def test_compile_errors_carry_the_compiler_log(built_lib):
     with pytest.raises(L.BBMPCError) as ei:
         check_source(L.USER_KIND_REWARD, "__device__ float bbmpc_user_reward(const float* c) { return undeclared_name; }", 3, 1)
