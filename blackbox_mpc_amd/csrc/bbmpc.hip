@@ -664,6 +664,8 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     q.per_particle_state = per_particle_state ? 1 : 0;
     q.final_state = final_state;
     q.nw = mlp_nw;
+    q.traj = mlp_traj_out;
+    const bool record = mlp_traj_out != nullptr;       // trajectory recording lives in rollout_mlp_body's epilogue only
     for (int l = 0; l < mlp.n_layers; ++l) { q.wraw[l] = d_wraw[l].p; q.braw[l] = d_braw[l].p; q.wq4[l] = d_wq4[l].p; q.wbf[l] = reinterpret_cast<const uint4*>(d_wbf[l].p); }
     const MlpLds lay = mlp_lds_layout(mlp, ra.H, U, S, mlp_nw);
     const size_t lds = (size_t)lay.total * sizeof(float);
@@ -677,7 +679,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     if (sw.mlp_generic) spec = 0;
     const bool single_step = per_particle_state && ra.H == 1;
     if (single_step) spec = 3;
-    if (sw.mlp_bf16 && spec == 1 && !per_particle_state && !final_state) {
+    if (sw.mlp_bf16 && spec == 1 && !per_particle_state && !final_state && !record) {
         // opt-in reduced-precision mode (kernels_mlp.hpp): never selected automatically
         dim3 bgrid((ra.n_pop + MLP_TP - 1) / MLP_TP, A), bblock(mlp_nw * 64);
         dominant_kernel = sw.mlp_bf16 == 3 ? "k_rollout_mlp_bf16<3>" : "k_rollout_mlp_bf16<1>";
@@ -694,14 +696,17 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     if (lds > 64 * 1024) ensure_max_lds(fn, 159 * 1024);
     // pair mode (two tiles per workgroup, software-pipelined) when there are more tiles than CUs can hold one each
     const long tiles_total = (long)((ra.n_pop + MLP_TP - 1) / MLP_TP) * A;
-    const bool pair_ok = spec == 1 && mlp.tiles[1] == 13 && !per_particle_state && mlp.act[0] == BBMPC_ACT_TANH &&
-                         mlp.act[1] == BBMPC_ACT_TANH && mlp.act[2] == BBMPC_ACT_NONE;
+    // the 26-200-200-20 tanh/tanh/linear family has its own kernels; trajectory recording exists in the quad kernel and in
+    // the generic 16-particle tiling, not in the pipelined pair kernel
+    const bool fam_ok = spec == 1 && mlp.tiles[1] == 13 && !per_particle_state && mlp.act[0] == BBMPC_ACT_TANH &&
+                        mlp.act[1] == BBMPC_ACT_TANH && mlp.act[2] == BBMPC_ACT_NONE;
+    const bool pair_ok = fam_ok && !record;
     int pair = (pair_ok && tiles_total > 256) ? 1 : 0;
     if (sw.mlp_pair >= 0) pair = (sw.mlp_pair != 0 && pair_ok) ? 1 : 0;
     // quad mode (4 particles per workgroup, 4x4x1_16b MFMA, all weights in registers) when the population is too
     // small to give every CU a 16-particle tile
     {
-        const bool q4_ok = pair_ok && mlp.dims[0] <= 28 && mlp.dims[1] == 200 && mlp.dims[2] == 200 && mlp.dims[3] <= 64;
+        const bool q4_ok = fam_ok && mlp.dims[0] <= 28 && mlp.dims[1] == 200 && mlp.dims[2] == 200 && mlp.dims[3] <= 64;
         // measured on MI355X (tools/q4_sweep.py, PI2, H = 30, us per control step): a "wave" of 256 quad workgroups (one
         // per CU, 1024 particles) costs ~400 us, the 16-particle tiling ~850 us for anything up to 4096 particles:
         // quads win up to two waves (N*A <= 2048: 810 vs 860), lose from the third on (2500: 1177 vs 868)
@@ -772,6 +777,7 @@ void Engine::set_user_source(int kind, const char* src) {
     f.release();
     HIP_CHECK(hipModuleLoadData(&f.module, code.data()));
     HIP_CHECK(hipModuleGetFunction(&f.fn, f.module, kind == USER_KIND_REWARD ? "bbmpc_user_reward_rows" : "bbmpc_user_dynamics_rows"));
+    if (kind == USER_KIND_REWARD) HIP_CHECK(hipModuleGetFunction(&f.fn_traj, f.module, "bbmpc_user_reward_traj"));
     f.source = src;
     user_rollout_stale = true;
 }
@@ -893,6 +899,31 @@ void Engine::rollout_user_fused(int mode, bool pen, RolloutArgs& ra) {
     prof_end();
 }
 
+// Learned MLP + user reward: the whole-horizon MFMA rollout (16-particle tiles) records the state after every step,
+// then ONE launch of the user's function scores every trajectory -- 2 launches instead of 2*H + 2.
+void Engine::rollout_mlp_user_reward(int mode, bool pen, RolloutArgs& ra) {
+    REQUIRE(user_reward.fn_traj, BBMPC_E_STATE, "user reward: call bbmpc_set_reward_source before computing");
+    const size_t need = (size_t)ra.H * A * ra.Nst * S;
+    if (u_traj.n < need) u_traj.alloc(need);
+    mlp_traj_out = u_traj.p;
+    try {
+        launch_rollout_mlp(mode, pen, ra, false, nullptr);          // reward kind REW_NONE: leaves -(penalty) in ra.rewards
+    } catch (...) {
+        mlp_traj_out = nullptr;
+        throw;
+    }
+    mlp_traj_out = nullptr;
+    int n_pop = ra.n_pop, Aa = A, Hh = ra.H, Nst_ = ra.Nst, from_ref = mode == SRC_REF ? 1 : 0;
+    const float* state = ra.state;
+    const float* traj = u_traj.p;
+    const float* seq = ra.seq;
+    const float* cand = mode == SRC_BUF ? ra.cand : ra.samples;
+    float* rewards = ra.rewards;
+    if (mode != SRC_REF) REQUIRE(cand, BBMPC_E_STATE, "user reward over the learned model: no candidate buffer");
+    void* args[] = {&n_pop, &Aa, &Hh, &Nst_, &from_ref, &state, &traj, &seq, &cand, &rewards};
+    HIP_CHECK(hipModuleLaunchKernel(user_reward.fn_traj, (unsigned)((n_pop + 255) / 256), (unsigned)A, 1, 256, 1, 1, 0, stream, args, nullptr));
+}
+
 // DeterministicMLP.__call__ on already-processed rows (deterministic_mlp.py:27-51)
 __global__ __launch_bounds__(TAIL_THREADS) void k_rows_mlp_raw(RowMlp net, const float* x_in, float* out) {
     __shared__ float x[192];
@@ -916,6 +947,9 @@ void Engine::launch_rollout(int mode, bool pen, RolloutArgs& ra) {
         if (cfg.dynamics != BBMPC_DYN_MLP && !user_stepwise_only) {
             dominant_kernel = "bbmpc_user_rollout(hiprtc)";
             rollout_user_fused(mode, pen, ra);
+        } else if (cfg.dynamics == BBMPC_DYN_MLP && !user_stepwise_only) {
+            dominant_kernel = "k_rollout_mlp";
+            rollout_mlp_user_reward(mode, pen, ra);
         } else {
             dominant_kernel = "stepwise(user device function)";
             rollout_stepwise(mode, pen, ra);

@@ -178,6 +178,9 @@ struct Engine {
     bool user_rollout_stale = true;
     bool user_stepwise_only = false;   // BBMPC_USER_STEPWISE: never fuse (test / comparison hook)
     void rollout_user_fused(int mode, bool pen, RolloutArgs& ra);
+    void rollout_mlp_user_reward(int mode, bool pen, RolloutArgs& ra);
+    DevBuf<float> u_traj;              // [H][A][Nst][S] states after every step of the MFMA rollout
+    float* mlp_traj_out = nullptr;     // set around a launch_rollout_mlp call that should record the trajectory
     DevBuf<float> u_rows, u_x0, u_x1, u_total, u_pen, u_next;
     bool user_path() const { return cfg.reward == BBMPC_REW_USER || cfg.dynamics == BBMPC_DYN_USER; }
     int builtin_reward_kind() const { return cfg.reward == BBMPC_REW_USER ? REW_NONE : cfg.reward; }

@@ -67,6 +67,7 @@ struct MlpRolloutArgs {
     const float* braw[MLP_MAX_LAYERS];   // unpacked biases [out]
     const float* wq4[MLP_MAX_LAYERS];    // quad-mode operands [ceil(in/4)][Mp][4], Mp = out rounded up to 64, zero padded
     const uint4* wbf[MLP_MAX_LAYERS];    // bf16 mode operands [OT][IT][64] x (4 bf16 hi | 4 bf16 lo), k = 16*it + 4*(lane>>4) + r
+    float* traj;              // optional [H][A][Nst][S]: the state after every step (a user reward function scores them afterwards)
 };
 
 // tanh on the hardware exp/rcp units: sign(x) * (1 - 2 / (e^{2|x|} + 1)), 7 instructions.  Absolute error
@@ -402,6 +403,7 @@ __device__ __forceinline__ void rollout_mlp_body(const MlpRolloutArgs& q) {
                 const float dev = normd ? tmean[f] + acc * tstd[f] : acc;       // system_dynamics_handler.py:152-155
                 const float ns = dev + cur[pp * Sp + f];                        // transforms.py:34
                 nxt[pp * Sp + f] = ns;
+                if (q.traj && n0 + pp < p.n_pop) q.traj[((((size_t)t * p.A + a) * p.Nst) + n0 + pp) * S + f] = ns;
                 v = ns;
             } else {
                 const int tn = (t + 1 < H) ? t + 1 : t;
@@ -945,8 +947,9 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
     // registers -- lane g*4+pp owns features 4g..4g+3 of particle pp, exactly the float4 the next step's layer-0 B
     // operand wants -- so a step's epilogue is four 16-byte partial reads, ~40 VALU and one 16-byte write instead of
     // 104 threads doing scalar LDS gathers.  The action part of the next input is pre-normalised once.
-    const bool rew_inline0 = (p.reward_kind != REW_PENDULUM) && S > 17;
-    const bool fast_epi = rew_inline0 && (S & 3) == 0 && S <= 64 && (S + U) <= K0G * 4;
+    const bool rew_none = p.reward_kind == REW_NONE;          // a user reward function scores the recorded trajectory afterwards
+    const bool rew_inline0 = (p.reward_kind == REW_CHEETAH) && S > 17;
+    const bool fast_epi = (rew_inline0 || rew_none) && (S & 3) == 0 && S <= 64 && (S + U) <= K0G * 4;
     const int SG = S >> 2, AG = K0G - SG;
     if (fast_epi) {
         for (int e = tid; e < H * AG * 16; e += NT) {
@@ -978,7 +981,7 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
     // HalfCheetah reward (cost_func.py:5-22) needs only cur[5..7], cur[17], nxt[17] and the action: the epilogue
     // thread of output feature 17 accumulates it in place (same operation order as reward_generic); any other
     // reward goes through reward_generic on threads 0..3.
-    const bool rew_inline = (p.reward_kind != REW_PENDULUM) && S > 17;
+    const bool rew_inline = (p.reward_kind == REW_CHEETAH) && S > 17;
     float total = 0.0f;                                   // rew_inline: thread (feature 17, particle pp); else threads 0..3
 #ifdef BBMPC_KERNEL_DBG
     long long dbg_acc[6] = {0, 0, 0, 0, 0, 0}, dbg_t0 = 0;
@@ -1106,7 +1109,9 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
                     if (cur4.w >= 0.0f) fl = fl + (-10.0f);            // cur[7]
                     const float f0 = __builtin_amdgcn_readlane(fl, 4), f1 = __builtin_amdgcn_readlane(fl, 5),
                                 f2 = __builtin_amdgcn_readlane(fl, 6), f3 = __builtin_amdgcn_readlane(fl, 7);
-                    if ((lane >> 2) == 4) {
+                    if (q.traj && n0 + pl < p.n_pop)       // state after step t, features 4g..4g+3 of my particle
+                        *reinterpret_cast<f32x4*>(q.traj + ((((size_t)t * p.A + a) * p.Nst) + n0 + pl) * S + 4 * (lane >> 2)) = v4;
+                    if (!rew_none && (lane >> 2) == 4) {
                         float r = (pl == 0) ? f0 : (pl == 1) ? f1 : (pl == 2) ? f2 : f3;
                         r = r + (v4.y - cur4.y) / 0.01f;               // (nxt[17] - cur[17]) / 0.01
                         r = r - zs[t * QP + pl];
@@ -1140,6 +1145,7 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
                 const float ck = cur[pp * Sp + k];
                 v = dev + ck;
                 nxt[pp * Sp + k] = v;
+                if (q.traj && n0 + pp < p.n_pop) q.traj[((((size_t)t * p.A + a) * p.Nst) + n0 + pp) * S + k] = v;
                 if (rew_inline && k == 17) {
                     const float c5 = cur[pp * Sp + 5], c6 = cur[pp * Sp + 6], c7 = cur[pp * Sp + 7];
                     const float* ac = acts + (t * QP + pp) * U;

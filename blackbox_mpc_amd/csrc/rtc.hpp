@@ -92,6 +92,33 @@ extern "C" __global__ void bbmpc_user_reward_rows(const float* __restrict__ cur,
     const float r = bbmpc_user_reward(c, a, n, BBMPC_S, BBMPC_U);
     total[b] = accumulate ? total[b] + r : r;
 }
+
+// The learned MLP's rollouts run on the matrix cores (kernels_mlp.hpp) and leave the state after every step in
+// traj [H][A][Nst][S]; this scores the whole trajectory of one candidate per lane: sum_t r(s_t, a_t, s_t+1), NaN -> -1e6
+// (deterministic.py:62-77).  `rewards` holds -(penalty) from the rollout kernel (0 without one): R - penalty.
+extern "C" __global__ void bbmpc_user_reward_traj(int n_pop, int A, int H, int Nst, int from_ref,
+                                                  const float* __restrict__ state, const float* __restrict__ traj,
+                                                  const float* __restrict__ seq, const float* __restrict__ cand,
+                                                  float* __restrict__ rewards) {
+    const int a = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_pop) return;
+    const int HU = H * BBMPC_U;
+    float c[BBMPC_S], nx[BBMPC_S], ac[BBMPC_U];
+    for (int i = 0; i < BBMPC_S; ++i) c[i] = state[a * BBMPC_S + i];
+    float total = 0.0f;
+    for (int t = 0; t < H; ++t) {
+        const float* row = traj + ((((size_t)t * A + a) * Nst) + n) * BBMPC_S;
+        for (int i = 0; i < BBMPC_S; ++i) nx[i] = row[i];
+        for (int u = 0; u < BBMPC_U; ++u) {
+            const int j = t * BBMPC_U + u;
+            ac[u] = from_ref ? seq[((size_t)n * A + a) * HU + j] : cand[((size_t)a * HU + j) * Nst + n];
+        }
+        total = total + bbmpc_user_reward(c, ac, nx, BBMPC_S, BBMPC_U);
+        for (int i = 0; i < BBMPC_S; ++i) c[i] = nx[i];
+    }
+    if (total != total) total = -1.0e6f;
+    rewards[(size_t)a * Nst + n] = total + rewards[(size_t)a * Nst + n];
+}
 )RTC";
     } else {
         s += R"RTC(
@@ -235,10 +262,12 @@ struct UserFunction {
     std::string source;
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
+    hipFunction_t fn_traj = nullptr;       // reward module only: bbmpc_user_reward_traj
     void release() {
         if (module) (void)hipModuleUnload(module);
         module = nullptr;
         fn = nullptr;
+        fn_traj = nullptr;
     }
 };
 

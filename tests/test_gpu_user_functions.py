@@ -158,6 +158,33 @@ def test_user_reward_over_the_learned_model_agrees_with_the_fused_path(L):
     np.testing.assert_allclose(user.evaluate(states, seq), fused.evaluate(states, seq), rtol=1e-3, atol=1e-3 * H)
 
 
+@pytest.mark.parametrize("opt_name", ["CEM", "PI2", "PSO"])
+def test_optimizers_with_user_reward_over_the_learned_model(L, opt_name):
+    # the common "blackbox" case: learned MLP dynamics, custom reward.  The user's restatement of the cheetah reward must
+    # drive the optimizers exactly like the built-in one (same draws; selection steps stay in step because the rewards
+    # agree to rounding -- both sides run the same MFMA dynamics)
+    from blackbox_mpc_amd.engine import Engine
+    S, U, A, H, N, iters, k = 20, 6, 2, 15, 400, 3, 40
+    ws, bs = O.make_mlp_params([26, 200, 200, 20], seed=42)
+    stats = [np.zeros(S, F), np.ones(S, F), np.zeros(U, F), np.ones(U, F), np.zeros(S, F), np.full(S, 0.1, F)]
+    opt = {"CEM": L.OPT_CEM, "PI2": L.OPT_PI2, "PSO": L.OPT_PSO}[opt_name]
+    mk = lambda rew: Engine(opt, L.DYN_MLP, rew, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=A, planning_horizon=H,
+                            population_size=N, max_iterations=iters, num_elite=k, seed=77, lamda=1.0)
+    user, ref = mk(L.REW_USER), mk(L.REW_CHEETAH)
+    for e in (user, ref):
+        e.set_mlp(ws, bs, [1, 1, 0], stats)
+        e.reset()
+    user.set_reward_source(USER_CHEETAH_REWARD)
+    s_u = s_r = O.cheetah_start_states(A, S)
+    for t in range(3):
+        a_u, n_u, r_u = user.optimize(s_u, t)
+        a_r, n_r, r_r = ref.optimize(s_r, t)
+        np.testing.assert_allclose(a_u, a_r, rtol=0, atol=2e-3)
+        np.testing.assert_allclose(n_u, n_r, rtol=0, atol=2e-3)
+        np.testing.assert_allclose(r_u, r_r, rtol=1e-3, atol=0.3)        # (s'17 - s17)/0.01 amplifies the state tolerance x100
+        s_u, s_r = n_u, n_r
+
+
 @pytest.mark.parametrize("opt_name", ["RandomSearch", "CEM", "PI2", "PSO", "SPSA", "CMA-ES"])
 def test_optimizers_on_user_functions_walk_in_step_with_the_builtin_path(L, monkeypatch, opt_name):
     # the user-function engine (step-wise evaluator) against the built-in per-iteration engine with the op-for-op

@@ -51,6 +51,41 @@ def main():
         e.set_reward_source(INTENDED_PENDULUM_REWARD)
         e.set_dynamics_source(USER_PENDULUM_MODEL)
         out[name] = rate(e, start, 100)
+    # the common case: learned MLP dynamics + a custom reward (HalfCheetah MLP, CEM N=1000 H=30 5 iterations)
+    from test_gpu_user_functions import USER_CHEETAH_REWARD
+    S, U = 20, 6
+    kw = dict(dim_s=S, num_agents=1, planning_horizon=30, population_size=1000, max_iterations=5, num_elite=50)
+    cstart = SY.cheetah_start_states(1)
+
+    def cheetah(rew, env=None):
+        if env:
+            os.environ["BBMPC_USER_STEPWISE"] = env
+        e = Engine(L.OPT_CEM, L.DYN_MLP, rew, [-1.0] * U, [1.0] * U, **kw)
+        os.environ.pop("BBMPC_USER_STEPWISE", None)
+        e.set_mlp(*SY.make_mlp_params(), [1, 1, 0], SY.cheetah_stats(S, U))
+        if rew == L.REW_USER:
+            e.set_reward_source(USER_CHEETAH_REWARD)
+        return e
+
+    def rate27(eng, steps):
+        import torch
+        dev = torch.device("cuda", 0)
+        st = torch.from_numpy(cstart).to(dev)
+        nx = torch.empty_like(st)
+        rec = torch.zeros((1, 27), device=dev)
+        for _ in range(5):
+            eng.optimize_dev(st.data_ptr(), rec.data_ptr(), d_next_state=nx.data_ptr())
+            st, nx = nx, st
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.optimize_dev(st.data_ptr(), rec.data_ptr(), d_next_state=nx.data_ptr())
+            st, nx = nx, st
+        eng.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e6
+    out["MLP + built-in cheetah reward (4-particle MFMA kernel)"] = rate27(cheetah(L.REW_CHEETAH), 100)
+    out["MLP + user reward: MFMA rollout records the trajectory, one scoring launch"] = rate27(cheetah(L.REW_USER), 100)
+    out["MLP + user reward, step-wise"] = rate27(cheetah(L.REW_USER, "1"), 20)
     for k, v in out.items():
         print("| %s | %.1f |" % (k, v))
 
