@@ -46,15 +46,34 @@ __device__ __forceinline__ const float* row_mlp_forward(const RowMlp& q, const f
             const int g = t / Mr, o = t - g * Mr;
             if (o < M) {
                 const int k0 = g * Kc, k1 = min(K, k0 + Kc);
+                // a K-slice is one L2 round trip per batch of loads: 16 weights in flight per lane (a 50-term slice is four
+                // trips instead of thirteen), four accumulators
                 float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
                 int k = k0;
-                for (; k + 3 < k1; k += 4) {
-                    acc0 = fmaf(in[k], W[(size_t)k * M + o], acc0);
-                    acc1 = fmaf(in[k + 1], W[(size_t)(k + 1) * M + o], acc1);
-                    acc2 = fmaf(in[k + 2], W[(size_t)(k + 2) * M + o], acc2);
-                    acc3 = fmaf(in[k + 3], W[(size_t)(k + 3) * M + o], acc3);
+                for (; k + 15 < k1; k += 16) {
+                    float w[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) w[i] = W[(size_t)(k + i) * M + o];
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) {
+                        acc0 = fmaf(in[k + i], w[i], acc0);
+                        acc1 = fmaf(in[k + i + 1], w[i + 1], acc1);
+                        acc2 = fmaf(in[k + i + 2], w[i + 2], acc2);
+                        acc3 = fmaf(in[k + i + 3], w[i + 3], acc3);
+                    }
                 }
-                for (; k < k1; ++k) acc0 = fmaf(in[k], W[(size_t)k * M + o], acc0);
+                {
+                    float w[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) w[i] = (k + i < k1) ? W[(size_t)(k + i) * M + o] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) {
+                        acc0 = fmaf((k + i < k1) ? in[k + i] : 0.0f, w[i], acc0);
+                        acc1 = fmaf((k + i + 1 < k1) ? in[k + i + 1] : 0.0f, w[i + 1], acc1);
+                        acc2 = fmaf((k + i + 2 < k1) ? in[k + i + 2] : 0.0f, w[i + 2], acc2);
+                        acc3 = fmaf((k + i + 3 < k1) ? in[k + i + 3] : 0.0f, w[i + 3], acc3);
+                    }
+                }
                 part[g * TAIL_MAXW + o] = (acc0 + acc1) + (acc2 + acc3);
             }
         }
