@@ -1,7 +1,11 @@
 """Custom reward / dynamics functions (the reference accepts any TF callable, trajectory_evaluators/deterministic.py:13-18).
 Here they are HIP device code compiled at run time: a cart-like double integrator steered to the origin with CEM."""
+import os
+import sys
+
 import numpy as np
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from blackbox_mpc_amd.policies import MPCPolicy
 from blackbox_mpc_amd.spaces import Box
 from blackbox_mpc_amd.utils.device_functions import HipDynamicsFunction, HipRewardFunction
