@@ -199,3 +199,25 @@ def test_sequence_number_wrap(L, monkeypatch):
     for t in range(14):
         np.testing.assert_array_equal(got[t].view(np.int32), ref[t].view(np.int32))
         np.testing.assert_array_equal(got_g[t].view(np.int32), got[t].view(np.int32))
+
+
+def test_handles_on_two_devices_in_one_process():
+    # every entry point runs under a device guard -- handles on different GPUs in one process, and the
+    # caller's current device is left as it was.  Needs two GPUs (skipped on the one-GPU test box).
+    import torch
+    from blackbox_mpc_amd import _lib as L
+    from blackbox_mpc_amd.engine import Engine
+    from oracle import oracle_np as O
+    if L.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    torch.cuda.set_device(0)
+    mk = lambda dev: Engine(L.OPT_CEM, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=2,
+                            planning_horizon=10, population_size=128, max_iterations=2, num_elite=16, seed=3, device=dev)
+    e0, e1 = mk(0), mk(1)
+    assert torch.cuda.current_device() == 0
+    s = O.pendulum_start_states(2)
+    a0 = e0.optimize(s)[0]
+    a1 = e1.optimize(s)[0]                    # lazy allocations / launches of the second handle under device 1
+    assert torch.cuda.current_device() == 0
+    np.testing.assert_array_equal(a0, a1)     # same seed, same inputs: the device does not matter
+    np.testing.assert_array_equal(e0.optimize(s)[0], e1.optimize(s)[0])

@@ -96,3 +96,19 @@ def test_sharded_equals_unsharded_gloo_world2(A):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_sharded_policy_rejects_more_ranks_than_agents():
+    # a rank without agents has no record layout: refused at construction, before any collective is joined
+    from blackbox_mpc_amd.parallel import ShardedMPCPolicy, population_shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        with pytest.raises(ValueError, match="world_size"):
+            ShardedMPCPolicy(lambda off, cnt, tot: None, num_agents_global=0)
+    finally:
+        dist.destroy_process_group()
+    assert population_shard(1000, 4, 3) == (750, 250)
+    with pytest.raises(ValueError):
+        population_shard(1000, 3, 0)
