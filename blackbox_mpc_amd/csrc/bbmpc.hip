@@ -696,11 +696,10 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     if (lds > 64 * 1024) ensure_max_lds(fn, 159 * 1024);
     // pair mode (two tiles per workgroup, software-pipelined) when there are more tiles than CUs can hold one each
     const long tiles_total = (long)((ra.n_pop + MLP_TP - 1) / MLP_TP) * A;
-    // the 26-200-200-20 tanh/tanh/linear family has its own kernels; trajectory recording exists in the quad kernel and in
-    // the generic 16-particle tiling, not in the pipelined pair kernel
+    // the 26-200-200-20 tanh/tanh/linear family has its own kernels (all of them can record the trajectory)
     const bool fam_ok = spec == 1 && mlp.tiles[1] == 13 && !per_particle_state && mlp.act[0] == BBMPC_ACT_TANH &&
                         mlp.act[1] == BBMPC_ACT_TANH && mlp.act[2] == BBMPC_ACT_NONE;
-    const bool pair_ok = fam_ok && !record;
+    const bool pair_ok = fam_ok;
     int pair = (pair_ok && tiles_total > 256) ? 1 : 0;
     if (sw.mlp_pair >= 0) pair = (sw.mlp_pair != 0 && pair_ok) ? 1 : 0;
     // quad mode (4 particles per workgroup, 4x4x1_16b MFMA, all weights in registers) when the population is too

@@ -690,6 +690,10 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             const float c17 = cur[epp * Sp + ef];
             v = dev + c17;
             if (e_live) nxt[epp * Sp + ef] = v;
+            if (q.traj && e_live) {                                  // state after step t (a user reward scores it afterwards)
+                const int n = (blockIdx.x * NTILES + ti) * MLP_TP + epp;
+                if (n < p.n_pop) q.traj[((((size_t)t * p.A + a) * p.Nst) + n) * S + ef] = v;
+            }
             if (rew_inline && ef == 17) {
                 const float c5 = cur[epp * Sp + 5], c6 = cur[epp * Sp + 6], c7 = cur[epp * Sp + 7];
                 const float* ac = T_acts(ti) + (t * MLP_TP + epp) * U;

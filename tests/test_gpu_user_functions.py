@@ -158,6 +158,26 @@ def test_user_reward_over_the_learned_model_agrees_with_the_fused_path(L):
     np.testing.assert_allclose(user.evaluate(states, seq), fused.evaluate(states, seq), rtol=1e-3, atol=1e-3 * H)
 
 
+def test_user_reward_over_the_learned_model_large_population(L, user_rollout_form):
+    # 6000 rows per launch: the pipelined two-tile MFMA kernel records the trajectory (the quad kernel covers <= 2048)
+    if user_rollout_form == "stepwise":
+        pytest.skip("same arithmetic as the small-population test; the step-wise form needs 2H launches of 6000 rows")
+    from blackbox_mpc_amd.engine import Engine
+    S, U, A, H, N = 20, 6, 2, 20, 3000
+    ws, bs = O.make_mlp_params([26, 200, 200, 20], seed=42)
+    stats = [np.zeros(S, F), np.ones(S, F), np.zeros(U, F), np.ones(U, F), np.zeros(S, F), np.full(S, 0.1, F)]
+    mk = lambda rew: Engine(L.OPT_NONE, L.DYN_MLP, rew, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=A, planning_horizon=H)
+    user, fused = mk(L.REW_USER), mk(L.REW_CHEETAH)
+    for e in (user, fused):
+        e.set_mlp(ws, bs, [1, 1, 0], stats)
+    user.set_reward_source(USER_CHEETAH_REWARD)
+    rng = np.random.default_rng(17)
+    states = O.cheetah_start_states(A, S)
+    seq = rng.uniform(-1, 1, (N, A, H, U)).astype(F)
+    got, ref = user.evaluate(states, seq), fused.evaluate(states, seq)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-3)         # same dynamics kernel, same reward arithmetic
+
+
 @pytest.mark.parametrize("opt_name", ["CEM", "PI2", "PSO"])
 def test_optimizers_with_user_reward_over_the_learned_model(L, opt_name):
     # the common "blackbox" case: learned MLP dynamics, custom reward.  The user's restatement of the cheetah reward must
