@@ -110,7 +110,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         N = 0;
     }
     if (c.optimizer == BBMPC_OPT_CEM || c.optimizer == BBMPC_OPT_CMAES)
-        REQUIRE(k >= 1 && k <= N, BBMPC_E_INVALID, "num_elite must be in [1, population_size]");
+        REQUIRE(k >= 1 && k <= std::max(N, (int)c.population_global), BBMPC_E_INVALID, "num_elite must be in [1, population_size]");
     if (c.optimizer == BBMPC_OPT_CEM) REQUIRE(k <= 1024, BBMPC_E_UNSUPPORTED, "num_elite > 1024 not supported");
     if (c.optimizer == BBMPC_OPT_CMAES) {
         const bool per_agent = (c.quirks & BBMPC_CMAES_PER_AGENT) != 0;
@@ -127,8 +127,8 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         REQUIRE(c.population_global >= N && c.population_offset >= 0 && c.population_offset + N <= c.population_global, BBMPC_E_INVALID,
                 "population_offset / population_global: this handle's particles must lie inside the global population");
         if (c.population_global > N)
-            REQUIRE(c.optimizer == BBMPC_OPT_PI2, BBMPC_E_UNSUPPORTED,
-                    "population sharding is built for PI2 (min / sum reductions, pi2.py:80-87); CEM needs a top-k merge");
+            REQUIRE(c.optimizer == BBMPC_OPT_PI2 || c.optimizer == BBMPC_OPT_CEM, BBMPC_E_UNSUPPORTED,
+                    "population sharding is built for PI2 (min / sum reductions, pi2.py:80-87) and CEM (top-k merge, cem.py:97-112)");
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -160,7 +160,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.mlp_no_half_tail = flag("BBMPC_MLP_NO_HALF_TAIL");
         sw.dbg = flag("BBMPC_DBG");
         user_stepwise_only = flag("BBMPC_USER_STEPWISE");
-        if (c.optimizer == BBMPC_OPT_PI2) {
+        if (c.optimizer == BBMPC_OPT_PI2 || c.optimizer == BBMPC_OPT_CEM) {
             ps_loopback = ival("BBMPC_POPSHARD_LOOPBACK", 0);
             ps_force = flag("BBMPC_POPSHARD_FORCE");
         }
@@ -1375,6 +1375,42 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
             for (int it = 0; it < iters; ++it) {
                 ra.stream = BBMPC_NOISE_TRUNC_NORMAL; ra.iter = (uint32_t)it;
                 ra.inj = inj_t ? inj_t + inj_stride * it : nullptr;
+                if (pop_sharded()) {
+                    // population sharded over ranks: local top-k + rows, one exchange, global top-k + refit
+                    const int G = ps_loopback > 1 ? ps_loopback : std::max(1, rc.comm ? rc.nranks : 1);
+                    const size_t pw = (size_t)A * k * (HU + 2);
+                    if (!ps_part.p) ps_part.alloc(pw);
+                    if (ps_all.n < pw * G) ps_all.alloc(pw * G);
+                    const size_t tl = (size_t)fixed * 4;
+                    want_lds((const void*)k_cem_local_topk, tl);
+                    RefitArgs rfs = rf;
+                    if (!trace_on) rfs.elites = nullptr;
+                    if (ps_loopback > 1) {
+                        for (int r = 0; r < G; ++r) {
+                            ra.pop_offset = r * N;
+                            launch_rollout(SRC_TRUNC, false, ra);
+                            hipLaunchKernelGGL(k_cem_local_topk, dim3(A), dim3(1024), tl, stream, rf, r * N, ps_all.p + pw * r);
+                        }
+                        ra.pop_offset = cfg.population_offset;
+                    } else {
+                        launch_rollout(SRC_TRUNC, false, ra);
+                        hipLaunchKernelGGL(k_cem_local_topk, dim3(A), dim3(1024), tl, stream, rf, (int)cfg.population_offset, ps_part.p);
+                        if (rc.comm) {
+                            const Rccl& r = Rccl::get();
+                            r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (CEM local elites)");
+                        } else {
+                            REQUIRE(cfg.population_global <= N, BBMPC_E_STATE, "population sharding needs a communicator: call bbmpc_comm_init first");
+                            HIP_CHECK(hipMemcpyAsync(ps_all.p, ps_part.p, pw * 4, hipMemcpyDeviceToDevice, stream));
+                        }
+                    }
+                    HIP_CHECK(hipGetLastError());
+                    const size_t ml = ((size_t)2 * G * k + k) * 4;
+                    want_lds((const void*)k_cem_merge, ml);
+                    hipLaunchKernelGGL(k_cem_merge, dim3(A), dim3(256), ml, stream, rfs, ps_all.p, G);
+                    HIP_CHECK(hipGetLastError());
+                    capture_trace(it);
+                    continue;
+                }
                 launch_rollout(SRC_TRUNC, false, ra);
                 if (k <= 64 && !sw.refit_v1) {
                     const int rthreads = N > 512 ? 1024 : (N > 256 ? 512 : 256);

@@ -322,4 +322,88 @@ __global__ void k_refit_pi2_merge(RefitArgs p, const float* gathered, int G) {
     if (j < p.U) p.action[a * p.U + j] = m;
 }
 
+// ---- CEM refit with the population sharded over ranks --------------------------------------------
+// cem.py:97-125 split: every rank ships its LOCAL top-k per agent -- (reward, GLOBAL particle index, the H*U sample row)
+// -- in one all-gather; every rank then takes the global top-k of the G*k candidates (larger reward first, ties ->
+// lower global index: tf.nn.top_k's rule on the unsharded population) and refits mean / variance from the gathered
+// rows.  The global elite SET is exactly the unsharded one (a global winner is always a local winner of its rank);
+// only the order of the fp32 sums differs.  cand layout per agent: [k][HU + 2] = (reward | global index as float bits |
+// row); slots a short shard cannot fill carry reward -inf.
+// k_cem_local_topk: grid A, block 1024.  LDS: rewards[Nst] | eidx[kpad] | hist | ekeys[2*kpad]
+__global__ __launch_bounds__(1024) void k_cem_local_topk(RefitArgs p, int pop_offset, float* cand) {
+    extern __shared__ float smem[];
+    const int a = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    float* r = smem;
+    int* eidx = (int*)(smem + p.Nst);
+    const int kpad = (p.k + 3) & ~3;
+    uint32_t* hist = (uint32_t*)(eidx + kpad);
+    unsigned long long* ekeys = (unsigned long long*)(hist + TOPK_HIST_WORDS);
+    for (int n = tid; n < p.N; n += nthr) r[n] = p.rewards[(size_t)a * p.Nst + n];
+    __syncthreads();
+    const int kk = min(p.k, p.N);
+    block_topk_sorted(r, p.N, kk, eidx, hist, ekeys, tid, nthr);
+    const int W = p.HU + 2;
+    float* out = cand + (size_t)a * p.k * W;
+    for (int i = tid; i < p.k * W; i += nthr) {
+        const int e = i / W, c = i - e * W;
+        float v;
+        if (e >= kk) v = c == 0 ? -INFINITY : 0.0f;
+        else if (c == 0) v = r[eidx[e]];
+        else if (c == 1) v = __int_as_float(pop_offset + eidx[e]);
+        else v = p.samples[(size_t)(a * p.HU + (c - 2)) * p.Nst + eidx[e]];
+        out[i] = v;
+    }
+}
+
+// gathered: [G][A][k][HU+2].  grid A, block 256.  LDS: key rewards[G*k] | global idx[G*k] | chosen slot[k]
+__global__ __launch_bounds__(256) void k_cem_merge(RefitArgs p, const float* gathered, int G) {
+    extern __shared__ float smem[];
+    const int a = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int W = p.HU + 2, M = G * p.k;
+    float* cr = smem;
+    int* ci = (int*)(smem + M);
+    int* chosen = ci + M;                                    // chosen[rank] = candidate slot, rank < k
+    const size_t rstride = (size_t)p.A * p.k * W;
+    auto slot_ptr = [&](int m) { return gathered + (size_t)(m / p.k) * rstride + ((size_t)a * p.k + (m % p.k)) * W; };
+    for (int m = tid; m < M; m += nthr) {
+        const float* s = slot_ptr(m);
+        cr[m] = s[0];
+        ci[m] = __float_as_int(s[1]);
+    }
+    __syncthreads();
+    for (int m = tid; m < M; m += nthr) {                    // rank by counting: better = larger reward, then lower global index
+        const float rm = cr[m];
+        const int im = ci[m];
+        int rank = 0;
+        for (int o = 0; o < M; ++o) {
+            const float ro = cr[o];
+            rank += (ro > rm || (ro == rm && (ci[o] < im || (ci[o] == im && o < m)))) ? 1 : 0;
+        }
+        if (rank < p.k) chosen[rank] = m;
+    }
+    __syncthreads();
+    const float kf = (float)p.k, one_m = 1.0f - p.alpha;
+    if (p.elites)
+        for (int e = tid; e < p.k; e += nthr) p.elites[a * p.k + e] = ci[chosen[e]];        // GLOBAL indices, best first
+    for (int j = tid; j < p.HU; j += nthr) {
+        float sum = 0.0f;
+        for (int e = 0; e < p.k; ++e) sum = sum + slot_ptr(chosen[e])[2 + j];
+        const float em = sum / kf;                                           // cem.py:112
+        float vs = 0.0f;
+        for (int e = 0; e < p.k; ++e) {
+            const float d = slot_ptr(chosen[e])[2 + j] - em;
+            vs = vs + d * d;
+        }
+        const float ev = vs / kf;                                            // :113-119 (biased)
+        const int aj = a * p.HU + j;
+        const float m = p.alpha * p.mean[aj] + one_m * em;                   // :121-122
+        const float v = p.alpha * p.var[aj] + one_m * ev;                    // :123-125
+        p.mean[aj] = m;
+        p.var[aj] = v;
+        const int u = j % p.U;
+        p.sigma[aj] = cem_sigma(m, v, p.lo[u], p.hi[u]);
+        if (j < p.U) p.action[a * p.U + j] = m;                              // mean[:, 0]  cem.py:135
+    }
+}
+
 }  // namespace bbmpc
