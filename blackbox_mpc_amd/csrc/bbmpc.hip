@@ -149,6 +149,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.cma_svd_v1 = flag("BBMPC_CMA_SVD_V1"); sw.cma_svd_rounds = flag("BBMPC_CMA_SVD_ROUNDS");
         sw.cma_svd_general = flag("BBMPC_CMA_SVD_GENERAL");
         sw.cma_svd_gram = flag("BBMPC_CMA_SVD_GRAM");
+        sw.cma_fused = flag("BBMPC_CMA_FUSED");
         sw.mlp_generic = flag("BBMPC_MLP_GENERIC");
         { const int b = ival("BBMPC_MLP_BF16", 0); sw.mlp_bf16 = (b == 1 || b == 3) ? b : 0; }
         sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1);
@@ -1318,6 +1319,11 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
         optimize_fused_pso(d_state_in, add_noise, d_record_out, d_next_out, step);
         return;
     }
+    if (use_fused_cma()) {
+        dominant_kernel = "k_fused_cma_pendulum";
+        optimize_fused_cma(d_state_in, add_noise, d_record_out, d_next_out, step);
+        return;
+    }
     dominant_kernel = "k_rollout_pendulum";
     RolloutArgs ra;
     memset(&ra, 0, sizeof(ra));
@@ -1502,6 +1508,50 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
             throw HipError(BBMPC_E_UNSUPPORTED, "optimizer not built yet");
     }
     finalize(d_state_in, add_noise, d_record_out, d_next_out, step);
+}
+
+// CMA-ES on the analytic pendulum in one launch per control step when the search dimension is small (kernels_fused_cma.hpp)
+bool Engine::use_fused_cma() const {
+    if (cfg.optimizer != BBMPC_OPT_CMAES || cfg.dynamics != BBMPC_DYN_PENDULUM || cfg.reward != BBMPC_REW_PENDULUM) return false;
+    // opt-in: measured no faster than the per-iteration kernels (both are bound by the Jacobi sweeps)
+    if (!sw.cma_fused || fused_mode == 0 || trace_on) return false;      // the parity trace is captured between the per-iteration kernels
+    if (sw.cma_svd_v1 || sw.cma_svd_rounds || sw.cma_svd_general) return false;
+    return cma_G == A && cma_n <= 64 && N <= 1024 && k <= 1024;
+}
+
+void Engine::optimize_fused_cma(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step) {
+    FusedCmaArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.q = cma_args(step, 0u);
+    fa.iters = iters; fa.H = H;
+    fa.inj = injected(BBMPC_NOISE_NORMAL);
+    fa.inj_stride = (size_t)A * HU * Nst;
+    fa.evec = c_evec.p; fa.eval = c_eval.p; fa.info = c_info.p;
+    FinalArgs& fin = fa.fin;
+    fin.A = A; fin.U = U; fin.S = S;
+    fin.agent_offset = cfg.agent_offset;
+    fin.fix_q1 = fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
+    fin.fix_q7 = fix(BBMPC_FIX_Q7_EXPL_NOISE_ZERO_MEAN);
+    fin.add_noise = add_noise;
+    fin.state = d_state_in;
+    fin.action = d_action.p;
+    fin.lo = d_lo.p; fin.hi = d_hi.p;
+    fin.inj = injected(BBMPC_NOISE_EXPLORATION);
+    fin.record = d_record_out;
+    fin.next_state = d_next_out;
+    fin.key = key(step);
+    fin.key.q_per_agent = (uint32_t)((U + 3) / 4);
+    if (tail_flag) {
+        fa.done_flag = tail_flag; fa.done_count = tail_count; fa.done_value = tail_value;
+        tail_attached = true;
+    }
+    const int kp = (k + 3) & ~3;
+    const size_t lds = std::max((size_t)(Nst + TOPK_HIST_WORDS + 2 * kp) * 4, (size_t)cma_n * cma_n * 4);
+    prof_begin();
+    if (!fix(BBMPC_STRICT_MATH)) launch_with_tail(*this, k_fused_cma_pendulum<true>, dim3(cma_G), dim3(1024), lds, fa);
+    else launch_with_tail(*this, k_fused_cma_pendulum<false>, dim3(cma_G), dim3(1024), lds, fa);
+    HIP_CHECK(hipGetLastError());
+    prof_end();
 }
 
 // SPSAOptimizer._optimize  spsa.py:61-117
@@ -2209,7 +2259,9 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
     // single-kernel control steps read the state straight from the pinned, device-mapped host buffer; those and the
     // learned-dynamics path (whose last kernel, k_tail_mlp, owns the record) write the packed record straight into it
     const bool fused_step = e.sw.zero_copy && e.use_fused();
-    const bool mlp_tail = e.sw.zero_copy && !fused_step && e.cfg.dynamics == BBMPC_DYN_MLP && e.cfg.optimizer != BBMPC_OPT_NONE;
+    // (the fused small-n CMA-ES kernel is in the same position: many threads read the state, its last thread owns the record)
+    const bool mlp_tail = e.sw.zero_copy && !fused_step && e.cfg.optimizer != BBMPC_OPT_NONE &&
+                          (e.cfg.dynamics == BBMPC_DYN_MLP || e.use_fused_cma());
     if (fused_step || mlp_tail) {
         // the persistent kernel reads the [A,S] state and writes the packed record straight from / to the pinned,
         // device-mapped host buffer (a few PCIe transactions) -- no copy-engine round trips around a ~50 us kernel

@@ -16,6 +16,7 @@
 #include "comm.hpp"
 #include "kernels_cma.hpp"
 #include "kernels_fused.hpp"
+#include "kernels_fused_cma.hpp"
 #include "kernels_fused_pso.hpp"
 #include "kernels_mlp.hpp"
 #include "kernels_opt.hpp"
@@ -83,7 +84,7 @@ struct Engine {
     int fused_mode = -1;     // -1 auto, 0 never, 1 always (env BBMPC_FUSED)
     // development / parity switches, read from the environment ONCE when the handle is created
     struct Switches {
-        bool cma_svd_v1 = false, cma_svd_rounds = false, cma_svd_general = false, cma_svd_gram = false;   // BBMPC_CMA_SVD_V1 / _ROUNDS / _GENERAL
+        bool cma_svd_v1 = false, cma_svd_rounds = false, cma_svd_general = false, cma_svd_gram = false, cma_fused = false;   // BBMPC_CMA_SVD_V1 / _ROUNDS / _GENERAL
         bool mlp_generic = false;      // BBMPC_MLP_GENERIC
         int mlp_bf16 = 0;              // BBMPC_MLP_BF16: 0 off (default, fp32), 1 plain bf16 inputs, 3 split bf16 (hi+lo, three products)
         int mlp_pair = -1, mlp_q4 = -1;   // BBMPC_MLP_PAIR / BBMPC_MLP_Q4: -1 automatic, 0 / 1 forced
@@ -206,6 +207,8 @@ struct Engine {
     void optimize_dev(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out);
     bool use_fused_pso() const;
     void optimize_fused_pso(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step);
+    bool use_fused_cma() const;
+    void optimize_fused_cma(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step);
     bool use_fused() const;
     void optimize_fused(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step);
     void ensure_trace();

@@ -117,9 +117,8 @@ __global__ __launch_bounds__(256) void k_cma_gemm_y(CmaArgs p) {
 }
 
 // per group: (sum of) rewards -> sorted top-k.   LDS: rsum[Nst] | hist | ekeys[kp]
-__global__ __launch_bounds__(REFIT_THREADS) void k_cma_select(CmaArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int g = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void cma_select_body(const CmaArgs& p, int g, float* smem) {
+    const int tid = threadIdx.x;
     float* rs = smem;
     uint32_t* hist = (uint32_t*)(rs + p.Nst);
     unsigned long long* ekeys = (unsigned long long*)(hist + TOPK_HIST_WORDS);
@@ -134,17 +133,21 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_cma_select(CmaArgs p) {
     block_topk_sorted(rs, p.N, p.k, eidx_s, hist, ekeys, tid, REFIT_THREADS);   // argsort DESCENDING, first k
     for (int e = tid; e < p.k; e += REFIT_THREADS) p.eidx[g * p.k + e] = eidx_s[e];
 }
+__global__ __launch_bounds__(REFIT_THREADS) void k_cma_select(CmaArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    cma_select_body(p, blockIdx.x, smem);
+}
 
 // per group: elite deviations, weighted mean step, evolution paths, step size, new mean
 // (cma_es.py:161-177).  One workgroup per group; threads stride the n coordinates.
-__global__ __launch_bounds__(1024) void k_cma_paths(CmaArgs p) {
+__device__ __forceinline__ void cma_paths_body(const CmaArgs& p, int g) {
     // blockDim: any multiple of 64 up to 1024.  The loops keep several independent loads in flight and the row-wise
     // product runs one wave per row (coalesced), instead of one L2 latency per term of an n-term sum.
     __shared__ float red[16];
     __shared__ float s_norm;
     __shared__ int s_el[REFIT_THREADS];
     __shared__ float s_w[REFIT_THREADS];
-    const int g = blockIdx.x, tid = threadIdx.x, n = p.n, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, NW = nthr >> 6;
+    const int tid = threadIdx.x, n = p.n, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, NW = nthr >> 6;
     const size_t off = (size_t)g * n;
     const float* __restrict__ X = p.cand + off * p.Nst;
     float* __restrict__ Ye = p.Ye + (size_t)g * p.k * n;
@@ -221,6 +224,7 @@ __global__ __launch_bounds__(1024) void k_cma_paths(CmaArgs p) {
         p.m[off + c] = p.m[off + c] + p.xmean[off + c];                    // :163
     }
 }
+__global__ __launch_bounds__(1024) void k_cma_paths(CmaArgs p) { cma_paths_body(p, blockIdx.x); }
 
 // C = (1-c1-cmu) C + c1 pC pC^T + cmu sum_i w_i y_i y_i^T on the upper triangle, mirrored (cma_es.py:179-190)
 // grid (ceil(n/16), ceil(n/16), G), block (16,16)
@@ -486,11 +490,11 @@ __global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_al
     }
 }
 
-__global__ __launch_bounds__(1024) void k_cma_svd_finish(CmaArgs p, const float* At_all, float* norms_all, int* perm_all) {
+__device__ __forceinline__ void cma_svd_finish_body(const CmaArgs& p, int g, const float* At_all, float* norms_all, int* perm_all) {
     // column norms = singular values; ranks by counting over an LDS copy of the norms (n <= 2048); B, D.  blockDim any multiple of 64
     __shared__ float s_norm[2048];
     __shared__ int s_perm[2048];
-    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n, nthr = blockDim.x, NW = nthr >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n, nthr = blockDim.x, NW = nthr >> 6;
     const size_t nn = (size_t)n * n;
     const float* At = At_all + (size_t)g * nn;
     float* norms = norms_all + (size_t)g * n;
@@ -518,6 +522,9 @@ __global__ __launch_bounds__(1024) void k_cma_svd_finish(CmaArgs p, const float*
         B[i] = (sv > 0.0f) ? At[(size_t)src * n + r] / sv : ((r == c) ? 1.0f : 0.0f);
     }
     for (int c = tid; c < n; c += nthr) p.Dd[(size_t)g * n + c] = sqrtf(s_norm[s_perm[c]]);   // D = diag(sqrt(s))
+}
+__global__ __launch_bounds__(1024) void k_cma_svd_finish(CmaArgs p, const float* At_all, float* norms_all, int* perm_all) {
+    cma_svd_finish_body(p, blockIdx.x, At_all, norms_all, perm_all);
 }
 
 // 16-byte write-through (sc0 sc1) accesses for blocks that travel between workgroups: the 4-byte scalar form costs ~6x
@@ -1033,10 +1040,10 @@ __global__ __launch_bounds__(1024) void k_cma_svd_gram(CmaArgs p, float* At_all,
 // instructions per wave + one barrier; the general kernels above spend ~1 us per round on predicated 512-wide code.
 // LDS: n*n floats.  blockDim = 64 * ceil(pairs / 4).  sync: [G][32] as above (sweep flags only).
 template <int EC>   // elements per lane: 4 (n <= 64) or 8 (n <= 128)
-__global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
-    extern __shared__ __attribute__((aligned(16))) float at_s[];
+__device__ __forceinline__ void cma_svd_small_body(const CmaArgs& p, int g, float* At_all, int max_sweeps, float* at_s) {
+    // any blockDim >= 64 * ceil(pairs / 4): 16-lane rows beyond the pair slots only take part in the barriers
     __shared__ int s_rot;
-    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
     float* At_g = At_all + (size_t)g * n * n;
     const float tol = fminf(fmaxf(3.0e-8f * (float)n, 2.0e-6f), 1.0e-5f);
     const int nc = (n + 15) >> 4;                              // elements per lane (<= 8: n <= 128)
@@ -1048,6 +1055,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all
         if (tid == 0) s_rot = 0;
         __syncthreads();
         for (int r = 0; r < m - 1; ++r) {
+            if (wv * 4 >= m / 2) { __syncthreads(); continue; }          // a wave without pair slots only keeps the barrier count
             int pa = 0, pb = 0;
             bool act = slot < m / 2;
             if (act) {
@@ -1092,7 +1100,12 @@ __global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all
     }
     __syncthreads();
     for (int i = tid; i < n * n; i += blockDim.x) At_g[i] = at_s[i];
+}
+template <int EC>
+__global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
+    extern __shared__ __attribute__((aligned(16))) float at_s[];
     (void)sync_all;
+    cma_svd_small_body<EC>(p, blockIdx.x, At_all, max_sweeps, at_s);
 }
 
 }  // namespace bbmpc

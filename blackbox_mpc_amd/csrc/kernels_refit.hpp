@@ -342,13 +342,11 @@ __device__ __forceinline__ float exploration_action(const FinalArgs& p, int a, i
     return clipf(act + noise, lo, hi);                            // :87-90
 }
 
-__global__ void k_finalize_pendulum(FinalArgs p) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= p.A) return;
+__device__ __forceinline__ void finalize_pendulum_agent(const FinalArgs& p, int a, float action_in) {
     const PendulumModel model{p.fix_q1 != 0};
     float s[3] = {p.state[a * 3 + 0], p.state[a * 3 + 1], p.state[a * 3 + 2]};
     float act[1];
-    act[0] = exploration_action(p, a, 0, p.action[a]);
+    act[0] = exploration_action(p, a, 0, action_in);
     const float r = model.step(s, act);
     float* rec = p.record + (size_t)a * (1 + 3 + 1);
     rec[0] = act[0];
@@ -361,6 +359,11 @@ __global__ void k_finalize_pendulum(FinalArgs p) {
         p.next_state[a * 3 + 1] = s[1];
         p.next_state[a * 3 + 2] = s[2];
     }
+}
+__global__ void k_finalize_pendulum(FinalArgs p) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= p.A) return;
+    finalize_pendulum_agent(p, a, p.action[a]);
 }
 
 }  // namespace bbmpc

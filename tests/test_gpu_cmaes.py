@@ -177,3 +177,37 @@ def test_block_jacobi_path_uneven_blocks_and_sharding(L, monkeypatch, H):
         D = st2["D"][g * n:(g + 1) * n].astype(np.float64)
         C = st2["C"][g].astype(np.float64)
         np.testing.assert_allclose(B @ np.diag(D ** 2) @ B.T, C, rtol=0, atol=5e-5 * max(1.0, np.abs(C).max()))
+
+
+@pytest.mark.parametrize("A,per_agent,H", [(1, False, 30), (3, True, 12), (2, True, 50)])
+def test_fused_control_step_is_bit_identical_to_the_per_iteration_kernels(L, monkeypatch, A, per_agent, H):
+    # opt-in (BBMPC_CMA_FUSED=1): small search dimensions (n = H*U <= 64) run the whole control step -- every
+    # iteration's sampling, rollouts, top-k, evolution paths, covariance, warm start, Jacobi -- in ONE launch
+    # (kernels_fused_cma.hpp); it calls the same device functions / operation orders as the eleven per-iteration
+    # kernels, so results must match bit for bit, state included
+    N, k, iters = 500, 50, 5
+    q = L.CMAES_PER_AGENT if per_agent else 0
+    ref = _engine(L, A, H, N, iters, k, seed=9, quirks=q)
+    monkeypatch.setenv("BBMPC_CMA_FUSED", "1")
+    fus = _engine(L, A, H, N, iters, k, seed=9, quirks=q)
+    monkeypatch.delenv("BBMPC_CMA_FUSED")
+    n, G = (H if per_agent else A * H), (A if per_agent else 1)
+    s_r = s_f = O.pendulum_start_states(A)
+    ref.set_profiling(True)
+    fus.set_profiling(True)
+    for t in range(5):
+        if t == 3:
+            ref.reset()
+            fus.reset()
+        a_r, n_r, r_r = ref.optimize(s_r, t, add_exploration_noise=(t == 2))
+        a_f, n_f, r_f = fus.optimize(s_f, t, add_exploration_noise=(t == 2))
+        np.testing.assert_array_equal(a_f, a_r)
+        np.testing.assert_array_equal(n_f, n_r)
+        np.testing.assert_array_equal(r_f, r_r)
+        st_r, st_f = _state(ref, n, G), _state(fus, n, G)
+        for name in st_r:
+            np.testing.assert_array_equal(st_f[name], st_r[name], err_msg=name)
+        s_r, s_f = n_r, n_f
+    fused_applies = n <= 64 and G == A
+    assert fus.get_profile()[2] == ("k_fused_cma_pendulum" if fused_applies else "k_rollout_pendulum")
+    assert ref.get_profile()[2] == "k_rollout_pendulum"

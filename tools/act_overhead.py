@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Where the wall time of one MPCPolicy.act goes (config 2): raw C-ABI call vs Engine.optimize vs MPCPolicy.act."""
+"""Where the wall time of one MPCPolicy.act goes (config 2): raw C-ABI call vs Engine.optimize vs MPCPolicy.act.
+
+usage: act_overhead.py [CEM|CMA-ES|PI2|...]"""
 import os
 import sys
 import time
@@ -9,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def med(f, n=3000, w=200):
+def med(f, n=600, w=50):
     for _ in range(w):
         f()
     ts = np.empty(n)
@@ -21,6 +23,7 @@ def med(f, n=3000, w=200):
 
 
 def main():
+    opt = sys.argv[1] if len(sys.argv) > 1 else "CEM"
     from blackbox_mpc_amd import _build
     _build.build()
     from blackbox_mpc_amd import _lib as L
@@ -30,7 +33,7 @@ def main():
     from blackbox_mpc_amd.utils.pendulum import PendulumTrueModel, pendulum_reward_function
     pol = MPCPolicy(reward_function=pendulum_reward_function, env_action_space=Box([-2.0], [2.0]),
                     env_observation_space=Box([-1, -1, -8], [1, 1, 8]), true_model=True, dynamics_function=PendulumTrueModel(),
-                    optimizer_name="CEM", num_agents=1, planning_horizon=30, population_size=500, max_iterations=5, num_elite=50)
+                    optimizer_name=opt, num_agents=1, planning_horizon=30, population_size=500, max_iterations=5, num_elite=50)
     eng = pol._optimizer._require_engine()
     obs = SY.pendulum_start_states(1)
     st, action, nxt, rew, p_st, p_act, p_nxt, p_rew = eng._io_buffers()
