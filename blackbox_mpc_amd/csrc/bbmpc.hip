@@ -153,6 +153,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.mlp_generic = flag("BBMPC_MLP_GENERIC");
         { const int b = ival("BBMPC_MLP_BF16", 0); sw.mlp_bf16 = (b == 1 || b == 3) ? b : 0; }
         sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1);
+        sw.mlp_wave = ival("BBMPC_MLP_WAVE", 1);
         sw.balance = ival("BBMPC_BALANCE", 1);
         sw.ilp = ival("BBMPC_ILP", 1) == 2 ? 2 : 1;
         sw.refit_v1 = flag("BBMPC_REFIT_V1");
@@ -692,6 +693,31 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
         HIP_CHECK(hipGetLastError());
         prof_end();
         return;
+    }
+    // small networks: one wave per 16-particle tile, the whole Dense stack in its registers (kernels_mlp_wave.hpp)
+    if (!sw.mlp_generic && sw.mlp_wave != 0 && !single_step && small_io && mlp.n_layers >= 2 && mlp.n_layers <= 4 && mlp.tiles[1] <= 4) {
+        bool same = true;
+        for (int l = 2; l < mlp.n_layers; ++l) same = same && mlp.tiles[l] == mlp.tiles[1];
+        if (same) {
+            using KFn = void (*)(MlpRolloutArgs);
+            static const KFn table[3][4] = {
+                {k_rollout_mlp_wave<1, 1>, k_rollout_mlp_wave<1, 2>, k_rollout_mlp_wave<1, 3>, k_rollout_mlp_wave<1, 4>},
+                {k_rollout_mlp_wave<2, 1>, k_rollout_mlp_wave<2, 2>, k_rollout_mlp_wave<2, 3>, k_rollout_mlp_wave<2, 4>},
+                {k_rollout_mlp_wave<3, 1>, k_rollout_mlp_wave<3, 2>, k_rollout_mlp_wave<3, 3>, k_rollout_mlp_wave<3, 4>}};
+            const KFn wfn = table[mlp.n_layers - 2][mlp.tiles[1] - 1];
+            const int wht = mlp.tiles[1];
+            const size_t wlds = (size_t)mlp_wave_lds_layout(ra.H, U, S, mlp.n_layers - 1, wht).total * sizeof(float);
+            if (wlds <= 159 * 1024) {
+                if (wlds > 64 * 1024) ensure_max_lds((const void*)wfn, 159 * 1024);
+                dim3 wgrid((ra.n_pop + MLP_TP - 1) / MLP_TP, per_particle_state ? 1 : A), wblock(64 * mlp_wave_waves(wht));
+                dominant_kernel = "k_rollout_mlp_wave";
+                prof_begin();
+                hipLaunchKernelGGL(wfn, wgrid, wblock, wlds, stream, q);
+                HIP_CHECK(hipGetLastError());
+                prof_end();
+                return;
+            }
+        }
     }
     const void* fn = spec == 3 ? (const void*)k_step_mlp : spec == 1 ? (const void*)k_rollout_mlp<1> : (spec == 2 ? (const void*)k_rollout_mlp<2> : (const void*)k_rollout_mlp<0>);
     if (lds > 64 * 1024) ensure_max_lds(fn, 159 * 1024);

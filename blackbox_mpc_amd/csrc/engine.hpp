@@ -19,6 +19,7 @@
 #include "kernels_fused_cma.hpp"
 #include "kernels_fused_pso.hpp"
 #include "kernels_mlp.hpp"
+#include "kernels_mlp_wave.hpp"
 #include "kernels_opt.hpp"
 #include "kernels_refit.hpp"
 #include "kernels_rollout.hpp"
@@ -88,6 +89,7 @@ struct Engine {
         bool mlp_generic = false;      // BBMPC_MLP_GENERIC
         int mlp_bf16 = 0;              // BBMPC_MLP_BF16: 0 off (default, fp32), 1 plain bf16 inputs, 3 split bf16 (hi+lo, three products)
         int mlp_pair = -1, mlp_q4 = -1;   // BBMPC_MLP_PAIR / BBMPC_MLP_Q4: -1 automatic, 0 / 1 forced
+        int mlp_wave = 1;                 // BBMPC_MLP_WAVE=0: never the one-wave-per-tile kernel for small networks
         int balance = 1;               // BBMPC_BALANCE
         int ilp = 1;                   // BBMPC_ILP
         bool refit_v1 = false;         // BBMPC_REFIT_V1

@@ -253,6 +253,68 @@ def test_wide_io_network_generic_kernel(L):
     np.testing.assert_allclose(eng.predict_next_state(s1, a1), ev.predict_next_state(s1, a1), rtol=2e-5, atol=2e-5)
 
 
+WAVE_SPECS = [
+    (PEND_MLP, True),                                                                     # tutorials: 3 hidden layers x 2 tiles
+    (([4, 16, 3], ["tanh", None], 3, 1, "pendulum"), True),                               # one hidden tile, one hidden layer
+    (([4, 64, 64, 3], ["relu", "sigmoid", None], 3, 1, "pendulum"), False),               # 4 tiles, other activations, raw I/O
+    (([26, 32, 32, 20], ["tanh", "tanh", None], 20, 6, "cheetah"), True),                 # two input tiles, two output tiles
+    (([26, 48, 20], ["tanh", "tanh"], 20, 6, "cheetah"), True),                           # 3 tiles, activation on the output
+    (([4, 21, 24, 3], ["sigmoid", "tanh", None], 3, 1, "pendulum"), True),                # half-empty last tiles
+]
+
+
+@pytest.mark.parametrize("spec,normalized", WAVE_SPECS)
+def test_small_networks_run_the_wave_kernel_and_match(L, monkeypatch, spec, normalized):
+    # hidden width <= 64: kernels_mlp_wave.hpp (one wave per hidden tile, the recurrence in registers, a reward wave);
+    # checked against the oracle at the evaluator tolerance and against the general kernel (same arithmetic up to the
+    # order in which the last layer's bias joins the K-split partial sums) much tighter
+    dims, acts, S, U, reward = spec
+    N, A, H = 77, 2, 25
+    rng = np.random.default_rng(11)
+    states = O.cheetah_start_states(A, S) if reward == "cheetah" else O.pendulum_start_states(A)
+    seq = rng.uniform(-1, 1, (N, A, H, U)).astype(F)
+    eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, normalized, A=A, H=H)
+    eng.set_profiling(True)
+    got = eng.evaluate(states, seq)
+    assert eng.get_profile()[2] == "k_rollout_mlp_wave"
+    want = ev(states, seq)
+    assert np.all(np.isfinite(want))
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3 * H)
+    monkeypatch.setenv("BBMPC_MLP_WAVE", "0")
+    gen, _, _, _ = _problem(L, dims, acts, S, U, reward, normalized, A=A, H=H)
+    monkeypatch.delenv("BBMPC_MLP_WAVE")
+    gen.set_profiling(True)
+    ref = gen.evaluate(states, seq)
+    assert gen.get_profile()[2] != "k_rollout_mlp_wave"
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * H)
+
+
+def test_wave_kernel_in_the_optimizers(L, monkeypatch):
+    # PI2 (clip + penalty candidates), CEM and the __call__ tail on the tutorial network: same injected draws through the
+    # wave kernel and the general kernel
+    dims, acts, S, U, reward = PEND_MLP
+    N, A, H, iters = 200, 3, 12, 3
+    states = O.pendulum_start_states(A)
+    rng = np.random.default_rng(5)
+    draws = np.stack([O.truncated_normal_noise(rng, (N, A, H, U)) for _ in range(iters)])
+    for opt, kw in ((L.OPT_PI2, dict(lamda=2.0)), (L.OPT_CEM, dict(k=20))):
+        out = []
+        for wave in ("1", "0"):
+            monkeypatch.setenv("BBMPC_MLP_WAVE", wave)
+            eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, True, A=A, H=H, opt=opt, N=N, iters=iters, **kw)
+            eng.set_trace(True)
+            eng.set_profiling(True)
+            eng.inject_noise(L.NOISE_TRUNC_NORMAL, draws)
+            a, n, r = eng.optimize(states)
+            assert (eng.get_profile()[2] == "k_rollout_mlp_wave") == (wave == "1")
+            out.append((a, n, r, [eng.get_trace(it, L.TRACE_REWARDS) for it in range(iters)]))
+        monkeypatch.delenv("BBMPC_MLP_WAVE")
+        for it in range(iters):
+            np.testing.assert_allclose(out[0][3][it], out[1][3][it], rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=2e-3)
+
+
 @pytest.mark.parametrize("mode,q99,frac_flip", [("3", 1e-3, 0.005), ("1", 15.0, 0.1)])
 def test_optional_bf16_modes_against_oracle(L, monkeypatch, mode, q99, frac_flip):
     # BBMPC_MLP_BF16 = 3: every MFMA operand split into bf16 hi + lo, three products per K tile (~16 mantissa bits per
