@@ -158,6 +158,28 @@ def test_user_reward_over_the_learned_model_agrees_with_the_fused_path(L):
     np.testing.assert_allclose(user.evaluate(states, seq), fused.evaluate(states, seq), rtol=1e-3, atol=1e-3 * H)
 
 
+def test_user_reward_over_a_small_learned_pendulum_model(L, user_rollout_form):
+    # the tutorials' learned Pendulum model (4-32-32-32-3) with a user reward: the small-network kernel
+    # (kernels_mlp_wave.hpp) records the trajectory, the user function scores it
+    from blackbox_mpc_amd.engine import Engine
+    S, U, A, H, N = 3, 1, 2, 15, 150
+    dims, acts = [4, 32, 32, 32, 3], ["tanh", "tanh", "tanh", None]
+    ws, bs = O.make_mlp_params(dims, seed=8)
+    stats = [np.zeros(S, F), np.ones(S, F), np.zeros(U, F), np.ones(U, F), np.zeros(S, F), np.full(S, 0.1, F)]
+    user = Engine(L.OPT_NONE, L.DYN_MLP, L.REW_USER, LO, HI, dim_s=S, num_agents=A, planning_horizon=H)
+    user.set_mlp(ws, bs, [1, 1, 1, 0], stats)
+    user.set_reward_source(INTENDED_PENDULUM_REWARD)
+    rng = np.random.default_rng(27)
+    states = O.pendulum_start_states(A)
+    seq = rng.uniform(-2, 2, (N, A, H, U)).astype(F)
+    ev = O.Evaluator(_intended, O.Handler(O.MLP(ws, bs, acts), False, True, stats))
+    user.set_profiling(True)
+    got = user.evaluate(states, seq)
+    if user_rollout_form != "stepwise":
+        assert user.get_profile()[2] == "k_rollout_mlp_wave"
+    np.testing.assert_allclose(got, ev(states, seq), rtol=1e-3, atol=1e-3 * H)
+
+
 def test_user_reward_over_the_learned_model_large_population(L, user_rollout_form):
     # 6000 rows per launch: the pipelined two-tile MFMA kernel records the trajectory (the quad kernel covers <= 2048)
     if user_rollout_form == "stepwise":
