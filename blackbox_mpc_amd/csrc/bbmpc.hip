@@ -700,11 +700,16 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
         for (int l = 2; l < mlp.n_layers; ++l) same = same && mlp.tiles[l] == mlp.tiles[1];
         if (same) {
             using KFn = void (*)(MlpRolloutArgs);
-            static const KFn table[3][4] = {
-                {k_rollout_mlp_wave<1, 1>, k_rollout_mlp_wave<1, 2>, k_rollout_mlp_wave<1, 3>, k_rollout_mlp_wave<1, 4>},
-                {k_rollout_mlp_wave<2, 1>, k_rollout_mlp_wave<2, 2>, k_rollout_mlp_wave<2, 3>, k_rollout_mlp_wave<2, 4>},
-                {k_rollout_mlp_wave<3, 1>, k_rollout_mlp_wave<3, 2>, k_rollout_mlp_wave<3, 3>, k_rollout_mlp_wave<3, 4>}};
-            const KFn wfn = table[mlp.n_layers - 2][mlp.tiles[1] - 1];
+            static const KFn table[2][3][4] = {
+                {{k_rollout_mlp_wave<1, 1, false>, k_rollout_mlp_wave<1, 2, false>, k_rollout_mlp_wave<1, 3, false>, k_rollout_mlp_wave<1, 4, false>},
+                 {k_rollout_mlp_wave<2, 1, false>, k_rollout_mlp_wave<2, 2, false>, k_rollout_mlp_wave<2, 3, false>, k_rollout_mlp_wave<2, 4, false>},
+                 {k_rollout_mlp_wave<3, 1, false>, k_rollout_mlp_wave<3, 2, false>, k_rollout_mlp_wave<3, 3, false>, k_rollout_mlp_wave<3, 4, false>}},
+                {{k_rollout_mlp_wave<1, 1, true>, k_rollout_mlp_wave<1, 2, true>, k_rollout_mlp_wave<1, 3, true>, k_rollout_mlp_wave<1, 4, true>},
+                 {k_rollout_mlp_wave<2, 1, true>, k_rollout_mlp_wave<2, 2, true>, k_rollout_mlp_wave<2, 3, true>, k_rollout_mlp_wave<2, 4, true>},
+                 {k_rollout_mlp_wave<3, 1, true>, k_rollout_mlp_wave<3, 2, true>, k_rollout_mlp_wave<3, 3, true>, k_rollout_mlp_wave<3, 4, true>}}};
+            bool tanh_net = mlp.act[mlp.n_layers - 1] == BBMPC_ACT_NONE;
+            for (int l = 0; l + 1 < mlp.n_layers; ++l) tanh_net = tanh_net && mlp.act[l] == BBMPC_ACT_TANH;
+            const KFn wfn = table[tanh_net ? 1 : 0][mlp.n_layers - 2][mlp.tiles[1] - 1];
             const int wht = mlp.tiles[1];
             const size_t wlds = (size_t)mlp_wave_lds_layout(ra.H, U, S, mlp.n_layers - 1, wht).total * sizeof(float);
             if (wlds <= 159 * 1024) {

@@ -60,7 +60,8 @@ __device__ __forceinline__ f32x4 act4(f32x4 v, int a) {
 __host__ __device__ constexpr int mlp_wave_waves(int HT) { return HT + 1; }
 
 // NH hidden layers of exactly HT 16-feature tiles each; S+U <= 32, S <= 32.  grid (ceil(n_pop/16), A), block 64*waves.
-template <int NH, int HT>
+// TANH: every hidden activation is tanh and the output layer is linear (the tutorials' networks): no run-time dispatch
+template <int NH, int HT, bool TANH>
 __global__ __launch_bounds__(64 * mlp_wave_waves(HT)) void k_rollout_mlp_wave(MlpRolloutArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutArgs& p = q.r;
@@ -136,14 +137,12 @@ __global__ __launch_bounds__(64 * mlp_wave_waves(HT)) void k_rollout_mlp_wave(Ml
     // ---- prologue: the tile's action block [H][16][U] (candidate -> clip/penalty -> store), as the general kernels
     mlp_fill_actions<MLP_TP>(q, a, n0, tid, 64 * mlp_wave_waves(HT), acts, pens);
     // the raw state of every step goes to the ring (wave 0 writes it); the reward reads (state t, action t, state t+1) there
-    auto ring_store = [&](int t) {
+    auto ring_store = [&](int t) {            // one 16-byte store per tile: the padding slots f in [S, Sp) carry zeros
 #pragma unroll
         for (int it = 0; it < OTLM; ++it)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 16 * it + 4 * g + r;
-                if (it < OTL && f < S) ring[((size_t)t * MLP_TP + pp) * Sp + f] = sraw[it][r];
-            }
+            if (it < OTL && 16 * it + 4 * g < Sp)
+                *reinterpret_cast<f32x4*>(ring + ((size_t)t * MLP_TP + pp) * Sp + 16 * it + 4 * g) =
+                    f32x4{sraw[it][0], sraw[it][1], sraw[it][2], sraw[it][3]};
     };
     auto score = [&](int t) {                 // lanes 0..15: reward of step t for particle `lane`
         if (lane < MLP_TP)
@@ -174,7 +173,10 @@ __global__ __launch_bounds__(64 * mlp_wave_waves(HT)) void k_rollout_mlp_wave(Ml
 #pragma unroll
         for (int it = 0; it < IT0M; ++it)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) anext[it][r] = (aidx[it][r] >= 0) ? acts[(t * MLP_TP + pp) * U + aidx[it][r]] : 0.0f;
+            for (int r = 0; r < 4; ++r) {      // branch-free: slots that are no action read action 0 and drop it
+                const float v = acts[(t * MLP_TP + pp) * U + max(aidx[it][r], 0)];
+                anext[it][r] = (aidx[it][r] >= 0) ? v : 0.0f;
+            }
     };
     auto stage_input = [&]() {
 #pragma unroll
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(64 * mlp_wave_waves(HT)) void k_rollout_mlp_wave(Ml
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in[1][s], xin[1][s], acc, 0, 0, 0);
         }
-        acc = act4(acc, m.act[0]);
+        acc = act4(acc, TANH ? ACT_TANH : m.act[0]);
         // ---- hidden -> hidden: all-gather the HT tiles through LDS (a buffer per layer: reused a whole step later)
 #pragma unroll
         for (int h = 1; h < NH; ++h) {
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(64 * mlp_wave_waves(HT)) void k_rollout_mlp_wave(Ml
 #pragma unroll
                 for (int s = 0; s < 4; ++s) nx = __builtin_amdgcn_mfma_f32_16x16x4f32(w_hid[h - 1][it][s], b[s], nx, 0, 0, 0);
             }
-            acc = act4(nx, m.act[h]);
+            acc = act4(nx, TANH ? ACT_TANH : m.act[h]);
         }
         // ---- last layer, K split: my last-hidden tile (still in `acc`) times my slab of W_last
         f32x4 o[OTLM];
@@ -256,18 +258,24 @@ __global__ __launch_bounds__(64 * mlp_wave_waves(HT)) void k_rollout_mlp_wave(Ml
 #pragma unroll
         for (int it = 0; it < OTLM; ++it) {
             if (it < OTL) {
-                const f32x4 ov = act4(o[it], m.act[L - 1]);
+                const f32x4 ov = act4(o[it], TANH ? ACT_NONE : m.act[L - 1]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int f = 16 * it + 4 * g + r;
-                    if (f < S) {
-                        const float dev = normd ? tmean[it][r] + ov[r] * tstd[it][r] : ov[r];
-                        const float ns = dev + sraw[it][r];
-                        sraw[it][r] = ns;
-                        if (q.traj && wave == 0 && n < p.n_pop) q.traj[((((size_t)t * p.A + a) * p.Nst) + n) * S + f] = ns;
-                    }
+                    const float dev = tmean[it][r] + ov[r] * tstd[it][r];     // (0, 1) when not normalised
+                    const float ns = dev + sraw[it][r];
+                    sraw[it][r] = (f < S) ? ns : 0.0f;                       // a select, no branch
                 }
             }
+        }
+        if (q.traj && wave == 0 && n < p.n_pop) {     // a user reward function scores the recorded trajectory afterwards
+#pragma unroll
+            for (int it = 0; it < OTLM; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * it + 4 * g + r;
+                    if (it < OTL && f < S) q.traj[((((size_t)t * p.A + a) * p.Nst) + n) * S + f] = sraw[it][r];
+                }
         }
         if (wave == 0) ring_store(t + 1);
         stage_input();
