@@ -70,18 +70,19 @@ struct MlpRolloutArgs {
     float* traj;              // optional [H][A][Nst][S]: the state after every step (a user reward function scores them afterwards)
 };
 
-// tanh on the hardware exp/rcp units: sign(x) * (1 - 2 / (e^{2|x|} + 1)), 7 instructions.  Absolute error
-// <= ~2.5e-7 over the whole range (v_exp_f32 / v_rcp_f32 are ~1 ulp); near zero the RELATIVE error grows
-// (cancellation) but an activation feeds a dot product, where only absolute error matters -- it is the size of
-// one fp32 rounding of an O(1) pre-activation.  fp32-input MFMA executes at the vector rate on the same
-// datapath as VALU work (measured: step time = MFMA time + VALU time, not the max), so every VALU
-// instruction shaved off the activations is matrix time gained.
+// tanh on the hardware exp/rcp units: sign(x) * (1 - 2 / (2^{c|x|} + 1)), c = 2 log2(e): six instructions
+// (v_mul with |x|, v_exp_f32, v_add, v_rcp_f32, v_fma, v_bfi).  Absolute error <= ~2.5e-7 over the whole range (v_exp_f32 /
+// v_rcp_f32 are ~1 ulp); near zero the RELATIVE error grows (cancellation) but an activation feeds a dot product, where
+// only absolute error matters -- it is the size of one fp32 rounding of an O(1) pre-activation.  fp32-input MFMA
+// executes at the vector rate on the same datapath as VALU work (measured: step time = MFMA time + VALU time, not the
+// max), so every VALU instruction shaved off the activations is matrix time gained: this form replaced
+// exp(2|x|) -> 1 - 2r spelled as (|x|+|x|) * log2e, exp2, +1, rcp, r+r, 1-  (eight instructions).
 __device__ __forceinline__ float bb_tanhf(float x) {
-    const float e = __expf(2.0f * fabsf(x));                 // +inf for large |x| -> 1 - 0
+    const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * fabsf(x));   // +inf for large |x| -> 1 - 0
     // v_rcp_f32 (1 ulp).  __frcp_rn is the correctly rounded reciprocal, i.e. a full IEEE division: ten instructions
     // (v_div_scale x2, v_rcp, four fmas, v_div_fmas, v_div_fixup) per activation value, on the MFMAs' issue port.
-    const float r = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
-    return copysignf(r, x);                                  // NaN stays NaN (exp(NaN) = NaN)
+    const float r = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+    return copysignf(r, x);                                  // NaN stays NaN (exp2(NaN) = NaN)
 }
 
 __device__ __forceinline__ float apply_act(float x, int act) {
