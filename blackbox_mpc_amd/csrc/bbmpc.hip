@@ -544,7 +544,7 @@ void Engine::get_profile(double* ms, int64_t* launches) {
 void Engine::set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, const float* const* w, const float* const* b,
                      int is_normalized, const float* const* stats) {
     REQUIRE(cfg.dynamics == BBMPC_DYN_MLP, BBMPC_E_STATE, "handle was not created with BBMPC_DYN_MLP");
-    REQUIRE(n_layers >= 1 && n_layers <= MLP_MAX_LAYERS, BBMPC_E_UNSUPPORTED, "1..4 Dense layers are supported");
+    REQUIRE(n_layers >= 1 && n_layers <= MLP_MAX_LAYERS, BBMPC_E_UNSUPPORTED, "1..8 Dense layers are supported");
     REQUIRE(dims && acts && w && b, BBMPC_E_INVALID, "null argument");
     REQUIRE(dims[0] == S + U && dims[n_layers] == S, BBMPC_E_INVALID, "MLP must map dim_S+dim_U -> dim_S");
     HIP_CHECK(hipStreamSynchronize(stream));

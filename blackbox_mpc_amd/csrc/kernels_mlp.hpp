@@ -31,7 +31,7 @@ namespace bbmpc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MLP_MAX_LAYERS = 4;
+constexpr int MLP_MAX_LAYERS = 8;      // Dense layers (the generic kernel walks any number; the specialisations cover 2-4)
 constexpr int MLP_TP = 16;          // particles per workgroup tile
 constexpr int MLP_TMAX = 2;         // output tiles per wave per layer
 

@@ -234,6 +234,32 @@ def test_host_api_with_learned_dynamics(L, tmp_path):
     np.testing.assert_allclose(pol._trajectory_evaluator.predict_next_state(obs, a), n, rtol=1e-6, atol=1e-6)
 
 
+def test_deep_network_generic_kernel(L):
+    # more Dense layers than the weights-stationary specialisations cover (PETS-style 4 x 200 hidden): generic kernel,
+    # 5 and 8 layers (the limit)
+    for dims, acts in (([26, 200, 200, 200, 200, 20], ["tanh", "tanh", "relu", "tanh", None]),
+                       ([4, 24, 24, 24, 24, 24, 24, 24, 3], ["tanh"] * 7 + [None])):
+        S = dims[-1]
+        U = dims[0] - S
+        reward = "cheetah" if S == 20 else "pendulum"
+        eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, True, A=2, H=12)
+        rng = np.random.default_rng(len(dims))
+        states = O.cheetah_start_states(2, S) if reward == "cheetah" else O.pendulum_start_states(2)
+        seq = rng.uniform(-1, 1, (60, 2, 12, U)).astype(F)
+        want = ev(states, seq)
+        assert np.all(np.isfinite(want))
+        np.testing.assert_allclose(eng.evaluate(states, seq), want, rtol=1e-3, atol=1e-3 * 12)
+        s1 = states[:1].repeat(9, 0)
+        a1 = rng.uniform(-1, 1, (9, U)).astype(F)
+        np.testing.assert_allclose(eng.predict_next_state(s1, a1), ev.predict_next_state(s1, a1), rtol=2e-5, atol=2e-5)
+    from blackbox_mpc_amd.engine import Engine
+    dims = [4] + [8] * 8 + [3]
+    ws, bs = O.make_mlp_params(dims, seed=1)
+    eng = Engine(L.OPT_NONE, L.DYN_MLP, L.REW_PENDULUM, [-1.0], [1.0], dim_s=3, num_agents=1, planning_horizon=4)
+    with pytest.raises(Exception):
+        eng.set_mlp(ws, bs, [1] * 8 + [0], None)                                     # 9 Dense layers
+
+
 def test_wide_io_network_generic_kernel(L):
     # S + U > 32 and S > 32: outside the weights-stationary specialisations -> generic streaming kernel
     S, U = 40, 9
