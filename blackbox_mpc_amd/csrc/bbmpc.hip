@@ -1067,7 +1067,8 @@ void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_ou
     fa.key = key(step);
     fa.key.q_per_agent = (uint32_t)((U + 3) / 4);
     if (cfg.dynamics == BBMPC_DYN_PENDULUM && !user_path()) {
-        hipLaunchKernelGGL(k_finalize_pendulum, dim3((A + 63) / 64), dim3(64), 0, stream, fa);
+        if (tail_flag) tail_attached = true;         // the record is complete when this kernel ends: it publishes the sequence number
+        hipLaunchKernelGGL(k_finalize_pendulum, dim3((A + 63) / 64), dim3(64), 0, stream, fa, tail_flag, tail_count, tail_value);
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -1629,7 +1630,7 @@ void Engine::optimize_spsa(RolloutArgs& ra, uint32_t step) {
 
 // PSO on the true pendulum model in one launch per control step (kernels_fused_pso.hpp) when the swarm's positions
 // and velocities fit one CU's LDS
-static size_t fused_pso_lds(int H, int Nst) { return ((size_t)2 * H * Nst + ((H + 3) & ~3) + 16 + 16 + 4) * sizeof(float); }
+static size_t fused_pso_lds(int H, int Nst) { return ((size_t)2 * H * Nst + ((H + 3) & ~3) + 16 + 16 + 8) * sizeof(float); }
 
 bool Engine::use_fused_pso() const {
     if (cfg.dynamics != BBMPC_DYN_PENDULUM || cfg.reward != BBMPC_REW_PENDULUM || cfg.optimizer != BBMPC_OPT_PSO || U != 1) return false;
@@ -2289,10 +2290,11 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
     bool published = false;
     // single-kernel control steps read the state straight from the pinned, device-mapped host buffer; those and the
     // learned-dynamics path (whose last kernel, k_tail_mlp, owns the record) write the packed record straight into it
-    const bool fused_step = e.sw.zero_copy && e.use_fused();
-    // (the fused small-n CMA-ES kernel is in the same position: many threads read the state, its last thread owns the record)
-    const bool mlp_tail = e.sw.zero_copy && !fused_step && e.cfg.optimizer != BBMPC_OPT_NONE &&
-                          (e.cfg.dynamics == BBMPC_DYN_MLP || e.use_fused_cma());
+    const bool fused_step = e.sw.zero_copy && (e.use_fused() || e.use_fused_pso());   // PSO: the swarm re-seed that follows touches neither
+    // every other optimizer path: the state goes to HBM once (many workgroups read it), the record comes back on its own --
+    // whichever kernel packs it writes straight into the pinned buffer; k_tail_mlp, k_finalize_pendulum and the fused
+    // CMA-ES kernel also publish the completion word, the rest is waited for on the stream
+    const bool mlp_tail = e.sw.zero_copy && !fused_step && e.cfg.optimizer != BBMPC_OPT_NONE;
     if (fused_step || mlp_tail) {
         // the persistent kernel reads the [A,S] state and writes the packed record straight from / to the pinned,
         // device-mapped host buffer (a few PCIe transactions) -- no copy-engine round trips around a ~50 us kernel

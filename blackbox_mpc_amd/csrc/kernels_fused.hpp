@@ -111,7 +111,9 @@ __global__ void k_fused_pendulum(FusedArgs p) {
 #endif
     const PendulumModel model{p.fix_q1 != 0};
     const float lo = p.lo[0], hi = p.hi[0];
-    const float s0 = p.state[a * 3 + 0], s1 = p.state[a * 3 + 1], s2 = p.state[a * 3 + 2];
+    // the [A,3] state may live in pinned host memory (bbmpc_optimize's zero-copy path): three lanes fetch it -- one PCIe
+    // read per workgroup instead of three per wave (3072 at 64 agents x 16 waves) -- and LDS hands it to everybody
+    if (tid < 3) red[60 + tid] = p.state[a * 3 + tid];
 
     // ---- distribution init (cem.py:129-132 starts every control step from the ctor mean/var, quirk Q2)
     for (int j = tid; j < p.HU; j += nthr) {
@@ -122,6 +124,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         sigma[j] = (OPT == FOPT_CEM) ? cem_sigma(m, v, lo, hi) : ((OPT == FOPT_SPSA) ? 0.0f : sqrtf(v));
     }
     __syncthreads();
+    const float s0 = red[60], s1 = red[61], s2 = red[62];
 
     float action0 = (OPT == FOPT_RS) ? 0.0f : mean[0];          // iters == 0 -> untouched mean[:,0]
 

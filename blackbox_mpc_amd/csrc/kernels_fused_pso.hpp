@@ -34,13 +34,13 @@ struct FusedPsoArgs {
     float* t_mean;
     int* t_elites;
     int t_elite_stride;
-    unsigned* done_flag;     // optional: see publish_records_done (kernels_opt.hpp)
+    unsigned* done_flag;     // optional: see publish_records_done (kernels_refit.hpp)
     unsigned* done_count;
     unsigned done_value;
     RngKey key;
 };
 
-// LDS (floats): pos[H][Nst] | vel[H][Nst] | gb[Hp] | sv[16] | si[16] | misc[4]
+// LDS (floats): pos[H][Nst] | vel[H][Nst] | gb[Hp] | sv[16] | si[16] | misc[8]
 template <bool FASTM>
 __global__ __launch_bounds__(1024) void k_fused_pso_pendulum(FusedPsoArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -51,11 +51,12 @@ __global__ __launch_bounds__(1024) void k_fused_pso_pendulum(FusedPsoArgs p) {
     float* gb = velL + (size_t)H * Nst;
     float* sv = gb + Hp;
     int* si = (int*)(sv + 16);
-    int* misc = si + 16;                                      // [0] global best index, [1] it improved this iteration
+    int* misc = si + 16;                                      // [0] global best index, [1] it improved this iteration, [4..6] start state
     const int n = tid;
     const bool live = n < p.N;
     const float lo = p.lo[0], hi = p.hi[0];
-    const float s0 = p.state[a * 3 + 0], s1 = p.state[a * 3 + 1], s2 = p.state[a * 3 + 2];
+    float* sst = (float*)(misc + 4);
+    if (tid < 3) sst[tid] = p.state[a * 3 + tid];             // one fetch per workgroup (pinned host memory on the zero-copy path)
     float* pos_g = p.s.pos + (size_t)a * H * Nst;
     float* vel_g = p.s.vel + (size_t)a * H * Nst;
     float* pb_g = p.s.pbest + (size_t)a * H * Nst;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(1024) void k_fused_pso_pendulum(FusedPsoArgs p) {
 #define PSO_MARK(i) do {} while (0)
 #endif
     __syncthreads();
+    const float s0 = sst[0], s1 = sst[1], s2 = sst[2];
     PSO_MARK(0);
 
     for (int it = 0; it < p.iters; ++it) {

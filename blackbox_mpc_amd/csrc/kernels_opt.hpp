@@ -12,26 +12,6 @@
 
 namespace bbmpc {
 
-// "records ready" for an all-gather that waits on another stream (comm.hpp, gather_records in bbmpc.hip): called by
-// one thread per workgroup after its record stores; the last of `nwg` workgroups publishes the sequence number in
-// signal memory.  No event and no extra packet on the launch stream.
-__device__ __forceinline__ void publish_records_done(unsigned* flag, unsigned* count, unsigned value, unsigned nwg) {
-    if (!flag) return;
-    // Each workgroup's arrival is a release (its record stores are written back before it is counted); the last arriver
-    // alone takes the matching acquire -- as a fence after its relaxed observation of the full count, so that the chain
-    // "record stores of every workgroup -> their release arrivals -> acquire fence -> system-scope release store of the
-    // flag" holds formally for a consumer that reads the records as soon as it sees the flag (the host polling a pinned
-    // word in bbmpc_optimize, or the communication stream's wait-value).  An ACQ_REL arrival in EVERY workgroup would
-    // invalidate the XCD's L2 under the workgroups that are still running; one fence in the last one costs nothing.
-    const unsigned old = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == nwg - 1u) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-
 struct OptArgs {
     int N, A, H, U, HU, Nst;
     int agent_offset;

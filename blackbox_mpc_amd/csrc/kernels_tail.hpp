@@ -122,7 +122,7 @@ struct TailArgs {
     int warm_mode, H, HU;
     const float* mean;      // [A][HU]
     float* prev_mean;       // [A][HU]
-    unsigned* done_flag;    // publish_records_done (kernels_opt.hpp) or null
+    unsigned* done_flag;    // publish_records_done (kernels_refit.hpp) or null
     unsigned* done_count;
     unsigned done_value;
 };
