@@ -439,7 +439,8 @@ def roofline(W, m, name, world):
     import glob
     try:
         tr = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]))
-        hit = [v for kn, v in tr.get(name, {}).items() if kname in kn]
+        # (the resident LINGER instantiation of the persistent kernel serves many control steps per dispatch: not a per-launch figure)
+        hit = [v for kn, v in tr.get(name, {}).items() if kname in kn and not (kname.startswith("k_fused_pendulum") and kn.rstrip().endswith("true>"))]
         if hit and world == 1:
             roof["traffic"] = hit[0]
             roof["traffic_source"] = "profiles/ (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes)"
@@ -451,7 +452,7 @@ def roofline(W, m, name, world):
     try:
         if not mlp and m["roll_n"] and world == 1:
             sqc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))[-1]))
-            hit = [v for kn, v in sqc.get(name, {}).items() if kname in kn and "noise" not in kn]
+            hit = [v for kn, v in sqc.get(name, {}).items() if kname in kn and "noise" not in kn and not kn.rstrip().endswith("true>")]
             if hit:
                 insts = hit[0]["SQ_INSTS_VALU"]
                 peak = A * 4 / 1.07e-9

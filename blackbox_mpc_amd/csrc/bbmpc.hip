@@ -154,6 +154,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         { const int b = ival("BBMPC_MLP_BF16", 0); sw.mlp_bf16 = (b == 1 || b == 3) ? b : 0; }
         sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1);
         sw.mlp_wave = ival("BBMPC_MLP_WAVE", 1);
+        sw.linger_us = std::max(0, ival("BBMPC_LINGER_US", 200));
         sw.balance = ival("BBMPC_BALANCE", 1);
         sw.ilp = ival("BBMPC_ILP", 1) == 2 ? 2 : 1;
         sw.refit_v1 = flag("BBMPC_REFIT_V1");
@@ -219,6 +220,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
 }
 
 Engine::~Engine() {
+    try { resident_stop(); } catch (...) {}
     if (lazy_sync && stream) (void)hipStreamSynchronize(stream);
     if (own_stream) (void)hipStreamSynchronize(own_stream);
     rc.destroy();
@@ -240,10 +242,65 @@ Engine::~Engine() {
 }
 
 void Engine::settle() {
+    resident_stop();
     if (lazy_sync) {
         lazy_sync = false;
         HIP_CHECK(hipStreamSynchronize(stream));
     }
+}
+
+// The resident kernel's side of this is at the end of k_fused_pendulum.  Returns false when the call has to go through
+// a launch after all (the kernel left, or this step's noise chunk is not there yet); the stream is idle then.
+bool Engine::resident_step(const float* state, int add_noise, uint32_t seq) {
+    const uint32_t step = step_counter;
+    const int64_t c = (int64_t)step / std::max(pf_steps, 1);
+    const int pb = (int)(c & 1), nb = pb ^ 1;
+    if (pf_mode != 1 || pf_chunk[pb] != c) { resident_stop(); return false; }
+    if (!pf_waited[pb]) {
+        if (hipEventQuery(pf_done[pb]) != hipSuccess) { resident_stop(); return false; }
+        pf_waited[pb] = true; pf_inflight[pb] = false;
+    }
+    const float* inj = d_noise_pf[pb].p + (size_t)((int64_t)step - c * pf_steps) * pf_step_floats;
+    if (pf_chunk[nb] != c + 1) {
+        // the other buffer held chunk c-1: every control step that read it has handed its record to this thread already
+        launch_noise_fill(c + 1, nb, pf_stream);
+        HIP_CHECK(hipEventRecord(pf_done[nb], pf_stream));
+        pf_chunk[nb] = c + 1; pf_waited[nb] = false; pf_inflight[nb] = true;
+    }
+    ++step_counter;
+    volatile uint32_t* m = mbox_host();
+    const uint64_t ip = (uint64_t)(uintptr_t)inj;
+    m[15] = seq;
+    m[1] = step; m[2] = (uint32_t)add_noise; m[3] = (uint32_t)ip; m[4] = (uint32_t)(ip >> 32);
+    uint32_t sw3[3];
+    memcpy(sw3, state, 12);
+    m[5] = sw3[0]; m[6] = sw3[1]; m[7] = sw3[2];
+    std::atomic_thread_fence(std::memory_order_release);
+    m[0] = seq;
+    volatile const uint32_t* ack = host_done;
+    volatile const uint32_t* gone = gone_host();
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    for (;;) {
+        if (*ack == seq) return true;
+        if (*gone != 0u) break;                                   // it left (before or after this request?)
+        if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));                      // the kernel has ended (or ends within linger_us)
+    resident_alive = false;
+    if (*ack == seq) return true;                                 // it took the request on its way out
+    --step_counter;                                               // the launch that follows does this step
+    return false;
+}
+
+void Engine::resident_stop() {
+    if (!resident_alive) return;
+    volatile uint32_t* m = mbox_host();
+    m[15] = 0xffffffffu;
+    std::atomic_thread_fence(std::memory_order_release);
+    m[0] = 0xffffffffu;
+    resident_alive = false;
+    HIP_CHECK(hipStreamSynchronize(stream));
 }
 
 float* Engine::pinned(size_t count) {
@@ -1144,6 +1201,24 @@ static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base
     const size_t limit = 160 * 1024;   // all of a CU's LDS
 #endif
     if (lds_base + lds_samples <= limit) {
+        if constexpr (INJ == 2 && FASTM && ILP == 1 && OPT != FOPT_SPSA) {
+            if (e.linger_launch && fa.done_flag && e.tail_event == nullptr) {
+                // the resident form: this launch serves the current call and then waits for the next ones (kernels_fused.hpp)
+                auto fl = k_fused_pendulum<OPT, true, FASTM, INJ, ILP, true>;
+                ensure_max_lds((const void*)fl, (int)limit);
+                volatile uint32_t* m = e.mbox_host();
+                m[15] = fa.done_value; m[0] = fa.done_value;          // nothing pending (a stale stop word must not end it)
+                *(volatile uint32_t*)e.gone_host() = 0u;
+                std::atomic_thread_fence(std::memory_order_release);
+                fa.mbox = e.host_done_dev + 16;
+                fa.gone = e.host_done_dev + 32;
+                fa.linger_ticks = (unsigned)e.sw.linger_us * 100u;
+                hipLaunchKernelGGL(fl, dim3(e.A), dim3(threads), lds_base + lds_samples, e.stream, fa);
+                HIP_CHECK(hipGetLastError());
+                e.resident_alive = true;
+                return;
+            }
+        }
         auto fn = k_fused_pendulum<OPT, true, FASTM, INJ, ILP>;
         ensure_max_lds((const void*)fn, (int)limit);
         launch_with_tail(e, fn, dim3(e.A), dim3(threads), lds_base + lds_samples, fa);
@@ -2304,8 +2379,8 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
             // stores (publish_records_done): the call returns when the host sees it, ~10 us earlier than
             // hipStreamSynchronize notices the kernel's completion; the stream itself is joined lazily (settle)
             if (!e.host_done) {
-                HIP_CHECK(hipHostMalloc((void**)&e.host_done, 64, hipHostMallocCoherent | hipHostMallocMapped));
-                memset(e.host_done, 0, 64);
+                HIP_CHECK(hipHostMalloc((void**)&e.host_done, 256, hipHostMallocCoherent | hipHostMallocMapped));   // completion word | request line | exit word, a cache line each
+                memset(e.host_done, 0, 256);
                 HIP_CHECK(hipHostGetDevicePointer((void**)&e.host_done_dev, e.host_done, 0));
                 HIP_CHECK(hipMalloc((void**)&e.host_count, 8));
                 HIP_CHECK(hipMemset(e.host_count, 0, 8));
@@ -2316,7 +2391,20 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
             e.tail_value = e.host_seq;
             e.tail_attached = false;
         }
+        // one agent on the persistent pendulum kernel: the previous call's kernel may still be there, waiting for this one
+        const bool linger_ok = fused_step && e.tail_flag != nullptr && e.sw.linger_us > 0 && e.A == 1 && e.use_fused() &&
+                               !e.profiling && e.tail_event == nullptr && e.cfg.optimizer != BBMPC_OPT_SPSA;
+        bool handled = false;
+        if (e.resident_alive) {
+            if (linger_ok) handled = e.resident_step(pin, noise, e.host_seq);
+            else e.resident_stop();
+        }
+        if (handled) {
+            published = true;
+            e.tail_flag = nullptr;
+        } else
         try {
+            e.linger_launch = linger_ok;
             if (fused_step) {
                 e.optimize_dev(dpin, noise, dpin + ns, nullptr);
             } else {
@@ -2324,12 +2412,14 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
                 HIP_CHECK(hipMemcpyAsync(e.d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e.stream));
                 e.optimize_dev(e.d_state.p, noise, dpin + ns, nullptr);
             }
+            e.linger_launch = false;
+            published = e.tail_flag != nullptr && e.tail_attached;
+            e.tail_flag = nullptr;
         } catch (...) {
+            e.linger_launch = false;
             e.tail_flag = nullptr;
             throw;
         }
-        published = e.tail_flag != nullptr && e.tail_attached;
-        e.tail_flag = nullptr;
     } else {
         HIP_CHECK(hipMemcpyAsync(e.d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e.stream));
         e.optimize_dev(e.d_state.p, noise, e.d_record.p, nullptr);

@@ -90,6 +90,7 @@ struct Engine {
         int mlp_bf16 = 0;              // BBMPC_MLP_BF16: 0 off (default, fp32), 1 plain bf16 inputs, 3 split bf16 (hi+lo, three products)
         int mlp_pair = -1, mlp_q4 = -1;   // BBMPC_MLP_PAIR / BBMPC_MLP_Q4: -1 automatic, 0 / 1 forced
         int mlp_wave = 1;                 // BBMPC_MLP_WAVE=0: never the one-wave-per-tile kernel for small networks
+        int linger_us = 200;              // BBMPC_LINGER_US: how long a one-agent control-step kernel waits for the next call (0 = never)
         int balance = 1;               // BBMPC_BALANCE
         int ilp = 1;                   // BBMPC_ILP
         bool refit_v1 = false;         // BBMPC_REFIT_V1
@@ -151,6 +152,14 @@ struct Engine {
     uint32_t host_seq = 0;
     bool lazy_sync = false;
     void settle();
+    // resident control-step kernel (one agent, persistent pendulum kernel, host-in / host-out calls): the kernel of one
+    // call stays on the GPU for linger_us and takes the next call's request from a pinned mailbox line (kernels_fused.hpp)
+    bool linger_launch = false;        // bbmpc_optimize asks optimize_fused for the LINGER variant
+    bool resident_alive = false;       // a LINGER kernel may still be polling the mailbox
+    uint32_t* mbox_host() { return host_done + 16; }
+    uint32_t* gone_host() { return host_done + 32; }
+    bool resident_step(const float* state, int add_noise, uint32_t seq);
+    void resident_stop();
     hipStream_t pf_stream = nullptr;
     hipEvent_t pf_done[2] = {nullptr, nullptr}, pf_free = nullptr;
     int64_t pf_chunk[2] = {-1, -1};   // chunk id (control step / pf_steps) a buffer holds

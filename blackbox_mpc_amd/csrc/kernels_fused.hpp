@@ -58,6 +58,11 @@ struct FusedArgs {
     float* t_samples;
     long long* dbg;          // optional phase clocks (debug)
     RngKey key;
+    // LINGER variant (one agent, host-in / host-out calls): after publishing its record the workgroup stays on the GPU and
+    // polls a 64-byte request line in pinned host memory for the next control step (see the end of the kernel)
+    const unsigned* mbox;    // 16 words: [0] = [15] = sequence number, [1] step, [2] add_noise, [3..4] noise pointer, [5..7] state
+    unsigned* gone;          // pinned word: the last sequence number handled, written when the kernel leaves
+    unsigned linger_ticks;   // how long to wait for a request, in wall_clock64 ticks (100 MHz)
 };
 
 // phase clocks for kernel development: build with -DBBMPC_KERNEL_DBG and run with BBMPC_DBG=1
@@ -88,7 +93,7 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nw)
 
 // LDS carve (4-byte words): rewards[Nst] | mean[HUp] | var[HUp] | sigma[HUp] | eidx[kp] | red[64] | hist[272] |
 //                            ekeys[2*kp] | samples[HU][Nst]      (every piece a multiple of 16 B)
-template <int OPT, bool SAMPLES_LDS, bool FASTM, int INJ, int ILP>
+template <int OPT, bool SAMPLES_LDS, bool FASTM, int INJ, int ILP, bool LINGER = false>
 __global__ void k_fused_pendulum(FusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int a = blockIdx.x;
@@ -111,9 +116,15 @@ __global__ void k_fused_pendulum(FusedArgs p) {
 #endif
     const PendulumModel model{p.fix_q1 != 0};
     const float lo = p.lo[0], hi = p.hi[0];
+    // what changes from one control step to the next (the LINGER variant serves several per launch)
+    RngKey key_s = p.key;
+    const float* inj_s = p.inj;
+    int add_noise_s = p.add_noise;
+    unsigned done_value_s = p.done_value;
     // the [A,3] state may live in pinned host memory (bbmpc_optimize's zero-copy path): three lanes fetch it -- one PCIe
     // read per workgroup instead of three per wave (3072 at 64 agents x 16 waves) -- and LDS hands it to everybody
     if (tid < 3) red[60 + tid] = p.state[a * 3 + tid];
+    for (;;) {      // one pass per control step; a single pass unless LINGER
 
     // ---- distribution init (cem.py:129-132 starts every control step from the ctor mean/var, quirk Q2)
     for (int j = tid; j < p.HU; j += nthr) {
@@ -138,7 +149,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         // The 4 candidate actions of Philox block b+1 are generated while the recurrence steps through
         // block b: their instructions carry no dependence on the state, so they fill the latency
         // shadows of the sequential theta/thdot chain (all straight-line code inside a block).
-        const float* inj = (INJ == 1) ? p.inj + ((size_t)it * p.A + a) * p.HU * p.Nst : nullptr;
+        const float* inj = (INJ == 1) ? inj_s + ((size_t)it * p.A + a) * p.HU * p.Nst : nullptr;
         const int nblk = p.H >> 2, rem = p.H & 3;
         const uint32_t rstream = (OPT == FOPT_RS) ? 2u : 1u;
         // ILP independent trajectories per lane: with half as many waves each SIMD runs a single wave whose two
@@ -157,7 +168,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                 [[maybe_unused]] const float4* mine4 = nullptr;
                 [[maybe_unused]] float4 cur4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
                 if constexpr (INJ == 2) {            // draws prefetched by k_noise_fill, one float4 per 4 steps
-                    mine4 = reinterpret_cast<const float4*>(p.inj) + (((size_t)it * p.A + a) * p.Nst + n) * nb4;
+                    mine4 = reinterpret_cast<const float4*>(inj_s) + (((size_t)it * p.A + a) * p.Nst + n) * nb4;
                     cur4 = mine4[0];
                 }
                 for (int b = 0; b < nb4; ++b) {
@@ -170,7 +181,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) d[i] = (4 * b + i < p.H) ? inj[(size_t)(4 * b + i) * p.Nst + n] : 1.0f;
                     } else {
-                        const U4 w = rng_block(p.key, 3u, (uint32_t)it, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)(4 * b));
+                        const U4 w = rng_block(key_s, 3u, (uint32_t)it, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)(4 * b));
                         d[0] = word_to_rademacher(w.x); d[1] = word_to_rademacher(w.y);
                         d[2] = word_to_rademacher(w.z); d[3] = word_to_rademacher(w.w);
                     }
@@ -205,7 +216,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             // Loads run TWO blocks (8 steps, ~2 us) ahead of their use so that L2/HBM latency never reaches the
             // recurrence; the Philox rounds (a quarter of this kernel's VALU work) are gone from the critical path.
             const int Q = (p.HU + 3) >> 2;
-            const float4* inj4 = reinterpret_cast<const float4*>(p.inj) + ((size_t)it * p.A + a) * p.Nst * Q;
+            const float4* inj4 = reinterpret_cast<const float4*>(inj_s) + ((size_t)it * p.A + a) * p.Nst * Q;
             int* prog = (int*)red;                             // per-wave progress (red[] is idle during the rollout)
             const int wave = tid >> 6, lane = tid & 63;
             const bool balance = p.balance != 0 && nw > 4 && nw <= 64 && p.N <= nthr;
@@ -286,7 +297,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) xi[i] = (4 * b + i < p.H) ? inj[(size_t)(4 * b + i) * p.Nst + n] : 0.0f;
                 } else {
-                    const U4 w = rng_block(p.key, rstream, (uint32_t)it, (uint32_t)n, (uint32_t)(p.agent_offset + a),
+                    const U4 w = rng_block(key_s, rstream, (uint32_t)it, (uint32_t)n, (uint32_t)(p.agent_offset + a),
                                            (uint32_t)(4 * b));
                     const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
@@ -526,10 +537,10 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         fa.A = p.A; fa.U = 1; fa.S = 3;
         fa.agent_offset = p.agent_offset;
         fa.fix_q1 = p.fix_q1; fa.fix_q7 = p.fix_q7;
-        fa.add_noise = p.add_noise;
+        fa.add_noise = add_noise_s;
         fa.lo = p.lo; fa.hi = p.hi;
         fa.inj = p.inj_expl;
-        fa.key = p.key;
+        fa.key = key_s;
         fa.key.q_per_agent = 1;
         float s[3] = {s0, s1, s2};
         float act[1];
@@ -549,7 +560,44 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         // "records ready" for the all-gather that waits on another stream (comm.hpp): the last agent's workgroup
         // publishes the sequence number once every agent's record is in HBM.  No event, no extra packet on the
         // launch stream.
-        publish_records_done(p.done_flag, p.done_count, p.done_value, (unsigned)p.A);
+        publish_records_done(p.done_flag, p.done_count, done_value_s, (unsigned)p.A);
+    }
+    if constexpr (!LINGER) {
+        break;
+    } else {
+        // ---- stay resident: wave 0 polls the request line over PCIe (one 64-byte read per poll; the host writes word 15,
+        // the payload, then word 0, so a line whose two sequence words agree is complete).  A request carrying the NEXT
+        // sequence number starts another pass without a launch (measured: 2.1 us host-to-host for a resident kernel's
+        // mailbox round trip against 6.8 us for launch + completion, tools/microbench/launch_latency.hip); anything else
+        // -- the stop word, or linger_ticks without a request -- ends the kernel, which says so in `gone` first and
+        // never looks at the line again, so the host knows whether to launch.
+        unsigned* mb = (unsigned*)ekeys;                       // 16 words of LDS that are idle outside the top-k
+        __syncthreads();
+        if (tid < 64) {
+            const long long t0 = (long long)wall_clock64();
+            unsigned w = 0u;
+            bool quit = false;
+            for (;;) {
+                w = (tid < 16) ? __hip_atomic_load(p.mbox + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+                const unsigned w0 = __builtin_amdgcn_readlane(w, 0), w15 = __builtin_amdgcn_readlane(w, 15);
+                if (w0 == w15 && w0 == done_value_s + 1u) break;
+                if ((w0 == w15 && w0 == 0xffffffffu) || (long long)wall_clock64() - t0 > (long long)p.linger_ticks) { quit = true; break; }
+            }
+            if (tid < 16) mb[tid] = (quit && tid == 0) ? 0xffffffffu : w;
+        }
+        __syncthreads();
+        if (mb[0] == 0xffffffffu) {
+            if (tid == 0) __hip_atomic_store(p.gone, done_value_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        done_value_s = mb[0];
+        key_s.step = mb[1];
+        add_noise_s = (int)mb[2];
+        inj_s = reinterpret_cast<const float*>(((unsigned long long)mb[4] << 32) | (unsigned long long)mb[3]);
+        const float st_next = __uint_as_float(mb[5 + min(tid, 2)]);
+        __syncthreads();                                        // every thread has read the request before `red` / `ekeys` are reused
+        if (tid < 3) red[60 + tid] = st_next;
+    }
     }
 }
 

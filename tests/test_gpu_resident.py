@@ -1,0 +1,115 @@
+"""The resident form of the one-agent persistent kernel (kernels_fused.hpp, LINGER): a host-in / host-out call's kernel
+stays on the GPU for BBMPC_LINGER_US and serves the next call from a pinned mailbox instead of a launch.  Same
+arithmetic, same draws: every result must be bit-identical to the launch-per-call path, whatever happens in between."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def L():
+    from blackbox_mpc_amd import _build
+    _build.build()
+    from blackbox_mpc_amd import _lib
+    assert _lib.device_count() >= 1
+    return _lib
+
+
+def _engine(L, opt, seed=5, **kw):
+    from blackbox_mpc_amd.engine import Engine
+    args = dict(dim_s=3, num_agents=1, planning_horizon=30, population_size=500, max_iterations=5, num_elite=50, seed=seed)
+    args.update(kw)
+    return Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], **args)
+
+
+def _run(eng, steps, between=None):
+    s = O.pendulum_start_states(1)
+    out = []
+    for t in range(steps):
+        a, s, r = eng.optimize(s, t, add_exploration_noise=(t % 7 == 3))
+        out.append(np.concatenate([a.ravel(), s.ravel(), np.ravel(r)]))
+        if between is not None:
+            between(eng, t)
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("opt_name", ["CEM", "PI2", "RS"])
+def test_resident_kernel_is_bit_identical_to_a_launch_per_call(L, monkeypatch, opt_name):
+    opt = {"CEM": L.OPT_CEM, "PI2": L.OPT_PI2, "RS": L.OPT_RANDOM_SEARCH}[opt_name]
+    steps = 70                                      # crosses several noise-prefetch chunks (8 steps each)
+    monkeypatch.setenv("BBMPC_LINGER_US", "0")
+    ref = _run(_engine(L, opt), steps)
+    monkeypatch.delenv("BBMPC_LINGER_US")
+    t0 = time.perf_counter()
+    got = _run(_engine(L, opt), steps)
+    assert time.perf_counter() - t0 < 5.0
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_resident_kernel_survives_gaps_and_other_calls(L, monkeypatch):
+    import torch
+    steps = 40
+    monkeypatch.setenv("BBMPC_LINGER_US", "0")
+    ref_eng = _engine(L, L.OPT_CEM)
+
+    def ref_between(eng, t):
+        if t == 20:
+            eng.reset()
+    ref = _run(ref_eng, steps, ref_between)
+    monkeypatch.delenv("BBMPC_LINGER_US")
+
+    def between(eng, t):
+        if t % 5 == 1:
+            time.sleep(0.002)                        # longer than the linger time: the kernel leaves, the next call launches
+        if t % 5 == 2:
+            eng.get_state("mean")                    # any other entry point stops the resident kernel first
+        if t % 5 == 3:
+            t0 = time.perf_counter()
+            torch.cuda.synchronize()                 # a caller's device-wide sync waits at most the linger time
+            assert time.perf_counter() - t0 < 0.05
+        if t == 20:
+            eng.reset()
+        if t == 30:
+            seq = np.random.default_rng(0).uniform(-2, 2, (64, 1, 30, 1)).astype(F)
+            eng.evaluate(O.pendulum_start_states(1), seq)
+    got = _run(_engine(L, L.OPT_CEM), steps, between)
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_two_resident_handles_and_destruction_while_resident(L):
+    a, b = _engine(L, L.OPT_CEM, seed=1), _engine(L, L.OPT_PI2, seed=2)
+    sa = sb = O.pendulum_start_states(1)
+    for t in range(20):                               # both kernels linger at the same time, on their own streams
+        _, sa, _ = a.optimize(sa, t)
+        _, sb, _ = b.optimize(sb, t)
+    t0 = time.perf_counter()
+    a.close()                                         # destroyed with its kernel still waiting
+    del b
+    assert time.perf_counter() - t0 < 1.0
+    c = _engine(L, L.OPT_CEM, seed=1)
+    sc = O.pendulum_start_states(1)
+    for t in range(5):
+        _, sc, _ = c.optimize(sc, t)
+    assert np.all(np.isfinite(sc))
+
+
+def test_policy_act_uses_it_and_more_agents_do_not(L):
+    from blackbox_mpc_amd.policies import MPCPolicy
+    from blackbox_mpc_amd.spaces import Box
+    from blackbox_mpc_amd.utils.pendulum import PendulumTrueModel, pendulum_reward_function
+    for A in (1, 3):
+        pol = MPCPolicy(reward_function=pendulum_reward_function, env_action_space=Box([-2.0], [2.0]),
+                        env_observation_space=Box([-1, -1, -8], [1, 1, 8]), true_model=True, dynamics_function=PendulumTrueModel(),
+                        optimizer_name="CEM", num_agents=A, planning_horizon=20, population_size=256, max_iterations=3, num_elite=32)
+        obs = O.pendulum_start_states(A)
+        ev = O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))
+        for t in range(25):
+            act, nxt, rew = pol.act(obs, t)
+            np.testing.assert_allclose(nxt, ev.predict_next_state(obs, act), rtol=1e-5, atol=1e-5)
+            obs = nxt
