@@ -1201,7 +1201,7 @@ static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base
     const size_t limit = 160 * 1024;   // all of a CU's LDS
 #endif
     if (lds_base + lds_samples <= limit) {
-        if constexpr (INJ == 2 && FASTM && ILP == 1 && OPT != FOPT_SPSA) {
+        if constexpr (INJ == 2 && FASTM && ILP == 1) {
             if (e.linger_launch && fa.done_flag && e.tail_event == nullptr) {
                 // the resident form: this launch serves the current call and then waits for the next ones (kernels_fused.hpp)
                 auto fl = k_fused_pendulum<OPT, true, FASTM, INJ, ILP, true>;
@@ -2393,7 +2393,7 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
         }
         // one agent on the persistent pendulum kernel: the previous call's kernel may still be there, waiting for this one
         const bool linger_ok = fused_step && e.tail_flag != nullptr && e.sw.linger_us > 0 && e.A == 1 && e.use_fused() &&
-                               !e.profiling && e.tail_event == nullptr && e.cfg.optimizer != BBMPC_OPT_SPSA;
+                               !e.profiling && e.tail_event == nullptr;
         bool handled = false;
         if (e.resident_alive) {
             if (linger_ok) handled = e.resident_step(pin, noise, e.host_seq);

@@ -39,9 +39,9 @@ def _run(eng, steps, between=None):
     return np.stack(out)
 
 
-@pytest.mark.parametrize("opt_name", ["CEM", "PI2", "RS"])
+@pytest.mark.parametrize("opt_name", ["CEM", "PI2", "RS", "SPSA"])
 def test_resident_kernel_is_bit_identical_to_a_launch_per_call(L, monkeypatch, opt_name):
-    opt = {"CEM": L.OPT_CEM, "PI2": L.OPT_PI2, "RS": L.OPT_RANDOM_SEARCH}[opt_name]
+    opt = {"CEM": L.OPT_CEM, "PI2": L.OPT_PI2, "RS": L.OPT_RANDOM_SEARCH, "SPSA": L.OPT_SPSA}[opt_name]
     steps = 70                                      # crosses several noise-prefetch chunks (8 steps each)
     monkeypatch.setenv("BBMPC_LINGER_US", "0")
     ref = _run(_engine(L, opt), steps)
