@@ -2393,7 +2393,8 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
         }
         // one agent on the persistent pendulum kernel: the previous call's kernel may still be there, waiting for this one
         const bool linger_ok = fused_step && e.tail_flag != nullptr && e.sw.linger_us > 0 && e.A == 1 && e.use_fused() &&
-                               !e.profiling && e.tail_event == nullptr;
+                               !e.profiling && e.tail_event == nullptr &&
+                               e.stream == e.own_stream;      // on a caller's stream it would hold back the caller's next work
         bool handled = false;
         if (e.resident_alive) {
             if (linger_ok) handled = e.resident_step(pin, noise, e.host_seq);
