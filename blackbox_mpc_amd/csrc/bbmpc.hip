@@ -236,12 +236,14 @@ Engine::~Engine() {
     user_dynamics.release();
     user_rollout.release();
     if (h_pin) (void)hipHostFree(h_pin);
+    for (auto*& hs : h_record_stage) { if (hs) (void)hipHostFree(hs); hs = nullptr; }
     if (host_done) (void)hipHostFree(host_done);
     if (host_count) (void)hipFree(host_count);
     if (own_stream) (void)hipStreamDestroy(own_stream);
 }
 
 void Engine::settle() {
+    if (settle_hook) settle_hook(this);          // staged records of bbmpc_optimize_gather go to the collective first
     resident_stop();
     if (lazy_sync) {
         lazy_sync = false;
@@ -277,6 +279,7 @@ bool Engine::resident_step(const float* state, int add_noise, uint32_t seq) {
     m[5] = sw3[0]; m[6] = sw3[1]; m[7] = sw3[2];
     std::atomic_thread_fence(std::memory_order_release);
     m[0] = seq;
+    if (in_flight_hook && !in_flight_called) { in_flight_called = true; in_flight_hook(this); }   // host work that hides under the kernel
     volatile const uint32_t* ack = host_done;
     volatile const uint32_t* gone = gone_host();
     const auto t0 = std::chrono::steady_clock::now();
@@ -2352,16 +2355,16 @@ int bbmpc_optimize_dev(bbmpc_handle h, const float* d_state, int32_t, int32_t no
     API_END
 }
 
-int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise, float* action, float* next_state,
-                   float* reward) {
-    API_BEGIN
-    CHECK_HANDLE_NOSETTLE(h);            // consecutive calls are ordered by the stream; everything else settles first
-    CHECK_PTR(state);
-    Engine& e = *h->e;
+}  // extern "C"
+
+// One host-in / host-out control step (the body of bbmpc_optimize, shared with bbmpc_optimize_gather): returns the packed
+// records [A][U+S+1] in the handle's pinned buffer.  The caller has NOT settled the handle: consecutive calls are ordered
+// by the stream (or served by the resident kernel), everything else settles first.
+static const float* optimize_host(bbmpc::Engine& e, const float* state, int32_t noise, float* action, float* next_state, float* reward) {
+    using namespace bbmpc;
     const size_t ns = (size_t)e.A * e.S, nr = (size_t)e.A * e.rec;
     float* pin = e.pinned(ns + nr);
     memcpy(pin, state, ns * 4);
-    (void)t;  // the reference evaluator accepts and ignores time_step (deterministic.py:26)
     bool published = false;
     // single-kernel control steps read the state straight from the pinned, device-mapped host buffer; those and the
     // learned-dynamics path (whose last kernel, k_tail_mlp, owns the record) write the packed record straight into it
@@ -2426,6 +2429,7 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
         e.optimize_dev(e.d_state.p, noise, e.d_record.p, nullptr);
         HIP_CHECK(hipMemcpyAsync(pin + ns, e.d_record.p, nr * 4, hipMemcpyDeviceToHost, e.stream));
     }
+    if (e.in_flight_hook && !e.in_flight_called) { e.in_flight_called = true; e.in_flight_hook(&e); }   // launch path: the kernels are enqueued
     if (published) {
         volatile const uint32_t* f = e.host_done;
         const uint32_t want = e.host_seq;
@@ -2450,6 +2454,18 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
         if (next_state) memcpy(next_state + (size_t)a * e.S, r + (size_t)a * e.rec + e.U, e.S * 4);
         if (reward) reward[a] = r[(size_t)a * e.rec + e.U + e.S];
     }
+    return r;
+}
+
+extern "C" {
+
+int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise, float* action, float* next_state,
+                   float* reward) {
+    API_BEGIN
+    CHECK_HANDLE_NOSETTLE(h);            // consecutive calls are ordered by the stream; everything else settles first
+    CHECK_PTR(state);
+    (void)t;  // the reference evaluator accepts and ignores time_step (deterministic.py:26)
+    (void)optimize_host(*h->e, state, noise, action, next_state, reward);
     API_END
 }
 
@@ -2724,6 +2740,33 @@ static uint32_t next_comm_seq(Engine* e) {
 //    polls it between the other queue's dispatches; measured +77 us on a 25-launch control step.)
 // Completion (sync_mode 1) goes to a second flag that the host polls in bbmpc_gather_wait: an event recorded on the
 // communication stream and queried from the host was measured to cost the launch stream another 4 us per step.
+// the collective itself + "slot done" on the communication stream (whatever made d_records ready is already ordered before it there)
+static void gather_enqueue(Engine* e, const float* d_records, float* d_gathered, size_t count, int slot, uint32_t v) {
+    RecordComm& c = e->rc;
+    const Rccl& r = Rccl::get();
+    r.check(r.AllGather(d_records, d_gathered, count, Rccl::kFloat32, c.comm, c.stream), "ncclAllGather");
+    if (c.sync_mode == 1) {
+        HIP_CHECK(hipStreamWriteValue32(c.stream, c.done_flag[slot], v, 0));
+        c.done_seq[slot] = v;
+    } else {
+        HIP_CHECK(hipEventRecord(c.done[slot], c.stream));
+    }
+    c.pending[slot] = true;
+}
+
+// staged records of earlier bbmpc_optimize_gather calls -> HBM -> collective, on the communication stream
+static void flush_deferred_gathers(Engine* e) {
+    RecordComm& c = e->rc;
+    if (!c.comm) return;
+    const size_t nr = (size_t)e->A * e->rec;
+    for (int s = 0; s < RecordComm::kSlots; ++s) {
+        if (!e->gather_deferred[s]) continue;
+        e->gather_deferred[s] = false;
+        HIP_CHECK(hipMemcpyAsync(e->d_record_slot[s].p, e->h_record_stage[s], nr * sizeof(float), hipMemcpyHostToDevice, c.stream));
+        gather_enqueue(e, e->d_record_slot[s].p, e->gather_deferred_dst[s], nr, s, c.sync_mode == 1 ? next_comm_seq(e) : 0u);
+    }
+}
+
 static void gather_records(Engine* e, const float* d_records, float* d_gathered, size_t count, int slot, bool event_attached,
                            bool published, uint32_t v) {
     RecordComm& c = e->rc;
@@ -2734,14 +2777,7 @@ static void gather_records(Engine* e, const float* d_records, float* d_gathered,
         if (!event_attached) HIP_CHECK(hipEventRecord(c.ready[slot], e->stream));
         HIP_CHECK(hipStreamWaitEvent(c.stream, c.ready[slot], 0));
     }
-    r.check(r.AllGather(d_records, d_gathered, count, Rccl::kFloat32, c.comm, c.stream), "ncclAllGather");
-    if (c.sync_mode == 1) {
-        HIP_CHECK(hipStreamWriteValue32(c.stream, c.done_flag[slot], v, 0));
-        c.done_seq[slot] = v;
-    } else {
-        HIP_CHECK(hipEventRecord(c.done[slot], c.stream));
-    }
-    c.pending[slot] = true;
+    gather_enqueue(e, d_records, d_gathered, count, slot, v);
 }
 
 int bbmpc_gather_records_dev(bbmpc_handle h, const float* d_records, float* d_gathered, int64_t count, int32_t slot) {
@@ -2804,7 +2840,7 @@ int bbmpc_optimize_gather_dev(bbmpc_handle h, const float* d_state, int32_t, int
 int bbmpc_optimize_gather(bbmpc_handle h, const float* state, int32_t, int32_t noise, float* action, float* next_state,
                           float* reward, float* d_gathered, int32_t slot) {
     API_BEGIN
-    CHECK_HANDLE(h);
+    CHECK_HANDLE_NOSETTLE(h);            // as bbmpc_optimize: consecutive calls are ordered by the stream / the resident kernel
     CHECK_PTR(state);
     CHECK_PTR(d_gathered);
     Engine* e = h->e;
@@ -2812,45 +2848,31 @@ int bbmpc_optimize_gather(bbmpc_handle h, const float* state, int32_t, int32_t n
     if (!c.comm) throw HipError(BBMPC_E_STATE, "bbmpc_optimize_gather: call bbmpc_comm_init first");
     if (slot < 0 || slot >= RecordComm::kSlots) throw HipError(BBMPC_E_INVALID, "bbmpc_optimize_gather: slot must be 0 or 1");
     if (c.pending[slot]) throw HipError(BBMPC_E_STATE, "bbmpc_optimize_gather: slot still pending (call bbmpc_gather_wait)");
-    const size_t ns = (size_t)e->A * e->S, nr = (size_t)e->A * e->rec;
+    // this rank's agents: exactly bbmpc_optimize (zero-copy state, records polled from pinned memory, resident kernel).
+    // While the control step runs on the GPU the host enqueues the collective of the PREVIOUS call's records: the
+    // ~20 us of host API time (H2D copy, ncclAllGather, completion word) hide under the kernel instead of sitting
+    // between two control steps.  This call's own records are staged at the end and travel during the next call, or
+    // when anything settles the handle (bbmpc_gather_wait on the slot, bbmpc_synchronize, any other entry point).
+    const size_t nr = (size_t)e->A * e->rec;
     if (!e->d_record_slot[slot].p) e->d_record_slot[slot].alloc(nr);
-    float* d_rec = e->d_record_slot[slot].p;
-    float* pin = e->pinned(ns + nr);
-    memcpy(pin, state, ns * 4);
-    uint32_t v = 0;
-    if (c.sync_mode == 1) {
-        v = next_comm_seq(e);
-        e->tail_flag = c.flag;
-        e->tail_count = c.count;
-        e->tail_value = v;
-    } else {
-        e->tail_event = c.ready[slot];
-    }
-    e->tail_attached = false;
+    if (!e->h_record_stage[slot])
+        HIP_CHECK(hipHostMalloc((void**)&e->h_record_stage[slot], nr * sizeof(float), hipHostMallocDefault));
+    e->in_flight_hook = flush_deferred_gathers;
+    e->in_flight_called = false;
+    const float* rec = nullptr;
     try {
-        if (e->sw.zero_copy && e->use_fused()) {
-            e->optimize_dev(e->h_pin_dev, noise, d_rec, nullptr);        // the kernel reads the state from pinned host memory
-        } else {
-            HIP_CHECK(hipMemcpyAsync(e->d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e->stream));
-            e->optimize_dev(e->d_state.p, noise, d_rec, nullptr);
-        }
+        rec = optimize_host(*e, state, noise, action, next_state, reward);
     } catch (...) {
-        e->tail_event = nullptr;
-        e->tail_flag = nullptr;
+        e->in_flight_hook = nullptr;
         throw;
     }
-    e->tail_event = nullptr;
-    e->tail_flag = nullptr;
-    const bool published = c.sync_mode == 1 && e->tail_attached;
-    gather_records(e, d_rec, d_gathered, nr, slot, c.sync_mode == 0 && e->tail_attached, published, v);
-    HIP_CHECK(hipMemcpyAsync(pin + ns, d_rec, nr * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_CHECK(hipStreamSynchronize(e->stream));
-    const float* r = pin + ns;
-    for (int a = 0; a < e->A; ++a) {
-        if (action) memcpy(action + (size_t)a * e->U, r + (size_t)a * e->rec, e->U * 4);
-        if (next_state) memcpy(next_state + (size_t)a * e->S, r + (size_t)a * e->rec + e->U, e->S * 4);
-        if (reward) reward[a] = r[(size_t)a * e->rec + e->U + e->S];
-    }
+    e->in_flight_hook = nullptr;
+    if (!e->in_flight_called) flush_deferred_gathers(e);
+    memcpy(e->h_record_stage[slot], rec, nr * sizeof(float));      // the slot is free: its last gather was waited for (pending == false)
+    e->gather_deferred[slot] = true;
+    e->gather_deferred_dst[slot] = d_gathered;
+    e->settle_hook = flush_deferred_gathers;
+    c.pending[slot] = true;
     API_END
 }
 
@@ -2873,11 +2895,17 @@ int bbmpc_comm_info(bbmpc_handle h, int32_t* nranks, int32_t* rank, int32_t* syn
 
 int bbmpc_gather_wait(bbmpc_handle h, int32_t slot, int32_t host_block) {
     API_BEGIN
-    CHECK_HANDLE(h);
+    CHECK_HANDLE_NOSETTLE(h);            // part of the control loop: must not stop a resident kernel
     Engine* e = h->e;
     RecordComm& c = e->rc;
     if (slot < 0 || slot >= RecordComm::kSlots) throw HipError(BBMPC_E_INVALID, "bbmpc_gather_wait: slot must be 0 or 1");
     if (c.pending[slot]) {
+        if (e->gather_deferred[slot]) {
+            flush_deferred_gathers(e);                           // staged by bbmpc_optimize_gather, not enqueued yet
+            host_block = 1;                                      // its staging buffer is host memory: the host has to see it consumed
+        } else if (e->h_record_stage[slot] && !host_block && c.sync_mode == 1 && *(volatile const uint32_t*)c.done_flag[slot] < c.done_seq[slot]) {
+            host_block = 1;                                      // ditto for an enqueued one that has not finished (rare: it is a control step old)
+        }
         if (c.sync_mode == 0) {
             if (host_block) {
                 HIP_CHECK(hipEventSynchronize(c.done[slot]));

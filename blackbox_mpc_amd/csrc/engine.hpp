@@ -139,6 +139,14 @@ struct Engine {
     DevBuf<float> d_noise_pf[2];      // two chunks of pf_steps control steps each
     RecordComm rc;           // multi-GPU record all-gather (comm.hpp); unused until bbmpc_comm_init
     DevBuf<float> d_record_slot[RecordComm::kSlots];   // bbmpc_optimize_gather: the all-gather of step t reads its records while step t+1 runs
+    float* h_record_stage[RecordComm::kSlots] = {nullptr, nullptr};   // pinned: the rank's records on their way host -> HBM (communication stream)
+    // bbmpc_optimize_gather enqueues the collective of a control step while the NEXT one runs on the GPU (its ~20 us of
+    // host API time would otherwise sit between two control steps): staged records whose gather is not enqueued yet
+    bool gather_deferred[RecordComm::kSlots] = {false, false};
+    float* gather_deferred_dst[RecordComm::kSlots] = {nullptr, nullptr};
+    void (*settle_hook)(Engine*) = nullptr;      // flushes them when anything settles the handle
+    void (*in_flight_hook)(Engine*) = nullptr;   // called once per host-in / host-out control step, right after it was handed to the GPU
+    bool in_flight_called = false;
     hipEvent_t tail_event = nullptr;   // completion event wanted on the control step's last kernel (launch_with_tail)
     bool tail_attached = false;
     uint32_t* tail_flag = nullptr;     // or: sequence number the last kernel should publish itself (RecordComm::flag / host_done)

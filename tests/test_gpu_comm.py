@@ -221,3 +221,40 @@ def test_handles_on_two_devices_in_one_process():
     assert torch.cuda.current_device() == 0
     np.testing.assert_array_equal(a0, a1)     # same seed, same inputs: the device does not matter
     np.testing.assert_array_equal(e0.optimize(s)[0], e1.optimize(s)[0])
+
+
+@pytest.mark.parametrize("sync", ["flags", "event"])
+@pytest.mark.parametrize("kind,A", [("cem", 1), ("pi2", 3), ("mlp", 2)])
+def test_host_call_with_gather_matches_the_plain_host_call(L, monkeypatch, kind, A, sync):
+    # bbmpc_optimize_gather = bbmpc_optimize for the rank's agents (for one agent: served by the resident kernel) + the
+    # records' way back to HBM and into the collective on the communication stream only
+    import torch
+    from blackbox_mpc_amd.engine import Engine
+    monkeypatch.setenv("BBMPC_COMM_SYNC", sync)
+
+    def make():
+        if kind == "mlp":
+            return _mlp_engine(L, A=A)
+        return _pendulum_engine(L, L.OPT_CEM if kind == "cem" else L.OPT_PI2, A=A)
+    ref, eng = make(), make()
+    eng.comm_init(Engine.comm_unique_id(), 1, 0)
+    dev = torch.device("cuda", 0)
+    S = ref.S
+    rec_w = ref.U + S + 1
+    gathered = [torch.full((A, rec_w), -7.0, device=dev) for _ in range(2)]
+    s_ref = s = (O.cheetah_start_states(A, S) if kind == "mlp" else O.pendulum_start_states(A))
+    for t in range(24):                              # crosses noise-prefetch chunks; slots alternate
+        b = t & 1
+        a_r, n_r, r_r = ref.optimize(s_ref, t)
+        eng.gather_wait(b)
+        a_g, n_g, r_g = eng.optimize_gather(s, gathered[b].data_ptr(), b, t)
+        np.testing.assert_array_equal(a_g, a_r)
+        np.testing.assert_array_equal(n_g, n_r)
+        np.testing.assert_array_equal(r_g, r_r)
+        if t % 5 == 0:
+            eng.gather_wait(b, host_block=True)
+            want = np.concatenate([a_g, n_g, r_g.reshape(-1, 1)], axis=1)
+            np.testing.assert_array_equal(gathered[b].cpu().numpy(), want)
+        s_ref, s = n_r, n_g
+    for b in range(2):
+        eng.gather_wait(b, host_block=True)
