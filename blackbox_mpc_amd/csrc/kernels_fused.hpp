@@ -126,478 +126,478 @@ __global__ void k_fused_pendulum(FusedArgs p) {
     if (tid < 3) red[60 + tid] = p.state[a * 3 + tid];
     for (;;) {      // one pass per control step; a single pass unless LINGER
 
-    // ---- distribution init (cem.py:129-132 starts every control step from the ctor mean/var, quirk Q2)
-    for (int j = tid; j < p.HU; j += nthr) {
-        const float m = p.prev_mean[a * p.HU + j];
-        const float v = p.var0[a * p.HU + j];
-        mean[j] = m;
-        var[j] = v;
-        sigma[j] = (OPT == FOPT_CEM) ? cem_sigma(m, v, lo, hi) : ((OPT == FOPT_SPSA) ? 0.0f : sqrtf(v));
-    }
-    __syncthreads();
-    const float s0 = red[60], s1 = red[61], s2 = red[62];
+        // ---- distribution init (cem.py:129-132 starts every control step from the ctor mean/var, quirk Q2)
+        for (int j = tid; j < p.HU; j += nthr) {
+            const float m = p.prev_mean[a * p.HU + j];
+            const float v = p.var0[a * p.HU + j];
+            mean[j] = m;
+            var[j] = v;
+            sigma[j] = (OPT == FOPT_CEM) ? cem_sigma(m, v, lo, hi) : ((OPT == FOPT_SPSA) ? 0.0f : sqrtf(v));
+        }
+        __syncthreads();
+        const float s0 = red[60], s1 = red[61], s2 = red[62];
 
-    float action0 = (OPT == FOPT_RS) ? 0.0f : mean[0];          // iters == 0 -> untouched mean[:,0]
+        float action0 = (OPT == FOPT_RS) ? 0.0f : mean[0];          // iters == 0 -> untouched mean[:,0]
 
-    BB_DBG(0);
+        BB_DBG(0);
 #ifdef BBMPC_KERNEL_DBG
-    if (p.dbg && tid == 0 && a == 0) dbg_lds[40] = (long long)clock64();
+        if (p.dbg && tid == 0 && a == 0) dbg_lds[40] = (long long)clock64();
 #endif
-    for (int it = 0; it < p.iters; ++it) {
-        BB_DBG(1 + it * 4);
-        // ---- sample + rollout: one lane per trajectory, state in VGPRs
-        // The 4 candidate actions of Philox block b+1 are generated while the recurrence steps through
-        // block b: their instructions carry no dependence on the state, so they fill the latency
-        // shadows of the sequential theta/thdot chain (all straight-line code inside a block).
-        const float* inj = (INJ == 1) ? inj_s + ((size_t)it * p.A + a) * p.HU * p.Nst : nullptr;
-        const int nblk = p.H >> 2, rem = p.H & 3;
-        const uint32_t rstream = (OPT == FOPT_RS) ? 2u : 1u;
-        // ILP independent trajectories per lane: with half as many waves each SIMD runs a single wave whose two
-        // recurrences interleave in program order, instead of two waves fighting over issue slots.
-        if constexpr (OPT == FOPT_SPSA) {
-            // SPSA (spsa.py:61-107): theta +- c_k * delta with delta in {-1,+1}; both candidates of a particle are
-            // rolled out by the same lane (two independent recurrences: four chains per SIMD at N = 500).  The
-            // Rademacher draws stay in LDS (samp) for the gradient estimate.
-            const float ck = p.spsa_ck[it];
-            const int nb4 = (p.H + 3) >> 2;
-            for (int n = tid; n < p.N; n += nthr) {
-                Roller<FASTM> rp, rm;
-                rp.init(p.fix_q1 != 0, s0, s1, s2);
-                rm.init(p.fix_q1 != 0, s0, s1, s2);
-                float tp = 0.0f, tm = 0.0f, pp = 0.0f, pm = 0.0f;
-                [[maybe_unused]] const float4* mine4 = nullptr;
-                [[maybe_unused]] float4 cur4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-                if constexpr (INJ == 2) {            // draws prefetched by k_noise_fill, one float4 per 4 steps
-                    mine4 = reinterpret_cast<const float4*>(inj_s) + (((size_t)it * p.A + a) * p.Nst + n) * nb4;
-                    cur4 = mine4[0];
-                }
-                for (int b = 0; b < nb4; ++b) {
-                    float d[4];
-                    if constexpr (INJ == 2) {
-                        const float4 nxt4 = mine4[min(b + 1, nb4 - 1)];
-                        d[0] = cur4.x; d[1] = cur4.y; d[2] = cur4.z; d[3] = cur4.w;
-                        cur4 = nxt4;
-                    } else if (INJ == 1) {
+        for (int it = 0; it < p.iters; ++it) {
+            BB_DBG(1 + it * 4);
+            // ---- sample + rollout: one lane per trajectory, state in VGPRs
+            // The 4 candidate actions of Philox block b+1 are generated while the recurrence steps through
+            // block b: their instructions carry no dependence on the state, so they fill the latency
+            // shadows of the sequential theta/thdot chain (all straight-line code inside a block).
+            const float* inj = (INJ == 1) ? inj_s + ((size_t)it * p.A + a) * p.HU * p.Nst : nullptr;
+            const int nblk = p.H >> 2, rem = p.H & 3;
+            const uint32_t rstream = (OPT == FOPT_RS) ? 2u : 1u;
+            // ILP independent trajectories per lane: with half as many waves each SIMD runs a single wave whose two
+            // recurrences interleave in program order, instead of two waves fighting over issue slots.
+            if constexpr (OPT == FOPT_SPSA) {
+                // SPSA (spsa.py:61-107): theta +- c_k * delta with delta in {-1,+1}; both candidates of a particle are
+                // rolled out by the same lane (two independent recurrences: four chains per SIMD at N = 500).  The
+                // Rademacher draws stay in LDS (samp) for the gradient estimate.
+                const float ck = p.spsa_ck[it];
+                const int nb4 = (p.H + 3) >> 2;
+                for (int n = tid; n < p.N; n += nthr) {
+                    Roller<FASTM> rp, rm;
+                    rp.init(p.fix_q1 != 0, s0, s1, s2);
+                    rm.init(p.fix_q1 != 0, s0, s1, s2);
+                    float tp = 0.0f, tm = 0.0f, pp = 0.0f, pm = 0.0f;
+                    [[maybe_unused]] const float4* mine4 = nullptr;
+                    [[maybe_unused]] float4 cur4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                    if constexpr (INJ == 2) {            // draws prefetched by k_noise_fill, one float4 per 4 steps
+                        mine4 = reinterpret_cast<const float4*>(inj_s) + (((size_t)it * p.A + a) * p.Nst + n) * nb4;
+                        cur4 = mine4[0];
+                    }
+                    for (int b = 0; b < nb4; ++b) {
+                        float d[4];
+                        if constexpr (INJ == 2) {
+                            const float4 nxt4 = mine4[min(b + 1, nb4 - 1)];
+                            d[0] = cur4.x; d[1] = cur4.y; d[2] = cur4.z; d[3] = cur4.w;
+                            cur4 = nxt4;
+                        } else if (INJ == 1) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) d[i] = (4 * b + i < p.H) ? inj[(size_t)(4 * b + i) * p.Nst + n] : 1.0f;
+                            for (int i = 0; i < 4; ++i) d[i] = (4 * b + i < p.H) ? inj[(size_t)(4 * b + i) * p.Nst + n] : 1.0f;
+                        } else {
+                            const U4 w = rng_block(key_s, 3u, (uint32_t)it, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)(4 * b));
+                            d[0] = word_to_rademacher(w.x); d[1] = word_to_rademacher(w.y);
+                            d[2] = word_to_rademacher(w.z); d[3] = word_to_rademacher(w.w);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int t = 4 * b + i;
+                            if (t < p.H) {
+                                const float th = mean[t], stp = ck * d[i];
+                                const float xp = th + stp, xm = th - stp;                      // spsa.py:76-77
+                                const float xpf = clipf(xp, lo, hi), xmf = clipf(xm, lo, hi);  // :78-81
+                                const float dp = xp - xpf, dm = xm - xmf;
+                                pp = pp + dp * dp;
+                                pm = pm + dm * dm;
+                                samp[(size_t)t * p.Nst + n] = d[i];
+                                tp = tp + rp.step(xpf);
+                                tm = tm + rm.step(xmf);
+                            }
+                        }
+                    }
+                    if (tp != tp) tp = -1.0e6f;                                                // deterministic.py:75-77
+                    if (tm != tm) tm = -1.0e6f;
+                    const float np_ = sqrtf(pp), nm_ = sqrtf(pm);                              // tf.norm(...)**2  spsa.py:82-89
+                    const float r_p = tp - np_ * np_, r_m = tm - nm_ * nm_;                    // :98-99
+                    if (p.t_rewards) {
+                        p.t_rewards[((size_t)it * p.A + a) * p.Nst + n] = r_p;
+                        p.t_rewards2[((size_t)it * p.A + a) * p.Nst + n] = r_m;
+                    }
+                    rew[n] = r_p - r_m;
+                }
+            } else if constexpr (INJ == 2) {
+                // Draws prefetched by idle CUs (k_noise_fill): one float4 = one Philox block = 4 steps of this trajectory.
+                // Loads run TWO blocks (8 steps, ~2 us) ahead of their use so that L2/HBM latency never reaches the
+                // recurrence; the Philox rounds (a quarter of this kernel's VALU work) are gone from the critical path.
+                const int Q = (p.HU + 3) >> 2;
+                const float4* inj4 = reinterpret_cast<const float4*>(inj_s) + ((size_t)it * p.A + a) * p.Nst * Q;
+                int* prog = (int*)red;                             // per-wave progress (red[] is idle during the rollout)
+                const int wave = tid >> 6, lane = tid & 63;
+                const bool balance = p.balance != 0 && nw > 4 && nw <= 64 && p.N <= nthr;
+                for (int n = tid; n < p.N; n += nthr) {
+                    Roller<FASTM> roll;
+                    roll.init(p.fix_q1 != 0, s0, s1, s2);
+                    float total = 0.0f, pen = 0.0f;
+                    const float4* mine = inj4 + (size_t)n * Q;
+                    auto ld = [&](int b) { return mine[min(b, Q - 1)]; };
+                    auto step1 = [&](int t, float xi) {
+                        float x = (OPT == FOPT_RS) ? xi * (hi - lo) + lo : xi * sigma[t] + mean[t];
+                        if (OPT == FOPT_PI2) {
+                            const float xf = clipf(x, lo, hi);
+                            const float d = x - xf;
+                            pen = pen + d * d;
+                            x = xf;
+                        }
+                        samp[(size_t)t * p.Nst + n] = x;
+                        total = total + roll.step(x);
+                    };
+                    auto block4 = [&](const float4& z, int b) {
+                        step1(4 * b + 0, z.x); step1(4 * b + 1, z.y); step1(4 * b + 2, z.z); step1(4 * b + 3, z.w);
+                    };
+                    float4 c0 = ld(0), c1 = ld(1);
+                    int b = 0;
+                    // Waves that share a SIMD (wave ids equal mod 4) run the same instruction stream, and the arbiter
+                    // favours the older one: it finishes early and the younger one then runs alone at a lone wave's
+                    // issue rate (measured: 4.5 us vs 6.0 us for the two halves of a 500-particle population).  Each
+                    // wave publishes its block counter in LDS and lowers its priority while it is ahead of a SIMD mate.
+                    if (balance && lane == 0) prog[wave] = 0;
+                    for (; b + 1 < nblk; b += 2) {
+                        const float4 n0 = ld(b + 2), n1 = ld(b + 3);
+                        if (balance) {
+                            if (lane == 0) prog[wave] = b;
+                            int behind = b;
+                            for (int w2 = wave & 3; w2 < nw; w2 += 4) behind = min(behind, prog[w2]);
+                            if (behind < b) __builtin_amdgcn_s_setprio(0);
+                            else __builtin_amdgcn_s_setprio(2);
+                        }
+                        block4(c0, b);
+                        block4(c1, b + 1);
+                        c0 = n0; c1 = n1;
+                    }
+                    if (balance) {
+                        if (lane == 0) prog[wave] = 1 << 30;
+                        __builtin_amdgcn_s_setprio(0);
+                    }
+                    if (b < nblk) { block4(c0, b); c0 = c1; ++b; }
+                    if (rem > 0) step1(4 * b + 0, c0.x);
+                    if (rem > 1) step1(4 * b + 1, c0.y);
+                    if (rem > 2) step1(4 * b + 2, c0.z);
+                    float tot = total;
+                    if (tot != tot) tot = -1.0e6f;                                   // deterministic.py:75-77
+                    if (OPT == FOPT_PI2) {
+                        const float nr = sqrtf(pen);
+                        tot = tot - nr * nr;
+                    }
+                    rew[n] = tot;
+                }
+            } else
+            for (int n0 = tid; n0 < p.N; n0 += ILP * nthr) {
+                int nn[ILP];
+                bool live[ILP];
+                Roller<FASTM> roll[ILP];
+                float total[ILP], pen[ILP], xn[ILP][4];
+#pragma unroll
+                for (int q = 0; q < ILP; ++q) {
+                    live[q] = n0 + q * nthr < p.N;
+                    nn[q] = live[q] ? n0 + q * nthr : n0;          // idle slots shadow particle n0 (never stored)
+                    roll[q].init(p.fix_q1 != 0, s0, s1, s2);
+                    total[q] = 0.0f;
+                    pen[q] = 0.0f;
+                }
+                auto gen = [&](int q, int b) {
+                    const int n = nn[q];
+                    float xi[4];
+                    if (INJ) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xi[i] = (4 * b + i < p.H) ? inj[(size_t)(4 * b + i) * p.Nst + n] : 0.0f;
                     } else {
-                        const U4 w = rng_block(key_s, 3u, (uint32_t)it, (uint32_t)n, (uint32_t)(p.agent_offset + a), (uint32_t)(4 * b));
-                        d[0] = word_to_rademacher(w.x); d[1] = word_to_rademacher(w.y);
-                        d[2] = word_to_rademacher(w.z); d[3] = word_to_rademacher(w.w);
+                        const U4 w = rng_block(key_s, rstream, (uint32_t)it, (uint32_t)n, (uint32_t)(p.agent_offset + a),
+                                               (uint32_t)(4 * b));
+                        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            xi[i] = (OPT == FOPT_RS) ? word_to_uniform(ww[i]) : word_to_trunc_normal(ww[i]);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int t = 4 * b + i;
-                        if (t < p.H) {
-                            const float th = mean[t], stp = ck * d[i];
-                            const float xp = th + stp, xm = th - stp;                      // spsa.py:76-77
-                            const float xpf = clipf(xp, lo, hi), xmf = clipf(xm, lo, hi);  // :78-81
-                            const float dp = xp - xpf, dm = xm - xmf;
-                            pp = pp + dp * dp;
-                            pm = pm + dm * dm;
-                            samp[(size_t)t * p.Nst + n] = d[i];
-                            tp = tp + rp.step(xpf);
-                            tm = tm + rm.step(xmf);
-                        }
+                        const int t = min(4 * b + i, p.H - 1);
+                        if (OPT == FOPT_RS) xn[q][i] = xi[i] * (hi - lo) + lo;      // random_search.py:40-41
+                        else xn[q][i] = xi[i] * sigma[t] + mean[t];                 // cem.py:90-94 / pi2.py:65-69
                     }
-                }
-                if (tp != tp) tp = -1.0e6f;                                                // deterministic.py:75-77
-                if (tm != tm) tm = -1.0e6f;
-                const float np_ = sqrtf(pp), nm_ = sqrtf(pm);                              // tf.norm(...)**2  spsa.py:82-89
-                const float r_p = tp - np_ * np_, r_m = tm - nm_ * nm_;                    // :98-99
-                if (p.t_rewards) {
-                    p.t_rewards[((size_t)it * p.A + a) * p.Nst + n] = r_p;
-                    p.t_rewards2[((size_t)it * p.A + a) * p.Nst + n] = r_m;
-                }
-                rew[n] = r_p - r_m;
-            }
-        } else if constexpr (INJ == 2) {
-            // Draws prefetched by idle CUs (k_noise_fill): one float4 = one Philox block = 4 steps of this trajectory.
-            // Loads run TWO blocks (8 steps, ~2 us) ahead of their use so that L2/HBM latency never reaches the
-            // recurrence; the Philox rounds (a quarter of this kernel's VALU work) are gone from the critical path.
-            const int Q = (p.HU + 3) >> 2;
-            const float4* inj4 = reinterpret_cast<const float4*>(inj_s) + ((size_t)it * p.A + a) * p.Nst * Q;
-            int* prog = (int*)red;                             // per-wave progress (red[] is idle during the rollout)
-            const int wave = tid >> 6, lane = tid & 63;
-            const bool balance = p.balance != 0 && nw > 4 && nw <= 64 && p.N <= nthr;
-            for (int n = tid; n < p.N; n += nthr) {
-                Roller<FASTM> roll;
-                roll.init(p.fix_q1 != 0, s0, s1, s2);
-                float total = 0.0f, pen = 0.0f;
-                const float4* mine = inj4 + (size_t)n * Q;
-                auto ld = [&](int b) { return mine[min(b, Q - 1)]; };
-                auto step1 = [&](int t, float xi) {
-                    float x = (OPT == FOPT_RS) ? xi * (hi - lo) + lo : xi * sigma[t] + mean[t];
-                    if (OPT == FOPT_PI2) {
+                };
+                auto consume = [&](int q, int t, float x) {
+                    if (OPT == FOPT_PI2) {                                           // pi2.py:70-75
                         const float xf = clipf(x, lo, hi);
                         const float d = x - xf;
-                        pen = pen + d * d;
+                        pen[q] = pen[q] + d * d;
                         x = xf;
                     }
-                    samp[(size_t)t * p.Nst + n] = x;
-                    total = total + roll.step(x);
+                    if (live[q]) samp[(size_t)t * p.Nst + nn[q]] = x;
+                    total[q] = total[q] + roll[q].step(x);
                 };
-                auto block4 = [&](const float4& z, int b) {
-                    step1(4 * b + 0, z.x); step1(4 * b + 1, z.y); step1(4 * b + 2, z.z); step1(4 * b + 3, z.w);
-                };
-                float4 c0 = ld(0), c1 = ld(1);
-                int b = 0;
-                // Waves that share a SIMD (wave ids equal mod 4) run the same instruction stream, and the arbiter
-                // favours the older one: it finishes early and the younger one then runs alone at a lone wave's
-                // issue rate (measured: 4.5 us vs 6.0 us for the two halves of a 500-particle population).  Each
-                // wave publishes its block counter in LDS and lowers its priority while it is ahead of a SIMD mate.
-                if (balance && lane == 0) prog[wave] = 0;
-                for (; b + 1 < nblk; b += 2) {
-                    const float4 n0 = ld(b + 2), n1 = ld(b + 3);
-                    if (balance) {
-                        if (lane == 0) prog[wave] = b;
-                        int behind = b;
-                        for (int w2 = wave & 3; w2 < nw; w2 += 4) behind = min(behind, prog[w2]);
-                        if (behind < b) __builtin_amdgcn_s_setprio(0);
-                        else __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+                for (int q = 0; q < ILP; ++q) gen(q, 0);
+                for (int b = 0; b < nblk; ++b) {
+                    float xc[ILP][4];
+#pragma unroll
+                    for (int q = 0; q < ILP; ++q) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xc[q][i] = xn[q][i];
+                        gen(q, b + 1);       // one block ahead (the block past the end is generated and dropped)
                     }
-                    block4(c0, b);
-                    block4(c1, b + 1);
-                    c0 = n0; c1 = n1;
-                }
-                if (balance) {
-                    if (lane == 0) prog[wave] = 1 << 30;
-                    __builtin_amdgcn_s_setprio(0);
-                }
-                if (b < nblk) { block4(c0, b); c0 = c1; ++b; }
-                if (rem > 0) step1(4 * b + 0, c0.x);
-                if (rem > 1) step1(4 * b + 1, c0.y);
-                if (rem > 2) step1(4 * b + 2, c0.z);
-                float tot = total;
-                if (tot != tot) tot = -1.0e6f;                                   // deterministic.py:75-77
-                if (OPT == FOPT_PI2) {
-                    const float nr = sqrtf(pen);
-                    tot = tot - nr * nr;
-                }
-                rew[n] = tot;
-            }
-        } else
-        for (int n0 = tid; n0 < p.N; n0 += ILP * nthr) {
-            int nn[ILP];
-            bool live[ILP];
-            Roller<FASTM> roll[ILP];
-            float total[ILP], pen[ILP], xn[ILP][4];
-#pragma unroll
-            for (int q = 0; q < ILP; ++q) {
-                live[q] = n0 + q * nthr < p.N;
-                nn[q] = live[q] ? n0 + q * nthr : n0;          // idle slots shadow particle n0 (never stored)
-                roll[q].init(p.fix_q1 != 0, s0, s1, s2);
-                total[q] = 0.0f;
-                pen[q] = 0.0f;
-            }
-            auto gen = [&](int q, int b) {
-                const int n = nn[q];
-                float xi[4];
-                if (INJ) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) xi[i] = (4 * b + i < p.H) ? inj[(size_t)(4 * b + i) * p.Nst + n] : 0.0f;
-                } else {
-                    const U4 w = rng_block(key_s, rstream, (uint32_t)it, (uint32_t)n, (uint32_t)(p.agent_offset + a),
-                                           (uint32_t)(4 * b));
-                    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        xi[i] = (OPT == FOPT_RS) ? word_to_uniform(ww[i]) : word_to_trunc_normal(ww[i]);
-                }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int t = min(4 * b + i, p.H - 1);
-                    if (OPT == FOPT_RS) xn[q][i] = xi[i] * (hi - lo) + lo;      // random_search.py:40-41
-                    else xn[q][i] = xi[i] * sigma[t] + mean[t];                 // cem.py:90-94 / pi2.py:65-69
+                        for (int q = 0; q < ILP; ++q) consume(q, 4 * b + i, xc[q][i]);
                 }
-            };
-            auto consume = [&](int q, int t, float x) {
-                if (OPT == FOPT_PI2) {                                           // pi2.py:70-75
-                    const float xf = clipf(x, lo, hi);
-                    const float d = x - xf;
-                    pen[q] = pen[q] + d * d;
-                    x = xf;
-                }
-                if (live[q]) samp[(size_t)t * p.Nst + nn[q]] = x;
-                total[q] = total[q] + roll[q].step(x);
-            };
+                for (int i = 0; i < rem; ++i)
 #pragma unroll
-            for (int q = 0; q < ILP; ++q) gen(q, 0);
-            for (int b = 0; b < nblk; ++b) {
-                float xc[ILP][4];
+                    for (int q = 0; q < ILP; ++q) consume(q, 4 * nblk + i, xn[q][i]);
 #pragma unroll
                 for (int q = 0; q < ILP; ++q) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) xc[q][i] = xn[q][i];
-                    gen(q, b + 1);       // one block ahead (the block past the end is generated and dropped)
+                    float tot = total[q];
+                    if (tot != tot) tot = -1.0e6f;                                   // deterministic.py:75-77
+                    if (OPT == FOPT_PI2) {
+                        const float nr = sqrtf(pen[q]);
+                        tot = tot - nr * nr;
+                    }
+                    if (live[q]) rew[nn[q]] = tot;
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int q = 0; q < ILP; ++q) consume(q, 4 * b + i, xc[q][i]);
             }
-            for (int i = 0; i < rem; ++i)
-#pragma unroll
-                for (int q = 0; q < ILP; ++q) consume(q, 4 * nblk + i, xn[q][i]);
-#pragma unroll
-            for (int q = 0; q < ILP; ++q) {
-                float tot = total[q];
-                if (tot != tot) tot = -1.0e6f;                                   // deterministic.py:75-77
-                if (OPT == FOPT_PI2) {
-                    const float nr = sqrtf(pen[q]);
-                    tot = tot - nr * nr;
-                }
-                if (live[q]) rew[nn[q]] = tot;
-            }
-        }
 #ifdef BBMPC_KERNEL_DBG
-        if (p.dbg && a == 0 && it == 0 && (tid & 63) == 0) dbg_lds[24 + (tid >> 6) % 8] = (long long)wall_clock64();
+            if (p.dbg && a == 0 && it == 0 && (tid & 63) == 0) dbg_lds[24 + (tid >> 6) % 8] = (long long)wall_clock64();
 #endif
-        BB_DBG(2 + it * 4);
-        __syncthreads();
-        BB_DBG(3 + it * 4);
-        if (p.t_rewards) {
-            if (OPT != FOPT_SPSA)
-                for (int n = tid; n < p.N; n += nthr) p.t_rewards[((size_t)it * p.A + a) * p.Nst + n] = rew[n];
-            for (int i = tid; i < p.HU * p.Nst; i += nthr) {
-                const int j = i / p.Nst, n = i % p.Nst;
-                if (n < p.N) p.t_samples[(((size_t)it * p.A + a) * p.HU + j) * p.Nst + n] = samp[(size_t)j * p.Nst + n];
+            BB_DBG(2 + it * 4);
+            __syncthreads();
+            BB_DBG(3 + it * 4);
+            if (p.t_rewards) {
+                if (OPT != FOPT_SPSA)
+                    for (int n = tid; n < p.N; n += nthr) p.t_rewards[((size_t)it * p.A + a) * p.Nst + n] = rew[n];
+                for (int i = tid; i < p.HU * p.Nst; i += nthr) {
+                    const int j = i / p.Nst, n = i % p.Nst;
+                    if (n < p.N) p.t_samples[(((size_t)it * p.A + a) * p.HU + j) * p.Nst + n] = samp[(size_t)j * p.Nst + n];
+                }
             }
-        }
 
-        // ---- refit
-        if (OPT == FOPT_CEM) {
-            // exact sorted top-k (tf.nn.top_k, cem.py:97-99): LDS radix select, see topk.hpp
-            // The refit needs the elite SET only, so the winners are listed in ascending index order (no ranking);
-            // the sorted list tf.nn.top_k returns is produced only for the parity trace.  The statistics below always
-            // run over the index-ordered list, so results do not depend on tracing.
-            const TopkSel sel = block_topk_select(rew, p.N, p.k, hist, tid, nthr);
-            if (p.t_elites) {
-                block_topk_finish_sorted(rew, p.N, p.k, eidx, hist, ekeys, sel, tid, nthr);
-                for (int e = tid; e < p.k; e += nthr) p.t_elites[((size_t)it * p.A + a) * p.k + e] = eidx[e];
-                __syncthreads();
-            }
-            block_topk_finish_indexed(rew, p.N, p.k, eidx, hist, sel, tid, nthr);
-            BB_DBG(4 + it * 4);
+            // ---- refit
+            if (OPT == FOPT_CEM) {
+                // exact sorted top-k (tf.nn.top_k, cem.py:97-99): LDS radix select, see topk.hpp
+                // The refit needs the elite SET only, so the winners are listed in ascending index order (no ranking);
+                // the sorted list tf.nn.top_k returns is produced only for the parity trace.  The statistics below always
+                // run over the index-ordered list, so results do not depend on tracing.
+                const TopkSel sel = block_topk_select(rew, p.N, p.k, hist, tid, nthr);
+                if (p.t_elites) {
+                    block_topk_finish_sorted(rew, p.N, p.k, eidx, hist, ekeys, sel, tid, nthr);
+                    for (int e = tid; e < p.k; e += nthr) p.t_elites[((size_t)it * p.A + a) * p.k + e] = eidx[e];
+                    __syncthreads();
+                }
+                block_topk_finish_indexed(rew, p.N, p.k, eidx, hist, sel, tid, nthr);
+                BB_DBG(4 + it * 4);
 #ifdef BBMPC_KERNEL_DBG
-            if (p.dbg && tid == 0 && a == 0 && it == 1) for (int i = 0; i < 12; ++i) p.dbg[48 + i] = g_topk_dbg[i];
+                if (p.dbg && tid == 0 && a == 0 && it == 1) for (int i = 0; i < 12; ++i) p.dbg[48 + i] = g_topk_dbg[i];
 #endif
-            // elite statistics (cem.py:112-125): one 16-lane DPP row per (h,u) element -- 4 elements per wave,
-            // every element of the horizon at once for H*U <= 4*waves; mean and biased variance two-pass,
-            // as the reference computes them.
-            const float kf = (float)p.k;
-            const int sub = tid & 15;
-            // up to 64 elites: a lane's (<= 4) elite indices and sample values stay in registers -- every LDS read of
-            // a phase is issued before the first use (a dependent eidx -> row read per element costs two LDS
-            // latencies each, 16 in a row for k = 50)
-            constexpr int EC = 4;
-            const bool small_k = p.k <= 16 * EC;
-            int ei[EC];
+                // elite statistics (cem.py:112-125): one 16-lane DPP row per (h,u) element -- 4 elements per wave,
+                // every element of the horizon at once for H*U <= 4*waves; mean and biased variance two-pass,
+                // as the reference computes them.
+                const float kf = (float)p.k;
+                const int sub = tid & 15;
+                // up to 64 elites: a lane's (<= 4) elite indices and sample values stay in registers -- every LDS read of
+                // a phase is issued before the first use (a dependent eidx -> row read per element costs two LDS
+                // latencies each, 16 in a row for k = 50)
+                constexpr int EC = 4;
+                const bool small_k = p.k <= 16 * EC;
+                int ei[EC];
 #pragma unroll
-            for (int i = 0; i < EC; ++i) ei[i] = (small_k && sub + 16 * i < p.k) ? eidx[sub + 16 * i] : -1;
-            for (int j = tid >> 4; j < ((p.HU + 3) & ~3); j += nthr >> 4) {       // all 16 lanes of a row share j
-                const bool live = j < p.HU;
-                const float* row = samp + (size_t)(live ? j : 0) * p.Nst;
-                float sum = 0.0f, vs = 0.0f, em;
-                if (small_k) {
-                    float x[EC];
+                for (int i = 0; i < EC; ++i) ei[i] = (small_k && sub + 16 * i < p.k) ? eidx[sub + 16 * i] : -1;
+                for (int j = tid >> 4; j < ((p.HU + 3) & ~3); j += nthr >> 4) {       // all 16 lanes of a row share j
+                    const bool live = j < p.HU;
+                    const float* row = samp + (size_t)(live ? j : 0) * p.Nst;
+                    float sum = 0.0f, vs = 0.0f, em;
+                    if (small_k) {
+                        float x[EC];
 #pragma unroll
-                    for (int i = 0; i < EC; ++i) x[i] = row[ei[i] >= 0 ? ei[i] : 0];
+                        for (int i = 0; i < EC; ++i) x[i] = row[ei[i] >= 0 ? ei[i] : 0];
 #pragma unroll
-                    for (int i = 0; i < EC; ++i) if (ei[i] >= 0) sum += x[i];
-                    sum = row16_sum(sum);
-                    em = sum / kf;                                               // cem.py:112
+                        for (int i = 0; i < EC; ++i) if (ei[i] >= 0) sum += x[i];
+                        sum = row16_sum(sum);
+                        em = sum / kf;                                               // cem.py:112
 #pragma unroll
-                    for (int i = 0; i < EC; ++i)
-                        if (ei[i] >= 0) {
-                            const float d = x[i] - em;
+                        for (int i = 0; i < EC; ++i)
+                            if (ei[i] >= 0) {
+                                const float d = x[i] - em;
+                                vs += d * d;
+                            }
+                    } else {
+                        for (int e = sub; e < p.k; e += 16) sum += row[eidx[e]];
+                        sum = row16_sum(sum);
+                        em = sum / kf;
+                        for (int e = sub; e < p.k; e += 16) {
+                            const float d = row[eidx[e]] - em;
                             vs += d * d;
                         }
-                } else {
-                    for (int e = sub; e < p.k; e += 16) sum += row[eidx[e]];
-                    sum = row16_sum(sum);
-                    em = sum / kf;
-                    for (int e = sub; e < p.k; e += 16) {
-                        const float d = row[eidx[e]] - em;
-                        vs += d * d;
+                    }
+                    vs = row16_sum(vs);
+                    if (live && sub == 0) {
+                        const float ev = vs / kf;                                    // cem.py:113-119
+                        const float one_m = 1.0f - p.alpha;
+                        const float m = p.alpha * mean[j] + one_m * em;              // cem.py:121-122
+                        const float v = p.alpha * var[j] + one_m * ev;               // cem.py:123-125
+                        mean[j] = m;
+                        var[j] = v;
+                        sigma[j] = cem_sigma(m, v, lo, hi);
                     }
                 }
-                vs = row16_sum(vs);
-                if (live && sub == 0) {
-                    const float ev = vs / kf;                                    // cem.py:113-119
-                    const float one_m = 1.0f - p.alpha;
-                    const float m = p.alpha * mean[j] + one_m * em;              // cem.py:121-122
-                    const float v = p.alpha * var[j] + one_m * ev;               // cem.py:123-125
-                    mean[j] = m;
-                    var[j] = v;
-                    sigma[j] = cem_sigma(m, v, lo, hi);
+                if (it == 0) BB_DBG(33);
+                __syncthreads();
+                action0 = mean[0];                                                   // cem.py:135
+            } else if (OPT == FOPT_PI2) {
+                // pi2.py:78-87.  Cross-wave reductions use their own LDS slots (no second barrier to recycle them) and the
+                // per-wave slots are combined by every wave with one LDS round trip + a DPP reduction.
+                float lmin = INFINITY;
+                for (int n = tid; n < p.N; n += nthr) {
+                    const float c = -rew[n];                                         // pi2.py:78
+                    rew[n] = c;
+                    lmin = fminf(lmin, c);
+                }
+                lmin = wave_min(lmin);
+                if ((tid & 63) == 0) red[tid >> 6] = lmin;
+                __syncthreads();
+                float beta = ((tid & 63) < nw) ? red[tid & 63] : INFINITY;
+                beta = wave_min(beta);                                               // pi2.py:81
+                float lsum = 0.0f;
+                for (int n = tid; n < p.N; n += nthr) {
+                    const float pr = expf((-p.inv_lamda) * (rew[n] - beta));         // pi2.py:82
+                    rew[n] = pr;
+                    lsum += pr;
+                }
+                lsum = wave_sum(lsum);
+                if ((tid & 63) == 0) red[32 + (tid >> 6)] = lsum;
+                __syncthreads();
+                float eta = ((tid & 63) < nw) ? red[32 + (tid & 63)] : 0.0f;
+                eta = wave_sum(eta);                                                 // pi2.py:83
+                const float inv_eta = 1.0f / eta;
+                // new_mean[j] = sum_n x[j][n] * omega[n],  omega = inv_eta * prob   (pi2.py:85-87): one wave per j
+                for (int j = tid >> 6; j < p.HU; j += nw) {
+                    const float* row = samp + (size_t)j * p.Nst;
+                    float acc = 0.0f;
+                    for (int n = tid & 63; n < p.N; n += 64) acc += row[n] * (inv_eta * rew[n]);
+                    acc = wave_sum(acc);
+                    if ((tid & 63) == 0) mean[j] = acc;
+                }
+                __syncthreads();
+                action0 = mean[0];                                                   // pi2.py:94
+            } else if (OPT == FOPT_SPSA) {
+                // ghat[j] = mean_n (r+ - r-)[n] / (2 c_k delta[j][n]);  theta = clip(theta + a_k ghat)   (spsa.py:101-107)
+                const float two_ck = 2.0f * p.spsa_ck[it], ak = p.spsa_ak[it];
+                for (int j = tid >> 6; j < p.HU; j += nw) {
+                    const float* row = samp + (size_t)j * p.Nst;
+                    float acc = 0.0f;
+                    for (int n = tid & 63; n < p.N; n += 64) acc += rew[n] / (two_ck * row[n]);
+                    acc = wave_sum(acc);
+                    if ((tid & 63) == 0) mean[j] = clipf(mean[j] + ak * (acc / (float)p.N), lo, hi);
+                }
+                __syncthreads();
+                action0 = mean[0];                                                   // spsa.py:117
+            } else {  // RandomSearch: argmax, first maximum (random_search.py:43-47)
+                float bv = -INFINITY;
+                int bi = 0x7fffffff;
+                for (int n = tid; n < p.N; n += nthr) {
+                    const float v = rew[n];
+                    if (v > bv || (v == bv && n < bi)) { bv = v; bi = n; }
+                }
+                wave_argmax(bv, bi);
+                int* redi = (int*)(red + 32);
+                if ((tid & 63) == 0) { red[tid >> 6] = bv; redi[tid >> 6] = bi; }
+                __syncthreads();
+                bv = ((tid & 63) < nw) ? red[tid & 63] : -INFINITY;
+                bi = ((tid & 63) < nw) ? redi[tid & 63] : 0x7fffffff;
+                wave_argmax(bv, bi);
+                if (bi == 0x7fffffff) bi = 0;
+                action0 = samp[bi];                                                  // sample[best][t=0]
+                if (p.t_elites && tid == 0) p.t_elites[a] = bi;
+                __syncthreads();
+            }
+            if (p.t_mean && OPT != FOPT_RS)
+                for (int j = tid; j < p.HU; j += nthr) {
+                    p.t_mean[((size_t)it * p.A + a) * p.HU + j] = mean[j];
+                    p.t_var[((size_t)it * p.A + a) * p.HU + j] = var[j];
+                }
+        }
+
+        BB_DBG(1 + p.iters * 4);
+#ifdef BBMPC_KERNEL_DBG
+        if (p.dbg && tid == 0 && a == 0) {
+            dbg_lds[41] = (long long)clock64();
+            for (int i = 0; i < 48; ++i) p.dbg[i] = dbg_lds[i];
+        }
+#endif
+        // ---- state carried to the next control step
+        if (OPT != FOPT_RS) {
+            for (int j = tid; j < p.HU; j += nthr) {
+                p.mean_out[a * p.HU + j] = mean[j];
+                p.var_out[a * p.HU + j] = var[j];
+                if (OPT == FOPT_PI2 || OPT == FOPT_SPSA) {                           // shift-left warm start pi2.py:92-93 / spsa.py:114-115
+                    const int js = (j + 1 < p.HU) ? j + 1 : p.HU - 1;
+                    p.prev_mean[a * p.HU + j] = mean[js];
+                } else if (p.warm_start) {
+                    p.prev_mean[a * p.HU + j] = mean[j];
                 }
             }
-            if (it == 0) BB_DBG(33);
-            __syncthreads();
-            action0 = mean[0];                                                   // cem.py:135
-        } else if (OPT == FOPT_PI2) {
-            // pi2.py:78-87.  Cross-wave reductions use their own LDS slots (no second barrier to recycle them) and the
-            // per-wave slots are combined by every wave with one LDS round trip + a DPP reduction.
-            float lmin = INFINITY;
-            for (int n = tid; n < p.N; n += nthr) {
-                const float c = -rew[n];                                         // pi2.py:78
-                rew[n] = c;
-                lmin = fminf(lmin, c);
-            }
-            lmin = wave_min(lmin);
-            if ((tid & 63) == 0) red[tid >> 6] = lmin;
-            __syncthreads();
-            float beta = ((tid & 63) < nw) ? red[tid & 63] : INFINITY;
-            beta = wave_min(beta);                                               // pi2.py:81
-            float lsum = 0.0f;
-            for (int n = tid; n < p.N; n += nthr) {
-                const float pr = expf((-p.inv_lamda) * (rew[n] - beta));         // pi2.py:82
-                rew[n] = pr;
-                lsum += pr;
-            }
-            lsum = wave_sum(lsum);
-            if ((tid & 63) == 0) red[32 + (tid >> 6)] = lsum;
-            __syncthreads();
-            float eta = ((tid & 63) < nw) ? red[32 + (tid & 63)] : 0.0f;
-            eta = wave_sum(eta);                                                 // pi2.py:83
-            const float inv_eta = 1.0f / eta;
-            // new_mean[j] = sum_n x[j][n] * omega[n],  omega = inv_eta * prob   (pi2.py:85-87): one wave per j
-            for (int j = tid >> 6; j < p.HU; j += nw) {
-                const float* row = samp + (size_t)j * p.Nst;
-                float acc = 0.0f;
-                for (int n = tid & 63; n < p.N; n += 64) acc += row[n] * (inv_eta * rew[n]);
-                acc = wave_sum(acc);
-                if ((tid & 63) == 0) mean[j] = acc;
-            }
-            __syncthreads();
-            action0 = mean[0];                                                   // pi2.py:94
-        } else if (OPT == FOPT_SPSA) {
-            // ghat[j] = mean_n (r+ - r-)[n] / (2 c_k delta[j][n]);  theta = clip(theta + a_k ghat)   (spsa.py:101-107)
-            const float two_ck = 2.0f * p.spsa_ck[it], ak = p.spsa_ak[it];
-            for (int j = tid >> 6; j < p.HU; j += nw) {
-                const float* row = samp + (size_t)j * p.Nst;
-                float acc = 0.0f;
-                for (int n = tid & 63; n < p.N; n += 64) acc += rew[n] / (two_ck * row[n]);
-                acc = wave_sum(acc);
-                if ((tid & 63) == 0) mean[j] = clipf(mean[j] + ak * (acc / (float)p.N), lo, hi);
-            }
-            __syncthreads();
-            action0 = mean[0];                                                   // spsa.py:117
-        } else {  // RandomSearch: argmax, first maximum (random_search.py:43-47)
-            float bv = -INFINITY;
-            int bi = 0x7fffffff;
-            for (int n = tid; n < p.N; n += nthr) {
-                const float v = rew[n];
-                if (v > bv || (v == bv && n < bi)) { bv = v; bi = n; }
-            }
-            wave_argmax(bv, bi);
-            int* redi = (int*)(red + 32);
-            if ((tid & 63) == 0) { red[tid >> 6] = bv; redi[tid >> 6] = bi; }
-            __syncthreads();
-            bv = ((tid & 63) < nw) ? red[tid & 63] : -INFINITY;
-            bi = ((tid & 63) < nw) ? redi[tid & 63] : 0x7fffffff;
-            wave_argmax(bv, bi);
-            if (bi == 0x7fffffff) bi = 0;
-            action0 = samp[bi];                                                  // sample[best][t=0]
-            if (p.t_elites && tid == 0) p.t_elites[a] = bi;
-            __syncthreads();
         }
-        if (p.t_mean && OPT != FOPT_RS)
-            for (int j = tid; j < p.HU; j += nthr) {
-                p.t_mean[((size_t)it * p.A + a) * p.HU + j] = mean[j];
-                p.t_var[((size_t)it * p.A + a) * p.HU + j] = var[j];
-            }
-    }
 
-    BB_DBG(1 + p.iters * 4);
-#ifdef BBMPC_KERNEL_DBG
-    if (p.dbg && tid == 0 && a == 0) {
-        dbg_lds[41] = (long long)clock64();
-        for (int i = 0; i < 48; ++i) p.dbg[i] = dbg_lds[i];
-    }
-#endif
-    // ---- state carried to the next control step
-    if (OPT != FOPT_RS) {
-        for (int j = tid; j < p.HU; j += nthr) {
-            p.mean_out[a * p.HU + j] = mean[j];
-            p.var_out[a * p.HU + j] = var[j];
-            if (OPT == FOPT_PI2 || OPT == FOPT_SPSA) {                           // shift-left warm start pi2.py:92-93 / spsa.py:114-115
-                const int js = (j + 1 < p.HU) ? j + 1 : p.HU - 1;
-                p.prev_mean[a * p.HU + j] = mean[js];
-            } else if (p.warm_start) {
-                p.prev_mean[a * p.HU + j] = mean[j];
+        // ---- OptimizerBase.__call__ tail (optimizer_base.py:82-94)
+        if (tid == 0) {
+            FinalArgs fa;
+            fa.A = p.A; fa.U = 1; fa.S = 3;
+            fa.agent_offset = p.agent_offset;
+            fa.fix_q1 = p.fix_q1; fa.fix_q7 = p.fix_q7;
+            fa.add_noise = add_noise_s;
+            fa.lo = p.lo; fa.hi = p.hi;
+            fa.inj = p.inj_expl;
+            fa.key = key_s;
+            fa.key.q_per_agent = 1;
+            float s[3] = {s0, s1, s2};
+            float act[1];
+            act[0] = exploration_action(fa, a, 0, action0);
+            const float r = model.step(s, act);
+            float* rec = p.record + (size_t)a * 5;
+            rec[0] = act[0];
+            rec[1] = s[0];
+            rec[2] = s[1];
+            rec[3] = s[2];
+            rec[4] = r;
+            if (p.next_state) {
+                p.next_state[a * 3 + 0] = s[0];
+                p.next_state[a * 3 + 1] = s[1];
+                p.next_state[a * 3 + 2] = s[2];
             }
+            // "records ready" for the all-gather that waits on another stream (comm.hpp): the last agent's workgroup
+            // publishes the sequence number once every agent's record is in HBM.  No event, no extra packet on the
+            // launch stream.
+            publish_records_done(p.done_flag, p.done_count, done_value_s, (unsigned)p.A);
         }
-    }
-
-    // ---- OptimizerBase.__call__ tail (optimizer_base.py:82-94)
-    if (tid == 0) {
-        FinalArgs fa;
-        fa.A = p.A; fa.U = 1; fa.S = 3;
-        fa.agent_offset = p.agent_offset;
-        fa.fix_q1 = p.fix_q1; fa.fix_q7 = p.fix_q7;
-        fa.add_noise = add_noise_s;
-        fa.lo = p.lo; fa.hi = p.hi;
-        fa.inj = p.inj_expl;
-        fa.key = key_s;
-        fa.key.q_per_agent = 1;
-        float s[3] = {s0, s1, s2};
-        float act[1];
-        act[0] = exploration_action(fa, a, 0, action0);
-        const float r = model.step(s, act);
-        float* rec = p.record + (size_t)a * 5;
-        rec[0] = act[0];
-        rec[1] = s[0];
-        rec[2] = s[1];
-        rec[3] = s[2];
-        rec[4] = r;
-        if (p.next_state) {
-            p.next_state[a * 3 + 0] = s[0];
-            p.next_state[a * 3 + 1] = s[1];
-            p.next_state[a * 3 + 2] = s[2];
-        }
-        // "records ready" for the all-gather that waits on another stream (comm.hpp): the last agent's workgroup
-        // publishes the sequence number once every agent's record is in HBM.  No event, no extra packet on the
-        // launch stream.
-        publish_records_done(p.done_flag, p.done_count, done_value_s, (unsigned)p.A);
-    }
-    if constexpr (!LINGER) {
-        break;
-    } else {
-        // ---- stay resident: wave 0 polls the request line over PCIe (one 64-byte read per poll; the host writes word 15,
-        // the payload, then word 0, so a line whose two sequence words agree is complete).  A request carrying the NEXT
-        // sequence number starts another pass without a launch (measured: 2.1 us host-to-host for a resident kernel's
-        // mailbox round trip against 6.8 us for launch + completion, tools/microbench/launch_latency.hip); anything else
-        // -- the stop word, or linger_ticks without a request -- ends the kernel, which says so in `gone` first and
-        // never looks at the line again, so the host knows whether to launch.
-        unsigned* mb = (unsigned*)ekeys;                       // 16 words of LDS that are idle outside the top-k
-        __syncthreads();
-        if (tid < 64) {
-            const long long t0 = (long long)wall_clock64();
-            unsigned w = 0u;
-            bool quit = false;
-            for (;;) {
-                w = (tid < 16) ? __hip_atomic_load(p.mbox + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
-                const unsigned w0 = __builtin_amdgcn_readlane(w, 0), w15 = __builtin_amdgcn_readlane(w, 15);
-                if (w0 == w15 && w0 == done_value_s + 1u) break;
-                if ((w0 == w15 && w0 == 0xffffffffu) || (long long)wall_clock64() - t0 > (long long)p.linger_ticks) { quit = true; break; }
+        if constexpr (!LINGER) {
+            break;
+        } else {
+            // ---- stay resident: wave 0 polls the request line over PCIe (one 64-byte read per poll; the host writes word 15,
+            // the payload, then word 0, so a line whose two sequence words agree is complete).  A request carrying the NEXT
+            // sequence number starts another pass without a launch (measured: 2.1 us host-to-host for a resident kernel's
+            // mailbox round trip against 6.8 us for launch + completion, tools/microbench/launch_latency.hip); anything else
+            // -- the stop word, or linger_ticks without a request -- ends the kernel, which says so in `gone` first and
+            // never looks at the line again, so the host knows whether to launch.
+            unsigned* mb = (unsigned*)ekeys;                       // 16 words of LDS that are idle outside the top-k
+            __syncthreads();
+            if (tid < 64) {
+                const long long t0 = (long long)wall_clock64();
+                unsigned w = 0u;
+                bool quit = false;
+                for (;;) {
+                    w = (tid < 16) ? __hip_atomic_load(p.mbox + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+                    const unsigned w0 = __builtin_amdgcn_readlane(w, 0), w15 = __builtin_amdgcn_readlane(w, 15);
+                    if (w0 == w15 && w0 == done_value_s + 1u) break;
+                    if ((w0 == w15 && w0 == 0xffffffffu) || (long long)wall_clock64() - t0 > (long long)p.linger_ticks) { quit = true; break; }
+                }
+                if (tid < 16) mb[tid] = (quit && tid == 0) ? 0xffffffffu : w;
             }
-            if (tid < 16) mb[tid] = (quit && tid == 0) ? 0xffffffffu : w;
+            __syncthreads();
+            if (mb[0] == 0xffffffffu) {
+                if (tid == 0) __hip_atomic_store(p.gone, done_value_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+            done_value_s = mb[0];
+            key_s.step = mb[1];
+            add_noise_s = (int)mb[2];
+            inj_s = reinterpret_cast<const float*>(((unsigned long long)mb[4] << 32) | (unsigned long long)mb[3]);
+            const float st_next = __uint_as_float(mb[5 + min(tid, 2)]);
+            __syncthreads();                                        // every thread has read the request before `red` / `ekeys` are reused
+            if (tid < 3) red[60 + tid] = st_next;
         }
-        __syncthreads();
-        if (mb[0] == 0xffffffffu) {
-            if (tid == 0) __hip_atomic_store(p.gone, done_value_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            return;
-        }
-        done_value_s = mb[0];
-        key_s.step = mb[1];
-        add_noise_s = (int)mb[2];
-        inj_s = reinterpret_cast<const float*>(((unsigned long long)mb[4] << 32) | (unsigned long long)mb[3]);
-        const float st_next = __uint_as_float(mb[5 + min(tid, 2)]);
-        __syncthreads();                                        // every thread has read the request before `red` / `ekeys` are reused
-        if (tid < 3) red[60 + tid] = st_next;
-    }
     }
 }
 
