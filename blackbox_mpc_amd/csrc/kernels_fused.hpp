@@ -124,15 +124,26 @@ __global__ void k_fused_pendulum(FusedArgs p) {
     // the [A,3] state may live in pinned host memory (bbmpc_optimize's zero-copy path): three lanes fetch it -- one PCIe
     // read per workgroup instead of three per wave (3072 at 64 agents x 16 waves) -- and LDS hands it to everybody
     if (tid < 3) red[60 + tid] = p.state[a * 3 + tid];
+    // CEM restarts every control step from the same mean / variance (quirk Q2): a resident kernel keeps them in registers
+    const bool keep_init = LINGER && OPT == FOPT_CEM && p.warm_start == 0 && p.HU <= nthr;
+    [[maybe_unused]] float m_keep = 0.0f, v_keep = 0.0f, s_keep = 0.0f;
+    [[maybe_unused]] bool have_init = false;
     for (;;) {      // one pass per control step; a single pass unless LINGER
 
         // ---- distribution init (cem.py:129-132 starts every control step from the ctor mean/var, quirk Q2)
-        for (int j = tid; j < p.HU; j += nthr) {
-            const float m = p.prev_mean[a * p.HU + j];
-            const float v = p.var0[a * p.HU + j];
-            mean[j] = m;
-            var[j] = v;
-            sigma[j] = (OPT == FOPT_CEM) ? cem_sigma(m, v, lo, hi) : ((OPT == FOPT_SPSA) ? 0.0f : sqrtf(v));
+        if (keep_init && have_init) {        // resident CEM pass: the same constants as last time, no global round trip
+            if (tid < p.HU) { mean[tid] = m_keep; var[tid] = v_keep; sigma[tid] = s_keep; }
+        } else {
+            for (int j = tid; j < p.HU; j += nthr) {
+                const float m = p.prev_mean[a * p.HU + j];
+                const float v = p.var0[a * p.HU + j];
+                const float sg = (OPT == FOPT_CEM) ? cem_sigma(m, v, lo, hi) : ((OPT == FOPT_SPSA) ? 0.0f : sqrtf(v));
+                mean[j] = m;
+                var[j] = v;
+                sigma[j] = sg;
+                if (keep_init) { m_keep = m; v_keep = v; s_keep = sg; }
+            }
+            have_init = true;
         }
         __syncthreads();
         const float s0 = red[60], s1 = red[61], s2 = red[62];

@@ -371,6 +371,10 @@ __device__ __forceinline__ void publish_records_done(unsigned* flag, unsigned* c
     // flag" holds formally for a consumer that reads the records as soon as it sees the flag (the host polling a pinned
     // word in bbmpc_optimize, or the communication stream's wait-value).  An ACQ_REL arrival in EVERY workgroup would
     // invalidate the XCD's L2 under the workgroups that are still running; one fence in the last one costs nothing.
+    if (nwg == 1u) {       // a single workgroup (one agent): its own release store is the whole chain, no counter round trip
+        __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     const unsigned old = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (old == nwg - 1u) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
