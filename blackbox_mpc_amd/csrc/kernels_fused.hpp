@@ -124,15 +124,20 @@ __global__ void k_fused_pendulum(FusedArgs p) {
     // the [A,3] state may live in pinned host memory (bbmpc_optimize's zero-copy path): three lanes fetch it -- one PCIe
     // read per workgroup instead of three per wave (3072 at 64 agents x 16 waves) -- and LDS hands it to everybody
     if (tid < 3) red[60 + tid] = p.state[a * 3 + tid];
-    // CEM restarts every control step from the same mean / variance (quirk Q2): a resident kernel keeps them in registers
-    const bool keep_init = LINGER && OPT == FOPT_CEM && p.warm_start == 0 && p.HU <= nthr;
+    // a resident kernel keeps the next control step's starting distribution in registers (CEM: the same restart mean /
+    // variance every time, quirk Q2; PI2 / SPSA / warm-started CEM: the mean it has just written to prev_mean)
+    const bool keep_init = LINGER && OPT != FOPT_RS && p.HU <= nthr;
     [[maybe_unused]] float m_keep = 0.0f, v_keep = 0.0f, s_keep = 0.0f;
     [[maybe_unused]] bool have_init = false;
     for (;;) {      // one pass per control step; a single pass unless LINGER
 
         // ---- distribution init (cem.py:129-132 starts every control step from the ctor mean/var, quirk Q2)
-        if (keep_init && have_init) {        // resident CEM pass: the same constants as last time, no global round trip
-            if (tid < p.HU) { mean[tid] = m_keep; var[tid] = v_keep; sigma[tid] = s_keep; }
+        if (keep_init && have_init) {        // resident pass: no global round trip
+            if (tid < p.HU) {
+                mean[tid] = m_keep;
+                var[tid] = v_keep;
+                sigma[tid] = (OPT == FOPT_CEM && p.warm_start) ? cem_sigma(m_keep, v_keep, lo, hi) : s_keep;
+            }
         } else {
             for (int j = tid; j < p.HU; j += nthr) {
                 const float m = p.prev_mean[a * p.HU + j];
@@ -535,9 +540,13 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                 p.var_out[a * p.HU + j] = var[j];
                 if (OPT == FOPT_PI2 || OPT == FOPT_SPSA) {                           // shift-left warm start pi2.py:92-93 / spsa.py:114-115
                     const int js = (j + 1 < p.HU) ? j + 1 : p.HU - 1;
-                    p.prev_mean[a * p.HU + j] = mean[js];
+                    const float pm = mean[js];
+                    p.prev_mean[a * p.HU + j] = pm;
+                    if (keep_init) m_keep = pm;
                 } else if (p.warm_start) {
-                    p.prev_mean[a * p.HU + j] = mean[j];
+                    const float pm = mean[j];
+                    p.prev_mean[a * p.HU + j] = pm;
+                    if (keep_init) m_keep = pm;
                 }
             }
         }

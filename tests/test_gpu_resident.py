@@ -39,15 +39,16 @@ def _run(eng, steps, between=None):
     return np.stack(out)
 
 
-@pytest.mark.parametrize("opt_name", ["CEM", "PI2", "RS", "SPSA"])
+@pytest.mark.parametrize("opt_name", ["CEM", "CEM-warm", "PI2", "RS", "SPSA"])
 def test_resident_kernel_is_bit_identical_to_a_launch_per_call(L, monkeypatch, opt_name):
-    opt = {"CEM": L.OPT_CEM, "PI2": L.OPT_PI2, "RS": L.OPT_RANDOM_SEARCH, "SPSA": L.OPT_SPSA}[opt_name]
+    opt = {"CEM": L.OPT_CEM, "CEM-warm": L.OPT_CEM, "PI2": L.OPT_PI2, "RS": L.OPT_RANDOM_SEARCH, "SPSA": L.OPT_SPSA}[opt_name]
+    kw = dict(quirks=L.FIX_Q2_CEM_WARM_START) if opt_name == "CEM-warm" else {}
     steps = 70                                      # crosses several noise-prefetch chunks (8 steps each)
     monkeypatch.setenv("BBMPC_LINGER_US", "0")
-    ref = _run(_engine(L, opt), steps)
+    ref = _run(_engine(L, opt, **kw), steps)
     monkeypatch.delenv("BBMPC_LINGER_US")
     t0 = time.perf_counter()
-    got = _run(_engine(L, opt), steps)
+    got = _run(_engine(L, opt, **kw), steps)
     assert time.perf_counter() - t0 < 5.0
     np.testing.assert_array_equal(got, ref)
 
