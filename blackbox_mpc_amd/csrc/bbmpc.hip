@@ -1474,7 +1474,8 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
         }
         case BBMPC_OPT_CEM: {
             hipLaunchKernelGGL(k_dist_init, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, HU, U, d_lo.p, d_hi.p,
-                               d_prev_mean.p, d_var0.p, d_mean.p, d_var.p, d_sigma.p, 1);
+                               d_prev_mean.p, d_var0.p, d_mean.p, d_var.p, d_sigma.p, 1, stage_state_src, d_state.p, A * S);
+            stage_state_src = nullptr;
             // iters == 0: action = mean[:,0] of the untouched distribution (otherwise the last refit writes it)
             if (iters == 0)
                 HIP_CHECK(hipMemcpy2DAsync(d_action.p, U * 4, d_prev_mean.p, HU * 4, U * 4, A, hipMemcpyDeviceToDevice, stream));
@@ -1547,7 +1548,8 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
         }
         case BBMPC_OPT_PI2: {
             hipLaunchKernelGGL(k_dist_init, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, HU, U, d_lo.p, d_hi.p,
-                               d_prev_mean.p, d_var0.p, d_mean.p, d_var.p, d_sigma.p, 0);
+                               d_prev_mean.p, d_var0.p, d_mean.p, d_var.p, d_sigma.p, 0, stage_state_src, d_state.p, A * S);
+            stage_state_src = nullptr;
             if (iters == 0)              // otherwise the last refit writes the action
                 HIP_CHECK(hipMemcpy2DAsync(d_action.p, U * 4, d_prev_mean.p, HU * 4, U * 4, A, hipMemcpyDeviceToDevice, stream));
             const float* inj_t = injected(BBMPC_NOISE_TRUNC_NORMAL);
@@ -2412,9 +2414,17 @@ static const float* optimize_host(bbmpc::Engine& e, const float* state, int32_t 
             if (fused_step) {
                 e.optimize_dev(dpin, noise, dpin + ns, nullptr);
             } else {
-                // hundreds of rollout workgroups read the state: it goes to HBM once, the record comes back on its own
-                HIP_CHECK(hipMemcpyAsync(e.d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e.stream));
+                // hundreds of rollout workgroups read the state: it goes to HBM once, the record comes back on its own.
+                // CEM / PI2 begin with k_dist_init, which fetches it from the pinned buffer itself; the others get a copy
+                const bool stage = (e.cfg.optimizer == BBMPC_OPT_CEM || e.cfg.optimizer == BBMPC_OPT_PI2) && !e.pop_sharded() &&
+                                   !e.user_path();
+                if (stage) e.stage_state_src = dpin;
+                else HIP_CHECK(hipMemcpyAsync(e.d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e.stream));
                 e.optimize_dev(e.d_state.p, noise, dpin + ns, nullptr);
+                if (e.stage_state_src) {
+                    e.stage_state_src = nullptr;
+                    throw HipError(BBMPC_E_HIP, "internal: the control step did not stage its state");
+                }
             }
             e.linger_launch = false;
             published = e.tail_flag != nullptr && e.tail_attached;

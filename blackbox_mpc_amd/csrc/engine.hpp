@@ -162,6 +162,7 @@ struct Engine {
     void settle();
     // resident control-step kernel (one agent, persistent pendulum kernel, host-in / host-out calls): the kernel of one
     // call stays on the GPU for linger_us and takes the next call's request from a pinned mailbox line (kernels_fused.hpp)
+    const float* stage_state_src = nullptr;   // pinned [A,S] state that the control step's first kernel (k_dist_init) copies to d_state
     bool linger_launch = false;        // bbmpc_optimize asks optimize_fused for the LINGER variant
     bool resident_alive = false;       // a LINGER kernel may still be polling the mailbox
     uint32_t* mbox_host() { return host_done + 16; }

@@ -89,9 +89,14 @@ __device__ __forceinline__ float cem_sigma(float mean, float var, float lo, floa
 
 // (Re)initialise the distribution at the start of a control step.
 // CEM quirk Q2: every control step restarts from the constructor mean/variance (cem.py:129-134).
+// state_src (optional): the [A,S] state of a host-in / host-out call, in pinned host memory -- the first kernel of the
+// control step brings it to HBM (state_dst) itself instead of a copy-engine transfer in front of it
 __global__ void k_dist_init(int A, int HU, int U, const float* lo, const float* hi, const float* prev_mean,
-                            const float* var0, float* mean, float* var, float* sigma, int constrain) {
+                            const float* var0, float* mean, float* var, float* sigma, int constrain,
+                            const float* state_src, float* state_dst, int nstate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (state_src)
+        for (int k = i; k < nstate; k += gridDim.x * blockDim.x) state_dst[k] = state_src[k];
     if (i >= A * HU) return;
     const int u = i % U;
     const float m = prev_mean[i];
