@@ -155,6 +155,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1);
         sw.mlp_wave = ival("BBMPC_MLP_WAVE", 1);
         sw.linger_us = std::max(0, ival("BBMPC_LINGER_US", 200));
+        linger_test_quit = ival("BBMPC_LINGER_TEST_QUIT", 0) - 1;
         sw.balance = ival("BBMPC_BALANCE", 1);
         sw.ilp = ival("BBMPC_ILP", 1) == 2 ? 2 : 1;
         sw.refit_v1 = flag("BBMPC_REFIT_V1");
@@ -251,8 +252,10 @@ void Engine::settle() {
     }
 }
 
-// The resident kernel's side of this is at the end of k_fused_pendulum.  Returns false when the call has to go through
-// a launch after all (the kernel left, or this step's noise chunk is not there yet); the stream is idle then.
+// The resident workgroups' side of this is at the end of k_fused_pendulum.  Returns false when the call has to go through
+// a launch after all: the workgroups left (the stream is idle then), this step's noise chunk is not there yet, or -- a
+// request that crossed some workgroups' exit -- only part of the agents were served: subset_n / amap_host() then name the
+// rest and the launch that follows covers exactly those.
 bool Engine::resident_step(const float* state, int add_noise, uint32_t seq) {
     const uint32_t step = step_counter;
     const int64_t c = (int64_t)step / std::max(pf_steps, 1);
@@ -270,38 +273,48 @@ bool Engine::resident_step(const float* state, int add_noise, uint32_t seq) {
         pf_chunk[nb] = c + 1; pf_waited[nb] = false; pf_inflight[nb] = true;
     }
     ++step_counter;
-    volatile uint32_t* m = mbox_host();
     const uint64_t ip = (uint64_t)(uintptr_t)inj;
-    m[15] = seq;
-    m[1] = step; m[2] = (uint32_t)add_noise; m[3] = (uint32_t)ip; m[4] = (uint32_t)(ip >> 32);
-    uint32_t sw3[3];
-    memcpy(sw3, state, 12);
-    m[5] = sw3[0]; m[6] = sw3[1]; m[7] = sw3[2];
-    std::atomic_thread_fence(std::memory_order_release);
-    m[0] = seq;
-    if (in_flight_hook && !in_flight_called) { in_flight_called = true; in_flight_hook(this); }   // host work that hides under the kernel
-    volatile const uint32_t* ack = host_done;
-    volatile const uint32_t* gone = gone_host();
-    const auto t0 = std::chrono::steady_clock::now();
-    uint32_t spins = 0;
-    for (;;) {
-        if (*ack == seq) return true;
-        if (*gone != 0u) break;                                   // it left (before or after this request?)
-        if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+    for (int a = 0; a < A; ++a) {                                 // one request line per agent: sequence word 15, payload, sequence word 0
+        volatile uint32_t* m = mbox_host(a);
+        uint32_t sw3[3];
+        memcpy(sw3, state + (size_t)a * 3, 12);
+        m[15] = seq;
+        m[1] = step; m[2] = (uint32_t)add_noise; m[3] = (uint32_t)ip; m[4] = (uint32_t)(ip >> 32);
+        m[5] = sw3[0]; m[6] = sw3[1]; m[7] = sw3[2];
     }
-    HIP_CHECK(hipStreamSynchronize(stream));                      // the kernel has ended (or ends within linger_us)
-    resident_alive = false;
-    if (*ack == seq) return true;                                 // it took the request on its way out
-    --step_counter;                                               // the launch that follows does this step
+    std::atomic_thread_fence(std::memory_order_release);
+    for (int a = 0; a < A; ++a) mbox_host(a)[0] = seq;
+    if (in_flight_hook && !in_flight_called) { in_flight_called = true; in_flight_hook(this); }   // host work that hides under the kernel
+    const auto t0 = std::chrono::steady_clock::now();
+    bool all = true;
+    for (int a = 0; a < A; ++a) {
+        volatile const uint32_t* ack = ack_host(a);
+        volatile const uint32_t* gone = gone_host(a);
+        uint32_t spins = 0;
+        for (;;) {
+            if (*ack == seq) break;
+            if (*gone != 0u) { all = false; break; }               // it left (before or after this request?)
+            if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { all = false; break; }
+        }
+    }
+    if (all) return true;
+    // some workgroups have left: end the others too (they finish the step they are in), then see who is missing
+    resident_stop();
+    int missing = 0;
+    int32_t* amap = amap_host();
+    for (int a = 0; a < A; ++a)
+        if (*(volatile const uint32_t*)ack_host(a) != seq) amap[missing++] = a;
+    if (missing == 0) return true;                                // everybody took the request on the way out
+    --step_counter;                                               // the launch that follows does this step ...
+    subset_n = missing < A ? missing : 0;                         // ... for the agents that were not served (all of them: an ordinary launch)
     return false;
 }
 
 void Engine::resident_stop() {
     if (!resident_alive) return;
-    volatile uint32_t* m = mbox_host();
-    m[15] = 0xffffffffu;
+    for (int a = 0; a < A; ++a) mbox_host(a)[15] = 0xffffffffu;
     std::atomic_thread_fence(std::memory_order_release);
-    m[0] = 0xffffffffu;
+    for (int a = 0; a < A; ++a) mbox_host(a)[0] = 0xffffffffu;
     resident_alive = false;
     HIP_CHECK(hipStreamSynchronize(stream));
 }
@@ -1204,23 +1217,39 @@ static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base
     const size_t limit = 160 * 1024;   // all of a CU's LDS
 #endif
     if (lds_base + lds_samples <= limit) {
+        fa.test_quit_agent = -1;
         if constexpr (INJ == 2 && FASTM && ILP == 1) {
-            if (e.linger_launch && fa.done_flag && e.tail_event == nullptr) {
-                // the resident form: this launch serves the current call and then waits for the next ones (kernels_fused.hpp)
+            if (e.linger_launch && e.subset_n == 0 && fa.done_flag && e.tail_event == nullptr) {
+                // the resident form: this launch serves the current call and then every workgroup waits for its agent's next
+                // request on its own (kernels_fused.hpp)
                 auto fl = k_fused_pendulum<OPT, true, FASTM, INJ, ILP, true>;
                 ensure_max_lds((const void*)fl, (int)limit);
-                volatile uint32_t* m = e.mbox_host();
-                m[15] = fa.done_value; m[0] = fa.done_value;          // nothing pending (a stale stop word must not end it)
-                *(volatile uint32_t*)e.gone_host() = 0u;
+                for (int a = 0; a < e.A; ++a) {
+                    volatile uint32_t* m = e.mbox_host(a);
+                    m[15] = fa.done_value; m[0] = fa.done_value;      // nothing pending (a stale stop word must not end it)
+                    *(volatile uint32_t*)e.gone_host(a) = 0u;
+                }
                 std::atomic_thread_fence(std::memory_order_release);
-                fa.mbox = e.host_done_dev + 16;
-                fa.gone = e.host_done_dev + 32;
+                fa.done_flag = e.sync_dev(e.ack_host(0));
+                fa.mbox = e.sync_dev(e.mbox_host(0));
+                fa.gone = e.sync_dev(e.gone_host(0));
                 fa.linger_ticks = (unsigned)e.sw.linger_us * 100u;
+                fa.test_quit_agent = e.linger_test_quit;
                 hipLaunchKernelGGL(fl, dim3(e.A), dim3(threads), lds_base + lds_samples, e.stream, fa);
                 HIP_CHECK(hipGetLastError());
                 e.resident_alive = true;
                 return;
             }
+        }
+        if (e.subset_n > 0) {
+            // the agents whose resident workgroups had left when this control step was posted (Engine::resident_step)
+            auto fs = k_fused_pendulum<OPT, true, FASTM, INJ, ILP>;
+            ensure_max_lds((const void*)fs, (int)limit);
+            fa.amap = reinterpret_cast<const int*>(e.sync_dev(e.amap_host()));
+            hipLaunchKernelGGL(fs, dim3(e.subset_n), dim3(threads), lds_base + lds_samples, e.stream, fa);
+            HIP_CHECK(hipGetLastError());
+            e.subset_n = 0;
+            return;
         }
         auto fn = k_fused_pendulum<OPT, true, FASTM, INJ, ILP>;
         ensure_max_lds((const void*)fn, (int)limit);
@@ -2368,6 +2397,7 @@ static const float* optimize_host(bbmpc::Engine& e, const float* state, int32_t 
     float* pin = e.pinned(ns + nr);
     memcpy(pin, state, ns * 4);
     bool published = false;
+    bool handled_resident = false;       // served by the resident workgroups: the records are already in the pinned buffer
     // single-kernel control steps read the state straight from the pinned, device-mapped host buffer; those and the
     // learned-dynamics path (whose last kernel, k_tail_mlp, owns the record) write the packed record straight into it
     const bool fused_step = e.sw.zero_copy && (e.use_fused() || e.use_fused_pso());   // PSO: the swarm re-seed that follows touches neither
@@ -2384,8 +2414,8 @@ static const float* optimize_host(bbmpc::Engine& e, const float* state, int32_t 
             // stores (publish_records_done): the call returns when the host sees it, ~10 us earlier than
             // hipStreamSynchronize notices the kernel's completion; the stream itself is joined lazily (settle)
             if (!e.host_done) {
-                HIP_CHECK(hipHostMalloc((void**)&e.host_done, 256, hipHostMallocCoherent | hipHostMallocMapped));   // completion word | request line | exit word, a cache line each
-                memset(e.host_done, 0, 256);
+                HIP_CHECK(hipHostMalloc((void**)&e.host_done, (size_t)e.sync_lines() * 64, hipHostMallocCoherent | hipHostMallocMapped));   // engine.hpp: completion words | request lines | exit words
+                memset(e.host_done, 0, (size_t)e.sync_lines() * 64);
                 HIP_CHECK(hipHostGetDevicePointer((void**)&e.host_done_dev, e.host_done, 0));
                 HIP_CHECK(hipMalloc((void**)&e.host_count, 8));
                 HIP_CHECK(hipMemset(e.host_count, 0, 8));
@@ -2397,7 +2427,7 @@ static const float* optimize_host(bbmpc::Engine& e, const float* state, int32_t 
             e.tail_attached = false;
         }
         // one agent on the persistent pendulum kernel: the previous call's kernel may still be there, waiting for this one
-        const bool linger_ok = fused_step && e.tail_flag != nullptr && e.sw.linger_us > 0 && e.A == 1 && e.use_fused() &&
+        const bool linger_ok = fused_step && e.tail_flag != nullptr && e.sw.linger_us > 0 && e.A <= Engine::kLingerMaxAgents && e.use_fused() &&
                                !e.profiling && e.tail_event == nullptr &&
                                e.stream == e.own_stream;      // on a caller's stream it would hold back the caller's next work
         bool handled = false;
@@ -2407,10 +2437,11 @@ static const float* optimize_host(bbmpc::Engine& e, const float* state, int32_t 
         }
         if (handled) {
             published = true;
+            handled_resident = true;
             e.tail_flag = nullptr;
         } else
         try {
-            e.linger_launch = linger_ok;
+            e.linger_launch = linger_ok && e.subset_n == 0;      // a subset launch (after a crossed exit) is an ordinary one
             if (fused_step) {
                 e.optimize_dev(dpin, noise, dpin + ns, nullptr);
             } else {
@@ -2440,7 +2471,26 @@ static const float* optimize_host(bbmpc::Engine& e, const float* state, int32_t 
         HIP_CHECK(hipMemcpyAsync(pin + ns, e.d_record.p, nr * 4, hipMemcpyDeviceToHost, e.stream));
     }
     if (e.in_flight_hook && !e.in_flight_called) { e.in_flight_called = true; e.in_flight_hook(&e); }   // launch path: the kernels are enqueued
-    if (published) {
+    if (handled_resident) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        e.lazy_sync = true;
+    } else if (published && e.resident_alive) {
+        // a LINGER launch: every agent's workgroup publishes its own completion word
+        const uint32_t want = e.host_seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int a = 0; a < e.A; ++a) {
+            volatile const uint32_t* f = e.ack_host(a);
+            uint32_t spins = 0;
+            while (*f != want) {
+                if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                    e.resident_stop();                               // a fault surfaces in its synchronize
+                    if (*f != want) throw HipError(BBMPC_E_HIP, "bbmpc_optimize: the control step finished without publishing its records");
+                }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        e.lazy_sync = true;
+    } else if (published) {
         volatile const uint32_t* f = e.host_done;
         const uint32_t want = e.host_seq;
         const auto t0 = std::chrono::steady_clock::now();

@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -165,8 +166,17 @@ struct Engine {
     const float* stage_state_src = nullptr;   // pinned [A,S] state that the control step's first kernel (k_dist_init) copies to d_state
     bool linger_launch = false;        // bbmpc_optimize asks optimize_fused for the LINGER variant
     bool resident_alive = false;       // a LINGER kernel may still be polling the mailbox
-    uint32_t* mbox_host() { return host_done + 16; }
-    uint32_t* gone_host() { return host_done + 32; }
+    // pinned block host_done, 16-word lines: 0 completion word of the launch-per-call paths | 1..A per-agent completion
+    // words | A+1..2A request lines | 2A+1..3A exit words | 3A+1 agent map of a subset launch
+    static constexpr int kLingerMaxAgents = 64;
+    int sync_lines() const { return 2 + 3 * std::max(1, std::min(A, kLingerMaxAgents)); }
+    uint32_t* ack_host(int a) { return host_done + 16 * (1 + a); }
+    uint32_t* mbox_host(int a) { return host_done + 16 * (1 + std::min(A, kLingerMaxAgents) + a); }
+    uint32_t* gone_host(int a) { return host_done + 16 * (1 + 2 * std::min(A, kLingerMaxAgents) + a); }
+    int32_t* amap_host() { return reinterpret_cast<int32_t*>(host_done + 16 * (1 + 3 * std::min(A, kLingerMaxAgents))); }
+    uint32_t* sync_dev(const void* host_ptr) { return host_done_dev + (reinterpret_cast<const uint32_t*>(host_ptr) - host_done); }
+    int subset_n = 0;                  // > 0: the next persistent-kernel launch covers only the agents listed in amap_host()
+    int linger_test_quit = -1;         // BBMPC_LINGER_TEST_QUIT (test hook, kernels_fused.hpp)
     bool resident_step(const float* state, int add_noise, uint32_t seq);
     void resident_stop();
     hipStream_t pf_stream = nullptr;

@@ -60,9 +60,13 @@ struct FusedArgs {
     RngKey key;
     // LINGER variant (one agent, host-in / host-out calls): after publishing its record the workgroup stays on the GPU and
     // polls a 64-byte request line in pinned host memory for the next control step (see the end of the kernel)
-    const unsigned* mbox;    // 16 words: [0] = [15] = sequence number, [1] step, [2] add_noise, [3..4] noise pointer, [5..7] state
-    unsigned* gone;          // pinned word: the last sequence number handled, written when the kernel leaves
+    // Every agent's workgroup is on its own: a request line, a completion word and an exit word per agent (one cache line
+    // each, arrays indexed by the agent), so no two workgroups ever have to agree on anything.
+    const unsigned* mbox;    // [A][16] words: [0] = [15] = sequence number, [1] step, [2] add_noise, [3..4] noise pointer, [5..7] state
+    unsigned* gone;          // [A][16] pinned words: the last sequence number handled, written when the workgroup leaves
     unsigned linger_ticks;   // how long to wait for a request, in wall_clock64 ticks (100 MHz)
+    int test_quit_agent;     // test hook (BBMPC_LINGER_TEST_QUIT): this agent's workgroup leaves after every control step, -1 = none
+    const int* amap;         // optional: blockIdx.x -> agent (a launch for a subset of the agents), null = identity
 };
 
 // phase clocks for kernel development: build with -DBBMPC_KERNEL_DBG and run with BBMPC_DBG=1
@@ -96,7 +100,7 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nw)
 template <int OPT, bool SAMPLES_LDS, bool FASTM, int INJ, int ILP, bool LINGER = false>
 __global__ void k_fused_pendulum(FusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int a = blockIdx.x;
+    const int a = p.amap ? p.amap[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
     const int nw = nthr >> 6;
@@ -580,7 +584,8 @@ __global__ void k_fused_pendulum(FusedArgs p) {
             // "records ready" for the all-gather that waits on another stream (comm.hpp): the last agent's workgroup
             // publishes the sequence number once every agent's record is in HBM.  No event, no extra packet on the
             // launch stream.
-            publish_records_done(p.done_flag, p.done_count, done_value_s, (unsigned)p.A);
+            if constexpr (LINGER) publish_records_done(p.done_flag + a * 16, nullptr, done_value_s, 1u);    // this agent's own completion word
+            else publish_records_done(p.done_flag, p.done_count, done_value_s, gridDim.x);
         }
         if constexpr (!LINGER) {
             break;
@@ -598,16 +603,16 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                 unsigned w = 0u;
                 bool quit = false;
                 for (;;) {
-                    w = (tid < 16) ? __hip_atomic_load(p.mbox + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+                    w = (tid < 16) ? __hip_atomic_load(p.mbox + a * 16 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
                     const unsigned w0 = __builtin_amdgcn_readlane(w, 0), w15 = __builtin_amdgcn_readlane(w, 15);
                     if (w0 == w15 && w0 == done_value_s + 1u) break;
-                    if ((w0 == w15 && w0 == 0xffffffffu) || (long long)wall_clock64() - t0 > (long long)p.linger_ticks) { quit = true; break; }
+                    if ((w0 == w15 && w0 == 0xffffffffu) || (long long)wall_clock64() - t0 > (long long)p.linger_ticks || a == p.test_quit_agent) { quit = true; break; }
                 }
                 if (tid < 16) mb[tid] = (quit && tid == 0) ? 0xffffffffu : w;
             }
             __syncthreads();
             if (mb[0] == 0xffffffffu) {
-                if (tid == 0) __hip_atomic_store(p.gone, done_value_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (tid == 0) __hip_atomic_store(p.gone + a * 16, done_value_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 return;
             }
             done_value_s = mb[0];

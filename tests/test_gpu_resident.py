@@ -29,7 +29,7 @@ def _engine(L, opt, seed=5, **kw):
 
 
 def _run(eng, steps, between=None):
-    s = O.pendulum_start_states(1)
+    s = O.pendulum_start_states(eng.A)
     out = []
     for t in range(steps):
         a, s, r = eng.optimize(s, t, add_exploration_noise=(t % 7 == 3))
@@ -39,10 +39,12 @@ def _run(eng, steps, between=None):
     return np.stack(out)
 
 
+@pytest.mark.parametrize("A", [1, 3, 8, 40])
 @pytest.mark.parametrize("opt_name", ["CEM", "CEM-warm", "PI2", "RS", "SPSA"])
-def test_resident_kernel_is_bit_identical_to_a_launch_per_call(L, monkeypatch, opt_name):
+def test_resident_kernel_is_bit_identical_to_a_launch_per_call(L, monkeypatch, opt_name, A):
     opt = {"CEM": L.OPT_CEM, "CEM-warm": L.OPT_CEM, "PI2": L.OPT_PI2, "RS": L.OPT_RANDOM_SEARCH, "SPSA": L.OPT_SPSA}[opt_name]
     kw = dict(quirks=L.FIX_Q2_CEM_WARM_START) if opt_name == "CEM-warm" else {}
+    kw["num_agents"] = A
     steps = 70                                      # crosses several noise-prefetch chunks (8 steps each)
     monkeypatch.setenv("BBMPC_LINGER_US", "0")
     ref = _run(_engine(L, opt, **kw), steps)
@@ -80,6 +82,21 @@ def test_resident_kernel_survives_gaps_and_other_calls(L, monkeypatch):
             seq = np.random.default_rng(0).uniform(-2, 2, (64, 1, 30, 1)).astype(F)
             eng.evaluate(O.pendulum_start_states(1), seq)
     got = _run(_engine(L, L.OPT_CEM), steps, between)
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("quit_agent", [1, 3])
+def test_a_request_that_crosses_some_workgroups_exit(L, monkeypatch, quit_agent):
+    # every agent's workgroup lingers on its own; if some have left when the next request is posted the others serve it and
+    # the call launches the kernel for exactly the missing agents.  BBMPC_LINGER_TEST_QUIT makes one agent's workgroup leave
+    # after every control step, so every call takes that path.
+    steps = 30
+    monkeypatch.setenv("BBMPC_LINGER_US", "0")
+    ref = _run(_engine(L, L.OPT_PI2, num_agents=3), steps)
+    monkeypatch.delenv("BBMPC_LINGER_US")
+    monkeypatch.setenv("BBMPC_LINGER_TEST_QUIT", str(quit_agent))
+    got = _run(_engine(L, L.OPT_PI2, num_agents=3), steps)
+    monkeypatch.delenv("BBMPC_LINGER_TEST_QUIT")
     np.testing.assert_array_equal(got, ref)
 
 
