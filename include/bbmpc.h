@@ -204,7 +204,11 @@ int bbmpc_reset(bbmpc_handle h);
 
 /* ---- hot path ----------------------------------------------------------- */
 /* OptimizerBase.__call__(current_state, time_step, add_exploration_noise)
- * -> (action[A,U], next_state[A,S], reward[A])      optimizer_base.py:55-95 */
+ * -> (action[A,U], next_state[A,S], reward[A])      optimizer_base.py:55-95
+ * Host buffers in, host buffers out, synchronous.  On the analytic path with up to 64 agents the control step's kernel
+ * stays resident on the GPU for BBMPC_LINGER_US (default 200) after the call returns and serves the next bbmpc_optimize
+ * without a launch; any other entry point of the handle stops it first, and a device-wide synchronisation by the
+ * caller waits at most that long.  Results do not depend on it (BBMPC_LINGER_US=0: one launch per call). */
 int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t time_step, int32_t add_exploration_noise,
                    float* action, float* next_state, float* reward);
 /* Same with device pointers; record is [A, U+S+1] = (action | next_state | reward) per agent.
