@@ -13,6 +13,27 @@
 
 namespace bbmpc {
 
+// every live handle of the process (see Engine::mbox_pub)
+static std::mutex g_engines_mu;
+static std::set<Engine*> g_engines;
+static std::atomic<int> g_resident_handles{0};
+
+// Called at every entry point: resident workgroups of OTHER handles on this device are asked to leave (a few stores into
+// pinned memory, no synchronisation); costs one relaxed load when nothing is resident.
+void stop_foreign_residents(Engine* self) {
+    const int mine = (self && self->mbox_pub.load(std::memory_order_relaxed)) ? 1 : 0;
+    if (g_resident_handles.load(std::memory_order_relaxed) - mine <= 0) return;
+    std::lock_guard<std::mutex> lock(g_engines_mu);
+    for (Engine* o : g_engines) {
+        if (o == self || (self && o->device != self->device)) continue;
+        uint32_t* m = o->mbox_pub.load(std::memory_order_acquire);
+        if (!m) continue;
+        for (int a = 0; a < o->mbox_pub_agents; ++a) ((volatile uint32_t*)m)[a * 16 + 15] = 0xffffffffu;
+        std::atomic_thread_fence(std::memory_order_release);
+        for (int a = 0; a < o->mbox_pub_agents; ++a) ((volatile uint32_t*)m)[a * 16] = 0xffffffffu;
+    }
+}
+
 static thread_local std::string g_last_error;
 
 // ------------------------------------------------------------------------------------------------
@@ -87,6 +108,7 @@ static void want_lds(const void* fn, size_t bytes) {
 
 Engine::Engine(const bbmpc_config& c) : cfg(c) {
     REQUIRE(c.abi_version == BBMPC_ABI_VERSION, BBMPC_E_INVALID, "bbmpc_config.abi_version mismatch");
+    stop_foreign_residents(nullptr);     // creation allocates and copies: nothing should wait behind a lingering kernel
     N = c.population_size; A = c.num_agents; H = c.planning_horizon; U = c.dim_u; S = c.dim_s;
     iters = c.optimizer == BBMPC_OPT_RANDOM_SEARCH ? 1 : c.max_iterations;
     if (c.optimizer == BBMPC_OPT_NONE) iters = 0;
@@ -218,10 +240,13 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         }
     }
     HIP_CHECK(hipStreamSynchronize(stream));
+    // registered last: a constructor that throws never runs the destructor
+    { std::lock_guard<std::mutex> lock(g_engines_mu); g_engines.insert(this); }
 }
 
 Engine::~Engine() {
     try { resident_stop(); } catch (...) {}
+    { std::lock_guard<std::mutex> lock(g_engines_mu); g_engines.erase(this); }
     if (lazy_sync && stream) (void)hipStreamSynchronize(stream);
     if (own_stream) (void)hipStreamSynchronize(own_stream);
     rc.destroy();
@@ -252,11 +277,22 @@ void Engine::settle() {
     }
 }
 
+static void resident_unpublish(Engine* e);
+
 // The resident workgroups' side of this is at the end of k_fused_pendulum.  Returns false when the call has to go through
 // a launch after all: the workgroups left (the stream is idle then), this step's noise chunk is not there yet, or -- a
 // request that crossed some workgroups' exit -- only part of the agents were served: subset_n / amap_host() then name the
 // rest and the launch that follows covers exactly those.
 bool Engine::resident_step(const float* state, int add_noise, uint32_t seq) {
+    {   // all workgroups gone already (linger time over, or another handle asked them to leave): nothing to stop or wait for
+        bool all_gone = true;
+        for (int a = 0; a < A && all_gone; ++a) all_gone = *(volatile const uint32_t*)gone_host(a) != 0u;
+        if (all_gone) {
+            resident_unpublish(this);
+            resident_alive = false;
+            return false;
+        }
+    }
     const uint32_t step = step_counter;
     const int64_t c = (int64_t)step / std::max(pf_steps, 1);
     const int pb = (int)(c & 1), nb = pb ^ 1;
@@ -310,8 +346,16 @@ bool Engine::resident_step(const float* state, int add_noise, uint32_t seq) {
     return false;
 }
 
+static void resident_unpublish(Engine* e) {
+    if (e->mbox_pub.load(std::memory_order_relaxed)) {
+        e->mbox_pub.store(nullptr, std::memory_order_release);
+        g_resident_handles.fetch_sub(1, std::memory_order_relaxed);
+    }
+}
+
 void Engine::resident_stop() {
     if (!resident_alive) return;
+    resident_unpublish(this);
     for (int a = 0; a < A; ++a) mbox_host(a)[15] = 0xffffffffu;
     std::atomic_thread_fence(std::memory_order_release);
     for (int a = 0; a < A; ++a) mbox_host(a)[0] = 0xffffffffu;
@@ -1238,6 +1282,11 @@ static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base
                 hipLaunchKernelGGL(fl, dim3(e.A), dim3(threads), lds_base + lds_samples, e.stream, fa);
                 HIP_CHECK(hipGetLastError());
                 e.resident_alive = true;
+                if (!e.mbox_pub.load(std::memory_order_relaxed)) {
+                    e.mbox_pub_agents = e.A;
+                    e.mbox_pub.store(e.mbox_host(0), std::memory_order_release);
+                    g_resident_handles.fetch_add(1, std::memory_order_relaxed);
+                }
                 return;
             }
         }
@@ -2187,7 +2236,8 @@ struct DeviceGuard {
 
 #define CHECK_HANDLE_NOSETTLE(h)                                            \
     if (!(h) || !(h)->e) throw HipError(BBMPC_E_INVALID, "null handle");    \
-    DeviceGuard _device_guard((h)->e->device)
+    DeviceGuard _device_guard((h)->e->device);                              \
+    bbmpc::stop_foreign_residents((h)->e)
 #define CHECK_HANDLE(h)        \
     CHECK_HANDLE_NOSETTLE(h);  \
     (h)->e->settle()

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -175,6 +176,11 @@ struct Engine {
     uint32_t* gone_host(int a) { return host_done + 16 * (1 + 2 * std::min(A, kLingerMaxAgents) + a); }
     int32_t* amap_host() { return reinterpret_cast<int32_t*>(host_done + 16 * (1 + 3 * std::min(A, kLingerMaxAgents))); }
     uint32_t* sync_dev(const void* host_ptr) { return host_done_dev + (reinterpret_cast<const uint32_t*>(host_ptr) - host_done); }
+    // Another handle of the process starting work on the same device asks the resident workgroups of this one to leave
+    // (streams share a few hardware queues: a lingering kernel would hold back whatever lands behind it): it writes the stop
+    // word into the request lines published here, nothing else -- this handle finds the exit words at its next call.
+    std::atomic<uint32_t*> mbox_pub{nullptr};      // request lines of a (possibly) live resident kernel, null otherwise
+    int mbox_pub_agents = 0;
     int subset_n = 0;                  // > 0: the next persistent-kernel launch covers only the agents listed in amap_host()
     int linger_test_quit = -1;         // BBMPC_LINGER_TEST_QUIT (test hook, kernels_fused.hpp)
     bool resident_step(const float* state, int add_noise, uint32_t seq);

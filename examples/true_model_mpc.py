@@ -40,6 +40,7 @@ for name, kwargs in [("RandomSearch", dict(population_size=1024)),
                            env_observation_space=observation_space, true_model=True,
                            dynamics_function=PendulumTrueModel(), optimizer_name=name, num_agents=num_agents,
                            planning_horizon=30, **kwargs)
+    mpc_policy.act(start, 0)      # first use of an optimizer loads its kernels (and, once per process, the sampling tables): not timed
     t0 = time.time()
     traj_obs, traj_acs, traj_rews = perform_rollouts(env, 1, task_horizon, mpc_policy)
     dt = time.time() - t0
