@@ -1417,7 +1417,12 @@ void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_rec
         pf_steps = pf_step_floats ? (int)std::min<size_t>(8, budget / (pf_step_floats * 4)) : 0;
         pf_mode = ((ev ? atoi(ev) != 0 : true) && pf_steps >= 1 && U == 1) ? 1 : 0;
         if (pf_mode) {
-            HIP_CHECK(hipStreamCreateWithFlags(&pf_stream, hipStreamNonBlocking));
+            {   // its own priority class, hence its own pool of hardware queues: a fill must never sit in the queue
+                // behind a resident control-step kernel of the launch stream (normal priority)
+                int least = 0, greatest = 0;
+                HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIP_CHECK(hipStreamCreateWithPriority(&pf_stream, hipStreamNonBlocking, greatest));
+            }
             HIP_CHECK(hipEventCreateWithFlags(&pf_free, hipEventDisableTiming));
             for (int b = 0; b < 2; ++b) {
                 d_noise_pf[b].alloc(pf_step_floats * pf_steps);
