@@ -160,7 +160,13 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         HIP_CHECK(hipSetDevice(c.device));        // bbmpc_create restores the caller's device (DeviceGuard)
     }
     HIP_CHECK(hipGetDevice(&device));
-    HIP_CHECK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+    {   // control steps are latency-critical, and a resident control-step kernel must not hold back unrelated work of the
+        // process: hardware queues are pooled per priority, so the handle's streams live in the high-priority pool, away
+        // from PyTorch's and the caller's normal-priority streams (the handles among themselves: stop_foreign_residents)
+        int least = 0, greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&own_stream, hipStreamNonBlocking, greatest));
+    }
     stream = own_stream;
     init_tnq_table();
 
@@ -3021,6 +3027,11 @@ int bbmpc_gather_wait(bbmpc_handle h, int32_t slot, int32_t host_block) {
         } else if (e->h_record_stage[slot] && !host_block && c.sync_mode == 1 && *(volatile const uint32_t*)c.done_flag[slot] < c.done_seq[slot]) {
             host_block = 1;                                      // ditto for an enqueued one that has not finished (rare: it is a control step old)
         }
+        // about to block on the collective: should it sit in a hardware queue behind this handle's resident kernel, that kernel
+        // has to go first (it would otherwise leave only when its linger time is over)
+        if (host_block && e->resident_alive &&
+            (c.sync_mode == 0 ? hipEventQuery(c.done[slot]) != hipSuccess : *(volatile const uint32_t*)c.done_flag[slot] < c.done_seq[slot]))
+            e->resident_stop();
         if (c.sync_mode == 0) {
             if (host_block) {
                 HIP_CHECK(hipEventSynchronize(c.done[slot]));
