@@ -617,9 +617,10 @@ void Engine::from_internal(const float* in, int n_pop, float* ref) const {
 // PyTorch / c10d easily holds more streams than that.  If the communication stream lands on the launch stream's queue
 // its cross-stream wait serialises the two (record all-gather, config 2: 53.7 -> 70 us per control step, depending only
 // on how many streams the process happened to create before).  Queues are pooled per priority, so the communication
-// stream is created with the highest priority -- a latency-critical, tiny collective -- and can never share a queue
-// with a normal-priority launch stream: 56-57 us whatever else the process creates.  (Do not combine with
-// GPU_MAX_HW_QUEUES=8: measured 112 us.)
+// stream is created with the highest priority -- a latency-critical, tiny collective: 56-57 us whatever else the process
+// creates.  (Do not combine with GPU_MAX_HW_QUEUES=8: measured 112 us.)  Round 2: ALL of a handle's streams (launch,
+// noise prefetch, communication) are in that pool, three streams for its four queues, so that the resident control-step
+// kernel never holds back PyTorch's or the caller's normal-priority work; between handles see stop_foreign_residents.
 hipStream_t create_comm_stream() {
     int least = 0, greatest = 0;
     HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
