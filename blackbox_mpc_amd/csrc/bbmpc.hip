@@ -308,12 +308,6 @@ bool Engine::resident_step(const float* state, int add_noise, uint32_t seq) {
         pf_waited[pb] = true; pf_inflight[pb] = false;
     }
     const float* inj = d_noise_pf[pb].p + (size_t)((int64_t)step - c * pf_steps) * pf_step_floats;
-    if (pf_chunk[nb] != c + 1) {
-        // the other buffer held chunk c-1: every control step that read it has handed its record to this thread already
-        launch_noise_fill(c + 1, nb, pf_stream);
-        HIP_CHECK(hipEventRecord(pf_done[nb], pf_stream));
-        pf_chunk[nb] = c + 1; pf_waited[nb] = false; pf_inflight[nb] = true;
-    }
     ++step_counter;
     const uint64_t ip = (uint64_t)(uintptr_t)inj;
     for (int a = 0; a < A; ++a) {                                 // one request line per agent: sequence word 15, payload, sequence word 0
@@ -326,7 +320,14 @@ bool Engine::resident_step(const float* state, int add_noise, uint32_t seq) {
     }
     std::atomic_thread_fence(std::memory_order_release);
     for (int a = 0; a < A; ++a) mbox_host(a)[0] = seq;
-    if (in_flight_hook && !in_flight_called) { in_flight_called = true; in_flight_hook(this); }   // host work that hides under the kernel
+    // host work that hides under the kernel: the next chunk's noise, the previous call's collective
+    if (pf_chunk[nb] != c + 1) {
+        // the other buffer held chunk c-1: every control step that read it has handed its record to this thread already
+        launch_noise_fill(c + 1, nb, pf_stream);
+        HIP_CHECK(hipEventRecord(pf_done[nb], pf_stream));
+        pf_chunk[nb] = c + 1; pf_waited[nb] = false; pf_inflight[nb] = true;
+    }
+    if (in_flight_hook && !in_flight_called) { in_flight_called = true; in_flight_hook(this); }
     const auto t0 = std::chrono::steady_clock::now();
     bool all = true;
     for (int a = 0; a < A; ++a) {
