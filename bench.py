@@ -71,7 +71,7 @@ class Workload:
     """One rank's share of a configuration on the GPU.  `act_step` = what the metric brackets (MPCPolicy.act);
     `dev_step` = the same control step with the state resident in HBM."""
 
-    def __init__(self, name, rank, world, local, dev, use_dist, backend, gather_mode):
+    def __init__(self, name, rank, world, local, dev, use_dist, backend, gather_mode, agents=None):
         import torch
         import torch.distributed as dist
         from blackbox_mpc_amd import _lib as L
@@ -82,7 +82,9 @@ class Workload:
         from blackbox_mpc_amd.utils import synthetic as SY
         self.torch, self.dist, self.L = torch, dist, L
         self.name, self.rank, self.world, self.dev, self.use_dist, self.backend = name, rank, world, dev, use_dist, backend
-        c = self.c = CONFIGS[name]
+        c = self.c = dict(CONFIGS[name])
+        if agents is not None:
+            c["A"] = int(agents)                 # agents this rank owns (config 3 as BASELINE states it: 64 in total)
         N, A, H, iters, k = c["N"], c["A"], c["H"], c["iters"], c["k"]
         self.mlp = c["env"] == "cheetah"
         quirks = L.CMAES_PER_AGENT if c["opt"] == "CMA-ES" else 0   # the shardable CMA-ES mode
@@ -287,12 +289,14 @@ class StubWorkload:
     backend in the CPU test suite (tests/test_bench_ranks_cpu.py).  It computes nothing worth timing and its numbers
     mean nothing; it is refused outside BBMPC_BENCH_BACKEND=gloo."""
 
-    def __init__(self, name, rank, world, local, dev, use_dist, backend, gather_mode):
+    def __init__(self, name, rank, world, local, dev, use_dist, backend, gather_mode, agents=None):
         import torch
         import torch.distributed as dist
         assert backend == "gloo", "the stub workload only exists for the gloo rank-logic test"
         self.torch, self.dist = torch, dist
-        c = self.c = CONFIGS[name]
+        c = self.c = dict(CONFIGS[name])
+        if agents is not None:
+            c["A"] = int(agents)
         self.name, self.rank, self.world, self.use_dist, self.backend = name, rank, world, use_dist, backend
         self.mlp = c["env"] == "cheetah"
         self.U, self.S = (6, 20) if self.mlp else (1, 3)
@@ -341,9 +345,10 @@ class StubWorkload:
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def measure(W, steps, warmup, dist, use_dist, red_dev):
+def measure(W, steps, warmup, dist, use_dist, red_dev, act_only=False):
     """Times `steps` control steps twice: through MPCPolicy.act (the metric) and device-resident (the roofline).
-    Both regions are bracketed by barrier + synchronize on both sides; elapsed = MAX over ranks."""
+    Both regions are bracketed by barrier + synchronize on both sides; elapsed = MAX over ranks.
+    act_only: just the MPCPolicy.act region (the launch-per-call repeat of the headline)."""
     torch = W.torch
 
     def reduce_max(x):
@@ -376,6 +381,9 @@ def measure(W, steps, warmup, dist, use_dist, red_dev):
     rows_act = W.check_gather(host_records)
     act_elapsed = reduce_max(t1 - t0)
     med, p10, p90 = (reduce_max(_pct(walls, q)) for q in (50, 10, 90))
+    if act_only:
+        return dict(walls=walls, act_elapsed=act_elapsed, median=med, p10=p10, p90=p90, n_samples=n_samples,
+                    gather_rows_checked=rows_act)
 
     # ---- (2) device-resident closed loop + HIP events around the dominant kernel ----------------------------------
     for _ in range(max(2, min(warmup, 20))):
@@ -407,7 +415,7 @@ def measure(W, steps, warmup, dist, use_dist, red_dev):
 
 
 def roofline(W, m, name, world):
-    c = CONFIGS[name]
+    c = W.c
     N, A, H, iters = c["N"], c["A"], c["H"], c["iters"]
     U, S, mlp, kname = W.U, W.S, W.mlp, m["kname"]
     bytes_per_traj = 4.0 * (H * U + 1) + 4.0 * S / N        # SURVEY 8d / BASELINE.md
@@ -466,14 +474,29 @@ def roofline(W, m, name, world):
 
 
 def describe(name, W, world):
-    c = CONFIGS[name]
+    c = W.c
     return ("BASELINE %s: %s, %s, num_agents=%d/GPU, N=%d, H=%d, %d iters%s, closed loop (the model is the environment)"
             % (name, "HalfCheetah(mod) S=20 U=6 learned MLP 26-200-200-20 dynamics" if W.mlp else "Pendulum-v0 true dynamics",
                c["opt"], c["A"], c["N"], c["H"], c["iters"], (", k=%d" % c["k"]) if c["k"] else ""))
 
 
+def multi_gpu_block(W, m, world):
+    """Evidence that the exchange ran: communicator size, hand-off mode, gathered rows checked."""
+    return {
+        "ranks": world,
+        "rccl_ranks": W.comm_info[0] if W.comm_info else None,             # ncclCommCount of the engine's communicator
+        "rccl_rank0": W.comm_info[1] if W.comm_info else None,
+        "gather_mode": ("engine-owned RCCL communicator + stream (%s hand-off)"
+                        % ("signal-memory sequence number" if W.comm_info and W.comm_info[2] == 1 else "event"))
+                       if W.native else "torch.distributed " + W.gather_mode,
+        "fallback_reason": W.fallback_reason,
+        "gathered_rows_checked": m["gather_rows_checked"],
+        "gathered_rows_check": "rows of the local agents bit-equal to the records produced, all rows finite",
+    }
+
+
 def result_block(name, W, m, world, steps, warmup):
-    c = CONFIGS[name]
+    c = W.c
     total_agents = world * c["A"]
     value = total_agents / m["median"]
     dev_rate = steps * total_agents / m["dev_elapsed"]
@@ -483,8 +506,15 @@ def result_block(name, W, m, world, steps, warmup):
                   % ("HalfCheetah learned MLP 26-200-200-20" if W.mlp else "Pendulum true model", c["opt"], c["N"], c["H"]),
         "value": value,
         "unit": "control-steps/s",
-        "value_definition": "agents / median wall time of MPCPolicy.act(obs, t): NumPy observation in, all optimizer "
-                            "iterations on the GPU, NumPy action / next observation / reward out (rollouts.py:92-101 bracket)",
+        "value_definition": ("agents / median wall time of MPCPolicy.act(obs, t): NumPy observation in, all optimizer "
+                             "iterations on the GPU, NumPy action / next observation / reward out (rollouts.py:92-101 bracket)")
+                            if not getattr(W, "native", False) else
+                            ("all ranks' agents / MAX over ranks of the median wall time of Engine.optimize_gather(obs, t) -- "
+                             "the call MPCPolicy.act makes (NumPy observation in, all optimizer iterations, NumPy action / next "
+                             "observation / reward out) with the rank's records handed to the engine's RCCL all-gather; the "
+                             "collective of call t is enqueued by call t+1 and overlaps it, so the per-call median does not "
+                             "contain the collective's latency: ms_per_step (barrier to barrier, every gather completed) is "
+                             "the figure that does"),
         "median_ms": m["median"] * 1e3, "p10_ms": m["p10"] * 1e3, "p90_ms": m["p90"] * 1e3,
         "percentile_samples": m["n_samples"],
         "steps": steps, "warmup": warmup,

@@ -180,7 +180,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.cma_fused = flag("BBMPC_CMA_FUSED");
         sw.mlp_generic = flag("BBMPC_MLP_GENERIC");
         { const int b = ival("BBMPC_MLP_BF16", 0); sw.mlp_bf16 = (b == 1 || b == 3) ? b : 0; }
-        sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1);
+        sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1); sw.mlp_q4r = ival("BBMPC_MLP_Q4R", 1);
         sw.mlp_wave = ival("BBMPC_MLP_WAVE", 1);
         sw.linger_us = std::max(0, ival("BBMPC_LINGER_US", 200));
         linger_test_quit = ival("BBMPC_LINGER_TEST_QUIT", 0) - 1;
@@ -869,6 +869,22 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
         const long quads_total = (long)((ra.n_pop + 3) / 4) * A;
         int q4 = (q4_ok && quads_total <= 512) ? 1 : 0;
         if (sw.mlp_q4 >= 0) q4 = (sw.mlp_q4 != 0 && q4_ok) ? 1 : 0;
+        // register-resident-state form (two barriers per model step, kernels_mlp_q4r.hpp): dim_S == 20, cheetah reward or none
+        if (q4 && !sw.mlp_generic && sw.mlp_q4r && S == 20 && U <= 8 && mlp.dims[3] == 20 &&
+            (ra.reward_kind == REW_CHEETAH || ra.reward_kind == REW_NONE)) {
+            const size_t qlds = (size_t)mlp_q4r_lds_floats(50, 7, ra.H, U) * sizeof(float);
+            if (qlds <= 160 * 1024) {
+                auto fn = k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE>;
+                if (qlds > 64 * 1024) ensure_max_lds((const void*)fn, 160 * 1024);
+                dim3 qgrid((ra.n_pop + 3) / 4, A), qblock(256);
+                dominant_kernel = "k_rollout_mlp_q4r";
+                prof_begin();
+                hipLaunchKernelGGL(fn, qgrid, qblock, qlds, stream, q);
+                HIP_CHECK(hipGetLastError());
+                prof_end();
+                return;
+            }
+        }
         if (q4 && !sw.mlp_generic) {
             const size_t qlds = (size_t)mlp_q4_lds_floats(50, 7, 4, ra.H, U, S) * sizeof(float);
             if (qlds <= 160 * 1024) {

@@ -1,0 +1,544 @@
+// Quad mode, register-resident state ("q4r"): the 4-particle workgroup of k_rollout_mlp_q4 with TWO barriers per
+// model step instead of four and a quarter fewer matrix instructions.  Same fused path (reference files under
+// blackbox_mpc/):
+//   SystemDynamicsHandler.process_input / process_output   dynamics_handlers/system_dynamics_handler.py:97-161
+//   DeterministicMLP.__call__                              dynamics_functions/deterministic_mlp.py:27-51
+//   reward_function                                        tutorials/mujoco/cost_func.py:5-22
+//   DeterministicTrajectoryEvaluator.__call__              trajectory_evaluators/deterministic.py:26-77
+//
+// v_mfma_f32_4x4x1_16b_f32 is 16 independent 4x4 outer products, and nothing says the 16 blocks have to work on the
+// same k.  k_rollout_mlp_q4 gives every block the same k and 64 different output features; a wave then issues 200
+// MFMAs for layer 1 whatever its share of the 200 hidden units is (the fourth wave: 8 of 64 lanes useful), and the
+// 200 -> 20 layer has to be K-split ACROSS the waves, which costs an exchange of partial sums plus a wave-0-only
+// epilogue plus an exchange of the next input: four barrier / LDS round trips per model step, 0.86 us of 2.33.
+// Here the K split is INSIDE the instruction:
+//  * layer 1 runs as "jobs" of 16 output features: block (row r, quad g) = features 16j+4g..+3 over the k-slice of
+//    16-lane row r (13 k-groups), 52 MFMAs per job, three jobs per wave sharing ONE set of B operands (13 LDS reads
+//    per lane instead of 50) + an 8-feature tail job (2 feature blocks x 8 slices, 28 MFMAs) on wave 3:
+//    156 / 184 MFMAs per wave instead of 200;
+//  * the last layer is computed whole by every wave: set A (features 0..15: 4 quads x 4 row slices, 52 MFMAs) and
+//    set B (features 16..19: block b takes k-groups b, b+16, b+32, b+48, 16 MFMAs);
+//  * the slices are reduced in registers: inside a row with DPP rotations (8 then 4: every block adds the same pairs,
+//    so all blocks hold the same bits), across the four rows with v_permlane32_swap / v_permlane16_swap used as a
+//    reduce-scatter (one swap + one add folds TWO registers: 4 registers -> 1 in 6 instructions; row r ends up with
+//    element {0,2,1,3}[r]).  Activation / bias / de-normalisation / residual / normalisation then touch 1-2 values
+//    per lane, and for the state the same swaps run backwards as an all-gather;
+//  * a lane then holds the normalised input groups "own quad" and 4 of its particle: layer 0 takes the other three
+//    state groups from its row neighbours by DPP rotation -- block g multiplies group (g - j) mod 4 in round j, its
+//    stationary A operands are loaded in that order once -- so the next step's layer 0 starts from registers.
+// Barriers remain after h0 and after h1.  The action part of layer 0 (independent of the state) is issued one step
+// ahead, after the h1 store, where the wave would otherwise sit in the barrier.
+// Requires dim_S == 20 (5 state groups: four rotate inside a row, the fifth is replicated), the HalfCheetah reward or
+// none (a user function scores the recorded trajectory); everything else keeps k_rollout_mlp_q4.
+#pragma once
+#include "kernels_mlp.hpp"
+
+namespace bbmpc {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    // all lanes are sources here (row rotations), so no "old" value has to be materialised (bound_ctrl)
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128, DPP_ROW_ROR12 = 0x12c;   // dst[i] = src[(i - n) & 15] in each 16-lane row
+// a = [a.lo32 | b.lo32], b = [a.hi32 | b.hi32]              (tools/microbench/lane_ops.hip prints the maps)
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(a), __float_as_int(b), false, false);
+    a = __int_as_float(r[0]); b = __int_as_float(r[1]);
+}
+// rows of 16 lanes: a = [a.r0, b.r0, a.r2, b.r2], b = [a.r1, b.r1, a.r3, b.r3]
+__device__ __forceinline__ void swap16(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(a), __float_as_int(b), false, false);
+    a = __int_as_float(r[0]); b = __int_as_float(r[1]);
+}
+// sum over the four 16-lane rows of four registers at once: row r of the result holds the total of v[{0,2,1,3}[r]]
+__device__ __forceinline__ float rows_reduce_scatter(f32x4 v) {
+    float a0 = v.x, a1 = v.y, a2 = v.z, a3 = v.w;
+    swap32(a0, a1);
+    swap32(a2, a3);
+    float t01 = a0 + a1, t23 = a2 + a3;
+    swap16(t01, t23);
+    return t01 + t23;
+}
+// inverse: row r holds element {0,2,1,3}[r]; afterwards every row holds all four
+__device__ __forceinline__ f32x4 rows_all_gather(float z) {
+    float v0 = z, v1 = z;
+    swap16(v0, v1);                 // v0 = [z0 z0 z2 z2], v1 = [z1 z1 z3 z3]   (z_r = row r's value)
+    float c0 = v0, c1 = v1;
+    swap32(v0, c0);                 // v0 = z0 everywhere, c0 = z2 everywhere
+    swap32(v1, c1);                 // v1 = z1,            c1 = z3
+    f32x4 o;
+    o.x = v0; o.y = c0; o.z = v1; o.w = c1;       // rows hold elements 0, 2, 1, 3: z0 = e0, z2 = e1, z1 = e2, z3 = e3
+    return o;
+}
+// ---- MFMAs through inline asm: accumulators stay in VGPRs (the compiler gives builtin MFMAs AccVGPR destinations as
+// soon as the kernel touches AccVGPRs at all and then pays a v_accvgpr_read per result register), the stationary A
+// operand comes from a VGPR ("v") or straight from an AccVGPR ("a"), and the first MFMA of a chain takes its C operand
+// from the bias registers (or the inline constant 0) instead of a copy.  The compiler neither sees the instruction nor
+// pads its hazards (cdna_hip_programming.md 5.7): every sequence below
+//   * starts behind a sched_barrier + mfma4_operands_settled() (VALU-written operands -> MFMA read: 2 wait states),
+//   * keeps consecutive MFMAs on one accumulator >= 3 issues apart (three or four chains, round robin),
+//   * ends with mfma4_results_ready() (2-pass MFMA result -> VALU read: 4 wait states), which also ties the accumulators.
+#define BBMPC_MFMA4 "v_mfma_f32_4x4x1_16b_f32 "
+__device__ __forceinline__ void mfma4_v(f32x4& acc, float a, float b) {
+    asm volatile(BBMPC_MFMA4 "%0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma4_v_c(f32x4& acc, float a, float b, const f32x4& c) {
+    asm volatile(BBMPC_MFMA4 "%0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void mfma4_v_0(f32x4& acc, float a, float b) {
+    asm volatile(BBMPC_MFMA4 "%0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma4_a(f32x4& acc, float a_in_agpr, float b) {
+    asm volatile(BBMPC_MFMA4 "%0, %1, %2, %0" : "+v"(acc) : "a"(a_in_agpr), "v"(b));
+}
+__device__ __forceinline__ void mfma4_a_c(f32x4& acc, float a_in_agpr, float b, const f32x4& c) {
+    asm volatile(BBMPC_MFMA4 "%0, %1, %2, %3" : "=&v"(acc) : "a"(a_in_agpr), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void mfma4_a_0(f32x4& acc, float a_in_agpr, float b) {
+    asm volatile(BBMPC_MFMA4 "%0, %1, %2, 0" : "=&v"(acc) : "a"(a_in_agpr), "v"(b));
+}
+__device__ __forceinline__ void mfma4_operands_settled() { asm volatile("s_nop 1"); }
+__device__ __forceinline__ void mfma4_results_ready(f32x4& c0, f32x4& c1, f32x4& c2) {
+    asm volatile("s_nop 4" : "+v"(c0), "+v"(c1), "+v"(c2));
+}
+__device__ __forceinline__ void mfma4_results_ready(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3) {
+    asm volatile("s_nop 4" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+}
+__device__ __forceinline__ void mfma4_results_ready(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, f32x4& c4) {
+    asm volatile("s_nop 4" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4));
+}
+
+template <int HG, int K0G, int A0, int A1, int A2>
+__global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const RolloutArgs& p = q.r;
+    const MlpDesc& m = q.m;
+    constexpr int NT = 256, QP = 4;
+    constexpr int SG = 5, AG = K0G - SG;                 // state / action input groups (dim_S == 20)
+    constexpr int KA = (HG + 3) / 4;                     // k groups per 16-lane row when K is split over the rows
+    constexpr int KB = (HG + 15) / 16;                   // last layer set B: k groups per 4-lane block
+    constexpr int HP = 64;                               // h0 / h1 are padded to 64 groups (zero): clamp-free operand addresses
+    constexpr int NJ = HG / 16;                          // layer-1 jobs of 16 output features per wave (12 jobs = 192 features)
+    constexpr int TF = HG * 4 - NJ * 64;                 // features left for the tail job (8)
+    constexpr int KT = (HG + 7) / 8;                     // tail job: k groups per slice (8 slices)
+    static_assert(HG < HP && KA * 4 <= HP && (KB - 1) * 16 + 15 < HP && K0G > SG, "padding / input groups");
+    static_assert(NJ == 3 && TF == 8 && KT <= KA && KB <= KA && AG == 2, "written for 200 hidden units, 20 + <= 8 inputs");
+    const int a = blockIdx.y, n0 = blockIdx.x * QP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = p.S, U = p.U, H = p.H;
+    const bool normd = m.normalized != 0;
+    const int row = lane >> 4, blk = lane >> 2, fgq = blk & 3, pl = lane & 3;
+    const int pr = ((row & 1) << 1) | (row >> 1);        // element of a reduce-scattered float4 this row holds
+    // ---- LDS: h0[HP][4][4] | h1[HP][4][4] | acts[H][4][U] | pen[4U] | xa[H][AG][4][4] | zs[H][4] | rwd[H][4][4] | constants
+    float* h0 = smem;
+    float* h1 = h0 + HP * 16;
+    float* acts = h1 + HP * 16;
+    float* pens = acts + ((H * QP * U + 3) & ~3);
+    float* xa = pens + ((QP * U + 3) & ~3);
+    float* zs = xa + H * AG * 16;
+    float* rwd = zs + H * QP;                             // per step and particle: (progress difference, flag 5, flag 6, flag 7)
+    float* nmean = rwd + H * QP * 4;                      // [S+U] input mean, [S+U] 1/(std+1e-7), [S] target mean, [S] std+1e-7,
+    float* ninv = nmean + 32;                             // [S] last bias, [S] start state   (S = 20, S+U <= 28)
+    float* tmean = ninv + 32;
+    float* tstd = tmean + 32;
+    float* lbias = tstd + 32;
+    float* st0 = lbias + 32;
+#ifdef BBMPC_KERNEL_DBG
+    long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_t0 = (long long)wall_clock64();
+#define Q4R_MARK(i) do { const long long now_ = (long long)wall_clock64(); dbg_acc[i] += now_ - dbg_t0; dbg_t0 = now_; } while (0)
+    long long dbg_cyc[4] = {0, 0, 0, 0}, dbg_c0 = 0;
+#define Q4R_CYC0() do { dbg_c0 = (long long)clock64(); } while (0)
+#define Q4R_CYC(i) do { dbg_cyc[i] += (long long)clock64() - dbg_c0; } while (0)
+#else
+#define Q4R_MARK(i) do {} while (0)
+#define Q4R_CYC0() do {} while (0)
+#define Q4R_CYC(i) do {} while (0)
+#endif
+
+    // ---- prologue, part 1 (small loads first: global loads return in order, nothing here may queue behind the
+    // ~300 KB of stationary operands): constants, start state, the 4 particles' action block
+    for (int i = tid; i < S + U; i += NT) {
+        const float mu = normd ? (i < S ? m.mean_s[i] : m.mean_a[i - S]) : 0.0f;
+        const float sd = normd ? (i < S ? m.std_s[i] : m.std_a[i - S]) : 1.0f;
+        nmean[i] = mu;
+        ninv[i] = normd ? 1.0f / (sd + 1e-7f) : 1.0f;
+        if (i < S) {
+            tmean[i] = normd ? m.mean_t[i] : 0.0f;         // un-normalised: 0 + z * 1 = z exactly
+            tstd[i] = normd ? (m.std_t[i] + 1e-7f) : 1.0f;
+            lbias[i] = q.braw[2][i];
+            st0[i] = p.state[a * S + i];
+        }
+    }
+    mlp_fill_actions<QP>(q, a, n0, tid, NT, acts, pens);
+    for (int i = tid; i < (HP - HG) * 16; i += NT) { h0[HG * 16 + i] = 0.0f; h1[HG * 16 + i] = 0.0f; }
+    __syncthreads();
+    Q4R_MARK(5);
+
+    // ---- stationary A operands (packed [k/4][Mp][4] by bbmpc_set_mlp)
+    const int M1 = m.dims[1], M3 = m.dims[3];
+    const int Mp1 = (M1 + 63) & ~63, Mp3 = (M3 + 63) & ~63;
+    const float4* __restrict__ Q0 = reinterpret_cast<const float4*>(q.wq4[0]);
+    const float4* __restrict__ Q1 = reinterpret_cast<const float4*>(q.wq4[1]);
+    const float4* __restrict__ Q2 = reinterpret_cast<const float4*>(q.wq4[2]);
+    const int f = wave * 64 + lane;                      // hidden feature of this lane's layer-0 A operands
+    float wA0r[16], wA0b[4], wA0a[AG * 4], wJ[NJ][KA * 4], wT[KT * 4], wA2a[KA * 4], wA2b[KB * 4];
+#pragma unroll
+    for (int g = 0; g < AG; ++g) {
+        const float4 v = Q0[(size_t)(SG + g) * Mp1 + f];
+        wA0a[4 * g + 0] = v.x; wA0a[4 * g + 1] = v.y; wA0a[4 * g + 2] = v.z; wA0a[4 * g + 3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                        // round j of layer 0: my block multiplies state group (fgq - j) & 3
+        const float4 v = Q0[(size_t)((fgq - j) & 3) * Mp1 + f];
+        wA0r[4 * j + 0] = v.x; wA0r[4 * j + 1] = v.y; wA0r[4 * j + 2] = v.z; wA0r[4 * j + 3] = v.w;
+    }
+    {
+        const float4 v = Q0[(size_t)4 * Mp1 + f];
+        wA0b[0] = v.x; wA0b[1] = v.y; wA0b[2] = v.z; wA0b[3] = v.w;
+    }
+    // K split over the rows (layer-1 jobs, last-layer set A): row r takes k groups [KA*r, KA*r + cnt)
+    const int startA = KA * row;
+    const int cntA = min(KA, HG - startA);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {                    // job = wave + 4*jj: output features 16*job + (lane & 15)
+        const int o = 16 * (wave + 4 * jj) + (lane & 15);
+#pragma unroll
+        for (int c = 0; c < KA; ++c) {
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (c < cntA) v = Q1[(size_t)(startA + c) * Mp1 + o];
+            wJ[jj][4 * c + 0] = v.x; wJ[jj][4 * c + 1] = v.y; wJ[jj][4 * c + 2] = v.z; wJ[jj][4 * c + 3] = v.w;
+        }
+    }
+    // tail job (wave 3): block b = feature block b & 1 (features 64*NJ + 4*(b&1) + (lane&3)), k slice b >> 1 of 8
+    const int sT = blk >> 1;
+    const int startT = (HG / 8) * sT + min(sT, HG % 8);
+    const int cntT = HG / 8 + (sT < HG % 8 ? 1 : 0);
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (wave == 3 && c < cntT) v = Q1[(size_t)(startT + c) * Mp1 + 64 * NJ + 4 * (blk & 1) + (lane & 3)];
+        wT[4 * c + 0] = v.x; wT[4 * c + 1] = v.y; wT[4 * c + 2] = v.z; wT[4 * c + 3] = v.w;
+    }
+    // last layer, set A: output feature = lane & 15, k slice of my row
+#pragma unroll
+    for (int c = 0; c < KA; ++c) {
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (c < cntA) v = Q2[(size_t)(startA + c) * Mp3 + (lane & 15)];
+        wA2a[4 * c + 0] = v.x; wA2a[4 * c + 1] = v.y; wA2a[4 * c + 2] = v.z; wA2a[4 * c + 3] = v.w;
+    }
+    // set B: block b takes k groups b, b + 16, ...; output feature = 16 + (lane & 3)
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+        const int gg = blk + 16 * c;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (gg < HG) v = Q2[(size_t)gg * Mp3 + 16 + (lane & 3)];
+        wA2b[4 * c + 0] = v.x; wA2b[4 * c + 1] = v.y; wA2b[4 * c + 2] = v.z; wA2b[4 * c + 3] = v.w;
+    }
+    // biases enter as the C operand of a chain's first MFMA: layer 0 for my 4 D rows (features 64*wave + 4*blk + r);
+    // the K-split layers through ONE k slice (row 0; tail job: slice 0; last layer: row 0 for set A, block 0 for set B)
+    f32x4 b0;
+    {
+        const int fb = wave * 64 + 4 * blk;
+        b0.x = fb + 0 < M1 ? q.braw[0][fb + 0] : 0.0f; b0.y = fb + 1 < M1 ? q.braw[0][fb + 1] : 0.0f;
+        b0.z = fb + 2 < M1 ? q.braw[0][fb + 2] : 0.0f; b0.w = fb + 3 < M1 ? q.braw[0][fb + 3] : 0.0f;
+    }
+    f32x4 b1j[NJ], b1t = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int fb = 16 * (wave + 4 * jj) + 4 * fgq;
+        b1j[jj] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (row == 0) { b1j[jj].x = q.braw[1][fb + 0]; b1j[jj].y = q.braw[1][fb + 1]; b1j[jj].z = q.braw[1][fb + 2]; b1j[jj].w = q.braw[1][fb + 3]; }
+    }
+    if (wave == 3 && sT == 0) {
+        const int fb = 64 * NJ + 4 * (blk & 1);
+        b1t.x = q.braw[1][fb + 0]; b1t.y = q.braw[1][fb + 1]; b1t.z = q.braw[1][fb + 2]; b1t.w = q.braw[1][fb + 3];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- prologue, part 2 (LDS only, while the operands land): normalised action groups, 0 * sum(a^2), constants
+    for (int e = tid; e < H * AG * 16; e += NT) {
+        const int c = e & 3, pp = (e >> 2) & 3, ga = (e >> 4) % AG, t = e / (16 * AG);
+        const int u = ga * 4 + c;
+        xa[e] = (u < U) ? (acts[(t * QP + pp) * U + u] - nmean[S + u]) * ninv[S + u] : 0.0f;
+    }
+    for (int e = tid; e < H * QP; e += NT) {
+        const float* ac = acts + e * U;                    // e = t*QP + pp
+        float ss = 0.0f;
+        for (int u = 0; u < U; ++u) ss = ss + ac[u] * ac[u];
+        zs[e] = 0.0f * ss;                                 // cost_func.py:21 (NaN / inf actions propagate)
+    }
+    // the two output features this lane finishes: fA = 4*fgq + pr, fB = 16 + pr
+    const int fA = 4 * fgq + pr, fB = 16 + pr;
+    const float tmA = tmean[fA], tsA = tstd[fA], tmB = tmean[fB], tsB = tstd[fB];
+    const float nmA = nmean[fA], niA = ninv[fA], nmB = nmean[fB], niB = ninv[fB];
+    f32x4 biasA = {0.0f, 0.0f, 0.0f, 0.0f}, biasB = biasA;
+    if (row == 0) { biasA.x = lbias[4 * fgq + 0]; biasA.y = lbias[4 * fgq + 1]; biasA.z = lbias[4 * fgq + 2]; biasA.w = lbias[4 * fgq + 3]; }
+    if (blk == 0) { biasB.x = lbias[16]; biasB.y = lbias[17]; biasB.z = lbias[18]; biasB.w = lbias[19]; }
+    // start state: the scattered copies (residual) and the normalised input groups "own quad" and 4
+    float curA = st0[fA], curB = st0[fB];
+    f32x4 xA, xB;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        xA[c] = (st0[4 * fgq + c] - nmean[4 * fgq + c]) * ninv[4 * fgq + c];
+        xB[c] = (st0[16 + c] - nmean[16 + c]) * ninv[16 + c];
+    }
+    __syncthreads();
+    Q4R_MARK(6);
+
+    const int my_row = (wave * 16 + blk) * 16 + pl * 4;   // where my layer-0 D fragment goes in h0 (floats)
+    const bool own_rows = (wave * 64 + 4 * blk) < HG * 4;
+    const bool rew_on = p.reward_kind == REW_CHEETAH;
+    const float flag_thr = (pr == 1) ? 0.2f : 0.0f;       // cur[5] >= 0.2, cur[6] >= 0, cur[7] >= 0   cost_func.py:9-17
+    // reward terms are parked per step and summed in step order after the loop (one IEEE division per (step, particle)
+    // there instead of a ~12-instruction expansion inside every step): wave 0, quad 1 rows 1..3 own the flags of
+    // cur[6], cur[5], cur[7]; wave 0, quad 0 of row 2 (feature 17) owns the progress difference
+    const bool rwd_flag_lane = rew_on && wave == 0 && fgq == 1 && pr != 0;
+    const bool rwd_prog_lane = rew_on && wave == 0 && fgq == 0 && pr == 1;
+    float* rwd_f = rwd + pl * 4 + pr;                     // + t*16
+    float* rwd_d = rwd + pl * 4;
+    // where my layer-1 results go: job feature 16*job + 4*fgq + pr -> h1[group 4*job + fgq][pl][pr]
+    float* h1w = h1 + ((size_t)(4 * wave + fgq) * 4 + pl) * 4 + pr;          // + jj * 16 groups
+    float* h1t = h1 + ((size_t)(16 * NJ + (blk & 1)) * 4 + pl) * 4 + pr;
+    const float* hA0 = h0 + ((size_t)startA * 4 + pl) * 4;
+    const float* hT0 = h0 + ((size_t)startT * 4 + pl) * 4;
+    const float* hA1 = h1 + ((size_t)startA * 4 + pl) * 4;
+    const float* hB1 = h1 + ((size_t)blk * 4 + pl) * 4;
+    // layer-0 accumulators (three chains), started with the bias and the action part of step 0
+    f32x4 acc0, acc1, acc2;
+    {
+        f32x4 ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)0 * 4 + pl) * 4);
+        f32x4 ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)1 * 4 + pl) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4_operands_settled();
+        mfma4_v_c(acc0, wA0a[0], ba0.x, b0); mfma4_v_0(acc1, wA0a[1], ba0.y); mfma4_v_0(acc2, wA0a[2], ba0.z);
+        mfma4_v(acc0, wA0a[3], ba0.w);       mfma4_v(acc1, wA0a[4], ba1.x);   mfma4_v(acc2, wA0a[5], ba1.y);
+        mfma4_v(acc0, wA0a[6], ba1.z);       mfma4_v(acc1, wA0a[7], ba1.w);
+    }
+#ifdef BBMPC_KERNEL_DBG
+    Q4R_MARK(7);
+    const long long dbg_start = dbg_t0, dbg_cyc0 = (long long)clock64();
+#endif
+    for (int t = 0; t < H; ++t) {
+        // ---- layer 0, state part: groups 0..3 rotate through the row, group 4 is replicated
+        {
+            f32x4 r1, r2, r3;
+            r1.x = dpp_mov<DPP_ROW_ROR4>(xA.x); r1.y = dpp_mov<DPP_ROW_ROR4>(xA.y);
+            r1.z = dpp_mov<DPP_ROW_ROR4>(xA.z); r1.w = dpp_mov<DPP_ROW_ROR4>(xA.w);
+            r2.x = dpp_mov<DPP_ROW_ROR8>(xA.x); r2.y = dpp_mov<DPP_ROW_ROR8>(xA.y);
+            r2.z = dpp_mov<DPP_ROW_ROR8>(xA.z); r2.w = dpp_mov<DPP_ROW_ROR8>(xA.w);
+            r3.x = dpp_mov<DPP_ROW_ROR12>(xA.x); r3.y = dpp_mov<DPP_ROW_ROR12>(xA.y);
+            r3.z = dpp_mov<DPP_ROW_ROR12>(xA.z); r3.w = dpp_mov<DPP_ROW_ROR12>(xA.w);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4_operands_settled();
+            // (the action part left the chains at acc2: 8 MFMAs = 0 1 2 0 1 2 0 1)
+            mfma4_v(acc2, wA0r[0], xA.x);  mfma4_v(acc0, wA0r[1], xA.y);  mfma4_v(acc1, wA0r[2], xA.z);
+            mfma4_v(acc2, wA0r[3], xA.w);  mfma4_v(acc0, wA0r[4], r1.x);  mfma4_v(acc1, wA0r[5], r1.y);
+            mfma4_v(acc2, wA0r[6], r1.z);  mfma4_v(acc0, wA0r[7], r1.w);  mfma4_v(acc1, wA0r[8], r2.x);
+            mfma4_v(acc2, wA0r[9], r2.y);  mfma4_v(acc0, wA0r[10], r2.z); mfma4_v(acc1, wA0r[11], r2.w);
+            mfma4_v(acc2, wA0r[12], r3.x); mfma4_v(acc0, wA0r[13], r3.y); mfma4_v(acc1, wA0r[14], r3.z);
+            mfma4_v(acc2, wA0r[15], r3.w); mfma4_v(acc0, wA0b[0], xB.x);  mfma4_v(acc1, wA0b[1], xB.y);
+            mfma4_v(acc2, wA0b[2], xB.z);  mfma4_v(acc0, wA0b[3], xB.w);
+            mfma4_results_ready(acc0, acc1, acc2);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 o;
+            o.x = apply_act_ct<A0>((acc0.x + acc1.x) + acc2.x); o.y = apply_act_ct<A0>((acc0.y + acc1.y) + acc2.y);
+            o.z = apply_act_ct<A0>((acc0.z + acc1.z) + acc2.z); o.w = apply_act_ct<A0>((acc0.w + acc1.w) + acc2.w);
+            if (own_rows) *reinterpret_cast<f32x4*>(h0 + my_row) = o;
+        }
+        Q4R_MARK(0);
+        __syncthreads();
+        Q4R_MARK(1);
+        // ---- layer 1: three 16-feature jobs per wave, K split over the rows, one shared set of B operands;
+        // stationary A operands in AccVGPRs, read by the MFMA directly.  Wave 3 carries the 8-feature tail job as a
+        // fourth chain through its first KT rounds.
+        f32x4 ba0, ba1;
+        {
+            f32x4 cj0, cj1, cj2, ct;
+            f32x4 bq[KA];
+#pragma unroll
+            for (int c = 0; c < KA; ++c) bq[c] = *reinterpret_cast<const f32x4*>(hA0 + c * 16);
+            {   // next step's normalised action groups (consumed after the h1 store)
+                const int tn = (t + 1 < H) ? t + 1 : t;
+                ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 0) * 4 + pl) * 4);
+                ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 1) * 4 + pl) * 4);
+            }
+            if (wave != 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                Q4R_CYC0();
+                mfma4_a_c(cj0, wJ[0][0], bq[0].x, b1j[0]); mfma4_a_c(cj1, wJ[1][0], bq[0].x, b1j[1]); mfma4_a_c(cj2, wJ[2][0], bq[0].x, b1j[2]);
+                mfma4_a(cj0, wJ[0][1], bq[0].y); mfma4_a(cj1, wJ[1][1], bq[0].y); mfma4_a(cj2, wJ[2][1], bq[0].y);
+                mfma4_a(cj0, wJ[0][2], bq[0].z); mfma4_a(cj1, wJ[1][2], bq[0].z); mfma4_a(cj2, wJ[2][2], bq[0].z);
+                mfma4_a(cj0, wJ[0][3], bq[0].w); mfma4_a(cj1, wJ[1][3], bq[0].w); mfma4_a(cj2, wJ[2][3], bq[0].w);
+#pragma unroll
+                for (int c = 1; c < KA; ++c) {
+                    const f32x4 b = bq[c];
+                    mfma4_a(cj0, wJ[0][c * 4 + 0], b.x); mfma4_a(cj1, wJ[1][c * 4 + 0], b.x); mfma4_a(cj2, wJ[2][c * 4 + 0], b.x);
+                    mfma4_a(cj0, wJ[0][c * 4 + 1], b.y); mfma4_a(cj1, wJ[1][c * 4 + 1], b.y); mfma4_a(cj2, wJ[2][c * 4 + 1], b.y);
+                    mfma4_a(cj0, wJ[0][c * 4 + 2], b.z); mfma4_a(cj1, wJ[1][c * 4 + 2], b.z); mfma4_a(cj2, wJ[2][c * 4 + 2], b.z);
+                    mfma4_a(cj0, wJ[0][c * 4 + 3], b.w); mfma4_a(cj1, wJ[1][c * 4 + 3], b.w); mfma4_a(cj2, wJ[2][c * 4 + 3], b.w);
+                }
+                mfma4_results_ready(cj0, cj1, cj2);
+                __builtin_amdgcn_sched_barrier(0);
+                Q4R_CYC(0);
+                Q4R_CYC0();
+                h1w[0 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj0));
+                h1w[1 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj1));
+                h1w[2 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj2));
+                Q4R_CYC(1);
+            } else {
+                f32x4 bt[KT];
+#pragma unroll
+                for (int c = 0; c < KT; ++c) bt[c] = *reinterpret_cast<const f32x4*>(hT0 + c * 16);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma4_a_c(cj0, wJ[0][0], bq[0].x, b1j[0]); mfma4_a_c(cj1, wJ[1][0], bq[0].x, b1j[1]); mfma4_a_c(cj2, wJ[2][0], bq[0].x, b1j[2]);
+                mfma4_a_c(ct, wT[0], bt[0].x, b1t);
+                mfma4_a(cj0, wJ[0][1], bq[0].y); mfma4_a(cj1, wJ[1][1], bq[0].y); mfma4_a(cj2, wJ[2][1], bq[0].y); mfma4_a(ct, wT[1], bt[0].y);
+                mfma4_a(cj0, wJ[0][2], bq[0].z); mfma4_a(cj1, wJ[1][2], bq[0].z); mfma4_a(cj2, wJ[2][2], bq[0].z); mfma4_a(ct, wT[2], bt[0].z);
+                mfma4_a(cj0, wJ[0][3], bq[0].w); mfma4_a(cj1, wJ[1][3], bq[0].w); mfma4_a(cj2, wJ[2][3], bq[0].w); mfma4_a(ct, wT[3], bt[0].w);
+#pragma unroll
+                for (int c = 1; c < KA; ++c) {
+                    const f32x4 b = bq[c];
+                    if (c < KT) {
+                        const f32x4 d = bt[c];
+                        mfma4_a(cj0, wJ[0][c * 4 + 0], b.x); mfma4_a(cj1, wJ[1][c * 4 + 0], b.x); mfma4_a(cj2, wJ[2][c * 4 + 0], b.x); mfma4_a(ct, wT[c * 4 + 0], d.x);
+                        mfma4_a(cj0, wJ[0][c * 4 + 1], b.y); mfma4_a(cj1, wJ[1][c * 4 + 1], b.y); mfma4_a(cj2, wJ[2][c * 4 + 1], b.y); mfma4_a(ct, wT[c * 4 + 1], d.y);
+                        mfma4_a(cj0, wJ[0][c * 4 + 2], b.z); mfma4_a(cj1, wJ[1][c * 4 + 2], b.z); mfma4_a(cj2, wJ[2][c * 4 + 2], b.z); mfma4_a(ct, wT[c * 4 + 2], d.z);
+                        mfma4_a(cj0, wJ[0][c * 4 + 3], b.w); mfma4_a(cj1, wJ[1][c * 4 + 3], b.w); mfma4_a(cj2, wJ[2][c * 4 + 3], b.w); mfma4_a(ct, wT[c * 4 + 3], d.w);
+                    } else {
+                        mfma4_a(cj0, wJ[0][c * 4 + 0], b.x); mfma4_a(cj1, wJ[1][c * 4 + 0], b.x); mfma4_a(cj2, wJ[2][c * 4 + 0], b.x);
+                        mfma4_a(cj0, wJ[0][c * 4 + 1], b.y); mfma4_a(cj1, wJ[1][c * 4 + 1], b.y); mfma4_a(cj2, wJ[2][c * 4 + 1], b.y);
+                        mfma4_a(cj0, wJ[0][c * 4 + 2], b.z); mfma4_a(cj1, wJ[1][c * 4 + 2], b.z); mfma4_a(cj2, wJ[2][c * 4 + 2], b.z);
+                        mfma4_a(cj0, wJ[0][c * 4 + 3], b.w); mfma4_a(cj1, wJ[1][c * 4 + 3], b.w); mfma4_a(cj2, wJ[2][c * 4 + 3], b.w);
+                    }
+                }
+                mfma4_results_ready(cj0, cj1, cj2, ct);
+                __builtin_amdgcn_sched_barrier(0);
+                h1w[0 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj0));
+                h1w[1 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj1));
+                h1w[2 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj2));
+                // tail: the row's two slices of a feature block sit 8 lanes apart
+                ct.x = ct.x + dpp_mov<DPP_ROW_ROR8>(ct.x); ct.y = ct.y + dpp_mov<DPP_ROW_ROR8>(ct.y);
+                ct.z = ct.z + dpp_mov<DPP_ROW_ROR8>(ct.z); ct.w = ct.w + dpp_mov<DPP_ROW_ROR8>(ct.w);
+                const float z = apply_act_ct<A1>(rows_reduce_scatter(ct));
+                if ((blk & 2) == 0) *h1t = z;
+            }
+        }
+        // ---- action part of the NEXT step's layer 0, in the shadow of the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4_v_c(acc0, wA0a[0], ba0.x, b0); mfma4_v_0(acc1, wA0a[1], ba0.y); mfma4_v_0(acc2, wA0a[2], ba0.z);
+        mfma4_v(acc0, wA0a[3], ba0.w);       mfma4_v(acc1, wA0a[4], ba1.x);   mfma4_v(acc2, wA0a[5], ba1.y);
+        mfma4_v(acc0, wA0a[6], ba1.z);       mfma4_v(acc1, wA0a[7], ba1.w);
+        Q4R_MARK(2);
+        __syncthreads();
+        Q4R_MARK(3);
+        // ---- last layer, whole K in every wave, K-split over the MFMA's blocks: set A in three chains, set B in two
+        float zA, zB;
+        {
+            f32x4 cA0, cA1, cA2, cB0, cB1;
+            f32x4 bqA[KA], bqB[KB];
+#pragma unroll
+            for (int c = 0; c < KB; ++c) bqB[c] = *reinterpret_cast<const f32x4*>(hB1 + c * 16 * 16);
+#pragma unroll
+            for (int c = 0; c < KA; ++c) bqA[c] = *reinterpret_cast<const f32x4*>(hA1 + c * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            Q4R_CYC0();
+            // rounds 0 .. KB-1 carry both sets: A0 B0 A1 B1 A2 B0 A0 B1 | A1 B0 A2 B1 A0 B0 A1 B1 | ...
+            mfma4_v_c(cA0, wA2a[0], bqA[0].x, biasA); mfma4_v_c(cB0, wA2b[0], bqB[0].x, biasB);
+            mfma4_v_0(cA1, wA2a[1], bqA[0].y);        mfma4_v_0(cB1, wA2b[1], bqB[0].y);
+            mfma4_v_0(cA2, wA2a[2], bqA[0].z);        mfma4_v(cB0, wA2b[2], bqB[0].z);
+            mfma4_v(cA0, wA2a[3], bqA[0].w);          mfma4_v(cB1, wA2b[3], bqB[0].w);
+#pragma unroll
+            for (int c = 1; c < KA; ++c) {
+                // chain of set A's MFMA i = 4c + e is i % 3 (compile-time after unrolling)
+                f32x4& a0_ = ((4 * c + 0) % 3 == 0) ? cA0 : ((4 * c + 0) % 3 == 1) ? cA1 : cA2;
+                f32x4& a1_ = ((4 * c + 1) % 3 == 0) ? cA0 : ((4 * c + 1) % 3 == 1) ? cA1 : cA2;
+                f32x4& a2_ = ((4 * c + 2) % 3 == 0) ? cA0 : ((4 * c + 2) % 3 == 1) ? cA1 : cA2;
+                f32x4& a3_ = ((4 * c + 3) % 3 == 0) ? cA0 : ((4 * c + 3) % 3 == 1) ? cA1 : cA2;
+                if (c < KB) {
+                    mfma4_v(a0_, wA2a[c * 4 + 0], bqA[c].x); mfma4_v(cB0, wA2b[c * 4 + 0], bqB[c].x);
+                    mfma4_v(a1_, wA2a[c * 4 + 1], bqA[c].y); mfma4_v(cB1, wA2b[c * 4 + 1], bqB[c].y);
+                    mfma4_v(a2_, wA2a[c * 4 + 2], bqA[c].z); mfma4_v(cB0, wA2b[c * 4 + 2], bqB[c].z);
+                    mfma4_v(a3_, wA2a[c * 4 + 3], bqA[c].w); mfma4_v(cB1, wA2b[c * 4 + 3], bqB[c].w);
+                } else {
+                    mfma4_v(a0_, wA2a[c * 4 + 0], bqA[c].x); mfma4_v(a1_, wA2a[c * 4 + 1], bqA[c].y);
+                    mfma4_v(a2_, wA2a[c * 4 + 2], bqA[c].z); mfma4_v(a3_, wA2a[c * 4 + 3], bqA[c].w);
+                }
+            }
+            mfma4_results_ready(cA0, cA1, cA2, cB0, cB1);
+            __builtin_amdgcn_sched_barrier(0);
+            Q4R_CYC(2);
+            Q4R_CYC0();
+            f32x4 sB = {cB0.x + cB1.x, cB0.y + cB1.y, cB0.z + cB1.z, cB0.w + cB1.w};
+            const f32x4 sA = {(cA0.x + cA1.x) + cA2.x, (cA0.y + cA1.y) + cA2.y, (cA0.z + cA1.z) + cA2.z, (cA0.w + cA1.w) + cA2.w};
+            // set B: the row's four blocks (8 first: every block then adds the same two pairs)
+            sB.x = sB.x + dpp_mov<DPP_ROW_ROR8>(sB.x); sB.y = sB.y + dpp_mov<DPP_ROW_ROR8>(sB.y);
+            sB.z = sB.z + dpp_mov<DPP_ROW_ROR8>(sB.z); sB.w = sB.w + dpp_mov<DPP_ROW_ROR8>(sB.w);
+            sB.x = sB.x + dpp_mov<DPP_ROW_ROR4>(sB.x); sB.y = sB.y + dpp_mov<DPP_ROW_ROR4>(sB.y);
+            sB.z = sB.z + dpp_mov<DPP_ROW_ROR4>(sB.z); sB.w = sB.w + dpp_mov<DPP_ROW_ROR4>(sB.w);
+            zA = rows_reduce_scatter(sA);                 // output feature 4*fgq + pr of particle pl
+            zB = rows_reduce_scatter(sB);                 // output feature 16 + pr
+        }
+        // ---- epilogue on the two features this lane finishes (process_output, then process_input of the next step)
+        {
+            zA = apply_act_ct<A2>(zA); zB = apply_act_ct<A2>(zB);
+            const float vA = (tmA + zA * tsA) + curA, vB = (tmB + zB * tsB) + curB;
+            if (rwd_flag_lane) rwd_f[t * 16] = (curA >= flag_thr) ? -10.0f : 0.0f;
+            if (rwd_prog_lane) rwd_d[t * 16] = vB - curB;
+            curA = vA; curB = vB;
+            if (q.traj) {                                  // state after step t, for a user reward function
+                const f32x4 rA = rows_all_gather(vA), rB = rows_all_gather(vB);
+                if (n0 + pl < p.n_pop) {
+                    float* dst = q.traj + ((((size_t)t * p.A + a) * p.Nst) + n0 + pl) * S;
+                    if (wave == 0 && row == 0) *reinterpret_cast<f32x4*>(dst + 4 * fgq) = rA;
+                    if (wave == 0 && row == 1 && fgq == 0) *reinterpret_cast<f32x4*>(dst + 16) = rB;
+                }
+            }
+            xA = rows_all_gather((vA - nmA) * niA);
+            xB = rows_all_gather((vB - nmB) * niB);
+        }
+        Q4R_CYC(3);
+        Q4R_MARK(4);
+    }
+#ifdef BBMPC_KERNEL_DBG
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        printf("[q4rdbg] H=%d | entry->actions %lld  operands+constants %lld  first mfma %lld | loop %lld (%lld shader cycles): layer0 %lld bar %lld layer1+act %lld bar %lld last+epi %lld (10ns units)\n",
+               H, dbg_acc[5], dbg_acc[6], dbg_acc[7], (long long)wall_clock64() - dbg_start, (long long)clock64() - dbg_cyc0, dbg_acc[0], dbg_acc[1], dbg_acc[2], dbg_acc[3], dbg_acc[4]);
+        printf("[q4rdbg] shader cycles per step: layer-1 MFMA block (156) %lld | layer-1 reduce+tanh+store %lld | last-layer MFMA block (68) %lld | reduce+epilogue+gather %lld\n",
+               dbg_cyc[0] / H, dbg_cyc[1] / H, dbg_cyc[2] / H, dbg_cyc[3] / H);
+    }
+#endif
+    // ---- rewards: cost_func.py:5-22 per step, summed in step order (deterministic.py:62-73)
+    __syncthreads();
+    if (tid < QP) {
+        float total = 0.0f;
+        if (rew_on)
+            for (int t = 0; t < H; ++t) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(rwd + (t * QP + tid) * 4);   // (d17, flag 5, flag 6, flag 7)
+                float r = 0.0f;
+                r = r + w.y; r = r + w.z; r = r + w.w;
+                r = r + w.x / 0.01f;
+                r = r - zs[t * QP + tid];
+                total = total + r;
+            }
+        const int n = n0 + tid;
+        if (n < p.n_pop) {
+            if (total != total) total = -1.0e6f;
+            if (q.pen) {
+                float pen = 0.0f;
+                for (int u = 0; u < U; ++u) pen = pen + pens[tid * U + u];
+                const float nr = sqrtf(pen);
+                pen = nr * nr;
+                total = total - pen;
+                if (p.penalty_out) p.penalty_out[(size_t)a * p.Nst + n] = pen;
+            }
+            p.rewards[(size_t)a * p.Nst + n] = total;
+        }
+    }
+}
+
+inline int mlp_q4r_lds_floats(int HG, int K0G, int H, int U) {
+    return 2 * 64 * 16 + ((H * 4 * U + 3) & ~3) + ((4 * U + 3) & ~3) + H * (K0G - 5) * 16 + H * 4 + H * 16 + 6 * 32 + 8;
+}
+
+}  // namespace bbmpc
