@@ -28,9 +28,8 @@ void stop_foreign_residents(Engine* self) {
         if (o == self || (self && o->device != self->device)) continue;
         uint32_t* m = o->mbox_pub.load(std::memory_order_acquire);
         if (!m) continue;
-        for (int a = 0; a < o->mbox_pub_agents; ++a) ((volatile uint32_t*)m)[a * 16 + 15] = 0xffffffffu;
+        for (int a = 0; a < o->mbox_pub_agents; ++a) ((volatile uint32_t*)m)[a * 16 + 15] = 0xffffffffu;   // the stop word
         std::atomic_thread_fence(std::memory_order_release);
-        for (int a = 0; a < o->mbox_pub_agents; ++a) ((volatile uint32_t*)m)[a * 16] = 0xffffffffu;
     }
 }
 
@@ -310,16 +309,22 @@ bool Engine::resident_step(const float* state, int add_noise, uint32_t seq) {
     const float* inj = d_noise_pf[pb].p + (size_t)((int64_t)step - c * pf_steps) * pf_step_floats;
     ++step_counter;
     const uint64_t ip = (uint64_t)(uintptr_t)inj;
-    for (int a = 0; a < A; ++a) {                                 // one request line per agent: sequence word 15, payload, sequence word 0
+    // One request line per agent.  Every payload word carries 16 bits of payload and the low 16 bits of the request's
+    // sequence number, word 15 the whole sequence number: the kernel accepts a line only when all fourteen words name
+    // the request it waits for, so nothing depends on the 64-byte line being read (or written) in one piece or in order.
+    for (int a = 0; a < A; ++a) {
         volatile uint32_t* m = mbox_host(a);
         uint32_t sw3[3];
         memcpy(sw3, state + (size_t)a * 3, 12);
+        const uint32_t tag = seq & 0xffffu;
+        const uint16_t half[13] = {(uint16_t)step, (uint16_t)(step >> 16), (uint16_t)(add_noise != 0),
+                                   (uint16_t)ip, (uint16_t)(ip >> 16), (uint16_t)(ip >> 32), (uint16_t)(ip >> 48),
+                                   (uint16_t)sw3[0], (uint16_t)(sw3[0] >> 16), (uint16_t)sw3[1], (uint16_t)(sw3[1] >> 16),
+                                   (uint16_t)sw3[2], (uint16_t)(sw3[2] >> 16)};
+        for (int i = 0; i < 13; ++i) m[i] = ((uint32_t)half[i] << 16) | tag;
         m[15] = seq;
-        m[1] = step; m[2] = (uint32_t)add_noise; m[3] = (uint32_t)ip; m[4] = (uint32_t)(ip >> 32);
-        m[5] = sw3[0]; m[6] = sw3[1]; m[7] = sw3[2];
     }
     std::atomic_thread_fence(std::memory_order_release);
-    for (int a = 0; a < A; ++a) mbox_host(a)[0] = seq;
     // host work that hides under the kernel: the next chunk's noise, the previous call's collective
     if (pf_chunk[nb] != c + 1) {
         // the other buffer held chunk c-1: every control step that read it has handed its record to this thread already
@@ -363,9 +368,8 @@ static void resident_unpublish(Engine* e) {
 void Engine::resident_stop() {
     if (!resident_alive) return;
     resident_unpublish(this);
-    for (int a = 0; a < A; ++a) mbox_host(a)[15] = 0xffffffffu;
+    for (int a = 0; a < A; ++a) mbox_host(a)[15] = 0xffffffffu;   // the stop word (word 15 alone decides)
     std::atomic_thread_fence(std::memory_order_release);
-    for (int a = 0; a < A; ++a) mbox_host(a)[0] = 0xffffffffu;
     resident_alive = false;
     HIP_CHECK(hipStreamSynchronize(stream));
 }
@@ -725,8 +729,9 @@ void Engine::set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, con
         upload(d_bpack[l], bp);
         upload(d_wraw[l], std::vector<float>(w[l], w[l] + (size_t)K * M));
         upload(d_braw[l], std::vector<float>(b[l], b[l] + M));
-        {   // quad-mode operand order [k/4][Mp][4]
-            const int Mp = (M + 63) & ~63, KG = (K + 3) / 4;
+        {   // quad-mode operand order [k/4][Mp][4]; the k/4 axis is zero padded to a multiple of 64 groups so that the
+            // kernels can load a fixed number of groups per lane without bounds (group 63 of a <= 252-input layer is a zero row)
+            const int Mp = (M + 63) & ~63, KG = ((K + 3) / 4 + 63) & ~63;
             std::vector<float> wq((size_t)KG * Mp * 4, 0.0f);
             for (int kk = 0; kk < K; ++kk)
                 for (int o = 0; o < M; ++o) wq[((size_t)(kk >> 2) * Mp + o) * 4 + (kk & 3)] = w[l][(size_t)kk * M + o];
@@ -873,8 +878,9 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
         if (q4 && !sw.mlp_generic && sw.mlp_q4r && S == 20 && U <= 8 && mlp.dims[3] == 20 &&
             (ra.reward_kind == REW_CHEETAH || ra.reward_kind == REW_NONE)) {
             const size_t qlds = (size_t)mlp_q4r_lds_floats(50, 7, ra.H, U) * sizeof(float);
-            if (qlds <= 160 * 1024) {
-                auto fn = k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE>;
+            if (qlds <= 160 * 1024 && ra.H * 4 * U <= Q4R_MAX_ACTION_ELEMS) {
+                auto fn = (ra.H * 4 * U <= 1024) ? k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 4>
+                                                 : k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 8>;
                 if (qlds > 64 * 1024) ensure_max_lds((const void*)fn, 160 * 1024);
                 dim3 qgrid((ra.n_pop + 3) / 4, A), qblock(256);
                 dominant_kernel = "k_rollout_mlp_q4r";
@@ -1294,7 +1300,8 @@ static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base
                 ensure_max_lds((const void*)fl, (int)limit);
                 for (int a = 0; a < e.A; ++a) {
                     volatile uint32_t* m = e.mbox_host(a);
-                    m[15] = fa.done_value; m[0] = fa.done_value;      // nothing pending (a stale stop word must not end it)
+                    for (int i = 0; i < 13; ++i) m[i] = fa.done_value & 0xffffu;   // no payload word may carry the next request's tag by accident
+                    m[15] = fa.done_value;                            // nothing pending (a stale stop word must not end it)
                     *(volatile uint32_t*)e.gone_host(a) = 0u;
                 }
                 std::atomic_thread_fence(std::memory_order_release);
@@ -2542,6 +2549,7 @@ static const float* optimize_host(bbmpc::Engine& e, const float* state, int32_t 
         } catch (...) {
             e.linger_launch = false;
             e.tail_flag = nullptr;
+            e.subset_n = 0;                                  // a subset named by resident_step must not outlive the call it was for
             throw;
         }
     } else {

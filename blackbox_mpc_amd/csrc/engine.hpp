@@ -170,9 +170,13 @@ struct Engine {
     bool linger_launch = false;        // bbmpc_optimize asks optimize_fused for the LINGER variant
     bool resident_alive = false;       // a LINGER kernel may still be polling the mailbox
     // pinned block host_done, 16-word lines: 0 completion word of the launch-per-call paths | 1..A per-agent completion
-    // words | A+1..2A request lines | 2A+1..3A exit words | 3A+1 agent map of a subset launch
+    // words | A+1..2A request lines | 2A+1..3A exit words | 3A+1.. agent map of a subset launch (one int32 per agent:
+    // ceil(A/16) lines -- every agent but one may be listed)
     static constexpr int kLingerMaxAgents = 64;
-    int sync_lines() const { return 2 + 3 * std::max(1, std::min(A, kLingerMaxAgents)); }
+    int sync_lines() const {
+        const int al = std::max(1, std::min(A, kLingerMaxAgents));
+        return 1 + 3 * al + (al + 15) / 16;
+    }
     uint32_t* ack_host(int a) { return host_done + 16 * (1 + a); }
     uint32_t* mbox_host(int a) { return host_done + 16 * (1 + std::min(A, kLingerMaxAgents) + a); }
     uint32_t* gone_host(int a) { return host_done + 16 * (1 + 2 * std::min(A, kLingerMaxAgents) + a); }

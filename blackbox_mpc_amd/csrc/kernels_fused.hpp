@@ -590,36 +590,42 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         if constexpr (!LINGER) {
             break;
         } else {
-            // ---- stay resident: wave 0 polls the request line over PCIe (one 64-byte read per poll; the host writes word 15,
-            // the payload, then word 0, so a line whose two sequence words agree is complete).  A request carrying the NEXT
-            // sequence number starts another pass without a launch (measured: 2.1 us host-to-host for a resident kernel's
-            // mailbox round trip against 6.8 us for launch + completion, tools/microbench/launch_latency.hip); anything else
-            // -- the stop word, or linger_ticks without a request -- ends the kernel, which says so in `gone` first and
-            // never looks at the line again, so the host knows whether to launch.
+            // ---- stay resident: wave 0 polls the request line over PCIe (one 64-byte read per poll).  Words 0..12 of a
+            // request carry 16 bits of payload each plus the low 16 bits of the request's sequence number, word 15 the
+            // whole number (Engine::resident_step): a line is accepted when ALL fourteen words name the request this
+            // workgroup waits for, so neither the order of the host's stores nor how the fabric splits the read matters.
+            // A request carrying the NEXT sequence number starts another pass without a launch (measured: 2.1 us
+            // host-to-host for a resident kernel's mailbox round trip against 6.8 us for launch + completion,
+            // tools/microbench/launch_latency.hip); the stop word in word 15, or linger_ticks without a request, ends the
+            // kernel, which says so in `gone` first and never looks at the line again, so the host knows whether to launch.
             unsigned* mb = (unsigned*)ekeys;                       // 16 words of LDS that are idle outside the top-k
             __syncthreads();
             if (tid < 64) {
                 const long long t0 = (long long)wall_clock64();
+                const unsigned want = done_value_s + 1u;
                 unsigned w = 0u;
                 bool quit = false;
                 for (;;) {
                     w = (tid < 16) ? __hip_atomic_load(p.mbox + a * 16 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
-                    const unsigned w0 = __builtin_amdgcn_readlane(w, 0), w15 = __builtin_amdgcn_readlane(w, 15);
-                    if (w0 == w15 && w0 == done_value_s + 1u) break;
-                    if ((w0 == w15 && w0 == 0xffffffffu) || (long long)wall_clock64() - t0 > (long long)p.linger_ticks || a == p.test_quit_agent) { quit = true; break; }
+                    const bool mine = tid < 13 ? (w & 0xffffu) == (want & 0xffffu) : (tid == 15 ? w == want : true);
+                    const unsigned w15 = __builtin_amdgcn_readlane(w, 15);
+                    if (__builtin_amdgcn_ballot_w64(mine) == ~0ull) break;
+                    if (w15 == 0xffffffffu || (long long)wall_clock64() - t0 > (long long)p.linger_ticks || a == p.test_quit_agent) { quit = true; break; }
                 }
-                if (tid < 16) mb[tid] = (quit && tid == 0) ? 0xffffffffu : w;
+                if (tid < 16) mb[tid] = (quit && tid == 15) ? 0xffffffffu : w;
             }
             __syncthreads();
-            if (mb[0] == 0xffffffffu) {
+            if (mb[15] == 0xffffffffu) {
                 if (tid == 0) __hip_atomic_store(p.gone + a * 16, done_value_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 return;
             }
-            done_value_s = mb[0];
-            key_s.step = mb[1];
-            add_noise_s = (int)mb[2];
-            inj_s = reinterpret_cast<const float*>(((unsigned long long)mb[4] << 32) | (unsigned long long)mb[3]);
-            const float st_next = __uint_as_float(mb[5 + min(tid, 2)]);
+            done_value_s = mb[15];
+            key_s.step = (mb[0] >> 16) | (mb[1] & 0xffff0000u);
+            add_noise_s = (int)(mb[2] >> 16);
+            inj_s = reinterpret_cast<const float*>(((unsigned long long)(mb[3] >> 16)) | ((unsigned long long)(mb[4] >> 16) << 16) |
+                                                   ((unsigned long long)(mb[5] >> 16) << 32) | ((unsigned long long)(mb[6] >> 16) << 48));
+            const int sw_ = 7 + 2 * min(tid, 2);
+            const float st_next = __uint_as_float((mb[sw_] >> 16) | (mb[sw_ + 1] & 0xffff0000u));
             __syncthreads();                                        // every thread has read the request before `red` / `ekeys` are reused
             if (tid < 3) red[60 + tid] = st_next;
         }

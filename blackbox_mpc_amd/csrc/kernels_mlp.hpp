@@ -190,10 +190,54 @@ __device__ __forceinline__ int tile_addr(int f, int p) {
 // (particle,u) in t order afterwards, from LDS.  Contains a barrier when q.pen is set (uniform).
 template <int TP>
 __device__ __forceinline__ void mlp_fill_actions(const MlpRolloutArgs& q, int a, int n0, int tid, int nthr,
-                                                 float* acts, float* pens) {
+                                                 float* acts, float* pens, float* dsq = nullptr) {
     const RolloutArgs& p = q.r;
     const int U = p.U, H = p.H;
     const int total = H * TP * U;                       // element e = (t*TP + pp)*U + u is also its index in acts
+    if (dsq) {
+        // dsq = H*TP*U floats of scratch: every thread clips its own elements and parks (x - clip(x))^2 there; the
+        // TP*U penalty threads then only SUM, in the same step order as the serial form below (same bits) -- that form
+        // is one dependent LDS read / write pair per step on TP*U threads (1.4 us at H = 30 in the quad kernels).
+        for (int e = tid; e < total; e += nthr) {
+            const int u = e % U, pp = (e / U) % TP, t = e / (U * TP);
+            const int n = n0 + pp;
+            const int j = t * U + u;
+            float x = 0.0f, d2 = 0.0f;
+            if (n < p.n_pop) {
+                if (q.mode == SRC_REF) x = p.seq[((size_t)n * p.A + a) * p.HU + j];
+                else if (q.mode == SRC_BUF) x = p.cand[((size_t)a * p.HU + j) * p.Nst + n];
+                else {
+                    float xi;
+                    if (p.inj) xi = p.inj[((size_t)a * p.HU + j) * p.Nst + n];
+                    else {
+                        const U4 blk = rng_block(p.key, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j);
+                        const uint32_t w = pick_word(blk, (uint32_t)j);
+                        xi = (q.mode == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
+                    }
+                    if (q.mode == SRC_UNIFORM) x = xi * (p.hi[u] - p.lo[u]) + p.lo[u];
+                    else x = xi * p.sigma[a * p.HU + j] + p.mean[a * p.HU + j];
+                }
+                if (q.pen) {
+                    const float xf = clipf(x, p.lo[u], p.hi[u]);
+                    const float d = x - xf;
+                    d2 = d * d;
+                    x = xf;
+                }
+                if (p.samples) p.samples[((size_t)a * p.HU + j) * p.Nst + n] = x;
+            }
+            acts[e] = x;
+            dsq[e] = d2;
+        }
+        __syncthreads();
+        for (int i = tid; i < TP * U; i += nthr) {
+            const int pp = i / U, u = i % U;
+            float pen_part = 0.0f;
+            if (q.pen && n0 + pp < p.n_pop)
+                for (int t = 0; t < H; ++t) pen_part = pen_part + dsq[(t * TP + pp) * U + u];
+            pens[i] = pen_part;
+        }
+        return;
+    }
     for (int e = tid; e < total; e += nthr) {
         const int u = e % U, pp = (e / U) % TP, t = e / (U * TP);
         const int n = n0 + pp;

@@ -27,13 +27,15 @@
 //    state groups from its row neighbours by DPP rotation -- block g multiplies group (g - j) mod 4 in round j, its
 //    stationary A operands are loaded in that order once -- so the next step's layer 0 starts from registers.
 // Barriers remain after h0 and after h1.  The action part of layer 0 (independent of the state) is issued one step
-// ahead, after the h1 store, where the wave would otherwise sit in the barrier.
+// ahead, behind the last layer's LDS reads, whose latency it fills.
 // Requires dim_S == 20 (5 state groups: four rotate inside a row, the fifth is replicated), the HalfCheetah reward or
 // none (a user function scores the recorded trajectory); everything else keeps k_rollout_mlp_q4.
 #pragma once
 #include "kernels_mlp.hpp"
 
 namespace bbmpc {
+
+constexpr int Q4R_MAX_ACTION_ELEMS = 2048;              // H * 4 * dim_U a workgroup's threads keep in registers across the operand loads
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
@@ -109,7 +111,7 @@ __device__ __forceinline__ void mfma4_results_ready(f32x4& c0, f32x4& c1, f32x4&
     asm volatile("s_nop 4" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4));
 }
 
-template <int HG, int K0G, int A0, int A1, int A2>
+template <int HG, int K0G, int A0, int A1, int A2, int NE>
 __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutArgs& p = q.r;
@@ -119,13 +121,14 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     constexpr int KA = (HG + 3) / 4;                     // k groups per 16-lane row when K is split over the rows
     constexpr int KB = (HG + 15) / 16;                   // last layer set B: k groups per 4-lane block
     constexpr int HP = 64;                               // h0 / h1 are padded to 64 groups (zero): clamp-free operand addresses
+    constexpr int ZROW = HP - 1;                         // a zero group of the packed operands (bbmpc_set_mlp pads the k/4 axis to 64)
     constexpr int NJ = HG / 16;                          // layer-1 jobs of 16 output features per wave (12 jobs = 192 features)
     constexpr int TF = HG * 4 - NJ * 64;                 // features left for the tail job (8)
     constexpr int KT = (HG + 7) / 8;                     // tail job: k groups per slice (8 slices)
     static_assert(HG < HP && KA * 4 <= HP && (KB - 1) * 16 + 15 < HP && K0G > SG, "padding / input groups");
     static_assert(NJ == 3 && TF == 8 && KT <= KA && KB <= KA && AG == 2, "written for 200 hidden units, 20 + <= 8 inputs");
     const int a = blockIdx.y, n0 = blockIdx.x * QP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches
     const int S = p.S, U = p.U, H = p.H;
     const bool normd = m.normalized != 0;
     const int row = lane >> 4, blk = lane >> 2, fgq = blk & 3, pl = lane & 3;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     float* lbias = tstd + 32;
     float* st0 = lbias + 32;
 #ifdef BBMPC_KERNEL_DBG
-    long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_t0 = (long long)wall_clock64();
+    long long dbg_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dbg_t0 = (long long)wall_clock64();
 #define Q4R_MARK(i) do { const long long now_ = (long long)wall_clock64(); dbg_acc[i] += now_ - dbg_t0; dbg_t0 = now_; } while (0)
     long long dbg_cyc[4] = {0, 0, 0, 0}, dbg_c0 = 0;
 #define Q4R_CYC0() do { dbg_c0 = (long long)clock64(); } while (0)
@@ -156,26 +159,62 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
 #define Q4R_CYC(i) do {} while (0)
 #endif
 
-    // ---- prologue, part 1 (small loads first: global loads return in order, nothing here may queue behind the
-    // ~300 KB of stationary operands): constants, start state, the 4 particles' action block
-    for (int i = tid; i < S + U; i += NT) {
-        const float mu = normd ? (i < S ? m.mean_s[i] : m.mean_a[i - S]) : 0.0f;
-        const float sd = normd ? (i < S ? m.std_s[i] : m.std_a[i - S]) : 1.0f;
-        nmean[i] = mu;
-        ninv[i] = normd ? 1.0f / (sd + 1e-7f) : 1.0f;
-        if (i < S) {
-            tmean[i] = normd ? m.mean_t[i] : 0.0f;         // un-normalised: 0 + z * 1 = z exactly
-            tstd[i] = normd ? (m.std_t[i] + 1e-7f) : 1.0f;
-            lbias[i] = q.braw[2][i];
-            st0[i] = p.state[a * S + i];
+    // ---- prologue.  Vector memory returns in order, so the SMALL loads (constants, start state, the sources of the 4
+    // particles' action block) are issued first, then the ~260 KB of stationary operands, and only then is anything
+    // consumed: the small results arrive first and are worked on while the operands stream in (the two waits used to
+    // add up, 3.2 + 4.1 us of a 70 us kernel).
+    // NE = action-block elements per thread (H * 4 * U <= 256 * NE)
+    const int a_total = H * QP * U;
+    const int ci = min(tid, S + U - 1), cs = min(tid, S - 1);
+    const float* cmu_base = !normd ? p.state : (ci < S ? m.mean_s : m.mean_a);
+    const float* csd_base = !normd ? p.state : (ci < S ? m.std_s : m.std_a);
+    const int cmi = !normd ? 0 : (ci < S ? ci : ci - S);
+    const float c_mu = cmu_base[cmi], c_sd = csd_base[cmi];
+    const float c_tm = (normd ? m.mean_t : p.state)[normd ? cs : 0], c_ts = (normd ? m.std_t : p.state)[normd ? cs : 0];
+    const float c_lb = q.braw[2][cs], c_st = p.state[a * S + cs];
+    // (branch-free: a load under a branch makes the compiler wait for everything in flight at the join, so elements that
+    // do not exist / sources a mode does not have read word 0 of the state instead)
+    const bool m_ref = q.mode == SRC_REF, m_buf = q.mode == SRC_BUF, m_uni = q.mode == SRC_UNIFORM;
+    const bool has_raw = m_ref || m_buf || p.inj != nullptr, has_dist = !m_ref && !m_buf && !m_uni, has_bounds = q.pen || m_uni;
+    const float* raw_base = m_ref ? p.seq : m_buf ? p.cand : (p.inj ? p.inj : p.state);
+    const float* sg_base = has_dist ? p.sigma : p.state;
+    const float* mn_base = has_dist ? p.mean : p.state;
+    const float* lo_base = has_bounds ? p.lo : p.state;
+    const float* hi_base = has_bounds ? p.hi : p.state;
+    const bool has_rng = !has_raw;                         // draws made here (rng.hpp counters), SRC_UNIFORM or truncated normal
+    float a_raw[NE], a_sg[NE], a_mn[NE], a_lo[NE], a_hi[NE], a_f[NE], a_tq[NE];
+    int a_j[NE], a_nu[NE];                               // j = t*U + u; (n << 8) | u, -1 = no such element / particle
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + i * NT;
+        const int u = e % U, pp = (e / U) % QP, t = e / (U * QP);
+        const int n = n0 + pp, j = t * U + u;
+        const bool valid = e < a_total && n < p.n_pop;
+        a_j[i] = j; a_nu[i] = valid ? ((n << 8) | u) : -1;
+        const int di = (valid && has_dist) ? a * p.HU + j : 0;
+        a_sg[i] = sg_base[di]; a_mn[i] = mn_base[di];
+        const int ui = (valid && has_bounds) ? u : 0;
+        a_lo[i] = lo_base[ui]; a_hi[i] = hi_base[ui];
+        // word_to_trunc_normal (rng.hpp) split in two: the table entry is loaded here, the interpolation happens with the
+        // other small results -- as one piece it would sit behind the operand loads.  One unconditional pair of loads
+        // per element whatever the mode (a load inside a branch costs a wait at the join).
+        uint32_t w = 0u;
+        if (has_rng) {
+            const U4 blk4 = rng_block(p.key, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j);
+            w = pick_word(blk4, (uint32_t)j);
         }
+        const uint32_t v = w >> 9;
+        const bool tn = has_rng && !m_uni;
+        a_f[i] = m_uni ? word_to_uniform(w)
+                       : ((float)(v & ((1u << (23 - TNQ_BITS)) - 1u)) + 0.5f) * (1.0f / (float)(1u << (23 - TNQ_BITS)));
+        const size_t ri = m_ref ? ((size_t)n * p.A + a) * p.HU + j : ((size_t)a * p.HU + j) * p.Nst + n;
+        const float* tqp = reinterpret_cast<const float*>(g_tnq) + 2 * (v >> (23 - TNQ_BITS));
+        const float* rp = tn ? tqp : raw_base + ((valid && has_raw) ? ri : (size_t)0);
+        const float* tp = tn ? tqp + 1 : p.state;
+        a_raw[i] = *rp; a_tq[i] = *tp;
     }
-    mlp_fill_actions<QP>(q, a, n0, tid, NT, acts, pens);
-    for (int i = tid; i < (HP - HG) * 16; i += NT) { h0[HG * 16 + i] = 0.0f; h1[HG * 16 + i] = 0.0f; }
-    __syncthreads();
-    Q4R_MARK(5);
-
-    // ---- stationary A operands (packed [k/4][Mp][4] by bbmpc_set_mlp)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- stationary A operands (packed [k/4][Mp][4] by bbmpc_set_mlp): ~260 KB per workgroup
     const int M1 = m.dims[1], M3 = m.dims[3];
     const int Mp1 = (M1 + 63) & ~63, Mp3 = (M3 + 63) & ~63;
     const float4* __restrict__ Q0 = reinterpret_cast<const float4*>(q.wq4[0]);
@@ -205,8 +244,8 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
         const int o = 16 * (wave + 4 * jj) + (lane & 15);
 #pragma unroll
         for (int c = 0; c < KA; ++c) {
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (c < cntA) v = Q1[(size_t)(startA + c) * Mp1 + o];
+            // (an exec-masked load would be followed by a wait for everything issued so far: invalid groups read the zero row instead)
+            const float4 v = Q1[(size_t)(c < cntA ? startA + c : ZROW) * Mp1 + o];
             wJ[jj][4 * c + 0] = v.x; wJ[jj][4 * c + 1] = v.y; wJ[jj][4 * c + 2] = v.z; wJ[jj][4 * c + 3] = v.w;
         }
     }
@@ -216,23 +255,20 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     const int cntT = HG / 8 + (sT < HG % 8 ? 1 : 0);
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (wave == 3 && c < cntT) v = Q1[(size_t)(startT + c) * Mp1 + 64 * NJ + 4 * (blk & 1) + (lane & 3)];
+        const float4 v = Q1[(size_t)((wave == 3 && c < cntT) ? startT + c : ZROW) * Mp1 + 64 * NJ + 4 * (blk & 1) + (lane & 3)];
         wT[4 * c + 0] = v.x; wT[4 * c + 1] = v.y; wT[4 * c + 2] = v.z; wT[4 * c + 3] = v.w;
     }
     // last layer, set A: output feature = lane & 15, k slice of my row
 #pragma unroll
     for (int c = 0; c < KA; ++c) {
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (c < cntA) v = Q2[(size_t)(startA + c) * Mp3 + (lane & 15)];
+        const float4 v = Q2[(size_t)(c < cntA ? startA + c : ZROW) * Mp3 + (lane & 15)];
         wA2a[4 * c + 0] = v.x; wA2a[4 * c + 1] = v.y; wA2a[4 * c + 2] = v.z; wA2a[4 * c + 3] = v.w;
     }
     // set B: block b takes k groups b, b + 16, ...; output feature = 16 + (lane & 3)
 #pragma unroll
     for (int c = 0; c < KB; ++c) {
         const int gg = blk + 16 * c;
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (gg < HG) v = Q2[(size_t)gg * Mp3 + 16 + (lane & 3)];
+        const float4 v = Q2[(size_t)(gg < HG ? gg : ZROW) * Mp3 + 16 + (lane & 3)];
         wA2b[4 * c + 0] = v.x; wA2b[4 * c + 1] = v.y; wA2b[4 * c + 2] = v.z; wA2b[4 * c + 3] = v.w;
     }
     // biases enter as the C operand of a chain's first MFMA: layer 0 for my 4 D rows (features 64*wave + 4*blk + r);
@@ -255,8 +291,61 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
         b1t.x = q.braw[1][fb + 0]; b1t.y = q.braw[1][fb + 1]; b1t.z = q.braw[1][fb + 2]; b1t.w = q.braw[1][fb + 3];
     }
     __builtin_amdgcn_sched_barrier(0);
+    Q4R_MARK(5);
 
-    // ---- prologue, part 2 (LDS only, while the operands land): normalised action groups, 0 * sum(a^2), constants
+    // ---- the small results: constants to LDS; the action block (mlp_fill_actions' arithmetic, every thread clipping its
+    // own elements; xa is scratch for the squared clip distances, summed per (particle, u) in step order below)
+    if (tid < S + U) {
+        nmean[tid] = normd ? c_mu : 0.0f;
+        ninv[tid] = normd ? 1.0f / (c_sd + 1e-7f) : 1.0f;
+        if (tid < S) {
+            tmean[tid] = normd ? c_tm : 0.0f;              // un-normalised: 0 + z * 1 = z exactly
+            tstd[tid] = normd ? (c_ts + 1e-7f) : 1.0f;
+            lbias[tid] = c_lb;
+            st0[tid] = c_st;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) asm volatile("" : "+v"(a_raw[i]), "+v"(a_tq[i]));   // the interpolation stays down here
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + i * NT;
+        if (e < a_total) {
+            float x = 0.0f, d2 = 0.0f;
+            if (a_nu[i] >= 0) {
+                const int n = a_nu[i] >> 8, j = a_j[i];
+                if (m_ref || m_buf) x = a_raw[i];
+                else {
+                    // word_to_trunc_normal's last line / the uniform draw / the injected draw
+                    const float xi = has_rng ? (m_uni ? a_f[i] : fmaf(a_f[i], a_tq[i], a_raw[i])) : a_raw[i];
+                    if (m_uni) x = xi * (a_hi[i] - a_lo[i]) + a_lo[i];
+                    else x = xi * a_sg[i] + a_mn[i];
+                }
+                if (q.pen) {
+                    const float xf = clipf(x, a_lo[i], a_hi[i]);
+                    const float d = x - xf;
+                    d2 = d * d;
+                    x = xf;
+                }
+                if (p.samples) p.samples[((size_t)a * p.HU + j) * p.Nst + n] = x;
+            }
+            acts[e] = x;
+            xa[e] = d2;
+        }
+    }
+    for (int i = tid; i < (HP - HG) * 16; i += NT) { h0[HG * 16 + i] = 0.0f; h1[HG * 16 + i] = 0.0f; }
+    __syncthreads();
+    if (tid < QP * U) {
+        const int pp = tid / U, u = tid % U;
+        float pen_part = 0.0f;
+        if (q.pen && n0 + pp < p.n_pop)
+            for (int t = 0; t < H; ++t) pen_part = pen_part + xa[(t * QP + pp) * U + u];
+        pens[tid] = pen_part;
+    }
+    __syncthreads();
+    Q4R_MARK(6);
+
+    // ---- prologue, part 2 (LDS only): normalised action groups, 0 * sum(a^2), constants
     for (int e = tid; e < H * AG * 16; e += NT) {
         const int c = e & 3, pp = (e >> 2) & 3, ga = (e >> 4) % AG, t = e / (16 * AG);
         const int u = ga * 4 + c;
@@ -284,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
         xB[c] = (st0[16 + c] - nmean[16 + c]) * ninv[16 + c];
     }
     __syncthreads();
-    Q4R_MARK(6);
+    Q4R_MARK(8);
 
     const int my_row = (wave * 16 + blk) * 16 + pl * 4;   // where my layer-0 D fragment goes in h0 (floats)
     const bool own_rows = (wave * 64 + 4 * blk) < HG * 4;
@@ -424,11 +513,6 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
                 if ((blk & 2) == 0) *h1t = z;
             }
         }
-        // ---- action part of the NEXT step's layer 0, in the shadow of the barrier
-        __builtin_amdgcn_sched_barrier(0);
-        mfma4_v_c(acc0, wA0a[0], ba0.x, b0); mfma4_v_0(acc1, wA0a[1], ba0.y); mfma4_v_0(acc2, wA0a[2], ba0.z);
-        mfma4_v(acc0, wA0a[3], ba0.w);       mfma4_v(acc1, wA0a[4], ba1.x);   mfma4_v(acc2, wA0a[5], ba1.y);
-        mfma4_v(acc0, wA0a[6], ba1.z);       mfma4_v(acc1, wA0a[7], ba1.w);
         Q4R_MARK(2);
         __syncthreads();
         Q4R_MARK(3);
@@ -441,6 +525,12 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
             for (int c = 0; c < KB; ++c) bqB[c] = *reinterpret_cast<const f32x4*>(hB1 + c * 16 * 16);
 #pragma unroll
             for (int c = 0; c < KA; ++c) bqA[c] = *reinterpret_cast<const f32x4*>(hA1 + c * 16);
+            // ---- action part of the NEXT step's layer 0 while those reads are in flight (in front of the barrier it
+            // sat on the critical path of wave 3, the wave the others wait for)
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4_v_c(acc0, wA0a[0], ba0.x, b0); mfma4_v_0(acc1, wA0a[1], ba0.y); mfma4_v_0(acc2, wA0a[2], ba0.z);
+            mfma4_v(acc0, wA0a[3], ba0.w);       mfma4_v(acc1, wA0a[4], ba1.x);   mfma4_v(acc2, wA0a[5], ba1.y);
+            mfma4_v(acc0, wA0a[6], ba1.z);       mfma4_v(acc1, wA0a[7], ba1.w);
             __builtin_amdgcn_sched_barrier(0);
             Q4R_CYC0();
             // rounds 0 .. KB-1 carry both sets: A0 B0 A1 B1 A2 B0 A0 B1 | A1 B0 A2 B1 A0 B0 A1 B1 | ...
@@ -502,8 +592,8 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     }
 #ifdef BBMPC_KERNEL_DBG
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-        printf("[q4rdbg] H=%d | entry->actions %lld  operands+constants %lld  first mfma %lld | loop %lld (%lld shader cycles): layer0 %lld bar %lld layer1+act %lld bar %lld last+epi %lld (10ns units)\n",
-               H, dbg_acc[5], dbg_acc[6], dbg_acc[7], (long long)wall_clock64() - dbg_start, (long long)clock64() - dbg_cyc0, dbg_acc[0], dbg_acc[1], dbg_acc[2], dbg_acc[3], dbg_acc[4]);
+        printf("[q4rdbg] H=%d | operand loads issued %lld  constants+actions %lld  LDS part 2 %lld  first mfma %lld | loop %lld (%lld shader cycles): layer0 %lld bar %lld layer1+act %lld bar %lld last+epi %lld (10ns units)\n",
+               H, dbg_acc[5], dbg_acc[6], dbg_acc[8], dbg_acc[7], (long long)wall_clock64() - dbg_start, (long long)clock64() - dbg_cyc0, dbg_acc[0], dbg_acc[1], dbg_acc[2], dbg_acc[3], dbg_acc[4]);
         printf("[q4rdbg] shader cycles per step: layer-1 MFMA block (156) %lld | layer-1 reduce+tanh+store %lld | last-layer MFMA block (68) %lld | reduce+epilogue+gather %lld\n",
                dbg_cyc[0] / H, dbg_cyc[1] / H, dbg_cyc[2] / H, dbg_cyc[3] / H);
     }
