@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     float* lbias = tstd + 32;
     float* st0 = lbias + 32;
 #ifdef BBMPC_KERNEL_DBG
-    long long dbg_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dbg_t0 = (long long)wall_clock64();
+    long long dbg_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dbg_t0 = (long long)wall_clock64();
 #define Q4R_MARK(i) do { const long long now_ = (long long)wall_clock64(); dbg_acc[i] += now_ - dbg_t0; dbg_t0 = now_; } while (0)
     long long dbg_cyc[4] = {0, 0, 0, 0}, dbg_c0 = 0;
 #define Q4R_CYC0() do { dbg_c0 = (long long)clock64(); } while (0)
@@ -214,27 +214,48 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
         a_raw[i] = *rp; a_tq[i] = *tp;
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- stationary A operands (packed [k/4][Mp][4] by bbmpc_set_mlp): ~260 KB per workgroup
+    // ---- roles.  Waves 0..2 are STATE waves: layer 0 for their 64 hidden features, three layer-1 jobs, the whole last
+    // layer, the state.  Wave 3 is the HELPER: layer-1 jobs 3, 7, 11 with the others and, after the second barrier,
+    // job 12 (hidden features 192..199) while the state waves are already in the last layer, which takes job 12's
+    // output last, behind a third barrier the helper reaches first.  The helper holds no state, so the eight layer-0
+    // features that used to be its share (192..199) are a K-split "mini job" inside every state wave's layer-0
+    // stream (zero weights except on wave MJ, which reduces and stores them).
+    const bool helper = wave == 3;
+    constexpr int MJ = 2;
+    const bool mini = wave == MJ;
+    // ---- stationary A operands (packed [k/4][Mp][4] by bbmpc_set_mlp): ~250 KB per workgroup.  Operands a role does
+    // not use are read from a zero row (one cached 1 KB line) instead of being branched around: a load under a branch
+    // is followed by a wait for everything issued so far.
     const int M1 = m.dims[1], M3 = m.dims[3];
     const int Mp1 = (M1 + 63) & ~63, Mp3 = (M3 + 63) & ~63;
     const float4* __restrict__ Q0 = reinterpret_cast<const float4*>(q.wq4[0]);
     const float4* __restrict__ Q1 = reinterpret_cast<const float4*>(q.wq4[1]);
     const float4* __restrict__ Q2 = reinterpret_cast<const float4*>(q.wq4[2]);
     const int f = wave * 64 + lane;                      // hidden feature of this lane's layer-0 A operands
-    float wA0r[16], wA0b[4], wA0a[AG * 4], wJ[NJ][KA * 4], wT[KT * 4], wA2a[KA * 4], wA2b[KB * 4];
+    float wA0r[16], wA0b[4], wA0a[AG * 4], wM[4], wMa[4], wJ[NJ][KA * 4], wU[KA * 4], wA2b[KB * 4];
 #pragma unroll
     for (int g = 0; g < AG; ++g) {
-        const float4 v = Q0[(size_t)(SG + g) * Mp1 + f];
+        const float4 v = Q0[(size_t)(helper ? ZROW : SG + g) * Mp1 + f];
         wA0a[4 * g + 0] = v.x; wA0a[4 * g + 1] = v.y; wA0a[4 * g + 2] = v.z; wA0a[4 * g + 3] = v.w;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                        // round j of layer 0: my block multiplies state group (fgq - j) & 3
-        const float4 v = Q0[(size_t)((fgq - j) & 3) * Mp1 + f];
+        const float4 v = Q0[(size_t)(helper ? ZROW : ((fgq - j) & 3)) * Mp1 + f];
         wA0r[4 * j + 0] = v.x; wA0r[4 * j + 1] = v.y; wA0r[4 * j + 2] = v.z; wA0r[4 * j + 3] = v.w;
     }
     {
-        const float4 v = Q0[(size_t)4 * Mp1 + f];
+        const float4 v = Q0[(size_t)(helper ? ZROW : 4) * Mp1 + f];
         wA0b[0] = v.x; wA0b[1] = v.y; wA0b[2] = v.z; wA0b[3] = v.w;
+    }
+    {   // mini job: block (row, quad g) works on hidden quad 48 + (row >> 1); even rows multiply state group g (the lane's own
+        // x), odd rows state group 4 (g == 0) and, one step ahead, action groups 5 / 6 (g == 1 / 2)
+        const int om = 64 * NJ + 4 * (row >> 1) + (lane & 3);
+        const int gs = (row & 1) ? (fgq == 0 ? 4 : ZROW) : fgq;
+        const int ga = ((row & 1) && (fgq == 1 || fgq == 2)) ? SG - 1 + fgq : ZROW;
+        const float4 v = Q0[(size_t)(mini ? gs : ZROW) * Mp1 + om];
+        const float4 u = Q0[(size_t)(mini ? ga : ZROW) * Mp1 + om];
+        wM[0] = v.x; wM[1] = v.y; wM[2] = v.z; wM[3] = v.w;
+        wMa[0] = u.x; wMa[1] = u.y; wMa[2] = u.z; wMa[3] = u.w;
     }
     // K split over the rows (layer-1 jobs, last-layer set A): row r takes k groups [KA*r, KA*r + cnt)
     const int startA = KA * row;
@@ -244,52 +265,42 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
         const int o = 16 * (wave + 4 * jj) + (lane & 15);
 #pragma unroll
         for (int c = 0; c < KA; ++c) {
-            // (an exec-masked load would be followed by a wait for everything issued so far: invalid groups read the zero row instead)
             const float4 v = Q1[(size_t)(c < cntA ? startA + c : ZROW) * Mp1 + o];
             wJ[jj][4 * c + 0] = v.x; wJ[jj][4 * c + 1] = v.y; wJ[jj][4 * c + 2] = v.z; wJ[jj][4 * c + 3] = v.w;
         }
     }
-    // tail job (wave 3): block b = feature block b & 1 (features 64*NJ + 4*(b&1) + (lane&3)), k slice b >> 1 of 8
-    const int sT = blk >> 1;
-    const int startT = (HG / 8) * sT + min(sT, HG % 8);
-    const int cntT = HG / 8 + (sT < HG % 8 ? 1 : 0);
+    // wU: the helper's job 12 (output features 192 + (lane & 15); the packed rows past the 200th are zero) or, on a state
+    // wave, the last layer's set A (output feature = lane & 15, k slice of my row)
+    {
+        const float4* __restrict__ QU = helper ? Q1 : Q2;
+        const size_t MpU = helper ? Mp1 : Mp3;
+        const int oU = (helper ? 16 * 4 * NJ : 0) + (lane & 15);
 #pragma unroll
-    for (int c = 0; c < KT; ++c) {
-        const float4 v = Q1[(size_t)((wave == 3 && c < cntT) ? startT + c : ZROW) * Mp1 + 64 * NJ + 4 * (blk & 1) + (lane & 3)];
-        wT[4 * c + 0] = v.x; wT[4 * c + 1] = v.y; wT[4 * c + 2] = v.z; wT[4 * c + 3] = v.w;
-    }
-    // last layer, set A: output feature = lane & 15, k slice of my row
-#pragma unroll
-    for (int c = 0; c < KA; ++c) {
-        const float4 v = Q2[(size_t)(c < cntA ? startA + c : ZROW) * Mp3 + (lane & 15)];
-        wA2a[4 * c + 0] = v.x; wA2a[4 * c + 1] = v.y; wA2a[4 * c + 2] = v.z; wA2a[4 * c + 3] = v.w;
+        for (int c = 0; c < KA; ++c) {
+            const float4 v = QU[(size_t)(c < cntA ? startA + c : ZROW) * MpU + oU];
+            wU[4 * c + 0] = v.x; wU[4 * c + 1] = v.y; wU[4 * c + 2] = v.z; wU[4 * c + 3] = v.w;
+        }
     }
     // set B: block b takes k groups b, b + 16, ...; output feature = 16 + (lane & 3)
 #pragma unroll
     for (int c = 0; c < KB; ++c) {
         const int gg = blk + 16 * c;
-        const float4 v = Q2[(size_t)(gg < HG ? gg : ZROW) * Mp3 + 16 + (lane & 3)];
+        const float4 v = Q2[(size_t)((gg < HG && !helper) ? gg : ZROW) * Mp3 + 16 + (lane & 3)];
         wA2b[4 * c + 0] = v.x; wA2b[4 * c + 1] = v.y; wA2b[4 * c + 2] = v.z; wA2b[4 * c + 3] = v.w;
     }
-    // biases enter as the C operand of a chain's first MFMA: layer 0 for my 4 D rows (features 64*wave + 4*blk + r);
-    // the K-split layers through ONE k slice (row 0; tail job: slice 0; last layer: row 0 for set A, block 0 for set B)
+    // biases: layer 0 enters as the C operand of a chain's first MFMA (my 4 D rows: features 64*wave + 4*blk + r); the
+    // K-split products get theirs after the reduction, where a lane holds ONE feature -- one register per product instead
+    // of a four-register C operand that is zero in 15 of 16 blocks (the kernel is short of registers, not of VALU slots)
     f32x4 b0;
     {
-        const int fb = wave * 64 + 4 * blk;
-        b0.x = fb + 0 < M1 ? q.braw[0][fb + 0] : 0.0f; b0.y = fb + 1 < M1 ? q.braw[0][fb + 1] : 0.0f;
-        b0.z = fb + 2 < M1 ? q.braw[0][fb + 2] : 0.0f; b0.w = fb + 3 < M1 ? q.braw[0][fb + 3] : 0.0f;
+        const int fb = helper ? 0 : wave * 64 + 4 * blk;      // < 192 on a state wave
+        b0.x = q.braw[0][fb + 0]; b0.y = q.braw[0][fb + 1]; b0.z = q.braw[0][fb + 2]; b0.w = q.braw[0][fb + 3];
     }
-    f32x4 b1j[NJ], b1t = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float bMs = q.braw[0][64 * NJ + 4 * (row >> 1) + 2 * (fgq >> 1) + (row & 1)];     // mini job: the feature this lane finishes
+    float b1s[NJ];
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        const int fb = 16 * (wave + 4 * jj) + 4 * fgq;
-        b1j[jj] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (row == 0) { b1j[jj].x = q.braw[1][fb + 0]; b1j[jj].y = q.braw[1][fb + 1]; b1j[jj].z = q.braw[1][fb + 2]; b1j[jj].w = q.braw[1][fb + 3]; }
-    }
-    if (wave == 3 && sT == 0) {
-        const int fb = 64 * NJ + 4 * (blk & 1);
-        b1t.x = q.braw[1][fb + 0]; b1t.y = q.braw[1][fb + 1]; b1t.z = q.braw[1][fb + 2]; b1t.w = q.braw[1][fb + 3];
-    }
+    for (int jj = 0; jj < NJ; ++jj) b1s[jj] = q.braw[1][16 * (wave + 4 * jj) + 4 * fgq + pr];
+    const float b1xs = q.braw[1][min(16 * 4 * NJ + 4 * fgq + pr, M1 - 1)];                    // job 12: features 192 + 4*fgq + pr (< 200 for fgq < 2)
     __builtin_amdgcn_sched_barrier(0);
     Q4R_MARK(5);
 
@@ -361,9 +372,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     const int fA = 4 * fgq + pr, fB = 16 + pr;
     const float tmA = tmean[fA], tsA = tstd[fA], tmB = tmean[fB], tsB = tstd[fB];
     const float nmA = nmean[fA], niA = ninv[fA], nmB = nmean[fB], niB = ninv[fB];
-    f32x4 biasA = {0.0f, 0.0f, 0.0f, 0.0f}, biasB = biasA;
-    if (row == 0) { biasA.x = lbias[4 * fgq + 0]; biasA.y = lbias[4 * fgq + 1]; biasA.z = lbias[4 * fgq + 2]; biasA.w = lbias[4 * fgq + 3]; }
-    if (blk == 0) { biasB.x = lbias[16]; biasB.y = lbias[17]; biasB.z = lbias[18]; biasB.w = lbias[19]; }
+    const float lbA = lbias[fA], lbB = lbias[fB];
     // start state: the scattered copies (residual) and the normalised input groups "own quad" and 4
     float curA = st0[fA], curB = st0[fB];
     f32x4 xA, xB;
@@ -375,8 +384,9 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     __syncthreads();
     Q4R_MARK(8);
 
-    const int my_row = (wave * 16 + blk) * 16 + pl * 4;   // where my layer-0 D fragment goes in h0 (floats)
-    const bool own_rows = (wave * 64 + 4 * blk) < HG * 4;
+    const int my_row = (wave * 16 + blk) * 16 + pl * 4;   // where my layer-0 D fragment goes in h0 (floats; state waves)
+    // mini job: lane (row, g, pl) ends up with feature 192 + 4*(row >> 1) + 2*(g >> 1) + (row & 1) of particle pl
+    float* h0m = h0 + ((size_t)(16 * NJ + (row >> 1)) * 4 + pl) * 4 + 2 * (fgq >> 1) + (row & 1);
     const bool rew_on = p.reward_kind == REW_CHEETAH;
     const float flag_thr = (pr == 1) ? 0.2f : 0.0f;       // cur[5] >= 0.2, cur[6] >= 0, cur[7] >= 0   cost_func.py:9-17
     // reward terms are parked per step and summed in step order after the loop (one IEEE division per (step, particle)
@@ -388,173 +398,256 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     float* rwd_d = rwd + pl * 4;
     // where my layer-1 results go: job feature 16*job + 4*fgq + pr -> h1[group 4*job + fgq][pl][pr]
     float* h1w = h1 + ((size_t)(4 * wave + fgq) * 4 + pl) * 4 + pr;          // + jj * 16 groups
-    float* h1t = h1 + ((size_t)(16 * NJ + (blk & 1)) * 4 + pl) * 4 + pr;
+    float* h1x = h1 + ((size_t)(16 * NJ + fgq) * 4 + pl) * 4 + pr;           // job 12 (groups 50, 51 receive tanh(0) = 0)
     const float* hA0 = h0 + ((size_t)startA * 4 + pl) * 4;
-    const float* hT0 = h0 + ((size_t)startT * 4 + pl) * 4;
     const float* hA1 = h1 + ((size_t)startA * 4 + pl) * 4;
     const float* hB1 = h1 + ((size_t)blk * 4 + pl) * 4;
-    // layer-0 accumulators (three chains), started with the bias and the action part of step 0
-    f32x4 acc0, acc1, acc2;
-    {
-        f32x4 ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)0 * 4 + pl) * 4);
-        f32x4 ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)1 * 4 + pl) * 4);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma4_operands_settled();
-        mfma4_v_c(acc0, wA0a[0], ba0.x, b0); mfma4_v_0(acc1, wA0a[1], ba0.y); mfma4_v_0(acc2, wA0a[2], ba0.z);
-        mfma4_v(acc0, wA0a[3], ba0.w);       mfma4_v(acc1, wA0a[4], ba1.x);   mfma4_v(acc2, wA0a[5], ba1.y);
-        mfma4_v(acc0, wA0a[6], ba1.z);       mfma4_v(acc1, wA0a[7], ba1.w);
+    // rounds of the last layer that read job 12's output (h1 groups 48, 49): set A rounds LA0 .. LA0+1 (row 3), set B round KB-1
+    constexpr int LA0 = 16 * NJ - KA * 3;                 // 48 - 39 = 9
+    static_assert(LA0 + 2 <= KA - 2 && 16 * (KB - 1) == 16 * NJ, "late rounds of the last layer");
+    // layer-0 accumulators (three chains + the mini job's), started with the bias and the action part of step 0
+    f32x4 acc0, acc1, acc2, accM;
+    // the action part: 8 MFMAs in the chains 0 1 2 0 1 2 0 1 with the mini job's four spread between them
+#define Q4R_ACTION_PART(ba0_, ba1_) do {                                                                            \
+        const f32x4 bm_ = (fgq == 1) ? ba0_ : ba1_;                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        mfma4_operands_settled();                                                                                     \
+        mfma4_v_0(accM, wMa[0], bm_.x);                                                                               \
+        mfma4_v_c(acc0, wA0a[0], ba0_.x, b0); mfma4_v_0(acc1, wA0a[1], ba0_.y); mfma4_v_0(acc2, wA0a[2], ba0_.z);     \
+        mfma4_v(accM, wMa[1], bm_.y);                                                                                 \
+        mfma4_v(acc0, wA0a[3], ba0_.w);       mfma4_v(acc1, wA0a[4], ba1_.x);   mfma4_v(acc2, wA0a[5], ba1_.y);       \
+        mfma4_v(accM, wMa[2], bm_.z);                                                                                 \
+        mfma4_v(acc0, wA0a[6], ba1_.z);       mfma4_v(acc1, wA0a[7], ba1_.w);                                         \
+        mfma4_v(accM, wMa[3], bm_.w);                                                                                 \
+    } while (0)
+    if (!helper) {
+        const f32x4 ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)0 * 4 + pl) * 4);
+        const f32x4 ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)1 * 4 + pl) * 4);
+        Q4R_ACTION_PART(ba0, ba1);
     }
 #ifdef BBMPC_KERNEL_DBG
     Q4R_MARK(7);
     const long long dbg_start = dbg_t0, dbg_cyc0 = (long long)clock64();
 #endif
-    for (int t = 0; t < H; ++t) {
-        // ---- layer 0, state part: groups 0..3 rotate through the row, group 4 is replicated
+    // Two loops, one per role, with the same three barriers per model step: as ONE loop with role branches every value a
+    // role defines (the state, the layer-0 accumulators, ...) is live through the other role's path as far as the
+    // register allocator can tell, which cost ~40 VGPR <-> AccVGPR copies per step.
+    if (helper) {
+        for (int t = 0; t < H; ++t) {
+            __syncthreads();                               // h0 of step t is complete
+        f32x4 bq[KA];
         {
-            f32x4 r1, r2, r3;
+            f32x4 cj0, cj1, cj2;
+#pragma unroll
+            for (int c = 0; c < KA; ++c) bq[c] = *reinterpret_cast<const f32x4*>(hA0 + c * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4_a_0(cj0, wJ[0][0], bq[0].x); mfma4_a_0(cj1, wJ[1][0], bq[0].x); mfma4_a_0(cj2, wJ[2][0], bq[0].x);
+            mfma4_a(cj0, wJ[0][1], bq[0].y); mfma4_a(cj1, wJ[1][1], bq[0].y); mfma4_a(cj2, wJ[2][1], bq[0].y);
+            mfma4_a(cj0, wJ[0][2], bq[0].z); mfma4_a(cj1, wJ[1][2], bq[0].z); mfma4_a(cj2, wJ[2][2], bq[0].z);
+            mfma4_a(cj0, wJ[0][3], bq[0].w); mfma4_a(cj1, wJ[1][3], bq[0].w); mfma4_a(cj2, wJ[2][3], bq[0].w);
+#pragma unroll
+            for (int c = 1; c < KA; ++c) {
+                const f32x4 b = bq[c];
+                mfma4_a(cj0, wJ[0][c * 4 + 0], b.x); mfma4_a(cj1, wJ[1][c * 4 + 0], b.x); mfma4_a(cj2, wJ[2][c * 4 + 0], b.x);
+                mfma4_a(cj0, wJ[0][c * 4 + 1], b.y); mfma4_a(cj1, wJ[1][c * 4 + 1], b.y); mfma4_a(cj2, wJ[2][c * 4 + 1], b.y);
+                mfma4_a(cj0, wJ[0][c * 4 + 2], b.z); mfma4_a(cj1, wJ[1][c * 4 + 2], b.z); mfma4_a(cj2, wJ[2][c * 4 + 2], b.z);
+                mfma4_a(cj0, wJ[0][c * 4 + 3], b.w); mfma4_a(cj1, wJ[1][c * 4 + 3], b.w); mfma4_a(cj2, wJ[2][c * 4 + 3], b.w);
+            }
+            mfma4_results_ready(cj0, cj1, cj2);
+            __builtin_amdgcn_sched_barrier(0);
+            h1w[0 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj0) + b1s[0]);
+            h1w[1 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj1) + b1s[1]);
+            h1w[2 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj2) + b1s[2]);
+        }
+            __syncthreads();                               // every wave's jobs are in h1
+            // ---- job 12 (hidden features 192..199) from the same B operands, three chains over its 52 MFMAs, while the
+            // state waves run the part of the last layer that does not need it
+            f32x4 cx0, cx1, cx2;
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4_a_0(cx0, wU[0], bq[0].x); mfma4_a_0(cx1, wU[1], bq[0].y); mfma4_a_0(cx2, wU[2], bq[0].z);
+            mfma4_a(cx0, wU[3], bq[0].w);
+#pragma unroll
+            for (int c = 1; c < KA; ++c) {
+                // MFMA i = 4c + e goes to chain (i + ...) % 3: consecutive MFMAs rotate through the three chains
+                f32x4& x0_ = ((4 * c + 0) % 3 == 0) ? cx0 : ((4 * c + 0) % 3 == 1) ? cx1 : cx2;
+                f32x4& x1_ = ((4 * c + 1) % 3 == 0) ? cx0 : ((4 * c + 1) % 3 == 1) ? cx1 : cx2;
+                f32x4& x2_ = ((4 * c + 2) % 3 == 0) ? cx0 : ((4 * c + 2) % 3 == 1) ? cx1 : cx2;
+                f32x4& x3_ = ((4 * c + 3) % 3 == 0) ? cx0 : ((4 * c + 3) % 3 == 1) ? cx1 : cx2;
+                mfma4_a(x0_, wU[c * 4 + 0], bq[c].x); mfma4_a(x1_, wU[c * 4 + 1], bq[c].y);
+                mfma4_a(x2_, wU[c * 4 + 2], bq[c].z); mfma4_a(x3_, wU[c * 4 + 3], bq[c].w);
+            }
+            mfma4_results_ready(cx0, cx1, cx2);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 sx = {(cx0.x + cx1.x) + cx2.x, (cx0.y + cx1.y) + cx2.y, (cx0.z + cx1.z) + cx2.z, (cx0.w + cx1.w) + cx2.w};
+            *h1x = apply_act_ct<A1>(rows_reduce_scatter(sx) + (fgq < 2 ? b1xs : 0.0f));
+            __syncthreads();                               // job 12's output is in h1
+        }
+    } else {
+    float zA = 0.0f, zB = 0.0f;
+    for (int t = 0; t < H; ++t) {
+        // ---- layer 0, state part: groups 0..3 rotate through the row, group 4 is replicated; the mini job rides along
+        {
+            f32x4 r1, r2, r3, bm;
             r1.x = dpp_mov<DPP_ROW_ROR4>(xA.x); r1.y = dpp_mov<DPP_ROW_ROR4>(xA.y);
             r1.z = dpp_mov<DPP_ROW_ROR4>(xA.z); r1.w = dpp_mov<DPP_ROW_ROR4>(xA.w);
             r2.x = dpp_mov<DPP_ROW_ROR8>(xA.x); r2.y = dpp_mov<DPP_ROW_ROR8>(xA.y);
             r2.z = dpp_mov<DPP_ROW_ROR8>(xA.z); r2.w = dpp_mov<DPP_ROW_ROR8>(xA.w);
             r3.x = dpp_mov<DPP_ROW_ROR12>(xA.x); r3.y = dpp_mov<DPP_ROW_ROR12>(xA.y);
             r3.z = dpp_mov<DPP_ROW_ROR12>(xA.z); r3.w = dpp_mov<DPP_ROW_ROR12>(xA.w);
+            bm.x = (row & 1) ? xB.x : xA.x; bm.y = (row & 1) ? xB.y : xA.y;
+            bm.z = (row & 1) ? xB.z : xA.z; bm.w = (row & 1) ? xB.w : xA.w;
             __builtin_amdgcn_sched_barrier(0);
             mfma4_operands_settled();
-            // (the action part left the chains at acc2: 8 MFMAs = 0 1 2 0 1 2 0 1)
+            // (the action part left the main chains at acc2)
             mfma4_v(acc2, wA0r[0], xA.x);  mfma4_v(acc0, wA0r[1], xA.y);  mfma4_v(acc1, wA0r[2], xA.z);
+            mfma4_v(accM, wM[0], bm.x);
             mfma4_v(acc2, wA0r[3], xA.w);  mfma4_v(acc0, wA0r[4], r1.x);  mfma4_v(acc1, wA0r[5], r1.y);
+            mfma4_v(accM, wM[1], bm.y);
             mfma4_v(acc2, wA0r[6], r1.z);  mfma4_v(acc0, wA0r[7], r1.w);  mfma4_v(acc1, wA0r[8], r2.x);
+            mfma4_v(accM, wM[2], bm.z);
             mfma4_v(acc2, wA0r[9], r2.y);  mfma4_v(acc0, wA0r[10], r2.z); mfma4_v(acc1, wA0r[11], r2.w);
+            mfma4_v(accM, wM[3], bm.w);
             mfma4_v(acc2, wA0r[12], r3.x); mfma4_v(acc0, wA0r[13], r3.y); mfma4_v(acc1, wA0r[14], r3.z);
             mfma4_v(acc2, wA0r[15], r3.w); mfma4_v(acc0, wA0b[0], xB.x);  mfma4_v(acc1, wA0b[1], xB.y);
             mfma4_v(acc2, wA0b[2], xB.z);  mfma4_v(acc0, wA0b[3], xB.w);
-            mfma4_results_ready(acc0, acc1, acc2);
+            mfma4_results_ready(acc0, acc1, acc2, accM);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 o;
             o.x = apply_act_ct<A0>((acc0.x + acc1.x) + acc2.x); o.y = apply_act_ct<A0>((acc0.y + acc1.y) + acc2.y);
             o.z = apply_act_ct<A0>((acc0.z + acc1.z) + acc2.z); o.w = apply_act_ct<A0>((acc0.w + acc1.w) + acc2.w);
-            if (own_rows) *reinterpret_cast<f32x4*>(h0 + my_row) = o;
+            *reinterpret_cast<f32x4*>(h0 + my_row) = o;
+            if (mini) {
+                // the 8 blocks of a quad (two rows) hold its partial sums: fold the rows (two registers per swap), then the
+                // row's four blocks as a reduce-scatter -- one value, one activation per lane (valid in the odd blocks)
+                float mx = accM.x, my = accM.y, mz = accM.z, mw = accM.w;
+                swap16(mx, my);                              // mx + my = [x.r0 + x.r1, y.r0 + y.r1, x.r2 + x.r3, y.r2 + y.r3]
+                swap16(mz, mw);
+                const float s1 = mx + my, s2 = mz + mw;
+                const float u1 = s1 + dpp_mov<DPP_ROW_ROR8>(s1), u2 = s2 + dpp_mov<DPP_ROW_ROR8>(s2);
+                const float tt = (fgq < 2) ? u1 : u2;
+                // the other block of my pair sits one block down for the odd blocks, which therefore finish the sum and
+                // store (a lane-dependent choice between two DPP sources would put the DPP under a partial exec mask)
+                const float hv = apply_act_ct<A0>((tt + dpp_mov<DPP_ROW_ROR4>(tt)) + bMs);
+                if (fgq & 1) *h0m = hv;
+            }
         }
         Q4R_MARK(0);
         __syncthreads();
         Q4R_MARK(1);
-        // ---- layer 1: three 16-feature jobs per wave, K split over the rows, one shared set of B operands;
-        // stationary A operands in AccVGPRs, read by the MFMA directly.  Wave 3 carries the 8-feature tail job as a
-        // fourth chain through its first KT rounds.
-        f32x4 ba0, ba1;
+        // ---- layer 1: three 16-feature jobs per wave (156 MFMAs on every wave), K split over the rows, one shared set of
+        // B operands; stationary A operands in AccVGPRs, read by the MFMA directly
         {
-            f32x4 cj0, cj1, cj2, ct;
             f32x4 bq[KA];
+            f32x4 cj0, cj1, cj2;
 #pragma unroll
             for (int c = 0; c < KA; ++c) bq[c] = *reinterpret_cast<const f32x4*>(hA0 + c * 16);
-            {   // next step's normalised action groups (consumed after the h1 store)
-                const int tn = (t + 1 < H) ? t + 1 : t;
-                ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 0) * 4 + pl) * 4);
-                ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 1) * 4 + pl) * 4);
+            __builtin_amdgcn_sched_barrier(0);
+            Q4R_CYC0();
+            mfma4_a_0(cj0, wJ[0][0], bq[0].x); mfma4_a_0(cj1, wJ[1][0], bq[0].x); mfma4_a_0(cj2, wJ[2][0], bq[0].x);
+            mfma4_a(cj0, wJ[0][1], bq[0].y); mfma4_a(cj1, wJ[1][1], bq[0].y); mfma4_a(cj2, wJ[2][1], bq[0].y);
+            mfma4_a(cj0, wJ[0][2], bq[0].z); mfma4_a(cj1, wJ[1][2], bq[0].z); mfma4_a(cj2, wJ[2][2], bq[0].z);
+            mfma4_a(cj0, wJ[0][3], bq[0].w); mfma4_a(cj1, wJ[1][3], bq[0].w); mfma4_a(cj2, wJ[2][3], bq[0].w);
+#pragma unroll
+            for (int c = 1; c < KA; ++c) {
+                const f32x4 b = bq[c];
+                mfma4_a(cj0, wJ[0][c * 4 + 0], b.x); mfma4_a(cj1, wJ[1][c * 4 + 0], b.x); mfma4_a(cj2, wJ[2][c * 4 + 0], b.x);
+                mfma4_a(cj0, wJ[0][c * 4 + 1], b.y); mfma4_a(cj1, wJ[1][c * 4 + 1], b.y); mfma4_a(cj2, wJ[2][c * 4 + 1], b.y);
+                mfma4_a(cj0, wJ[0][c * 4 + 2], b.z); mfma4_a(cj1, wJ[1][c * 4 + 2], b.z); mfma4_a(cj2, wJ[2][c * 4 + 2], b.z);
+                mfma4_a(cj0, wJ[0][c * 4 + 3], b.w); mfma4_a(cj1, wJ[1][c * 4 + 3], b.w); mfma4_a(cj2, wJ[2][c * 4 + 3], b.w);
             }
-            if (wave != 3) {
-                __builtin_amdgcn_sched_barrier(0);
-                Q4R_CYC0();
-                mfma4_a_c(cj0, wJ[0][0], bq[0].x, b1j[0]); mfma4_a_c(cj1, wJ[1][0], bq[0].x, b1j[1]); mfma4_a_c(cj2, wJ[2][0], bq[0].x, b1j[2]);
-                mfma4_a(cj0, wJ[0][1], bq[0].y); mfma4_a(cj1, wJ[1][1], bq[0].y); mfma4_a(cj2, wJ[2][1], bq[0].y);
-                mfma4_a(cj0, wJ[0][2], bq[0].z); mfma4_a(cj1, wJ[1][2], bq[0].z); mfma4_a(cj2, wJ[2][2], bq[0].z);
-                mfma4_a(cj0, wJ[0][3], bq[0].w); mfma4_a(cj1, wJ[1][3], bq[0].w); mfma4_a(cj2, wJ[2][3], bq[0].w);
-#pragma unroll
-                for (int c = 1; c < KA; ++c) {
-                    const f32x4 b = bq[c];
-                    mfma4_a(cj0, wJ[0][c * 4 + 0], b.x); mfma4_a(cj1, wJ[1][c * 4 + 0], b.x); mfma4_a(cj2, wJ[2][c * 4 + 0], b.x);
-                    mfma4_a(cj0, wJ[0][c * 4 + 1], b.y); mfma4_a(cj1, wJ[1][c * 4 + 1], b.y); mfma4_a(cj2, wJ[2][c * 4 + 1], b.y);
-                    mfma4_a(cj0, wJ[0][c * 4 + 2], b.z); mfma4_a(cj1, wJ[1][c * 4 + 2], b.z); mfma4_a(cj2, wJ[2][c * 4 + 2], b.z);
-                    mfma4_a(cj0, wJ[0][c * 4 + 3], b.w); mfma4_a(cj1, wJ[1][c * 4 + 3], b.w); mfma4_a(cj2, wJ[2][c * 4 + 3], b.w);
-                }
-                mfma4_results_ready(cj0, cj1, cj2);
-                __builtin_amdgcn_sched_barrier(0);
-                Q4R_CYC(0);
-                Q4R_CYC0();
-                h1w[0 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj0));
-                h1w[1 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj1));
-                h1w[2 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj2));
-                Q4R_CYC(1);
-            } else {
-                f32x4 bt[KT];
-#pragma unroll
-                for (int c = 0; c < KT; ++c) bt[c] = *reinterpret_cast<const f32x4*>(hT0 + c * 16);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma4_a_c(cj0, wJ[0][0], bq[0].x, b1j[0]); mfma4_a_c(cj1, wJ[1][0], bq[0].x, b1j[1]); mfma4_a_c(cj2, wJ[2][0], bq[0].x, b1j[2]);
-                mfma4_a_c(ct, wT[0], bt[0].x, b1t);
-                mfma4_a(cj0, wJ[0][1], bq[0].y); mfma4_a(cj1, wJ[1][1], bq[0].y); mfma4_a(cj2, wJ[2][1], bq[0].y); mfma4_a(ct, wT[1], bt[0].y);
-                mfma4_a(cj0, wJ[0][2], bq[0].z); mfma4_a(cj1, wJ[1][2], bq[0].z); mfma4_a(cj2, wJ[2][2], bq[0].z); mfma4_a(ct, wT[2], bt[0].z);
-                mfma4_a(cj0, wJ[0][3], bq[0].w); mfma4_a(cj1, wJ[1][3], bq[0].w); mfma4_a(cj2, wJ[2][3], bq[0].w); mfma4_a(ct, wT[3], bt[0].w);
-#pragma unroll
-                for (int c = 1; c < KA; ++c) {
-                    const f32x4 b = bq[c];
-                    if (c < KT) {
-                        const f32x4 d = bt[c];
-                        mfma4_a(cj0, wJ[0][c * 4 + 0], b.x); mfma4_a(cj1, wJ[1][c * 4 + 0], b.x); mfma4_a(cj2, wJ[2][c * 4 + 0], b.x); mfma4_a(ct, wT[c * 4 + 0], d.x);
-                        mfma4_a(cj0, wJ[0][c * 4 + 1], b.y); mfma4_a(cj1, wJ[1][c * 4 + 1], b.y); mfma4_a(cj2, wJ[2][c * 4 + 1], b.y); mfma4_a(ct, wT[c * 4 + 1], d.y);
-                        mfma4_a(cj0, wJ[0][c * 4 + 2], b.z); mfma4_a(cj1, wJ[1][c * 4 + 2], b.z); mfma4_a(cj2, wJ[2][c * 4 + 2], b.z); mfma4_a(ct, wT[c * 4 + 2], d.z);
-                        mfma4_a(cj0, wJ[0][c * 4 + 3], b.w); mfma4_a(cj1, wJ[1][c * 4 + 3], b.w); mfma4_a(cj2, wJ[2][c * 4 + 3], b.w); mfma4_a(ct, wT[c * 4 + 3], d.w);
-                    } else {
-                        mfma4_a(cj0, wJ[0][c * 4 + 0], b.x); mfma4_a(cj1, wJ[1][c * 4 + 0], b.x); mfma4_a(cj2, wJ[2][c * 4 + 0], b.x);
-                        mfma4_a(cj0, wJ[0][c * 4 + 1], b.y); mfma4_a(cj1, wJ[1][c * 4 + 1], b.y); mfma4_a(cj2, wJ[2][c * 4 + 1], b.y);
-                        mfma4_a(cj0, wJ[0][c * 4 + 2], b.z); mfma4_a(cj1, wJ[1][c * 4 + 2], b.z); mfma4_a(cj2, wJ[2][c * 4 + 2], b.z);
-                        mfma4_a(cj0, wJ[0][c * 4 + 3], b.w); mfma4_a(cj1, wJ[1][c * 4 + 3], b.w); mfma4_a(cj2, wJ[2][c * 4 + 3], b.w);
-                    }
-                }
-                mfma4_results_ready(cj0, cj1, cj2, ct);
-                __builtin_amdgcn_sched_barrier(0);
-                h1w[0 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj0));
-                h1w[1 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj1));
-                h1w[2 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj2));
-                // tail: the row's two slices of a feature block sit 8 lanes apart
-                ct.x = ct.x + dpp_mov<DPP_ROW_ROR8>(ct.x); ct.y = ct.y + dpp_mov<DPP_ROW_ROR8>(ct.y);
-                ct.z = ct.z + dpp_mov<DPP_ROW_ROR8>(ct.z); ct.w = ct.w + dpp_mov<DPP_ROW_ROR8>(ct.w);
-                const float z = apply_act_ct<A1>(rows_reduce_scatter(ct));
-                if ((blk & 2) == 0) *h1t = z;
-            }
+            mfma4_results_ready(cj0, cj1, cj2);
+            __builtin_amdgcn_sched_barrier(0);
+            Q4R_CYC(0);
+            Q4R_CYC0();
+            h1w[0 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj0) + b1s[0]);
+            h1w[1 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj1) + b1s[1]);
+            h1w[2 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj2) + b1s[2]);
+            Q4R_CYC(1);
         }
         Q4R_MARK(2);
         __syncthreads();
         Q4R_MARK(3);
-        // ---- last layer, whole K in every wave, K-split over the MFMA's blocks: set A in three chains, set B in two
-        float zA, zB;
+        // ---- the last layer, whole K in every wave, K-split over the MFMA's blocks (set A: features 0..15 in 4 quads x 4
+        // row slices; set B: features 16..19, block b takes k groups b, b + 16, ...), its rounds ordered so that those
+        // reading job 12's output come last; the action part of the NEXT step's layer 0 fills the LDS latency
+        f32x4 cA0, cA1, cA2, cB0, cB1;
+        f32x4 bqA[KA], bqB[KB];
         {
-            f32x4 cA0, cA1, cA2, cB0, cB1;
-            f32x4 bqA[KA], bqB[KB];
+            f32x4 ba0, ba1;
+            {   // next step's normalised action groups
+                const int tn = (t + 1 < H) ? t + 1 : t;
+                ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 0) * 4 + pl) * 4);
+                ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 1) * 4 + pl) * 4);
+            }
 #pragma unroll
-            for (int c = 0; c < KB; ++c) bqB[c] = *reinterpret_cast<const f32x4*>(hB1 + c * 16 * 16);
+            for (int c = 0; c < KB - 1; ++c) bqB[c] = *reinterpret_cast<const f32x4*>(hB1 + c * 16 * 16);
 #pragma unroll
-            for (int c = 0; c < KA; ++c) bqA[c] = *reinterpret_cast<const f32x4*>(hA1 + c * 16);
-            // ---- action part of the NEXT step's layer 0 while those reads are in flight (in front of the barrier it
-            // sat on the critical path of wave 3, the wave the others wait for)
-            __builtin_amdgcn_sched_barrier(0);
-            mfma4_v_c(acc0, wA0a[0], ba0.x, b0); mfma4_v_0(acc1, wA0a[1], ba0.y); mfma4_v_0(acc2, wA0a[2], ba0.z);
-            mfma4_v(acc0, wA0a[3], ba0.w);       mfma4_v(acc1, wA0a[4], ba1.x);   mfma4_v(acc2, wA0a[5], ba1.y);
-            mfma4_v(acc0, wA0a[6], ba1.z);       mfma4_v(acc1, wA0a[7], ba1.w);
+            for (int c = 0; c < 6; ++c) bqA[c] = *reinterpret_cast<const f32x4*>(hA1 + c * 16);
+            Q4R_ACTION_PART(ba0, ba1);
             __builtin_amdgcn_sched_barrier(0);
             Q4R_CYC0();
-            // rounds 0 .. KB-1 carry both sets: A0 B0 A1 B1 A2 B0 A0 B1 | A1 B0 A2 B1 A0 B0 A1 B1 | ...
-            mfma4_v_c(cA0, wA2a[0], bqA[0].x, biasA); mfma4_v_c(cB0, wA2b[0], bqB[0].x, biasB);
-            mfma4_v_0(cA1, wA2a[1], bqA[0].y);        mfma4_v_0(cB1, wA2b[1], bqB[0].y);
-            mfma4_v_0(cA2, wA2a[2], bqA[0].z);        mfma4_v(cB0, wA2b[2], bqB[0].z);
-            mfma4_v(cA0, wA2a[3], bqA[0].w);          mfma4_v(cB1, wA2b[3], bqB[0].w);
+            // part 1, 36 MFMAs: rounds 0..2 of both sets (A0 B0 A1 B1 A2 B0 A0 B1 | A1 B0 A2 B1 A0 B0 A1 B1 | ...), rounds 3..5 of set A
+            mfma4_a_0(cA0, wU[0], bqA[0].x);        mfma4_v_0(cB0, wA2b[0], bqB[0].x);
+            mfma4_a_0(cA1, wU[1], bqA[0].y);        mfma4_v_0(cB1, wA2b[1], bqB[0].y);
+            mfma4_a_0(cA2, wU[2], bqA[0].z);        mfma4_v(cB0, wA2b[2], bqB[0].z);
+            mfma4_a(cA0, wU[3], bqA[0].w);          mfma4_v(cB1, wA2b[3], bqB[0].w);
 #pragma unroll
-            for (int c = 1; c < KA; ++c) {
-                // chain of set A's MFMA i = 4c + e is i % 3 (compile-time after unrolling)
+            for (int c = 1; c < 6; ++c) {
+                // set A's MFMA number i = 4c + e goes to chain i % 3 (compile-time after unrolling)
                 f32x4& a0_ = ((4 * c + 0) % 3 == 0) ? cA0 : ((4 * c + 0) % 3 == 1) ? cA1 : cA2;
                 f32x4& a1_ = ((4 * c + 1) % 3 == 0) ? cA0 : ((4 * c + 1) % 3 == 1) ? cA1 : cA2;
                 f32x4& a2_ = ((4 * c + 2) % 3 == 0) ? cA0 : ((4 * c + 2) % 3 == 1) ? cA1 : cA2;
                 f32x4& a3_ = ((4 * c + 3) % 3 == 0) ? cA0 : ((4 * c + 3) % 3 == 1) ? cA1 : cA2;
-                if (c < KB) {
-                    mfma4_v(a0_, wA2a[c * 4 + 0], bqA[c].x); mfma4_v(cB0, wA2b[c * 4 + 0], bqB[c].x);
-                    mfma4_v(a1_, wA2a[c * 4 + 1], bqA[c].y); mfma4_v(cB1, wA2b[c * 4 + 1], bqB[c].y);
-                    mfma4_v(a2_, wA2a[c * 4 + 2], bqA[c].z); mfma4_v(cB0, wA2b[c * 4 + 2], bqB[c].z);
-                    mfma4_v(a3_, wA2a[c * 4 + 3], bqA[c].w); mfma4_v(cB1, wA2b[c * 4 + 3], bqB[c].w);
+                if (c < KB - 1) {
+                    mfma4_a(a0_, wU[c * 4 + 0], bqA[c].x); mfma4_v(cB0, wA2b[c * 4 + 0], bqB[c].x);
+                    mfma4_a(a1_, wU[c * 4 + 1], bqA[c].y); mfma4_v(cB1, wA2b[c * 4 + 1], bqB[c].y);
+                    mfma4_a(a2_, wU[c * 4 + 2], bqA[c].z); mfma4_v(cB0, wA2b[c * 4 + 2], bqB[c].z);
+                    mfma4_a(a3_, wU[c * 4 + 3], bqA[c].w); mfma4_v(cB1, wA2b[c * 4 + 3], bqB[c].w);
                 } else {
-                    mfma4_v(a0_, wA2a[c * 4 + 0], bqA[c].x); mfma4_v(a1_, wA2a[c * 4 + 1], bqA[c].y);
-                    mfma4_v(a2_, wA2a[c * 4 + 2], bqA[c].z); mfma4_v(a3_, wA2a[c * 4 + 3], bqA[c].w);
+                    if (c == KB - 1) {                    // the B operands of part 2, into the registers rounds 0..2 have released
+                        __builtin_amdgcn_sched_barrier(0);
+                        bqA[6] = *reinterpret_cast<const f32x4*>(hA1 + 6 * 16);
+                        bqA[7] = *reinterpret_cast<const f32x4*>(hA1 + 7 * 16);
+                        bqA[8] = *reinterpret_cast<const f32x4*>(hA1 + 8 * 16);
+                        bqA[LA0 + 2] = *reinterpret_cast<const f32x4*>(hA1 + (LA0 + 2) * 16);
+                        bqA[LA0 + 3] = *reinterpret_cast<const f32x4*>(hA1 + (LA0 + 3) * 16);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    mfma4_a(a0_, wU[c * 4 + 0], bqA[c].x); mfma4_a(a1_, wU[c * 4 + 1], bqA[c].y);
+                    mfma4_a(a2_, wU[c * 4 + 2], bqA[c].z); mfma4_a(a3_, wU[c * 4 + 3], bqA[c].w);
                 }
             }
+        }
+        Q4R_MARK(9);
+        __syncthreads();                                   // job 12's output is in h1 (the helper got here first)
+        Q4R_MARK(10);
+        {
+            bqB[KB - 1] = *reinterpret_cast<const f32x4*>(hB1 + (KB - 1) * 16 * 16);
+            bqA[LA0] = *reinterpret_cast<const f32x4*>(hA1 + LA0 * 16);
+            bqA[LA0 + 1] = *reinterpret_cast<const f32x4*>(hA1 + (LA0 + 1) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            // part 2, 20 MFMAs that do not need them: set A rounds 6..8 and 11, 12 (chains keep rotating: 24 MFMAs so far)
+            {
+                constexpr int order[5] = {6, 7, 8, LA0 + 2, LA0 + 3};
+                static_assert(LA0 == 9 && KA == 13, "round order of the last layer");
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int c = order[j];
+                    f32x4& a0_ = ((4 * (6 + j) + 0) % 3 == 0) ? cA0 : ((4 * (6 + j) + 0) % 3 == 1) ? cA1 : cA2;
+                    f32x4& a1_ = ((4 * (6 + j) + 1) % 3 == 0) ? cA0 : ((4 * (6 + j) + 1) % 3 == 1) ? cA1 : cA2;
+                    f32x4& a2_ = ((4 * (6 + j) + 2) % 3 == 0) ? cA0 : ((4 * (6 + j) + 2) % 3 == 1) ? cA1 : cA2;
+                    f32x4& a3_ = ((4 * (6 + j) + 3) % 3 == 0) ? cA0 : ((4 * (6 + j) + 3) % 3 == 1) ? cA1 : cA2;
+                    mfma4_a(a0_, wU[c * 4 + 0], bqA[c].x); mfma4_a(a1_, wU[c * 4 + 1], bqA[c].y);
+                    mfma4_a(a2_, wU[c * 4 + 2], bqA[c].z); mfma4_a(a3_, wU[c * 4 + 3], bqA[c].w);
+                }
+            }
+            // part 3, 12 MFMAs: set A rounds 9, 10 (issue numbers 44..51 -> chains 2 0 1 2 0 1 2 0) and set B round 3
+            mfma4_a(cA2, wU[LA0 * 4 + 0], bqA[LA0].x); mfma4_v(cB0, wA2b[(KB - 1) * 4 + 0], bqB[KB - 1].x);
+            mfma4_a(cA0, wU[LA0 * 4 + 1], bqA[LA0].y); mfma4_v(cB1, wA2b[(KB - 1) * 4 + 1], bqB[KB - 1].y);
+            mfma4_a(cA1, wU[LA0 * 4 + 2], bqA[LA0].z); mfma4_v(cB0, wA2b[(KB - 1) * 4 + 2], bqB[KB - 1].z);
+            mfma4_a(cA2, wU[LA0 * 4 + 3], bqA[LA0].w); mfma4_v(cB1, wA2b[(KB - 1) * 4 + 3], bqB[KB - 1].w);
+            mfma4_a(cA0, wU[(LA0 + 1) * 4 + 0], bqA[LA0 + 1].x); mfma4_a(cA1, wU[(LA0 + 1) * 4 + 1], bqA[LA0 + 1].y);
+            mfma4_a(cA2, wU[(LA0 + 1) * 4 + 2], bqA[LA0 + 1].z); mfma4_a(cA0, wU[(LA0 + 1) * 4 + 3], bqA[LA0 + 1].w);
             mfma4_results_ready(cA0, cA1, cA2, cB0, cB1);
             __builtin_amdgcn_sched_barrier(0);
             Q4R_CYC(2);
@@ -566,11 +659,9 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
             sB.z = sB.z + dpp_mov<DPP_ROW_ROR8>(sB.z); sB.w = sB.w + dpp_mov<DPP_ROW_ROR8>(sB.w);
             sB.x = sB.x + dpp_mov<DPP_ROW_ROR4>(sB.x); sB.y = sB.y + dpp_mov<DPP_ROW_ROR4>(sB.y);
             sB.z = sB.z + dpp_mov<DPP_ROW_ROR4>(sB.z); sB.w = sB.w + dpp_mov<DPP_ROW_ROR4>(sB.w);
-            zA = rows_reduce_scatter(sA);                 // output feature 4*fgq + pr of particle pl
-            zB = rows_reduce_scatter(sB);                 // output feature 16 + pr
-        }
-        // ---- epilogue on the two features this lane finishes (process_output, then process_input of the next step)
-        {
+            zA = rows_reduce_scatter(sA) + lbA;           // output feature 4*fgq + pr of particle pl
+            zB = rows_reduce_scatter(sB) + lbB;           // output feature 16 + pr
+            // ---- epilogue on the two features this lane finishes (process_output, then process_input of the next step)
             zA = apply_act_ct<A2>(zA); zB = apply_act_ct<A2>(zB);
             const float vA = (tmA + zA * tsA) + curA, vB = (tmB + zB * tsB) + curB;
             if (rwd_flag_lane) rwd_f[t * 16] = (curA >= flag_thr) ? -10.0f : 0.0f;
@@ -586,14 +677,16 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
             }
             xA = rows_all_gather((vA - nmA) * niA);
             xB = rows_all_gather((vB - nmB) * niB);
+            Q4R_CYC(3);
         }
-        Q4R_CYC(3);
         Q4R_MARK(4);
     }
+    }
+#undef Q4R_ACTION_PART
 #ifdef BBMPC_KERNEL_DBG
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-        printf("[q4rdbg] H=%d | operand loads issued %lld  constants+actions %lld  LDS part 2 %lld  first mfma %lld | loop %lld (%lld shader cycles): layer0 %lld bar %lld layer1+act %lld bar %lld last+epi %lld (10ns units)\n",
-               H, dbg_acc[5], dbg_acc[6], dbg_acc[8], dbg_acc[7], (long long)wall_clock64() - dbg_start, (long long)clock64() - dbg_cyc0, dbg_acc[0], dbg_acc[1], dbg_acc[2], dbg_acc[3], dbg_acc[4]);
+        printf("[q4rdbg] H=%d | operand loads issued %lld  constants+actions %lld  LDS part 2 %lld  first mfma %lld | loop %lld (%lld shader cycles): layer0 %lld bar %lld layer1 %lld bar %lld action+last part 1 %lld bar %lld last parts 2,3+epilogue %lld (10ns units)\n",
+               H, dbg_acc[5], dbg_acc[6], dbg_acc[8], dbg_acc[7], (long long)wall_clock64() - dbg_start, (long long)clock64() - dbg_cyc0, dbg_acc[0], dbg_acc[1], dbg_acc[2], dbg_acc[3], dbg_acc[9], dbg_acc[10], dbg_acc[4]);
         printf("[q4rdbg] shader cycles per step: layer-1 MFMA block (156) %lld | layer-1 reduce+tanh+store %lld | last-layer MFMA block (68) %lld | reduce+epilogue+gather %lld\n",
                dbg_cyc[0] / H, dbg_cyc[1] / H, dbg_cyc[2] / H, dbg_cyc[3] / H);
     }
