@@ -35,7 +35,7 @@
 
 namespace bbmpc {
 
-constexpr int Q4R_MAX_ACTION_ELEMS = 2048;              // H * 4 * dim_U a workgroup's threads keep in registers across the operand loads
+constexpr int Q4R_MAX_ACTION_PAIRS = 512;               // (particle, 4 consecutive action-sequence elements) pairs a workgroup's threads keep in registers across the operand loads
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
@@ -100,6 +100,27 @@ __device__ __forceinline__ void mfma4_a_c(f32x4& acc, float a_in_agpr, float b, 
 __device__ __forceinline__ void mfma4_a_0(f32x4& acc, float a_in_agpr, float b) {
     asm volatile(BBMPC_MFMA4 "%0, %1, %2, 0" : "=&v"(acc) : "a"(a_in_agpr), "v"(b));
 }
+// One k-group of three layer-1 jobs = 12 MFMAs in ONE asm statement (three chains, round robin): between separate
+// statements the compiler pads every re-use of an accumulator with an s_nop it cannot know to be unnecessary.
+__device__ __forceinline__ void mfma4_a_round3(f32x4& c0, f32x4& c1, f32x4& c2, const float* w0, const float* w1, const float* w2, const f32x4& b) {
+    asm volatile(BBMPC_MFMA4 "%0, %3, %15, %0\n\t" BBMPC_MFMA4 "%1, %7, %15, %1\n\t" BBMPC_MFMA4 "%2, %11, %15, %2\n\t"
+                 BBMPC_MFMA4 "%0, %4, %16, %0\n\t" BBMPC_MFMA4 "%1, %8, %16, %1\n\t" BBMPC_MFMA4 "%2, %12, %16, %2\n\t"
+                 BBMPC_MFMA4 "%0, %5, %17, %0\n\t" BBMPC_MFMA4 "%1, %9, %17, %1\n\t" BBMPC_MFMA4 "%2, %13, %17, %2\n\t"
+                 BBMPC_MFMA4 "%0, %6, %18, %0\n\t" BBMPC_MFMA4 "%1, %10, %18, %1\n\t" BBMPC_MFMA4 "%2, %14, %18, %2"
+                 : "+v"(c0), "+v"(c1), "+v"(c2)
+                 : "a"(w0[0]), "a"(w0[1]), "a"(w0[2]), "a"(w0[3]), "a"(w1[0]), "a"(w1[1]), "a"(w1[2]), "a"(w1[3]),
+                   "a"(w2[0]), "a"(w2[1]), "a"(w2[2]), "a"(w2[3]), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+}
+// the first k-group: the chains start from the inline constant 0
+__device__ __forceinline__ void mfma4_a_round3_first(f32x4& c0, f32x4& c1, f32x4& c2, const float* w0, const float* w1, const float* w2, const f32x4& b) {
+    asm volatile(BBMPC_MFMA4 "%0, %3, %15, 0\n\t"  BBMPC_MFMA4 "%1, %7, %15, 0\n\t"  BBMPC_MFMA4 "%2, %11, %15, 0\n\t"
+                 BBMPC_MFMA4 "%0, %4, %16, %0\n\t" BBMPC_MFMA4 "%1, %8, %16, %1\n\t" BBMPC_MFMA4 "%2, %12, %16, %2\n\t"
+                 BBMPC_MFMA4 "%0, %5, %17, %0\n\t" BBMPC_MFMA4 "%1, %9, %17, %1\n\t" BBMPC_MFMA4 "%2, %13, %17, %2\n\t"
+                 BBMPC_MFMA4 "%0, %6, %18, %0\n\t" BBMPC_MFMA4 "%1, %10, %18, %1\n\t" BBMPC_MFMA4 "%2, %14, %18, %2"
+                 : "=&v"(c0), "=&v"(c1), "=&v"(c2)
+                 : "a"(w0[0]), "a"(w0[1]), "a"(w0[2]), "a"(w0[3]), "a"(w1[0]), "a"(w1[1]), "a"(w1[2]), "a"(w1[3]),
+                   "a"(w2[0]), "a"(w2[1]), "a"(w2[2]), "a"(w2[3]), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+}
 __device__ __forceinline__ void mfma4_operands_settled() { asm volatile("s_nop 1"); }
 __device__ __forceinline__ void mfma4_results_ready(f32x4& c0, f32x4& c1, f32x4& c2) {
     asm volatile("s_nop 4" : "+v"(c0), "+v"(c1), "+v"(c2));
@@ -148,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     float* lbias = tstd + 32;
     float* st0 = lbias + 32;
 #ifdef BBMPC_KERNEL_DBG
-    long long dbg_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dbg_t0 = (long long)wall_clock64();
+    long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dbg_t0 = (long long)wall_clock64();
 #define Q4R_MARK(i) do { const long long now_ = (long long)wall_clock64(); dbg_acc[i] += now_ - dbg_t0; dbg_t0 = now_; } while (0)
     long long dbg_cyc[4] = {0, 0, 0, 0}, dbg_c0 = 0;
 #define Q4R_CYC0() do { dbg_c0 = (long long)clock64(); } while (0)
@@ -163,8 +184,10 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     // particles' action block) are issued first, then the ~260 KB of stationary operands, and only then is anything
     // consumed: the small results arrive first and are worked on while the operands stream in (the two waits used to
     // add up, 3.2 + 4.1 us of a 70 us kernel).
-    // NE = action-block elements per thread (H * 4 * U <= 256 * NE)
-    const int a_total = H * QP * U;
+    // The action block is handled in (particle, 4 consecutive j) pairs, NE per thread (4 * ceil(H*U / 4) <= 256 * NE): the
+    // four elements of a pair share one Philox block (rng.hpp: rng_block is keyed by j >> 2), so a thread draws once,
+    // not four times -- 120 VALU instructions each at a lone wave's issue rate were a good microsecond of the prologue.
+    const int HU = p.HU, a_pairs = QP * ((HU + 3) >> 2);
     const int ci = min(tid, S + U - 1), cs = min(tid, S - 1);
     const float* cmu_base = !normd ? p.state : (ci < S ? m.mean_s : m.mean_a);
     const float* csd_base = !normd ? p.state : (ci < S ? m.std_s : m.std_a);
@@ -182,38 +205,46 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     const float* lo_base = has_bounds ? p.lo : p.state;
     const float* hi_base = has_bounds ? p.hi : p.state;
     const bool has_rng = !has_raw;                         // draws made here (rng.hpp counters), SRC_UNIFORM or truncated normal
-    float a_raw[NE], a_sg[NE], a_mn[NE], a_lo[NE], a_hi[NE], a_f[NE], a_tq[NE];
-    int a_j[NE], a_nu[NE];                               // j = t*U + u; (n << 8) | u, -1 = no such element / particle
+    float a_raw[NE][4], a_sg[NE][4], a_mn[NE][4], a_lo[NE][4], a_hi[NE][4], a_f[NE][4], a_tq[NE][4];
+    int a_n[NE], a_j0[NE], a_tu[NE];                     // particle (-1: no such pair / particle), first j, (t << 8) | u of the first element
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        const int e = tid + i * NT;
-        const int u = e % U, pp = (e / U) % QP, t = e / (U * QP);
-        const int n = n0 + pp, j = t * U + u;
-        const bool valid = e < a_total && n < p.n_pop;
-        a_j[i] = j; a_nu[i] = valid ? ((n << 8) | u) : -1;
-        const int di = (valid && has_dist) ? a * p.HU + j : 0;
-        a_sg[i] = sg_base[di]; a_mn[i] = mn_base[di];
-        const int ui = (valid && has_bounds) ? u : 0;
-        a_lo[i] = lo_base[ui]; a_hi[i] = hi_base[ui];
+        const int pi = tid + i * NT;
+        const int pp = pi & (QP - 1), j0 = (pi >> 2) << 2;
+        const int n = n0 + pp;
+        const bool pvalid = pi < a_pairs && n < p.n_pop;
+        const int t0 = j0 / U, u0 = j0 - t0 * U;
+        a_n[i] = pvalid ? n : -1; a_j0[i] = j0; a_tu[i] = (t0 << 8) | u0;
         // word_to_trunc_normal (rng.hpp) split in two: the table entry is loaded here, the interpolation happens with the
         // other small results -- as one piece it would sit behind the operand loads.  One unconditional pair of loads
         // per element whatever the mode (a load inside a branch costs a wait at the join).
-        uint32_t w = 0u;
-        if (has_rng) {
-            const U4 blk4 = rng_block(p.key, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j);
-            w = pick_word(blk4, (uint32_t)j);
-        }
-        const uint32_t v = w >> 9;
+        U4 blk4 = {0u, 0u, 0u, 0u};
+        if (has_rng) blk4 = rng_block(p.key, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j0);
         const bool tn = has_rng && !m_uni;
-        a_f[i] = m_uni ? word_to_uniform(w)
-                       : ((float)(v & ((1u << (23 - TNQ_BITS)) - 1u)) + 0.5f) * (1.0f / (float)(1u << (23 - TNQ_BITS)));
-        const size_t ri = m_ref ? ((size_t)n * p.A + a) * p.HU + j : ((size_t)a * p.HU + j) * p.Nst + n;
-        const float* tqp = reinterpret_cast<const float*>(g_tnq) + 2 * (v >> (23 - TNQ_BITS));
-        const float* rp = tn ? tqp : raw_base + ((valid && has_raw) ? ri : (size_t)0);
-        const float* tp = tn ? tqp + 1 : p.state;
-        a_raw[i] = *rp; a_tq[i] = *tp;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int j = j0 + l;
+            int u = u0 + l;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) u = (u >= U) ? u - U : u;
+            const bool valid = pvalid && j < HU;
+            const int di = (valid && has_dist) ? a * HU + j : 0;
+            a_sg[i][l] = sg_base[di]; a_mn[i][l] = mn_base[di];
+            const int ui = (valid && has_bounds) ? u : 0;
+            a_lo[i][l] = lo_base[ui]; a_hi[i][l] = hi_base[ui];
+            const uint32_t w = l == 0 ? blk4.x : (l == 1 ? blk4.y : (l == 2 ? blk4.z : blk4.w));      // pick_word(blk4, j)
+            const uint32_t v = w >> 9;
+            a_f[i][l] = m_uni ? word_to_uniform(w)
+                              : ((float)(v & ((1u << (23 - TNQ_BITS)) - 1u)) + 0.5f) * (1.0f / (float)(1u << (23 - TNQ_BITS)));
+            const size_t ri = m_ref ? ((size_t)n * p.A + a) * HU + j : ((size_t)a * HU + j) * p.Nst + n;
+            const float* tqp = reinterpret_cast<const float*>(g_tnq) + 2 * (v >> (23 - TNQ_BITS));
+            const float* rp = tn ? tqp : raw_base + ((valid && has_raw) ? ri : (size_t)0);
+            const float* tp = tn ? tqp + 1 : p.state;
+            a_raw[i][l] = *rp; a_tq[i][l] = *tp;
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
+    Q4R_MARK(11);
     // ---- roles.  Waves 0..2 are STATE waves: layer 0 for their 64 hidden features, three layer-1 jobs, the whole last
     // layer, the state.  Wave 3 is the HELPER: layer-1 jobs 3, 7, 11 with the others and, after the second barrier,
     // job 12 (hidden features 192..199) while the state waves are already in the last layer, which takes job 12's
@@ -317,31 +348,43 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < NE; ++i) asm volatile("" : "+v"(a_raw[i]), "+v"(a_tq[i]));   // the interpolation stays down here
+    for (int i = 0; i < NE; ++i)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) asm volatile("" : "+v"(a_raw[i][l]), "+v"(a_tq[i][l]));   // the interpolation stays down here
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        const int e = tid + i * NT;
-        if (e < a_total) {
-            float x = 0.0f, d2 = 0.0f;
-            if (a_nu[i] >= 0) {
-                const int n = a_nu[i] >> 8, j = a_j[i];
-                if (m_ref || m_buf) x = a_raw[i];
-                else {
-                    // word_to_trunc_normal's last line / the uniform draw / the injected draw
-                    const float xi = has_rng ? (m_uni ? a_f[i] : fmaf(a_f[i], a_tq[i], a_raw[i])) : a_raw[i];
-                    if (m_uni) x = xi * (a_hi[i] - a_lo[i]) + a_lo[i];
-                    else x = xi * a_sg[i] + a_mn[i];
+        const int pi = tid + i * NT;
+        if (pi < a_pairs) {
+            const int n = a_n[i], pp = pi & (QP - 1);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const int j = a_j0[i] + l;
+                int u = (a_tu[i] & 255) + l, t = a_tu[i] >> 8;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { t = (u >= U) ? t + 1 : t; u = (u >= U) ? u - U : u; }
+                if (j < HU) {
+                    float x = 0.0f, d2 = 0.0f;
+                    if (n >= 0) {
+                        if (m_ref || m_buf) x = a_raw[i][l];
+                        else {
+                            // word_to_trunc_normal's last line / the uniform draw / the injected draw
+                            const float xi = has_rng ? (m_uni ? a_f[i][l] : fmaf(a_f[i][l], a_tq[i][l], a_raw[i][l])) : a_raw[i][l];
+                            if (m_uni) x = xi * (a_hi[i][l] - a_lo[i][l]) + a_lo[i][l];
+                            else x = xi * a_sg[i][l] + a_mn[i][l];
+                        }
+                        if (q.pen) {
+                            const float xf = clipf(x, a_lo[i][l], a_hi[i][l]);
+                            const float d = x - xf;
+                            d2 = d * d;
+                            x = xf;
+                        }
+                        if (p.samples) p.samples[((size_t)a * HU + j) * p.Nst + n] = x;
+                    }
+                    const int e = (t * QP + pp) * U + u;
+                    acts[e] = x;
+                    xa[e] = d2;
                 }
-                if (q.pen) {
-                    const float xf = clipf(x, a_lo[i], a_hi[i]);
-                    const float d = x - xf;
-                    d2 = d * d;
-                    x = xf;
-                }
-                if (p.samples) p.samples[((size_t)a * p.HU + j) * p.Nst + n] = x;
             }
-            acts[e] = x;
-            xa[e] = d2;
         }
     }
     for (int i = tid; i < (HP - HG) * 16; i += NT) { h0[HG * 16 + i] = 0.0f; h1[HG * 16 + i] = 0.0f; }
@@ -435,40 +478,31 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     if (helper) {
         for (int t = 0; t < H; ++t) {
             __syncthreads();                               // h0 of step t is complete
-        f32x4 bq[KA];
-        {
-            f32x4 cj0, cj1, cj2;
+            // ---- layer-1 jobs 3, 7, 11 (see the state loop)
+            f32x4 bq[KA];
+            {
+                f32x4 cj0, cj1, cj2;
 #pragma unroll
-            for (int c = 0; c < KA; ++c) bq[c] = *reinterpret_cast<const f32x4*>(hA0 + c * 16);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma4_a_0(cj0, wJ[0][0], bq[0].x); mfma4_a_0(cj1, wJ[1][0], bq[0].x); mfma4_a_0(cj2, wJ[2][0], bq[0].x);
-            mfma4_a(cj0, wJ[0][1], bq[0].y); mfma4_a(cj1, wJ[1][1], bq[0].y); mfma4_a(cj2, wJ[2][1], bq[0].y);
-            mfma4_a(cj0, wJ[0][2], bq[0].z); mfma4_a(cj1, wJ[1][2], bq[0].z); mfma4_a(cj2, wJ[2][2], bq[0].z);
-            mfma4_a(cj0, wJ[0][3], bq[0].w); mfma4_a(cj1, wJ[1][3], bq[0].w); mfma4_a(cj2, wJ[2][3], bq[0].w);
+                for (int c = 0; c < KA; ++c) bq[c] = *reinterpret_cast<const f32x4*>(hA0 + c * 16);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma4_a_round3_first(cj0, cj1, cj2, wJ[0], wJ[1], wJ[2], bq[0]);
 #pragma unroll
-            for (int c = 1; c < KA; ++c) {
-                const f32x4 b = bq[c];
-                mfma4_a(cj0, wJ[0][c * 4 + 0], b.x); mfma4_a(cj1, wJ[1][c * 4 + 0], b.x); mfma4_a(cj2, wJ[2][c * 4 + 0], b.x);
-                mfma4_a(cj0, wJ[0][c * 4 + 1], b.y); mfma4_a(cj1, wJ[1][c * 4 + 1], b.y); mfma4_a(cj2, wJ[2][c * 4 + 1], b.y);
-                mfma4_a(cj0, wJ[0][c * 4 + 2], b.z); mfma4_a(cj1, wJ[1][c * 4 + 2], b.z); mfma4_a(cj2, wJ[2][c * 4 + 2], b.z);
-                mfma4_a(cj0, wJ[0][c * 4 + 3], b.w); mfma4_a(cj1, wJ[1][c * 4 + 3], b.w); mfma4_a(cj2, wJ[2][c * 4 + 3], b.w);
+                for (int c = 1; c < KA; ++c) mfma4_a_round3(cj0, cj1, cj2, wJ[0] + 4 * c, wJ[1] + 4 * c, wJ[2] + 4 * c, bq[c]);
+                mfma4_results_ready(cj0, cj1, cj2);
+                __builtin_amdgcn_sched_barrier(0);
+                h1w[0 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj0) + b1s[0]);
+                h1w[1 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj1) + b1s[1]);
+                h1w[2 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj2) + b1s[2]);
             }
-            mfma4_results_ready(cj0, cj1, cj2);
-            __builtin_amdgcn_sched_barrier(0);
-            h1w[0 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj0) + b1s[0]);
-            h1w[1 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj1) + b1s[1]);
-            h1w[2 * 256] = apply_act_ct<A1>(rows_reduce_scatter(cj2) + b1s[2]);
-        }
             __syncthreads();                               // every wave's jobs are in h1
-            // ---- job 12 (hidden features 192..199) from the same B operands, three chains over its 52 MFMAs, while the
-            // state waves run the part of the last layer that does not need it
+            // ---- job 12 (hidden features 192..199) from the same B operands, three chains over its 52 MFMAs (MFMA number
+            // i = 4c + e goes to chain i % 3), while the state waves run the part of the last layer that does not need it
             f32x4 cx0, cx1, cx2;
             __builtin_amdgcn_sched_barrier(0);
             mfma4_a_0(cx0, wU[0], bq[0].x); mfma4_a_0(cx1, wU[1], bq[0].y); mfma4_a_0(cx2, wU[2], bq[0].z);
             mfma4_a(cx0, wU[3], bq[0].w);
 #pragma unroll
             for (int c = 1; c < KA; ++c) {
-                // MFMA i = 4c + e goes to chain (i + ...) % 3: consecutive MFMAs rotate through the three chains
                 f32x4& x0_ = ((4 * c + 0) % 3 == 0) ? cx0 : ((4 * c + 0) % 3 == 1) ? cx1 : cx2;
                 f32x4& x1_ = ((4 * c + 1) % 3 == 0) ? cx0 : ((4 * c + 1) % 3 == 1) ? cx1 : cx2;
                 f32x4& x2_ = ((4 * c + 2) % 3 == 0) ? cx0 : ((4 * c + 2) % 3 == 1) ? cx1 : cx2;
@@ -498,42 +532,63 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
             bm.z = (row & 1) ? xB.z : xA.z; bm.w = (row & 1) ? xB.w : xA.w;
             __builtin_amdgcn_sched_barrier(0);
             mfma4_operands_settled();
-            // (the action part left the main chains at acc2)
-            mfma4_v(acc2, wA0r[0], xA.x);  mfma4_v(acc0, wA0r[1], xA.y);  mfma4_v(acc1, wA0r[2], xA.z);
+            // (the action part left the main chains at acc2.)  The mini job's four MFMAs go first; its reduction -- the 8
+            // blocks of a quad (two rows) hold its partial sums: fold the rows (two registers per swap), then the row's
+            // four blocks as a reduce-scatter (one value, one activation per lane, valid in the odd blocks) -- is a chain
+            // of ~15 dependent VALU instructions, fed one link at a time between the remaining MFMAs, whose issue time
+            // covers its latency (behind the MFMAs it cost the mini wave, and through the barrier everyone, ~230 cycles).
+            // Every state wave runs it (zero weights off wave MJ); only wave MJ stores.
+#define Q4R_FENCE() __builtin_amdgcn_sched_barrier(0)
             mfma4_v(accM, wM[0], bm.x);
-            mfma4_v(acc2, wA0r[3], xA.w);  mfma4_v(acc0, wA0r[4], r1.x);  mfma4_v(acc1, wA0r[5], r1.y);
+            mfma4_v(acc2, wA0r[0], xA.x);  mfma4_v(acc0, wA0r[1], xA.y);
             mfma4_v(accM, wM[1], bm.y);
-            mfma4_v(acc2, wA0r[6], r1.z);  mfma4_v(acc0, wA0r[7], r1.w);  mfma4_v(acc1, wA0r[8], r2.x);
+            mfma4_v(acc1, wA0r[2], xA.z);  mfma4_v(acc2, wA0r[3], xA.w);
             mfma4_v(accM, wM[2], bm.z);
-            mfma4_v(acc2, wA0r[9], r2.y);  mfma4_v(acc0, wA0r[10], r2.z); mfma4_v(acc1, wA0r[11], r2.w);
+            mfma4_v(acc0, wA0r[4], r1.x);  mfma4_v(acc1, wA0r[5], r1.y);
             mfma4_v(accM, wM[3], bm.w);
-            mfma4_v(acc2, wA0r[12], r3.x); mfma4_v(acc0, wA0r[13], r3.y); mfma4_v(acc1, wA0r[14], r3.z);
-            mfma4_v(acc2, wA0r[15], r3.w); mfma4_v(acc0, wA0b[0], xB.x);  mfma4_v(acc1, wA0b[1], xB.y);
+            mfma4_v(acc2, wA0r[6], r1.z);  mfma4_v(acc0, wA0r[7], r1.w);  mfma4_v(acc1, wA0r[8], r2.x);
+            asm volatile("" : "+v"(accM));                 // three MFMAs (>= 24 cycles) behind its last one: safe to read
+            Q4R_FENCE();
+            float mx = accM.x, my = accM.y, mz = accM.z, mw = accM.w;
+            swap16(mx, my);                                  // mx + my = [x.r0 + x.r1, y.r0 + y.r1, x.r2 + x.r3, y.r2 + y.r3]
+            swap16(mz, mw);
+            Q4R_FENCE();
+            mfma4_v(acc2, wA0r[9], r2.y);  mfma4_v(acc0, wA0r[10], r2.z);
+            Q4R_FENCE();
+            const float s1 = mx + my, s2 = mz + mw;
+            Q4R_FENCE();
+            mfma4_v(acc1, wA0r[11], r2.w); mfma4_v(acc2, wA0r[12], r3.x);
+            Q4R_FENCE();
+            const float u1 = s1 + dpp_mov<DPP_ROW_ROR8>(s1), u2 = s2 + dpp_mov<DPP_ROW_ROR8>(s2);
+            Q4R_FENCE();
+            mfma4_v(acc0, wA0r[13], r3.y); mfma4_v(acc1, wA0r[14], r3.z);
+            Q4R_FENCE();
+            const float tt = (fgq < 2) ? u1 : u2;
+            Q4R_FENCE();
+            mfma4_v(acc2, wA0r[15], r3.w);
+            Q4R_FENCE();
+            // the other block of my pair sits one block down for the odd blocks, which therefore finish the sum and store (a
+            // lane-dependent choice between two DPP sources would put the DPP under a partial exec mask)
+            const float pre = (tt + dpp_mov<DPP_ROW_ROR4>(tt)) + bMs;
+            Q4R_FENCE();
+            mfma4_v(acc0, wA0b[0], xB.x);  mfma4_v(acc1, wA0b[1], xB.y);
+            Q4R_FENCE();
+            const float hv = apply_act_ct<A0>(pre);
+            Q4R_FENCE();
             mfma4_v(acc2, wA0b[2], xB.z);  mfma4_v(acc0, wA0b[3], xB.w);
-            mfma4_results_ready(acc0, acc1, acc2, accM);
-            __builtin_amdgcn_sched_barrier(0);
+            mfma4_results_ready(acc0, acc1, acc2);
+            Q4R_FENCE();
+#undef Q4R_FENCE
             f32x4 o;
             o.x = apply_act_ct<A0>((acc0.x + acc1.x) + acc2.x); o.y = apply_act_ct<A0>((acc0.y + acc1.y) + acc2.y);
             o.z = apply_act_ct<A0>((acc0.z + acc1.z) + acc2.z); o.w = apply_act_ct<A0>((acc0.w + acc1.w) + acc2.w);
             *reinterpret_cast<f32x4*>(h0 + my_row) = o;
-            if (mini) {
-                // the 8 blocks of a quad (two rows) hold its partial sums: fold the rows (two registers per swap), then the
-                // row's four blocks as a reduce-scatter -- one value, one activation per lane (valid in the odd blocks)
-                float mx = accM.x, my = accM.y, mz = accM.z, mw = accM.w;
-                swap16(mx, my);                              // mx + my = [x.r0 + x.r1, y.r0 + y.r1, x.r2 + x.r3, y.r2 + y.r3]
-                swap16(mz, mw);
-                const float s1 = mx + my, s2 = mz + mw;
-                const float u1 = s1 + dpp_mov<DPP_ROW_ROR8>(s1), u2 = s2 + dpp_mov<DPP_ROW_ROR8>(s2);
-                const float tt = (fgq < 2) ? u1 : u2;
-                // the other block of my pair sits one block down for the odd blocks, which therefore finish the sum and
-                // store (a lane-dependent choice between two DPP sources would put the DPP under a partial exec mask)
-                const float hv = apply_act_ct<A0>((tt + dpp_mov<DPP_ROW_ROR4>(tt)) + bMs);
-                if (fgq & 1) *h0m = hv;
-            }
+            if (mini && (fgq & 1)) *h0m = hv;
         }
         Q4R_MARK(0);
         __syncthreads();
         Q4R_MARK(1);
+        f32x4 ba0, ba1;
         // ---- layer 1: three 16-feature jobs per wave (156 MFMAs on every wave), K split over the rows, one shared set of
         // B operands; stationary A operands in AccVGPRs, read by the MFMA directly
         {
@@ -541,20 +596,17 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
             f32x4 cj0, cj1, cj2;
 #pragma unroll
             for (int c = 0; c < KA; ++c) bq[c] = *reinterpret_cast<const f32x4*>(hA0 + c * 16);
+            {   // next step's normalised action groups: static data, fetched here so that the action part can start right
+                // behind the second barrier
+                const int tn = (t + 1 < H) ? t + 1 : t;
+                ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 0) * 4 + pl) * 4);
+                ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 1) * 4 + pl) * 4);
+            }
             __builtin_amdgcn_sched_barrier(0);
             Q4R_CYC0();
-            mfma4_a_0(cj0, wJ[0][0], bq[0].x); mfma4_a_0(cj1, wJ[1][0], bq[0].x); mfma4_a_0(cj2, wJ[2][0], bq[0].x);
-            mfma4_a(cj0, wJ[0][1], bq[0].y); mfma4_a(cj1, wJ[1][1], bq[0].y); mfma4_a(cj2, wJ[2][1], bq[0].y);
-            mfma4_a(cj0, wJ[0][2], bq[0].z); mfma4_a(cj1, wJ[1][2], bq[0].z); mfma4_a(cj2, wJ[2][2], bq[0].z);
-            mfma4_a(cj0, wJ[0][3], bq[0].w); mfma4_a(cj1, wJ[1][3], bq[0].w); mfma4_a(cj2, wJ[2][3], bq[0].w);
+            mfma4_a_round3_first(cj0, cj1, cj2, wJ[0], wJ[1], wJ[2], bq[0]);
 #pragma unroll
-            for (int c = 1; c < KA; ++c) {
-                const f32x4 b = bq[c];
-                mfma4_a(cj0, wJ[0][c * 4 + 0], b.x); mfma4_a(cj1, wJ[1][c * 4 + 0], b.x); mfma4_a(cj2, wJ[2][c * 4 + 0], b.x);
-                mfma4_a(cj0, wJ[0][c * 4 + 1], b.y); mfma4_a(cj1, wJ[1][c * 4 + 1], b.y); mfma4_a(cj2, wJ[2][c * 4 + 1], b.y);
-                mfma4_a(cj0, wJ[0][c * 4 + 2], b.z); mfma4_a(cj1, wJ[1][c * 4 + 2], b.z); mfma4_a(cj2, wJ[2][c * 4 + 2], b.z);
-                mfma4_a(cj0, wJ[0][c * 4 + 3], b.w); mfma4_a(cj1, wJ[1][c * 4 + 3], b.w); mfma4_a(cj2, wJ[2][c * 4 + 3], b.w);
-            }
+            for (int c = 1; c < KA; ++c) mfma4_a_round3(cj0, cj1, cj2, wJ[0] + 4 * c, wJ[1] + 4 * c, wJ[2] + 4 * c, bq[c]);
             mfma4_results_ready(cj0, cj1, cj2);
             __builtin_amdgcn_sched_barrier(0);
             Q4R_CYC(0);
@@ -573,12 +625,6 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
         f32x4 cA0, cA1, cA2, cB0, cB1;
         f32x4 bqA[KA], bqB[KB];
         {
-            f32x4 ba0, ba1;
-            {   // next step's normalised action groups
-                const int tn = (t + 1 < H) ? t + 1 : t;
-                ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 0) * 4 + pl) * 4);
-                ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 1) * 4 + pl) * 4);
-            }
 #pragma unroll
             for (int c = 0; c < KB - 1; ++c) bqB[c] = *reinterpret_cast<const f32x4*>(hB1 + c * 16 * 16);
 #pragma unroll
@@ -685,8 +731,8 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
 #undef Q4R_ACTION_PART
 #ifdef BBMPC_KERNEL_DBG
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-        printf("[q4rdbg] H=%d | operand loads issued %lld  constants+actions %lld  LDS part 2 %lld  first mfma %lld | loop %lld (%lld shader cycles): layer0 %lld bar %lld layer1 %lld bar %lld action+last part 1 %lld bar %lld last parts 2,3+epilogue %lld (10ns units)\n",
-               H, dbg_acc[5], dbg_acc[6], dbg_acc[8], dbg_acc[7], (long long)wall_clock64() - dbg_start, (long long)clock64() - dbg_cyc0, dbg_acc[0], dbg_acc[1], dbg_acc[2], dbg_acc[3], dbg_acc[9], dbg_acc[10], dbg_acc[4]);
+        printf("[q4rdbg] H=%d | small loads issued %lld  operand loads issued %lld  constants+actions %lld  LDS part 2 %lld  first mfma %lld | loop %lld (%lld shader cycles): layer0 %lld bar %lld layer1 %lld bar %lld action+last part 1 %lld bar %lld last parts 2,3+epilogue %lld (10ns units)\n",
+               H, dbg_acc[11], dbg_acc[5], dbg_acc[6], dbg_acc[8], dbg_acc[7], (long long)wall_clock64() - dbg_start, (long long)clock64() - dbg_cyc0, dbg_acc[0], dbg_acc[1], dbg_acc[2], dbg_acc[3], dbg_acc[9], dbg_acc[10], dbg_acc[4]);
         printf("[q4rdbg] shader cycles per step: layer-1 MFMA block (156) %lld | layer-1 reduce+tanh+store %lld | last-layer MFMA block (68) %lld | reduce+epilogue+gather %lld\n",
                dbg_cyc[0] / H, dbg_cyc[1] / H, dbg_cyc[2] / H, dbg_cyc[3] / H);
     }
