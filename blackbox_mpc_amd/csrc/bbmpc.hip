@@ -2522,6 +2522,7 @@ static const float* optimize_host(bbmpc::Engine& e, const float* state, int32_t 
             if (linger_ok) handled = e.resident_step(pin, noise, e.host_seq);
             else e.resident_stop();
         }
+        if (handled) ++e.calls_resident; else ++e.calls_launched;
         if (handled) {
             published = true;
             handled_resident = true;
@@ -2554,6 +2555,7 @@ static const float* optimize_host(bbmpc::Engine& e, const float* state, int32_t 
             throw;
         }
     } else {
+        ++e.calls_launched;
         HIP_CHECK(hipMemcpyAsync(e.d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e.stream));
         e.optimize_dev(e.d_state.p, noise, e.d_record.p, nullptr);
         HIP_CHECK(hipMemcpyAsync(pin + ns, e.d_record.p, nr * 4, hipMemcpyDeviceToHost, e.stream));
@@ -3026,6 +3028,14 @@ int bbmpc_optimize_gather(bbmpc_handle h, const float* state, int32_t, int32_t n
 
 // What the communicator itself reports (ncclCommCount / ncclCommUserRank) + the hand-off mode in use:
 // sync_mode 1 = sequence numbers in signal memory, 0 = events.
+int bbmpc_call_stats(bbmpc_handle h, int64_t* served_resident, int64_t* launched) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    if (served_resident) *served_resident = h->e->calls_resident;
+    if (launched) *launched = h->e->calls_launched;
+    API_END
+}
+
 int bbmpc_comm_info(bbmpc_handle h, int32_t* nranks, int32_t* rank, int32_t* sync_mode) {
     API_BEGIN
     CHECK_HANDLE(h);

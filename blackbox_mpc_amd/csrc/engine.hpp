@@ -189,6 +189,7 @@ struct Engine {
     int mbox_pub_agents = 0;
     int subset_n = 0;                  // > 0: the next persistent-kernel launch covers only the agents listed in amap_host()
     int linger_test_quit = -1;         // BBMPC_LINGER_TEST_QUIT (test hook, kernels_fused.hpp)
+    int64_t calls_resident = 0, calls_launched = 0;   // bbmpc_call_stats
     bool resident_step(const float* state, int add_noise, uint32_t seq);
     void resident_stop();
     hipStream_t pf_stream = nullptr;

@@ -159,6 +159,12 @@ class Engine:
                                                 ctypes.c_void_p(d_next_state or 0), ctypes.c_void_p(d_gathered),
                                                 int(slot)))
 
+    def call_stats(self):
+        """(calls served by the resident kernel of the previous call, calls that launched) -- bbmpc_call_stats."""
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        L.check(L.lib.bbmpc_call_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def comm_info(self):
         """(nranks, rank, sync_mode) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
         n, r, m = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()

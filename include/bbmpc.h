@@ -211,6 +211,12 @@ int bbmpc_reset(bbmpc_handle h);
  * caller waits at most that long.  Results do not depend on it (BBMPC_LINGER_US=0: one launch per call). */
 int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t time_step, int32_t add_exploration_noise,
                    float* action, float* next_state, float* reward);
+/* How the host-in / host-out calls (bbmpc_optimize, bbmpc_optimize_gather) of this handle were served so far: by the
+ * resident kernel of the previous call (request mailbox, no launch) or by launching.  Either pointer may be NULL.
+ * No counterpart in the reference (its act() is one TF graph call per control step, policies/mpc_policy.py:160-164);
+ * exists so that a benchmark can say which of the two paths its number was measured on. */
+int bbmpc_call_stats(bbmpc_handle h, int64_t* served_resident, int64_t* launched);
+
 /* Same with device pointers; record is [A, U+S+1] = (action | next_state | reward) per agent.
  * d_next_state (optional, may be NULL) additionally receives the predicted next state as a contiguous
  * [A,S] tensor, so a closed-loop caller can feed it straight back as the next d_state. */
