@@ -343,6 +343,9 @@ class StubWorkload:
 
     check_gather = Workload.check_gather
 
+    def call_stats(self):
+        return 0, self.tick
+
     def close(self):
         pass
 

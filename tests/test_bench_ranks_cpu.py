@@ -52,6 +52,36 @@ def test_multi_rank_launch_line(nproc, config):
     assert out["value"] > 0 and out["p10_ms"] <= out["median_ms"] <= out["p90_ms"]
 
 
+def test_plain_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what a driver that does not wrap the call would run): the
+    script re-runs itself under torch.distributed.run and rank 0's line comes out of the parent's stdout.  The default
+    configuration (BASELINE configs[1], weak scaling) carries BASELINE configs[2] -- 64 agents in total, 64 / N per GPU --
+    as its `secondary`, and both say how their exchange ran."""
+    env = dict(os.environ, BBMPC_BENCH_BACKEND="gloo", BBMPC_BENCH_STUB="1", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
+                          "--no-cpu-baseline"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "started its own ranks" in out["launch"]
+    assert out["multi_gpu"]["ranks"] == 2 and out["multi_gpu"]["gathered_rows_checked"] > 0
+    for key in ("value_launch_per_call", "resident", "launch_per_call_median_ms"):
+        assert key in out, key
+    sec = out["secondary"]
+    assert sec["scaling"] == "strong" and sec["n_gpus"] == 2 and "64 agents in total, 32 per GPU" in sec["note"]
+    assert sec["multi_gpu"]["ranks"] == 2 and sec["multi_gpu"]["gathered_rows_checked"] == 2 * 2 * 64
+    assert "PI2" in sec["metric"] and sec["value"] > 0
+
+
+def test_world_size_mismatch_is_an_error_message():
+    env = dict(os.environ, BBMPC_BENCH_BACKEND="gloo", BBMPC_BENCH_STUB="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], capture_output=True,
+                         text=True, env=env, cwd=ROOT, timeout=120)
+    assert res.returncode != 0 and "--gpus 2 but the launcher started 1 rank" in (res.stdout + res.stderr)
+
+
 def test_stub_is_refused_outside_gloo():
     env = dict(os.environ, BBMPC_BENCH_STUB="1", BBMPC_BENCH_BACKEND="nccl")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2"], capture_output=True, text=True,
