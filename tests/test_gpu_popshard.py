@@ -142,3 +142,105 @@ def test_population_sharding_argument_checks(L):
     with pytest.raises(L.BBMPCError) as ei:              # sharded, but nobody to exchange with
         eng.optimize(O.pendulum_start_states(1))
     assert ei.value.code == L.E_STATE
+
+
+# ---- the sharded refits held to the ORACLE (pi2.py:80-87, cem.py:97-112), not only to the unsharded engine ------------
+# RNG is keyed by the global particle index, so an unsharded engine with the same seed draws the sharded run's samples:
+# its dumped draws feed the NumPy optimizer (C library doing the 1000 x 30-step rollouts), its per-iteration rewards
+# are checked against the oracle's within the MLP tolerance and carried over (lock-step, as in
+# tests/test_gpu_fullsize.py::test_northstar_mlp_pi2_lockstep_full_size), and the SHARDED engine's refit -- partials,
+# exchange, merge in rank order / global-index top-k -- is compared with the oracle's refit of the same inputs.
+MLP_DIMS, MLP_ACTS = [26, 200, 200, 20], ["tanh", "tanh", None]
+
+
+def _oracle_rollouts(N, k=1, iters=5):
+    from oracle import oracle_c as OC
+    S, U = 20, 6
+    ws, bs = O.make_mlp_params(MLP_DIMS, seed=42)
+    stats = [np.zeros(S, F), np.ones(S, F), np.zeros(U, F), np.ones(U, F), np.zeros(S, F), np.full(S, 0.1, F)]
+    return OC.COracle("mlp", "cheetah", [-1.0] * U, [1.0] * U, N, 1, 30, S, iters=iters, k=max(k, 1),
+                      mlp=(ws, bs, MLP_ACTS), stats=stats)
+
+
+@pytest.mark.parametrize("G", [2, 8])
+def test_sharded_pi2_against_the_oracle_northstar_shape(L, monkeypatch, G):
+    N, A, H, U, iters = 1000, 1, 30, 6, 5
+    lo, hi = [-1.0] * U, [1.0] * U
+    full = _mlp_engine(L, N)
+    monkeypatch.setenv("BBMPC_POPSHARD_LOOPBACK", str(G))
+    shard = _mlp_engine(L, N // G, population_offset=0, population_global=N)
+    monkeypatch.delenv("BBMPC_POPSHARD_LOOPBACK")
+    full.set_trace(True)
+    shard.set_trace(True)
+    co = _oracle_rollouts(N)
+    pi2 = O.PI2(co.as_evaluator(), lo, hi, horizon=H, max_iterations=iters, population=N, num_agents=A, lamda=1.0)
+    RT, AT = 1e-3, 1e-3 * H
+    s = O.cheetah_start_states(1, 20)
+    for t in range(2):                                   # second control step: shift-left warm start (pi2.py:92-93)
+        noise = {"trunc": [full.dump_noise(L.NOISE_TRUNC_NORMAL, t, it, (N, A, H, U)) for it in range(iters)]}
+        a_f, n_f, _ = full.optimize(s, t)
+        a_s, n_s, _ = shard.optimize(s, t)
+        hip_r = [full.get_trace(it, L.TRACE_REWARDS) for it in range(iters)]
+        # the rollouts are the same per particle: the shard last played (particles [N - N/G, N)) shows the unsharded bits
+        # in iteration 0 of the first control step; afterwards the two runs' means differ in the last bits (order of the
+        # fp32 sums), so do their samples and rewards -- by 1e-7 relative, far inside what is carried over below
+        if t == 0:
+            np.testing.assert_array_equal(shard.get_trace(0, L.TRACE_REWARDS), hip_r[0][N - N // G:])
+        for it in range(iters):
+            np.testing.assert_allclose(shard.get_trace(it, L.TRACE_REWARDS), hip_r[it][N - N // G:], rtol=2e-6, atol=2e-3)
+
+        def lock(it, r_o):
+            np.testing.assert_allclose(hip_r[it], r_o, rtol=RT, atol=AT)
+            return hip_r[it]
+        act_o = pi2._optimize(s, noise, rewards_override=lock)
+        for it in range(iters):
+            np.testing.assert_allclose(shard.get_trace(it, L.TRACE_MEAN), pi2.trace[it]["mean"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(a_s, act_o, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(shard.get_state("prev_mean"), pi2.prev, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(n_s, co.predict_next_state(s, act_o), rtol=2e-5, atol=2e-4)
+        s = n_f
+
+
+@pytest.mark.parametrize("G", [2, 8])
+def test_sharded_cem_against_the_oracle_config4_shape(L, monkeypatch, G):
+    from blackbox_mpc_amd.engine import Engine
+    N, A, H, U, iters, k, S = 1000, 1, 30, 6, 5, 50, 20
+    lo, hi = [-1.0] * U, [1.0] * U
+    ws, bs = O.make_mlp_params(MLP_DIMS, seed=42)
+    stats = [np.zeros(S, F), np.ones(S, F), np.zeros(U, F), np.ones(U, F), np.zeros(S, F), np.full(S, 0.1, F)]
+
+    def mk(n, **kw):
+        e = Engine(L.OPT_CEM, L.DYN_MLP, L.REW_CHEETAH, lo, hi, dim_s=S, num_agents=1, planning_horizon=H,
+                   population_size=n, max_iterations=iters, num_elite=k, alpha=0.25, seed=4, **kw)
+        e.set_mlp(ws, bs, [1, 1, 0], stats)
+        e.set_trace(True)
+        return e
+    full = mk(N)
+    monkeypatch.setenv("BBMPC_POPSHARD_LOOPBACK", str(G))
+    shard = mk(N // G, population_global=N)
+    monkeypatch.delenv("BBMPC_POPSHARD_LOOPBACK")
+    co = _oracle_rollouts(N, k=k)
+    cem = O.CEM(co.as_evaluator(), lo, hi, horizon=H, max_iterations=iters, population=N, num_elite=k, num_agents=A, alpha=0.25)
+    RT, AT = 1e-3, 1e-3 * H
+    s = O.cheetah_start_states(1, S)
+    for t in range(2):
+        noise = {"trunc": [full.dump_noise(L.NOISE_TRUNC_NORMAL, t, it, (N, A, H, U)) for it in range(iters)]}
+        a_f, n_f, _ = full.optimize(s, t)
+        a_s, n_s, _ = shard.optimize(s, t)
+        hip_r = [full.get_trace(it, L.TRACE_REWARDS) for it in range(iters)]
+
+        def elites(it, r_o, own):
+            # this oracle's rewards against the device's, then the elite set tf.nn.top_k takes from the DEVICE's rewards
+            # (ties: lower index first), so that near-ties at the k-th place cannot split the two refits
+            np.testing.assert_allclose(hip_r[it], r_o, rtol=RT, atol=AT)
+            return O.topk_desc(hip_r[it].T, k)
+        act_o = cem._optimize(s, noise, forced_elites=elites)
+        for it in range(iters):
+            # the sharded elite set, by GLOBAL particle index, is that set
+            want = O.topk_desc(hip_r[it][:, 0], k)
+            assert set(shard.get_trace(it, L.TRACE_ELITES)[0].tolist()) == set(np.asarray(want).tolist())
+            np.testing.assert_allclose(shard.get_trace(it, L.TRACE_MEAN), cem.trace[it]["mean"], rtol=0, atol=1e-4)
+            np.testing.assert_allclose(shard.get_trace(it, L.TRACE_VAR), cem.trace[it]["var"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(a_s, act_o, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(n_s, co.predict_next_state(s, act_o), rtol=2e-5, atol=2e-4)
+        s = n_f
