@@ -3,7 +3,8 @@
 The reference ships no golden vectors and cannot be executed here (TensorFlow 2.0 absent), so these fixtures
 are ORACLE outputs, committed to (a) freeze the oracle against accidental change (CPU test) and (b) give the
 GPU tests a fixed set of expected values that does not depend on the oracle code that runs on the GPU box.
-Shrunken versions of BASELINE configs 1-5.  Run from the repo root:  python tests/golden/make_golden.py
+Shrunken versions of BASELINE configs 1-5, plus cfg6 (SPSA) and cfg7 (CMA-ES iteration 0).  Run from the repo root:
+python tests/golden/make_golden.py [cfgN ...]   (no argument: rewrite every fixture)
 """
 import os
 import sys
@@ -89,7 +90,37 @@ def main():
     out["cfg5"] = dict(states=st, reset_pos=rn["uniform_pos"], reset_vel=rn["uniform_vel"], normal2=noise["normal2"],
                        trunc=noise["trunc"], uniform=noise["uniform"], action=a, pos=pso.pos, vel=pso.vel,
                        gbest=pso.gbest, rewards=np.stack([t["rewards"] for t in pso.trace]))
+    # cfg6: SPSA on pendulum (spsa.py:61-117), 3 agents, two control steps (shift-left warm start :114-115)
+    rng = np.random.default_rng(106)
+    N, A, H, iters = 64, 3, 10, 3
+    st = O.pendulum_start_states(A)
+    spsa = O.SPSA(pend_eval(), [-2.0], [2.0], horizon=H, max_iterations=iters, population=N, num_agents=A)
+    rads, acts, params, ghats = [], [], [], []
+    for step in range(2):
+        rad = (rng.integers(0, 2, (iters, N, A, H, 1)) * 2 - 1).astype(F)
+        a, n, r = spsa.call(st, {"rademacher": list(rad)})
+        rads.append(rad); acts.append(a); params.append(spsa.params.copy())
+        ghats.append(np.stack([t["ghat"] for t in spsa.trace]))
+    out["cfg6"] = dict(states=st, rademacher=np.stack(rads), action=np.stack(acts), params=np.stack(params),
+                       ghat=np.stack(ghats))
+    # cfg7: CMA-ES on pendulum (cma_es.py:129-213), coupled agents, ONE iteration from the constructor state (B = D = I,
+    # so the samples do not depend on anybody's SVD conventions) + the deterministic (m, p_sigma, sigma, p_C, C) update;
+    # D = sqrt(singular values of C), descending, is convention-free as well
+    rng = np.random.default_rng(107)
+    N, A, H, k = 96, 2, 6, 12
+    n = A * H * 1
+    st = O.pendulum_start_states(A)
+    z = rng.standard_normal((1, N, n)).astype(F)
+    cma = O.CMAES(pend_eval(), [-2.0], [2.0], horizon=H, max_iterations=1, population=N, num_elite=k, num_agents=A)
+    a, nx, r = cma.call(st, {"normal": list(z)})
+    tr = cma.trace[0]
+    out["cfg7"] = dict(states=st, normal=z, action=a, next_state=nx, reward=r, samples=tr["samples"], rewards=tr["rewards"],
+                       order=tr["order"][:k].astype(np.int32), m=tr["m"], sigma=tr["sigma"], p_sigma=tr["p_sigma"], p_C=tr["p_C"],
+                       C=tr["C"], D=np.diag(cma.D).copy())
+    only = set(sys.argv[1:])
     for name, d in out.items():
+        if only and name not in only:
+            continue
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
         print(name, {k_: np.asarray(v).shape for k_, v in d.items()})
 

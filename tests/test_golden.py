@@ -52,6 +52,36 @@ def test_oracle_reproduces_golden_cfg4():
     np.testing.assert_array_equal(ev.predict_next_state(g["step_states"], g["step_actions"]), g["step_next"])
 
 
+def test_oracle_reproduces_golden_cfg5_cfg6_cfg7():
+    g = load("cfg5")
+    pso = O.PSO(_pend_eval(), [-2.0], [2.0], horizon=8, max_iterations=3, population=96, num_agents=2)
+    pso.reset({"uniform_pos": g["reset_pos"], "uniform_vel": g["reset_vel"]})
+    a, _, _ = pso.call(g["states"], {"normal2": g["normal2"], "trunc": g["trunc"], "uniform": g["uniform"]})
+    np.testing.assert_array_equal(a, g["action"])
+    np.testing.assert_array_equal(pso.pos, g["pos"])
+    np.testing.assert_array_equal(pso.vel, g["vel"])
+    g = load("cfg6")                                     # SPSA, spsa.py:61-117, two control steps
+    spsa = O.SPSA(_pend_eval(), [-2.0], [2.0], horizon=10, max_iterations=3, population=64, num_agents=3)
+    for step in range(2):
+        a, _, _ = spsa.call(g["states"], {"rademacher": list(g["rademacher"][step])})
+        np.testing.assert_array_equal(a, g["action"][step])
+        np.testing.assert_array_equal(spsa.params, g["params"][step])
+        np.testing.assert_array_equal(np.stack([t["ghat"] for t in spsa.trace]), g["ghat"][step])
+    g = load("cfg7")                                     # CMA-ES, cma_es.py:129-213, iteration 0 from B = D = I
+    cma = O.CMAES(_pend_eval(), [-2.0], [2.0], horizon=6, max_iterations=1, population=96, num_elite=12, num_agents=2)
+    a, n, r = cma.call(g["states"], {"normal": list(g["normal"])})
+    tr = cma.trace[0]
+    np.testing.assert_array_equal(a, g["action"])
+    np.testing.assert_array_equal(tr["samples"], g["samples"])
+    np.testing.assert_array_equal(tr["order"][:12], g["order"])
+    for key in ("m", "sigma", "p_sigma", "p_C", "C"):
+        np.testing.assert_array_equal(tr[key], g[key])
+    np.testing.assert_array_equal(np.diag(cma.D), g["D"])
+    # what the fixture is worth: with B = D = I the samples are m + sigma * z, whoever's SVD conventions follow
+    z = g["normal"][0].reshape(96, 2, 6, 1)
+    np.testing.assert_array_equal(np.clip((z * F(1.0)).astype(F) + F(0.0), -2.0, 2.0).astype(F), g["samples"])
+
+
 # ---------------------------------------------------------------- GPU: engine vs golden
 @pytest.fixture(scope="module")
 def L():
@@ -141,3 +171,42 @@ def test_gpu_matches_golden_cfg5_pso_swarm(L):
     np.testing.assert_allclose(eng.get_state("pos", (96, 2, 8, 1)), g["pos"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(eng.get_state("vel", (96, 2, 8, 1)), g["vel"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(eng.get_state("gbest"), g["gbest"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_gpu_matches_golden_cfg6_spsa(L, monkeypatch, fused):
+    monkeypatch.setenv("BBMPC_FUSED", fused)
+    g = load("cfg6")
+    eng = _pend_engine(L, L.OPT_SPSA, 3, 10, N=64, iters=3)
+    eng.set_trace(True)
+    for step in range(2):
+        eng.inject_noise(L.NOISE_RADEMACHER, g["rademacher"][step])
+        a, _, _ = eng.optimize(g["states"])
+        np.testing.assert_allclose(a, g["action"][step], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(eng.get_state("prev_mean"), g["params"][step], rtol=0, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_matches_golden_cfg7_cmaes_iteration0(L):
+    g = load("cfg7")
+    N, A, H, k = 96, 2, 6, 12
+    n = A * H
+    eng = _pend_engine(L, L.OPT_CMAES, A, H, N=N, iters=1, k=k)
+    eng.set_trace(True)
+    eng.inject_noise(L.NOISE_NORMAL, g["normal"].reshape(1, N, A, H, 1))
+    a, nx, r = eng.optimize(g["states"])
+    np.testing.assert_allclose(eng.get_trace(0, L.TRACE_SAMPLES), g["samples"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(eng.get_trace(0, L.TRACE_REWARDS), g["rewards"], rtol=2e-4, atol=2e-3)
+    hip_order = eng.get_trace(0, L.TRACE_ELITES)[0]
+    rsum = g["rewards"].sum(axis=1)
+    for a_, b_ in zip(g["order"], hip_order):            # only near-ties may swap
+        assert a_ == b_ or abs(rsum[a_] - rsum[b_]) <= 2e-3 * A + 2e-4 * abs(rsum[a_])
+    st = lambda name, shape: eng.get_state(name, shape)
+    np.testing.assert_allclose(st("m", (n,)), g["m"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(st("sigma", (n,)), g["sigma"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(st("p_sigma", (n,)), g["p_sigma"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(st("p_C", (n,)), g["p_C"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(st("C", (1, n, n))[0], g["C"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(st("D", (n,)), g["D"], rtol=1e-4, atol=2e-5)          # sqrt of the singular values, descending
+    np.testing.assert_allclose(a, g["action"], rtol=0, atol=2e-5)

@@ -11,8 +11,8 @@ This script is what closes that gap on any machine that has the reference's own 
 
 It imports the reference, replaces `tf.random.truncated_normal / uniform / normal` by functions that hand out the
 fixtures' injected standard draws in call order (scaled and shifted exactly as TF's own would be:
-`mean + stddev * z`, `minval + (maxval - minval) * u`), runs the reference's own RandomSearch / CEM / PI2 / PSO
-optimizers and DeterministicTrajectoryEvaluator on the fixtures' inputs, and diffs every stored output against
+`mean + stddev * z`, `minval + (maxval - minval) * u`), runs the reference's own RandomSearch / CEM / PI2 / PSO /
+SPSA / CMA-ES optimizers and DeterministicTrajectoryEvaluator on the fixtures' inputs, and diffs every stored output against
 `tests/golden/`.  Exit codes: 0 = every fixture reproduced within tolerance (parity PINNED: record the printed
 summary in DESIGN.md), 1 = a mismatch (the oracle is wrong somewhere: the diff says where), 3 = tensorflow or the
 reference is not importable here -- said LOUDLY, nothing is compared, parity stays unpinned.
@@ -137,6 +137,8 @@ def main():
         from blackbox_mpc.dynamics_functions.deterministic_mlp import DeterministicMLP
         from blackbox_mpc.dynamics_handlers.system_dynamics_handler import SystemDynamicsHandler
         from blackbox_mpc.optimizers.cem import CEMOptimizer
+        from blackbox_mpc.optimizers.cma_es import CMAESOptimizer
+        from blackbox_mpc.optimizers.spsa import SPSAOptimizer
         from blackbox_mpc.optimizers.pi2 import PI2Optimizer
         from blackbox_mpc.optimizers.pso import PSOOptimizer
         from blackbox_mpc.optimizers.random_search import RandomSearchOptimizer
@@ -240,6 +242,35 @@ def main():
     rep.check("cfg5", "pos", opt._particle_positions.numpy(), g["pos"], atol=2e-5)
     rep.check("cfg5", "vel", opt._particle_velocities.numpy(), g["vel"], atol=2e-5)
     rep.check("cfg5", "gbest", opt._global_best_known_position.numpy(), g["gbest"], atol=2e-5)
+    # ---- cfg6: SPSA (spsa.py:61-117), two control steps with the shift-left warm start (:114-115) --------------------
+    g = load("cfg6")
+    opt = SPSAOptimizer(act_space, obs_space, planning_horizon=10, max_iterations=3, population_size=64, num_agents=3)
+    opt.set_trajectory_evaluator(pend_evaluator())
+    for step in range(2):
+        for it in range(3):                                     # :73-75 the int32 {0, 1} draw, mapped to -1 / +1 by the reference
+            nq.push("uniform", g["rademacher"][step][it])
+        a, _, _ = call(opt, g["states"])
+        nq.assert_drained("cfg6 step %d" % step)
+        rep.check("cfg6", "action[step %d]" % step, a, g["action"][step], atol=1e-4)
+        rep.check("cfg6", "params[step %d]" % step, opt._current_parameters.numpy(), g["params"][step], atol=1e-4)
+    # ---- cfg7: CMA-ES (cma_es.py:129-213), ONE iteration from the constructor state: B = D = I, so the samples and the
+    # (m, p_sigma, sigma, p_C, C) update do not depend on tf.linalg.svd's conventions; D = sqrt(singular values) neither
+    g = load("cfg7")
+    opt = CMAESOptimizer(act_space, obs_space, planning_horizon=6, max_iterations=1, population_size=96, num_elite=12,
+                         num_agents=2)
+    opt.set_trajectory_evaluator(pend_evaluator())
+    nq.push("normal", g["normal"][0])
+    a, n, r = call(opt, g["states"])
+    nq.assert_drained("cfg7")
+    rep.check("cfg7", "action", a, g["action"], atol=2e-5)
+    rep.check("cfg7", "next_state", n, g["next_state"], rtol=1e-5, atol=1e-5)
+    rep.check("cfg7", "x_sorted[:k] (samples in rank order)", opt._x_sorted.numpy()[:12], g["samples"][g["order"]], atol=2e-5)
+    rep.check("cfg7", "m", opt._m.numpy(), g["m"], atol=2e-5)
+    rep.check("cfg7", "sigma", opt._sigma.numpy(), g["sigma"], rtol=2e-5, atol=1e-6)
+    rep.check("cfg7", "p_sigma", opt._p_sigma.numpy(), g["p_sigma"], rtol=1e-4, atol=2e-5)
+    rep.check("cfg7", "p_C", opt._p_C.numpy(), g["p_C"], rtol=1e-4, atol=2e-5)
+    rep.check("cfg7", "C", opt._C.numpy(), g["C"], rtol=1e-4, atol=2e-5)
+    rep.check("cfg7", "diag(D)", np.diag(opt._D.numpy()), g["D"], rtol=1e-4, atol=2e-5)
     nq.restore()
 
     w = max(len(r[1]) for r in rep.rows)
