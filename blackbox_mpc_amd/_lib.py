@@ -67,9 +67,13 @@ SYMBOLS = [
     "bbmpc_comm_unique_id", "bbmpc_comm_init", "bbmpc_gather_records_dev", "bbmpc_gather_wait", "bbmpc_comm_destroy",
     "bbmpc_optimize_gather_dev", "bbmpc_set_stream_default", "bbmpc_optimize_gather", "bbmpc_comm_info", "bbmpc_call_stats",
     "bbmpc_set_reward_source", "bbmpc_set_dynamics_source", "bbmpc_check_user_source", "bbmpc_mlp_forward",
+    "bbmpc_set_reward_callback", "bbmpc_set_dynamics_callback",
     "bbmpc_process_input", "bbmpc_process_output", "bbmpc_check_user_rollout",
 ]
 COMM_ID_BYTES = 128
+# bbmpc_rows_callback (include/bbmpc.h): user, d_cur, d_actions, d_next, batch, d_out, hip_stream -> status
+ROWS_CALLBACK = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                 ctypes.c_void_p, ctypes.c_void_p)
 
 
 def _load():
@@ -126,6 +130,8 @@ def _load():
     lib.bbmpc_call_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.bbmpc_set_reward_source.argtypes = [vp, ctypes.c_char_p]
     lib.bbmpc_set_dynamics_source.argtypes = [vp, ctypes.c_char_p]
+    lib.bbmpc_set_reward_callback.argtypes = [vp, ROWS_CALLBACK, vp]
+    lib.bbmpc_set_dynamics_callback.argtypes = [vp, ROWS_CALLBACK, vp]
     lib.bbmpc_check_user_source.argtypes = [i32, ctypes.c_char_p, i32, i32]
     lib.bbmpc_mlp_forward.argtypes = [vp, vp, i32, vp]
     lib.bbmpc_check_user_rollout.argtypes = [i32, i32, ctypes.c_char_p, ctypes.c_char_p, i32, i32]
@@ -137,9 +143,19 @@ def _load():
 lib = _load()
 
 
+# an exception raised inside a Python callback the engine called (utils/device_functions.py): the C ABI can only carry a
+# status code, so the callback parks it here and check() re-raises it as the cause
+callback_error = None
+
+
 def check(code):
+    global callback_error
     if code != 0:
-        raise BBMPCError(code, lib.bbmpc_last_error().decode("utf-8", "replace"))
+        err = BBMPCError(code, lib.bbmpc_last_error().decode("utf-8", "replace"))
+        cause, callback_error = callback_error, None
+        if cause is not None:
+            raise err from cause
+        raise err
 
 
 def device_count():

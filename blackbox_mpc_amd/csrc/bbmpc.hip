@@ -958,13 +958,43 @@ void Engine::set_user_source(int kind, const char* src) {
     HIP_CHECK(hipModuleGetFunction(&f.fn, f.module, kind == USER_KIND_REWARD ? "bbmpc_user_reward_rows" : "bbmpc_user_dynamics_rows"));
     if (kind == USER_KIND_REWARD) HIP_CHECK(hipModuleGetFunction(&f.fn_traj, f.module, "bbmpc_user_reward_traj"));
     f.source = src;
+    f.cb = nullptr; f.cb_user = nullptr;
     user_rollout_stale = true;
+}
+
+void Engine::set_user_callback(int kind, bbmpc_rows_callback fn, void* user) {
+    if (kind == USER_KIND_REWARD) REQUIRE(cfg.reward == BBMPC_REW_USER, BBMPC_E_STATE, "handle was not created with BBMPC_REW_USER");
+    else REQUIRE(cfg.dynamics == BBMPC_DYN_USER, BBMPC_E_STATE, "handle was not created with BBMPC_DYN_USER");
+    HIP_CHECK(hipStreamSynchronize(stream));
+    UserFunction& f = kind == USER_KIND_REWARD ? user_reward : user_dynamics;
+    if (fn) { f.release(); f.source.clear(); }
+    f.cb = fn;
+    f.cb_user = fn ? user : nullptr;
+    user_rollout_stale = true;
+}
+
+// total (+)= the rewards a callback wrote for one batch of rows
+__global__ void k_rows_accumulate(const float* __restrict__ r, int batch, float* __restrict__ total, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < batch) total[i] = accumulate ? total[i] + r[i] : r[i];
 }
 
 // next = process_output(state, dynamics(process_input(state, action)))  on [batch] rows   deterministic.py:79-103
 void Engine::dynamics_rows(const float* d_states, const float* d_actions, int astride, int batch, float* d_next) {
+    if (cfg.dynamics == BBMPC_DYN_USER && user_dynamics.cb) {
+        const float* acts_c = d_actions;
+        if (astride != U) {                               // the callback sees a dense [batch, U] block
+            if (d_step_act.n < (size_t)batch * U) d_step_act.alloc((size_t)batch * U);
+            HIP_CHECK(hipMemcpy2DAsync(d_step_act.p, (size_t)U * 4, d_actions, (size_t)astride * 4, (size_t)U * 4, batch,
+                                       hipMemcpyDeviceToDevice, stream));
+            acts_c = d_step_act.p;
+        }
+        if (user_dynamics.cb(user_dynamics.cb_user, d_states, acts_c, nullptr, batch, d_next, (void*)stream) != 0)
+            throw HipError(BBMPC_E_INVALID, "the dynamics callback reported an error");
+        return;
+    }
     if (cfg.dynamics == BBMPC_DYN_USER) {
-        REQUIRE(user_dynamics.fn, BBMPC_E_STATE, "user dynamics: call bbmpc_set_dynamics_source before computing");
+        REQUIRE(user_dynamics.fn, BBMPC_E_STATE, "user dynamics: call bbmpc_set_dynamics_source (or bbmpc_set_dynamics_callback) before computing");
         void* args[] = {(void*)&d_states, (void*)&d_actions, (void*)&astride, (void*)&batch, (void*)&d_next};
         HIP_CHECK(hipModuleLaunchKernel(user_dynamics.fn, (unsigned)((batch + 255) / 256), 1, 1, 256, 1, 1, 0, stream, args, nullptr));
         return;
@@ -981,8 +1011,23 @@ void Engine::dynamics_rows(const float* d_states, const float* d_actions, int as
 // total (+)= reward_function(cur, actions, next) on [batch] rows   deterministic.py:65-66, 105-127
 void Engine::reward_rows(const float* d_cur, const float* d_next, const float* d_actions, int astride, int batch, float* d_total,
                          int accumulate) {
+    if (cfg.reward == BBMPC_REW_USER && user_reward.cb) {
+        const float* acts_c = d_actions;
+        if (astride != U) {
+            if (d_step_act.n < (size_t)batch * U) d_step_act.alloc((size_t)batch * U);
+            HIP_CHECK(hipMemcpy2DAsync(d_step_act.p, (size_t)U * 4, d_actions, (size_t)astride * 4, (size_t)U * 4, batch,
+                                       hipMemcpyDeviceToDevice, stream));
+            acts_c = d_step_act.p;
+        }
+        if (u_cb_rew.n < (size_t)batch) u_cb_rew.alloc((size_t)batch);
+        if (user_reward.cb(user_reward.cb_user, d_cur, acts_c, d_next, batch, u_cb_rew.p, (void*)stream) != 0)
+            throw HipError(BBMPC_E_INVALID, "the reward callback reported an error");
+        hipLaunchKernelGGL(k_rows_accumulate, dim3((batch + 255) / 256), dim3(256), 0, stream, u_cb_rew.p, batch, d_total, accumulate);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (cfg.reward == BBMPC_REW_USER) {
-        REQUIRE(user_reward.fn, BBMPC_E_STATE, "user reward: call bbmpc_set_reward_source before computing");
+        REQUIRE(user_reward.fn, BBMPC_E_STATE, "user reward: call bbmpc_set_reward_source (or bbmpc_set_reward_callback) before computing");
         void* args[] = {(void*)&d_cur, (void*)&d_next, (void*)&d_actions, (void*)&astride, (void*)&batch, (void*)&d_total, (void*)&accumulate};
         HIP_CHECK(hipModuleLaunchKernel(user_reward.fn, (unsigned)((batch + 255) / 256), 1, 1, 256, 1, 1, 0, stream, args, nullptr));
         return;
@@ -1123,7 +1168,10 @@ void Engine::mlp_forward_rows(const float* d_x, int batch, float* d_out) {
 
 void Engine::launch_rollout(int mode, bool pen, RolloutArgs& ra) {
     if (user_path()) {
-        if (cfg.dynamics != BBMPC_DYN_MLP && !user_stepwise_only) {
+        if (user_callbacks()) {                           // a host callback per planning step: step-wise only
+            dominant_kernel = "stepwise(user callback)";
+            rollout_stepwise(mode, pen, ra);
+        } else if (cfg.dynamics != BBMPC_DYN_MLP && !user_stepwise_only) {
             dominant_kernel = "bbmpc_user_rollout(hiprtc)";
             rollout_user_fused(mode, pen, ra);
         } else if (cfg.dynamics == BBMPC_DYN_MLP && !user_stepwise_only) {
@@ -2354,6 +2402,20 @@ int bbmpc_set_reward_source(bbmpc_handle h, const char* src) {
     CHECK_HANDLE(h);
     CHECK_PTR(src);
     h->e->set_user_source(bbmpc::USER_KIND_REWARD, src);
+    API_END
+}
+
+int bbmpc_set_reward_callback(bbmpc_handle h, bbmpc_rows_callback fn, void* user) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    h->e->set_user_callback(bbmpc::USER_KIND_REWARD, fn, user);
+    API_END
+}
+
+int bbmpc_set_dynamics_callback(bbmpc_handle h, bbmpc_rows_callback fn, void* user) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    h->e->set_user_callback(bbmpc::USER_KIND_DYNAMICS, fn, user);
     API_END
 }
 

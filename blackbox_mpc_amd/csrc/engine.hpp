@@ -229,6 +229,9 @@ struct Engine {
     bool user_path() const { return cfg.reward == BBMPC_REW_USER || cfg.dynamics == BBMPC_DYN_USER; }
     int builtin_reward_kind() const { return cfg.reward == BBMPC_REW_USER ? REW_NONE : cfg.reward; }
     void set_user_source(int kind, const char* src);
+    void set_user_callback(int kind, bbmpc_rows_callback fn, void* user);
+    bool user_callbacks() const { return user_reward.cb != nullptr || user_dynamics.cb != nullptr; }
+    DevBuf<float> u_cb_rew;            // rewards of one planning step as a callback wrote them
     void rollout_stepwise(int mode, bool pen, RolloutArgs& ra);
     void dynamics_rows(const float* d_states, const float* d_actions, int astride, int batch, float* d_next);
     void reward_rows(const float* d_cur, const float* d_next, const float* d_actions, int astride, int batch, float* d_total, int accumulate);

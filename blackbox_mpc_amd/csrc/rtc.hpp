@@ -12,6 +12,7 @@
 // run time, next to the HIP runtime the process already uses; compiling needs no GPU.
 #pragma once
 #include <dlfcn.h>
+#include "../../include/bbmpc.h"   // bbmpc_rows_callback
 #include <hip/hip_runtime.h>
 
 #include <stdexcept>
@@ -263,6 +264,9 @@ struct UserFunction {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
     hipFunction_t fn_traj = nullptr;       // reward module only: bbmpc_user_reward_traj
+    bbmpc_rows_callback cb = nullptr;      // or: a host callback working on device memory (bbmpc_set_*_callback)
+    void* cb_user = nullptr;
+    bool ready() const { return fn != nullptr || cb != nullptr; }
     void release() {
         if (module) (void)hipModuleUnload(module);
         module = nullptr;

@@ -16,8 +16,11 @@ class SystemDynamicsHandler:
     def __init__(self, env_action_space, env_observation_space, dynamics_function=None, true_model=False,
                  is_normalized=True, log_dir=None, tf_writer=None, save_model_frequency=1, saved_model_dir=None,
                  transform_targets_func=None, inverse_transform_targets_func=None):
-        if transform_targets_func is not None or inverse_transform_targets_func is not None:
-            raise NotImplementedError("only the default delta target transform (next = state + delta) is built")
+        # custom target transforms (reference :128-161 applies inverse_transform_targets_func(states, raw)): honoured on the
+        # torch-callable path, where process_output runs in torch (utils/device_functions.py); the built-in and HIP-source
+        # models fuse the default delta transform and refuse a custom one (trajectory_evaluators/deterministic.py)
+        self._transform_targets_func = transform_targets_func
+        self._inverse_transform_targets_func = inverse_transform_targets_func
         self._is_true_model = bool(true_model)
         self._dim_S = int(env_observation_space.shape[0])
         self._dim_U = int(env_action_space.shape[0])
@@ -152,6 +155,8 @@ class SystemDynamicsHandler:
         (the reference's callers only ever pass tf.keras.optimizers.Adam).  Keyword-only extras: `device` (default: the GPU -- training on the
         host has to be asked for explicitly with device="cpu"), and the injected random draws `split_mask`,
         `permutations` (one per epoch) / `seed` for reproducible runs."""
+        if self._transform_targets_func is not None:
+            raise NotImplementedError("training with a custom transform_targets_func is not built (default: next - state)")
         if self._is_true_model:
             raise Exception("the true model has nothing to train")
         # the reference instantiates `nn_optimizer(learning_rate=learning_rate)` (:261): a Keras optimizer CLASS (or its

@@ -45,6 +45,17 @@ class Engine:
         self.k = c.num_elite
         L.check(L.lib.bbmpc_create(ctypes.byref(c), ctypes.byref(self._h)))
 
+    @property
+    def device(self):
+        """The GPU this handle lives on (bbmpc_config.device; -1 = the process's current device)."""
+        if self.cfg.device >= 0:
+            return int(self.cfg.device)
+        try:
+            import torch
+            return int(torch.cuda.current_device())
+        except Exception:                                 # noqa: BLE001
+            return 0
+
     # -- lifecycle -------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -97,6 +108,16 @@ class Engine:
     def set_dynamics_source(self, hip_source):
         """HIP source defining `__device__ void bbmpc_user_dynamics(x, delta, S, U)` (include/bbmpc.h)."""
         L.check(L.lib.bbmpc_set_dynamics_source(self._h, hip_source.encode()))
+
+    def set_reward_callback(self, fn):
+        """fn(d_cur, d_actions, d_next, batch, d_out, hip_stream) -> status, all device pointers (include/bbmpc.h
+        bbmpc_rows_callback); `fn` is an _lib.ROWS_CALLBACK the caller keeps alive; None clears it."""
+        self._rew_cb = fn
+        L.check(L.lib.bbmpc_set_reward_callback(self._h, fn if fn is not None else L.ROWS_CALLBACK(), None))
+
+    def set_dynamics_callback(self, fn):
+        self._dyn_cb = fn
+        L.check(L.lib.bbmpc_set_dynamics_callback(self._h, fn if fn is not None else L.ROWS_CALLBACK(), None))
 
     def mlp_forward(self, x):
         """DeterministicMLP.__call__ on the device: raw Dense stack on processed inputs [B, S+U] -> [B, S]."""

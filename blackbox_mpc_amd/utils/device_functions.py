@@ -17,7 +17,19 @@ source compiled at run time (hiprtc) and called per row from the engine's step-w
 Argument order of the reward is the order of the reference's CALL, `reward_function(current_state, actions,
 next_state)` (deterministic.py:65-66).  A user dynamics function is a true model: it returns the state delta and the
 handler adds the state back (utils/transforms.py:34).  Both objects are also directly callable with NumPy batches
-(they run the same device code through the C ABI), like the built-in plug-ins."""
+(they run the same device code through the C ABI), like the built-in plug-ins.
+
+PLAIN CALLABLES (what the reference's users pass) are accepted when they work on PyTorch tensors on the GPU -- the
+counterpart of the reference's TensorFlow callables:
+
+    reward = lambda cur, act, nxt: -(cur[:, 0] ** 2) - 0.1 * act[:, 0] ** 2          # torch ops on [B,S] / [B,U] / [B,S]
+    dynamics = torch.nn.Sequential(...).cuda()                                       # f(x[B,S+U]) -> [B,S]
+
+The engine then evaluates step by step (SURVEY.md H5's unfused fallback) and calls back once per planning step with
+the row batches of its own HBM buffers aliased as torch tensors (TorchRewardFunction / TorchDynamicsFunction below,
+bbmpc_set_*_callback in include/bbmpc.h); the torch work is enqueued on the engine's stream, nothing is copied to the
+host.  Slower than device code (2 * H + 2 launches plus the framework's per-op overhead) but never on the CPU.  A callable
+that cannot take CUDA tensors is refused (NotImplementedError), as before."""
 import numpy as np
 
 from .. import _lib as L
@@ -82,3 +94,166 @@ class HipDynamicsFunction(_HipFunction):
             raise ValueError("calling a HipDynamicsFunction directly needs dim_s / dim_u (constructor) to split x")
         s, a = x[:, :dim_s], x[:, dim_s:dim_s + dim_u]
         return self._engine(dim_s, dim_u).predict_next_state(s, a) - s
+
+
+# ---- plain callables on torch CUDA tensors --------------------------------------------------------------------------------
+class _DeviceBlock:
+    """A float32 block of the engine's device memory as an object torch.as_tensor aliases without a copy."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+class _TorchCallback:
+    """Common half of the two adapters: the ctypes callback, the torch stream that IS the engine's stream, error parking."""
+
+    def __init__(self, fn):
+        if not callable(fn):
+            raise TypeError("expected a callable, got %r" % (fn,))
+        self.fn = fn
+        self._streams = {}
+        self._engines = {}
+
+    def _alias(self, torch, ptr, shape, device):
+        return torch.as_tensor(_DeviceBlock(ptr, shape), device=device)
+
+    def _stream(self, torch, ptr, device):
+        st = self._streams.get(ptr)
+        if st is None:
+            st = self._streams[ptr] = torch.cuda.ExternalStream(int(ptr), device=device) if ptr else torch.cuda.default_stream(device)
+        return st
+
+    def _guard(self, body):
+        def cb(user, d_cur, d_act, d_next, batch, d_out, stream):
+            try:
+                body(d_cur, d_act, d_next, int(batch), d_out, stream or 0)
+                return 0
+            except BaseException as ex:                   # noqa: BLE001 -- nothing may unwind through the C frames
+                L.callback_error = ex
+                return 1
+        return L.ROWS_CALLBACK(cb)
+
+    @staticmethod
+    def _result(torch, r, shape, what):
+        if not torch.is_tensor(r) or not r.is_cuda:
+            raise TypeError("%s must return a torch tensor on the GPU, got %s" % (what, type(r).__name__))
+        return r.to(torch.float32).reshape(shape)
+
+
+class TorchRewardFunction(_TorchCallback):
+    """reward_function(current_state[B,S], actions[B,U], next_state[B,S]) -> [B] on torch CUDA tensors
+    (the argument order of the reference's call, deterministic.py:65-66)."""
+    _bbmpc_reward_kind = L.REW_USER
+
+    def make_callback(self, dim_s, dim_u, device):
+        import torch
+        dev = torch.device("cuda", int(device))
+
+        def body(d_cur, d_act, d_next, batch, d_out, stream):
+            with torch.cuda.stream(self._stream(torch, stream, dev)):
+                cur = self._alias(torch, d_cur, (batch, dim_s), dev)
+                act = self._alias(torch, d_act, (batch, dim_u), dev)
+                nxt = self._alias(torch, d_next, (batch, dim_s), dev)
+                out = self._alias(torch, d_out, (batch,), dev)
+                out.copy_(self._result(torch, self.fn(cur, act, nxt), (batch,), "reward_function"))
+        return self._guard(body)
+
+    def probe(self, dim_s, dim_u, device):
+        import torch
+        dev = torch.device("cuda", int(device))
+        z = lambda *shape: torch.zeros(shape, device=dev)
+        self._result(torch, self.fn(z(2, dim_s), z(2, dim_u), z(2, dim_s)), (2,), "reward_function")
+
+    def __call__(self, current_state, actions, next_state):
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = lambda v: torch.as_tensor(np.asarray(v, np.float32), device=dev)
+        return self.fn(t(current_state), t(actions), t(next_state)).to(torch.float32).cpu().numpy()
+
+
+def call_torch_dynamics(fn, x):
+    """dynamics_function(x, train=False) (deterministic.py:99-100); a torch.nn.Module takes x alone."""
+    import torch
+    if isinstance(fn, torch.nn.Module):
+        return fn(x)
+    try:
+        return fn(x, False)
+    except TypeError:
+        return fn(x)
+
+
+class TorchDynamicsFunction(_TorchCallback):
+    """dynamics_function(x[B,S+U], train) -> raw[B,S] on torch CUDA tensors; the handler's process_input / process_output
+    (system_dynamics_handler.py:97-161, utils/transforms.py:20-34) run around it in torch, on the same stream."""
+    _bbmpc_dynamics_kind = L.DYN_USER
+
+    def make_callback(self, handler, device):
+        import torch
+        dev = torch.device("cuda", int(device))
+        dim_s, dim_u = handler._dim_S, handler._dim_U
+        step = self.stepper(handler, dev)
+
+        def body(d_cur, d_act, d_next, batch, d_out, stream):
+            with torch.cuda.stream(self._stream(torch, stream, dev)):
+                cur = self._alias(torch, d_cur, (batch, dim_s), dev)
+                act = self._alias(torch, d_act, (batch, dim_u), dev)
+                out = self._alias(torch, d_out, (batch, dim_s), dev)
+                out.copy_(step(cur, act))
+        return self._guard(body)
+
+    def stepper(self, handler, dev):
+        """(states, actions) -> absolute next states, op for op what the handler does around the model."""
+        import torch
+        dim_s = handler._dim_S
+        stats = handler.normalization_stats()
+        inverse = getattr(handler, "_inverse_transform_targets_func", None)
+        if stats is not None:
+            ms, ss, ma, sa, mt, st_ = (torch.as_tensor(v, device=dev) for v in stats)
+            ss, sa, st_ = ss + 1e-7, sa + 1e-7, st_ + 1e-7
+
+        def step(cur, act):
+            if stats is None:
+                x = torch.cat([cur, act], dim=1)                                   # :104-108
+            else:
+                x = torch.cat([(cur - ms) / ss, (act - ma) / sa], dim=1)           # :109-125
+            raw = self._result(torch, call_torch_dynamics(self.fn, x), (cur.shape[0], dim_s), "dynamics_function")
+            if stats is not None:
+                raw = mt + raw * st_                                                # :150-156
+            return inverse(cur, raw) if inverse is not None else raw + cur          # transforms.py:34
+        return step
+
+    def probe(self, handler, device):
+        import torch
+        dev = torch.device("cuda", int(device))
+        step = self.stepper(handler, dev)
+        out = step(torch.zeros((2, handler._dim_S), device=dev), torch.zeros((2, handler._dim_U), device=dev))
+        self._result(torch, out, (2, handler._dim_S), "dynamics_function")
+
+    def __call__(self, x, train=False):
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        return call_torch_dynamics(self.fn, torch.as_tensor(np.asarray(x, np.float32), device=dev)).to(torch.float32).cpu().numpy()
+
+
+_torch_plugins = {}                                        # id(callable) -> adapter (keeps the callable alive with it)
+
+
+def torch_plugin(fn, cls):
+    """The adapter of a plain callable, one per callable object."""
+    key = (id(fn), cls)
+    p = _torch_plugins.get(key)
+    if p is None or p.fn is not fn:
+        p = _torch_plugins[key] = cls(fn)
+    return p
+
+
+def gpu_for_callables():
+    """The device index torch callables run on, or None when there is no GPU (or no torch) to run them."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.cuda.current_device()
+    except Exception:                                     # noqa: BLE001
+        pass
+    return None

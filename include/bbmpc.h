@@ -54,12 +54,12 @@ extern "C" {
 /* dynamics plugin: utils/pendulum.py:38-92 | dynamics_functions/deterministic_mlp.py:5-51 */
 #define BBMPC_DYN_PENDULUM 1
 #define BBMPC_DYN_MLP      2
-#define BBMPC_DYN_USER     3   /* device function given as HIP source: bbmpc_set_dynamics_source */
+#define BBMPC_DYN_USER     3   /* caller-supplied: HIP source (bbmpc_set_dynamics_source) or a device-memory callback */
 
 /* reward plugin: utils/pendulum.py:10-35 | tutorials/mujoco/cost_func.py:5-22 */
 #define BBMPC_REW_PENDULUM 1
 #define BBMPC_REW_CHEETAH  2
-#define BBMPC_REW_USER     3   /* device function given as HIP source: bbmpc_set_reward_source */
+#define BBMPC_REW_USER     3   /* caller-supplied: HIP source (bbmpc_set_reward_source) or a device-memory callback */
 
 /* Dense activations (tutorials use tf.math.tanh and None) */
 #define BBMPC_ACT_NONE    0
@@ -180,6 +180,21 @@ int bbmpc_set_mlp(bbmpc_handle h, int32_t n_layers, const int32_t* dims, const i
 int bbmpc_set_reward_source(bbmpc_handle h, const char* hip_source);
 int bbmpc_set_dynamics_source(bbmpc_handle h, const char* hip_source);
 int bbmpc_check_user_source(int32_t kind, const char* hip_source, int32_t dim_s, int32_t dim_u);
+/* The same two plug-ins as HOST callbacks that work on DEVICE memory -- for callers whose functions are written in a
+ * GPU array framework (the reference's users pass TensorFlow callables, deterministic.py:13-18; the Python layer wraps
+ * PyTorch callables this way).  The engine calls back once per planning step with row batches that
+ * live in its own HBM buffers; the callback enqueues its work on `hip_stream` (the handle's launch stream) and
+ * returns without synchronising -- nothing is copied to the host, nothing runs on the CPU but the enqueueing.
+ *   reward:   d_cur [batch,S], d_actions [batch,U], d_next [batch,S]  ->  d_out [batch]     (the reference's CALL order)
+ *   dynamics: d_cur [batch,S], d_actions [batch,U], d_next = NULL     ->  d_out [batch,S] = the ABSOLUTE next states, i.e.
+ *             process_output(state, f(process_input(state, action))) of dynamics_handlers/system_dynamics_handler.py:97-161
+ * A non-zero return aborts the control step with BBMPC_E_INVALID.  A handle with a callback evaluates step by step
+ * (2 * H + 2 launches plus the callback's own); setting a callback replaces HIP source of the same kind and vice versa.
+ * fn == NULL clears it. */
+typedef int32_t (*bbmpc_rows_callback)(void* user, const float* d_cur, const float* d_actions, const float* d_next,
+                                       int32_t batch, float* d_out, void* hip_stream);
+int bbmpc_set_reward_callback(bbmpc_handle h, bbmpc_rows_callback fn, void* user);
+int bbmpc_set_dynamics_callback(bbmpc_handle h, bbmpc_rows_callback fn, void* user);
 /* Compile-only check of the FUSED rollout kernel the engine builds for analytic models (one lane per trajectory, the
  * user function(s) inlined next to the built-in PendulumTrueModel / rewards): dynamics / reward = BBMPC_DYN_* /
  * BBMPC_REW_* kinds, sources NULL for built-ins.  Needs no GPU. */
