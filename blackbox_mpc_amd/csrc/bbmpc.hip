@@ -507,7 +507,8 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * CMA_SYNC_WORDS * sizeof(unsigned), stream));
             hipLaunchKernelGGL(k_cma_warm, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(256), 0, stream, q, c_evec.p);
             const int bsz = (n + 7) / 8;
-            const size_t blds = (size_t)2 * bsz * n * sizeof(float);
+            const int ncb = (n + 63) / 64;                               // k_cma_svd_block<ncb>: LDS column pitch 64 * ncb
+            const size_t blds = (size_t)2 * bsz * 64 * ncb * sizeof(float);
             if (n >= 128 && (n & 3) == 0 && bsz <= 64 && cma_gram_lds_bytes(n) <= 159 * 1024 && cma_gram_wp(n) <= 128 && G * 4 <= 256 &&
                 !sw.cma_svd_rounds && sw.cma_svd_gram) {
                 // block Jacobi in the Gram domain: Gram matrix / column update on the matrix cores, rotations on 2bs x 2bs data
@@ -517,9 +518,19 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                 int sweeps = 15;
                 void* kargs[] = {(void*)&q, (void*)&evp, (void*)&syp, (void*)&sweeps};
                 HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_cma_svd_gram, dim3(4, G), dim3(1024), kargs, cma_gram_lds_bytes(n), stream));
-            } else if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 159 * 1024 && G * 4 <= 256 && !sw.cma_svd_rounds) {
+            } else if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 159 * 1024 && 32 * ((G + 7) / 8) <= 256 && !sw.cma_svd_rounds) {
                 // block Jacobi: 4 workgroups per instance, block pairs resident in LDS, 7 instance barriers per sweep
-                ensure_max_lds((const void*)k_cma_svd_block, 159 * 1024);     // + a few static words
+                const void* kfn = nullptr;
+                switch (ncb) {
+                    case 2: kfn = (const void*)k_cma_svd_block<2>; break;
+                    case 3: kfn = (const void*)k_cma_svd_block<3>; break;
+                    case 4: kfn = (const void*)k_cma_svd_block<4>; break;
+                    case 5: kfn = (const void*)k_cma_svd_block<5>; break;
+                    case 6: kfn = (const void*)k_cma_svd_block<6>; break;
+                    case 7: kfn = (const void*)k_cma_svd_block<7>; break;
+                    default: kfn = (const void*)k_cma_svd_block<8>; break;
+                }
+                ensure_max_lds(kfn, 159 * 1024);     // + a few static words
                 // cooperative launch: the instance barrier spins, so every workgroup of the grid must be resident at
                 // once -- the runtime checks that and orders the launch against other cooperative grids
                 {
@@ -527,7 +538,8 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                     unsigned* syp = c_sync.p;
                     int sweeps = 15;
                     void* kargs[] = {(void*)&q, (void*)&evp, (void*)&syp, (void*)&sweeps};
-                    HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_cma_svd_block, dim3(4, G), dim3(1024), kargs, blds, stream));
+                    // 1-D grid, an instance's four workgroups on one XCD (kernels_cma.hpp); surplus workgroups return at once
+                    HIP_CHECK(hipLaunchCooperativeKernel(kfn, dim3(8 * 4 * ((G + 7) / 8)), dim3(1024), kargs, blds, stream));
                 }
             } else {
                 if (n <= 128 && !sw.cma_svd_general) {

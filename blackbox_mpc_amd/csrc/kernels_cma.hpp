@@ -402,6 +402,7 @@ __device__ __forceinline__ void cma_instance_barrier_light(unsigned* ctr, unsign
 }
 
 constexpr int CMA_SYNC_WORDS = 128;
+constexpr int CMA_SYNC_XCC_MASK = 24;                  // k_cma_svd_block: bit x = some workgroup of the instance runs on XCD x
 // sync: [G][CMA_SYNC_WORDS] unsigned: [0] barrier counter, [1 + sweep] "some pair rotated in this sweep"; the block kernel keeps
 // its block-pair bookkeeping in words 32..111
 __global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps, int lds_floats) {
@@ -548,17 +549,38 @@ __device__ __forceinline__ void coh_load16x4(const float* p0, const float* p1, c
 __device__ __forceinline__ void coh_store16(float* p, cma_f32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
 }
+// the same store WITHOUT the write-through bits: the line stays (dirty) in this XCD's L2, where the `sc0 sc1` loads of
+// workgroups on the SAME XCD find it -- a `sc0 sc1` store drops the line, and the next reader pays the fabric round
+// trip (measured in this kernel: 29 us instead of 3.5 us per block-pair load).  Only valid when every reader is on
+// this XCD (k_cma_svd_block checks that at run time).
+__device__ __forceinline__ void l2_store16(float* p, cma_f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
 
 // ---- Block Jacobi: the columns are cut into 8 blocks; 4 workgroups per instance each hold one PAIR of blocks in
 // LDS and orthogonalise every column pair inside it without touching global memory; the block pairs follow a
 // round-robin tournament (7 block rounds per sweep), so an instance needs 7 instance-wide barriers per sweep instead
 // of n-1, and the one-CU memory path that bounds k_cma_svd_rounds (67 GB/s, 3.2 ms per sweep at n = 300) is out of
 // the picture.  Same rotation, threshold and convergence rule as above.
-// LDS: 2*bs columns of n floats.  sync: [G][32] as above.
+// LDS: 2*bs columns at a pitch of 64 * ceil(n / 64) floats.  sync: [G][CMA_SYNC_WORDS] as above.
+// Placement: a 1-D grid of 8 * WPG * ceil(G / 8) workgroups.  Workgroup `id` is dispatched to XCD id % 8 (observed, not
+// promised: MI355X_MICROARCH.md, workgroup dispatch), so instance g = (id % 8) + 8 * (slot / WPG), member slot % WPG with
+// slot = id / 8 puts an instance's workgroups behind ONE L2.  Every workgroup reads its XCC id and the instance agrees
+// (first barrier) whether that held; only then do the blocks travel as L2-resident lines, otherwise as write-through
+// stores as before -- placement buys speed, never correctness.
+// NC = ceil(n / 64): the resident columns sit in LDS at a pitch of ld = 64 * NC floats, zero beyond n, so that every
+// per-element loop has a compile-time trip count and no bounds test (at n = 300 the tests, masks and branches were two
+// thirds of the instructions of a cross round).
+template <int NC>
 __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
     extern __shared__ __attribute__((aligned(16))) float cols[];
-    constexpr int NB = 8;                                   // blocks; gridDim.x == NB / 2 workgroups per instance
-    const int g = blockIdx.y, wg = blockIdx.x, WPG = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
+    constexpr int NB = 8;                                   // blocks; NB / 2 workgroups per instance
+    constexpr int WPG = NB / 2;
+    const int slot = blockIdx.x >> 3;
+    const int g = (blockIdx.x & 7) + 8 * (slot / WPG), wg = slot % WPG;
+    if (g >= p.G) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
+    constexpr int ld = 64 * NC;
     const int NW = blockDim.x >> 6;
     const int bs = (n + NB - 1) / NB;                       // columns per block (the last block may be short)
     float* At = At_all + (size_t)g * n * n;
@@ -571,35 +593,50 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
     unsigned* iseen = sync + 40;
     unsigned* pseen = sync + 48;
     __shared__ int s_skip[3], s_rotf[3];          // [0] cross pairs, [1] inner pairs of block x, [2] of block y
+    __shared__ int s_same_xcd;
+    __shared__ float s_ynrm[64], s_ysc[64];     // tracked |y_j|^2 and scale of the resident y-columns (bs <= 64)
     const float tol = fminf(fmaxf(3.0e-8f * (float)n, 2.0e-6f), 1.0e-5f);
     unsigned bar = 0;
+    for (int i = tid; i < 2 * bs * ld; i += blockDim.x) cols[i] = 0.0f;     // the padding beyond n stays zero for good
+    // which XCD am I on?  (s_getreg_b32 hwreg(HW_REG_XCC_ID = 20), bits 3:0)
+    if (tid == 0) __hip_atomic_fetch_or(sync + CMA_SYNC_XCC_MASK, 1u << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u), __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+    ++bar;
+    cma_instance_barrier_light(sync, bar * (unsigned)WPG);
+    if (tid == 0) {
+        const unsigned mask = __hip_atomic_load(sync + CMA_SYNC_XCC_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_same_xcd = (mask & (mask - 1u)) == 0u;
+    }
+    __syncthreads();
+    const bool same_xcd = s_same_xcd != 0;
+#ifdef BBMPC_KERNEL_DBG
+    if (tid == 0 && wg == 0) printf("[svdb] instance %d block %d: XCC mask 0x%x same_xcd %d\n", g, (int)blockIdx.x, sync[CMA_SYNC_XCC_MASK], (int)same_xcd);
+#endif
 
     // one column pair (LDS columns ia, ib; global column ids ca, cb < n guaranteed by the caller)
     auto rotate = [&](int ia, int ib) -> bool {
-        float* x = cols + (size_t)ia * n;
-        float* y = cols + (size_t)ib * n;
-        float xv[8], yv[8];
+        float* x = cols + (size_t)ia * ld;
+        float* y = cols + (size_t)ib * ld;
+        float xv[NC], yv[NC];
         float al = 0.0f, be = 0.0f, ga = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int e = lane + 64 * c;
-            xv[c] = (e < n) ? x[e] : 0.0f;
-            yv[c] = (e < n) ? y[e] : 0.0f;
+            xv[c] = x[e];
+            yv[c] = y[e];
         }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { al = fmaf(xv[c], xv[c], al); be = fmaf(yv[c], yv[c], be); ga = fmaf(xv[c], yv[c], ga); }
+        for (int c = 0; c < NC; ++c) { al = fmaf(xv[c], xv[c], al); be = fmaf(yv[c], yv[c], be); ga = fmaf(xv[c], yv[c], ga); }
         al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
         if (fabsf(ga) <= tol * sqrtf(al * be) || ga == 0.0f) return false;
         const float zeta = (be - al) / (2.0f * ga);
         const float t = copysignf(1.0f, zeta) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
         const float cs = 1.0f / sqrtf(1.0f + t * t), sn = cs * t;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int e = lane + 64 * c;
-            if (e < n) {
-                x[e] = fmaf(cs, xv[c], -(sn * yv[c]));
-                y[e] = fmaf(sn, xv[c], cs * yv[c]);
-            }
+            x[e] = fmaf(cs, xv[c], -(sn * yv[c]));          // (the zero padding stays zero)
+            y[e] = fmaf(sn, xv[c], cs * yv[c]);
         }
         return true;
     };
@@ -649,10 +686,10 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                         cma_f32x4 v0, v1, v2, v3;
                         coh_load16x4(src[0] + 4 * e4, src[1] + 4 * e4, src[2] + 4 * e4, src[3] + 4 * e4, v0, v1, v2, v3);
                         if (h0 + lane < n4) {
-                            if (c0 < nx + ny) *reinterpret_cast<cma_f32x4*>(cols + (size_t)c0 * n + 4 * e4) = v0;
-                            if (c0 + NW < nx + ny) *reinterpret_cast<cma_f32x4*>(cols + (size_t)(c0 + NW) * n + 4 * e4) = v1;
-                            if (c0 + 2 * NW < nx + ny) *reinterpret_cast<cma_f32x4*>(cols + (size_t)(c0 + 2 * NW) * n + 4 * e4) = v2;
-                            if (c0 + 3 * NW < nx + ny) *reinterpret_cast<cma_f32x4*>(cols + (size_t)(c0 + 3 * NW) * n + 4 * e4) = v3;
+                            if (c0 < nx + ny) *reinterpret_cast<cma_f32x4*>(cols + (size_t)c0 * ld + 4 * e4) = v0;
+                            if (c0 + NW < nx + ny) *reinterpret_cast<cma_f32x4*>(cols + (size_t)(c0 + NW) * ld + 4 * e4) = v1;
+                            if (c0 + 2 * NW < nx + ny) *reinterpret_cast<cma_f32x4*>(cols + (size_t)(c0 + 2 * NW) * ld + 4 * e4) = v2;
+                            if (c0 + 3 * NW < nx + ny) *reinterpret_cast<cma_f32x4*>(cols + (size_t)(c0 + 3 * NW) * ld + 4 * e4) = v3;
                         }
                     }
                 }
@@ -689,34 +726,59 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             const int mm = max(nx, ny);
             if (!skip_cross) {
                 bool rot_cross = false;
-                constexpr int EC = 8;                                // float4 chunks per lane: n <= 512
-                const int sub = lane & 15, row = wv * 4 + (lane >> 4), nc = (n + 63) >> 6;
+                constexpr int EC = NC;                               // float4 chunks per lane
+                const int sub = lane & 15, row = wv * 4 + (lane >> 4);
                 const bool has_x = row < nx, wave_on = wv * 4 < nx;
+                // Round 3: the rounds are instruction-issue bound (38 pairs x ~200 instructions on one CU), so the pair's
+                // arithmetic was cut roughly in half:
+                //  * |x|^2 and |y|^2 are TRACKED, not recomputed: a Jacobi rotation maps them to al - t*ga and be + t*ga
+                //    exactly, so a round computes ONE dot product (x.y) instead of three; they are recomputed from the
+                //    data at every block-pair visit (here), i.e. after at most bs rotations of a column;
+                //  * the rotation is applied in its scaled ("fast Givens") form: with x = sx*x~, y = sy*y~ the update
+                //    x' = cs*(x - t*y), y' = cs*(y + t*x) is x~' = x~ - (t*sy/sx)*y~, y~' = y~ + (t*sx/sy)*x~ and
+                //    sx' = cs*sx, sy' = cs*sy: one FMA per element instead of a multiply and an FMA; the scales are
+                //    folded back into the columns at the end of the visit (cs >= 0.707: at most 2^-32 after bs = 64).
                 float4 xr[EC];
+                float alx = 0.0f, sx = 1.0f;
 #pragma unroll
                 for (int c = 0; c < EC; ++c) {
                     const int e = 4 * (sub + 16 * c);
-                    xr[c] = (c < nc && has_x && e < n) ? *reinterpret_cast<const float4*>(cols + (size_t)row * n + e)
-                                                       : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    xr[c] = has_x ? *reinterpret_cast<const float4*>(cols + (size_t)row * ld + e) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    alx = fmaf(xr[c].x, xr[c].x, alx); alx = fmaf(xr[c].y, xr[c].y, alx);
+                    alx = fmaf(xr[c].z, xr[c].z, alx); alx = fmaf(xr[c].w, xr[c].w, alx);
                 }
+                alx = row16_sum(alx);
+                {   // |y_j|^2 of the y-columns: row `row` takes column `row`
+                    float by = 0.0f;
+                    const bool has_y = row < ny;
+#pragma unroll
+                    for (int c = 0; c < EC; ++c) {
+                        const int e = 4 * (sub + 16 * c);
+                        if (has_y) {
+                            const float4 v = *reinterpret_cast<const float4*>(cols + (size_t)(nx + row) * ld + e);
+                            by = fmaf(v.x, v.x, by); by = fmaf(v.y, v.y, by); by = fmaf(v.z, v.z, by); by = fmaf(v.w, v.w, by);
+                        }
+                    }
+                    by = row16_sum(by);
+                    if (has_y && sub == 0) { s_ynrm[row] = by; s_ysc[row] = 1.0f; }
+                }
+                __syncthreads();
                 for (int r = 0; r < mm; ++r) {
                     if (wave_on) {
                         const int j = (row + r) % mm;
                         const bool act = has_x && j < ny;
-                        float* y = cols + (size_t)(nx + (act ? j : 0)) * n;
+                        const int jc = act ? j : 0;
+                        float* y = cols + (size_t)(nx + jc) * ld;
                         float4 yv[EC];
-                        float al = 0.0f, be = 0.0f, ga = 0.0f;
+                        float gs = 0.0f;
 #pragma unroll
                         for (int c = 0; c < EC; ++c) {
-                            if (c < nc) {
-                                const int e = 4 * (sub + 16 * c);
-                                yv[c] = (act && e < n) ? *reinterpret_cast<const float4*>(y + e) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                                al = fmaf(xr[c].x, xr[c].x, al); al = fmaf(xr[c].y, xr[c].y, al); al = fmaf(xr[c].z, xr[c].z, al); al = fmaf(xr[c].w, xr[c].w, al);
-                                be = fmaf(yv[c].x, yv[c].x, be); be = fmaf(yv[c].y, yv[c].y, be); be = fmaf(yv[c].z, yv[c].z, be); be = fmaf(yv[c].w, yv[c].w, be);
-                                ga = fmaf(xr[c].x, yv[c].x, ga); ga = fmaf(xr[c].y, yv[c].y, ga); ga = fmaf(xr[c].z, yv[c].z, ga); ga = fmaf(xr[c].w, yv[c].w, ga);
-                            }
+                            const int e = 4 * (sub + 16 * c);
+                            yv[c] = *reinterpret_cast<const float4*>(y + e);     // (an idle row reads column 0 and does not rotate)
+                            gs = fmaf(xr[c].x, yv[c].x, gs); gs = fmaf(xr[c].y, yv[c].y, gs); gs = fmaf(xr[c].z, yv[c].z, gs); gs = fmaf(xr[c].w, yv[c].w, gs);
                         }
-                        al = row16_sum(al); be = row16_sum(be); ga = row16_sum(ga);
+                        const float sy = s_ysc[jc], be = s_ynrm[jc], al = alx;
+                        const float ga = (sx * sy) * row16_sum(gs);
                         // |ga| <= tol * sqrt(al*be)  <=>  ga^2 <= tol^2 * al * be  (no sqrt)
                         const bool rot = act && ga != 0.0f && (ga * ga > (tol * tol) * (al * be));
                         if (rot) {
@@ -726,29 +788,45 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                             const float w = fmaf(t, t, 1.0f);
                             float cs = __builtin_amdgcn_rsqf(w);
                             cs = cs * fmaf(-0.5f * w * cs, cs, 1.5f);           // Newton step: cs^2 * (1 + t^2) = 1 to fp32
-                            const float sn = cs * t;
+                            // sy / sx and sx / sy to fp32 (reciprocal + one Newton step): the pair of updates is an exact
+                            // rotation only if the two factors are reciprocal to each other
+                            float rx = __builtin_amdgcn_rcpf(sx), ry = __builtin_amdgcn_rcpf(sy);
+                            rx = rx * fmaf(-sx, rx, 2.0f); ry = ry * fmaf(-sy, ry, 2.0f);
+                            const float tau1 = t * (sy * rx), tau2 = t * (sx * ry);
 #pragma unroll
                             for (int c = 0; c < EC; ++c) {
-                                if (c < nc) {
-                                    const int e = 4 * (sub + 16 * c);
-                                    float4 xn, yn;
-                                    xn.x = fmaf(cs, xr[c].x, -(sn * yv[c].x)); yn.x = fmaf(sn, xr[c].x, cs * yv[c].x);
-                                    xn.y = fmaf(cs, xr[c].y, -(sn * yv[c].y)); yn.y = fmaf(sn, xr[c].y, cs * yv[c].y);
-                                    xn.z = fmaf(cs, xr[c].z, -(sn * yv[c].z)); yn.z = fmaf(sn, xr[c].z, cs * yv[c].z);
-                                    xn.w = fmaf(cs, xr[c].w, -(sn * yv[c].w)); yn.w = fmaf(sn, xr[c].w, cs * yv[c].w);
-                                    xr[c] = xn;
-                                    if (e < n) *reinterpret_cast<float4*>(y + e) = yn;
-                                }
+                                const int e = 4 * (sub + 16 * c);
+                                float4 xn, yn;
+                                xn.x = fmaf(-tau1, yv[c].x, xr[c].x); yn.x = fmaf(tau2, xr[c].x, yv[c].x);
+                                xn.y = fmaf(-tau1, yv[c].y, xr[c].y); yn.y = fmaf(tau2, xr[c].y, yv[c].y);
+                                xn.z = fmaf(-tau1, yv[c].z, xr[c].z); yn.z = fmaf(tau2, xr[c].z, yv[c].z);
+                                xn.w = fmaf(-tau1, yv[c].w, xr[c].w); yn.w = fmaf(tau2, xr[c].w, yv[c].w);
+                                xr[c] = xn;
+                                *reinterpret_cast<float4*>(y + e) = yn;
                             }
+                            sx = sx * cs;
+                            alx = fmaf(-t, ga, al);
+                            if (sub == 0) { s_ysc[jc] = sy * cs; s_ynrm[jc] = fmaf(t, ga, be); }
                             rot_cross = true;
                         }
                     }
                     __syncthreads();
                 }
+                // fold the scales back: x from the registers, y in place
 #pragma unroll
                 for (int c = 0; c < EC; ++c) {
                     const int e = 4 * (sub + 16 * c);
-                    if (c < nc && has_x && e < n) *reinterpret_cast<float4*>(cols + (size_t)row * n + e) = xr[c];
+                    if (has_x)
+                        *reinterpret_cast<float4*>(cols + (size_t)row * ld + e) = make_float4(sx * xr[c].x, sx * xr[c].y, sx * xr[c].z, sx * xr[c].w);
+                }
+                for (int c = wv; c < ny; c += NW) {
+                    const float sc = s_ysc[c];
+                    if (sc != 1.0f)
+                        for (int q4 = lane; q4 < (n >> 2); q4 += 64) {
+                            float4 v = *reinterpret_cast<const float4*>(cols + (size_t)(nx + c) * ld + 4 * q4);
+                            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                            *reinterpret_cast<float4*>(cols + (size_t)(nx + c) * ld + 4 * q4) = v;
+                        }
                 }
                 if (rot_cross && sub == 0) s_rotf[0] = 1;
                 rotated |= rot_cross;
@@ -762,7 +840,10 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                 for (int c = wv; c < nx + ny; c += NW) {
                     if (c < nx ? !(rc || rix) : !(rc || riy)) continue;
                     float* dst = At + (size_t)(c < nx ? x0 + c : y0 + (c - nx)) * n;
-                    for (int q4 = lane; q4 < (n >> 2); q4 += 64) coh_store16(dst + 4 * q4, *reinterpret_cast<const cma_f32x4*>(cols + (size_t)c * n + 4 * q4));
+                    if (same_xcd)
+                        for (int q4 = lane; q4 < (n >> 2); q4 += 64) l2_store16(dst + 4 * q4, *reinterpret_cast<const cma_f32x4*>(cols + (size_t)c * ld + 4 * q4));
+                    else
+                        for (int q4 = lane; q4 < (n >> 2); q4 += 64) coh_store16(dst + 4 * q4, *reinterpret_cast<const cma_f32x4*>(cols + (size_t)c * ld + 4 * q4));
                 }
             }
             if (tid == 0) {
