@@ -613,32 +613,47 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
     if (tid == 0 && wg == 0) printf("[svdb] instance %d block %d: XCC mask 0x%x same_xcd %d\n", g, (int)blockIdx.x, sync[CMA_SYNC_XCC_MASK], (int)same_xcd);
 #endif
 
-    // one column pair (LDS columns ia, ib; global column ids ca, cb < n guaranteed by the caller)
-    auto rotate = [&](int ia, int ib) -> bool {
+    // one column pair per 16-lane DPP row (LDS columns ia, ib), four pairs per wave: 16-byte LDS accesses, 4-step row
+    // reductions, hardware rcp / rsq (+ one Newton step on the cosine) for the rotation scalars.  (Until round 3 a
+    // whole wave took one pair with scalar LDS accesses and IEEE divisions; with 19 pairs on 16 waves a round of the
+    // inner tournament then cost two pair times.)
+    const int sub = lane & 15, prow = wv * 4 + (lane >> 4);
+    auto rotate16 = [&](int ia, int ib, bool act) -> bool {
         float* x = cols + (size_t)ia * ld;
         float* y = cols + (size_t)ib * ld;
-        float xv[NC], yv[NC];
+        float4 xv[NC], yv[NC];
         float al = 0.0f, be = 0.0f, ga = 0.0f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int e = lane + 64 * c;
-            xv[c] = x[e];
-            yv[c] = y[e];
+            const int e = 4 * (sub + 16 * c);
+            xv[c] = *reinterpret_cast<const float4*>(x + e);
+            yv[c] = *reinterpret_cast<const float4*>(y + e);
+            al = fmaf(xv[c].x, xv[c].x, al); al = fmaf(xv[c].y, xv[c].y, al); al = fmaf(xv[c].z, xv[c].z, al); al = fmaf(xv[c].w, xv[c].w, al);
+            be = fmaf(yv[c].x, yv[c].x, be); be = fmaf(yv[c].y, yv[c].y, be); be = fmaf(yv[c].z, yv[c].z, be); be = fmaf(yv[c].w, yv[c].w, be);
+            ga = fmaf(xv[c].x, yv[c].x, ga); ga = fmaf(xv[c].y, yv[c].y, ga); ga = fmaf(xv[c].z, yv[c].z, ga); ga = fmaf(xv[c].w, yv[c].w, ga);
         }
+        al = row16_sum(al); be = row16_sum(be); ga = row16_sum(ga);
+        const bool rot = act && ga != 0.0f && (ga * ga > (tol * tol) * (al * be));
+        if (rot) {
+            const float zeta = (be - al) * __builtin_amdgcn_rcpf(2.0f * ga);
+            const float t = copysignf(__builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.0f))), zeta);
+            const float w = fmaf(t, t, 1.0f);
+            float cs = __builtin_amdgcn_rsqf(w);
+            cs = cs * fmaf(-0.5f * w * cs, cs, 1.5f);
+            const float sn = cs * t;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { al = fmaf(xv[c], xv[c], al); be = fmaf(yv[c], yv[c], be); ga = fmaf(xv[c], yv[c], ga); }
-        al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
-        if (fabsf(ga) <= tol * sqrtf(al * be) || ga == 0.0f) return false;
-        const float zeta = (be - al) / (2.0f * ga);
-        const float t = copysignf(1.0f, zeta) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
-        const float cs = 1.0f / sqrtf(1.0f + t * t), sn = cs * t;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int e = lane + 64 * c;
-            x[e] = fmaf(cs, xv[c], -(sn * yv[c]));          // (the zero padding stays zero)
-            y[e] = fmaf(sn, xv[c], cs * yv[c]);
+            for (int c = 0; c < NC; ++c) {
+                const int e = 4 * (sub + 16 * c);
+                float4 xn, yn;
+                xn.x = fmaf(cs, xv[c].x, -(sn * yv[c].x)); yn.x = fmaf(sn, xv[c].x, cs * yv[c].x);
+                xn.y = fmaf(cs, xv[c].y, -(sn * yv[c].y)); yn.y = fmaf(sn, xv[c].y, cs * yv[c].y);
+                xn.z = fmaf(cs, xv[c].z, -(sn * yv[c].z)); yn.z = fmaf(sn, xv[c].z, cs * yv[c].z);
+                xn.w = fmaf(cs, xv[c].w, -(sn * yv[c].w)); yn.w = fmaf(sn, xv[c].w, cs * yv[c].w);
+                *reinterpret_cast<float4*>(x + e) = xn;          // (the zero padding stays zero)
+                *reinterpret_cast<float4*>(y + e) = yn;
+            }
         }
-        return true;
+        return rot;
     };
 
 #ifdef BBMPC_KERNEL_DBG
@@ -704,15 +719,19 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                     const int m = (cnt + 1) & ~1;
                     bool rot_here = false;
                     for (int r = 0; r < m - 1; ++r) {
-                        for (int i = wv; i < m / 2; i += NW) {
-                            int pa, pb;
-                            if (i == 0) { pa = m - 1; pb = r; }
-                            else { pa = (r + i) % (m - 1); pb = (r - i + (m - 1)) % (m - 1); }
-                            if (pa < cnt && pb < cnt) rot_here |= rotate(base + pa, base + pb);
+                        for (int i0 = 0; i0 < m / 2; i0 += 4 * NW) {       // one trip for bs <= 8 * NW columns
+                            const int i = i0 + prow;
+                            if (i0 + wv * 4 < m / 2) {
+                                int pa, pb;
+                                if (i == 0) { pa = m - 1; pb = r; }
+                                else { pa = (r + i) % (m - 1); pb = (r - i + (m - 1)) % (m - 1); }
+                                const bool act = i < m / 2 && pa < cnt && pb < cnt;
+                                rot_here |= rotate16(base + (act ? pa : 0), base + (act ? pb : 0), act);
+                            }
                         }
                         __syncthreads();
                     }
-                    if (rot_here && lane == 0) s_rotf[1 + blk] = 1;
+                    if (rot_here && sub == 0) s_rotf[1 + blk] = 1;
                     rotated |= rot_here;
                 }
             }
@@ -727,7 +746,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             if (!skip_cross) {
                 bool rot_cross = false;
                 constexpr int EC = NC;                               // float4 chunks per lane
-                const int sub = lane & 15, row = wv * 4 + (lane >> 4);
+                const int row = prow;
                 const bool has_x = row < nx, wave_on = wv * 4 < nx;
                 // Round 3: the rounds are instruction-issue bound (38 pairs x ~200 instructions on one CU), so the pair's
                 // arithmetic was cut roughly in half:
@@ -835,6 +854,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             SVDB_MARK(2);
             __syncthreads();
             const bool rc = s_rotf[0] != 0, rix = s_rotf[1] != 0, riy = s_rotf[2] != 0;
+            rotated |= rc || rix || riy;            // (workgroup-wide: a row's own flag is not the wave's)
             // ---- write back what changed
             if (rc || rix || riy) {
                 for (int c = wv; c < nx + ny; c += NW) {
