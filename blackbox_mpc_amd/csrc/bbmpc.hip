@@ -491,7 +491,8 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
         q.inj = inj_n ? inj_n + inj_stride * it : nullptr;
         hipLaunchKernelGGL(k_cma_noise, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, q);
         hipLaunchKernelGGL(k_cma_bd, dim3((unsigned)((gnn + 255) / 256)), dim3(256), 0, stream, q);
-        hipLaunchKernelGGL(k_cma_gemm_y, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
+        if (n > 128 && (n & 3) == 0) hipLaunchKernelGGL(k_cma_gemm_y_mfma, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL(k_cma_gemm_y, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
         HIP_CHECK(hipGetLastError());
         ra.cand = d_cand_a.p; ra.samples = d_cand_a.p; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
         launch_rollout(SRC_BUF, true, ra);                          // clip + penalty (cma_es.py:147-157)
@@ -560,7 +561,12 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                                    (int)(rl / sizeof(float)));
                 }
             }
-            hipLaunchKernelGGL(k_cma_svd_finish, dim3(G), dim3(n > 256 ? 1024 : 256), 0, stream, q, c_evec.p, c_eval.p, c_info.p);
+            if (n > 128 && n <= 2048) {
+                hipLaunchKernelGGL(k_cma_svd_norms, dim3(G), dim3(1024), 0, stream, q, c_evec.p, c_eval.p, c_info.p);
+                hipLaunchKernelGGL(k_cma_svd_build_b, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(32, 8), 0, stream, q, c_evec.p, c_eval.p, c_info.p);
+            } else {
+                hipLaunchKernelGGL(k_cma_svd_finish, dim3(G), dim3(n > 256 ? 1024 : 256), 0, stream, q, c_evec.p, c_eval.p, c_info.p);
+            }
         } else {
             hipLaunchKernelGGL(k_cma_svd, dim3(G), dim3(REFIT_THREADS), 0, stream, q, c_evec.p, c_eval.p, c_info.p, 15);
         }

@@ -116,6 +116,46 @@ __global__ __launch_bounds__(256) void k_cma_gemm_y(CmaArgs p) {
     }
 }
 
+// The same product on the matrix cores for large n (n % 4 == 0): v_mfma_f32_16x16x4_f32, operands straight from L2 --
+// for a fixed l both BD[l][i0 .. i0+15] and Z^T[l][q0 .. q0+15] are contiguous, which is exactly the A / B fragment of
+// lane (l & 3, i or q) -- no LDS staging.  Workgroup tile 64 (i) x 64 (q): wave w owns rows 16w .. 16w+15 and four
+// q fragments; the B fragments are shared by the four waves through L1.  76 -> ~20 us at n = 300, N = 2000, G = 4.
+// (The small-n path keeps k_cma_gemm_y: its accumulation order is what the fused control-step kernel reproduces.)
+__global__ __launch_bounds__(256) void k_cma_gemm_y_mfma(CmaArgs p) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int g = blockIdx.z, n = p.n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = blockIdx.y * 64 + wave * 16, q0 = blockIdx.x * 64;
+    if (i0 >= n) return;
+    const int lm = lane & 15, lk = lane >> 4;
+    const float* A = p.BD + (size_t)g * n * n + min(i0 + lm, n - 1);                 // + l * n
+    const float* Z = p.z + (size_t)g * n * p.Nst + q0 + lm;                           // + l * Nst (+ 16 * f); Nst is a multiple of 64
+    f4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 5
+    for (int l0 = 0; l0 < n; l0 += 4) {
+        const int l = l0 + lk;
+        const float a = A[(size_t)l * n];
+        const float* zr = Z + (size_t)l * p.Nst;
+        const float b0 = zr[0], b1 = zr[16], b2 = zr[32], b3 = zr[48];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b3, acc[3], 0, 0, 0);
+    }
+    // samples = m + sigma * y   (cma_es.py:141): lane holds rows i0 + 4*lk + r, column q0 + 16*f + lm
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * lk + r;
+        if (i >= n) continue;
+        const float mi = p.m[(size_t)g * n + i], si = p.sigma[(size_t)g * n + i];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int q = q0 + 16 * f + lm;
+            if (q < p.N) p.cand[((size_t)g * n + i) * p.Nst + q] = mi + si * acc[f][r];
+        }
+    }
+}
+
 // per group: (sum of) rewards -> sorted top-k.   LDS: rsum[Nst] | hist | ekeys[kp]
 __device__ __forceinline__ void cma_select_body(const CmaArgs& p, int g, float* smem) {
     const int tid = threadIdx.x;
@@ -526,6 +566,59 @@ __device__ __forceinline__ void cma_svd_finish_body(const CmaArgs& p, int g, con
 }
 __global__ __launch_bounds__(1024) void k_cma_svd_finish(CmaArgs p, const float* At_all, float* norms_all, int* perm_all) {
     cma_svd_finish_body(p, blockIdx.x, At_all, norms_all, perm_all);
+}
+
+// The same finish for large n as two launches: norms / ranks / D per instance, then B in 32 x 32 tiles over many
+// workgroups.  (One workgroup per instance walked its n^2 elements with an integer division each and read At along the
+// strided direction: 79 us at n = 300, a tenth of which is left.)  Same arithmetic, same bits.
+__global__ __launch_bounds__(1024) void k_cma_svd_norms(CmaArgs p, const float* At_all, float* norms_all, int* perm_all) {
+    __shared__ float s_norm[2048];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n, nthr = blockDim.x, NW = nthr >> 6;
+    const float* At = At_all + (size_t)g * n * n;
+    float* norms = norms_all + (size_t)g * n;
+    int* perm = perm_all + (size_t)g * n;
+    for (int j = wv; j < n; j += NW) {
+        float al = 0.0f;
+        for (int e = lane; e < n; e += 64) { const float v = At[(size_t)j * n + e]; al = fmaf(v, v, al); }
+        al = wave_sum(al);
+        if (lane == 0) { const float nj = sqrtf(al); s_norm[j] = nj; norms[j] = nj; }
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += nthr) {
+        const float nj = s_norm[j];
+        int rank = 0;
+        for (int o = 0; o < n; ++o) { const float no = s_norm[o]; rank += (no > nj || (no == nj && o < j)) ? 1 : 0; }
+        perm[rank] = j;
+        p.Dd[(size_t)g * n + rank] = sqrtf(nj);                      // D = diag(sqrt(s)), descending
+    }
+}
+__global__ __launch_bounds__(256) void k_cma_svd_build_b(CmaArgs p, const float* At_all, const float* norms_all, const int* perm_all) {
+    __shared__ float tile[32][33];
+    __shared__ int s_src[32];
+    __shared__ float s_sv[32];
+    const int g = blockIdx.z, n = p.n, tx = threadIdx.x, ty = threadIdx.y;       // block (32, 8)
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const float* At = At_all + (size_t)g * n * n;
+    if (ty == 0) {
+        const int c = c0 + tx;
+        const int src = c < n ? perm_all[(size_t)g * n + c] : 0;
+        s_src[tx] = src;
+        s_sv[tx] = c < n ? norms_all[(size_t)g * n + src] : 0.0f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {                                // column c0 + k of B = row src of At, along r
+        const int r = r0 + tx;
+        tile[k][tx] = (c0 + k < n && r < n) ? At[(size_t)s_src[k] * n + r] : 0.0f;
+    }
+    __syncthreads();
+    float* B = p.B + (size_t)g * n * n;
+    for (int k = ty; k < 32; k += 8) {                                // row r0 + k of B, along c
+        const int r = r0 + k, c = c0 + tx;
+        if (r < n && c < n) {
+            const float sv = s_sv[tx];
+            B[(size_t)r * n + c] = (sv > 0.0f) ? tile[tx][k] / sv : ((r == c) ? 1.0f : 0.0f);
+        }
+    }
 }
 
 // 16-byte write-through (sc0 sc1) accesses for blocks that travel between workgroups: the 4-byte scalar form costs ~6x
