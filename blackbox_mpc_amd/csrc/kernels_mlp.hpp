@@ -190,58 +190,19 @@ __device__ __forceinline__ int tile_addr(int f, int p) {
 // (particle,u) in t order afterwards, from LDS.  Contains a barrier when q.pen is set (uniform).
 template <int TP>
 __device__ __forceinline__ void mlp_fill_actions(const MlpRolloutArgs& q, int a, int n0, int tid, int nthr,
-                                                 float* acts, float* pens, float* dsq = nullptr) {
+                                                 float* acts, float* pens) {
     const RolloutArgs& p = q.r;
     const int U = p.U, H = p.H;
     const int total = H * TP * U;                       // element e = (t*TP + pp)*U + u is also its index in acts
-    if (dsq) {
-        // dsq = H*TP*U floats of scratch: every thread clips its own elements and parks (x - clip(x))^2 there; the
-        // TP*U penalty threads then only SUM, in the same step order as the serial form below (same bits) -- that form
-        // is one dependent LDS read / write pair per step on TP*U threads (1.4 us at H = 30 in the quad kernels).
-        for (int e = tid; e < total; e += nthr) {
-            const int u = e % U, pp = (e / U) % TP, t = e / (U * TP);
-            const int n = n0 + pp;
-            const int j = t * U + u;
-            float x = 0.0f, d2 = 0.0f;
-            if (n < p.n_pop) {
-                if (q.mode == SRC_REF) x = p.seq[((size_t)n * p.A + a) * p.HU + j];
-                else if (q.mode == SRC_BUF) x = p.cand[((size_t)a * p.HU + j) * p.Nst + n];
-                else {
-                    float xi;
-                    if (p.inj) xi = p.inj[((size_t)a * p.HU + j) * p.Nst + n];
-                    else {
-                        const U4 blk = rng_block(p.key, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j);
-                        const uint32_t w = pick_word(blk, (uint32_t)j);
-                        xi = (q.mode == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
-                    }
-                    if (q.mode == SRC_UNIFORM) x = xi * (p.hi[u] - p.lo[u]) + p.lo[u];
-                    else x = xi * p.sigma[a * p.HU + j] + p.mean[a * p.HU + j];
-                }
-                if (q.pen) {
-                    const float xf = clipf(x, p.lo[u], p.hi[u]);
-                    const float d = x - xf;
-                    d2 = d * d;
-                    x = xf;
-                }
-                if (p.samples) p.samples[((size_t)a * p.HU + j) * p.Nst + n] = x;
-            }
-            acts[e] = x;
-            dsq[e] = d2;
-        }
-        __syncthreads();
-        for (int i = tid; i < TP * U; i += nthr) {
-            const int pp = i / U, u = i % U;
-            float pen_part = 0.0f;
-            if (q.pen && n0 + pp < p.n_pop)
-                for (int t = 0; t < H; ++t) pen_part = pen_part + dsq[(t * TP + pp) * U + u];
-            pens[i] = pen_part;
-        }
-        return;
-    }
-    for (int e = tid; e < total; e += nthr) {
-        const int u = e % U, pp = (e / U) % TP, t = e / (U * TP);
+    // thread <-> element: the particle index runs fastest, so that a wave's stores to the particle-minor sample matrix
+    // [A][H*U][Nst] are TP-particle (64-byte at TP = 16) segments.  With the action index fastest -- the order of `acts` --
+    // every lane wrote 4 bytes into a different row, 8 KB apart: rocprofv3 counted 27 MB written per launch for 9.6 MB of
+    // samples at the config-5 shape (profiles/r2_cfg5cem.md).
+    for (int e2 = tid; e2 < total; e2 += nthr) {
+        const int pp = e2 % TP, j = e2 / TP;
+        const int t = j / U, u = j - t * U;
+        const int e = (t * TP + pp) * U + u;
         const int n = n0 + pp;
-        const int j = t * U + u;
         float x = 0.0f;
         if (n < p.n_pop) {
             if (q.mode == SRC_REF) x = p.seq[((size_t)n * p.A + a) * p.HU + j];
@@ -263,8 +224,8 @@ __device__ __forceinline__ void mlp_fill_actions(const MlpRolloutArgs& q, int a,
     }
     if (q.pen) {
         __syncthreads();
-        for (int i = tid; i < TP * U; i += nthr) {
-            const int pp = i / U, u = i % U;
+        for (int i2 = tid; i2 < TP * U; i2 += nthr) {
+            const int pp = i2 % TP, u = i2 / TP;          // particle fastest here too (the clipped samples go back)
             const int n = n0 + pp;
             const float lo = p.lo[u], hi = p.hi[u];
             float pen_part = 0.0f;
@@ -277,7 +238,7 @@ __device__ __forceinline__ void mlp_fill_actions(const MlpRolloutArgs& q, int a,
                     acts[(t * TP + pp) * U + u] = xf;
                     if (p.samples) p.samples[((size_t)a * p.HU + t * U + u) * p.Nst + n] = xf;
                 }
-            pens[i] = pen_part;
+            pens[pp * U + u] = pen_part;
         }
     } else {
         for (int i = tid; i < TP * U; i += nthr) pens[i] = 0.0f;
@@ -556,7 +517,12 @@ __device__ __forceinline__ float apply_act_ct(float x) {
 // 7 / 7 / 6 / 6 (tile-jobs per SIMD) and the critical SIMD's matrix time drops by an eighth.
 constexpr int mlp_pair_waves(int HT, int NTILES) { return HT + (NTILES == 2 ? 1 : 0); }
 
-template <int HT, int A0, int A1, int A2, int NTILES>
+// CS / CU / CH: dim_S / dim_U / the planning horizon at compile time (0 = read them from the arguments).  With run-time dimensions the compiler keeps
+// some forty loop-invariant LDS addresses per thread, does not fit them into the 128 registers a 14-wave workgroup
+// leaves per lane and spills 84 bytes per thread: 84 B x 896 threads x 250 workgroups = 18.8 MB of scratch written per
+// launch -- the "27 MB written for 9.6 MB of samples" of profiles/r2_cfg5cem.md (WRITE_SIZE itself is exact:
+// tools/microbench/write_size_calib.hip) -- and ~20 scratch reloads per pipeline step.
+template <int HT, int A0, int A1, int A2, int NTILES, int CS = 0, int CU = 0, int CH = 0>
 __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutArgs& p = q.r;
@@ -568,7 +534,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     // which particle tiles this wave works on (everything else -- barriers, epilogue threads -- is common)
     const bool serves0 = NTILES == 1 || wid != HT;
     const bool serves1 = NTILES == 2 && wid != HT - 1;
-    const int S = p.S, U = p.U, H = p.H;
+    const int S = CS ? CS : p.S, U = CU ? CU : p.U, H = CH ? CH : p.H;
     const int Sp = (S + 3) & ~3;
     const bool normd = m.normalized != 0;
     const bool half1 = m.half_tail[1] != 0, half2 = m.half_tail[2] != 0;   // inputs of layer 1 / of the last layer
