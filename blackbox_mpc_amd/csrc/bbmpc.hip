@@ -176,6 +176,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.cma_svd_v1 = flag("BBMPC_CMA_SVD_V1"); sw.cma_svd_rounds = flag("BBMPC_CMA_SVD_ROUNDS");
         sw.cma_svd_general = flag("BBMPC_CMA_SVD_GENERAL");
         sw.cma_svd_gram = flag("BBMPC_CMA_SVD_GRAM");
+        sw.cma_coop = flag("BBMPC_CMA_COOP"); sw.cma_nb = ival("BBMPC_CMA_NB", 0);
         sw.cma_fused = flag("BBMPC_CMA_FUSED");
         sw.mlp_generic = flag("BBMPC_MLP_GENERIC");
         { const int b = ival("BBMPC_MLP_BF16", 0); sw.mlp_bf16 = (b == 1 || b == 3) ? b : 0; }
@@ -508,8 +509,11 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * CMA_SYNC_WORDS * sizeof(unsigned), stream));
             hipLaunchKernelGGL(k_cma_warm, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(256), 0, stream, q, c_evec.p);
             const int bsz = (n + 7) / 8;
-            const int ncb = (n + 63) / 64;                               // k_cma_svd_block<ncb>: LDS column pitch 64 * ncb
-            const size_t blds = (size_t)2 * bsz * 64 * ncb * sizeof(float);
+            const int ncb = (n + 63) / 64;                               // k_cma_svd_block<ncb, NB>: LDS column pitch 64 * ncb
+            // NB = 16 column blocks on 8 workgroups per instance when there are CUs for them (BBMPC_CMA_NB overrides)
+            const int nbk = (sw.cma_nb == 8 || sw.cma_nb == 16) ? sw.cma_nb : ((64 * ((G + 7) / 8) <= 256 && n >= 256) ? 16 : 8);
+            const int bsk = (n + nbk - 1) / nbk;
+            const size_t blds = (size_t)2 * bsk * 64 * ncb * sizeof(float);
             if (n >= 128 && (n & 3) == 0 && bsz <= 64 && cma_gram_lds_bytes(n) <= 159 * 1024 && cma_gram_wp(n) <= 128 && G * 4 <= 256 &&
                 !sw.cma_svd_rounds && sw.cma_svd_gram) {
                 // block Jacobi in the Gram domain: Gram matrix / column update on the matrix cores, rotations on 2bs x 2bs data
@@ -519,28 +523,31 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                 int sweeps = 15;
                 void* kargs[] = {(void*)&q, (void*)&evp, (void*)&syp, (void*)&sweeps};
                 HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_cma_svd_gram, dim3(4, G), dim3(1024), kargs, cma_gram_lds_bytes(n), stream));
-            } else if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 159 * 1024 && 32 * ((G + 7) / 8) <= 256 && !sw.cma_svd_rounds) {
+            } else if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 159 * 1024 && 8 * (nbk / 2) * ((G + 7) / 8) <= 256 && !sw.cma_svd_rounds) {
                 // block Jacobi: 4 workgroups per instance, block pairs resident in LDS, 7 instance barriers per sweep
                 const void* kfn = nullptr;
+#define BBMPC_SVD_CASE(NC_) case NC_: kfn = nbk == 16 ? (const void*)k_cma_svd_block<NC_, 16> : (const void*)k_cma_svd_block<NC_, 8>; break;
                 switch (ncb) {
-                    case 2: kfn = (const void*)k_cma_svd_block<2>; break;
-                    case 3: kfn = (const void*)k_cma_svd_block<3>; break;
-                    case 4: kfn = (const void*)k_cma_svd_block<4>; break;
-                    case 5: kfn = (const void*)k_cma_svd_block<5>; break;
-                    case 6: kfn = (const void*)k_cma_svd_block<6>; break;
-                    case 7: kfn = (const void*)k_cma_svd_block<7>; break;
-                    default: kfn = (const void*)k_cma_svd_block<8>; break;
+                    BBMPC_SVD_CASE(2) BBMPC_SVD_CASE(3) BBMPC_SVD_CASE(4) BBMPC_SVD_CASE(5) BBMPC_SVD_CASE(6) BBMPC_SVD_CASE(7)
+                    default: kfn = nbk == 16 ? (const void*)k_cma_svd_block<8, 16> : (const void*)k_cma_svd_block<8, 8>; break;
                 }
+#undef BBMPC_SVD_CASE
                 ensure_max_lds(kfn, 159 * 1024);     // + a few static words
-                // cooperative launch: the instance barrier spins, so every workgroup of the grid must be resident at
-                // once -- the runtime checks that and orders the launch against other cooperative grids
+                // The instance barrier spins, so an instance's workgroups must be resident together.  The grid is at most
+                // 256 workgroups of one per CU (97 KB of LDS each), i.e. it always fits the idle part of a 256-CU device, and
+                // a plain launch has the residency of a cooperative one (MI355X_MICROARCH.md); the cooperative form only
+                // adds the launch-time size check -- and 15-19 us of host time per launch during which this thread cannot
+                // run ahead of the GPU (five of them per control step: act() 10.5 ms against 9.3 ms device-resident).
+                // BBMPC_CMA_COOP=1 brings it back.
                 {
                     float* evp = c_evec.p;
                     unsigned* syp = c_sync.p;
                     int sweeps = 15;
                     void* kargs[] = {(void*)&q, (void*)&evp, (void*)&syp, (void*)&sweeps};
                     // 1-D grid, an instance's four workgroups on one XCD (kernels_cma.hpp); surplus workgroups return at once
-                    HIP_CHECK(hipLaunchCooperativeKernel(kfn, dim3(8 * 4 * ((G + 7) / 8)), dim3(1024), kargs, blds, stream));
+                    const dim3 sgrid(8 * (nbk / 2) * ((G + 7) / 8)), sblock(nbk == 16 ? 512 : 1024);
+                    if (sw.cma_coop) HIP_CHECK(hipLaunchCooperativeKernel(kfn, sgrid, sblock, kargs, blds, stream));
+                    else HIP_CHECK(hipLaunchKernel(kfn, sgrid, sblock, kargs, blds, stream));
                 }
             } else {
                 if (n <= 128 && !sw.cma_svd_general) {

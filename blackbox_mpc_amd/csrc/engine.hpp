@@ -88,7 +88,8 @@ struct Engine {
     int fused_mode = -1;     // -1 auto, 0 never, 1 always (env BBMPC_FUSED)
     // development / parity switches, read from the environment ONCE when the handle is created
     struct Switches {
-        bool cma_svd_v1 = false, cma_svd_rounds = false, cma_svd_general = false, cma_svd_gram = false, cma_fused = false;   // BBMPC_CMA_SVD_V1 / _ROUNDS / _GENERAL
+        bool cma_svd_v1 = false, cma_svd_rounds = false, cma_svd_general = false, cma_svd_gram = false, cma_fused = false, cma_coop = false;
+        int cma_nb = 0;                // BBMPC_CMA_NB: 8 / 16 column blocks in the block Jacobi (0 = automatic)   // BBMPC_CMA_SVD_V1 / _ROUNDS / _GENERAL
         bool mlp_generic = false;      // BBMPC_MLP_GENERIC
         int mlp_bf16 = 0;              // BBMPC_MLP_BF16: 0 off (default, fp32), 1 plain bf16 inputs, 3 split bf16 (hi+lo, three products)
         int mlp_pair = -1, mlp_q4 = -1;   // BBMPC_MLP_PAIR / BBMPC_MLP_Q4: -1 automatic, 0 / 1 forced

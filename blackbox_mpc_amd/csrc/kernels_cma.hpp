@@ -441,10 +441,10 @@ __device__ __forceinline__ void cma_instance_barrier_light(unsigned* ctr, unsign
     __syncthreads();
 }
 
-constexpr int CMA_SYNC_WORDS = 128;
+constexpr int CMA_SYNC_WORDS = 384;
 constexpr int CMA_SYNC_XCC_MASK = 24;                  // k_cma_svd_block: bit x = some workgroup of the instance runs on XCD x
 // sync: [G][CMA_SYNC_WORDS] unsigned: [0] barrier counter, [1 + sweep] "some pair rotated in this sweep"; the block kernel keeps
-// its block-pair bookkeeping in words 32..111
+// its block-pair bookkeeping in words 32.. (2 * NB + NB * NB of them)
 __global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps, int lds_floats) {
     const int g = blockIdx.y, WPG = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
     const int NW = blockDim.x >> 6;
@@ -664,10 +664,10 @@ __device__ __forceinline__ void l2_store16(float* p, cma_f32x4 v) {
 // NC = ceil(n / 64): the resident columns sit in LDS at a pitch of ld = 64 * NC floats, zero beyond n, so that every
 // per-element loop has a compile-time trip count and no bounds test (at n = 300 the tests, masks and branches were two
 // thirds of the instructions of a cross round).
-template <int NC>
+template <int NC, int NB>
 __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
     extern __shared__ __attribute__((aligned(16))) float cols[];
-    constexpr int NB = 8;                                   // blocks; NB / 2 workgroups per instance
+    // NB blocks of columns, NB / 2 workgroups per instance (8 / 4 or 16 / 8)
     constexpr int WPG = NB / 2;
     const int slot = blockIdx.x >> 3;
     const int g = (blockIdx.x & 7) + 8 * (slot / WPG), wg = slot % WPG;
@@ -681,10 +681,11 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
     // Block-pair bookkeeping (all zero at launch): a pair of blocks that was checked without a single rotation stays
     // clean until one of its blocks changes, so late sweeps -- and the final verification sweep entirely -- skip it.
     //   ver[b] + 1 = version of block b; iseen[b] = version at which block b's inner pairs were last found clean;
-    //   pseen[min*8+max] = (version of the lower block << 16 | version of the higher block) at the last clean check
+    //   pseen[min*NB+max] = (version of the lower block << 16 | version of the higher block) at the last clean check
     unsigned* ver = sync + 32;
-    unsigned* iseen = sync + 40;
-    unsigned* pseen = sync + 48;
+    unsigned* iseen = ver + NB;
+    unsigned* pseen = iseen + NB;                   // [NB][NB]
+    static_assert(32 + 2 * NB + NB * NB <= CMA_SYNC_WORDS, "sync words");
     __shared__ int s_skip[3], s_rotf[3];          // [0] cross pairs, [1] inner pairs of block x, [2] of block y
     __shared__ int s_same_xcd;
     __shared__ float s_ynrm[64], s_ysc[64];     // tracked |y_j|^2 and scale of the resident y-columns (bs <= 64)
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                 vx = __hip_atomic_load(ver + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
                 vy = __hip_atomic_load(ver + by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
                 const unsigned packed = ((bx < by ? vx : vy) << 16) | (bx < by ? vy : vx);
-                s_skip[0] = __hip_atomic_load(pseen + blo * 8 + bhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == packed;
+                s_skip[0] = __hip_atomic_load(pseen + blo * NB + bhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == packed;
                 s_skip[1] = R != 0 || __hip_atomic_load(iseen + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == vx;
                 s_skip[2] = R != 0 || __hip_atomic_load(iseen + by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == vy;
                 s_rotf[0] = s_rotf[1] = s_rotf[2] = 0;
@@ -966,7 +967,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                 if (!skip_ix && !rix && !rc) __hip_atomic_store(iseen + bx, nvx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!skip_iy && !riy && !rc) __hip_atomic_store(iseen + by, nvy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!skip_cross && !rc)
-                    __hip_atomic_store(pseen + blo * 8 + bhi, ((bx < by ? nvx : nvy) << 16) | (bx < by ? nvy : nvx), __ATOMIC_RELAXED,
+                    __hip_atomic_store(pseen + blo * NB + bhi, ((bx < by ? nvx : nvy) << 16) | (bx < by ? nvy : nvx), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
             }
             }   // not everything skipped
