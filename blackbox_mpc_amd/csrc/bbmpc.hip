@@ -3027,6 +3027,10 @@ static void gather_records(Engine* e, const float* d_records, float* d_gathered,
 int bbmpc_gather_records_dev(bbmpc_handle h, const float* d_records, float* d_gathered, int64_t count, int32_t slot) {
     API_BEGIN
     CHECK_HANDLE(h);
+    // the communicator of a population-sharded handle carries the per-iteration partials on the LAUNCH stream; one RCCL
+    // communicator must not be driven from two unsynchronised streams, so such a handle has no record gather (its ranks
+    // all hold the same agents: there is nothing to gather)
+    if (h->e->pop_sharded()) throw HipError(BBMPC_E_UNSUPPORTED, "record gather on a population-sharded handle (every rank already holds every agent's record)");
     CHECK_PTR(d_records);
     CHECK_PTR(d_gathered);
     Engine* e = h->e;
@@ -3043,6 +3047,10 @@ int bbmpc_optimize_gather_dev(bbmpc_handle h, const float* d_state, int32_t, int
                               float* d_next_state, float* d_gathered, int32_t slot) {
     API_BEGIN
     CHECK_HANDLE(h);
+    // the communicator of a population-sharded handle carries the per-iteration partials on the LAUNCH stream; one RCCL
+    // communicator must not be driven from two unsynchronised streams, so such a handle has no record gather (its ranks
+    // all hold the same agents: there is nothing to gather)
+    if (h->e->pop_sharded()) throw HipError(BBMPC_E_UNSUPPORTED, "record gather on a population-sharded handle (every rank already holds every agent's record)");
     CHECK_PTR(d_state);
     CHECK_PTR(d_records);
     CHECK_PTR(d_gathered);
@@ -3085,6 +3093,10 @@ int bbmpc_optimize_gather(bbmpc_handle h, const float* state, int32_t, int32_t n
                           float* reward, float* d_gathered, int32_t slot) {
     API_BEGIN
     CHECK_HANDLE_NOSETTLE(h);            // as bbmpc_optimize: consecutive calls are ordered by the stream / the resident kernel
+    // the communicator of a population-sharded handle carries the per-iteration partials on the LAUNCH stream; one RCCL
+    // communicator must not be driven from two unsynchronised streams, so such a handle has no record gather (its ranks
+    // all hold the same agents: there is nothing to gather)
+    if (h->e->pop_sharded()) throw HipError(BBMPC_E_UNSUPPORTED, "record gather on a population-sharded handle (every rank already holds every agent's record)");
     CHECK_PTR(state);
     CHECK_PTR(d_gathered);
     Engine* e = h->e;

@@ -65,7 +65,8 @@ struct FusedArgs {
     const unsigned* mbox;    // [A][16] words: [0] = [15] = sequence number, [1] step, [2] add_noise, [3..4] noise pointer, [5..7] state
     unsigned* gone;          // [A][16] pinned words: the last sequence number handled, written when the workgroup leaves
     unsigned linger_ticks;   // how long to wait for a request, in wall_clock64 ticks (100 MHz)
-    int test_quit_agent;     // test hook (BBMPC_LINGER_TEST_QUIT): this agent's workgroup leaves after every control step, -1 = none
+    int test_quit_agent;     // test hook (BBMPC_LINGER_TEST_QUIT = a + 1): agent a's workgroup leaves after every control step, -1 = none;
+                             // 1000 + a: every agent from a on leaves (more than one 16-entry line of the agent map)
     const int* amap;         // optional: blockIdx.x -> agent (a launch for a subset of the agents), null = identity
 };
 
@@ -610,7 +611,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                     const bool mine = tid < 13 ? (w & 0xffffu) == (want & 0xffffu) : (tid == 15 ? w == want : true);
                     const unsigned w15 = __builtin_amdgcn_readlane(w, 15);
                     if (__builtin_amdgcn_ballot_w64(mine) == ~0ull) break;
-                    if (w15 == 0xffffffffu || (long long)wall_clock64() - t0 > (long long)p.linger_ticks || a == p.test_quit_agent) { quit = true; break; }
+                    if (w15 == 0xffffffffu || (long long)wall_clock64() - t0 > (long long)p.linger_ticks || a == p.test_quit_agent || (p.test_quit_agent >= 999 && a >= p.test_quit_agent - 999)) { quit = true; break; }
                 }
                 if (tid < 16) mb[tid] = (quit && tid == 15) ? 0xffffffffu : w;
             }

@@ -100,6 +100,33 @@ def test_a_request_that_crosses_some_workgroups_exit(L, monkeypatch, quit_agent)
     np.testing.assert_array_equal(got, ref)
 
 
+def test_more_than_sixteen_agents_leave_at_once(L, monkeypatch):
+    # the agent map of a subset relaunch holds one int32 per agent (ceil(A / 16) lines of the pinned block): 30 of 40
+    # workgroups leave after every control step (BBMPC_LINGER_TEST_QUIT = 1000 + first leaving agent)
+    steps, A = 12, 40
+    monkeypatch.setenv("BBMPC_LINGER_US", "0")
+    ref = _run(_engine(L, L.OPT_PI2, num_agents=A), steps)
+    monkeypatch.delenv("BBMPC_LINGER_US")
+    monkeypatch.setenv("BBMPC_LINGER_TEST_QUIT", str(1000 + 10))
+    eng = _engine(L, L.OPT_PI2, num_agents=A)
+    got = _run(eng, steps)
+    monkeypatch.delenv("BBMPC_LINGER_TEST_QUIT")
+    np.testing.assert_array_equal(got, ref)
+    served, launched = eng.call_stats()             # every call after the first: 10 agents served resident, 30 relaunched
+    assert served + launched == steps and launched >= steps - 1
+
+
+def test_call_stats_say_which_path_served(L, monkeypatch):
+    eng = _engine(L, L.OPT_CEM)
+    _run(eng, 20)
+    served, launched = eng.call_stats()
+    assert served + launched == 20 and served >= 15          # back-to-back calls ride the resident kernel
+    monkeypatch.setenv("BBMPC_LINGER_US", "0")
+    eng0 = _engine(L, L.OPT_CEM)
+    _run(eng0, 10)
+    assert eng0.call_stats() == (0, 10)
+
+
 def test_two_resident_handles_and_destruction_while_resident(L):
     a, b = _engine(L, L.OPT_CEM, seed=1), _engine(L, L.OPT_PI2, seed=2)
     sa = sb = O.pendulum_start_states(1)
