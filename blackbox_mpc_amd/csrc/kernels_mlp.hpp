@@ -188,6 +188,23 @@ __device__ __forceinline__ int tile_addr(int f, int p) {
 // spread over ALL threads: one thread per (particle,u) walking t serially pays one global-memory latency per step
 // (H x ~1 us -- a fifth of the quad kernel's run time at config 4).  The squared bound violation is summed per
 // (particle,u) in t order afterwards, from LDS.  Contains a barrier when q.pen is set (uniform).
+// XCD-aware workgroup -> tile map for grids of (tiles, agents).  Workgroup `lin` = bx + gx * by is dispatched to XCD
+// lin % 8 (observed, for speed only: MI355X_MICROARCH.md, workgroup dispatch), and each XCD has its own L2.  The
+// workgroups of one XCD get a CONTIGUOUS range of an agent's tiles, so that the 16-byte pieces a 4-particle workgroup
+// writes into a row of the particle-minor sample matrix [A][H*U][Nst] fill whole 128-byte lines inside ONE L2 instead
+// of leaving eight L2s with a partial line each (config 4: 1.4 MB written back for 0.72 MB of samples).  A bijection of
+// [0, gx) for every by, whatever the placement really is.
+__device__ __forceinline__ int xcd_tile(int bx, int gx, int by) {
+    const int off = (gx * by) & 7;
+    const int xr = (bx + off) & 7;                        // my XCD
+    int base = 0;
+    for (int x = 0; x < xr; ++x) {
+        const int first = (x - off) & 7;                    // smallest bx of this row on XCD x
+        base += first < gx ? (gx - first + 7) >> 3 : 0;
+    }
+    return base + ((bx - ((xr - off) & 7)) >> 3);
+}
+
 template <int TP>
 __device__ __forceinline__ void mlp_fill_actions(const MlpRolloutArgs& q, int a, int n0, int tid, int nthr,
                                                  float* acts, float* pens) {
@@ -876,7 +893,7 @@ __global__ __launch_bounds__(NWQ * 64, 1) void k_rollout_mlp_q4(MlpRolloutArgs q
     constexpr int NT = NWQ * 64, QP = 4;                 // threads, particles per workgroup
     constexpr int HK = HG * 4;                           // hidden width (multiple of 4)
     constexpr int KS = (HG + NWQ - 1) / NWQ;             // k groups per wave in the K-split last layer
-    const int a = blockIdx.y, n0 = blockIdx.x * QP;
+    const int a = blockIdx.y, n0 = xcd_tile(blockIdx.x, gridDim.x, blockIdx.y) * QP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = p.S, U = p.U, H = p.H;
     const int Sp = (S + 3) & ~3;

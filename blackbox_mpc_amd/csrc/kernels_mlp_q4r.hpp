@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     constexpr int KT = (HG + 7) / 8;                     // tail job: k groups per slice (8 slices)
     static_assert(HG < HP && KA * 4 <= HP && (KB - 1) * 16 + 15 < HP && K0G > SG, "padding / input groups");
     static_assert(NJ == 3 && TF == 8 && KT <= KA && KB <= KA && AG == 2, "written for 200 hidden units, 20 + <= 8 inputs");
-    const int a = blockIdx.y, n0 = blockIdx.x * QP;
+    const int a = blockIdx.y, n0 = xcd_tile(blockIdx.x, gridDim.x, blockIdx.y) * QP;     // an XCD's workgroups: contiguous particles
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches
     const int S = p.S, U = p.U, H = p.H;
     const bool normd = m.normalized != 0;
