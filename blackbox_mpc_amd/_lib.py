@@ -1,6 +1,7 @@
 """ctypes binding of include/bbmpc.h.  There is no CPU fallback: if the HIP
 library cannot be loaded, importing this module raises."""
 import ctypes
+import threading
 import os
 
 import numpy as np
@@ -145,14 +146,17 @@ lib = _load()
 
 # an exception raised inside a Python callback the engine called (utils/device_functions.py): the C ABI can only carry a
 # status code, so the callback parks it here and check() re-raises it as the cause
-callback_error = None
+_callback_state = threading.local()                       # per thread, like bbmpc_last_error()
+
+
+def park_callback_error(ex):
+    _callback_state.error = ex
 
 
 def check(code):
-    global callback_error
     if code != 0:
         err = BBMPCError(code, lib.bbmpc_last_error().decode("utf-8", "replace"))
-        cause, callback_error = callback_error, None
+        cause, _callback_state.error = getattr(_callback_state, "error", None), None
         if cause is not None:
             raise err from cause
         raise err

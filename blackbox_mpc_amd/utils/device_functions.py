@@ -130,7 +130,7 @@ class _TorchCallback:
                 body(d_cur, d_act, d_next, int(batch), d_out, stream or 0)
                 return 0
             except BaseException as ex:                   # noqa: BLE001 -- nothing may unwind through the C frames
-                L.callback_error = ex
+                L.park_callback_error(ex)
                 return 1
         return L.ROWS_CALLBACK(cb)
 
@@ -236,15 +236,21 @@ class TorchDynamicsFunction(_TorchCallback):
         return call_torch_dynamics(self.fn, torch.as_tensor(np.asarray(x, np.float32), device=dev)).to(torch.float32).cpu().numpy()
 
 
-_torch_plugins = {}                                        # id(callable) -> adapter (keeps the callable alive with it)
+_torch_plugins = {}                                        # fallback for callables that take no attributes (builtins, slots)
 
 
 def torch_plugin(fn, cls):
-    """The adapter of a plain callable, one per callable object."""
-    key = (id(fn), cls)
-    p = _torch_plugins.get(key)
-    if p is None or p.fn is not fn:
-        p = _torch_plugins[key] = cls(fn)
+    """The adapter of a plain callable, one per callable object: kept on the callable itself when it takes attributes
+    (functions, lambdas, torch modules), so that it lives exactly as long as the callable does."""
+    attr = "_bbmpc_" + cls.__name__
+    p = getattr(fn, attr, None) or _torch_plugins.get((id(fn), cls))
+    if isinstance(p, cls) and p.fn is fn:
+        return p
+    p = cls(fn)
+    try:
+        object.__setattr__(fn, attr, p)
+    except (AttributeError, TypeError):
+        _torch_plugins[(id(fn), cls)] = p                 # (holds fn through p.fn: the id cannot be recycled)
     return p
 
 
