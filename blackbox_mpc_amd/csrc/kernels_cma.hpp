@@ -218,20 +218,53 @@ __device__ __forceinline__ void cma_paths_body(const CmaArgs& p, int g) {
     float* t2 = p.BD + (size_t)g * n * n;      // BD scratch is free after the sampling GEMM
     const float* __restrict__ B = p.B + (size_t)g * n * n;
     const float* __restrict__ ym = p.ymean + off;
-    for (int j = tid; j < n; j += nthr) {
-        float s = 0.0f;
-        for (int i0 = 0; i0 < n; i0 += 8) {
-            float bv[8], yv[8];
+    {
+        // the sum over i is split into K-slices over thread groups of ceil(n / 64) waves (as many as the workgroup holds,
+        // at most 4) and combined in slice order: one thread per column walked all n terms, eight L2 trips at a time
+        __shared__ float s_part[4][512];
+        const int npad = (n + 63) & ~63;
+        const int ng = (n > 128 && n <= 512) ? max(1, min(4, nthr / npad)) : 1;     // (small n: the order the fused kernel shares)
+        if (ng > 1) {
+            const int gi = tid / npad, j = tid - gi * npad;
+            const int Kc = (n + ng - 1) / ng, i_lo = gi * Kc, i_hi = min(n, i_lo + Kc);
+            if (gi < ng && j < n) {
+                float s = 0.0f;
+                for (int i0 = i_lo; i0 < i_hi; i0 += 8) {
+                    float bv[8], yv[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i = min(i0 + q, n - 1);
-                bv[q] = B[(size_t)i * n + j];
-                yv[q] = ym[i];
+                    for (int q = 0; q < 8; ++q) {
+                        const int i = min(i0 + q, i_hi - 1);
+                        bv[q] = B[(size_t)i * n + j];
+                        yv[q] = ym[i];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (i0 + q < i_hi) s = fmaf(bv[q], yv[q], s);
+                }
+                s_part[gi][j] = s;
             }
+            __syncthreads();
+            for (int j2 = tid; j2 < n; j2 += nthr) {
+                float s = s_part[0][j2];
+                for (int q = 1; q < ng; ++q) s = s + s_part[q][j2];
+                t2[j2] = s * (1.0f / p.Dd[off + j2]);
+            }
+        } else {
+            for (int j = tid; j < n; j += nthr) {
+                float s = 0.0f;
+                for (int i0 = 0; i0 < n; i0 += 8) {
+                    float bv[8], yv[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) if (i0 + q < n) s = fmaf(bv[q], yv[q], s);
+                    for (int q = 0; q < 8; ++q) {
+                        const int i = min(i0 + q, n - 1);
+                        bv[q] = B[(size_t)i * n + j];
+                        yv[q] = ym[i];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (i0 + q < n) s = fmaf(bv[q], yv[q], s);
+                }
+                t2[j] = s * (1.0f / p.Dd[off + j]);
+            }
         }
-        t2[j] = s * (1.0f / p.Dd[off + j]);
     }
     __syncthreads();
     const float cs = p.c.c_sigma, cc = p.c.cc;
@@ -239,15 +272,23 @@ __device__ __forceinline__ void cma_paths_body(const CmaArgs& p, int g) {
     const float coef_c = p.c.h_sigma * sqrtf((cc * (2.0f - cc)) * p.c.mu_eff);
     // s_i = sum_j B[i][j] t2[j]: one wave per row i, lanes along j (64-lane partial sums in j order, then the wave reduction)
     float part = 0.0f;
-    for (int i = wv; i < n; i += NW) {
-        float s = 0.0f;
-        for (int j = lane; j < n; j += 64) s = fmaf(B[(size_t)i * n + j], t2[j], s);
-        s = wave_sum(s);
-        if (lane == 0) {
-            const float ps = (1.0f - cs) * p.p_sigma[off + i] + coef_s * s;    // :170-171
-            p.p_sigma[off + i] = ps;
-            part += ps * ps;
-            p.p_C[off + i] = (1.0f - cc) * p.p_C[off + i] + coef_c * ym[i];    // :177
+    for (int ib = wv; ib < n; ib += 4 * NW) {              // four rows per trip: their loads are in flight together
+        float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = lane; j < n; j += 64) {
+            const float tj = t2[j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s4[q] = fmaf(B[(size_t)min(ib + q * NW, n - 1) * n + j], tj, s4[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ib + q * NW;
+            const float s = wave_sum(s4[q]);
+            if (lane == 0 && i < n) {
+                const float ps = (1.0f - cs) * p.p_sigma[off + i] + coef_s * s;    // :170-171
+                p.p_sigma[off + i] = ps;
+                part += ps * ps;
+                p.p_C[off + i] = (1.0f - cc) * p.p_C[off + i] + coef_c * ym[i];    // :177
+            }
         }
     }
     if (lane == 0) red[wv] = part;
@@ -577,11 +618,18 @@ __global__ __launch_bounds__(1024) void k_cma_svd_norms(CmaArgs p, const float* 
     const float* At = At_all + (size_t)g * n * n;
     float* norms = norms_all + (size_t)g * n;
     int* perm = perm_all + (size_t)g * n;
-    for (int j = wv; j < n; j += NW) {
-        float al = 0.0f;
-        for (int e = lane; e < n; e += 64) { const float v = At[(size_t)j * n + e]; al = fmaf(v, v, al); }
-        al = wave_sum(al);
-        if (lane == 0) { const float nj = sqrtf(al); s_norm[j] = nj; norms[j] = nj; }
+    for (int jb = wv; jb < n; jb += 4 * NW) {              // four columns per trip (same sums, their loads in flight together)
+        float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int e = lane; e < n; e += 64) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float v = At[(size_t)min(jb + q * NW, n - 1) * n + e]; a4[q] = fmaf(v, v, a4[q]); }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = jb + q * NW;
+            const float al = wave_sum(a4[q]);
+            if (lane == 0 && j < n) { const float nj = sqrtf(al); s_norm[j] = nj; norms[j] = nj; }
+        }
     }
     __syncthreads();
     for (int j = tid; j < n; j += nthr) {
