@@ -507,7 +507,8 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
         if (n <= 512 && !sw.cma_svd_v1) {
             // warm-started Jacobi, one 1024-thread workgroup per instance (kernels_cma.hpp)
             HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * CMA_SYNC_WORDS * sizeof(unsigned), stream));
-            hipLaunchKernelGGL(k_cma_warm, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(256), 0, stream, q, c_evec.p);
+            if (n > 128 && (n & 3) == 0) hipLaunchKernelGGL(k_cma_warm_mfma, dim3((n + 31) / 32, (n + 63) / 64, G), dim3(256), 0, stream, q, c_evec.p);
+            else hipLaunchKernelGGL(k_cma_warm, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(256), 0, stream, q, c_evec.p);
             const int bsz = (n + 7) / 8;
             const int ncb = (n + 63) / 64;                               // k_cma_svd_block<ncb, NB>: LDS column pitch 64 * ncb
             // NB = 16 column blocks on 8 workgroups per instance when there are CUs for them (BBMPC_CMA_NB overrides)

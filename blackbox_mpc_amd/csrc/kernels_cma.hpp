@@ -451,6 +451,38 @@ __global__ __launch_bounds__(256) void k_cma_warm(CmaArgs p, float* At_all) {
         }
 }
 
+// The same product on the matrix cores for large n (n % 4 == 0), as k_cma_gemm_y_mfma: for a fixed k both B[k][j0 ..] and
+// C[k][e0 ..] are contiguous, i.e. the A / B fragments of v_mfma_f32_16x16x4_f32 load straight from L2.  Workgroup tile
+// 64 (j) x 32 (e), wave w owns rows 16w .. 16w+15.  grid (ceil(n/32), ceil(n/64), G), block 256.  32 -> ~8 us at n = 300.
+__global__ __launch_bounds__(256) void k_cma_warm_mfma(CmaArgs p, float* At_all) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int g = blockIdx.z, n = p.n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = blockIdx.y * 64 + wave * 16, e0 = blockIdx.x * 32;
+    if (j0 >= n) return;
+    const int lm = lane & 15, lk = lane >> 4;
+    const float* Bm = p.B + (size_t)g * n * n + min(j0 + lm, n - 1);                 // + k * n
+    const float* Cm = p.C + (size_t)g * n * n;
+    const int ec0 = min(e0 + lm, n - 1), ec1 = min(e0 + 16 + lm, n - 1);
+    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 5
+    for (int k0 = 0; k0 < n; k0 += 4) {
+        const size_t kr = (size_t)(k0 + lk) * n;
+        const float a = Bm[kr];
+        const float b0 = Cm[kr + ec0], b1 = Cm[kr + ec1];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc1, 0, 0, 0);
+    }
+    float* At = At_all + (size_t)g * n * n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + 4 * lk + r;
+        if (j >= n) continue;
+        if (e0 + lm < n) At[(size_t)j * n + e0 + lm] = acc0[r];
+        if (e0 + 16 + lm < n) At[(size_t)j * n + e0 + 16 + lm] = acc1[r];
+    }
+}
+
 __device__ __forceinline__ void cma_instance_barrier(unsigned* ctr, unsigned target) {
     __threadfence();
     __syncthreads();
