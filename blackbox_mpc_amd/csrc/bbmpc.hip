@@ -942,8 +942,11 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
             dim3 pgrid((ra.n_pop + nt * MLP_TP - 1) / (nt * MLP_TP), A), pblock(mlp_pair_waves(13, nt) * 64);
             dominant_kernel = "k_rollout_mlp_pair";
             prof_begin();
-            if (nt == 2 && S == 20 && U == 6 && ra.H == 50) {
-                // BASELINE config 5: dimensions at compile time (fewer register spills, kernels_mlp.hpp)
+            if (nt == 2 && S == 20 && U == 6 && ra.H == 50 && ra.reward_kind == REW_CHEETAH && !q.traj && mlp.half_tail[1] && mlp.half_tail[2]) {
+                // BASELINE config 5: dimensions and the reward at compile time (no register spills, kernels_mlp.hpp)
+                ensure_max_lds((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2, 20, 6, 50, REW_CHEETAH, 1>), 159 * 1024);
+                hipLaunchKernelGGL((k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2, 20, 6, 50, REW_CHEETAH, 1>), pgrid, pblock, plds, stream, q);
+            } else if (nt == 2 && S == 20 && U == 6 && ra.H == 50) {
                 ensure_max_lds((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2, 20, 6, 50>), 159 * 1024);
                 hipLaunchKernelGGL((k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2, 20, 6, 50>), pgrid, pblock, plds, stream, q);
             } else if (nt == 2 && S == 20 && U == 6) {

@@ -528,37 +528,55 @@ __device__ __forceinline__ float apply_act_ct(float x) {
     else return x;
 }
 
-// Two-tile mode runs HT + 1 waves: feature tile HT-1 (the 13th, half-empty one for 200 hidden units) is served by TWO
-// waves, wave HT-1 for particle tile 0 and wave HT for particle tile 1.  Waves land on SIMD (wave & 3), so with HT = 13
-// SIMD 0 used to carry four waves x two tile-jobs = 8 jobs against 6 on the others; split like this the load is
-// 7 / 7 / 6 / 6 (tile-jobs per SIMD) and the critical SIMD's matrix time drops by an eighth.
-constexpr int mlp_pair_waves(int HT, int NTILES) { return HT + (NTILES == 2 ? 1 : 0); }
+// Two-tile mode runs HT - 1 waves (12 for 200 hidden units: three per SIMD, 168 registers each -- fourteen waves had
+// 128 and spilled).  Waves land on SIMD (wave & 3).  Feature tile HT-1 (the 13th, half-empty one) has no wave of its
+// own: its layer-1 job is one more dependent chain of 50 MFMAs, and whichever SIMD carries it whole runs 4 jobs against
+// 3 while the barrier at the end of the interval waits -- a quarter of the matrix time of every layer-1 interval.  So
+// the K loop of that job is split in four quarters taken by the last four waves (wid HT-5 .. HT-2, one per SIMD) next
+// to their own tile: quarters 0..2 go first in the interval, leave their partial pre-activations in LDS and raise a
+// flag; quarter 3's wave (the owner: also layer 0 of that tile, the shortest quarter) runs its own job first, then
+// its quarter, adds the partials, applies the activation and does the K slab of the last layer.  The flags are LDS
+// words polled inside the interval (they are long up when the owner looks) -- no extra barrier.
+constexpr int mlp_pair_waves(int HT, int NTILES) { return NTILES == 2 ? HT - 1 : HT; }
+// development hook (tools/microbench/pair_probe.hip): per-wave clocks at the interval boundaries of one step
+#ifndef BBMPC_PAIR_CLK
+#define BBMPC_PAIR_CLK(slot)
+#endif
+constexpr int mlp_pair_kq(int HT) { return (HT + 3) / 4; }          // k tiles per helper quarter
+template <int V> struct IC { static constexpr int value = V; };
 
 // CS / CU / CH: dim_S / dim_U / the planning horizon at compile time (0 = read them from the arguments).  With run-time dimensions the compiler keeps
 // some forty loop-invariant LDS addresses per thread, does not fit them into the 128 registers a 14-wave workgroup
 // leaves per lane and spills 84 bytes per thread: 84 B x 896 threads x 250 workgroups = 18.8 MB of scratch written per
 // launch -- the "27 MB written for 9.6 MB of samples" of profiles/r2_cfg5cem.md (WRITE_SIZE itself is exact:
 // tools/microbench/write_size_calib.hip) -- and ~20 scratch reloads per pipeline step.
-template <int HT, int A0, int A1, int A2, int NTILES, int CS = 0, int CU = 0, int CH = 0>
+// CR: the built-in reward kind at compile time (-1 = read it from the arguments).
+// CHALF: whether the last hidden 16-feature tile is half empty (MlpDesc::half_tail of both hidden layers), -1 = run time.
+template <int HT, int A0, int A1, int A2, int NTILES, int CS = 0, int CU = 0, int CH = 0, int CR = -1, int CHALF = -1>
 __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp_pair(MlpRolloutArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RolloutArgs& p = q.r;
     const MlpDesc& m = q.m;
     constexpr int NW = HT, NT = mlp_pair_waves(HT, NTILES) * 64, IT0 = 2, OTL = 2;   // NW: feature tiles = partial-sum slots
     const int a = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wave = wid < HT ? wid : HT - 1;                 // the feature tile this wave serves
-    // which particle tiles this wave works on (everything else -- barriers, epilogue threads -- is common)
-    const bool serves0 = NTILES == 1 || wid != HT;
-    const bool serves1 = NTILES == 2 && wid != HT - 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: roles are scalar branches
+    const int wave = wid;                                     // the feature tile this wave serves
+    // two-tile mode: waves HT-5 .. HT-2 also take quarter hq of feature tile HT-1's K loop, hq = 3 owns that tile
+    constexpr int KQ = mlp_pair_kq(HT), XT = HT - 1;
+    const int hq = (NTILES == 2 && wid >= HT - 5) ? wid - (HT - 5) : -1;
+    const bool helper = hq >= 0, owner = hq == 3;
+    const int kbase = helper ? hq * KQ : 0;                   // first k tile of the quarter
     const int S = CS ? CS : p.S, U = CU ? CU : p.U, H = CH ? CH : p.H;
     const int Sp = (S + 3) & ~3;
     const bool normd = m.normalized != 0;
-    const bool half1 = m.half_tail[1] != 0, half2 = m.half_tail[2] != 0;   // inputs of layer 1 / of the last layer
+    const bool half1 = CHALF >= 0 ? CHALF != 0 : m.half_tail[1] != 0;      // inputs of layer 1 / of the last layer
+    const bool half2 = CHALF >= 0 ? CHALF != 0 : m.half_tail[2] != 0;
     // ---- LDS carve
     const int sz_xs = IT0 * 256, sz_h0 = HT * 256, sz_part = NW * OTL * 256, sz_st = 2 * MLP_TP * Sp,
               sz_acts = (H * MLP_TP * U + 3) & ~3, sz_pen = (MLP_TP * U + 63) & ~63;
-    const int tile_sz = sz_xs + sz_h0 + sz_part + sz_st + sz_acts + sz_pen;
+    const int sz_qp = NTILES == 2 ? 3 * 256 + 64 : 0;   // helper partials [3][64 lanes][4] + their flags
+    const int tile_sz = sz_xs + sz_h0 + sz_part + sz_st + sz_acts + sz_pen + sz_qp;
     float* nmean = smem + NTILES * tile_sz;
     float* ninv = nmean + (S + U);
     float* tmean = ninv + (S + U);
@@ -570,33 +588,94 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     auto T_st = [&](int ti) { return smem + ti * tile_sz + sz_xs + sz_h0 + sz_part; };
     auto T_acts = [&](int ti) { return smem + ti * tile_sz + sz_xs + sz_h0 + sz_part + sz_st; };
     auto T_pen = [&](int ti) { return smem + ti * tile_sz + sz_xs + sz_h0 + sz_part + sz_st + sz_acts; };
+    auto T_qp = [&](int ti) { return smem + ti * tile_sz + sz_xs + sz_h0 + sz_part + sz_st + sz_acts + sz_pen; };
 
     // ---- stationary weights (operand order, see set_mlp)
     // layer-1 and last-layer slabs stay in VGPRs for the whole recurrence; with two tiles in flight the 8
     // layer-0 operands do not fit the 128-register budget any more and are re-read per stage (L1/L2-resident)
     float wr_in[IT0 * 4], wr_hid[HT * 4], wr_out[OTL * 4];
-    const float* __restrict__ w_in_p = m.wpack[0] + ((size_t)wave * m.tiles[0]) * 256 + lane;
+    // per-lane 32-bit offsets from the (uniform) packed-array bases: the loads take an SGPR base + VGPR offset and no
+    // 64-bit per-lane pointer has to stay live across the recurrence
     const int it0n = m.tiles[0];
-    auto load_w_in = [&]() {
+    const unsigned w_in_off = (unsigned)(wave * it0n * 256 + lane);
+    const float* __restrict__ w_in_b = m.wpack[0];
+    auto load_w_in = [&](float* w, unsigned off) {
 #pragma unroll
         for (int it = 0; it < IT0; ++it)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) wr_in[it * 4 + s] = (it < it0n) ? w_in_p[(it * 4 + s) * 64] : 0.0f;
+            for (int s = 0; s < 4; ++s) w[it * 4 + s] = (it < it0n) ? w_in_b[off + (unsigned)((it * 4 + s) * 64)] : 0.0f;
     };
-    if (NTILES == 1) load_w_in();
+    load_w_in(wr_in, w_in_off);
 #pragma unroll
     for (int it = 0; it < HT; ++it)
 #pragma unroll
         for (int s = 0; s < 4; ++s) wr_hid[it * 4 + s] = m.wpack[1][(((size_t)wave * HT + it) * 4 + s) * 64 + lane];
+    // feature tile XT: a helper's quarter of the layer-1 operands stays in registers (the owner's is one k tile); what only
+    // the owner needs -- layer-0 operands, last-layer slab, the two biases of that tile -- waits in LDS, [slot][lane][4]:
+    // slots 0 .. IT0-1 layer 0, IT0 .. IT0+OTL-1 last layer, then bias 0, bias 1
+    constexpr int XO_B0 = IT0 + OTL, XO_B1 = XO_B0 + 1, XO_N = XO_B1 + 1;
+    static_assert(HT - 3 * KQ <= 1, "owner quarter = one k tile");
+    float wx[NTILES == 2 ? KQ * 4 : 1];
+    float* xo = nmean + (((S + U) * 2 + S * 3 + 3) & ~3);          // 16-byte aligned behind the statistics
+    if constexpr (NTILES == 2) {
+#pragma unroll
+        for (int i = 0; i < KQ * 4; ++i) wx[i] = 0.0f;
+        if (helper) {
+#pragma unroll
+            for (int j = 0; j < KQ; ++j)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (kbase + j < HT) wx[j * 4 + s] = m.wpack[1][(((size_t)XT * HT + kbase + j) * 4 + s) * 64 + lane];
+        }
+        if (owner) {
+            float t8[IT0 * 4];
+            load_w_in(t8, (unsigned)(XT * it0n * 256 + lane));
+#pragma unroll
+            for (int it = 0; it < IT0; ++it)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) xo[(it * 64 + lane) * 4 + s] = t8[it * 4 + s];
+#pragma unroll
+            for (int ot = 0; ot < OTL; ++ot)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    xo[((IT0 + ot) * 64 + lane) * 4 + s] = (ot < m.tiles[3]) ? m.wpack[2][(((size_t)ot * HT + XT) * 4 + s) * 64 + lane] : 0.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                xo[(XO_B0 * 64 + lane) * 4 + s] = m.bpack[0][(unsigned)((XT * 64 + lane) * 4 + s)];
+                xo[(XO_B1 * 64 + lane) * 4 + s] = m.bpack[1][(unsigned)((XT * 64 + lane) * 4 + s)];
+            }
+        }
+    }
+    auto xo_get = [&](int slot) { return *reinterpret_cast<const f32x4*>(xo + ((size_t)slot * 64 + lane) * 4); };
+    // Interval 1 of the two-tile pipeline holds layer 0 of tile X and the epilogue of tile Y, both latency bound; a wave
+    // that runs them one after the other makes the interval twice as long as it has to be.  The EWS waves whose threads
+    // reduce state features (tid < 16 S) therefore do no layer 0 there: wave EWS + i (no reduction work) takes feature
+    // tile i next to its own as a second, independent chain, with tile i's operands in LDS ([i][it | bias][lane][4]).
+    const int EWS = (MLP_TP * S + 63) >> 6;
+    const bool split_i1 = NTILES == 2 && 2 * EWS <= HT - 2;
+    const int t2 = (split_i1 && wid >= EWS && wid < 2 * EWS) ? wid - EWS : -1;         // second feature tile of this wave
+    float* xo2 = xo + XO_N * 256;
+    if constexpr (NTILES == 2) {
+        if (t2 >= 0) {
+            float t8[IT0 * 4];
+            load_w_in(t8, (unsigned)(t2 * it0n * 256 + lane));
+#pragma unroll
+            for (int it = 0; it < IT0; ++it)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) xo2[((t2 * (IT0 + 1) + it) * 64 + lane) * 4 + s] = t8[it * 4 + s];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xo2[((t2 * (IT0 + 1) + IT0) * 64 + lane) * 4 + s] = m.bpack[0][(unsigned)((t2 * 64 + lane) * 4 + s)];
+        }
+    }
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
             wr_out[ot * 4 + s] = (ot < m.tiles[3]) ? m.wpack[2][(((size_t)ot * HT + wave) * 4 + s) * 64 + lane] : 0.0f;
-    // biases are re-read per stage (one L1-resident 16-byte load each): 8 VGPRs that the 128-register budget
-    // of a 13-wave workgroup cannot spare
-    const float* __restrict__ bias0_p = m.bpack[0] + ((size_t)wave * 64 + lane) * 4;
-    const float* __restrict__ bias1_p = m.bpack[1] + ((size_t)wave * 64 + lane) * 4;
+    const unsigned bias_off = (unsigned)((wave * 64 + lane) * 4);
+    const f32x4 bias0_r = *reinterpret_cast<const f32x4*>(m.bpack[0] + bias_off);
+    const f32x4 bias1_r = *reinterpret_cast<const f32x4*>(m.bpack[1] + bias_off);
+
     for (int f = tid; f < S + U; f += NT) {
         const float mu = normd ? (f < S ? m.mean_s[f] : m.mean_a[f - S]) : 0.0f;
         const float sd = normd ? (f < S ? m.std_s[f] : m.std_a[f - S]) : 1.0f;
@@ -618,6 +697,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
         mlp_fill_actions<MLP_TP>(q, a, n0, tid, NT, acts, pens);
         for (int i = tid; i < sz_xs; i += NT) xs[i] = 0.0f;
         for (int i = tid; i < MLP_TP * S; i += NT) st[(i / S) * Sp + (i % S)] = p.state[a * S + (i % S)];
+        if (NTILES == 2 && tid < 64) reinterpret_cast<int*>(T_qp(ti) + 3 * 256)[tid] = 0;       // helper flags
     }
     __syncthreads();
     for (int ti = 0; ti < NTILES; ++ti) {
@@ -633,11 +713,41 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     __syncthreads();
 
     // ---- stages
-    auto stage_A = [&](int ti) {
-        if (!(ti == 0 ? serves0 : serves1)) return;
+    auto layer0 = [&](int ti, int ft, const float* w, f32x4 acc) {
         const float* xs = T_xs(ti);
-        if (NTILES == 2) load_w_in();
-        f32x4 acc = *reinterpret_cast<const f32x4*>(bias0_p);
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(xs + ((size_t)it * 64 + lane) * 4);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[it * 4 + 0], b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[it * 4 + 1], b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[it * 4 + 2], b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[it * 4 + 3], b.w, acc, 0, 0, 0);
+        }
+        acc.x = apply_act_ct<A0>(acc.x); acc.y = apply_act_ct<A0>(acc.y);
+        acc.z = apply_act_ct<A0>(acc.z); acc.w = apply_act_ct<A0>(acc.w);
+        *reinterpret_cast<f32x4*>(T_h0(ti) + ((size_t)ft * 64 + lane) * 4) = acc;
+    };
+    auto stage_A = [&](int ti) {
+        layer0(ti, wave, wr_in, bias0_r);
+        if constexpr (NTILES == 2)
+            if (owner) {                                                    // feature tile XT as well
+                float w[IT0 * 4];
+#pragma unroll
+                for (int it = 0; it < IT0; ++it) {
+                    const f32x4 v = xo_get(it);
+                    w[it * 4 + 0] = v.x; w[it * 4 + 1] = v.y; w[it * 4 + 2] = v.z; w[it * 4 + 3] = v.w;
+                }
+                layer0(ti, XT, w, xo_get(XO_B0));
+            }
+    };
+    // layer 0 of this wave's tile and, as a second chain, of tile t2 (or XT for the owner): interval 1 with split_i1
+    auto stage_A1 = [&](int ti) {
+        const float* xs = T_xs(ti);
+        const bool has2 = t2 >= 0 || owner;
+        const float* w2 = owner ? xo : xo2 + (size_t)(t2 < 0 ? 0 : t2) * (IT0 + 1) * 256;
+        const float* b2 = owner ? xo + XO_B0 * 256 : w2 + IT0 * 256;
+        f32x4 acc = bias0_r, acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (has2) acc2 = *reinterpret_cast<const f32x4*>(b2 + (size_t)lane * 4);
 #pragma unroll
         for (int it = 0; it < IT0; ++it) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(xs + ((size_t)it * 64 + lane) * 4);
@@ -645,32 +755,171 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 1], b.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 2], b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 3], b.w, acc, 0, 0, 0);
+            if (has2) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(w2 + ((size_t)it * 64 + lane) * 4);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b.x, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b.y, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b.z, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b.w, acc2, 0, 0, 0);
+            }
         }
         acc.x = apply_act_ct<A0>(acc.x); acc.y = apply_act_ct<A0>(acc.y);
         acc.z = apply_act_ct<A0>(acc.z); acc.w = apply_act_ct<A0>(acc.w);
         *reinterpret_cast<f32x4*>(T_h0(ti) + ((size_t)wave * 64 + lane) * 4) = acc;
+        if (has2) {
+            acc2.x = apply_act_ct<A0>(acc2.x); acc2.y = apply_act_ct<A0>(acc2.y);
+            acc2.z = apply_act_ct<A0>(acc2.z); acc2.w = apply_act_ct<A0>(acc2.w);
+            *reinterpret_cast<f32x4*>(T_h0(ti) + ((size_t)(owner ? XT : t2) * 64 + lane) * 4) = acc2;
+        }
+    };
+    // the owner's end of feature tile XT: collect quarters 0..2, activation, K slab of the last layer
+    auto finish_x = [&](int ti, int seq, f32x4 acc) {
+        float* qp = T_qp(ti);
+        const int* qflag = reinterpret_cast<const int*>(qp + 3 * 256);
+        while (__hip_atomic_load(qflag + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq ||
+               __hip_atomic_load(qflag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq ||
+               __hip_atomic_load(qflag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(qp + ((size_t)h * 64 + lane) * 4);
+            acc.x = acc.x + o.x; acc.y = acc.y + o.y; acc.z = acc.z + o.z; acc.w = acc.w + o.w;
+        }
+        acc.x = apply_act_ct<A1>(acc.x); acc.y = apply_act_ct<A1>(acc.y);
+        acc.z = apply_act_ct<A1>(acc.z); acc.w = apply_act_ct<A1>(acc.w);
+        float* part = T_part(ti);
+#pragma unroll
+        for (int ot = 0; ot < OTL; ++ot) {
+            f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+            const f32x4 wo = xo_get(IT0 + ot);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo.x, acc.x, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo.y, acc.y, o, 0, 0, 0);
+            if (!half2) {
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo.z, acc.z, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo.w, acc.w, o, 0, 0, 0);
+            }
+            *reinterpret_cast<f32x4*>(part + (((size_t)XT * OTL + ot) * 64 + lane) * 4) = o;
+        }
     };
     // Layer 1 + K split of tile `ti`.  When `co` >= 0 the partial-sum reduction of tile `co`'s epilogue
     // (one LDS read + one add per producing wave) is issued between this tile's dependent MFMA groups, so
     // it costs no time of its own; `cacc` returns the reduced value.
-    auto stage_B = [&](int ti, int co, const float* cpart, float& cacc) {
-        if (!(ti == 0 ? serves0 : serves1)) return;       // only waves HT-1 / HT skip: no epilogue threads, never the `co` form
+    // Two-tile mode: a helper wave's quarter of feature tile XT rides in the first KQ groups as a second, independent
+    // accumulator chain (published right after); the owner collects the quarters two thirds of the way down its chain.
+    // `ta` >= 0 (two-tile mode): layer 0 of tile `ta` rides in groups apos, apos+1 (+2, +3 for the owner's tile XT) as one
+    // more independent chain instead of running, latency bound, before or after this one.
+    // The K loop runs on two accumulators (even / odd k tiles) so that a wave alone on its SIMD still issues back to back.
+    auto stage_B = [&](int ti, int co, const float* cpart, float& cacc, int seq, auto ta_c, auto apos_c) {
+        constexpr int ta = decltype(ta_c)::value, apos = decltype(apos_c)::value;
         const float* h0 = T_h0(ti);
-        f32x4 acc = *reinterpret_cast<const f32x4*>(bias1_p);
-        f32x4 bn = *reinterpret_cast<const f32x4*>(h0 + (size_t)lane * 4);
-#pragma unroll
-        for (int it = 0; it < HT; ++it) {
-            const f32x4 b = bn;                       // operand of this group was loaded during the previous one
-            if (it + 1 < HT) bn = *reinterpret_cast<const f32x4*>(h0 + ((size_t)(it + 1) * 64 + lane) * 4);
-            float pv = 0.0f;
-            if (co >= 0) pv = cpart[(size_t)it * OTL * 256];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 0], b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 1], b.y, acc, 0, 0, 0);
-            if (it + 1 < HT || !half1) {               // the padded half of the last K tile multiplies zeros
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 2], b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 3], b.w, acc, 0, 0, 0);
+        f32x4 acc = bias1_r;
+        f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 accx = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 acca = bias0_r, accb = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (NTILES == 2)
+            if (owner) {
+                accx = xo_get(XO_B1);
+                if (ta >= 0) accb = xo_get(XO_B0);
             }
-            if (co >= 0) cacc = cacc + pv;
+        const float* xsa = T_xs(ta >= 0 ? ta : 0);
+        const bool xt_wave = NTILES == 1 && wave == HT - 1;
+        if (xt_wave) {
+            // one-tile mode: the wave of feature tile XT sums its K loop in the two-tile mode's order (quarters 0..2 from
+            // zero, the owner's from the bias, then owner + q0 + q1 + q2), so that the two modes agree bit for bit
+            f32x4 aq[4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}, bias1_r};
+#pragma unroll
+            for (int it = 0; it < HT; ++it) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(h0 + ((size_t)it * 64 + lane) * 4);
+                f32x4& a = aq[it / KQ];
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 0], b.x, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 1], b.y, a, 0, 0, 0);
+                if (it + 1 < HT || !half1) {
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 2], b.z, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 3], b.w, a, 0, 0, 0);
+                }
+            }
+            acc = aq[3];
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                acc.x = acc.x + aq[h].x; acc.y = acc.y + aq[h].y; acc.z = acc.z + aq[h].z; acc.w = acc.w + aq[h].w;
+            }
+        } else {
+            f32x4 bn = *reinterpret_cast<const f32x4*>(h0 + (size_t)lane * 4);
+#pragma unroll
+            for (int it = 0; it < HT; ++it) {
+                const f32x4 b = bn;                       // operand of this group was loaded during the previous one
+                if (it + 1 < HT) bn = *reinterpret_cast<const f32x4*>(h0 + ((size_t)(it + 1) * 64 + lane) * 4);
+                float pv = 0.0f;
+                if (co >= 0) pv = cpart[(size_t)it * OTL * 256];
+                if constexpr (NTILES == 2) {
+                    if (it < KQ && helper && kbase + it < HT) {               // wave-uniform
+                        const f32x4 bx = *reinterpret_cast<const f32x4*>(h0 + ((size_t)(kbase + it) * 64 + lane) * 4);
+                        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[it * 4 + 0], bx.x, accx, 0, 0, 0);
+                        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[it * 4 + 1], bx.y, accx, 0, 0, 0);
+                        if (kbase + it + 1 < HT || !half1) {
+                            accx = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[it * 4 + 2], bx.z, accx, 0, 0, 0);
+                            accx = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[it * 4 + 3], bx.w, accx, 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < IT0; ++j) {
+                        if (ta >= 0 && it == apos + j) {
+                            const f32x4 ba = *reinterpret_cast<const f32x4*>(xsa + ((size_t)j * 64 + lane) * 4);
+                            acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[j * 4 + 0], ba.x, acca, 0, 0, 0);
+                            acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[j * 4 + 1], ba.y, acca, 0, 0, 0);
+                            acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[j * 4 + 2], ba.z, acca, 0, 0, 0);
+                            acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[j * 4 + 3], ba.w, acca, 0, 0, 0);
+                        }
+                        if (ta >= 0 && owner && it == apos + IT0 + j) {
+                            const f32x4 ba = *reinterpret_cast<const f32x4*>(xsa + ((size_t)j * 64 + lane) * 4);
+                            const f32x4 wa = xo_get(j);
+                            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, ba.x, accb, 0, 0, 0);
+                            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, ba.y, accb, 0, 0, 0);
+                            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, ba.z, accb, 0, 0, 0);
+                            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, ba.w, accb, 0, 0, 0);
+                        }
+                    }
+                }
+                if ((it & 1) == 0) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 0], b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 1], b.y, acc, 0, 0, 0);
+                    if (it + 1 < HT || !half1) {               // the padded half of the last K tile multiplies zeros
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 2], b.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 3], b.w, acc, 0, 0, 0);
+                    }
+                } else {
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 0], b.x, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 1], b.y, acc2, 0, 0, 0);
+                    if (it + 1 < HT || !half1) {
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 2], b.z, acc2, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 3], b.w, acc2, 0, 0, 0);
+                    }
+                }
+                if (co >= 0) cacc = cacc + pv;
+                if constexpr (NTILES == 2) {
+                    if (it == KQ - 1 && helper && !owner) {
+                        float* qp = T_qp(ti);
+                        *reinterpret_cast<f32x4*>(qp + ((size_t)hq * 64 + lane) * 4) = accx;
+                        // LDS operations of a wave complete in order: whoever sees the flag sees the partials
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0)
+                            __hip_atomic_store(reinterpret_cast<int*>(qp + 3 * 256) + hq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    if (ta >= 0 && it == apos + IT0 - 1) {
+                        acca.x = apply_act_ct<A0>(acca.x); acca.y = apply_act_ct<A0>(acca.y);
+                        acca.z = apply_act_ct<A0>(acca.z); acca.w = apply_act_ct<A0>(acca.w);
+                        *reinterpret_cast<f32x4*>(T_h0(ta) + ((size_t)wave * 64 + lane) * 4) = acca;
+                    }
+                    if (ta >= 0 && owner && it == apos + 2 * IT0 - 1) {
+                        accb.x = apply_act_ct<A0>(accb.x); accb.y = apply_act_ct<A0>(accb.y);
+                        accb.z = apply_act_ct<A0>(accb.z); accb.w = apply_act_ct<A0>(accb.w);
+                        *reinterpret_cast<f32x4*>(T_h0(ta) + ((size_t)XT * 64 + lane) * 4) = accb;
+                    }
+                    if (it == (2 * HT) / 3 && owner) finish_x(ti, seq, accx);
+                }
+            }
+            acc.x = acc.x + acc2.x; acc.y = acc.y + acc2.y; acc.z = acc.z + acc2.z; acc.w = acc.w + acc2.w;
         }
         acc.x = apply_act_ct<A1>(acc.x); acc.y = apply_act_ct<A1>(acc.y);
         acc.z = apply_act_ct<A1>(acc.z); acc.w = apply_act_ct<A1>(acc.w);
@@ -680,7 +929,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
             o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 0], acc.x, o, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 1], acc.y, o, 0, 0, 0);
-            if (wave + 1 < HT || !half2) {             // this wave's K slice is the half-empty tile
+            if (NTILES == 2 || wave + 1 < HT || !half2) {       // one-tile mode: the last wave's K slice is the half-empty tile
                 o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 2], acc.z, o, 0, 0, 0);
                 o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 3], acc.w, o, 0, 0, 0);
             }
@@ -695,6 +944,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     const int e_xaddr = tile_addr(ef, epp);
     auto epi_part = [&](int ti) { return T_part(ti) + (((size_t)e_ot) * 64 + e_ln) * 4 + e_rg; };
     auto epi_reduce = [&](int ti) {
+        if (NTILES == 2 && wid * 64 >= MLP_TP * S) return 0.0f;      // a wave of action features only: nothing to reduce
         const float* part = epi_part(ti);
         float acc = lbias[min(ef, S - 1)];
 #pragma unroll
@@ -705,7 +955,8 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     // cheetah reward (cost_func.py:5-22) needs cur[5..7], cur[17], next[17] and the actions only: the epilogue
     // thread that produces feature 17 of particle epp has next[17] in hand and evaluates it right there
     // (its reward accumulator is collected at the end); other rewards go through reward() below.
-    const bool rew_inline = p.reward_kind == REW_CHEETAH && S > 17;
+    const int rkind = CR >= 0 ? CR : p.reward_kind;
+    const bool rew_inline = rkind == REW_CHEETAH && S > 17;
     float rew_acc[2] = {0.0f, 0.0f};
     auto epi_finish = [&](int ti, int t, float acc) {
         float* st = T_st(ti);
@@ -718,9 +969,11 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             const float c17 = cur[epp * Sp + ef];
             v = dev + c17;
             if (e_live) nxt[epp * Sp + ef] = v;
-            if (q.traj && e_live) {                                  // state after step t (a user reward scores it afterwards)
+            if (CR < 0 && q.traj && e_live) {                        // state after step t (a user reward scores it afterwards: never with a built-in reward at compile time)
+                // uniform 64-bit base + a 32-bit per-lane offset: no 64-bit per-lane index lives across the recurrence
                 const int n = (blockIdx.x * NTILES + ti) * MLP_TP + epp;
-                if (n < p.n_pop) q.traj[((((size_t)t * p.A + a) * p.Nst) + n) * S + ef] = v;
+                float* trow = q.traj + (((size_t)t * p.A + a) * p.Nst) * S;
+                if (n < p.n_pop) trow[(unsigned)(n * S + ef)] = v;
             }
             if (rew_inline && ef == 17) {
                 const float c5 = cur[epp * Sp + 5], c6 = cur[epp * Sp + 6], c7 = cur[epp * Sp + 7];
@@ -747,7 +1000,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             const float* st = T_st(ti);
             const float* cur = st + (t & 1) * MLP_TP * Sp;
             const float* nxt = st + ((t + 1) & 1) * MLP_TP * Sp;
-            total[ti] = total[ti] + reward_generic(p.reward_kind, p.fix_q1 != 0, cur + tid * Sp,
+            total[ti] = total[ti] + reward_generic(rkind, p.fix_q1 != 0, cur + tid * Sp,
                                                    T_acts(ti) + (t * MLP_TP + tid) * U, nxt + tid * Sp, S, U);
         }
     };
@@ -760,7 +1013,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             stage_A(0);
             if (t > 0) reward(0, t - 1);
             __syncthreads();
-            stage_B(0, -1, nullptr, dummy);
+            stage_B(0, -1, nullptr, dummy, 0, IC<-1>{}, IC<0>{});
             __syncthreads();
             epi_finish(0, t, epi_reduce(0));
             __syncthreads();
@@ -772,36 +1025,47 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
         // the same time and leave the matrix pipe idle.  Waves w, w+4, w+8, ... share a SIMD, so (w >> 2) & 1
         // alternates within each SIMD.
         const bool grp = ((wid >> 2) & 1) != 0;
+        const bool epi_wave = wid * 64 < MLP_TP * (S + U);
+        if (helper) __builtin_amdgcn_s_setprio(1);        // the longest instruction streams of their SIMDs go first
         for (int t = 0; t < H; ++t) {
-            if (!grp) {
+            BBMPC_PAIR_CLK(0);
+            // epilogue threads are tid < 16 (S + U): waves 0 .. EW-1 (the others have nothing to reduce)
+            if (split_i1) {
+                if (wid >= EWS) stage_A1(0);                          // A_X(t), two feature tiles per wave
+                if (t > 0 && epi_wave) epi_finish(1, t - 1, epi_reduce(1));       // C_Y(t-1)
+            } else if (!grp) {
                 stage_A(0);                                           // A_X(t)
-                if (t > 0) epi_finish(1, t - 1, epi_reduce(1));       // C_Y(t-1)
+                if (t > 0 && epi_wave) epi_finish(1, t - 1, epi_reduce(1));       // C_Y(t-1)
             } else {
-                if (t > 0) epi_finish(1, t - 1, epi_reduce(1));
+                if (t > 0 && epi_wave) epi_finish(1, t - 1, epi_reduce(1));
                 stage_A(0);
             }
             if (t > 0) reward(0, t - 1);                  // state pair (t-1, t) of tile 0 is complete since the last barrier
+            BBMPC_PAIR_CLK(1);
             __syncthreads();
-            if (!grp) {
-                stage_A(1);                                           // A_Y(t)
-                stage_B(0, -1, nullptr, dummy);                       // B_X(t)
-            } else {
-                stage_B(0, -1, nullptr, dummy);
-                stage_A(1);
-            }
+            BBMPC_PAIR_CLK(2);
+            // B_X(t) with A_Y(t) inside, early or late
+            if (!grp) stage_B(0, -1, nullptr, dummy, t + 1, IC<1>{}, IC<0>{});
+            else stage_B(0, -1, nullptr, dummy, t + 1, IC<1>{}, IC<HT - 5>{});
             if (t > 0) reward(1, t - 1);
+            BBMPC_PAIR_CLK(3);
             __syncthreads();
-            if (!grp) {
+            BBMPC_PAIR_CLK(4);
+            if (!epi_wave) {
+                stage_B(1, -1, nullptr, dummy, t + 1, IC<-1>{}, IC<0>{});
+            } else if (!grp) {
                 float cacc = lbias[min(ef, S - 1)];                   // C_X(t): reduction rides under B_Y(t)'s MFMA chain
-                stage_B(1, 0, epi_part(0), cacc);
+                stage_B(1, 0, epi_part(0), cacc, t + 1, IC<-1>{}, IC<0>{});
                 epi_finish(0, t, cacc);
             } else {
                 epi_finish(0, t, epi_reduce(0));
-                stage_B(1, -1, nullptr, dummy);
+                stage_B(1, -1, nullptr, dummy, t + 1, IC<-1>{}, IC<0>{});
             }
+            BBMPC_PAIR_CLK(5);
             __syncthreads();
+            BBMPC_PAIR_CLK(6);
         }
-        epi_finish(1, H - 1, epi_reduce(1));
+        if (epi_wave) epi_finish(1, H - 1, epi_reduce(1));
         reward(0, H - 1);
         __syncthreads();
         reward(1, H - 1);
@@ -829,9 +1093,9 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
                     const float nr = sqrtf(pen);
                     pen = nr * nr;
                     tot = tot - pen;
-                    if (p.penalty_out) p.penalty_out[(size_t)a * p.Nst + n] = pen;
+                    if (p.penalty_out) (p.penalty_out + (size_t)a * p.Nst)[(unsigned)n] = pen;
                 }
-                p.rewards[(size_t)a * p.Nst + n] = tot;
+                (p.rewards + (size_t)a * p.Nst)[(unsigned)n] = tot;
             }
         }
     }
@@ -840,8 +1104,9 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
 // LDS floats the pair kernel needs
 inline int mlp_pair_lds_floats(int HT, int H, int U, int S, int ntiles) {
     const int Sp = (S + 3) & ~3;
-    const int tile = 2 * 256 + HT * 256 + HT * 2 * 256 + 2 * MLP_TP * Sp + ((H * MLP_TP * U + 3) & ~3) + ((MLP_TP * U + 63) & ~63);
-    return ntiles * tile + (((S + U) * 2 + S * 3 + 63) & ~63);
+    const int tile = 2 * 256 + HT * 256 + HT * 2 * 256 + 2 * MLP_TP * Sp + ((H * MLP_TP * U + 3) & ~3) + ((MLP_TP * U + 63) & ~63) +
+                     (ntiles == 2 ? 3 * 256 + 64 : 0);
+    return ntiles * tile + (((S + U) * 2 + S * 3 + 3 + 63) & ~63) + (ntiles == 2 ? (6 + 5 * 3) * 256 : 0);   // + the owner's operands (6 slots) + second-tile layer-0 operands (5 x 3)
 }
 
 }  // namespace bbmpc
