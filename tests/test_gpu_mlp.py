@@ -92,6 +92,29 @@ def test_evaluator_matches_oracle(L, spec, N, A, H):
     np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3 * H)
 
 
+@pytest.mark.parametrize("pair", ["0", "1"])
+@pytest.mark.parametrize("dims,S,U,N,A,H,normalized", [
+    ([26, 200, 200, 20], 20, 6, 75, 3, 7, True),       # ragged population, dimensions of the cheetah family (compile-time S, U)
+    ([26, 200, 200, 20], 20, 6, 130, 2, 50, False),    # the compile-time-horizon instance, un-normalised
+    ([24, 200, 200, 19], 19, 5, 90, 2, 9, True),       # same family, other dim_S / dim_U: run-time dimensions
+    ([27, 204, 204, 21], 21, 6, 64, 1, 5, True),       # 13 hidden tiles whose last one is NOT half empty; 6 state-reduction waves (no interval-1 split)
+])
+def test_pipelined_tile_kernel_variants(L, monkeypatch, pair, dims, S, U, N, A, H, normalized):
+    # k_rollout_mlp_pair in its one-tile (13 waves) and two-tile (12 waves: the 13th hidden tile's K loop in quarters on
+    # four waves, layer 0 fused into the layer-1 loop) forms, forced through the environment switches at shapes the
+    # size heuristics would give to the quad kernels; every template instance against the NumPy oracle.
+    monkeypatch.setenv("BBMPC_MLP_Q4", "0")
+    monkeypatch.setenv("BBMPC_MLP_PAIR", pair)
+    eng, ev, lo, hi = _problem(L, dims, ["tanh", "tanh", None], S, U, "cheetah", normalized, A=A, H=H)
+    rng = np.random.default_rng(N + H)
+    states = O.cheetah_start_states(A, S)
+    seq = rng.uniform(-1, 1, (N, A, H, U)).astype(F)
+    got = eng.evaluate(states, seq)
+    want = ev(states, seq)
+    assert np.all(np.isfinite(want))
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3 * H)
+
+
 @pytest.mark.parametrize("q4", ["0", "1"])
 def test_evaluator_properties_at_config5_size(L, monkeypatch, q4):
     # BASELINE config-5 shape (per GPU): N=2000, A=4, H=50, S=20, U=6.  Size-independent properties:
