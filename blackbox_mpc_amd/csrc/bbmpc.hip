@@ -181,6 +181,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.mlp_generic = flag("BBMPC_MLP_GENERIC");
         { const int b = ival("BBMPC_MLP_BF16", 0); sw.mlp_bf16 = (b == 1 || b == 3) ? b : 0; }
         sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1); sw.mlp_q4r = ival("BBMPC_MLP_Q4R", 1);
+        sw.refit_wgs = ival("BBMPC_REFIT_WGS", 0);
         sw.mlp_wave = ival("BBMPC_MLP_WAVE", 1);
         sw.linger_us = std::max(0, ival("BBMPC_LINGER_US", 200));
         linger_test_quit = ival("BBMPC_LINGER_TEST_QUIT", 0) - 1;
@@ -1732,7 +1733,9 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                     const int rthreads = N > 512 ? 1024 : (N > 256 ? 512 : 256);
                     RefitArgs rf2 = rf;
                     if (!trace_on) rf2.elites = nullptr;          // the sorted elite list is only needed by the parity trace
-                    hipLaunchKernelGGL(k_refit_cem_v2, dim3(A), dim3(rthreads), (size_t)fixed * 4, stream, rf2);
+                    // G workgroups per agent share the elite gather (kernels_refit.hpp); at least 16 rows each
+                    const int rg = sw.refit_wgs > 0 ? sw.refit_wgs : std::max(1, std::min(8, HU / 16));
+                    hipLaunchKernelGGL(k_refit_cem_v2, dim3(rg, A), dim3(rthreads), (size_t)fixed * 4, stream, rf2);
                 } else {
                     hipLaunchKernelGGL(k_refit_cem, dim3(A), dim3(REFIT_THREADS), lds, stream, rf, JC);
                 }

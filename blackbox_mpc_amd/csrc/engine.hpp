@@ -94,6 +94,7 @@ struct Engine {
         int mlp_bf16 = 0;              // BBMPC_MLP_BF16: 0 off (default, fp32), 1 plain bf16 inputs, 3 split bf16 (hi+lo, three products)
         int mlp_pair = -1, mlp_q4 = -1;   // BBMPC_MLP_PAIR / BBMPC_MLP_Q4: -1 automatic, 0 / 1 forced
         int mlp_q4r = 1;                  // BBMPC_MLP_Q4R=0: keep k_rollout_mlp_q4 where k_rollout_mlp_q4r would run
+        int refit_wgs = 0;                // BBMPC_REFIT_WGS=n: workgroups per agent in k_refit_cem_v2 (0 = by problem size)
         int mlp_wave = 1;                 // BBMPC_MLP_WAVE=0: never the one-wave-per-tile kernel for small networks
         int linger_us = 200;              // BBMPC_LINGER_US: how long a one-agent control-step kernel waits for the next call (0 = never)
         int balance = 1;               // BBMPC_BALANCE

@@ -163,10 +163,15 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_refit_cem(RefitArgs p, int JC
 // refit: elite SET from the radix select, listed in ascending index order; statistics over 16-lane rows).
 // blockDim up to 1024: the gathers are 4 independent global loads per lane with up to four rows in flight, the
 // elite statistics a 16-lane DPP reduction -- no LDS tile, no serial 50-element loops.
+// grid (G, A): the elite gather reads 4 bytes out of every cache line it touches (the elites are scattered along the
+// particle-minor axis), k x HU lines through one CU's L1 -- 1.2 MB at config 4, 1.9 MB at config 5 and most of the
+// kernel's time.  So G workgroups per agent each repeat the (cheap, reward-only) selection and take HU / G rows.
 // LDS: rewards[Nst] | elite idx[kpad] | hist[TOPK_HIST_WORDS] | ekeys[2*kpad]
 __global__ __launch_bounds__(1024) void k_refit_cem_v2(RefitArgs p) {
     extern __shared__ float smem[];
-    const int a = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int a = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+    const int rows_wg = (p.HU + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int jlo = blockIdx.x * rows_wg, jhi = min(p.HU, jlo + rows_wg);
     float* r = smem;
     int* eidx = (int*)(smem + p.Nst);
     const int kpad = (p.k + 3) & ~3;
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(1024) void k_refit_cem_v2(RefitArgs p) {
     for (int n = tid; n < p.N; n += nthr) r[n] = p.rewards[(size_t)a * p.Nst + n];
     __syncthreads();
     const TopkSel sel = block_topk_select(r, p.N, p.k, hist, tid, nthr);
-    if (p.elites) {                                   // parity trace wants tf.nn.top_k's sorted order
+    if (p.elites && blockIdx.x == 0) {                // parity trace wants tf.nn.top_k's sorted order
         block_topk_finish_sorted(r, p.N, p.k, eidx, hist, ekeys, sel, tid, nthr);
         for (int e = tid; e < p.k; e += nthr) p.elites[a * p.k + e] = eidx[e];
         __syncthreads();
@@ -190,14 +195,18 @@ __global__ __launch_bounds__(1024) void k_refit_cem_v2(RefitArgs p) {
     for (int i = 0; i < EC; ++i) ei[i] = (sub + 16 * i < p.k) ? eidx[sub + 16 * i] : -1;
     const float kf = (float)p.k, one_m = 1.0f - p.alpha;
     const float* __restrict__ samples = p.samples + (size_t)a * p.HU * p.Nst;
-    for (int j0 = 0; j0 < p.HU; j0 += RC * ngrp) {
+    for (int j0 = jlo; j0 < jhi; j0 += RC * ngrp) {
         float x[RC][EC];
 #pragma unroll
         for (int rr = 0; rr < RC; ++rr) {
             const int j = j0 + rr * ngrp + grp;
-            const float* row = samples + (size_t)(j < p.HU ? j : 0) * p.Nst;
 #pragma unroll
-            for (int i = 0; i < EC; ++i) x[rr][i] = row[ei[i] >= 0 ? ei[i] : 0];
+            for (int i = 0; i < EC; ++i) x[rr][i] = 0.0f;
+            if (j < jhi) {                                                 // 16-lane groups without a row issue no loads
+                const float* row = samples + (size_t)j * p.Nst;
+#pragma unroll
+                for (int i = 0; i < EC; ++i) x[rr][i] = row[ei[i] >= 0 ? ei[i] : 0];
+            }
         }
 #pragma unroll
         for (int rr = 0; rr < RC; ++rr) {
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(1024) void k_refit_cem_v2(RefitArgs p) {
                     vs += d * d;
                 }
             vs = row16_sum(vs);
-            if (j < p.HU && sub == 0) {
+            if (j < jhi && sub == 0) {
                 const float ev = vs / kf;                                  // cem.py:113-119
                 const int aj = a * p.HU + j;
                 const float m = p.alpha * p.mean[aj] + one_m * em;         // cem.py:121-122

@@ -196,6 +196,17 @@ __global__ __launch_bounds__(64 * PI2_ROWS) void k_refit_pi2_mw(RefitArgs p) {
     float* red = smem + p.Nst;
     const int a = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int NW = PI2_ROWS, NT = 64 * PI2_ROWS;
+    // this wave's row of the sample matrix does not depend on the weights: for populations up to 64 PF its loads go out
+    // with the reward loads (one memory round trip for the kernel instead of two)
+    constexpr int PF = 16;
+    const int j = blockIdx.x * PI2_ROWS + wv;
+    const float* __restrict__ row = p.samples + (size_t)(a * p.HU + (j < p.HU ? j : 0)) * p.Nst;
+    const bool pf = p.N <= 64 * PF;
+    float xr[PF];
+    if (pf) {
+#pragma unroll
+        for (int m = 0; m < PF; ++m) xr[m] = (lane + 64 * m < p.N) ? row[lane + 64 * m] : 0.0f;
+    }
     float lmin = INFINITY;
     for (int n = tid; n < p.N; n += NT) {
         const float c = -p.rewards[(size_t)a * p.Nst + n];               // costs = -rewards   pi2.py:78-79
@@ -223,19 +234,37 @@ __global__ __launch_bounds__(64 * PI2_ROWS) void k_refit_pi2_mw(RefitArgs p) {
     __syncthreads();
     for (int n = tid; n < p.N; n += NT) om[n] = inv_eta * om[n];         // pi2.py:85
     __syncthreads();
-    const int j = blockIdx.x * PI2_ROWS + wv;
     if (j >= p.HU) return;
-    const float* __restrict__ row = p.samples + (size_t)(a * p.HU + j) * p.Nst;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    int n = lane;
-    for (; n + 192 < p.N; n += 256) {                                    // four independent loads per trip
-        const float x0 = row[n], x1 = row[n + 64], x2 = row[n + 128], x3 = row[n + 192];
-        acc[0] = fmaf(x0, om[n], acc[0]);
-        acc[1] = fmaf(x1, om[n + 64], acc[1]);
-        acc[2] = fmaf(x2, om[n + 128], acc[2]);
-        acc[3] = fmaf(x3, om[n + 192], acc[3]);
+    if (pf) {
+        // the same sums in the same order as the loop below, on the prefetched registers
+        bool tail = false;
+#pragma unroll
+        for (int i = 0; i < PF / 4; ++i) {
+            const int n = lane + 256 * i;
+            if (!tail && n + 192 < p.N) {
+                acc[0] = fmaf(xr[4 * i + 0], om[n], acc[0]);
+                acc[1] = fmaf(xr[4 * i + 1], om[n + 64], acc[1]);
+                acc[2] = fmaf(xr[4 * i + 2], om[n + 128], acc[2]);
+                acc[3] = fmaf(xr[4 * i + 3], om[n + 192], acc[3]);
+            } else {
+                tail = true;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (n + 64 * c < p.N) acc[0] = fmaf(xr[4 * i + c], om[n + 64 * c], acc[0]);
+            }
+        }
+    } else {
+        int n = lane;
+        for (; n + 192 < p.N; n += 256) {                                    // four independent loads per trip
+            const float x0 = row[n], x1 = row[n + 64], x2 = row[n + 128], x3 = row[n + 192];
+            acc[0] = fmaf(x0, om[n], acc[0]);
+            acc[1] = fmaf(x1, om[n + 64], acc[1]);
+            acc[2] = fmaf(x2, om[n + 128], acc[2]);
+            acc[3] = fmaf(x3, om[n + 192], acc[3]);
+        }
+        for (; n < p.N; n += 64) acc[0] = fmaf(row[n], om[n], acc[0]);
     }
-    for (; n < p.N; n += 64) acc[0] = fmaf(row[n], om[n], acc[0]);
     const float s = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
     if (lane == 0) {
         p.mean[a * p.HU + j] = s;                                        // pi2.py:86-87
