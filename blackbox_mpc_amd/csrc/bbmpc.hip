@@ -513,7 +513,10 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             const int bsz = (n + 7) / 8;
             const int ncb = (n + 63) / 64;                               // k_cma_svd_block<ncb, NB>: LDS column pitch 64 * ncb
             // NB = 16 column blocks on 8 workgroups per instance when there are CUs for them (BBMPC_CMA_NB overrides)
-            const int nbk = (sw.cma_nb == 8 || sw.cma_nb == 16) ? sw.cma_nb : ((64 * ((G + 7) / 8) <= 256 && n >= 256) ? 16 : 8);
+            // 20 blocks for 256 < n <= 320: 15-16 columns per block = 16-lane rows of FOUR waves, one per SIMD, in the cross rounds
+            // (19 columns are five waves, two of them on one SIMD: a round is instruction-issue bound and takes twice as long)
+            const int nb_auto = (ncb == 5 && 80 * ((G + 7) / 8) <= 256) ? 20 : ((64 * ((G + 7) / 8) <= 256 && n >= 256) ? 16 : 8);
+            const int nbk = (sw.cma_nb == 8 || sw.cma_nb == 16 || (sw.cma_nb == 20 && ncb == 5)) ? sw.cma_nb : nb_auto;
             const int bsk = (n + nbk - 1) / nbk;
             const size_t blds = (size_t)2 * bsk * 64 * ncb * sizeof(float);
             if (n >= 128 && (n & 3) == 0 && bsz <= 64 && cma_gram_lds_bytes(n) <= 159 * 1024 && cma_gram_wp(n) <= 128 && G * 4 <= 256 &&
@@ -529,6 +532,8 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                 // block Jacobi: 4 workgroups per instance, block pairs resident in LDS, 7 instance barriers per sweep
                 const void* kfn = nullptr;
 #define BBMPC_SVD_CASE(NC_) case NC_: kfn = nbk == 16 ? (const void*)k_cma_svd_block<NC_, 16> : (const void*)k_cma_svd_block<NC_, 8>; break;
+                if (nbk == 20) kfn = (const void*)k_cma_svd_block<5, 20>;
+                else
                 switch (ncb) {
                     BBMPC_SVD_CASE(2) BBMPC_SVD_CASE(3) BBMPC_SVD_CASE(4) BBMPC_SVD_CASE(5) BBMPC_SVD_CASE(6) BBMPC_SVD_CASE(7)
                     default: kfn = nbk == 16 ? (const void*)k_cma_svd_block<8, 16> : (const void*)k_cma_svd_block<8, 8>; break;
@@ -547,7 +552,7 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                     int sweeps = 15;
                     void* kargs[] = {(void*)&q, (void*)&evp, (void*)&syp, (void*)&sweeps};
                     // 1-D grid, an instance's four workgroups on one XCD (kernels_cma.hpp); surplus workgroups return at once
-                    const dim3 sgrid(8 * (nbk / 2) * ((G + 7) / 8)), sblock(nbk == 16 ? 512 : 1024);
+                    const dim3 sgrid(8 * (nbk / 2) * ((G + 7) / 8)), sblock(nbk >= 16 ? 512 : 1024);
                     if (sw.cma_coop) HIP_CHECK(hipLaunchCooperativeKernel(kfn, sgrid, sblock, kargs, blds, stream));
                     else HIP_CHECK(hipLaunchKernel(kfn, sgrid, sblock, kargs, blds, stream));
                 }

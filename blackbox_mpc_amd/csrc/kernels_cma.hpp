@@ -514,7 +514,7 @@ __device__ __forceinline__ void cma_instance_barrier_light(unsigned* ctr, unsign
     __syncthreads();
 }
 
-constexpr int CMA_SYNC_WORDS = 384;
+constexpr int CMA_SYNC_WORDS = 512;
 constexpr int CMA_SYNC_XCC_MASK = 24;                  // k_cma_svd_block: bit x = some workgroup of the instance runs on XCD x
 // sync: [G][CMA_SYNC_WORDS] unsigned: [0] barrier counter, [1 + sweep] "some pair rotated in this sweep"; the block kernel keeps
 // its block-pair bookkeeping in words 32.. (2 * NB + NB * NB of them)
