@@ -956,36 +956,77 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                     if (has_y && sub == 0) { s_ynrm[row] = by; s_ysc[row] = 1.0f; }
                 }
                 __syncthreads();
+#ifdef BBMPC_KERNEL_DBG
+                long long cr[6] = {0, 0, 0, 0, 0, 0}, ct = 0;
+#define SVDB_CLK(i) do { const long long now_ = (long long)__builtin_readcyclecounter(); cr[i] += now_ - ct; ct = now_; } while (0)
+#else
+#define SVDB_CLK(i) do {} while (0)
+#endif
+                int jrot = mm > 0 ? row % mm : 0;
                 for (int r = 0; r < mm; ++r) {
+#ifdef BBMPC_KERNEL_DBG
+                    ct = (long long)__builtin_readcyclecounter();
+#endif
                     if (wave_on) {
-                        const int j = (row + r) % mm;
+                        const int j = jrot;                               // (row + r) % mm without the division on the chain
+                        jrot = (jrot + 1 == mm) ? 0 : jrot + 1;
                         const bool act = has_x && j < ny;
                         const int jc = act ? j : 0;
                         float* y = cols + (size_t)(nx + jc) * ld;
+                        // tracked scale and norm of the y-column: read FIRST, through asm (the compiler sinks plain loads behind the
+                        // dot product and the threshold test -- two more LDS round trips on the round's dependent chain, a quarter
+                        // of a round by the segment clocks).  LDS returns in order, so once the column loads issued after them
+                        // have been waited for these two are there as well; the empty asm below ties their first use to the dot
+                        // product, i.e. behind that wait.
+                        float sy, be;
+                        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3"
+                                     : "=&v"(sy), "=&v"(be)
+                                     : "v"((unsigned)(uintptr_t)(s_ysc + jc)), "v"((unsigned)(uintptr_t)(s_ynrm + jc))
+                                     : "memory");
                         float4 yv[EC];
-                        float gs = 0.0f;
+                        // the round is one dependent chain (LDS read -> dot product -> row reduction -> rotation scalars ->
+                        // update -> LDS write -> barrier): four partial sums instead of a 4 EC-deep FMA chain
+#pragma unroll
+                        for (int c = 0; c < EC; ++c)
+                            yv[c] = *reinterpret_cast<const float4*>(y + 4 * (sub + 16 * c));   // (an idle row reads column 0 and does not rotate)
+                        // the two scalars are back once at most EC LDS operations are outstanding: everything that depends on them
+                        // and not on the dot product -- the reciprocals of the scales (+ Newton step), be - al -- is computed here,
+                        // in the shadow of the column loads, instead of behind the threshold test
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(sy), "+v"(be) : "n"(EC) : "memory");
+                        const float al = alx;
+                        // sy / sx and sx / sy to fp32 (reciprocal + one Newton step): the pair of updates is an exact
+                        // rotation only if the two factors are reciprocal to each other
+                        float rx = __builtin_amdgcn_rcpf(sx), ry = __builtin_amdgcn_rcpf(sy);
+                        rx = rx * fmaf(-sx, rx, 2.0f); ry = ry * fmaf(-sy, ry, 2.0f);
+                        const float sy_rx = sy * rx, sx_ry = sx * ry, dd = be - al, sxy = sx * sy, thr = (tol * tol) * (al * be);
+                        float gs0 = 0.0f, gs1 = 0.0f, gs2 = 0.0f, gs3 = 0.0f;
 #pragma unroll
                         for (int c = 0; c < EC; ++c) {
-                            const int e = 4 * (sub + 16 * c);
-                            yv[c] = *reinterpret_cast<const float4*>(y + e);     // (an idle row reads column 0 and does not rotate)
-                            gs = fmaf(xr[c].x, yv[c].x, gs); gs = fmaf(xr[c].y, yv[c].y, gs); gs = fmaf(xr[c].z, yv[c].z, gs); gs = fmaf(xr[c].w, yv[c].w, gs);
+                            gs0 = fmaf(xr[c].x, yv[c].x, gs0); gs1 = fmaf(xr[c].y, yv[c].y, gs1);
+                            gs2 = fmaf(xr[c].z, yv[c].z, gs2); gs3 = fmaf(xr[c].w, yv[c].w, gs3);
                         }
-                        const float sy = s_ysc[jc], be = s_ynrm[jc], al = alx;
-                        const float ga = (sx * sy) * row16_sum(gs);
+                        const float gs = (gs0 + gs1) + (gs2 + gs3);
+#ifdef BBMPC_KERNEL_DBG
+                        asm volatile("" :: "v"(gs));
+#endif
+                        SVDB_CLK(0);
+                        const float ga = sxy * row16_sum(gs);
+#ifdef BBMPC_KERNEL_DBG
+                        asm volatile("" :: "v"(ga));
+#endif
+                        SVDB_CLK(1);
                         // |ga| <= tol * sqrt(al*be)  <=>  ga^2 <= tol^2 * al * be  (no sqrt)
-                        const bool rot = act && ga != 0.0f && (ga * ga > (tol * tol) * (al * be));
+                        const bool rot = act && ga != 0.0f && (ga * ga > thr);
                         if (rot) {
-                            const float zeta = (be - al) * __builtin_amdgcn_rcpf(2.0f * ga);
-                            const float az = fabsf(zeta);
-                            const float t = copysignf(__builtin_amdgcn_rcpf(az + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.0f))), zeta);
+                            // t = sign(zeta) / (|zeta| + sqrt(zeta^2 + 1)), zeta = (be - al) / (2 ga), without forming zeta:
+                            // |2 ga| / (|d| + sqrt(d^2 + (2 ga)^2)), d = be - al -- one reciprocal less on the chain
+                            const float g2 = ga + ga;
+                            const float t = copysignf(fabsf(g2) * __builtin_amdgcn_rcpf(fabsf(dd) + __builtin_amdgcn_sqrtf(fmaf(dd, dd, g2 * g2))),
+                                                      (dd < 0.0f) != (g2 < 0.0f) ? -1.0f : 1.0f);
                             const float w = fmaf(t, t, 1.0f);
                             float cs = __builtin_amdgcn_rsqf(w);
                             cs = cs * fmaf(-0.5f * w * cs, cs, 1.5f);           // Newton step: cs^2 * (1 + t^2) = 1 to fp32
-                            // sy / sx and sx / sy to fp32 (reciprocal + one Newton step): the pair of updates is an exact
-                            // rotation only if the two factors are reciprocal to each other
-                            float rx = __builtin_amdgcn_rcpf(sx), ry = __builtin_amdgcn_rcpf(sy);
-                            rx = rx * fmaf(-sx, rx, 2.0f); ry = ry * fmaf(-sy, ry, 2.0f);
-                            const float tau1 = t * (sy * rx), tau2 = t * (sx * ry);
+                            const float tau1 = t * sy_rx, tau2 = t * sx_ry;
 #pragma unroll
                             for (int c = 0; c < EC; ++c) {
                                 const int e = 4 * (sub + 16 * c);
@@ -1002,9 +1043,19 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                             if (sub == 0) { s_ysc[jc] = sy * cs; s_ynrm[jc] = fmaf(t, ga, be); }
                             rot_cross = true;
                         }
+                        SVDB_CLK(2);
                     }
+#ifdef BBMPC_KERNEL_DBG
+                    asm volatile("s_waitcnt lgkmcnt(0)");
+                    SVDB_CLK(3);
+#endif
                     __syncthreads();
+                    SVDB_CLK(4);
                 }
+#ifdef BBMPC_KERNEL_DBG
+                if (g == 0 && wg == 1 && tid == 0 && sweep == 0 && R == 3)
+                    printf("[svdb] cross rounds (block round 3, %d rounds, cycles): load+dot %lld reduce %lld rotate %lld lds-drain %lld barrier %lld\n", mm, cr[0], cr[1], cr[2], cr[3], cr[4]);
+#endif
                 // fold the scales back: x from the registers, y in place
 #pragma unroll
                 for (int c = 0; c < EC; ++c) {
