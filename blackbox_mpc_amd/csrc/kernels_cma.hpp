@@ -963,7 +963,14 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
 #define SVDB_CLK(i) do {} while (0)
 #endif
                 int jrot = mm > 0 ? row % mm : 0;
-                for (int r = 0; r < mm; ++r) {
+                // The x-update of a rotation (x' = x - tau1 y_old) is not needed before the NEXT round's dot product: it is
+                // deferred into the shadow of that round's column loads (tau1p, and the old y kept in the other of two
+                // register buffers -- rounds alternate between them, so nothing is copied); tau1p = 0 leaves x as it is.
+                float4 ya[EC], yb[EC];
+#pragma unroll
+                for (int c = 0; c < EC; ++c) yb[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                float tau1p = 0.0f;
+                auto cross_round = [&](float4 (&yv)[EC], const float4 (&yp)[EC]) {
 #ifdef BBMPC_KERNEL_DBG
                     ct = (long long)__builtin_readcyclecounter();
 #endif
@@ -983,7 +990,6 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                                      : "=&v"(sy), "=&v"(be)
                                      : "v"((unsigned)(uintptr_t)(s_ysc + jc)), "v"((unsigned)(uintptr_t)(s_ynrm + jc))
                                      : "memory");
-                        float4 yv[EC];
                         // the round is one dependent chain (LDS read -> dot product -> row reduction -> rotation scalars ->
                         // update -> LDS write -> barrier): four partial sums instead of a 4 EC-deep FMA chain
 #pragma unroll
@@ -994,6 +1000,12 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                         // in the shadow of the column loads, instead of behind the threshold test
                         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(sy), "+v"(be) : "n"(EC) : "memory");
                         const float al = alx;
+#pragma unroll
+                        for (int c = 0; c < EC; ++c) {                    // the pending x-update of the previous round
+                            xr[c].x = fmaf(-tau1p, yp[c].x, xr[c].x); xr[c].y = fmaf(-tau1p, yp[c].y, xr[c].y);
+                            xr[c].z = fmaf(-tau1p, yp[c].z, xr[c].z); xr[c].w = fmaf(-tau1p, yp[c].w, xr[c].w);
+                        }
+                        tau1p = 0.0f;
                         // sy / sx and sx / sy to fp32 (reciprocal + one Newton step): the pair of updates is an exact
                         // rotation only if the two factors are reciprocal to each other
                         float rx = __builtin_amdgcn_rcpf(sx), ry = __builtin_amdgcn_rcpf(sy);
@@ -1030,14 +1042,12 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
 #pragma unroll
                             for (int c = 0; c < EC; ++c) {
                                 const int e = 4 * (sub + 16 * c);
-                                float4 xn, yn;
-                                xn.x = fmaf(-tau1, yv[c].x, xr[c].x); yn.x = fmaf(tau2, xr[c].x, yv[c].x);
-                                xn.y = fmaf(-tau1, yv[c].y, xr[c].y); yn.y = fmaf(tau2, xr[c].y, yv[c].y);
-                                xn.z = fmaf(-tau1, yv[c].z, xr[c].z); yn.z = fmaf(tau2, xr[c].z, yv[c].z);
-                                xn.w = fmaf(-tau1, yv[c].w, xr[c].w); yn.w = fmaf(tau2, xr[c].w, yv[c].w);
-                                xr[c] = xn;
+                                float4 yn;
+                                yn.x = fmaf(tau2, xr[c].x, yv[c].x); yn.y = fmaf(tau2, xr[c].y, yv[c].y);
+                                yn.z = fmaf(tau2, xr[c].z, yv[c].z); yn.w = fmaf(tau2, xr[c].w, yv[c].w);
                                 *reinterpret_cast<float4*>(y + e) = yn;
                             }
+                            tau1p = tau1;                                     // x' = x - tau1 y_old: next round (or the flush below)
                             sx = sx * cs;
                             alx = fmaf(-t, ga, al);
                             if (sub == 0) { s_ysc[jc] = sy * cs; s_ynrm[jc] = fmaf(t, ga, be); }
@@ -1051,6 +1061,18 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
 #endif
                     __syncthreads();
                     SVDB_CLK(4);
+                };
+                {
+                    int r = 0;
+                    for (; r + 1 < mm; r += 2) { cross_round(ya, yb); cross_round(yb, ya); }
+                    if (r < mm) cross_round(ya, yb);
+                    const bool last_a = (mm & 1) != 0;                    // the buffer the last round loaded holds the pending y
+#pragma unroll
+                    for (int c = 0; c < EC; ++c) {
+                        const float4 yl = last_a ? ya[c] : yb[c];
+                        xr[c].x = fmaf(-tau1p, yl.x, xr[c].x); xr[c].y = fmaf(-tau1p, yl.y, xr[c].y);
+                        xr[c].z = fmaf(-tau1p, yl.z, xr[c].z); xr[c].w = fmaf(-tau1p, yl.w, xr[c].w);
+                    }
                 }
 #ifdef BBMPC_KERNEL_DBG
                 if (g == 0 && wg == 1 && tid == 0 && sweep == 0 && R == 3)
