@@ -532,11 +532,14 @@ __device__ __forceinline__ float apply_act_ct(float x) {
 // 128 and spilled).  Waves land on SIMD (wave & 3).  Feature tile HT-1 (the 13th, half-empty one) has no wave of its
 // own: its layer-1 job is one more dependent chain of 50 MFMAs, and whichever SIMD carries it whole runs 4 jobs against
 // 3 while the barrier at the end of the interval waits -- a quarter of the matrix time of every layer-1 interval.  So
-// the K loop of that job is split in four quarters taken by the last four waves (wid HT-5 .. HT-2, one per SIMD) next
-// to their own tile: quarters 0..2 go first in the interval, leave their partial pre-activations in LDS and raise a
-// flag; quarter 3's wave (the owner: also layer 0 of that tile, the shortest quarter) runs its own job first, then
-// its quarter, adds the partials, applies the activation and does the K slab of the last layer.  The flags are LDS
-// words polled inside the interval (they are long up when the owner looks) -- no extra barrier.
+// the K loop of that job is split in four quarters taken by the last four waves (wid HT-5 .. HT-2, one per SIMD) as a
+// second, independent accumulator chain inside the first groups of their own layer-1 loop: quarters 0..2 leave their
+// partial pre-activations in LDS and raise a flag; quarter 3's wave (the owner: also layer 0 of that tile, the shortest
+// quarter) collects them two thirds of the way down its own chain, applies the activation and does the K slab of the
+// last layer.  The flags are LDS words polled inside the interval (long up when the owner looks) -- no extra barrier.
+// The one-tile mode's last wave sums its K loop in the same quarter order, so the two modes agree bit for bit.
+// Static __shared__ objects must not appear in this kernel: they move the base of the dynamic carve (measured: wrong
+// results and half the speed).
 constexpr int mlp_pair_waves(int HT, int NTILES) { return NTILES == 2 ? HT - 1 : HT; }
 // development hook (tools/microbench/pair_probe.hip): per-wave clocks at the interval boundaries of one step
 #ifndef BBMPC_PAIR_CLK
@@ -549,7 +552,8 @@ template <int V> struct IC { static constexpr int value = V; };
 // some forty loop-invariant LDS addresses per thread, does not fit them into the 128 registers a 14-wave workgroup
 // leaves per lane and spills 84 bytes per thread: 84 B x 896 threads x 250 workgroups = 18.8 MB of scratch written per
 // launch -- the "27 MB written for 9.6 MB of samples" of profiles/r2_cfg5cem.md (WRITE_SIZE itself is exact:
-// tools/microbench/write_size_calib.hip) -- and ~20 scratch reloads per pipeline step.
+// tools/microbench/write_size_calib.hip) -- and ~20 scratch reloads per pipeline step.  (With 12 waves and 168 registers
+// the config-5 instance spills nothing; the run-time-dimension instances still spill a few words.)
 // CR: the built-in reward kind at compile time (-1 = read it from the arguments).
 // CHALF: whether the last hidden 16-feature tile is half empty (MlpDesc::half_tail of both hidden layers), -1 = run time.
 template <int HT, int A0, int A1, int A2, int NTILES, int CS = 0, int CU = 0, int CH = 0, int CR = -1, int CHALF = -1>
