@@ -92,6 +92,22 @@ def test_evaluator_matches_oracle(L, spec, N, A, H):
     np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3 * H)
 
 
+def test_cem_refit_workgroup_count_does_not_change_results(L, monkeypatch):
+    # k_refit_cem_v2 shares the elite gather between G workgroups per agent (each repeats the selection and takes H*U / G
+    # rows): the control step must not depend on G, bit for bit.
+    dims, acts, S, U, reward = CHEETAH
+    N, A, H, iters, k = 300, 3, 12, 3, 20
+    outs = []
+    for g in ("1", "3", "8"):
+        monkeypatch.setenv("BBMPC_REFIT_WGS", g)
+        eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, True, A=A, H=H, opt=L.OPT_CEM, N=N, iters=iters, k=k, alpha=0.1, seed=5)
+        states = O.cheetah_start_states(A, S)
+        outs.append(eng.optimize(states))
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            np.testing.assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("pair", ["0", "1"])
 @pytest.mark.parametrize("dims,S,U,N,A,H,normalized", [
     ([26, 200, 200, 20], 20, 6, 75, 3, 7, True),       # ragged population, dimensions of the cheetah family (compile-time S, U)
