@@ -148,8 +148,9 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         REQUIRE(c.population_global >= N && c.population_offset >= 0 && c.population_offset + N <= c.population_global, BBMPC_E_INVALID,
                 "population_offset / population_global: this handle's particles must lie inside the global population");
         if (c.population_global > N)
-            REQUIRE(c.optimizer == BBMPC_OPT_PI2 || c.optimizer == BBMPC_OPT_CEM, BBMPC_E_UNSUPPORTED,
-                    "population sharding is built for PI2 (min / sum reductions, pi2.py:80-87) and CEM (top-k merge, cem.py:97-112)");
+            REQUIRE(c.optimizer == BBMPC_OPT_PI2 || c.optimizer == BBMPC_OPT_CEM || c.optimizer == BBMPC_OPT_SPSA, BBMPC_E_UNSUPPORTED,
+                    "population sharding is built for PI2 (min / sum reductions, pi2.py:80-87), CEM (top-k merge, cem.py:97-112) and "
+                    "SPSA (mean over the perturbation pairs, spsa.py:101-107)");
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -193,7 +194,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.mlp_no_half_tail = flag("BBMPC_MLP_NO_HALF_TAIL");
         sw.dbg = flag("BBMPC_DBG");
         user_stepwise_only = flag("BBMPC_USER_STEPWISE");
-        if (c.optimizer == BBMPC_OPT_PI2 || c.optimizer == BBMPC_OPT_CEM) {
+        if (c.optimizer == BBMPC_OPT_PI2 || c.optimizer == BBMPC_OPT_CEM || c.optimizer == BBMPC_OPT_SPSA) {
             ps_loopback = ival("BBMPC_POPSHARD_LOOPBACK", 0);
             ps_force = flag("BBMPC_POPSHARD_FORCE");
         }
@@ -395,6 +396,7 @@ OptArgs Engine::opt_args(uint32_t step, uint32_t iter) const {
     o.lo = d_lo.p; o.hi = d_hi.p;
     o.key = key(step);
     o.iter = iter;
+    o.pop_offset = cfg.population_offset;
     return o;
 }
 
@@ -1886,20 +1888,52 @@ void Engine::optimize_spsa(RolloutArgs& ra, uint32_t step) {
         const float tf = (float)it;
         const float ak = cfg.spsa_a / (float)pow((double)((tf + 1.0f) + big_a), (double)cfg.spsa_alpha);   // :69
         const float ck = cfg.spsa_c / (float)pow((double)(tf + 1.0f), (double)cfg.spsa_gamma);             // :70
-        const OptArgs oa = opt_args(step, (uint32_t)it);
-        hipLaunchKernelGGL(k_spsa_candidates, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, d_mean.p, ck,
-                           inj_r ? inj_r + inj_stride * it : nullptr, d_samples.p, d_cand_a.p, d_cand_b.p);
-        HIP_CHECK(hipGetLastError());
-        ra.samples = nullptr;              // candidates are clipped in place; delta lives in d_samples
-        ra.penalty_out = nullptr;
-        ra.cand = d_cand_a.p; ra.samples = d_cand_a.p; ra.rewards = d_rewards.p;
-        launch_rollout(SRC_BUF, true, ra);
-        ra.cand = d_cand_b.p; ra.samples = d_cand_b.p; ra.rewards = d_rewards2.p;
-        launch_rollout(SRC_BUF, true, ra);
+        OptArgs oa = opt_args(step, (uint32_t)it);
         want_lds((const void*)k_refit_spsa, (size_t)Nst * 4);
-        hipLaunchKernelGGL(k_refit_spsa, dim3(A), dim3(REFIT_THREADS), (size_t)Nst * 4, stream, oa, d_rewards.p, d_rewards2.p,
-                           d_samples.p, ak, ck, d_mean.p, d_action.p);
-        HIP_CHECK(hipGetLastError());
+        // candidates -> the two rollouts -> row sums of this handle's perturbation pairs (part != null: sharded population)
+        auto shard_pass = [&](float* part) {
+            hipLaunchKernelGGL(k_spsa_candidates, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, d_mean.p, ck,
+                               inj_r ? inj_r + inj_stride * it : nullptr, d_samples.p, d_cand_a.p, d_cand_b.p);
+            HIP_CHECK(hipGetLastError());
+            ra.samples = nullptr;              // candidates are clipped in place; delta lives in d_samples
+            ra.penalty_out = nullptr;
+            ra.cand = d_cand_a.p; ra.samples = d_cand_a.p; ra.rewards = d_rewards.p;
+            launch_rollout(SRC_BUF, true, ra);
+            ra.cand = d_cand_b.p; ra.samples = d_cand_b.p; ra.rewards = d_rewards2.p;
+            launch_rollout(SRC_BUF, true, ra);
+            hipLaunchKernelGGL(k_refit_spsa, dim3(A), dim3(REFIT_THREADS), (size_t)Nst * 4, stream, oa, d_rewards.p, d_rewards2.p,
+                               d_samples.p, ak, ck, d_mean.p, d_action.p, part);
+            HIP_CHECK(hipGetLastError());
+        };
+        if (pop_sharded()) {
+            // population sharded over ranks: row sums here, one exchange, the step in rank order (kernels_opt.hpp)
+            const int G = ps_loopback > 1 ? ps_loopback : std::max(1, rc.comm ? rc.nranks : 1);
+            const size_t pw = (size_t)A * HU;
+            if (!ps_part.p || ps_part.n < pw) ps_part.alloc(pw);
+            if (ps_all.n < pw * G) ps_all.alloc(pw * G);
+            if (ps_loopback > 1) {
+                // one handle plays every shard in turn (test / measurement hook): shard r = particles [r*N, (r+1)*N)
+                for (int r = 0; r < G; ++r) {
+                    oa.pop_offset = r * N;
+                    shard_pass(ps_all.p + pw * r);
+                }
+                oa.pop_offset = cfg.population_offset;
+            } else {
+                shard_pass(ps_part.p);
+                if (rc.comm) {
+                    const Rccl& r = Rccl::get();
+                    r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (SPSA row sums)");
+                } else {
+                    REQUIRE(cfg.population_global <= N, BBMPC_E_STATE, "population sharding needs a communicator: call bbmpc_comm_init first");
+                    HIP_CHECK(hipMemcpyAsync(ps_all.p, ps_part.p, pw * 4, hipMemcpyDeviceToDevice, stream));
+                }
+            }
+            const int n_global = ps_loopback > 1 ? G * N : std::max(N, (int)cfg.population_global);
+            hipLaunchKernelGGL(k_spsa_merge, dim3((HU + 255) / 256, A), dim3(256), 0, stream, oa, ps_all.p, G, n_global, ak, d_mean.p, d_action.p);
+            HIP_CHECK(hipGetLastError());
+        } else {
+            shard_pass(nullptr);
+        }
         if (trace_on) {
             capture_trace(it);
             if (!t_rewards2.p) t_rewards2.alloc((size_t)A * Nst * std::max(iters, 1));

@@ -19,6 +19,7 @@ struct OptArgs {
     const float* hi;
     RngKey key;
     uint32_t iter;
+    int pop_offset;       // global index of local particle 0 (population sharding): draws are keyed by the GLOBAL particle
 };
 
 __device__ __forceinline__ uint32_t elem_word(const RngKey& key, uint32_t stream, uint32_t iter, int n, int ga, int j) {
@@ -37,7 +38,7 @@ __global__ void k_spsa_candidates(OptArgs p, const float* solution /*[A][HU]*/, 
     const int j = blockIdx.y, a = blockIdx.z;
     if (n >= p.N) return;
     const size_t idx = ((size_t)a * p.HU + j) * p.Nst + n;
-    const float d = inj ? inj[idx] : word_to_rademacher(elem_word(p.key, 3u, p.iter, n, p.agent_offset + a, j));
+    const float d = inj ? inj[idx] : word_to_rademacher(elem_word(p.key, 3u, p.iter, n + p.pop_offset, p.agent_offset + a, j));
     const float sol = solution[a * p.HU + j];
     const float step = ck * d;
     delta[idx] = d;
@@ -47,9 +48,11 @@ __global__ void k_spsa_candidates(OptArgs p, const float* solution /*[A][HU]*/, 
 
 // ghat[j] = mean_n (r+ - r-)[n] / (2 c_k delta[j][n]);  solution = clip(solution + a_k ghat)   (spsa.py:101-107)
 // one workgroup per agent, one wave per j.
+// `part` != null (population sharded over ranks): this rank's particles only -- the row sums go to part[a][j] and the
+// update is k_spsa_merge's.
 __global__ __launch_bounds__(REFIT_THREADS) void k_refit_spsa(OptArgs p, const float* rew_plus, const float* rew_minus,
                                                               const float* delta, float ak, float ck, float* solution,
-                                                              float* action) {
+                                                              float* action, float* part) {
     extern __shared__ float diff[];
     const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int NW = REFIT_THREADS / 64;
@@ -61,6 +64,10 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_refit_spsa(OptArgs p, const f
         float acc = 0.0f;
         for (int n = lane; n < p.N; n += 64) acc += diff[n] / (two_ck * drow[n]);
         acc = wave_sum(acc);
+        if (part) {
+            if (lane == 0) part[a * p.HU + j] = acc;
+            continue;
+        }
         if (lane == 0) {
             const float ghat = acc / (float)p.N;
             const int u = j % p.U;
@@ -69,6 +76,22 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_refit_spsa(OptArgs p, const f
             if (j < p.U) action[a * p.U + j] = s;
         }
     }
+}
+
+// SPSA with the population sharded over ranks: spsa.py:101-107 is a mean over the perturbation pairs, so
+// every rank sums its own pairs (k_refit_spsa with `part`), one all-gather hands every rank all G row-sum vectors
+// all[r][a][j], and each rank adds them in rank order, divides by the GLOBAL population and takes the step: identical bits
+// on every rank; against the unsharded refit only the order of the fp32 sums differs.  grid (ceil(HU/256), A)
+__global__ void k_spsa_merge(OptArgs p, const float* all, int G, int n_global, float ak, float* solution, float* action) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, a = blockIdx.y;
+    if (j >= p.HU) return;
+    float acc = 0.0f;
+    for (int r = 0; r < G; ++r) acc = acc + all[((size_t)r * p.A + a) * p.HU + j];
+    const float ghat = acc / (float)n_global;
+    const int u = j % p.U;
+    const float s = clipf(solution[a * p.HU + j] + ak * ghat, p.lo[u], p.hi[u]);
+    solution[a * p.HU + j] = s;
+    if (j < p.U) action[a * p.U + j] = s;
 }
 
 // ------------------------------------------------------------------------------------------------

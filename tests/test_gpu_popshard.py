@@ -1,4 +1,4 @@
-"""f-4: population sharding for num_agents < n_gpus, PI2 and CEM.  PI2: the min / sum reductions of
+"""f-4: population sharding for num_agents < n_gpus, PI2, CEM and SPSA.  PI2: the min / sum reductions of
 pi2.py:80-87 split across ranks: per iteration every rank rolls out ITS particles of the shared population, produces
 (min cost, sum of weights, weighted sums [H*U]) per agent, one collective hands every rank all partials and each merges
 them in rank order.  RNG is keyed by the GLOBAL particle index, so a sharded run draws exactly the unsharded run's
@@ -107,6 +107,62 @@ def test_sharded_population_equals_unsharded_pendulum_pi2(L, monkeypatch):
         s = n_f
 
 
+@pytest.mark.parametrize("G", [2, 5])
+def test_sharded_spsa_against_the_oracle_and_the_unsharded_engine(L, monkeypatch, G):
+    # SPSA (spsa.py:61-117): the gradient estimate is a mean over the perturbation pairs, so every shard sums its own pairs,
+    # one all-gather, every rank adds the G row-sum vectors in rank order and divides by the GLOBAL population.  The
+    # Rademacher draws are keyed by the global particle index: the unsharded engine's dumped draws feed the NumPy oracle.
+    from blackbox_mpc_amd.engine import Engine
+    monkeypatch.setenv("BBMPC_FUSED", "0")
+    N, A, H, iters = 640, 2, 12, 4
+    mk = lambda n, **kw: Engine(L.OPT_SPSA, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=A,
+                                planning_horizon=H, population_size=n, max_iterations=iters, seed=13, **kw)
+    full = mk(N)
+    monkeypatch.setenv("BBMPC_POPSHARD_LOOPBACK", str(G))
+    shard = mk(N // G, population_global=N)
+    monkeypatch.delenv("BBMPC_POPSHARD_LOOPBACK")
+    ev = O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))
+    sp = O.SPSA(ev, [-2.0], [2.0], horizon=H, max_iterations=iters, population=N, num_agents=A)
+    s = O.pendulum_start_states(A)
+    for t in range(3):                                   # later control steps start from the shifted solution (spsa.py:114-115)
+        delta = [full.dump_noise(L.NOISE_RADEMACHER, t, it, (N, A, H, 1)) for it in range(iters)]
+        a_f, n_f, _ = full.optimize(s, t)
+        a_s, n_s, _ = shard.optimize(s, t)
+        a_o, n_o, _ = sp.call(s, {"rademacher": delta})
+        np.testing.assert_allclose(a_s, a_f, rtol=0, atol=2e-5)          # sharded vs unsharded engine: order of the fp32 sums only
+        np.testing.assert_allclose(shard.get_state("prev_mean"), full.get_state("prev_mean"), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(a_s, a_o, rtol=0, atol=1e-4)          # sharded engine vs the oracle (tolerances of test_gpu_spsa_pso.py)
+        np.testing.assert_allclose(shard.get_state("prev_mean"), sp.params, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(n_s, n_o, rtol=1e-4, atol=1e-4)
+        s = n_f
+
+
+def test_sharded_spsa_mlp_equals_unsharded(L, monkeypatch):
+    # learned-dynamics SPSA, population sharded 4 ways, over three control steps (warm start through k_tail_mlp)
+    from blackbox_mpc_amd.engine import Engine
+    S, U, N, H, iters, G = 20, 6, 512, 10, 3, 4
+    ws, bs = O.make_mlp_params([26, 200, 200, 20], seed=42)
+    stats = [np.zeros(S, F), np.ones(S, F), np.zeros(U, F), np.ones(U, F), np.zeros(S, F), np.full(S, 0.1, F)]
+
+    def mk(n, **kw):
+        e = Engine(L.OPT_SPSA, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=1, planning_horizon=H,
+                   population_size=n, max_iterations=iters, seed=3, **kw)
+        e.set_mlp(ws, bs, [1, 1, 0], stats)
+        return e
+    full = mk(N)
+    monkeypatch.setenv("BBMPC_POPSHARD_LOOPBACK", str(G))
+    shard = mk(N // G, population_global=N)
+    monkeypatch.delenv("BBMPC_POPSHARD_LOOPBACK")
+    s = O.cheetah_start_states(1, S)
+    for t in range(3):
+        a_f, n_f, _ = full.optimize(s, t)
+        a_s, n_s, _ = shard.optimize(s, t)
+        np.testing.assert_allclose(a_s, a_f, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(n_s, n_f, rtol=0, atol=2e-4)
+        np.testing.assert_allclose(shard.get_state("prev_mean"), full.get_state("prev_mean"), rtol=0, atol=2e-5)
+        s = n_f
+
+
 def test_exchange_through_a_one_rank_rccl_communicator(L, monkeypatch):
     # the real code path of a sharded rank -- partials, ncclAllGather on the launch stream, merge -- with one rank
     from blackbox_mpc_amd.engine import Engine
@@ -128,10 +184,33 @@ def test_exchange_through_a_one_rank_rccl_communicator(L, monkeypatch):
     one.comm_destroy()
 
 
+def test_spsa_exchange_through_a_one_rank_rccl_communicator(L, monkeypatch):
+    # SPSA's sharded code path as a rank runs it -- row sums, ncclAllGather on the launch stream, merge -- with one rank
+    from blackbox_mpc_amd.engine import Engine
+    monkeypatch.setenv("BBMPC_FUSED", "0")
+    N, A, H, iters = 256, 2, 9, 3
+    mk = lambda **kw: Engine(L.OPT_SPSA, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=A,
+                             planning_horizon=H, population_size=N, max_iterations=iters, seed=2, **kw)
+    full = mk()
+    monkeypatch.setenv("BBMPC_POPSHARD_FORCE", "1")
+    one = mk(population_global=N)
+    monkeypatch.delenv("BBMPC_POPSHARD_FORCE")
+    one.comm_init(Engine.comm_unique_id(), 1, 0)
+    s = O.pendulum_start_states(A)
+    for t in range(2):
+        a_f, n_f, _ = full.optimize(s, t)
+        a_o, n_o, _ = one.optimize(s, t)
+        np.testing.assert_allclose(a_o, a_f, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(n_o, n_f, rtol=0, atol=2e-5)
+        s = n_f
+    one.synchronize()
+    one.comm_destroy()
+
+
 def test_population_sharding_argument_checks(L):
     from blackbox_mpc_amd.engine import Engine
     kw = dict(dim_s=3, num_agents=1, planning_horizon=8, max_iterations=2)
-    with pytest.raises(L.BBMPCError) as ei:              # PSO / SPSA / CMA-ES carry per-particle state: not built, said so
+    with pytest.raises(L.BBMPCError) as ei:              # PSO / CMA-ES carry per-particle or joint state: not built, said so
         Engine(L.OPT_PSO, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], population_size=64, population_global=128, **kw)
     assert ei.value.code == L.E_UNSUPPORTED
     with pytest.raises(L.BBMPCError):                    # the shard must lie inside the population
