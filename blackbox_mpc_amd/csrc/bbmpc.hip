@@ -148,9 +148,10 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         REQUIRE(c.population_global >= N && c.population_offset >= 0 && c.population_offset + N <= c.population_global, BBMPC_E_INVALID,
                 "population_offset / population_global: this handle's particles must lie inside the global population");
         if (c.population_global > N)
-            REQUIRE(c.optimizer == BBMPC_OPT_PI2 || c.optimizer == BBMPC_OPT_CEM || c.optimizer == BBMPC_OPT_SPSA, BBMPC_E_UNSUPPORTED,
-                    "population sharding is built for PI2 (min / sum reductions, pi2.py:80-87), CEM (top-k merge, cem.py:97-112) and "
-                    "SPSA (mean over the perturbation pairs, spsa.py:101-107)");
+            REQUIRE(c.optimizer == BBMPC_OPT_PI2 || c.optimizer == BBMPC_OPT_CEM || c.optimizer == BBMPC_OPT_SPSA || c.optimizer == BBMPC_OPT_PSO,
+                    BBMPC_E_UNSUPPORTED,
+                    "population sharding is built for PI2 (min / sum reductions, pi2.py:80-87), CEM (top-k merge, cem.py:97-112), "
+                    "SPSA (mean over the perturbation pairs, spsa.py:101-107) and PSO (argmax of the personal bests, pso.py:94)");
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -194,7 +195,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.mlp_no_half_tail = flag("BBMPC_MLP_NO_HALF_TAIL");
         sw.dbg = flag("BBMPC_DBG");
         user_stepwise_only = flag("BBMPC_USER_STEPWISE");
-        if (c.optimizer == BBMPC_OPT_PI2 || c.optimizer == BBMPC_OPT_CEM || c.optimizer == BBMPC_OPT_SPSA) {
+        if (c.optimizer == BBMPC_OPT_PI2 || c.optimizer == BBMPC_OPT_CEM || c.optimizer == BBMPC_OPT_SPSA || c.optimizer == BBMPC_OPT_PSO) {
             ps_loopback = ival("BBMPC_POPSHARD_LOOPBACK", 0);
             ps_force = flag("BBMPC_POPSHARD_FORCE");
         }
@@ -240,8 +241,9 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         }
         if (c.optimizer == BBMPC_OPT_PSO) {
             // constructor state of the reference: every Variable zero (pso.py:50-59), quirk Q4
-            d_cand_a.alloc(big); d_vel.alloc(big); d_pbest.alloc(big);
-            d_pbest_r.alloc((size_t)A * Nst); d_cond.alloc((size_t)A * Nst);
+            const size_t gl = ps_loopback > 1 ? (size_t)ps_loopback : 1;      // the loopback hook keeps every shard's swarm
+            d_cand_a.alloc(big * gl); d_vel.alloc(big * gl); d_pbest.alloc(big * gl);
+            d_pbest_r.alloc((size_t)A * Nst * gl); d_cond.alloc((size_t)A * Nst * gl);
             d_gbest.alloc((size_t)A * HU); d_gbest_r.alloc((size_t)A); d_gidx.alloc((size_t)A);
             d_cand_a.zero(stream); d_vel.zero(stream); d_pbest.zero(stream); d_pbest_r.zero(stream);
             d_cond.zero(stream); d_gbest.zero(stream); d_gbest_r.zero(stream); d_gidx.zero(stream);
@@ -400,10 +402,11 @@ OptArgs Engine::opt_args(uint32_t step, uint32_t iter) const {
     return o;
 }
 
-PsoState Engine::pso_state() {
+PsoState Engine::pso_state(int shard) {
     PsoState s;
-    s.pos = d_cand_a.p; s.vel = d_vel.p; s.pbest = d_pbest.p; s.pbest_r = d_pbest_r.p;
-    s.gbest = d_gbest.p; s.gbest_r = d_gbest_r.p; s.cond = d_cond.p; s.gidx = d_gidx.p;
+    const size_t big = (size_t)A * HU * Nst * shard, small = (size_t)A * Nst * shard;
+    s.pos = d_cand_a.p + big; s.vel = d_vel.p + big; s.pbest = d_pbest.p + big; s.pbest_r = d_pbest_r.p + small;
+    s.gbest = d_gbest.p; s.gbest_r = d_gbest_r.p; s.cond = d_cond.p + small; s.gidx = d_gidx.p;
     return s;
 }
 
@@ -621,10 +624,13 @@ void Engine::reset() {
     }
     if (cfg.optimizer == BBMPC_OPT_PSO) {
         // PSOOptimizer.reset(): uniform positions / velocities, pbest = pos, rewards -inf  (pso.py:143-160)
-        const OptArgs oa = opt_args(step_counter, 0xFFFFu);
-        hipLaunchKernelGGL(k_pso_seed, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, pso_state(), d_var0.p,
-                           cfg.pso_v0_fraction, 1, injected(BBMPC_NOISE_PSO_RESET_POS), injected(BBMPC_NOISE_PSO_RESET_VEL));
-        HIP_CHECK(hipGetLastError());
+        OptArgs oa = opt_args(step_counter, 0xFFFFu);
+        for (int r = 0; r < (ps_loopback > 1 ? ps_loopback : 1); ++r) {
+            if (ps_loopback > 1) oa.pop_offset = r * N;
+            hipLaunchKernelGGL(k_pso_seed, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, pso_state(r), d_var0.p,
+                               cfg.pso_v0_fraction, 1, injected(BBMPC_NOISE_PSO_RESET_POS), injected(BBMPC_NOISE_PSO_RESET_VEL));
+            HIP_CHECK(hipGetLastError());
+        }
         HIP_CHECK(hipStreamSynchronize(stream));
         return;
     }
@@ -1955,7 +1961,7 @@ static size_t fused_pso_lds(int H, int Nst) { return ((size_t)2 * H * Nst + ((H 
 
 bool Engine::use_fused_pso() const {
     if (cfg.dynamics != BBMPC_DYN_PENDULUM || cfg.reward != BBMPC_REW_PENDULUM || cfg.optimizer != BBMPC_OPT_PSO || U != 1) return false;
-    if (fused_mode == 0) return false;
+    if (fused_mode == 0 || pop_sharded()) return false;           // a sharded swarm exchanges its bests every iteration
     return N <= 1024 && fused_pso_lds(H, Nst) <= 160 * 1024;
 }
 
@@ -2009,14 +2015,45 @@ void Engine::optimize_fused_pso(const float* d_state_in, int add_noise, float* d
 void Engine::optimize_pso(RolloutArgs& ra, uint32_t step) {
     PsoState ps = pso_state();
     const float* inj_s = injected(BBMPC_NOISE_PSO_SCALARS);
+    // population sharded over ranks: every rank moves ITS particles; the one cross-particle operation, the
+    // argmax of the personal bests (pso.py:94), becomes local best -> all-gather -> first maximum by global index
+    const bool sharded = pop_sharded();
+    const int G = !sharded ? 1 : (ps_loopback > 1 ? ps_loopback : std::max(1, rc.comm ? rc.nranks : 1));
+    const int shards_here = ps_loopback > 1 ? ps_loopback : 1;         // the loopback hook plays every shard in turn
+    const size_t pw = (size_t)A * (HU + 2);
+    if (sharded) {
+        if (!ps_part.p || ps_part.n < pw) ps_part.alloc(pw);
+        if (ps_all.n < pw * G) ps_all.alloc(pw * G);
+    }
     for (int it = 0; it < iters; ++it) {
-        const OptArgs oa = opt_args(step, (uint32_t)it);
-        ra.cand = ps.pos; ra.samples = ps.pos; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
-        launch_rollout(SRC_BUF, true, ra);                     // clip + penalty + write the feasible positions back
-        hipLaunchKernelGGL(k_pso_best, dim3(A), dim3(REFIT_THREADS), 0, stream, oa, ps, d_rewards.p);
-        hipLaunchKernelGGL(k_pso_move, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, ps, cfg.pso_w, cfg.pso_c1,
-                           cfg.pso_c2, inj_s ? inj_s + 2 * it : nullptr);
-        HIP_CHECK(hipGetLastError());
+        OptArgs oa = opt_args(step, (uint32_t)it);
+        for (int r = 0; r < shards_here; ++r) {
+            const PsoState pr = pso_state(r);
+            if (ps_loopback > 1) oa.pop_offset = r * N;
+            ra.cand = pr.pos; ra.samples = pr.pos; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
+            launch_rollout(SRC_BUF, true, ra);                 // clip + penalty + write the feasible positions back
+            hipLaunchKernelGGL(k_pso_best, dim3(A), dim3(REFIT_THREADS), 0, stream, oa, pr, d_rewards.p,
+                               !sharded ? nullptr : (ps_loopback > 1 ? ps_all.p + pw * r : ps_part.p));
+            HIP_CHECK(hipGetLastError());
+        }
+        if (sharded) {
+            if (ps_loopback <= 1) {
+                if (rc.comm) {
+                    const Rccl& r = Rccl::get();
+                    r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (PSO local bests)");
+                } else {
+                    REQUIRE(cfg.population_global <= N, BBMPC_E_STATE, "population sharding needs a communicator: call bbmpc_comm_init first");
+                    HIP_CHECK(hipMemcpyAsync(ps_all.p, ps_part.p, pw * 4, hipMemcpyDeviceToDevice, stream));
+                }
+            }
+            hipLaunchKernelGGL(k_pso_merge, dim3(A), dim3(256), 0, stream, oa, ps, ps_all.p, G);
+            HIP_CHECK(hipGetLastError());
+        }
+        for (int r = 0; r < shards_here; ++r) {
+            hipLaunchKernelGGL(k_pso_move, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, pso_state(r), cfg.pso_w, cfg.pso_c1,
+                               cfg.pso_c2, inj_s ? inj_s + 2 * it : nullptr);
+            HIP_CHECK(hipGetLastError());
+        }
         if (trace_on) {
             ensure_trace();
             const size_t nr = (size_t)A * Nst, nm = (size_t)A * HU;
@@ -2026,10 +2063,13 @@ void Engine::optimize_pso(RolloutArgs& ra, uint32_t step) {
         }
     }
     hipLaunchKernelGGL(k_take_first, dim3((A * U + 63) / 64), dim3(64), 0, stream, A, HU, U, ps.gbest, d_action.p);      // :114
-    const OptArgs oa = opt_args(step, 0u);
-    hipLaunchKernelGGL(k_pso_seed, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, ps, d_var0.p, cfg.pso_v0_fraction, 0,
-                       injected(BBMPC_NOISE_PSO_RESEED_TRUNC), injected(BBMPC_NOISE_PSO_RESEED_UNIFORM));              // :116-138
-    HIP_CHECK(hipGetLastError());
+    OptArgs oa = opt_args(step, 0u);
+    for (int r = 0; r < shards_here; ++r) {
+        if (ps_loopback > 1) oa.pop_offset = r * N;
+        hipLaunchKernelGGL(k_pso_seed, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, pso_state(r), d_var0.p, cfg.pso_v0_fraction, 0,
+                           injected(BBMPC_NOISE_PSO_RESEED_TRUNC), injected(BBMPC_NOISE_PSO_RESEED_UNIFORM));          // :116-138
+        HIP_CHECK(hipGetLastError());
+    }
 }
 
 void Engine::evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop, float* d_rew_out) {

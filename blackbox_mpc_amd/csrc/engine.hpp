@@ -267,7 +267,7 @@ struct Engine {
     void cma_reset_mean_sigma();
     CmaArgs cma_args(uint32_t step, uint32_t iter);
     OptArgs opt_args(uint32_t step, uint32_t iter) const;
-    PsoState pso_state();
+    PsoState pso_state(int shard = 0);       // shard > 0: the loopback hook's further copies of the per-particle state
     void evaluate_dev(const float* d_state_in, const float* d_seq, int n_pop, float* d_rew_out);
     void step_dev(const float* d_states, const float* d_actions, int astride, int batch, float* d_next, float* d_rew);
     void reward_dev(const float* d_cur, const float* d_next, const float* d_act, int batch, float* d_rew);

@@ -109,7 +109,9 @@ struct PsoState {
 };
 
 // per agent: personal-best rewards, global best index (first maximum), global best position (pso.py:84-100)
-__global__ __launch_bounds__(REFIT_THREADS) void k_pso_best(OptArgs p, PsoState s, const float* rewards) {
+// `part` != null (population sharded over ranks): this rank's particles only -- the local best goes to
+// part[a] = (value, GLOBAL particle index as bits, position[HU]) and k_pso_merge picks the swarm's.
+__global__ __launch_bounds__(REFIT_THREADS) void k_pso_best(OptArgs p, PsoState s, const float* rewards, float* part) {
     __shared__ float sv[REFIT_THREADS / 64];
     __shared__ int si[REFIT_THREADS / 64];
     __shared__ int s_gi;
@@ -135,15 +137,45 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_pso_best(OptArgs p, PsoState 
         bi = (lane < NW) ? si[lane] : 0x7fffffff;
         wave_argmax(bv, bi);
         if (bi == 0x7fffffff) bi = 0;
-        if (lane == 0) { s_gi = bi; s.gidx[a] = bi; s.gbest_r[a] = s.pbest_r[(size_t)a * p.Nst + bi]; }
+        if (lane == 0) {
+            s_gi = bi;
+            const float br = s.pbest_r[(size_t)a * p.Nst + bi];
+            if (part) {
+                part[(size_t)a * (p.HU + 2)] = br;
+                part[(size_t)a * (p.HU + 2) + 1] = __int_as_float(bi + p.pop_offset);
+            } else {
+                s.gidx[a] = bi;
+                s.gbest_r[a] = br;
+            }
+        }
     }
     __syncthreads();
     const int gi = s_gi;
     const bool cg = s.cond[(size_t)a * p.Nst + gi] != 0.0f;
+    float* dst = part ? part + (size_t)a * (p.HU + 2) + 2 : s.gbest + a * p.HU;
     for (int j = tid; j < p.HU; j += REFIT_THREADS) {
         const size_t i = ((size_t)a * p.HU + j) * p.Nst + gi;
-        s.gbest[a * p.HU + j] = cg ? s.pos[i] : s.pbest[i];      // pbest after this iteration's update
+        dst[j] = cg ? s.pos[i] : s.pbest[i];                     // pbest after this iteration's update
     }
+}
+
+// PSO with the swarm sharded over ranks: all[r][a] = (best value, global index, position[HU]) of rank r's particles; the
+// swarm's best is the first maximum by GLOBAL index (tf.argmax over the whole population: pso.py:94), so the sharded run
+// is the unsharded one bit for bit (the only cross-particle operation of PSO is this argmax).  grid A
+__global__ void k_pso_merge(OptArgs p, PsoState s, const float* all, int G) {
+    const int a = blockIdx.x, tid = threadIdx.x;
+    const size_t pw = (size_t)p.A * (p.HU + 2);
+    int br = 0, bi = 0x7fffffff;
+    float bv = -INFINITY;
+    for (int r = 0; r < G; ++r) {                                  // every thread the same scan: G is a handful
+        const float* e = all + pw * r + (size_t)a * (p.HU + 2);
+        const float v = e[0];
+        const int idx = __float_as_int(e[1]);
+        if (v > bv || (v == bv && idx < bi) || bi == 0x7fffffff) { bv = v; bi = idx; br = r; }
+    }
+    const float* src = all + pw * br + (size_t)a * (p.HU + 2) + 2;
+    for (int j = tid; j < p.HU; j += blockDim.x) s.gbest[a * p.HU + j] = src[j];
+    if (tid == 0) { s.gidx[a] = bi; s.gbest_r[a] = bv; }
 }
 
 // r1, r2: the two SCALAR N(0,1) draws shared by every particle / dim / agent (quirk Q3, pso.py:107-109)
@@ -188,7 +220,7 @@ __global__ void k_pso_seed(OptArgs p, PsoState s, const float* var0 /*[A][HU]*/,
     const int ga = p.agent_offset + a;
     float pos;
     if (is_reset) {
-        const float x = inj_pos ? inj_pos[i] : word_to_uniform(elem_word(p.key, 8u, p.iter, n, ga, j));
+        const float x = inj_pos ? inj_pos[i] : word_to_uniform(elem_word(p.key, 8u, p.iter, n + p.pop_offset, ga, j));
         pos = x * (hi - lo) + lo;
     } else {
         const float g = s.gbest[a * p.HU + j];
@@ -196,11 +228,11 @@ __global__ void k_pso_seed(OptArgs p, PsoState s, const float* var0 /*[A][HU]*/,
         const float cv = fminf(fminf(lb * lb, ub * ub), var0[a * p.HU + j]);
         const int hs = (h + 1 < p.H) ? h + 1 : p.H - 1;
         const float mean = s.gbest[a * p.HU + hs * p.U + u];
-        const float xi = inj_pos ? inj_pos[i] : word_to_trunc_normal(elem_word(p.key, 6u, p.iter, n, ga, j));
+        const float xi = inj_pos ? inj_pos[i] : word_to_trunc_normal(elem_word(p.key, 6u, p.iter, n + p.pop_offset, ga, j));
         pos = xi * sqrtf(cv) + mean;
     }
     const float v0 = v0frac * (hi - lo);
-    const float uv = inj_vel ? inj_vel[i] : word_to_uniform(elem_word(p.key, is_reset ? 9u : 7u, p.iter, n, ga, j));
+    const float uv = inj_vel ? inj_vel[i] : word_to_uniform(elem_word(p.key, is_reset ? 9u : 7u, p.iter, n + p.pop_offset, ga, j));
     s.pos[i] = pos;
     s.vel[i] = uv * (v0 - (-v0)) + (-v0);
     s.pbest[i] = pos;

@@ -1,4 +1,4 @@
-"""f-4: population sharding for num_agents < n_gpus, PI2, CEM and SPSA.  PI2: the min / sum reductions of
+"""f-4: population sharding for num_agents < n_gpus, PI2, CEM, SPSA and PSO.  PI2: the min / sum reductions of
 pi2.py:80-87 split across ranks: per iteration every rank rolls out ITS particles of the shared population, produces
 (min cost, sum of weights, weighted sums [H*U]) per agent, one collective hands every rank all partials and each merges
 them in rank order.  RNG is keyed by the GLOBAL particle index, so a sharded run draws exactly the unsharded run's
@@ -184,6 +184,90 @@ def test_exchange_through_a_one_rank_rccl_communicator(L, monkeypatch):
     one.comm_destroy()
 
 
+@pytest.mark.parametrize("G", [2, 4])
+def test_sharded_pso_is_the_unsharded_swarm_bit_for_bit(L, monkeypatch, G):
+    # PSO (pso.py:70-141): the particles live across iterations; their only cross-particle operation is the argmax of the
+    # personal bests (pso.py:94).  Sharded: local best -> all-gather -> first maximum by GLOBAL particle index, draws keyed
+    # by the global particle -- so a sharded swarm is the unsharded one bit for bit, over control steps, re-seeds and a reset.
+    from blackbox_mpc_amd.engine import Engine
+    monkeypatch.setenv("BBMPC_FUSED", "0")
+    N, A, H, iters = 256, 2, 11, 4
+    mk = lambda n, **kw: Engine(L.OPT_PSO, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=A,
+                                planning_horizon=H, population_size=n, max_iterations=iters, seed=17, **kw)
+    full = mk(N)
+    monkeypatch.setenv("BBMPC_POPSHARD_LOOPBACK", str(G))
+    shard = mk(N // G, population_global=N)
+    monkeypatch.delenv("BBMPC_POPSHARD_LOOPBACK")
+    full.set_trace(True)
+    shard.set_trace(True)
+    s = O.pendulum_start_states(A)
+    n = N // G
+    for t in range(5):
+        if t == 3:
+            full.reset()
+            shard.reset()
+        a_f, n_f, r_f = full.optimize(s, t)
+        a_s, n_s, r_s = shard.optimize(s, t)
+        np.testing.assert_array_equal(a_s, a_f)
+        np.testing.assert_array_equal(n_s, n_f)
+        np.testing.assert_array_equal(r_s, r_f)
+        for it in range(iters):                              # global best position and its GLOBAL particle index per iteration
+            np.testing.assert_array_equal(shard.get_trace(it, L.TRACE_MEAN), full.get_trace(it, L.TRACE_MEAN))
+            np.testing.assert_array_equal(shard.get_trace(it, L.TRACE_ELITES), full.get_trace(it, L.TRACE_ELITES))
+        # shard 0's particles are the first N / G of the swarm (re-seeded around the same global best)
+        np.testing.assert_array_equal(shard.get_state("pos", (n, A, H, 1)), full.get_state("pos", (N, A, H, 1))[:n])
+        np.testing.assert_array_equal(shard.get_state("vel", (n, A, H, 1)), full.get_state("vel", (N, A, H, 1))[:n])
+        s = n_f
+
+
+def test_sharded_pso_mlp_equals_unsharded(L, monkeypatch):
+    from blackbox_mpc_amd.engine import Engine
+    S, U, N, H, iters, G = 20, 6, 384, 8, 3, 3
+    ws, bs = O.make_mlp_params([26, 200, 200, 20], seed=42)
+    stats = [np.zeros(S, F), np.ones(S, F), np.zeros(U, F), np.ones(U, F), np.zeros(S, F), np.full(S, 0.1, F)]
+
+    def mk(n, **kw):
+        e = Engine(L.OPT_PSO, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=2, planning_horizon=H,
+                   population_size=n, max_iterations=iters, seed=8, **kw)
+        e.set_mlp(ws, bs, [1, 1, 0], stats)
+        return e
+    full = mk(N)
+    monkeypatch.setenv("BBMPC_POPSHARD_LOOPBACK", str(G))
+    shard = mk(N // G, population_global=N)
+    monkeypatch.delenv("BBMPC_POPSHARD_LOOPBACK")
+    s = O.cheetah_start_states(2, S)
+    for t in range(3):
+        a_f, n_f, _ = full.optimize(s, t)
+        a_s, n_s, _ = shard.optimize(s, t)
+        # a shard of 128 particles and the whole swarm of 384 are rolled out by different MFMA tilings (different order of the
+        # fp32 sums inside a model step): the swarm's best is compared within the MLP tolerance, not bit for bit
+        np.testing.assert_allclose(a_s, a_f, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(n_s, n_f, rtol=2e-5, atol=2e-4)
+        s = n_f
+
+
+def test_pso_exchange_through_a_one_rank_rccl_communicator(L, monkeypatch):
+    from blackbox_mpc_amd.engine import Engine
+    monkeypatch.setenv("BBMPC_FUSED", "0")
+    N, A, H, iters = 192, 2, 7, 3
+    mk = lambda **kw: Engine(L.OPT_PSO, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=A,
+                             planning_horizon=H, population_size=N, max_iterations=iters, seed=6, **kw)
+    full = mk()
+    monkeypatch.setenv("BBMPC_POPSHARD_FORCE", "1")
+    one = mk(population_global=N)
+    monkeypatch.delenv("BBMPC_POPSHARD_FORCE")
+    one.comm_init(Engine.comm_unique_id(), 1, 0)
+    s = O.pendulum_start_states(A)
+    for t in range(3):
+        a_f, n_f, _ = full.optimize(s, t)
+        a_o, n_o, _ = one.optimize(s, t)
+        np.testing.assert_array_equal(a_o, a_f)
+        np.testing.assert_array_equal(n_o, n_f)
+        s = n_f
+    one.synchronize()
+    one.comm_destroy()
+
+
 def test_spsa_exchange_through_a_one_rank_rccl_communicator(L, monkeypatch):
     # SPSA's sharded code path as a rank runs it -- row sums, ncclAllGather on the launch stream, merge -- with one rank
     from blackbox_mpc_amd.engine import Engine
@@ -210,8 +294,8 @@ def test_spsa_exchange_through_a_one_rank_rccl_communicator(L, monkeypatch):
 def test_population_sharding_argument_checks(L):
     from blackbox_mpc_amd.engine import Engine
     kw = dict(dim_s=3, num_agents=1, planning_horizon=8, max_iterations=2)
-    with pytest.raises(L.BBMPCError) as ei:              # PSO / CMA-ES carry per-particle or joint state: not built, said so
-        Engine(L.OPT_PSO, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], population_size=64, population_global=128, **kw)
+    with pytest.raises(L.BBMPCError) as ei:              # CMA-ES carries a joint covariance: not built, said so
+        Engine(L.OPT_CMAES, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], population_size=64, population_global=128, num_elite=8, **kw)
     assert ei.value.code == L.E_UNSUPPORTED
     with pytest.raises(L.BBMPCError):                    # the shard must lie inside the population
         Engine(L.OPT_PI2, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], population_size=64, population_offset=100,
