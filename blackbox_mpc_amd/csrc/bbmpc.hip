@@ -148,10 +148,10 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         REQUIRE(c.population_global >= N && c.population_offset >= 0 && c.population_offset + N <= c.population_global, BBMPC_E_INVALID,
                 "population_offset / population_global: this handle's particles must lie inside the global population");
         if (c.population_global > N)
-            REQUIRE(c.optimizer == BBMPC_OPT_PI2 || c.optimizer == BBMPC_OPT_CEM || c.optimizer == BBMPC_OPT_SPSA || c.optimizer == BBMPC_OPT_PSO,
-                    BBMPC_E_UNSUPPORTED,
-                    "population sharding is built for PI2 (min / sum reductions, pi2.py:80-87), CEM (top-k merge, cem.py:97-112), "
-                    "SPSA (mean over the perturbation pairs, spsa.py:101-107) and PSO (argmax of the personal bests, pso.py:94)");
+            REQUIRE(c.optimizer != BBMPC_OPT_CMAES && c.optimizer != BBMPC_OPT_NONE, BBMPC_E_UNSUPPORTED,
+                    "population sharding is built for RandomSearch (argmax, random_search.py:43-47), PI2 (min / sum reductions, "
+                    "pi2.py:80-87), CEM (top-k merge, cem.py:97-112), SPSA (mean over the perturbation pairs, spsa.py:101-107) and PSO "
+                    "(argmax of the personal bests, pso.py:94); CMA-ES keeps a joint covariance per instance and does not shard");
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -195,7 +195,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.mlp_no_half_tail = flag("BBMPC_MLP_NO_HALF_TAIL");
         sw.dbg = flag("BBMPC_DBG");
         user_stepwise_only = flag("BBMPC_USER_STEPWISE");
-        if (c.optimizer == BBMPC_OPT_PI2 || c.optimizer == BBMPC_OPT_CEM || c.optimizer == BBMPC_OPT_SPSA || c.optimizer == BBMPC_OPT_PSO) {
+        if (c.optimizer != BBMPC_OPT_CMAES && c.optimizer != BBMPC_OPT_NONE) {
             ps_loopback = ival("BBMPC_POPSHARD_LOOPBACK", 0);
             ps_force = flag("BBMPC_POPSHARD_FORCE");
         }
@@ -1679,8 +1679,38 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
         case BBMPC_OPT_RANDOM_SEARCH: {
             ra.stream = BBMPC_NOISE_UNIFORM; ra.iter = 0;
             ra.inj = injected(BBMPC_NOISE_UNIFORM);
+            if (pop_sharded()) {
+                // population sharded over ranks: local first maximum, one exchange, first maximum by global index
+                const int G = ps_loopback > 1 ? ps_loopback : std::max(1, rc.comm ? rc.nranks : 1);
+                const size_t pw = (size_t)A * (U + 2);
+                if (!ps_part.p || ps_part.n < pw) ps_part.alloc(pw);
+                if (ps_all.n < pw * G) ps_all.alloc(pw * G);
+                if (ps_loopback > 1) {
+                    for (int r = 0; r < G; ++r) {
+                        ra.pop_offset = r * N;
+                        launch_rollout(SRC_UNIFORM, false, ra);
+                        hipLaunchKernelGGL(k_refit_argmax, dim3(A), dim3(REFIT_THREADS), 0, stream, rf, ps_all.p + pw * r, r * N);
+                    }
+                    ra.pop_offset = cfg.population_offset;
+                } else {
+                    launch_rollout(SRC_UNIFORM, false, ra);
+                    hipLaunchKernelGGL(k_refit_argmax, dim3(A), dim3(REFIT_THREADS), 0, stream, rf, ps_part.p, (int)cfg.population_offset);
+                    if (rc.comm) {
+                        const Rccl& r = Rccl::get();
+                        r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (RandomSearch local bests)");
+                    } else {
+                        REQUIRE(cfg.population_global <= N, BBMPC_E_STATE, "population sharding needs a communicator: call bbmpc_comm_init first");
+                        HIP_CHECK(hipMemcpyAsync(ps_all.p, ps_part.p, pw * 4, hipMemcpyDeviceToDevice, stream));
+                    }
+                }
+                HIP_CHECK(hipGetLastError());
+                hipLaunchKernelGGL(k_argmax_merge, dim3(A), dim3(64), 0, stream, rf, ps_all.p, G);
+                HIP_CHECK(hipGetLastError());
+                capture_trace(0);
+                break;
+            }
             launch_rollout(SRC_UNIFORM, false, ra);
-            hipLaunchKernelGGL(k_refit_argmax, dim3(A), dim3(REFIT_THREADS), 0, stream, rf);
+            hipLaunchKernelGGL(k_refit_argmax, dim3(A), dim3(REFIT_THREADS), 0, stream, rf, (float*)nullptr, 0);
             HIP_CHECK(hipGetLastError());
             capture_trace(0);
             break;

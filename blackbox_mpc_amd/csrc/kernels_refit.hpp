@@ -297,7 +297,9 @@ __global__ void k_shift_left(int A, int H, int U, const float* mean, float* prev
 }
 
 // RandomSearch refit  random_search.py:43-47: per-agent argmax (first maximum), take its first action.
-__global__ __launch_bounds__(REFIT_THREADS) void k_refit_argmax(RefitArgs p) {
+// `part` != null (population sharded over ranks): part[a] = (best value, GLOBAL particle index as bits,
+// its first action[U]) of this rank's particles; k_argmax_merge takes the first maximum by global index.
+__global__ __launch_bounds__(REFIT_THREADS) void k_refit_argmax(RefitArgs p, float* part, int pop_offset) {
     __shared__ float sv[REFIT_THREADS / 64];
     __shared__ int si[REFIT_THREADS / 64];
     const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -318,9 +320,32 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_refit_argmax(RefitArgs p) {
         bi = (lane < NW) ? si[lane] : 0x7fffffff;
         wave_argmax(bv, bi);
         if (bi == 0x7fffffff) bi = 0;
+        if (part) {
+            float* e = part + (size_t)a * (p.U + 2);
+            if (lane == 0) { e[0] = p.rewards[(size_t)a * p.Nst + bi]; e[1] = __int_as_float(bi + pop_offset); }
+            if (lane < p.U) e[2 + lane] = p.samples[(size_t)(a * p.HU + lane) * p.Nst + bi];
+            return;
+        }
         if (lane == 0 && p.elites) p.elites[a] = bi;
         if (lane < p.U) p.action[a * p.U + lane] = p.samples[(size_t)(a * p.HU + lane) * p.Nst + bi];
     }
+}
+
+// RandomSearch with the population sharded over ranks: all[r][a] = (value, global index, action[U]).  grid A, block 64
+__global__ void k_argmax_merge(RefitArgs p, const float* all, int G) {
+    const int a = blockIdx.x, lane = threadIdx.x;
+    const size_t pw = (size_t)p.A * (p.U + 2);
+    int br = 0, bi = 0x7fffffff;
+    float bv = -INFINITY;
+    for (int r = 0; r < G; ++r) {
+        const float* e = all + pw * r + (size_t)a * (p.U + 2);
+        const float v = e[0];
+        const int idx = __float_as_int(e[1]);
+        if (v > bv || (v == bv && idx < bi) || bi == 0x7fffffff) { bv = v; bi = idx; br = r; }
+    }
+    const float* src = all + pw * br + (size_t)a * (p.U + 2) + 2;
+    if (lane == 0 && p.elites) p.elites[a] = bi;
+    if (lane < p.U) p.action[a * p.U + lane] = src[lane];
 }
 
 // Tail of OptimizerBase.__call__  optimizer_base.py:82-94 for the analytic pendulum:

@@ -1,4 +1,4 @@
-"""f-4: population sharding for num_agents < n_gpus, PI2, CEM, SPSA and PSO.  PI2: the min / sum reductions of
+"""f-4: population sharding for num_agents < n_gpus, RandomSearch, PI2, CEM, SPSA and PSO.  PI2: the min / sum reductions of
 pi2.py:80-87 split across ranks: per iteration every rank rolls out ITS particles of the shared population, produces
 (min cost, sum of weights, weighted sums [H*U]) per agent, one collective hands every rank all partials and each merges
 them in rank order.  RNG is keyed by the GLOBAL particle index, so a sharded run draws exactly the unsharded run's
@@ -244,6 +244,36 @@ def test_sharded_pso_mlp_equals_unsharded(L, monkeypatch):
         np.testing.assert_allclose(a_s, a_f, rtol=0, atol=1e-4)
         np.testing.assert_allclose(n_s, n_f, rtol=2e-5, atol=2e-4)
         s = n_f
+
+
+@pytest.mark.parametrize("G,force", [(4, False), (1, True)])
+def test_sharded_random_search_is_the_unsharded_one_bit_for_bit(L, monkeypatch, G, force):
+    # RandomSearch (random_search.py:36-47): uniform draws keyed by the global particle, first maximum by GLOBAL index --
+    # through the loopback hook (G shards) and through a one-rank RCCL communicator (the sharded rank's real code path)
+    from blackbox_mpc_amd.engine import Engine
+    monkeypatch.setenv("BBMPC_FUSED", "0")
+    N, A, H = 512, 3, 15
+    mk = lambda n, **kw: Engine(L.OPT_RANDOM_SEARCH, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=A,
+                                planning_horizon=H, population_size=n, seed=23, **kw)
+    full = mk(N)
+    monkeypatch.setenv("BBMPC_POPSHARD_FORCE" if force else "BBMPC_POPSHARD_LOOPBACK", "1" if force else str(G))
+    shard = mk(N // G, population_global=N)
+    monkeypatch.delenv("BBMPC_POPSHARD_FORCE" if force else "BBMPC_POPSHARD_LOOPBACK")
+    if force:
+        shard.comm_init(Engine.comm_unique_id(), 1, 0)
+    full.set_trace(True)
+    shard.set_trace(True)
+    s = O.pendulum_start_states(A)
+    for t in range(3):
+        a_f, n_f, r_f = full.optimize(s, t)
+        a_s, n_s, r_s = shard.optimize(s, t)
+        np.testing.assert_array_equal(a_s, a_f)
+        np.testing.assert_array_equal(n_s, n_f)
+        np.testing.assert_array_equal(shard.get_trace(0, L.TRACE_ELITES), full.get_trace(0, L.TRACE_ELITES))   # global index of the winner
+        s = n_f
+    if force:
+        shard.synchronize()
+        shard.comm_destroy()
 
 
 def test_pso_exchange_through_a_one_rank_rccl_communicator(L, monkeypatch):
