@@ -148,10 +148,9 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         REQUIRE(c.population_global >= N && c.population_offset >= 0 && c.population_offset + N <= c.population_global, BBMPC_E_INVALID,
                 "population_offset / population_global: this handle's particles must lie inside the global population");
         if (c.population_global > N)
-            REQUIRE(c.optimizer != BBMPC_OPT_CMAES && c.optimizer != BBMPC_OPT_NONE, BBMPC_E_UNSUPPORTED,
-                    "population sharding is built for RandomSearch (argmax, random_search.py:43-47), PI2 (min / sum reductions, "
-                    "pi2.py:80-87), CEM (top-k merge, cem.py:97-112), SPSA (mean over the perturbation pairs, spsa.py:101-107) and PSO "
-                    "(argmax of the personal bests, pso.py:94); CMA-ES keeps a joint covariance per instance and does not shard");
+            REQUIRE(c.optimizer != BBMPC_OPT_NONE, BBMPC_E_UNSUPPORTED, "population sharding needs an optimizer (evaluate-only handles roll out what they are given)");
+            if (c.optimizer == BBMPC_OPT_CMAES)
+                REQUIRE(k <= N && k <= 1024, BBMPC_E_UNSUPPORTED, "sharded CMA-ES: num_elite must not exceed this rank's share of the population (nor 1024)");
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -195,7 +194,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.mlp_no_half_tail = flag("BBMPC_MLP_NO_HALF_TAIL");
         sw.dbg = flag("BBMPC_DBG");
         user_stepwise_only = flag("BBMPC_USER_STEPWISE");
-        if (c.optimizer != BBMPC_OPT_CMAES && c.optimizer != BBMPC_OPT_NONE) {
+        if (c.optimizer != BBMPC_OPT_NONE) {
             ps_loopback = ival("BBMPC_POPSHARD_LOOPBACK", 0);
             ps_force = flag("BBMPC_POPSHARD_FORCE");
         }
@@ -484,6 +483,7 @@ CmaArgs Engine::cma_args(uint32_t step, uint32_t iter) {
     q.xmean = c_xm.p; q.ymean = c_ym.p;
     q.key = key(step);
     q.iter = iter;
+    q.pop_offset = cfg.population_offset;
     return q;
 }
 
@@ -496,17 +496,51 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
     for (int it = 0; it < iters; ++it) {
         CmaArgs q = cma_args(step, (uint32_t)it);
         q.inj = inj_n ? inj_n + inj_stride * it : nullptr;
-        hipLaunchKernelGGL(k_cma_noise, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, q);
         hipLaunchKernelGGL(k_cma_bd, dim3((unsigned)((gnn + 255) / 256)), dim3(256), 0, stream, q);
-        if (n > 128 && (n & 3) == 0) hipLaunchKernelGGL(k_cma_gemm_y_mfma, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
-        else hipLaunchKernelGGL(k_cma_gemm_y, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
-        HIP_CHECK(hipGetLastError());
-        ra.cand = d_cand_a.p; ra.samples = d_cand_a.p; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
-        launch_rollout(SRC_BUF, true, ra);                          // clip + penalty (cma_es.py:147-157)
         const int kp = (k + 3) & ~3;
         const size_t lds = (size_t)(Nst + TOPK_HIST_WORDS + 2 * kp) * 4;
         want_lds((const void*)k_cma_select, lds);
-        hipLaunchKernelGGL(k_cma_select, dim3(G), dim3(REFIT_THREADS), lds, stream, q);
+        // sample -> roll out -> sorted top-k of this handle's particles (part != null: sharded population)
+        auto shard_pass = [&](float* part) {
+            hipLaunchKernelGGL(k_cma_noise, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, q);
+            if (n > 128 && (n & 3) == 0) hipLaunchKernelGGL(k_cma_gemm_y_mfma, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
+            else hipLaunchKernelGGL(k_cma_gemm_y, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
+            HIP_CHECK(hipGetLastError());
+            ra.cand = d_cand_a.p; ra.samples = d_cand_a.p; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
+            launch_rollout(SRC_BUF, true, ra);                          // clip + penalty (cma_es.py:147-157)
+            hipLaunchKernelGGL(k_cma_select, dim3(G), dim3(REFIT_THREADS), lds, stream, q, part);
+            HIP_CHECK(hipGetLastError());
+        };
+        if (pop_sharded()) {
+            // population sharded over ranks: every rank samples and rolls out ITS particles, the sorted local
+            // elites (reward, global index, candidate) are exchanged and merged (kernels_cma.hpp); the path / covariance
+            // update and the eigen-decomposition run replicated on every rank
+            const int R = ps_loopback > 1 ? ps_loopback : std::max(1, rc.comm ? rc.nranks : 1);
+            const size_t pw = (size_t)G * k * (n + 2);
+            if (!ps_part.p || ps_part.n < pw) ps_part.alloc(pw);
+            if (ps_all.n < pw * R) ps_all.alloc(pw * R);
+            if (ps_loopback > 1) {
+                for (int r = 0; r < R; ++r) {
+                    q.pop_offset = r * N;
+                    shard_pass(ps_all.p + pw * r);
+                }
+                q.pop_offset = cfg.population_offset;
+            } else {
+                shard_pass(ps_part.p);
+                if (rc.comm) {
+                    const Rccl& r = Rccl::get();
+                    r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (CMA-ES local elites)");
+                } else {
+                    REQUIRE(cfg.population_global <= N, BBMPC_E_STATE, "population sharding needs a communicator: call bbmpc_comm_init first");
+                    HIP_CHECK(hipMemcpyAsync(ps_all.p, ps_part.p, pw * 4, hipMemcpyDeviceToDevice, stream));
+                }
+            }
+            if (trace_on && !c_eidx_glob.p) c_eidx_glob.alloc((size_t)G * k);
+            hipLaunchKernelGGL(k_cma_merge, dim3(G), dim3(1024), 0, stream, q, ps_all.p, R, trace_on ? c_eidx_glob.p : (int*)nullptr);
+            HIP_CHECK(hipGetLastError());
+        } else {
+            shard_pass(nullptr);
+        }
         hipLaunchKernelGGL(k_cma_paths, dim3(G), dim3(n > 128 ? 1024 : REFIT_THREADS), 0, stream, q);
         hipLaunchKernelGGL(k_cma_cov, dim3((n + 15) / 16, (n + 15) / 16, G), dim3(16, 16), 0, stream, q);
         HIP_CHECK(hipGetLastError());
@@ -596,8 +630,8 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             HIP_CHECK(hipMemcpyAsync(t_rewards.p + nr * it, d_rewards.p, nr * 4, hipMemcpyDeviceToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(t_mean.p + nm * it, c_m.p, nm * 4, hipMemcpyDeviceToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(t_samples.p + ns * it, d_cand_a.p, ns * 4, hipMemcpyDeviceToDevice, stream));
-            HIP_CHECK(hipMemcpyAsync(t_elites.p + (size_t)A * std::max(k, 1) * it, c_eidx.p, (size_t)G * k * 4,
-                                     hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(t_elites.p + (size_t)A * std::max(k, 1) * it, pop_sharded() ? c_eidx_glob.p : c_eidx.p, (size_t)G * k * 4,
+                                     hipMemcpyDeviceToDevice, stream));      // (sharded: the GLOBAL particle indices of the elites)
             // the eigen-system this iteration produced (B, D) and the covariance it factorises: parity tests feed the
             // oracle the engine's own (D^2, B) every iteration and check the factorisation's invariants
             if (!t_cma_B.p) {
@@ -1871,7 +1905,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
 bool Engine::use_fused_cma() const {
     if (cfg.optimizer != BBMPC_OPT_CMAES || cfg.dynamics != BBMPC_DYN_PENDULUM || cfg.reward != BBMPC_REW_PENDULUM) return false;
     // opt-in: measured no faster than the per-iteration kernels (both are bound by the Jacobi sweeps)
-    if (!sw.cma_fused || fused_mode == 0 || trace_on) return false;      // the parity trace is captured between the per-iteration kernels
+    if (!sw.cma_fused || fused_mode == 0 || trace_on || pop_sharded()) return false;      // the parity trace is captured between the per-iteration kernels
     if (sw.cma_svd_v1 || sw.cma_svd_rounds || sw.cma_svd_general) return false;
     return cma_G == A && cma_n <= 64 && N <= 1024 && k <= 1024;
 }

@@ -240,6 +240,7 @@ struct Engine {
     void mlp_forward_rows(const float* d_x, int batch, float* d_out);
     // population sharding (PI2): per-iteration partials of this rank and the gathered partials of all ranks
     DevBuf<float> ps_part, ps_all;
+    DevBuf<int> c_eidx_glob;                  // sharded CMA-ES: global particle indices of the merged elites (parity trace)
     int ps_loopback = 0;     // BBMPC_POPSHARD_LOOPBACK=G: one handle plays all G shards in turn (single-GPU test / measurement hook)
     bool ps_force = false;   // BBMPC_POPSHARD_FORCE: take the sharded code path (incl. the collective) even with one shard
     bool pop_sharded() const { return cfg.population_global > N || ps_loopback > 1 || ps_force; }

@@ -45,6 +45,7 @@ struct CmaArgs {
     RngKey key;
     uint32_t iter;
     const float* inj;        // injected z (internal layout) or null
+    int pop_offset;          // global index of local particle 0 (population sharding): draws keyed by the GLOBAL particle
 };
 
 // z ~ N(0,1): element j of a 4-block uses Box-Muller on word pairs (w0,w1)->(z0,z1), (w2,w3)->(z2,z3)
@@ -62,7 +63,7 @@ __global__ void k_cma_noise(CmaArgs p) {
     const int j = blockIdx.y, a = blockIdx.z;
     if (n >= p.N) return;
     const size_t i = ((size_t)a * p.HU + j) * p.Nst + n;
-    p.z[i] = p.inj ? p.inj[i] : elem_normal(p.key, p.iter, n, p.agent_offset + a, j);
+    p.z[i] = p.inj ? p.inj[i] : elem_normal(p.key, p.iter, n + p.pop_offset, p.agent_offset + a, j);
 }
 
 // BD = B @ D (D diagonal)   cma_es.py:140
@@ -157,7 +158,10 @@ __global__ __launch_bounds__(256) void k_cma_gemm_y_mfma(CmaArgs p) {
 }
 
 // per group: (sum of) rewards -> sorted top-k.   LDS: rsum[Nst] | hist | ekeys[kp]
-__device__ __forceinline__ void cma_select_body(const CmaArgs& p, int g, float* smem) {
+// `part` != null (population sharded over ranks): this rank's particles only -- the local elites go to
+// part[g][e] = (summed reward, GLOBAL particle index as bits, candidate x[n]) in sorted order; k_cma_merge merges the ranks'
+// lists and puts the swarm's k elites into columns 0..k-1 of the candidate matrix, where the path update finds them.
+__device__ __forceinline__ void cma_select_body(const CmaArgs& p, int g, float* smem, float* part = nullptr) {
     const int tid = threadIdx.x;
     float* rs = smem;
     uint32_t* hist = (uint32_t*)(rs + p.Nst);
@@ -171,11 +175,65 @@ __device__ __forceinline__ void cma_select_body(const CmaArgs& p, int g, float* 
     }
     __syncthreads();
     block_topk_sorted(rs, p.N, p.k, eidx_s, hist, ekeys, tid, REFIT_THREADS);   // argsort DESCENDING, first k
+    if (part) {
+        const int n = p.n, rowlen = n + 2;
+        float* out = part + (size_t)g * p.k * rowlen;
+        for (int e = tid; e < p.k; e += REFIT_THREADS) {
+            out[(size_t)e * rowlen] = rs[eidx_s[e]];
+            out[(size_t)e * rowlen + 1] = __int_as_float(eidx_s[e] + p.pop_offset);
+        }
+        const float* X = p.cand + (size_t)g * n * p.Nst;
+        for (int t = tid; t < p.k * n; t += REFIT_THREADS) {
+            const int e = t / n, c = t - e * n;
+            out[(size_t)e * rowlen + 2 + c] = X[(size_t)c * p.Nst + eidx_s[e]];
+        }
+        return;
+    }
     for (int e = tid; e < p.k; e += REFIT_THREADS) p.eidx[g * p.k + e] = eidx_s[e];
 }
-__global__ __launch_bounds__(REFIT_THREADS) void k_cma_select(CmaArgs p) {
+__global__ __launch_bounds__(REFIT_THREADS) void k_cma_select(CmaArgs p, float* part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    cma_select_body(p, blockIdx.x, smem);
+    cma_select_body(p, blockIdx.x, smem, part);
+}
+
+// CMA-ES with the population sharded over ranks: all[r][g][e] = (reward, global index, x[n]), every rank's list sorted
+// (larger reward first, ties -> lower index).  The rank of an entry in the merged order is its place in its own list plus,
+// for every other list, the number of entries that precede it there (binary search); the first k take columns 0..k-1 of
+// the candidate matrix (the local candidates are not needed any more) and eidx = 0..k-1, so the path / covariance update
+// runs unchanged; gidx (optional) receives the global particle indices for the parity trace.  grid G, block 1024, k <= 1024
+__global__ __launch_bounds__(1024) void k_cma_merge(CmaArgs p, const float* all, int R, int* gidx) {
+    __shared__ int s_src[1024];
+    const int g = blockIdx.x, tid = threadIdx.x, n = p.n, k = p.k, rowlen = n + 2;
+    const size_t pw = (size_t)p.G * k * rowlen;
+    auto row = [&](int r, int e) { return all + pw * r + ((size_t)g * k + e) * rowlen; };
+    for (int t = tid; t < R * k; t += blockDim.x) {
+        const int r = t / k, e = t - r * k;
+        const float v = row(r, e)[0];
+        const int idx = __float_as_int(row(r, e)[1]);
+        int rank = e;
+        for (int o = 0; o < R; ++o) {
+            if (o == r) continue;
+            int lo = 0, hi = k;                                   // entries of list o that precede (v, idx)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const float vo = row(o, mid)[0];
+                const int io = __float_as_int(row(o, mid)[1]);
+                if (vo > v || (vo == v && io < idx)) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            s_src[rank] = t;
+            p.eidx[g * k + rank] = rank;
+            if (gidx) gidx[g * k + rank] = idx;
+        }
+    }
+    __syncthreads();
+    float* X = p.cand + (size_t)g * n * p.Nst;
+    for (int t = tid; t < k * n; t += blockDim.x) {
+        const int w = t / n, c = t - w * n, src = s_src[w];
+        X[(size_t)c * p.Nst + w] = row(src / k, src - (src / k) * k)[2 + c];
+    }
 }
 
 // per group: elite deviations, weighted mean step, evolution paths, step size, new mean

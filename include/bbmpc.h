@@ -128,7 +128,7 @@ typedef struct bbmpc_config {
     float cma_alpha_cov, cma_h_sigma;                       /* cma_es.py:10 */
     const float* action_low;    /* [U] env_action_space.low  */
     const float* action_high;   /* [U] env_action_space.high */
-    /* population sharding for num_agents < n_gpus (every optimizer but CMA-ES): this handle rolls out particles
+    /* population sharding for num_agents < n_gpus (all six optimizers): this handle rolls out particles
      * [population_offset, population_offset + population_size) of a population of population_global particles that
      * every rank shares for the SAME agents; per iteration the ranks exchange (min cost, sum of weights, weighted
      * sums [H*U]) per agent (PI2, pi2.py:80-87) or their local top-k with the sample rows (CEM, cem.py:97-112) over the

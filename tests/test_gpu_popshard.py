@@ -1,4 +1,4 @@
-"""f-4: population sharding for num_agents < n_gpus, RandomSearch, PI2, CEM, SPSA and PSO.  PI2: the min / sum reductions of
+"""f-4: population sharding for num_agents < n_gpus, every optimizer: RandomSearch, PI2, CEM, SPSA, PSO, CMA-ES.  PI2: the min / sum reductions of
 pi2.py:80-87 split across ranks: per iteration every rank rolls out ITS particles of the shared population, produces
 (min cost, sum of weights, weighted sums [H*U]) per agent, one collective hands every rank all partials and each merges
 them in rank order.  RNG is keyed by the GLOBAL particle index, so a sharded run draws exactly the unsharded run's
@@ -276,6 +276,67 @@ def test_sharded_random_search_is_the_unsharded_one_bit_for_bit(L, monkeypatch, 
         shard.comm_destroy()
 
 
+@pytest.mark.parametrize("per_agent", [False, True])
+@pytest.mark.parametrize("G,force", [(4, False), (1, True)])
+def test_sharded_cmaes_is_the_unsharded_one_bit_for_bit(L, monkeypatch, G, force, per_agent):
+    # CMA-ES (cma_es.py:129-213): every rank samples (draws keyed by the global particle) and rolls out ITS candidates, the
+    # sorted local elites (summed reward, global index, candidate) are exchanged and merged into the swarm's k elites; mean,
+    # paths, covariance and eigen-decomposition run replicated.  The merged elite list IS the unsharded one (same values, same
+    # order), so everything downstream is bit-identical: coupled (the reference: one joint covariance over the agents) and
+    # per-agent forms, through the loopback hook and through a one-rank RCCL communicator.
+    from blackbox_mpc_amd.engine import Engine
+    N, A, H, iters, k = 256, 2, 6, 3, 24
+    quirks = L.CMAES_PER_AGENT if per_agent else 0
+    mk = lambda n, **kw: Engine(L.OPT_CMAES, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=A,
+                                planning_horizon=H, population_size=n, max_iterations=iters, num_elite=k, seed=31, quirks=quirks, **kw)
+    full = mk(N)
+    monkeypatch.setenv("BBMPC_POPSHARD_FORCE" if force else "BBMPC_POPSHARD_LOOPBACK", "1" if force else str(G))
+    shard = mk(N // G, population_global=N)
+    monkeypatch.delenv("BBMPC_POPSHARD_FORCE" if force else "BBMPC_POPSHARD_LOOPBACK")
+    if force:
+        shard.comm_init(Engine.comm_unique_id(), 1, 0)
+    full.set_trace(True)
+    shard.set_trace(True)
+    s = O.pendulum_start_states(A)
+    for t in range(3):
+        a_f, n_f, r_f = full.optimize(s, t)
+        a_s, n_s, r_s = shard.optimize(s, t)
+        np.testing.assert_array_equal(a_s, a_f)
+        np.testing.assert_array_equal(n_s, n_f)
+        for it in range(iters):
+            np.testing.assert_array_equal(shard.get_trace(it, L.TRACE_MEAN), full.get_trace(it, L.TRACE_MEAN))
+            np.testing.assert_array_equal(shard.get_trace(it, L.TRACE_ELITES), full.get_trace(it, L.TRACE_ELITES))   # global indices, sorted
+            np.testing.assert_array_equal(shard.get_trace(it, L.TRACE_CMA_C), full.get_trace(it, L.TRACE_CMA_C))
+        s = n_f
+    if force:
+        shard.synchronize()
+        shard.comm_destroy()
+
+
+def test_sharded_cmaes_mlp_equals_unsharded(L, monkeypatch):
+    from blackbox_mpc_amd.engine import Engine
+    S, U, N, H, iters, k, G = 20, 6, 384, 5, 3, 32, 3
+    ws, bs = O.make_mlp_params([26, 200, 200, 20], seed=42)
+    stats = [np.zeros(S, F), np.ones(S, F), np.zeros(U, F), np.ones(U, F), np.zeros(S, F), np.full(S, 0.1, F)]
+
+    def mk(n, **kw):
+        e = Engine(L.OPT_CMAES, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=2, planning_horizon=H,
+                   population_size=n, max_iterations=iters, num_elite=k, seed=12, quirks=L.CMAES_PER_AGENT, **kw)
+        e.set_mlp(ws, bs, [1, 1, 0], stats)
+        return e
+    full = mk(N)
+    monkeypatch.setenv("BBMPC_POPSHARD_LOOPBACK", str(G))
+    shard = mk(N // G, population_global=N)
+    monkeypatch.delenv("BBMPC_POPSHARD_LOOPBACK")
+    s = O.cheetah_start_states(2, S)
+    a_f, n_f, _ = full.optimize(s, 0)
+    a_s, n_s, _ = shard.optimize(s, 0)
+    # a shard and the whole population are rolled out by different MFMA tilings: rewards differ in the last bits, so near-ties
+    # at the k-th place may swap elites of (almost) equal weight -- the refitted mean is compared within the MLP tolerance
+    np.testing.assert_allclose(a_s, a_f, rtol=0, atol=2e-3)
+    np.testing.assert_allclose(n_s, n_f, rtol=1e-3, atol=2e-3)
+
+
 def test_pso_exchange_through_a_one_rank_rccl_communicator(L, monkeypatch):
     from blackbox_mpc_amd.engine import Engine
     monkeypatch.setenv("BBMPC_FUSED", "0")
@@ -324,8 +385,11 @@ def test_spsa_exchange_through_a_one_rank_rccl_communicator(L, monkeypatch):
 def test_population_sharding_argument_checks(L):
     from blackbox_mpc_amd.engine import Engine
     kw = dict(dim_s=3, num_agents=1, planning_horizon=8, max_iterations=2)
-    with pytest.raises(L.BBMPCError) as ei:              # CMA-ES carries a joint covariance: not built, said so
-        Engine(L.OPT_CMAES, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], population_size=64, population_global=128, num_elite=8, **kw)
+    with pytest.raises(L.BBMPCError) as ei:              # sharded CMA-ES: the elites must fit this rank's share
+        Engine(L.OPT_CMAES, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], population_size=16, population_global=128, num_elite=32, **kw)
+    assert ei.value.code == L.E_UNSUPPORTED
+    with pytest.raises(L.BBMPCError) as ei:              # an evaluate-only handle has no population of its own to shard
+        Engine(L.OPT_NONE, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], population_size=64, population_global=128, **kw)
     assert ei.value.code == L.E_UNSUPPORTED
     with pytest.raises(L.BBMPCError):                    # the shard must lie inside the population
         Engine(L.OPT_PI2, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], population_size=64, population_offset=100,
