@@ -20,7 +20,7 @@ def agent_shard(num_agents_global, world_size, rank):
 
 
 def population_shard(population_global, world_size, rank):
-    """Population sharding for num_agents < n_gpus: the contiguous block of particles
+    """Population sharding for num_agents < n_gpus (any optimizer): the contiguous block of particles
     (offset, count) rank `rank` rolls out.  Every shard must have the same size (the engine all-gathers fixed-size
     partials and keys its RNG by global particle index), so the population must divide evenly."""
     if population_global % world_size:
