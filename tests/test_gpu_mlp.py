@@ -156,7 +156,13 @@ def test_evaluator_properties_at_config5_size(L, monkeypatch, q4):
     np.testing.assert_allclose(full[sub], ev(states, seq[sub]), rtol=1e-3, atol=1e-3 * H)
 
 
-def test_nan_state_gives_minus_1e6(L):
+@pytest.mark.parametrize("tiling", ["auto", "pair1", "pair2"])
+def test_nan_state_gives_minus_1e6(L, monkeypatch, tiling):
+    # deterministic.py:75-77 on every MFMA tiling of the rollout (quads by default at this size, the pipelined tile kernel
+    # in its one-tile and two-tile forms when forced)
+    if tiling != "auto":
+        monkeypatch.setenv("BBMPC_MLP_Q4", "0")
+        monkeypatch.setenv("BBMPC_MLP_PAIR", "1" if tiling == "pair2" else "0")
     dims, acts, S, U, reward = CHEETAH
     eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, True, A=2, H=5)
     states = O.cheetah_start_states(2, S)
