@@ -1777,18 +1777,19 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                     if (ps_all.n < pw * G) ps_all.alloc(pw * G);
                     const size_t tl = (size_t)fixed * 4;
                     want_lds((const void*)k_cem_local_topk, tl);
+                    const int psg = sw.refit_wgs > 0 ? sw.refit_wgs : std::max(1, std::min(8, HU / 16));   // workgroups per agent (kernels_tail.hpp)
                     RefitArgs rfs = rf;
                     if (!trace_on) rfs.elites = nullptr;
                     if (ps_loopback > 1) {
                         for (int r = 0; r < G; ++r) {
                             ra.pop_offset = r * N;
                             launch_rollout(SRC_TRUNC, false, ra);
-                            hipLaunchKernelGGL(k_cem_local_topk, dim3(A), dim3(1024), tl, stream, rf, r * N, ps_all.p + pw * r);
+                            hipLaunchKernelGGL(k_cem_local_topk, dim3(psg, A), dim3(1024), tl, stream, rf, r * N, ps_all.p + pw * r);
                         }
                         ra.pop_offset = cfg.population_offset;
                     } else {
                         launch_rollout(SRC_TRUNC, false, ra);
-                        hipLaunchKernelGGL(k_cem_local_topk, dim3(A), dim3(1024), tl, stream, rf, (int)cfg.population_offset, ps_part.p);
+                        hipLaunchKernelGGL(k_cem_local_topk, dim3(psg, A), dim3(1024), tl, stream, rf, (int)cfg.population_offset, ps_part.p);
                         if (rc.comm) {
                             const Rccl& r = Rccl::get();
                             r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (CEM local elites)");
@@ -1800,7 +1801,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                     HIP_CHECK(hipGetLastError());
                     const size_t ml = ((size_t)2 * G * k + k) * 4;
                     want_lds((const void*)k_cem_merge, ml);
-                    hipLaunchKernelGGL(k_cem_merge, dim3(A), dim3(256), ml, stream, rfs, ps_all.p, G);
+                    hipLaunchKernelGGL(k_cem_merge, dim3(psg, A), dim3(256), ml, stream, rfs, ps_all.p, G);
                     HIP_CHECK(hipGetLastError());
                     capture_trace(it);
                     continue;

@@ -358,10 +358,13 @@ __global__ void k_refit_pi2_merge(RefitArgs p, const float* gathered, int G) {
 // rows.  The global elite SET is exactly the unsharded one (a global winner is always a local winner of its rank);
 // only the order of the fp32 sums differs.  cand layout per agent: [k][HU + 2] = (reward | global index as float bits |
 // row); slots a short shard cannot fill carry reward -inf.
-// k_cem_local_topk: grid A, block 1024.  LDS: rewards[Nst] | eidx[kpad] | hist | ekeys[2*kpad]
+// Both kernels run on (Gw, A) workgroups: every workgroup of an agent repeats the (cheap) selection / ranking and takes
+// its share of the H*U columns -- the scattered gather of k x H*U sample values, and the strided reads of the merge's
+// statistics, are what these kernels spend their time on (one workgroup per agent: +34 us per iteration at N = 1000).
+// k_cem_local_topk: grid (Gw, A), block 1024.  LDS: rewards[Nst] | eidx[kpad] | hist | ekeys[2*kpad]
 __global__ __launch_bounds__(1024) void k_cem_local_topk(RefitArgs p, int pop_offset, float* cand) {
     extern __shared__ float smem[];
-    const int a = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int a = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
     float* r = smem;
     int* eidx = (int*)(smem + p.Nst);
     const int kpad = (p.k + 3) & ~3;
@@ -372,22 +375,24 @@ __global__ __launch_bounds__(1024) void k_cem_local_topk(RefitArgs p, int pop_of
     const int kk = min(p.k, p.N);
     block_topk_sorted(r, p.N, kk, eidx, hist, ekeys, tid, nthr);
     const int W = p.HU + 2;
+    const int cw = (W + (int)gridDim.x - 1) / (int)gridDim.x, c_lo = blockIdx.x * cw, c_n = max(0, min(W, c_lo + cw) - c_lo);
     float* out = cand + (size_t)a * p.k * W;
-    for (int i = tid; i < p.k * W; i += nthr) {
-        const int e = i / W, c = i - e * W;
+    for (int i = tid; i < p.k * c_n; i += nthr) {
+        const int e = i / c_n, c = c_lo + (i - e * c_n);
         float v;
         if (e >= kk) v = c == 0 ? -INFINITY : 0.0f;
         else if (c == 0) v = r[eidx[e]];
         else if (c == 1) v = __int_as_float(pop_offset + eidx[e]);
         else v = p.samples[(size_t)(a * p.HU + (c - 2)) * p.Nst + eidx[e]];
-        out[i] = v;
+        out[(size_t)e * W + c] = v;
     }
 }
 
-// gathered: [G][A][k][HU+2].  grid A, block 256.  LDS: key rewards[G*k] | global idx[G*k] | chosen slot[k]
+// gathered: [G][A][k][HU+2].  grid (Gw, A), block 256.  LDS: key rewards[G*k] | global idx[G*k] | chosen slot[k]
+// Statistics of a row on a 16-lane group (elites over the lanes, DPP reduction), as in k_refit_cem_v2.
 __global__ __launch_bounds__(256) void k_cem_merge(RefitArgs p, const float* gathered, int G) {
     extern __shared__ float smem[];
-    const int a = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int a = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
     const int W = p.HU + 2, M = G * p.k;
     float* cr = smem;
     int* ci = (int*)(smem + M);
@@ -412,26 +417,35 @@ __global__ __launch_bounds__(256) void k_cem_merge(RefitArgs p, const float* gat
     }
     __syncthreads();
     const float kf = (float)p.k, one_m = 1.0f - p.alpha;
-    if (p.elites)
+    if (p.elites && blockIdx.x == 0)
         for (int e = tid; e < p.k; e += nthr) p.elites[a * p.k + e] = ci[chosen[e]];        // GLOBAL indices, best first
-    for (int j = tid; j < p.HU; j += nthr) {
+    const int rows_wg = (p.HU + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int jlo = blockIdx.x * rows_wg, jhi = min(p.HU, jlo + rows_wg);
+    const int sub = tid & 15, grp = tid >> 4, ngrp = nthr >> 4;
+    for (int j0 = jlo; j0 < jhi; j0 += ngrp) {
+        const int j = j0 + grp;
+        const bool live = j < jhi;
         float sum = 0.0f;
-        for (int e = 0; e < p.k; ++e) sum = sum + slot_ptr(chosen[e])[2 + j];
+        for (int e = sub; e < p.k; e += 16) sum = sum + (live ? slot_ptr(chosen[e])[2 + j] : 0.0f);
+        sum = row16_sum(sum);
         const float em = sum / kf;                                           // cem.py:112
         float vs = 0.0f;
-        for (int e = 0; e < p.k; ++e) {
-            const float d = slot_ptr(chosen[e])[2 + j] - em;
+        for (int e = sub; e < p.k; e += 16) {
+            const float d = (live ? slot_ptr(chosen[e])[2 + j] : em) - em;
             vs = vs + d * d;
         }
-        const float ev = vs / kf;                                            // :113-119 (biased)
-        const int aj = a * p.HU + j;
-        const float m = p.alpha * p.mean[aj] + one_m * em;                   // :121-122
-        const float v = p.alpha * p.var[aj] + one_m * ev;                    // :123-125
-        p.mean[aj] = m;
-        p.var[aj] = v;
-        const int u = j % p.U;
-        p.sigma[aj] = cem_sigma(m, v, p.lo[u], p.hi[u]);
-        if (j < p.U) p.action[a * p.U + j] = m;                              // mean[:, 0]  cem.py:135
+        vs = row16_sum(vs);
+        if (live && sub == 0) {
+            const float ev = vs / kf;                                        // :113-119 (biased)
+            const int aj = a * p.HU + j;
+            const float m = p.alpha * p.mean[aj] + one_m * em;               // :121-122
+            const float v = p.alpha * p.var[aj] + one_m * ev;                // :123-125
+            p.mean[aj] = m;
+            p.var[aj] = v;
+            const int u = j % p.U;
+            p.sigma[aj] = cem_sigma(m, v, p.lo[u], p.hi[u]);
+            if (j < p.U) p.action[a * p.U + j] = m;                          // mean[:, 0]  cem.py:135
+        }
     }
 }
 

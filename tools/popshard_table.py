@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""f-4 measured: does sharding ONE agent's population over G GPUs beat one GPU?  (SURVEY.md 8 f-4, PI2, MLP path)
+"""f-4 measured: does sharding ONE agent's population over G GPUs beat one GPU?  (SURVEY.md 8 f-4, MLP path)
+
+usage: popshard_table.py [PI2|CEM|SPSA|PSO|CMAES|RS ...]   (default: PI2)
 
 Run on a GPU box.  For each total population N and shard count G it times one rank's share of a control step --
 N/G particles, 5 PI2 iterations, each with the partial refit, the exchange and the merge -- on one MI355X:
@@ -20,13 +22,32 @@ sys.path.insert(0, ROOT)
 F = np.float32
 
 
+OPT = "PI2"
+
+
+def _opt_kwargs(L):
+    code = {"PI2": L.OPT_PI2, "CEM": L.OPT_CEM, "SPSA": L.OPT_SPSA, "PSO": L.OPT_PSO, "CMAES": L.OPT_CMAES,
+            "RS": L.OPT_RANDOM_SEARCH}[OPT]
+    kw = dict(max_iterations=5, seed=0)
+    if OPT == "PI2":
+        kw["lamda"] = 1.0
+    if OPT in ("CEM", "CMAES"):
+        kw["num_elite"] = 50
+    if OPT == "CMAES":
+        kw["quirks"] = L.CMAES_PER_AGENT
+    if OPT == "RS":
+        kw["max_iterations"] = 1
+    return code, kw
+
+
 def engine(L, N, Ntot, rccl):
     from blackbox_mpc_amd.engine import Engine
     from blackbox_mpc_amd.utils import synthetic as SY
     S, U = 20, 6
     os.environ["BBMPC_POPSHARD_FORCE"] = "1"
-    eng = Engine(L.OPT_PI2, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=1, planning_horizon=30,
-                 population_size=N, max_iterations=5, lamda=1.0, seed=0, population_global=N)
+    code, kw = _opt_kwargs(L)
+    eng = Engine(code, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=1, planning_horizon=30,
+                 population_size=N, population_global=N, **kw)
     del os.environ["BBMPC_POPSHARD_FORCE"]
     eng.set_mlp(*SY.make_mlp_params(), [1, 1, 0], SY.cheetah_stats(S, U))
     if rccl:
@@ -38,13 +59,14 @@ def plain(L, N):
     from blackbox_mpc_amd.engine import Engine
     from blackbox_mpc_amd.utils import synthetic as SY
     S, U = 20, 6
-    eng = Engine(L.OPT_PI2, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=1, planning_horizon=30,
-                 population_size=N, max_iterations=5, lamda=1.0, seed=0)
+    code, kw = _opt_kwargs(L)
+    eng = Engine(code, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=1, planning_horizon=30,
+                 population_size=N, **kw)
     eng.set_mlp(*SY.make_mlp_params(), [1, 1, 0], SY.cheetah_stats(S, U))
     return eng
 
 
-def rate(eng, steps=200):
+def rate(eng, steps=60):
     import torch
     from blackbox_mpc_amd.utils import synthetic as SY
     dev = torch.device("cuda", 0)
@@ -64,14 +86,21 @@ def rate(eng, steps=200):
 
 
 def main():
+    global OPT
     from blackbox_mpc_amd import _build
     _build.build()
     from blackbox_mpc_amd import _lib as L
-    iters = 5
+    for OPT in (sys.argv[1:] or ["PI2"]):
+        table(L)
+
+
+def table(L):
+    iters = 1 if OPT == "RS" else 5
+    print("\n### %s (HalfCheetah MLP 26-200-200-20, H = 30, %d iteration(s), one agent)\n" % (OPT, iters))
     print("| N total | G | particles/rank | one GPU, unsharded (us/step) | shard local (us) | shard + 1-rank ncclAllGather (us) | "
           "collective floor per iteration (us) | break-even link latency per iteration (us) |")
     print("|---|---|---|---|---|---|---|---|")
-    for Ntot in (1000, 2000, 4000, 8000):
+    for Ntot in (1000, 4000, 8000):
         base = rate(plain(L, Ntot))
         for G in (1, 2, 4, 8):
             n = Ntot // G
