@@ -1972,7 +1972,8 @@ void Engine::optimize_spsa(RolloutArgs& ra, uint32_t step) {
             launch_rollout(SRC_BUF, true, ra);
             ra.cand = d_cand_b.p; ra.samples = d_cand_b.p; ra.rewards = d_rewards2.p;
             launch_rollout(SRC_BUF, true, ra);
-            hipLaunchKernelGGL(k_refit_spsa, dim3(A), dim3(REFIT_THREADS), (size_t)Nst * 4, stream, oa, d_rewards.p, d_rewards2.p,
+            const int rgr = std::max(1, std::min(16, HU / (REFIT_THREADS / 64)));        // workgroups per agent: >= one row per wave
+            hipLaunchKernelGGL(k_refit_spsa, dim3(rgr, A), dim3(REFIT_THREADS), (size_t)Nst * 4, stream, oa, d_rewards.p, d_rewards2.p,
                                d_samples.p, ak, ck, d_mean.p, d_action.p, part);
             HIP_CHECK(hipGetLastError());
         };

@@ -47,19 +47,20 @@ __global__ void k_spsa_candidates(OptArgs p, const float* solution /*[A][HU]*/, 
 }
 
 // ghat[j] = mean_n (r+ - r-)[n] / (2 c_k delta[j][n]);  solution = clip(solution + a_k ghat)   (spsa.py:101-107)
-// one workgroup per agent, one wave per j.
+// grid (Gr, A): workgroup x takes the rows j = x * waves + wave, x * waves + wave + Gr * waves, ... (one wave per row; a single
+// workgroup per agent walked all H*U rows: 180 k divisions and 720 KB of delta through one CU at the north-star shape).
 // `part` != null (population sharded over ranks): this rank's particles only -- the row sums go to part[a][j] and the
 // update is k_spsa_merge's.
 __global__ __launch_bounds__(REFIT_THREADS) void k_refit_spsa(OptArgs p, const float* rew_plus, const float* rew_minus,
                                                               const float* delta, float ak, float ck, float* solution,
                                                               float* action, float* part) {
     extern __shared__ float diff[];
-    const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int a = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int NW = REFIT_THREADS / 64;
     for (int n = tid; n < p.N; n += REFIT_THREADS) diff[n] = rew_plus[(size_t)a * p.Nst + n] - rew_minus[(size_t)a * p.Nst + n];
     __syncthreads();
     const float two_ck = 2.0f * ck;
-    for (int j = wv; j < p.HU; j += NW) {
+    for (int j = blockIdx.x * NW + wv; j < p.HU; j += NW * gridDim.x) {
         const float* drow = delta + ((size_t)a * p.HU + j) * p.Nst;
         float acc = 0.0f;
         for (int n = lane; n < p.N; n += 64) acc += diff[n] / (two_ck * drow[n]);
