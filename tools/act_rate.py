@@ -1,5 +1,7 @@
-import time, numpy as np, sys
-sys.path.insert(0, "/root/repo")
+"""Wall time of one control step at config 2 through the three host layers (run on a GPU box): MPCPolicy.act, Engine.optimize
+(the ctypes wrapper) and the raw C-ABI call."""
+import os, time, numpy as np, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from blackbox_mpc_amd import Box
 from blackbox_mpc_amd.policies.mpc_policy import MPCPolicy
 from blackbox_mpc_amd.utils.pendulum import PendulumTrueModel, pendulum_reward_function

@@ -1,3 +1,5 @@
+"""Device-resident PI2 control-step time of the learned-model rollout on the 16-particle-tile kernels against the 4-particle
+quad kernels over the population size (run on a GPU box): where the engine's size heuristic should switch."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools"))
