@@ -126,7 +126,21 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
     if (c.optimizer != BBMPC_OPT_NONE) {
         REQUIRE(N >= 1, BBMPC_E_INVALID, "population_size must be >= 1");
         REQUIRE(iters >= 0, BBMPC_E_INVALID, "max_iterations must be >= 0");
-        REQUIRE(N <= 32768, BBMPC_E_UNSUPPORTED, "population_size > 32768: the refit kernels keep an agent's rewards in one CU's LDS");
+        if (N > 32768) {
+            // The refit kernels keep an agent's rewards in one CU's LDS (32768 floats).  A larger population is played as G
+            // equal shards of the population-sharding machinery on this one GPU: shard r = particles
+            // [r N/G, (r+1) N/G), draws keyed by the global particle, one merge per iteration -- the loopback hook, switched on
+            // by the size.  The parity hooks (trace, injected noise, per-particle state) stay per shard and are refused.
+            REQUIRE(c.population_global == 0 && c.population_offset == 0, BBMPC_E_UNSUPPORTED,
+                    "population_size > 32768 per rank: give every rank at most 32768 particles of the sharded population");
+            int g = (N + 32767) / 32768;
+            while (g <= 64 && N % g != 0) ++g;
+            REQUIRE(g <= 64, BBMPC_E_UNSUPPORTED, "population_size > 32768 must divide into at most 64 equal shards of at most 32768 particles");
+            if (c.optimizer == BBMPC_OPT_CMAES) REQUIRE(k <= N / g, BBMPC_E_UNSUPPORTED, "num_elite must not exceed a shard of the population");
+            auto_split = g;
+            cfg.population_global = N;
+            N /= g;
+        }
     } else {
         N = 0;
     }
@@ -195,7 +209,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.dbg = flag("BBMPC_DBG");
         user_stepwise_only = flag("BBMPC_USER_STEPWISE");
         if (c.optimizer != BBMPC_OPT_NONE) {
-            ps_loopback = ival("BBMPC_POPSHARD_LOOPBACK", 0);
+            ps_loopback = auto_split > 1 ? auto_split : ival("BBMPC_POPSHARD_LOOPBACK", 0);
             ps_force = flag("BBMPC_POPSHARD_FORCE");
         }
     }
@@ -2234,6 +2248,7 @@ void Engine::reward_dev(const float* d_cur, const float* d_next, const float* d_
 // parity hooks
 // ------------------------------------------------------------------------------------------------
 void Engine::inject(int kind, const float* data, int64_t count) {
+    REQUIRE(auto_split <= 1 || !data, BBMPC_E_UNSUPPORTED, "injected noise is per shard: not available for a population > 32768 (played as shards)");
     if (!data) {
         inj.erase(kind);
         return;
@@ -2306,7 +2321,7 @@ __global__ void k_dump_pso_scalars(OptArgs p, float* out) {
 }
 
 void Engine::dump_noise(int kind, int control_step, int iteration, float* out, int64_t count) {
-    int n = N, a = A, hu = HU;
+    int n = auto_split > 1 ? N * auto_split : N, a = A, hu = HU;       // (draws are keyed by the global particle)
     RngKey kk = key((uint32_t)control_step);
     if (kind == BBMPC_NOISE_PSO_SCALARS) {
         REQUIRE(count == 2, BBMPC_E_INVALID, "dump_noise: PSO scalars are [2] per (control step, iteration)");
@@ -2981,6 +2996,8 @@ int bbmpc_dump_noise(bbmpc_handle h, int32_t kind, int32_t control_step, int32_t
 int bbmpc_set_trace(bbmpc_handle h, int32_t enabled) {
     API_BEGIN
     CHECK_HANDLE(h);
+    if (enabled && h->e->auto_split > 1)
+        throw HipError(BBMPC_E_UNSUPPORTED, "the parity trace is per shard: not available for a population > 32768 (played as shards)");
     h->e->trace_on = enabled != 0;
     API_END
 }

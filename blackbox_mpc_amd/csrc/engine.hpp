@@ -241,6 +241,7 @@ struct Engine {
     // population sharding (PI2): per-iteration partials of this rank and the gathered partials of all ranks
     DevBuf<float> ps_part, ps_all;
     DevBuf<int> c_eidx_glob;                  // sharded CMA-ES: global particle indices of the merged elites (parity trace)
+    int auto_split = 0;      // > 1: population_size > 32768 is played as this many loopback shards (bbmpc.hip, constructor)
     int ps_loopback = 0;     // BBMPC_POPSHARD_LOOPBACK=G: one handle plays all G shards in turn (single-GPU test / measurement hook)
     bool ps_force = false;   // BBMPC_POPSHARD_FORCE: take the sharded code path (incl. the collective) even with one shard
     bool pop_sharded() const { return cfg.population_global > N || ps_loopback > 1 || ps_force; }

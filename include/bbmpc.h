@@ -108,7 +108,7 @@ typedef struct bbmpc_config {
     int32_t optimizer;          /* BBMPC_OPT_* */
     int32_t dynamics;           /* BBMPC_DYN_* */
     int32_t reward;             /* BBMPC_REW_* */
-    int32_t population_size;    /* N */
+    int32_t population_size;    /* N; above 32768 it must divide into <= 64 equal shards of <= 32768 (played in turn on the one GPU) */
     int32_t num_agents;         /* A  (agents owned by THIS handle / GPU) */
     int32_t planning_horizon;   /* H */
     int32_t dim_u;              /* U = env_action_space.shape[0] */

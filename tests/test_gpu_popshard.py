@@ -382,6 +382,41 @@ def test_spsa_exchange_through_a_one_rank_rccl_communicator(L, monkeypatch):
     one.comm_destroy()
 
 
+def test_population_above_32768_is_played_as_shards_on_one_gpu(L):
+    # The refit kernels keep an agent's rewards in one CU's LDS (32768 floats); a larger population runs as equal shards of
+    # the same machinery on the one GPU (draws keyed by the global particle).  PI2 at N = 40000 and CEM at N = 65536 (two
+    # shards of exactly 32768) against the NumPy oracle fed with the engine's own draws.
+    from blackbox_mpc_amd.engine import Engine
+    A, H, iters = 2, 6, 3
+    ev = O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))
+    s = O.pendulum_start_states(A)
+    N = 40000
+    eng = Engine(L.OPT_PI2, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=A, planning_horizon=H,
+                 population_size=N, max_iterations=iters, lamda=1.0, seed=3)
+    pi2 = O.PI2(ev, [-2.0], [2.0], horizon=H, max_iterations=iters, population=N, num_agents=A, lamda=1.0)
+    for t in range(2):
+        noise = {"trunc": [eng.dump_noise(L.NOISE_TRUNC_NORMAL, t, it, (N, A, H, 1)) for it in range(iters)]}
+        a_e, n_e, _ = eng.optimize(s, t)
+        a_o = pi2._optimize(s, noise)
+        np.testing.assert_allclose(a_e, a_o, rtol=0, atol=1e-4)
+        s = n_e
+    with pytest.raises(L.BBMPCError) as ei:              # the parity hooks are per shard
+        eng.set_trace(True)
+    assert ei.value.code == L.E_UNSUPPORTED
+    N, k = 65536, 100
+    eng = Engine(L.OPT_CEM, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=A, planning_horizon=H,
+                 population_size=N, max_iterations=iters, num_elite=k, alpha=0.2, seed=4)
+    cem = O.CEM(ev, [-2.0], [2.0], horizon=H, max_iterations=iters, population=N, num_elite=k, num_agents=A, alpha=0.2)
+    s = O.pendulum_start_states(A)
+    noise = {"trunc": [eng.dump_noise(L.NOISE_TRUNC_NORMAL, 0, it, (N, A, H, 1)) for it in range(iters)]}
+    a_e, n_e, _ = eng.optimize(s, 0)
+    a_o = cem._optimize(s, noise)
+    np.testing.assert_allclose(a_e, a_o, rtol=0, atol=2e-4)
+    with pytest.raises(L.BBMPCError):                    # 32771 is prime: no equal shards
+        Engine(L.OPT_PI2, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=1, planning_horizon=H,
+               population_size=32771, max_iterations=1)
+
+
 def test_population_sharding_argument_checks(L):
     from blackbox_mpc_amd.engine import Engine
     kw = dict(dim_s=3, num_agents=1, planning_horizon=8, max_iterations=2)
