@@ -315,7 +315,7 @@ def test_config5_cmaes_per_agent_full_size(L):
 @pytest.mark.parametrize("opt_name", ["CEM", "PI2", "RandomSearch"])
 def test_large_population_beyond_one_lds_default(L, monkeypatch, opt_name):
     # N = 20000 particles per agent (the refit kernels keep an agent's rewards in LDS: 80 KB here, past the 64 KB default
-    # allocation; limit 32768).  Pendulum, per-iteration kernels; engine-drawn noise replayed through the C oracle.
+    # allocation; 32768 is the most one shard holds).  Pendulum, per-iteration kernels; engine-drawn noise replayed through the C oracle.
     from blackbox_mpc_amd.engine import Engine
     N, A, H, iters, k = 20000, 2, 12, 2, 64
     opt = {"CEM": L.OPT_CEM, "PI2": L.OPT_PI2, "RandomSearch": L.OPT_RANDOM_SEARCH}[opt_name]
@@ -345,6 +345,6 @@ def test_large_population_beyond_one_lds_default(L, monkeypatch, opt_name):
     if opt_name == "PI2":
         a_c, _, _ = co.optimize("PI2", states, noise=noise)
         np.testing.assert_allclose(act, a_c, rtol=0, atol=5e-3)
-    with pytest.raises(L.BBMPCError):
+    with pytest.raises(L.BBMPCError):          # above 32768 a population is played as equal shards (test_gpu_popshard.py): 32771 is prime
         Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=1, planning_horizon=4,
-               population_size=40000, max_iterations=1, num_elite=8)
+               population_size=32771, max_iterations=1, num_elite=8)
