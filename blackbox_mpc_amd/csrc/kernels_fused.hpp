@@ -374,6 +374,9 @@ __global__ void k_fused_pendulum(FusedArgs p) {
 #ifdef BBMPC_KERNEL_DBG
             if (p.dbg && a == 0 && it == 0 && (tid & 63) == 0) dbg_lds[24 + (tid >> 6) % 8] = (long long)wall_clock64();
 #endif
+            // the selection's first part reads only the rewards this thread has just written: in front of the barrier the
+            // rollout needs anyway instead of behind it with a barrier of its own (topk.hpp)
+            if (OPT == FOPT_CEM) block_topk_prepass(rew, p.N, p.k, hist, tid, nthr);
             BB_DBG(2 + it * 4);
             __syncthreads();
             BB_DBG(3 + it * 4);
@@ -392,7 +395,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                 // The refit needs the elite SET only, so the winners are listed in ascending index order (no ranking);
                 // the sorted list tf.nn.top_k returns is produced only for the parity trace.  The statistics below always
                 // run over the index-ordered list, so results do not depend on tracing.
-                const TopkSel sel = block_topk_select(rew, p.N, p.k, hist, tid, nthr);
+                const TopkSel sel = block_topk_select(rew, p.N, p.k, hist, tid, nthr, true);
                 if (p.t_elites) {
                     block_topk_finish_sorted(rew, p.N, p.k, eidx, hist, ekeys, sel, tid, nthr);
                     for (int e = tid; e < p.k; e += nthr) p.t_elites[((size_t)it * p.A + a) * p.k + e] = eidx[e];

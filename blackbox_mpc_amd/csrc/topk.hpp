@@ -52,11 +52,11 @@ struct TopkSel {
     int top;             // number of low bits left undecided (early exit)
 };
 
-// Selection only: pins the boundary bucket of the k-th key.  Ends with a barrier; ctrl[3] (compaction cursor) is 0.
-__device__ __forceinline__ TopkSel block_topk_select(const float* vals, int N, int k, uint32_t* hist, int tid, int nthr) {
-    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
-    TOPK_DBG(0);
-    uint32_t* ctrl = hist + 256;                 // [0] bucket [1] wanted [2] bucket size [3] compaction cursor
+// First part of the selection, up to (not including) its first barrier: every thread reads only the elements
+// n = tid, tid + nthr, ... -- a caller whose threads have just WRITTEN exactly those elements (the persistent kernel's
+// rollout) runs it in front of the barrier it needs anyway and then calls block_topk_select(..., prepass_done = true).
+__device__ __forceinline__ void block_topk_prepass(const float* vals, int N, int k, uint32_t* hist, int tid, int nthr) {
+    const int lane = tid & 63, wave = tid >> 6;
     uint32_t* hist2 = hist + 272;                // second histogram: zeroed while the other one is scanned
     // ---- key range: digits are taken from the highest bit where the smallest key and an UPPER BOUND B of the
     // k-th smallest key differ.  Rewards of one population mostly share sign + exponent, so a fixed top-8-bit
@@ -102,7 +102,20 @@ __device__ __forceinline__ TopkSel block_topk_select(const float* vals, int N, i
     // both are consumed before the first histogram pass touches the bins
     if (lane == 0) { hist[wave] = kmin; hist[16 + wave] = kmax; }
     for (int i = tid; i < 256; i += nthr) hist2[i] = 0;          // first pass histograms into hist2
-    __syncthreads();
+}
+
+// Selection only: pins the boundary bucket of the k-th key.  Ends with a barrier; ctrl[3] (compaction cursor) is 0.
+__device__ __forceinline__ TopkSel block_topk_select(const float* vals, int N, int k, uint32_t* hist, int tid, int nthr,
+                                                     bool prepass_done = false) {
+    const int lane = tid & 63, nw = nthr >> 6;
+    TOPK_DBG(0);
+    uint32_t* ctrl = hist + 256;                 // [0] bucket [1] wanted [2] bucket size [3] compaction cursor
+    uint32_t* hist2 = hist + 272;                // second histogram: zeroed while the other one is scanned
+    if (!prepass_done) {
+        block_topk_prepass(vals, N, k, hist, tid, nthr);
+        __syncthreads();
+    }
+    uint32_t kmin, kmax;
     TOPK_DBG(1);
     // combine the (<= 16) per-wave slots with ONE LDS round trip: lane w fetches wave w's pair, then a 16-lane DPP
     // reduction (a serial loop over the slots costs one LDS latency per wave)
