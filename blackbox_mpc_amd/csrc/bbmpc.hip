@@ -98,10 +98,11 @@ static void ensure_max_lds(const void* fn, int bytes) {
 
 // kernels whose dynamic LDS grows with the population (an agent's rewards, Nst floats): past the 64 KB default they need
 // the attribute raised
-static void want_lds(const void* fn, size_t bytes) {
+// static_bytes: what the kernel declares as static __shared__ on top (the two together must fit the CU's 160 KB)
+static void want_lds(const void* fn, size_t bytes, size_t static_bytes = 0) {
     if (bytes > 64 * 1024) {
-        REQUIRE(bytes <= 159 * 1024, BBMPC_E_UNSUPPORTED, "population too large for one CU's LDS");
-        ensure_max_lds(fn, 159 * 1024);
+        REQUIRE(bytes + static_bytes <= 159 * 1024, BBMPC_E_UNSUPPORTED, "population too large for one CU's LDS");
+        ensure_max_lds(fn, (int)(159 * 1024 - static_bytes));
     }
 }
 
@@ -513,7 +514,7 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
         hipLaunchKernelGGL(k_cma_bd, dim3((unsigned)((gnn + 255) / 256)), dim3(256), 0, stream, q);
         const int kp = (k + 3) & ~3;
         const size_t lds = (size_t)(Nst + TOPK_HIST_WORDS + 2 * kp) * 4;
-        want_lds((const void*)k_cma_select, lds);
+        want_lds((const void*)k_cma_select, lds, 4096 + 512);       // eidx_s[1024] + the selection's small static words
         // sample -> roll out -> sorted top-k of this handle's particles (part != null: sharded population)
         auto shard_pass = [&](float* part) {
             hipLaunchKernelGGL(k_cma_noise, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, q);

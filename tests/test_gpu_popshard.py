@@ -417,6 +417,25 @@ def test_population_above_32768_is_played_as_shards_on_one_gpu(L):
                population_size=32771, max_iterations=1)
 
 
+@pytest.mark.parametrize("opt_name", ["RandomSearch", "PSO", "SPSA", "CMA-ES"])
+def test_population_above_32768_every_optimizer_runs(L, opt_name):
+    # the remaining optimizers on the shard-played path at N = 40000: control steps (with the warm starts / re-seeds in
+    # between) give finite, feasible actions and the same actions again from a second, identically seeded handle
+    from blackbox_mpc_amd.engine import Engine
+    opt = {"RandomSearch": L.OPT_RANDOM_SEARCH, "PSO": L.OPT_PSO, "SPSA": L.OPT_SPSA, "CMA-ES": L.OPT_CMAES}[opt_name]
+    kw = dict(num_elite=64, quirks=L.CMAES_PER_AGENT) if opt_name == "CMA-ES" else {}
+    mk = lambda: Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=2, planning_horizon=5,
+                        population_size=40000, max_iterations=2, seed=77, **kw)
+    e1, e2 = mk(), mk()
+    s1 = s2 = O.pendulum_start_states(2)
+    for t in range(3):
+        a1, s1, r1 = e1.optimize(s1, t)
+        a2, s2, r2 = e2.optimize(s2, t)
+        assert np.all(np.isfinite(a1)) and np.all(np.abs(a1) <= 2.0) and np.all(np.isfinite(r1))
+        np.testing.assert_array_equal(a1, a2)
+        np.testing.assert_array_equal(s1, s2)
+
+
 def test_population_sharding_argument_checks(L):
     from blackbox_mpc_amd.engine import Engine
     kw = dict(dim_s=3, num_agents=1, planning_horizon=8, max_iterations=2)
