@@ -890,7 +890,9 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     for (int l = 0; l < mlp.n_layers; ++l) { q.wraw[l] = d_wraw[l].p; q.braw[l] = d_braw[l].p; q.wq4[l] = d_wq4[l].p; q.wbf[l] = reinterpret_cast<const uint4*>(d_wbf[l].p); }
     const MlpLds lay = mlp_lds_layout(mlp, ra.H, U, S, mlp_nw);
     const size_t lds = (size_t)lay.total * sizeof(float);
-    REQUIRE(lds <= 159 * 1024, BBMPC_E_UNSUPPORTED, "planning horizon x action dim too large for the LDS action block");
+    REQUIRE(lds <= 159 * 1024, BBMPC_E_UNSUPPORTED,
+            "learned-model rollout: a 16-particle tile's action block (planning_horizon x 16 x dim_u floats) plus the activation / "
+            "partial-sum buffers of this network do not fit one CU's LDS (shorten the horizon or narrow the network)");
     // weights-stationary specialisations (kernels_mlp.hpp)
     int spec = 0;
     const bool small_io = mlp.tiles[0] <= 2 && mlp.tiles[mlp.n_layers] <= 2;
