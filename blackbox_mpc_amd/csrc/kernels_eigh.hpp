@@ -1,0 +1,510 @@
+// Direct symmetric eigensolver for the CMA-ES covariance (s, U, _ = tf.linalg.svd(C), cma_es.py:195) at
+// 128 < n <= 320 (BASELINE config 5: n = H*U = 300, four instances per GPU, 20 decompositions per control step).
+//
+// Why not Jacobi here: the covariance is alpha*I + E with E a sum of rank-51 updates of weight ~5.5e-4; the update of
+// one iteration has a larger Frobenius norm than the whole spectrum of E is wide, so the previous eigenvectors are no
+// warm start and a cyclic Jacobi needs 5 (fresh episode) to 10 sweeps of n - 1 dependent rounds each
+// (profiles/r4_cfg5cma.md).  A direct method has a fixed depth of ~n steps:
+//   1. k_eigh_tridiag      E = C - alpha*I (alpha = trace / n), Householder tridiagonalisation Q^T E Q = T with the matrix
+//                          in the registers of ONE workgroup (2/3 n^3 FMAs on one CU; everything else is small)
+//   2. k_eigh_tri_solve    eigenvalues of T by multisection (Sturm counts, 16 shifts per eigenvalue and pass), eigenvectors
+//                          by the twisted factorisation (one forward, one backward qd recurrence per eigenvalue); T is
+//                          split where |e_k| <= 4 eps max(|alpha|, |T|)  (C = alpha*I + low rank in the first
+//                          iterations of an episode: the Krylov space is exhausted after rank + 1 steps)
+//   3. k_eigh_gemm         Newton-Schulz polish Z <- Z (1.5 I - 0.5 Z^T Z), twice: the twisted vectors of eigenvalues
+//                          closer than ~1e-3 |T| are orthogonal to 1e-4 .. 1e-2 only; afterwards to 1e-6
+//   4. k_eigh_backtransform  B = Q Z in column slabs, reflectors applied in blocks of 32 (compact WY) on the matrix
+//                          cores; eigenvalues + alpha sorted descending, D = sqrt
+// The result is checked on the device (residual of every twisted vector, |Z^T Z - I| before the last polish); an
+// instance that fails keeps its flag set and the block Jacobi (kernels_cma.hpp) runs for it as before.
+// fp32 throughout; backward error ~1e-6 |E| -- two orders below the Jacobi threshold it replaces.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "kernels_refit.hpp"
+
+namespace bbmpc {
+
+constexpr int EIGH_LD = 320;                 // padded length of every vector / matrix row on this path (n <= 320)
+constexpr int EIGH_TRI_THREADS = 512;        // 32 row classes x 16 column classes, two waves per SIMD
+constexpr int EIGH_MAX_N = 320;
+
+struct EighArgs {
+    int n, G;
+    const float* C;      // [G][n][n] symmetric
+    float* d;            // [G][EIGH_LD] diagonal of T
+    float* e;            // [G][EIGH_LD] e[k] couples k and k + 1 (e[n-1] = 0)
+    float* tau;          // [G][EIGH_LD]
+    float* Vt;           // [G][EIGH_LD][EIGH_LD]: row k = Householder vector k (zero up to k, 1 at k + 1)
+    float* alpha;        // [G] shift (trace / n)
+    float* lam;          // [G][EIGH_LD] eigenvalues of T in slot order
+    float* Z;            // [G][EIGH_LD][EIGH_LD] row i, column j: component i of the eigenvector in slot j
+    float* Z2;           // second buffer of the same shape (polish ping-pong)
+    float* P;            // [G][EIGH_LD][EIGH_LD] 1.5 I - 0.5 Z^T Z
+    float* Tf;           // [G][EIGH_LD / 32][32][32] triangular factors of the reflector blocks
+    unsigned* flags;     // [G][8]: [0] failure bits, [1] max |Z^T Z - I| (float bits) of the last Gram, [2] max residual
+    float* B;            // [G][n][n] out: eigenvectors, columns by descending eigenvalue
+    float* Dd;           // [G][n] out: sqrt(eigenvalue)
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 1. Householder tridiagonalisation, one 512-thread workgroup per instance, the matrix in registers.
+// Thread (tr, tc), tr = tid / 16 in [0, 32), tc = tid % 16: rows tr + 32 i (i < 10), columns 4 (tc + 16 jj) + c (jj < 5,
+// c < 4): 200 registers, cyclic in both directions so that the work shrinks with the trailing matrix; the 16 lanes of a
+// DPP row hold one matrix row between them, so the matrix-vector product reduces with four DPP steps and every row of
+// lanes can form the Householder vector's column part for itself.  (VALU instructions only take a wave's 256
+// architectural registers -- AGPRs would cost a move per access -- so 8 waves x 256 is all the register file there is.)
+//
+// Step k (LAPACK ssytd2 on the full symmetric matrix: x~ = row k, entries > k):
+//   p~ = A x~                                   -- the product does not wait for the norm of x~
+//   beta, tau, scale from |x~|^2 (slarfg);  v = scale (x~ - beta e_{k+1});  p = A v = scale (p~ - beta y),  y = A[:, k+1]
+//   w = tau p - (tau^2 v.p / 2) v  =  c1 p~ + c2 y + c3 x~;      A -= v w^T + w v^T
+// Two schedules of that step:
+//   eigh_tri_steps_a  (k < 63, all ten row classes alive: no register to spare)   the owners of rows k and k + 1 publish
+//                     them -> barrier -> everybody: p~ -> barrier -> scalars, update
+//   eigh_tri_steps_b  (k >= 63: row classes 0, 1 are dead, their 40 registers carry the next step's x)   ONE barrier:
+//                     every thread forms the next row itself,  xn = y - w - w_{k+1} v  (v_{k+1} = 1),  at the end of the
+//                     update; before the barrier only p~ = A xn, the owner of row k + 1 publishing y, one row of lanes
+//                     publishing xn
+// LDS: Xc, Yc, Pt = x~, y, p~ (16-byte reads of a thread's own columns, 4-byte reads of its rows), double-buffered by the
+// parity of k.  Only column group JB (it holds index k + 1) and row class IB need per-element tests against k.
+// ---------------------------------------------------------------------------------------------------------------------
+// four floats WITHOUT a vector type behind them (HIP's float4 is an ext_vector: an aligned 128-bit register tuple)
+struct EighQuad {
+    float x, y, z, w;
+    __device__ __forceinline__ EighQuad() {}
+    __device__ __forceinline__ EighQuad(const float4& v) : x(v.x), y(v.y), z(v.z), w(v.w) {}
+    __device__ __forceinline__ operator float4() const { return make_float4(x, y, z, w); }
+};
+template <class A, class B>
+__device__ __forceinline__ float eigh_dot4(const A& a, const B& b, float s) {
+    s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+    return s;
+}
+
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. every barrier
+// would wait for the reflector row's global stores to be acknowledged (nothing in this kernel reads them back)
+__device__ __forceinline__ void eigh_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#ifdef EIGH_CLK
+__device__ long long g_eigh_clk[16];
+#endif
+#ifndef EIGH_SB
+#define EIGH_SB __builtin_amdgcn_sched_barrier(0)    /* keeps the next group's loads from being hoisted: register pressure */
+#endif
+
+#ifndef EIGH_SBA
+#define EIGH_SBA EIGH_SB
+#endif
+constexpr int EIGH_NI = 10, EIGH_NJ = 5;                     // row classes, column groups
+constexpr int EIGH_IL = 2;                                   // row classes 0, 1 (rows < 64) live in LDS, not in registers
+constexpr int EIGH_NR = EIGH_NI - EIGH_IL;
+constexpr int EIGH_KA = 63;                                  // steps k < EIGH_KA run on schedule a
+
+struct EighTriLds {
+    float AL[32 * EIGH_IL][EIGH_LD];     // matrix rows 0 .. 63 (dead once schedule a is over)
+    float Xc[2][EIGH_LD];
+    float Yc[2][EIGH_LD];
+    float Pt[2][EIGH_LD];
+};
+
+// comparisons of a per-thread index with k are written as (thread part) OP (uniform part): the uniform side lives in
+// SGPRs; otherwise the sums index + constant sit in VGPRs for the whole loop.  UF: a value that is the same in every lane.
+#define EIGH_U(x) __builtin_amdgcn_readfirstlane(x)
+#define EIGH_UF(x) __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)))
+
+struct EighStepScalars {
+    float scale, wk1, c1, c2, c3, n1, n2, n3, beta, t, yk;
+};
+
+// slarfg + the coefficients of w and of the next row, from |x~|^2 (sig, without the leading entry), x~ . p~ (g1), x~ . y (g2)
+__device__ __forceinline__ EighStepScalars eigh_step_scalars(float sig, float g1, float g2, float ain, float ptk, float yk) {
+    float beta = ain, t = 0.0f, scale = 0.0f;
+    if (sig > 0.0f) {                                    // hardware sqrt / rcp + one Newton step each
+        const float s2 = fmaf(ain, ain, sig);
+        float nrm = __builtin_amdgcn_sqrtf(s2);
+        nrm = fmaf(0.5f * __builtin_amdgcn_rcpf(nrm), fmaf(-nrm, nrm, s2), nrm);
+        beta = ain >= 0.0f ? -nrm : nrm;
+        float rb = __builtin_amdgcn_rcpf(beta);
+        rb = rb * fmaf(-beta, rb, 2.0f);
+        t = (beta - ain) * rb;
+        const float dd = ain - beta;
+        float rd = __builtin_amdgcn_rcpf(dd);
+        scale = rd * fmaf(-dd, rd, 2.0f);
+    }
+    EighStepScalars q;
+    q.scale = EIGH_UF(scale); q.t = EIGH_UF(t); q.beta = EIGH_UF(beta); q.yk = yk;
+    const float sb = q.scale * q.beta;
+    const float pk1 = EIGH_UF(fmaf(q.scale, ptk, -(sb * yk)));                  // p at index k + 1
+    // v = scale x~ + (1 - scale ain) e_{k+1};  p = scale p~ - scale beta y;  gamma = v . p
+    const float gam = EIGH_UF(fmaf(q.scale, fmaf(q.scale, g1, -(sb * g2)), (1.0f - ain * q.scale) * pk1));
+    const float coef = 0.5f * q.t * q.t * gam;
+    q.wk1 = fmaf(q.t, pk1, -coef);                                              // w at index k + 1 (v = 1 there)
+    // w = c1 p~ + c2 y + c3 x~ ;  next row  xn = y - w - wk1 v = n2 y + n1 p~ + n3 x~   (entries > k + 1)
+    q.c1 = q.t * q.scale; q.c2 = -(q.t * sb); q.c3 = -(coef * q.scale);
+    q.n1 = -q.c1; q.n2 = 1.0f - q.c2; q.n3 = -(q.c3 + q.wk1 * q.scale);
+    return q;
+}
+
+// x~ of column group JB: entries up to index k (kb inside the group) are dead
+__device__ __forceinline__ void eigh_mask_group(EighQuad& x, int cbase, int kb) {
+    x.x = cbase + 0 > kb ? x.x : 0.0f; x.y = cbase + 1 > kb ? x.y : 0.0f;
+    x.z = cbase + 2 > kb ? x.z : 0.0f; x.w = cbase + 3 > kb ? x.w : 0.0f;
+}
+// v, w at a thread's columns of one group (JBG: the group of index k + 1 -- dead entries, v = 1 / w = wk1 at k + 1)
+template <bool JBG>
+__device__ __forceinline__ void eigh_col_vw(const EighStepScalars& q, const EighQuad& x, const float4& pc, const float4& yc, int cbase, int kb,
+                                            float4& vc, float4& wc) {
+    vc.x = x.x * q.scale; vc.y = x.y * q.scale; vc.z = x.z * q.scale; vc.w = x.w * q.scale;
+    wc.x = fmaf(q.c1, pc.x, fmaf(q.c2, yc.x, q.c3 * x.x)); wc.y = fmaf(q.c1, pc.y, fmaf(q.c2, yc.y, q.c3 * x.y));
+    wc.z = fmaf(q.c1, pc.z, fmaf(q.c2, yc.z, q.c3 * x.z)); wc.w = fmaf(q.c1, pc.w, fmaf(q.c2, yc.w, q.c3 * x.w));
+    if (JBG) {
+        vc.x = cbase + 0 == kb + 1 ? 1.0f : vc.x; vc.y = cbase + 1 == kb + 1 ? 1.0f : vc.y;
+        vc.z = cbase + 2 == kb + 1 ? 1.0f : vc.z; vc.w = cbase + 3 == kb + 1 ? 1.0f : vc.w;
+        wc.x = cbase + 0 == kb + 1 ? q.wk1 : (cbase + 0 > kb + 1 ? wc.x : 0.0f); wc.y = cbase + 1 == kb + 1 ? q.wk1 : (cbase + 1 > kb + 1 ? wc.y : 0.0f);
+        wc.z = cbase + 2 == kb + 1 ? q.wk1 : (cbase + 2 > kb + 1 ? wc.z : 0.0f); wc.w = cbase + 3 == kb + 1 ? q.wk1 : (cbase + 3 > kb + 1 ? wc.w : 0.0f);
+    }
+}
+// v, w at row r = tr + 32 i (IBR: row class IB -- rows <= k are dead, row k + 1 has v = 1, w = wk1; kr = k inside the class)
+template <bool IBR>
+__device__ __forceinline__ void eigh_row_vw(const EighStepScalars& q, const float* Xc, const float* Pt, const float* Yc, int r, int tr, int kr,
+                                            float& vr, float& wr) {
+    const float xr = Xc[r], ptr = Pt[r], yr = Yc[r];
+    vr = xr * q.scale;
+    wr = fmaf(q.c1, ptr, fmaf(q.c2, yr, q.c3 * xr));
+    if (IBR) {
+        vr = tr == kr + 1 ? 1.0f : (tr > kr + 1 ? vr : 0.0f);
+        wr = tr == kr + 1 ? q.wk1 : (tr > kr + 1 ? wr : 0.0f);
+    }
+}
+__device__ __forceinline__ void eigh_rank2(EighQuad& ar, float vr, float wr, const float4& vc, const float4& wc) {
+    ar.x = fmaf(-vr, wc.x, fmaf(-wr, vc.x, ar.x)); ar.y = fmaf(-vr, wc.y, fmaf(-wr, vc.y, ar.y));
+    ar.z = fmaf(-vr, wc.z, fmaf(-wr, vc.z, ar.z)); ar.w = fmaf(-vr, wc.w, fmaf(-wr, vc.w, ar.w));
+}
+
+// p~ = A x (rows tr + 32 i, i >= IB); lane tc ends up with the sum of row tr + 32 tc and stores it.  Two rows at a time:
+// their DPP chains interleave, and no more than two sums are live -- the register file is full of matrix
+template <int IB, int JB>
+__device__ __forceinline__ void eigh_matvec(const EighQuad (&a)[EIGH_NR][EIGH_NJ], const EighQuad (&x)[EIGH_NJ], int tr, int tc, int cbase, float* Pt,
+                                            const float (*AL)[EIGH_LD]) {
+    float s0 = 0.0f;
+#pragma unroll
+    for (int i = IB; i < EIGH_IL; ++i) {                 // rows held in LDS
+        float acc = 0.0f;
+#pragma unroll
+        for (int jj = JB; jj < EIGH_NJ; ++jj) acc = eigh_dot4(*reinterpret_cast<const float4*>(&AL[tr + 32 * i][cbase + 64 * jj]), x[jj], acc);
+        acc = row16_sum(acc);
+        s0 = tc == i ? acc : s0;
+        EIGH_SB;
+    }
+    constexpr int IR = IB < EIGH_IL ? EIGH_IL : IB;
+#pragma unroll
+    for (int i = IR; i < EIGH_NI; i += 2) {
+        float sa = 0.0f, sb2 = 0.0f;
+#pragma unroll
+        for (int jj = JB; jj < EIGH_NJ; ++jj) sa = eigh_dot4(a[i - EIGH_IL][jj], x[jj], sa);
+        if (i + 1 < EIGH_NI) {
+#pragma unroll
+            for (int jj = JB; jj < EIGH_NJ; ++jj) sb2 = eigh_dot4(a[(i + 1 < EIGH_NI ? i + 1 : i) - EIGH_IL][jj], x[jj], sb2);
+        }
+        sa = row16_sum(sa);
+        s0 = tc == i ? sa : s0;
+        if (i + 1 < EIGH_NI) {
+            sb2 = row16_sum(sb2);
+            s0 = tc == i + 1 ? sb2 : s0;
+        }
+        EIGH_SB;
+    }
+    int trv = tr, cbv = cbase;
+    asm volatile("" : "+v"(trv), "+v"(cbv));              // (recomputed per step: as a loop invariant the address gets spilled)
+    if (cbv >= 4 * IB && cbv < 4 * EIGH_NI) Pt[trv + 8 * cbv] = s0;
+}
+
+// ---- schedule a: steps k < EIGH_KA with (k + 1) / 32 == IB (IB = 0, 1)
+template <int IB>
+__device__ __forceinline__ void eigh_tri_steps_a(EighQuad (&a)[EIGH_NR][EIGH_NJ], const int n, const int tr, const int tc, EighTriLds& L,
+                                                 float* __restrict__ d, float* __restrict__ e, float* __restrict__ tau, float* __restrict__ Vt) {
+    constexpr int JB = IB / 2;
+    const int k_lo = IB == 0 ? 0 : 32 * IB - 1;
+    const int k_hi = min(min(n - 3, 32 * IB + 30), EIGH_KA - 1);
+    const int cbase = 4 * tc;
+#ifdef EIGH_CLK
+    const long long t0_ = (long long)__builtin_readcyclecounter();
+#endif
+    for (int k = k_lo; k <= k_hi; ++k) {
+        const int par = k & 1;
+        float* Yc = L.Yc[par];
+        float* Pt = L.Pt[par];
+        const int kb = EIGH_U(k - 64 * JB), kr = EIGH_U(k - 32 * IB);
+        // rows k and k + 1 are LDS rows here: x~ is read in place (row k is dead: nothing writes it any more), y is copied
+        // after the first barrier (row k + 1 is updated in place later in this step)
+        const float* Xc = L.AL[k];
+        eigh_lds_barrier();
+        // ---- x~, |x~|^2 without the leading entry, p~ = A x~
+        {
+            EighQuad xt[EIGH_NJ];
+#pragma unroll
+            for (int jj = JB; jj < EIGH_NJ; ++jj) xt[jj] = EighQuad(*reinterpret_cast<const float4*>(Xc + cbase + 64 * jj));
+            eigh_mask_group(xt[JB], cbase, kb);
+            if (tr == EIGH_U((k + 1) & 31)) {               // owner of row k + 1: its 20 columns -> Yc
+#pragma unroll
+                for (int jj = JB; jj < EIGH_NJ; ++jj)
+                    *reinterpret_cast<float4*>(Yc + cbase + 64 * jj) = *reinterpret_cast<const float4*>(&L.AL[tr + 32 * IB][cbase + 64 * jj]);
+            }
+            eigh_matvec<IB, JB>(a, xt, tr, tc, cbase, Pt, L.AL);
+        }
+        eigh_lds_barrier();
+        float sig = 0.0f, g1 = 0.0f, g2 = 0.0f;
+#pragma unroll
+        for (int jj = JB; jj < EIGH_NJ; ++jj) {
+            EighQuad x(*reinterpret_cast<const float4*>(Xc + cbase + 64 * jj));
+            const float4 pc = *reinterpret_cast<const float4*>(Pt + cbase + 64 * jj);
+            const float4 yc = *reinterpret_cast<const float4*>(Yc + cbase + 64 * jj);
+            if (jj == JB) {
+                eigh_mask_group(x, cbase, kb);
+                sig = fmaf(cbase + 0 > kb + 1 ? x.x : 0.0f, x.x, sig); sig = fmaf(cbase + 1 > kb + 1 ? x.y : 0.0f, x.y, sig);
+                sig = fmaf(cbase + 2 > kb + 1 ? x.z : 0.0f, x.z, sig); sig = fmaf(cbase + 3 > kb + 1 ? x.w : 0.0f, x.w, sig);
+            } else {
+                sig = eigh_dot4(x, x, sig);
+            }
+            g1 = eigh_dot4(x, pc, g1);
+            g2 = eigh_dot4(x, yc, g2);
+            EIGH_SBA;
+        }
+        sig = row16_sum(sig); g1 = row16_sum(g1); g2 = row16_sum(g2);
+        const EighStepScalars q = eigh_step_scalars(sig, g1, g2, Xc[k + 1], Pt[k + 1], Yc[k + 1]);
+        float vr[EIGH_NI], wr[EIGH_NI];
+        eigh_row_vw<true>(q, Xc, Pt, Yc, tr + 32 * IB, tr, kr, vr[IB], wr[IB]);
+#pragma unroll
+        for (int i = IB + 1; i < EIGH_NI; ++i) {
+            eigh_row_vw<false>(q, Xc, Pt, Yc, tr + 32 * i, tr, kr, vr[i], wr[i]);
+            if (((i - IB) & 3) == 3) EIGH_SBA;
+        }
+        float* vrow = Vt + (size_t)k * EIGH_LD;
+        EIGH_SBA;
+#pragma unroll
+        for (int jj = 0; jj < EIGH_NJ; ++jj) {
+            if (jj < JB) {
+                if (tr == 0) *reinterpret_cast<float4*>(vrow + cbase + 64 * jj) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                continue;
+            }
+            EighQuad x(*reinterpret_cast<const float4*>(Xc + cbase + 64 * jj));
+            const float4 pc = *reinterpret_cast<const float4*>(Pt + cbase + 64 * jj);
+            const float4 yc = *reinterpret_cast<const float4*>(Yc + cbase + 64 * jj);
+            float4 vc, wc;
+            if (jj == JB) { eigh_mask_group(x, cbase, kb); eigh_col_vw<true>(q, x, pc, yc, cbase, kb, vc, wc); }
+            else eigh_col_vw<false>(q, x, pc, yc, cbase, kb, vc, wc);
+            if (tr == 0) *reinterpret_cast<float4*>(vrow + cbase + 64 * jj) = vc;
+#pragma unroll
+            for (int i = IB; i < EIGH_IL; ++i) {          // rows held in LDS
+                float4* ap = reinterpret_cast<float4*>(&L.AL[tr + 32 * i][cbase + 64 * jj]);
+                EighQuad al(*ap);
+                eigh_rank2(al, vr[i], wr[i], vc, wc);
+                *ap = (float4)al;
+            }
+#pragma unroll
+            for (int i = EIGH_IL; i < EIGH_NI; ++i) eigh_rank2(a[i - EIGH_IL][jj], vr[i], wr[i], vc, wc);
+            EIGH_SBA;
+        }
+        if (tr == 0 && tc == 0) { e[k] = q.beta; tau[k] = q.t; d[k + 1] = q.yk - 2.0f * q.wk1; }
+    }
+#ifdef EIGH_CLK
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_eigh_clk[IB] += (long long)__builtin_readcyclecounter() - t0_;
+#endif
+}
+
+// ---- schedule b: steps k >= EIGH_KA with (k + 1) / 32 == IB (IB >= 2); xn = the thread's 20 columns of row k on entry
+template <int IB>
+__device__ __forceinline__ void eigh_tri_steps_b(EighQuad (&a)[EIGH_NR][EIGH_NJ], EighQuad (&xn)[EIGH_NJ], const int n, const int tr, const int tc,
+                                                 EighTriLds& L, float* __restrict__ d, float* __restrict__ e, float* __restrict__ tau,
+                                                 float* __restrict__ Vt) {
+    constexpr int JB = IB / 2;
+    const int k_lo = max(32 * IB - 1, EIGH_KA);
+    const int k_hi = min(n - 3, 32 * IB + 30);
+    const int cbase = 4 * tc;
+#ifdef EIGH_CLK
+    const long long t0_ = (long long)__builtin_readcyclecounter();
+#endif
+    for (int k = k_lo; k <= k_hi; ++k) {
+        const int par = k & 1;
+        float* Xc = L.Xc[par];
+        float* Yc = L.Yc[par];
+        float* Pt = L.Pt[par];
+        const int kb = EIGH_U(k - 64 * JB), kr = EIGH_U(k - 32 * IB);
+        // ---- x~ = row k, entries > k;  |x~|^2 without the leading entry
+        eigh_mask_group(xn[JB], cbase, kb);
+        float sig = 0.0f;
+        sig = fmaf(cbase + 0 > kb + 1 ? xn[JB].x : 0.0f, xn[JB].x, sig); sig = fmaf(cbase + 1 > kb + 1 ? xn[JB].y : 0.0f, xn[JB].y, sig);
+        sig = fmaf(cbase + 2 > kb + 1 ? xn[JB].z : 0.0f, xn[JB].z, sig); sig = fmaf(cbase + 3 > kb + 1 ? xn[JB].w : 0.0f, xn[JB].w, sig);
+#pragma unroll
+        for (int jj = JB + 1; jj < EIGH_NJ; ++jj) sig = eigh_dot4(xn[jj], xn[jj], sig);
+        if (tr == 0) {
+#pragma unroll
+            for (int jj = JB; jj < EIGH_NJ; ++jj) *reinterpret_cast<float4*>(Xc + cbase + 64 * jj) = (float4)xn[jj];
+        }
+        if (tr == EIGH_U((k + 1) & 31)) {                // row k + 1 = 32 IB + tr: row class IB
+#pragma unroll
+            for (int jj = JB; jj < EIGH_NJ; ++jj) *reinterpret_cast<float4*>(Yc + cbase + 64 * jj) = (float4)a[IB - EIGH_IL][jj];
+        }
+        eigh_matvec<IB, JB>(a, xn, tr, tc, cbase, Pt, L.AL);
+        sig = row16_sum(sig);
+        eigh_lds_barrier();
+        // ---- x~ . p~ and x~ . y over the columns (x~ is zero on the dead entries)
+        float g1 = 0.0f, g2 = 0.0f;
+#pragma unroll
+        for (int jj = JB; jj < EIGH_NJ; ++jj) {
+            const float4 pc = *reinterpret_cast<const float4*>(Pt + cbase + 64 * jj);
+            const float4 yc = *reinterpret_cast<const float4*>(Yc + cbase + 64 * jj);
+            g1 = eigh_dot4(xn[jj], pc, g1);
+            g2 = eigh_dot4(xn[jj], yc, g2);
+            if (((jj - JB) & 1) == 1) EIGH_SB;
+        }
+        g1 = row16_sum(g1); g2 = row16_sum(g2);
+        const EighStepScalars q = eigh_step_scalars(sig, g1, g2, Xc[k + 1], Pt[k + 1], Yc[k + 1]);
+        float vr[EIGH_NI], wr[EIGH_NI];
+        eigh_row_vw<true>(q, Xc, Pt, Yc, tr + 32 * IB, tr, kr, vr[IB], wr[IB]);
+#pragma unroll
+        for (int i = IB + 1; i < EIGH_NI; ++i) {
+            eigh_row_vw<false>(q, Xc, Pt, Yc, tr + 32 * i, tr, kr, vr[i], wr[i]);
+            if (((i - IB) & 3) == 3) EIGH_SB;
+        }
+        float* vrow = Vt + (size_t)k * EIGH_LD;
+        EIGH_SB;
+#pragma unroll
+        for (int jj = 0; jj < EIGH_NJ; ++jj) {
+            if (jj < JB) {
+                if (tr == 0) *reinterpret_cast<float4*>(vrow + cbase + 64 * jj) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                continue;
+            }
+            const float4 pc = *reinterpret_cast<const float4*>(Pt + cbase + 64 * jj);
+            const float4 yc = *reinterpret_cast<const float4*>(Yc + cbase + 64 * jj);
+            float4 vc, wc;
+            if (jj == JB) eigh_col_vw<true>(q, xn[jj], pc, yc, cbase, kb, vc, wc);
+            else eigh_col_vw<false>(q, xn[jj], pc, yc, cbase, kb, vc, wc);
+            if (tr == 0) *reinterpret_cast<float4*>(vrow + cbase + 64 * jj) = vc;
+#pragma unroll
+            for (int i = IB; i < EIGH_NI; ++i) eigh_rank2(a[i - EIGH_IL][jj], vr[i], wr[i], vc, wc);
+            // row k + 1 after this step's update = the next step's x (its entries <= k + 1 are masked there)
+            xn[jj].x = fmaf(q.n2, yc.x, fmaf(q.n1, pc.x, q.n3 * xn[jj].x)); xn[jj].y = fmaf(q.n2, yc.y, fmaf(q.n1, pc.y, q.n3 * xn[jj].y));
+            xn[jj].z = fmaf(q.n2, yc.z, fmaf(q.n1, pc.z, q.n3 * xn[jj].z)); xn[jj].w = fmaf(q.n2, yc.w, fmaf(q.n1, pc.w, q.n3 * xn[jj].w));
+            EIGH_SB;
+        }
+        if (tr == 0 && tc == 0) { e[k] = q.beta; tau[k] = q.t; d[k + 1] = q.yk - 2.0f * q.wk1; }
+    }
+#ifdef EIGH_CLK
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_eigh_clk[IB] += (long long)__builtin_readcyclecounter() - t0_;
+#endif
+}
+
+// row r >= 64 of the register-resident matrix -> x[0 .. EIGH_LD)  (value selects over the row classes >= 2: classes 0 and
+// 1 must be dead after schedule a, or their 40 registers stay allocated through schedule b)
+__device__ __forceinline__ void eigh_row_to_lds(const EighQuad (&a)[EIGH_NR][EIGH_NJ], int r, int tr, int tc, float* x) {
+    const int i = r >> 5;
+#pragma unroll
+    for (int jj = 0; jj < EIGH_NJ; ++jj) {
+        EighQuad v = a[0][jj];
+#pragma unroll
+        for (int ii = EIGH_IL + 1; ii < EIGH_NI; ++ii) {
+            const EighQuad u = a[ii - EIGH_IL][jj];
+            v.x = i == ii ? u.x : v.x; v.y = i == ii ? u.y : v.y; v.z = i == ii ? u.z : v.z; v.w = i == ii ? u.w : v.w;
+        }
+        if (tr == (r & 31)) *reinterpret_cast<float4*>(x + 4 * tc + 64 * jj) = (float4)v;
+    }
+}
+
+// grid G, block 512, dynamic LDS sizeof(EighTriLds); 66 <= n <= 320
+__global__ __launch_bounds__(EIGH_TRI_THREADS) void k_eigh_tridiag(EighArgs q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char eigh_smem[];
+    EighTriLds& L = *reinterpret_cast<EighTriLds*>(eigh_smem);
+    __shared__ float s_red[EIGH_TRI_THREADS / 64];
+    const int g = blockIdx.x, tid = threadIdx.x, n = q.n;
+    const int tr = tid >> 4, tc = tid & 15;
+    const float* C = q.C + (size_t)g * n * n;
+    float* d = q.d + (size_t)g * EIGH_LD;
+    float* e = q.e + (size_t)g * EIGH_LD;
+    float* tau = q.tau + (size_t)g * EIGH_LD;
+    float* Vt = q.Vt + (size_t)g * EIGH_LD * EIGH_LD;
+    // alpha = trace / n
+    float tsum = tid < n ? C[(size_t)tid * n + tid] : 0.0f;          // n <= 320 < 512
+    tsum = wave_sum(tsum);
+    if ((tid & 63) == 0) s_red[tid >> 6] = tsum;
+    __syncthreads();
+    float alpha = 0.0f;
+#pragma unroll
+    for (int w = 0; w < EIGH_TRI_THREADS / 64; ++w) alpha += s_red[w];
+    alpha = alpha / (float)n;
+    if (tid == 0) q.alpha[g] = alpha;
+    EighQuad a[EIGH_NR][EIGH_NJ];
+    const bool vec = (n & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < EIGH_NI; ++i) {
+        const int r = tr + 32 * i;
+#pragma unroll
+        for (int jj = 0; jj < EIGH_NJ; ++jj) {
+            const int c0 = 4 * tc + 64 * jj;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (r < n) {
+                const unsigned off = (unsigned)r * (unsigned)n + (unsigned)c0;
+                if (vec) {
+                    if (c0 < n) v = *reinterpret_cast<const float4*>(C + off);
+                } else {
+                    if (c0 + 0 < n) v.x = C[off + 0];
+                    if (c0 + 1 < n) v.y = C[off + 1];
+                    if (c0 + 2 < n) v.z = C[off + 2];
+                    if (c0 + 3 < n) v.w = C[off + 3];
+                }
+                if (r == c0 + 0) v.x -= alpha;
+                if (r == c0 + 1) v.y -= alpha;
+                if (r == c0 + 2) v.z -= alpha;
+                if (r == c0 + 3) v.w -= alpha;
+            }
+            if (i < EIGH_IL) *reinterpret_cast<float4*>(&L.AL[r][c0]) = v;
+            else a[i < EIGH_IL ? 0 : i - EIGH_IL][jj] = EighQuad(v);
+        }
+    }
+    // unused tail of the outputs: zero reflectors
+    for (int i = tid; i < EIGH_LD; i += EIGH_TRI_THREADS) {
+        if (i >= n - 2) { tau[i] = 0.0f; e[i] = 0.0f; }
+        if (i >= n) d[i] = 0.0f;
+    }
+    for (int i = tid; i < 2 * EIGH_LD; i += EIGH_TRI_THREADS) {        // reflector rows n-2, n-1: zero
+        const int row = n - 2 + i / EIGH_LD;
+        if (row < EIGH_LD) Vt[(size_t)row * EIGH_LD + (i % EIGH_LD)] = 0.0f;
+    }
+    __syncthreads();
+    if (tid == 0) d[0] = L.AL[0][0];
+    eigh_tri_steps_a<0>(a, n, tr, tc, L, d, e, tau, Vt);
+    eigh_tri_steps_a<1>(a, n, tr, tc, L, d, e, tau, Vt);
+    if (n - 3 >= EIGH_KA) {
+        // hand-over: row EIGH_KA (row class 1) to every thread's columns
+        __syncthreads();
+        if (tr == (EIGH_KA & 31)) {
+#pragma unroll
+            for (int jj = 0; jj < EIGH_NJ; ++jj) *reinterpret_cast<float4*>(L.Xc[0] + 4 * tc + 64 * jj) = *reinterpret_cast<const float4*>(&L.AL[EIGH_KA][4 * tc + 64 * jj]);
+        }
+        __syncthreads();
+        EighQuad xn[EIGH_NJ];
+#pragma unroll
+        for (int jj = 0; jj < EIGH_NJ; ++jj) xn[jj] = EighQuad(*reinterpret_cast<const float4*>(L.Xc[0] + 4 * tc + 64 * jj));
+        __syncthreads();
+        eigh_tri_steps_b<2>(a, xn, n, tr, tc, L, d, e, tau, Vt);
+        eigh_tri_steps_b<3>(a, xn, n, tr, tc, L, d, e, tau, Vt);
+        eigh_tri_steps_b<4>(a, xn, n, tr, tc, L, d, e, tau, Vt);
+        eigh_tri_steps_b<5>(a, xn, n, tr, tc, L, d, e, tau, Vt);
+        eigh_tri_steps_b<6>(a, xn, n, tr, tc, L, d, e, tau, Vt);
+        eigh_tri_steps_b<7>(a, xn, n, tr, tc, L, d, e, tau, Vt);
+        eigh_tri_steps_b<8>(a, xn, n, tr, tc, L, d, e, tau, Vt);
+        eigh_tri_steps_b<9>(a, xn, n, tr, tc, L, d, e, tau, Vt);
+    }
+    // the trailing 2 x 2: d[n-2] is written by the last step; e[n-2] = A[n-1][n-2], d[n-1] = A[n-1][n-1]
+    __syncthreads();
+    eigh_row_to_lds(a, n - 1, tr, tc, L.Xc[0]);
+    __syncthreads();
+    if (tid == 0) { e[n - 2] = L.Xc[0][n - 2]; d[n - 1] = L.Xc[0][n - 1]; }
+}
+
+}  // namespace bbmpc
