@@ -471,10 +471,7 @@ __global__ __launch_bounds__(EIGH_TRI_THREADS) void k_eigh_tridiag(EighArgs q) {
         if (i >= n - 2) { tau[i] = 0.0f; e[i] = 0.0f; }
         if (i >= n) d[i] = 0.0f;
     }
-    for (int i = tid; i < 2 * EIGH_LD; i += EIGH_TRI_THREADS) {        // reflector rows n-2, n-1: zero
-        const int row = n - 2 + i / EIGH_LD;
-        if (row < EIGH_LD) Vt[(size_t)row * EIGH_LD + (i % EIGH_LD)] = 0.0f;
-    }
+    for (int i = (n - 2) * EIGH_LD + tid; i < EIGH_LD * EIGH_LD; i += EIGH_TRI_THREADS) Vt[i] = 0.0f;   // reflector rows n-2 .. : zero
     __syncthreads();
     if (tid == 0) d[0] = L.AL[0][0];
     eigh_tri_steps_a<0>(a, n, tr, tc, L, d, e, tau, Vt);
@@ -505,6 +502,441 @@ __global__ __launch_bounds__(EIGH_TRI_THREADS) void k_eigh_tridiag(EighArgs q) {
     eigh_row_to_lds(a, n - 1, tr, tc, L.Xc[0]);
     __syncthreads();
     if (tid == 0) { e[n - 2] = L.Xc[0][n - 2]; d[n - 1] = L.Xc[0][n - 1]; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2. Eigen-decomposition of the tridiagonal T (d, e) -- and, in the surplus workgroups of the same launch, the
+// triangular factors of the reflector blocks for stage 4.
+// grid (EIGH_LD / 16 + EIGH_LD / 32, G), block 256.  Workgroups x < 20: 16 eigenvalue slots each, one 16-lane DPP row
+// per slot.  T is split where |e_k| <= 4 eps max(|alpha|, |T|); slot j belongs to the unreduced block [s, t) that
+// contains index j and takes that block's (j - s)-th eigenvalue:
+//   multisection   the row's 16 lanes try 16 shifts per pass; Sturm count = negative pivots of T - x inside [s, t)
+//                  (the recurrence runs over the whole matrix: e^2 = 0 at a split restarts it); 7 passes of 17-fold
+//                  narrowing take the Gershgorin interval to below the last bit of |T|
+//   eigenvector    twisted factorisation: lane 0 runs the forward (L D+ L^T), lane 1 the backward (U D- U^T)
+//                  recurrence of T - lambda, both into LDS; the row finds r = argmin |gamma_i| and the two lanes run the
+//                  vector out from z_r = 1 upwards / downwards; normalised, residual |gamma_r| / |z| recorded
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int EIGH_SOLVE_THREADS = 256;
+constexpr int EIGH_SLOT_WGS = EIGH_LD / 16, EIGH_TF_WGS = EIGH_LD / 32;
+
+struct EighSolveLds {
+    float dd[EIGH_LD];          // d
+    float ee[EIGH_LD];          // thresholded e (ee[k] couples k, k + 1)
+    float e2p[EIGH_LD];         // e2p[i] = ee[i-1]^2 (0 for i = 0)
+    float fw[16][EIGH_LD + 4];  // per slot: D+ pivots, then the upper part of z
+    float bw[16][EIGH_LD + 4];  // per slot: D- pivots, then the lower part of z
+    float red[8];
+};
+
+__device__ __forceinline__ float row16_max(float v) { return -row16_min(-v); }
+
+__device__ __forceinline__ void eigh_tfactor_block(const EighArgs& q, int g, int b, float* smem);
+
+__global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char eigh_smem2[];
+    const int g = blockIdx.y, tid = threadIdx.x, n = q.n;
+    if (blockIdx.x >= EIGH_SLOT_WGS) {
+        eigh_tfactor_block(q, g, blockIdx.x - EIGH_SLOT_WGS, reinterpret_cast<float*>(eigh_smem2));
+        return;
+    }
+    EighSolveLds& L = *reinterpret_cast<EighSolveLds*>(eigh_smem2);
+    const float* d = q.d + (size_t)g * EIGH_LD;
+    const float* e = q.e + (size_t)g * EIGH_LD;
+    const float alpha = q.alpha[g];
+    const int lane = tid & 63, wv = tid >> 6, sub = lane & 15, row = wv * 4 + (lane >> 4);
+    // ---- T into LDS, split threshold, Gershgorin interval
+    float tn = 0.0f;
+    for (int i = tid; i < EIGH_LD; i += EIGH_SOLVE_THREADS) {
+        const float di = i < n ? d[i] : 0.0f, ei = i < n - 1 ? e[i] : 0.0f;
+        L.dd[i] = di; L.ee[i] = ei;
+        tn = fmaxf(tn, fmaxf(fabsf(di), fabsf(ei)));
+    }
+    tn = fmaxf(tn, __shfl_xor(tn, 32, 64));
+    tn = row16_max(tn); tn = fmaxf(tn, __shfl_xor(tn, 16, 64));
+    if (lane == 0) L.red[wv] = tn;
+    __syncthreads();
+    tn = fmaxf(fmaxf(L.red[0], L.red[1]), fmaxf(L.red[2], L.red[3]));
+    const float thr = 4.0f * 1.1920929e-07f * fmaxf(fabsf(alpha), tn);
+    __syncthreads();
+    float gl = 3.0e38f, gu = -3.0e38f;
+    float eth[2] = {0.0f, 0.0f};                                   // EIGH_LD <= 2 * EIGH_SOLVE_THREADS
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = tid + it * EIGH_SOLVE_THREADS;
+        if (i < EIGH_LD) {
+            float ei = L.ee[i];
+            if (fabsf(ei) <= thr) ei = 0.0f;
+            const float em = i > 0 ? L.ee[i - 1] : 0.0f;          // (unthresholded neighbour: only widens the interval)
+            if (i < n) {
+                const float rad = fabsf(ei) + fabsf(em);
+                gl = fminf(gl, L.dd[i] - rad); gu = fmaxf(gu, L.dd[i] + rad);
+            }
+            eth[it] = ei;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = tid + it * EIGH_SOLVE_THREADS;
+        if (i < EIGH_LD) L.ee[i] = eth[it];
+    }
+    __syncthreads();
+    for (int i = tid; i < EIGH_LD; i += EIGH_SOLVE_THREADS) L.e2p[i] = i > 0 ? L.ee[i - 1] * L.ee[i - 1] : 0.0f;
+    gl = fminf(gl, __shfl_xor(gl, 32, 64)); gu = fmaxf(gu, __shfl_xor(gu, 32, 64));
+    gl = row16_min(gl); gu = row16_max(gu);
+    gl = fminf(gl, __shfl_xor(gl, 16, 64)); gu = fmaxf(gu, __shfl_xor(gu, 16, 64));
+    if (lane == 0) { L.red[wv] = gl; L.red[4 + wv] = gu; }
+    __syncthreads();
+    gl = fminf(fminf(L.red[0], L.red[1]), fminf(L.red[2], L.red[3]));
+    gu = fmaxf(fmaxf(L.red[4], L.red[5]), fmaxf(L.red[6], L.red[7]));
+    {
+        const float span = gu - gl;
+        gl -= span * (2.0f * 1.1920929e-07f * (float)n) + thr;
+        gu += span * (2.0f * 1.1920929e-07f * (float)n) + thr;
+    }
+    const float pivmin = fmaxf(1.0e-30f, tn * tn * 1.0e-30f);
+    const int j = blockIdx.x * 16 + row;                          // eigenvalue slot of this 16-lane row
+    const bool live = j < n;
+    // ---- the unreduced block [s, t) around index j
+    int s = live ? j : 0, t = live ? j + 1 : 1;
+    while (s > 0 && L.ee[s - 1] != 0.0f) --s;
+    while (t < n && L.ee[t - 1] != 0.0f) ++t;
+    const int m = (live ? j : 0) - s;
+    // ---- multisection
+    float lo = gl, hi = gu;
+    if (t - s > 1) {
+        for (int pass = 0; pass < 7; ++pass) {
+            const float h = (hi - lo) * (1.0f / 17.0f);
+            const float x = fmaf((float)(sub + 1), h, lo);
+            int cnt = 0;
+            float qv = 1.0f;
+#pragma unroll 4
+            for (int i = 0; i < n; ++i) {
+                qv = (L.dd[i] - x) - L.e2p[i] * __builtin_amdgcn_rcpf(qv);
+                qv = fabsf(qv) < pivmin ? -pivmin : qv;
+                cnt += (i >= s && i < t && qv < 0.0f) ? 1 : 0;
+            }
+            // eigenvalue m of the block lies above every shift with cnt <= m and not above any shift with cnt > m
+            const float below = cnt <= m ? x : lo, above = cnt > m ? x : hi;
+            lo = row16_max(below); hi = row16_min(above);
+            if (!(hi > lo)) hi = lo;
+        }
+    } else {
+        lo = hi = L.dd[s];
+    }
+    const float lam = 0.5f * (lo + hi);
+    // ---- twisted factorisation of T - lam on [s, t)
+    float* fw = L.fw[row];
+    float* bw = L.bw[row];
+    const int len = t - s;
+    int lenmax = len;
+    lenmax = max(lenmax, __shfl_xor(lenmax, 16, 64)); lenmax = max(lenmax, __shfl_xor(lenmax, 32, 64));
+    if (sub < 2) {
+        const bool fwd = sub == 0;
+        float piv = fwd ? L.dd[s] - lam : L.dd[t - 1] - lam;
+        for (int st = 0; st < lenmax; ++st) {
+            if (st < len) {
+                const int i = fwd ? s + st : t - 1 - st;
+                piv = fabsf(piv) < pivmin ? -pivmin : piv;
+                (fwd ? fw : bw)[i] = piv;
+                if (st + 1 < len) {
+                    const int in = fwd ? i + 1 : i - 1;
+                    const float ec = fwd ? L.ee[i] : L.ee[i - 1];           // coupling between i and the next index
+                    piv = (L.dd[in] - lam) - (ec / piv) * ec;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // gamma_i = D+_i + D-_i - (d_i - lam); r = argmin |gamma_i|
+    float gmin = 3.0e38f;
+    int rbest = s;
+    for (int i = s + sub; i < t; i += 16) {
+        const float gam = fabsf((fw[i] + bw[i]) - (L.dd[i] - lam));
+        if (gam < gmin) { gmin = gam; rbest = i; }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const float og = __shfl_xor(gmin, o, 64);
+        const int orr = __shfl_xor(rbest, o, 64);
+        if (og < gmin || (og == gmin && orr < rbest)) { gmin = og; rbest = orr; }
+    }
+    const int r = rbest;
+    __builtin_amdgcn_wave_barrier();
+    // z_r = 1;  upwards z_i = -(e_i / D+_i) z_{i+1};  downwards z_{i+1} = -(e_i / D-_{i+1}) z_i
+    // (z_i overwrites D+_i for i <= r and D-_i for i > r)
+    if (sub < 2) {
+        const bool up = sub == 0;
+        float z = 1.0f;
+        if (up) {
+            for (int i = r - 1; i >= s; --i) { z = -(L.ee[i] / fw[i]) * z; fw[i] = z; }
+        } else {
+            for (int i = r; i < t - 1; ++i) { z = -(L.ee[i] / bw[i + 1]) * z; bw[i + 1] = z; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (sub == 0) fw[r] = 1.0f;
+    __builtin_amdgcn_wave_barrier();
+    float zz = 0.0f;
+    for (int i = s + sub; i < t; i += 16) { const float z = i <= r ? fw[i] : bw[i]; zz = fmaf(z, z, zz); }
+    zz = row16_sum(zz);
+    const float rn = 1.0f / sqrtf(zz);
+    if (live && sub == 0) {
+        q.lam[(size_t)g * EIGH_LD + j] = lam;
+        const float resid = gmin * rn;                                       // |(T - lam) z| for the normalised z
+        atomicMax(q.flags + (size_t)g * 8 + 2, __float_as_uint(resid));
+    }
+    // normalised vector back into fw (zero outside [s, t)), for every i < EIGH_LD
+    __builtin_amdgcn_wave_barrier();
+    for (int i = sub; i < EIGH_LD; i += 16) {
+        float z = 0.0f;
+        if (live && i >= s && i < t) z = (i <= r ? fw[i] : bw[i]) * rn;
+        __builtin_amdgcn_wave_barrier();
+        fw[i] = z;
+    }
+    __syncthreads();
+    // ---- Z[i][j0 + jj] for the 16 slots of this workgroup: 64-byte segments
+    float* Z = q.Z + (size_t)g * EIGH_LD * EIGH_LD + blockIdx.x * 16;
+    for (int idx = tid; idx < EIGH_LD * 16; idx += EIGH_SOLVE_THREADS) {
+        const int i = idx >> 4, jj = idx & 15;
+        Z[(size_t)i * EIGH_LD + jj] = L.fw[jj][i];
+    }
+    if (tid < 16 && blockIdx.x * 16 + tid >= n) q.lam[(size_t)g * EIGH_LD + blockIdx.x * 16 + tid] = -3.0e38f;   // padding slots sort last
+}
+
+// T factor of reflector block b (reflectors 32 b .. 32 b + 31):  H_{32b} ... H_{32b+31} = I - V T V^T, T upper triangular
+// (LAPACK slarft, forward / columnwise):  T[c][c] = tau_c,  T[0:c, c] = -tau_c T[0:c, 0:c] (V^T V)[0:c, c].
+// One 256-thread workgroup: the 32 reflector rows into LDS, S = V^T V by 4 entries per thread, then lane a of wave 0
+// builds row a of T.
+__device__ __forceinline__ void eigh_tfactor_block(const EighArgs& q, int g, int b, float* smem) {
+    float (*V)[EIGH_LD + 1] = reinterpret_cast<float (*)[EIGH_LD + 1]>(smem);         // [32][EIGH_LD + 1]
+    float (*S)[33] = reinterpret_cast<float (*)[33]>(smem + 32 * (EIGH_LD + 1));      // [32][33]
+    const int tid = threadIdx.x;
+    const float* Vt = q.Vt + (size_t)g * EIGH_LD * EIGH_LD + (size_t)(32 * b) * EIGH_LD;
+    const float* tau = q.tau + (size_t)g * EIGH_LD + 32 * b;
+    for (int idx = tid; idx < 32 * EIGH_LD; idx += EIGH_SOLVE_THREADS) V[idx / EIGH_LD][idx % EIGH_LD] = Vt[idx];
+    __syncthreads();
+    {
+        const int a = tid >> 3, c0 = (tid & 7) * 4;
+        float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < EIGH_LD; ++i) {
+            const float va = V[a][i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s4[c] = fmaf(va, V[c0 + c][i], s4[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) S[a][c0 + c] = s4[c];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int a = tid;
+        float trow[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            float s = 0.0f;
+#pragma unroll
+            for (int mm = 0; mm < c; ++mm) s = fmaf(trow[mm], S[mm][c], s);
+            const float tc = tau[c];
+            trow[c] = a == c ? tc : (a < c ? -(tc * s) : 0.0f);
+        }
+        float* Tf = q.Tf + ((size_t)g * EIGH_TF_WGS + b) * 32 * 32 + (size_t)a * 32;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) Tf[c] = trow[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3. Newton-Schulz polish of the eigenvector matrix in the tridiagonal basis:  Z <- Z (1.5 I - 0.5 Z^T Z).
+// The twisted vectors of eigenvalues closer than ~1e-3 |T| are orthogonal to 1e-4 .. 1e-2 only (their error lies along
+// the neighbours' vectors); the polish is the symmetric orthogonalisation, so it rotates inside those near-invariant
+// subspaces and leaves Z^T T Z diagonal to the same order.  Quadratic: 1e-2 -> 1e-4 -> 1e-8; two rounds.
+// v_mfma_f32_16x16x4_f32 straight from L2 (the matrices are 400 KB), 64 x 64 tile per workgroup.
+//   MODE 0:  P = 1.5 I - 0.5 A^T A   and  flags[slot] = max |A^T A - I|        (fragments contiguous for a fixed k)
+//   MODE 1:  Zout = A P                                                        (a lane's four k of A are one 16-byte load)
+// grid (EIGH_LD / 64, EIGH_LD / 64, G), block 256
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_eigh_gemm(EighArgs q, const float* __restrict__ A_all, const float* __restrict__ P_all,
+                                                    float* __restrict__ out_all, int slot) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int g = blockIdx.z, n = q.n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int r0 = blockIdx.y * 64 + wave * 16, c0 = blockIdx.x * 64;
+    const float* A = A_all + (size_t)g * EIGH_LD * EIGH_LD;
+    float* out = out_all + (size_t)g * EIGH_LD * EIGH_LD;
+    f4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (MODE == 0) {
+        // out[a][b] = sum_i A[i][a] A[i][b]
+        const float* pa = A + r0 + lm;
+        const float* pb = A + c0 + lm;
+#pragma unroll 4
+        for (int k0 = 0; k0 < EIGH_LD; k0 += 4) {
+            const size_t kr = (size_t)(k0 + lk) * EIGH_LD;
+            const float a = pa[kr];
+            const float b0 = pb[kr], b1 = pb[kr + 16], b2 = pb[kr + 32], b3 = pb[kr + 48];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b3, acc[3], 0, 0, 0);
+        }
+        float dmax = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + 4 * lk + r;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int col = c0 + 16 * f + lm;
+                const float gv = acc[f][r], id = row == col ? 1.0f : 0.0f;
+                if (row < n && col < n) dmax = fmaxf(dmax, fabsf(gv - id));
+                out[(size_t)row * EIGH_LD + col] = (row < n && col < n) ? fmaf(-0.5f, gv, 1.5f * id) : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
+        if (lane == 0) atomicMax(q.flags + (size_t)g * 8 + slot, __float_as_uint(dmax));
+    } else {
+        // out[i][c] = sum_b A[i][b] P[b][c]
+        const float* P = P_all + (size_t)g * EIGH_LD * EIGH_LD;
+        const float* pa = A + (size_t)(r0 + lm) * EIGH_LD + 4 * lk;
+        const float* pb = P + c0 + lm;
+#pragma unroll 2
+        for (int k0 = 0; k0 < EIGH_LD; k0 += 16) {
+            const float4 a4 = *reinterpret_cast<const float4*>(pa + k0);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t kr = (size_t)(k0 + 4 * lk + r) * EIGH_LD;
+                const float b0 = pb[kr], b1 = pb[kr + 16], b2 = pb[kr + 32], b3 = pb[kr + 48];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], b1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], b2, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], b3, acc[3], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + 4 * lk + r;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) out[(size_t)row * EIGH_LD + c0 + 16 * f + lm] = acc[f][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 4. Back-transformation B = Q Z,  Q = H_0 H_1 ... H_{n-3} = prod_b (I - V_b T_b V_b^T)  (blocks of 32 reflectors, stage 2's
+// T factors), applied from the last block to the first.  The columns of Z are independent: one workgroup per slab of
+// 16 columns, the slab (EIGH_LD x 16) in registers as twenty 16 x 16 MFMA accumulator tiles, five per wave.  Per block:
+//   W1 = V_b^T Zs    each wave over its row tiles (the accumulator registers ARE the B operands: register r of a tile
+//                    holds rows 4 (lane / 16) + r, the k-partition of the four MFMAs); partial sums meet in LDS
+//   W2 = T_b W1      32 x 32 by 32 x 16, every wave for itself
+//   Zs -= V_b W2
+// Row tiles entirely above the block's first reflector row see only zeros of V and are skipped.
+// Epilogue: eigenvalue + alpha, ranks by descending value (ties: lower slot first), D = sqrt, B[i][rank].
+// grid (EIGH_LD / 16, G), block 256
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, const float* __restrict__ Z_all) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ float w1p[4][32][17];            // per-wave partial W1
+    __shared__ float w1[32][17];
+    __shared__ float w2[32][17];
+    __shared__ float tf[32][33];
+    __shared__ float s_lam[EIGH_LD];
+    __shared__ int s_rank[16];
+    const int g = blockIdx.y, n = q.n, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, lm = lane & 15, lk = lane >> 4;
+    const int j0 = blockIdx.x * 16;
+    const float* Z = Z_all + (size_t)g * EIGH_LD * EIGH_LD;
+    const float* Vt = q.Vt + (size_t)g * EIGH_LD * EIGH_LD;
+    // slab: wave w owns row tiles w, w + 4, ..., w + 16
+    f4 zs[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int i0 = 16 * (wave + 4 * u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zs[u][r] = Z[(size_t)(i0 + 4 * lk + r) * EIGH_LD + j0 + lm];
+    }
+    const int nblk = (n - 2 + 31) / 32;
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int first_tile = (32 * b + 1) / 16;                  // reflector 32 b has its leading 1 in row 32 b + 1
+        // T factor of the block
+        for (int idx = tid; idx < 32 * 32; idx += 256) tf[idx >> 5][idx & 31] = q.Tf[((size_t)g * EIGH_TF_WGS + b) * 1024 + idx];
+        // ---- W1 partial of this wave
+        f4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int tile = wave + 4 * u, i0 = 16 * tile;
+            if (tile < first_tile) continue;
+            const float4 va = *reinterpret_cast<const float4*>(Vt + (size_t)(32 * b + lm) * EIGH_LD + i0 + 4 * lk);
+            const float4 vb = *reinterpret_cast<const float4*>(Vt + (size_t)(32 * b + 16 + lm) * EIGH_LD + i0 + 4 * lk);
+            const float a0[4] = {va.x, va.y, va.z, va.w}, a1[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], zs[u][r], p0, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], zs[u][r], p1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { w1p[wave][4 * lk + r][lm] = p0[r]; w1p[wave][16 + 4 * lk + r][lm] = p1[r]; }
+        __syncthreads();
+        for (int idx = tid; idx < 32 * 16; idx += 256) {
+            const int a = idx >> 4, c = idx & 15;
+            w1[a][c] = (w1p[0][a][c] + w1p[1][a][c]) + (w1p[2][a][c] + w1p[3][a][c]);
+        }
+        __syncthreads();
+        // ---- W2 = T W1 (wave 0 and 1: one 16-row half each)
+        if (wave < 2) {
+            f4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k0 = 0; k0 < 32; k0 += 4) o = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[16 * wave + lm][k0 + lk], w1[k0 + lk][lm], o, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w2[16 * wave + 4 * lk + r][lm] = o[r];
+        }
+        __syncthreads();
+        // ---- Zs -= V W2
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int tile = wave + 4 * u, i0 = 16 * tile;
+            if (tile < first_tile) continue;
+#pragma unroll
+            for (int k0 = 0; k0 < 32; k0 += 4) {
+                const float a = Vt[(size_t)(32 * b + k0 + lk) * EIGH_LD + i0 + lm];
+                zs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a, w2[k0 + lk][lm], zs[u], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- ranks of this slab's eigenvalues, D, B
+    const float alpha = q.alpha[g];
+    for (int i = tid; i < EIGH_LD; i += 256) s_lam[i] = q.lam[(size_t)g * EIGH_LD + i];
+    __syncthreads();
+    {
+        // 16 lanes per slot count the eigenvalues ahead of it
+        const int slot = tid >> 4, sub = tid & 15, j = j0 + slot;
+        const float lj = s_lam[j];
+        int cnt = 0;
+        for (int o = sub; o < n; o += 16) { const float lo = s_lam[o]; cnt += (lo > lj || (lo == lj && o < j)) ? 1 : 0; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (sub == 0) {
+            s_rank[slot] = cnt;
+            if (j < n) q.Dd[(size_t)g * n + cnt] = sqrtf(fabsf(lj + alpha));    // D = sqrt(s), s = |eigenvalue| (cma_es.py:195-197)
+        }
+    }
+    __syncthreads();
+    if (j0 + lm < n) {
+        float* B = q.B + (size_t)g * n * n + s_rank[lm];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int i0 = 16 * (wave + 4 * u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 4 * lk + r;
+                if (i < n) B[(size_t)i * n] = zs[u][r];
+            }
+        }
+    }
 }
 
 }  // namespace bbmpc

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "../../blackbox_mpc_amd/csrc/kernels_eigh.hpp"
 using namespace bbmpc;
@@ -21,7 +22,7 @@ int main(int argc, char** argv) {
     if (fread(mats.data(), 4, mats.size(), f) != mats.size()) return 1;
     fclose(f);
     printf("n = %d, %d matrices\n", n, cnt);
-    const int G = cnt;
+    const int G = argc > 2 ? atoi(argv[2]) : cnt;
     EighArgs q{};
     q.n = n; q.G = G;
     float* dC;
@@ -30,6 +31,9 @@ int main(int argc, char** argv) {
     const size_t LD = EIGH_LD, MAT = LD * LD;
     CK(hipMalloc(&q.d, G * LD * 4)); CK(hipMalloc(&q.e, G * LD * 4)); CK(hipMalloc(&q.tau, G * LD * 4)); CK(hipMalloc(&q.alpha, G * 4));
     CK(hipMalloc(&q.Vt, G * MAT * 4));
+    CK(hipMalloc(&q.lam, G * LD * 4)); CK(hipMalloc(&q.Z, G * MAT * 4)); CK(hipMalloc(&q.Z2, G * MAT * 4)); CK(hipMalloc(&q.P, G * MAT * 4));
+    CK(hipMalloc(&q.Tf, G * (LD / 32) * 1024 * 4)); CK(hipMalloc(&q.flags, G * 8 * 4)); CK(hipMemset(q.flags, 0, G * 8 * 4));
+    CK(hipMalloc(&q.B, (size_t)G * n * n * 4)); CK(hipMalloc(&q.Dd, G * n * 4));
     CK(hipMemset(q.Vt, 0xff, G * MAT * 4));
     CK(hipFuncSetAttribute((const void*)k_eigh_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EighTriLds)));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -52,7 +56,106 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(d.data(), q.d, d.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(e.data(), q.e, e.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(tau.data(), q.tau, tau.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(al.data(), q.alpha, G * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(Vt.data(), q.Vt, Vt.size() * 4, hipMemcpyDeviceToHost));
-    for (int g = 0; g < G; ++g) {
+    // ---- stage 2
+    const size_t lds2 = sizeof(EighSolveLds) > (32 * (EIGH_LD + 1) + 32 * 33) * 4 ? sizeof(EighSolveLds) : (32 * (EIGH_LD + 1) + 32 * 33) * 4;
+    CK(hipFuncSetAttribute((const void*)k_eigh_tri_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_eigh_tri_solve, dim3(EIGH_SLOT_WGS + EIGH_TF_WGS, G), dim3(EIGH_SOLVE_THREADS), lds2, 0, q);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("k_eigh_tri_solve: %.1f us (%d instances)\n", ms * 1e3, G);
+    }
+    CK(hipGetLastError());
+    std::vector<float> lam(G * LD), Z(G * MAT), Tf(G * (LD / 32) * 1024);
+    std::vector<unsigned> flags(G * 8);
+    CK(hipMemcpy(lam.data(), q.lam, lam.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(Z.data(), q.Z, Z.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(Tf.data(), q.Tf, Tf.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(flags.data(), q.flags, flags.size() * 4, hipMemcpyDeviceToHost));
+    for (int g = 0; g < (argc > 3 ? G : 0); ++g) {
+        const float* dg = &d[g * LD]; const float* eg = &e[g * LD]; const float* Zg = &Z[g * MAT];
+        double tn = 0; for (int i = 0; i < n; ++i) tn = fmax(tn, fmax(fabs(dg[i]), i < n - 1 ? fabs(eg[i]) : 0.0));
+        // residual |T z - lam z| and orthogonality in double
+        double maxres = 0, maxorth = 0;
+        for (int j = 0; j < n; ++j) {
+            double r2 = 0;
+            for (int i = 0; i < n; ++i) {
+                double tz = dg[i] * (double)Zg[i * LD + j];
+                if (i > 0) tz += eg[i - 1] * (double)Zg[(i - 1) * LD + j];
+                if (i < n - 1) tz += eg[i] * (double)Zg[(i + 1) * LD + j];
+                const double rr = tz - (double)lam[g * LD + j] * Zg[i * LD + j];
+                r2 += rr * rr;
+            }
+            maxres = fmax(maxres, sqrt(r2));
+        }
+        for (int a = 0; a < n; ++a) for (int b = a; b < n; ++b) {
+            double s = 0; for (int i = 0; i < n; ++i) s += (double)Zg[i * LD + a] * Zg[i * LD + b];
+            maxorth = fmax(maxorth, fabs(s - (a == b ? 1.0 : 0.0)));
+        }
+        float fr; memcpy(&fr, &flags[g * 8 + 2], 4);
+        printf("instance %d: |T| %.3e  max|Tz - lam z| %.3e (device says %.3e)  max|Z^T Z - I| %.3e\n", g, tn, maxres, fr, maxorth);
+        // T factors: I - V T V^T orthogonal?  check block 0 and the last block against the product of reflectors
+        for (int b : {0, (n - 3) / 32}) {
+            std::vector<double> Qb((size_t)n * n, 0.0), Qr((size_t)n * n, 0.0);
+            for (int i = 0; i < n; ++i) Qr[(size_t)i * n + i] = 1.0;
+            for (int k = 32 * b + 31; k >= 32 * b; --k) {      // Qr = H_{32b} ... H_{32b+31}
+                const float* v = &Vt[g * MAT + k * LD]; const double tk = tau[g * LD + k];
+                for (int c = 0; c < n; ++c) { double s = 0; for (int i = 0; i < n; ++i) s += (double)v[i] * Qr[(size_t)i * n + c]; s *= tk; for (int i = 0; i < n; ++i) Qr[(size_t)i * n + c] -= (double)v[i] * s; }
+            }
+            double maxd = 0;
+            const float* T = &Tf[((size_t)g * (LD / 32) + b) * 1024];
+            for (int i = 0; i < n; ++i) for (int c = 0; c < n; ++c) {
+                double s = (i == c) ? 1.0 : 0.0;
+                for (int a2 = 0; a2 < 32; ++a2) { double tv = 0; for (int c2 = 0; c2 < 32; ++c2) tv += (double)T[a2 * 32 + c2] * Vt[g * MAT + (32 * b + c2) * LD + c]; s -= (double)Vt[g * MAT + (32 * b + a2) * LD + i] * tv; }
+                maxd = fmax(maxd, fabs(s - Qr[(size_t)i * n + c]));
+            }
+            printf("   T factor block %d: max|I - V T V^T - H..H| %.3e\n", b, maxd);
+        }
+    }
+    // ---- stages 3, 4
+    auto polish_and_back = [&]() {
+        const dim3 gg(EIGH_LD / 64, EIGH_LD / 64, G);
+        hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, 0, q, (const float*)q.Z, (const float*)nullptr, q.P, 1);
+        hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, 0, q, (const float*)q.Z, (const float*)q.P, q.Z2, 0);
+        hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, 0, q, (const float*)q.Z2, (const float*)nullptr, q.P, 3);
+        hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, 0, q, (const float*)q.Z2, (const float*)q.P, q.Z, 0);
+        hipLaunchKernelGGL(k_eigh_backtransform, dim3(EIGH_LD / 16, G), dim3(256), 0, 0, q, (const float*)q.Z);
+    };
+    for (int rep = 0; rep < 3; ++rep) {
+        // (the polish overwrites Z: run the whole pipeline per repetition)
+        CK(hipMemset(q.flags, 0, G * 8 * 4));
+        float ms[4];
+        hipEvent_t ev[5]; for (auto& x : ev) CK(hipEventCreate(&x));
+        CK(hipEventRecord(ev[0]));
+        hipLaunchKernelGGL(k_eigh_tridiag, dim3(G), dim3(EIGH_TRI_THREADS), sizeof(EighTriLds), 0, q);
+        CK(hipEventRecord(ev[1]));
+        hipLaunchKernelGGL(k_eigh_tri_solve, dim3(EIGH_SLOT_WGS + EIGH_TF_WGS, G), dim3(EIGH_SOLVE_THREADS), lds2, 0, q);
+        CK(hipEventRecord(ev[2]));
+        polish_and_back();
+        CK(hipEventRecord(ev[3])); CK(hipEventSynchronize(ev[3]));
+        CK(hipGetLastError());
+        for (int i = 0; i < 3; ++i) CK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+        CK(hipEventElapsedTime(&ms[3], ev[0], ev[3]));
+        printf("pipeline: tridiag %.1f  tri_solve %.1f  polish+back %.1f  total %.1f us (%d instances)\n", ms[0] * 1e3, ms[1] * 1e3, ms[2] * 1e3, ms[3] * 1e3, G);
+    }
+    {
+        std::vector<float> B((size_t)G * n * n), Dd((size_t)G * n);
+        CK(hipMemcpy(B.data(), q.B, B.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(Dd.data(), q.Dd, Dd.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(flags.data(), q.flags, flags.size() * 4, hipMemcpyDeviceToHost));
+        for (int g = 0; g < G; ++g) {
+            const float* Bg = &B[(size_t)g * n * n]; const float* Cg = &mats[(size_t)g * n * n];
+            double rec = 0, orth = 0, sortbad = 0;
+            for (int i = 0; i < n; ++i) for (int j = i; j < n; ++j) {
+                double s = 0, o = 0;
+                for (int k2 = 0; k2 < n; ++k2) { const double dd = Dd[(size_t)g * n + k2]; s += (double)Bg[(size_t)i * n + k2] * dd * dd * Bg[(size_t)j * n + k2]; o += (double)Bg[(size_t)k2 * n + i] * Bg[(size_t)k2 * n + j]; }
+                if (!(fabs(s) < 1e30) || !(fabs(o) < 1e30)) { rec = orth = 1e30; } rec = fmax(rec, fabs(s - Cg[(size_t)i * n + j])); orth = fmax(orth, fabs(o - (i == j ? 1.0 : 0.0)));
+            }
+            for (int k2 = 1; k2 < n; ++k2) if (Dd[(size_t)g * n + k2] > Dd[(size_t)g * n + k2 - 1]) sortbad += 1;
+            float f1, f3, f2; memcpy(&f1, &flags[g * 8 + 1], 4); memcpy(&f3, &flags[g * 8 + 3], 4); memcpy(&f2, &flags[g * 8 + 2], 4);
+            printf("final %d: max|B D^2 B^T - C| %.3e  max|B^T B - I| %.3e  unsorted %g  D[0] %.5f D[n-1] %.5f  |ZtZ-I| before %.2e after one round %.2e  resid %.2e\n",
+                   g, rec, orth, sortbad, Dd[(size_t)g * n], Dd[(size_t)g * n + n - 1], f1, f3, f2);
+        }
+    }
+    for (int g = 0; g < (argc > 3 ? G : 0); ++g) {
         // Q = H_0 ... H_{n-3} in double; R = Q^T E Q - T
         std::vector<double> Q((size_t)n * n, 0.0), E((size_t)n * n);
         for (int i = 0; i < n; ++i) Q[(size_t)i * n + i] = 1.0;
