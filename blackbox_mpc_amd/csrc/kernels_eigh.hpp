@@ -527,6 +527,7 @@ struct EighSolveLds {
     float fw[16][EIGH_LD + 4];  // per slot: D+ pivots, then the upper part of z
     float bw[16][EIGH_LD + 4];  // per slot: D- pivots, then the lower part of z
     float red[8];
+    short bs[EIGH_LD], bt[EIGH_LD];   // unreduced block [bs[i], bt[i]) around index i
 };
 
 __device__ __forceinline__ float row16_max(float v) { return -row16_min(-v); }
@@ -541,6 +542,12 @@ __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs 
         return;
     }
     EighSolveLds& L = *reinterpret_cast<EighSolveLds*>(eigh_smem2);
+#ifdef EIGH_CLK
+    long long tl_ = (long long)__builtin_readcyclecounter(), clk_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SOLVE_MARK(i) do { const long long now_ = (long long)__builtin_readcyclecounter(); clk_[i] += now_ - tl_; tl_ = now_; } while (0)
+#else
+#define SOLVE_MARK(i) do {} while (0)
+#endif
     const float* d = q.d + (size_t)g * EIGH_LD;
     const float* e = q.e + (size_t)g * EIGH_LD;
     const float alpha = q.alpha[g];
@@ -598,33 +605,75 @@ __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs 
     const float pivmin = fmaxf(1.0e-30f, tn * tn * 1.0e-30f);
     const int j = blockIdx.x * 16 + row;                          // eigenvalue slot of this 16-lane row
     const bool live = j < n;
-    // ---- the unreduced block [s, t) around index j
-    int s = live ? j : 0, t = live ? j + 1 : 1;
-    while (s > 0 && L.ee[s - 1] != 0.0f) --s;
-    while (t < n && L.ee[t - 1] != 0.0f) ++t;
+    // ---- the unreduced block [s, t) around every index: running maximum of the split positions from the left, running
+    // minimum from the right (log-step scans over the 320 entries, two per thread)
+    for (int i = tid; i < EIGH_LD; i += EIGH_SOLVE_THREADS) {
+        L.bs[i] = (short)((i == 0 || i >= n || L.ee[i - 1] == 0.0f) ? i : 0);
+        L.bt[i] = (short)((i >= n - 1 || L.ee[i] == 0.0f) ? i + 1 : EIGH_LD);
+    }
+    __syncthreads();
+    for (int off = 1; off < EIGH_LD; off <<= 1) {
+        short vs[2], vt[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = tid + it * EIGH_SOLVE_THREADS;
+            if (i < EIGH_LD) {
+                vs[it] = i >= off ? max(L.bs[i], L.bs[i - off]) : L.bs[i];
+                vt[it] = i + off < EIGH_LD ? min(L.bt[i], L.bt[i + off]) : L.bt[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = tid + it * EIGH_SOLVE_THREADS;
+            if (i < EIGH_LD) { L.bs[i] = vs[it]; L.bt[i] = vt[it]; }
+        }
+        __syncthreads();
+    }
+    const int s = live ? (int)L.bs[j] : 0, t = live ? (int)L.bt[j] : 1;
     const int m = (live ? j : 0) - s;
-    // ---- multisection
+    SOLVE_MARK(0);
+    // ---- multisection: 32 shifts per slot and pass (two per lane: two independent chains share the latency of the
+    // reciprocal), five passes of 33-fold narrowing.  d and e^2 come from LDS four steps at a time, one group ahead of
+    // the chain.  (Measured and dropped: the product form p_{i+1} = (d_i - x) p_i - e^2 p_{i-1} with a power-of-two
+    // rescale every four steps -- one FMA on the chain instead of rcp / mul / sub / pivmin test, but more instructions
+    // per step, and with one wave per SIMD the loop is issue bound: 190 against 137 cycles per step.)
     float lo = gl, hi = gu;
     if (t - s > 1) {
-        for (int pass = 0; pass < 7; ++pass) {
-            const float h = (hi - lo) * (1.0f / 17.0f);
-            const float x = fmaf((float)(sub + 1), h, lo);
-            int cnt = 0;
-            float qv = 1.0f;
-#pragma unroll 4
-            for (int i = 0; i < n; ++i) {
-                qv = (L.dd[i] - x) - L.e2p[i] * __builtin_amdgcn_rcpf(qv);
-                qv = fabsf(qv) < pivmin ? -pivmin : qv;
-                cnt += (i >= s && i < t && qv < 0.0f) ? 1 : 0;
+        const float4* dd4 = reinterpret_cast<const float4*>(L.dd);
+        const float4* e24 = reinterpret_cast<const float4*>(L.e2p);
+        const int n4 = (n + 3) >> 2;                              // (entries beyond n are zero and lie outside every block)
+        for (int pass = 0; pass < 5; ++pass) {
+            const float h = (hi - lo) * (1.0f / 33.0f);
+            const float xa = fmaf((float)(sub + 1), h, lo), xb = fmaf((float)(sub + 17), h, lo);
+            int ca = 0, cb = 0;
+            float qa = 1.0f, qb = 1.0f;
+            float4 dA = dd4[0], eA = e24[0];
+            for (int i4 = 0; i4 < n4; ++i4) {
+                const float4 dB = dd4[i4 + 1], eB = e24[i4 + 1];  // (one group ahead; the arrays are followed by more LDS)
+                const float dv[4] = {dA.x, dA.y, dA.z, dA.w}, ev[4] = {eA.x, eA.y, eA.z, eA.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int i = 4 * i4 + c;
+                    const bool in = (unsigned)(i - s) < (unsigned)(t - s);
+                    qa = (dv[c] - xa) - ev[c] * __builtin_amdgcn_rcpf(qa);
+                    qb = (dv[c] - xb) - ev[c] * __builtin_amdgcn_rcpf(qb);
+                    qa = fabsf(qa) < pivmin ? -pivmin : qa;
+                    qb = fabsf(qb) < pivmin ? -pivmin : qb;
+                    ca += (in && qa < 0.0f) ? 1 : 0;
+                    cb += (in && qb < 0.0f) ? 1 : 0;
+                }
+                dA = dB; eA = eB;
             }
-            // eigenvalue m of the block lies above every shift with cnt <= m and not above any shift with cnt > m
-            const float below = cnt <= m ? x : lo, above = cnt > m ? x : hi;
+            // eigenvalue m of the block lies above every shift with count <= m and not above any shift with count > m
+            const float below = cb <= m ? xb : (ca <= m ? xa : lo), above = ca > m ? xa : (cb > m ? xb : hi);
             lo = row16_max(below); hi = row16_min(above);
             if (!(hi > lo)) hi = lo;
         }
     } else {
         lo = hi = L.dd[s];
     }
+    SOLVE_MARK(1);
     const float lam = 0.5f * (lo + hi);
     // ---- twisted factorisation of T - lam on [s, t)
     float* fw = L.fw[row];
@@ -643,12 +692,13 @@ __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs 
                 if (st + 1 < len) {
                     const int in = fwd ? i + 1 : i - 1;
                     const float ec = fwd ? L.ee[i] : L.ee[i - 1];           // coupling between i and the next index
-                    piv = (L.dd[in] - lam) - (ec / piv) * ec;
+                    piv = (L.dd[in] - lam) - (ec * __builtin_amdgcn_rcpf(piv)) * ec;     // (1-ulp reciprocal: the chain is the cost)
                 }
             }
         }
     }
     __builtin_amdgcn_wave_barrier();
+    SOLVE_MARK(2);
     // gamma_i = D+_i + D-_i - (d_i - lam); r = argmin |gamma_i|
     float gmin = 3.0e38f;
     int rbest = s;
@@ -664,18 +714,20 @@ __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs 
     }
     const int r = rbest;
     __builtin_amdgcn_wave_barrier();
+    SOLVE_MARK(3);
     // z_r = 1;  upwards z_i = -(e_i / D+_i) z_{i+1};  downwards z_{i+1} = -(e_i / D-_{i+1}) z_i
     // (z_i overwrites D+_i for i <= r and D-_i for i > r)
     if (sub < 2) {
         const bool up = sub == 0;
         float z = 1.0f;
         if (up) {
-            for (int i = r - 1; i >= s; --i) { z = -(L.ee[i] / fw[i]) * z; fw[i] = z; }
+            for (int i = r - 1; i >= s; --i) { z = -(L.ee[i] * __builtin_amdgcn_rcpf(fw[i])) * z; fw[i] = z; }
         } else {
-            for (int i = r; i < t - 1; ++i) { z = -(L.ee[i] / bw[i + 1]) * z; bw[i + 1] = z; }
+            for (int i = r; i < t - 1; ++i) { z = -(L.ee[i] * __builtin_amdgcn_rcpf(bw[i + 1])) * z; bw[i + 1] = z; }
         }
     }
     __builtin_amdgcn_wave_barrier();
+    SOLVE_MARK(4);
     if (sub == 0) fw[r] = 1.0f;
     __builtin_amdgcn_wave_barrier();
     float zz = 0.0f;
@@ -696,6 +748,7 @@ __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs 
         fw[i] = z;
     }
     __syncthreads();
+    SOLVE_MARK(5);
     // ---- Z[i][j0 + jj] for the 16 slots of this workgroup: 64-byte segments
     float* Z = q.Z + (size_t)g * EIGH_LD * EIGH_LD + blockIdx.x * 16;
     for (int idx = tid; idx < EIGH_LD * 16; idx += EIGH_SOLVE_THREADS) {
@@ -703,6 +756,10 @@ __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs 
         Z[(size_t)i * EIGH_LD + jj] = L.fw[jj][i];
     }
     if (tid < 16 && blockIdx.x * 16 + tid >= n) q.lam[(size_t)g * EIGH_LD + blockIdx.x * 16 + tid] = -3.0e38f;   // padding slots sort last
+    SOLVE_MARK(6);
+#ifdef EIGH_CLK
+    if (blockIdx.x == 9 && blockIdx.y == 1 && tid == 0) for (int i = 0; i < 8; ++i) g_eigh_clk[i] = clk_[i];
+#endif
 }
 
 // T factor of reflector block b (reflectors 32 b .. 32 b + 31):  H_{32b} ... H_{32b+31} = I - V T V^T, T upper triangular

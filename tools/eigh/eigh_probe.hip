@@ -22,7 +22,9 @@ int main(int argc, char** argv) {
     if (fread(mats.data(), 4, mats.size(), f) != mats.size()) return 1;
     fclose(f);
     printf("n = %d, %d matrices\n", n, cnt);
+    const int off = argc > 3 ? atoi(argv[3]) : 0;
     const int G = argc > 2 ? atoi(argv[2]) : cnt;
+    if (off) mats.erase(mats.begin(), mats.begin() + (size_t)off * n * n);
     EighArgs q{};
     q.n = n; q.G = G;
     float* dC;
@@ -66,12 +68,27 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("k_eigh_tri_solve: %.1f us (%d instances)\n", ms * 1e3, G);
     }
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_eigh_tri_solve, dim3(EIGH_SLOT_WGS, G), dim3(EIGH_SOLVE_THREADS), lds2, 0, q);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("k_eigh_tri_solve, slot workgroups only: %.1f us\n", ms * 1e3);
+    }
+#ifdef EIGH_CLK
+    {
+        long long clk[16];
+        CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(bbmpc::g_eigh_clk), sizeof(clk)));
+        const char* nm[7] = {"setup+scans", "multisection", "qd recurrences", "argmin", "z recurrences", "normalise", "write Z"};
+        for (int i = 0; i < 7; ++i) printf("  tri_solve %-16s %8lld cycles\n", nm[i], clk[i]);
+    }
+#endif
     CK(hipGetLastError());
     std::vector<float> lam(G * LD), Z(G * MAT), Tf(G * (LD / 32) * 1024);
     std::vector<unsigned> flags(G * 8);
     CK(hipMemcpy(lam.data(), q.lam, lam.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(Z.data(), q.Z, Z.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(Tf.data(), q.Tf, Tf.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(flags.data(), q.flags, flags.size() * 4, hipMemcpyDeviceToHost));
-    for (int g = 0; g < (argc > 3 ? G : 0); ++g) {
+    for (int g = 0; g < (argc > 4 ? G : 0); ++g) {
         const float* dg = &d[g * LD]; const float* eg = &e[g * LD]; const float* Zg = &Z[g * MAT];
         double tn = 0; for (int i = 0; i < n; ++i) tn = fmax(tn, fmax(fabs(dg[i]), i < n - 1 ? fabs(eg[i]) : 0.0));
         // residual |T z - lam z| and orthogonality in double
@@ -132,6 +149,19 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(ev[2]));
         polish_and_back();
         CK(hipEventRecord(ev[3])); CK(hipEventSynchronize(ev[3]));
+        {   // the five launches of stages 3, 4 one by one (results unchanged: the polish of an orthogonal Z is the identity)
+            const dim3 gg(EIGH_LD / 64, EIGH_LD / 64, G);
+            hipEvent_t f[6]; for (auto& x : f) CK(hipEventCreate(&x));
+            CK(hipEventRecord(f[0]));
+            hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, 0, q, (const float*)q.Z, (const float*)nullptr, q.P, 4);
+            CK(hipEventRecord(f[1]));
+            hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, 0, q, (const float*)q.Z, (const float*)q.P, q.Z2, 0);
+            CK(hipEventRecord(f[2]));
+            hipLaunchKernelGGL(k_eigh_backtransform, dim3(EIGH_LD / 16, G), dim3(256), 0, 0, q, (const float*)q.Z);
+            CK(hipEventRecord(f[3])); CK(hipEventSynchronize(f[3]));
+            float a, b, c; CK(hipEventElapsedTime(&a, f[0], f[1])); CK(hipEventElapsedTime(&b, f[1], f[2])); CK(hipEventElapsedTime(&c, f[2], f[3]));
+            if (rep == 2) printf("   single launches: gram %.1f  multiply %.1f  backtransform %.1f us\n", a * 1e3, b * 1e3, c * 1e3);
+        }
         CK(hipGetLastError());
         for (int i = 0; i < 3; ++i) CK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
         CK(hipEventElapsedTime(&ms[3], ev[0], ev[3]));
@@ -155,7 +185,7 @@ int main(int argc, char** argv) {
                    g, rec, orth, sortbad, Dd[(size_t)g * n], Dd[(size_t)g * n + n - 1], f1, f3, f2);
         }
     }
-    for (int g = 0; g < (argc > 3 ? G : 0); ++g) {
+    for (int g = 0; g < (argc > 4 ? G : 0); ++g) {
         // Q = H_0 ... H_{n-3} in double; R = Q^T E Q - T
         std::vector<double> Q((size_t)n * n, 0.0), E((size_t)n * n);
         for (int i = 0; i < n; ++i) Q[(size_t)i * n + i] = 1.0;
