@@ -175,6 +175,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         HIP_CHECK(hipSetDevice(c.device));        // bbmpc_create restores the caller's device (DeviceGuard)
     }
     HIP_CHECK(hipGetDevice(&device));
+    HIP_CHECK(hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, device));
     {   // control steps are latency-critical, and a resident control-step kernel must not hold back unrelated work of the
         // process: hardware queues are pooled per priority, so the handle's streams live in the high-priority pool, away
         // from PyTorch's and the caller's normal-priority streams (the handles among themselves: stop_foreign_residents)
@@ -193,6 +194,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.cma_svd_general = flag("BBMPC_CMA_SVD_GENERAL");
         sw.cma_svd_gram = flag("BBMPC_CMA_SVD_GRAM");
         sw.cma_coop = flag("BBMPC_CMA_COOP"); sw.cma_nb = ival("BBMPC_CMA_NB", 0);
+        sw.cma_eigh = ival("BBMPC_CMA_EIGH", 1);
         sw.cma_fused = flag("BBMPC_CMA_FUSED");
         sw.mlp_generic = flag("BBMPC_MLP_GENERIC");
         { const int b = ival("BBMPC_MLP_BF16", 0); sw.mlp_bf16 = (b == 1 || b == 3) ? b : 0; }
@@ -458,6 +460,14 @@ void Engine::cma_init() {
     c_eidx.alloc((size_t)G * k);
     c_info.alloc(gn);           // SVD: column permutation
     c_sync.alloc((size_t)G * CMA_SYNC_WORDS);
+    if (cma_use_eigh()) {
+        const size_t ld = EIGH_LD, mat = ld * ld;
+        e_d.alloc(G * ld); e_e.alloc(G * ld); e_tau.alloc(G * ld); e_alpha.alloc(G); e_lam.alloc(G * ld);
+        e_Vt.alloc(G * mat); e_Z.alloc(G * mat); e_Z2.alloc(G * mat); e_P.alloc(G * mat);
+        e_Tf.alloc((size_t)G * EIGH_TF_WGS * 1024);
+        e_flags.alloc((size_t)G * 8);
+        e_flags.zero(stream);
+    }
     // C = B = D = I, paths = 0 (cma_es.py:98-117)
     std::vector<float> eye(gnn, 0.0f), ones(gn, 1.0f);
     for (int g = 0; g < G; ++g)
@@ -500,6 +510,31 @@ CmaArgs Engine::cma_args(uint32_t step, uint32_t iter) {
     q.iter = iter;
     q.pop_offset = cfg.population_offset;
     return q;
+}
+
+// s, U, _ = tf.linalg.svd(C); B = U, D = diag(sqrt(s))  (cma_es.py:195-198) by the direct eigensolver of kernels_eigh.hpp:
+// eight launches on the handle's stream; instances that fail its checks keep e_flags[8 g] = 1 and B, D untouched
+void Engine::cma_eigh_launch(const CmaArgs& cq) {
+    EighArgs q;
+    memset(&q, 0, sizeof(q));
+    q.n = cma_n; q.G = cma_G;
+    q.C = cq.C; q.B = cq.B; q.Dd = cq.Dd;
+    q.d = e_d.p; q.e = e_e.p; q.tau = e_tau.p; q.Vt = e_Vt.p; q.alpha = e_alpha.p; q.lam = e_lam.p;
+    q.Z = e_Z.p; q.Z2 = e_Z2.p; q.P = e_P.p; q.Tf = e_Tf.p; q.flags = e_flags.p;
+    const int G = cma_G;
+    const size_t lds1 = sizeof(EighTriLds);
+    const size_t lds2 = std::max(sizeof(EighSolveLds), (size_t)(32 * (EIGH_LD + 1) + 32 * 33) * sizeof(float));
+    ensure_max_lds((const void*)k_eigh_tridiag, (int)lds1);
+    ensure_max_lds((const void*)k_eigh_tri_solve, (int)lds2);
+    hipLaunchKernelGGL(k_eigh_tridiag, dim3(G), dim3(EIGH_TRI_THREADS), lds1, stream, q);
+    hipLaunchKernelGGL(k_eigh_tri_solve, dim3(EIGH_SLOT_WGS + EIGH_TF_WGS, G), dim3(EIGH_SOLVE_THREADS), lds2, stream, q);
+    const dim3 gg(EIGH_LD / 64, EIGH_LD / 64, G);
+    hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, stream, q, (const float*)q.Z, (const float*)nullptr, q.P, 1);
+    hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, stream, q, (const float*)q.Z, (const float*)q.P, q.Z2, 0);
+    hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, stream, q, (const float*)q.Z2, (const float*)nullptr, q.P, 3);
+    hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, stream, q, (const float*)q.Z2, (const float*)q.P, q.Z, 0);
+    hipLaunchKernelGGL(k_eigh_backtransform, dim3(EIGH_LD / 16, G), dim3(256), 0, stream, q, (const float*)q.Z);
+    HIP_CHECK(hipGetLastError());
 }
 
 // CMAESOptimizer._optimize  cma_es.py:129-213
@@ -559,10 +594,13 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
         hipLaunchKernelGGL(k_cma_paths, dim3(G), dim3(n > 128 ? 1024 : REFIT_THREADS), 0, stream, q);
         hipLaunchKernelGGL(k_cma_cov, dim3((n + 15) / 16, (n + 15) / 16, G), dim3(16, 16), 0, stream, q);
         HIP_CHECK(hipGetLastError());
+        const bool eigh = cma_use_eigh();
+        const unsigned* need = eigh ? e_flags.p : nullptr;      // the Jacobi below then runs only for instances the direct solver gave up
+        if (eigh) cma_eigh_launch(q);
         if (n <= 512 && !sw.cma_svd_v1) {
             // warm-started Jacobi, one 1024-thread workgroup per instance (kernels_cma.hpp)
             HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * CMA_SYNC_WORDS * sizeof(unsigned), stream));
-            if (n > 128 && (n & 3) == 0) hipLaunchKernelGGL(k_cma_warm_mfma, dim3((n + 31) / 32, (n + 63) / 64, G), dim3(256), 0, stream, q, c_evec.p);
+            if (n > 128 && (n & 3) == 0) hipLaunchKernelGGL(k_cma_warm_mfma, dim3((n + 31) / 32, (n + 63) / 64, G), dim3(256), 0, stream, q, c_evec.p, need);
             else hipLaunchKernelGGL(k_cma_warm, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(256), 0, stream, q, c_evec.p);
             const int bsz = (n + 7) / 8;
             const int ncb = (n + 63) / 64;                               // k_cma_svd_block<ncb, NB>: LDS column pitch 64 * ncb
@@ -604,10 +642,14 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                     float* evp = c_evec.p;
                     unsigned* syp = c_sync.p;
                     int sweeps = 15;
-                    void* kargs[] = {(void*)&q, (void*)&evp, (void*)&syp, (void*)&sweeps};
+                    const unsigned* needp = need;
+                    void* kargs[] = {(void*)&q, (void*)&evp, (void*)&syp, (void*)&sweeps, (void*)&needp};
                     // 1-D grid, an instance's four workgroups on one XCD (kernels_cma.hpp); surplus workgroups return at once
                     const dim3 sgrid(8 * (nbk / 2) * ((G + 7) / 8)), sblock(nbk >= 16 ? 512 : 1024);
-                    if (sw.cma_coop) HIP_CHECK(hipLaunchCooperativeKernel(kfn, sgrid, sblock, kargs, blds, stream));
+                    // the plain launch is only as good as a cooperative one while every workgroup finds a CU of its own at once:
+                    // on a partition with fewer CUs (CPX / DPX modes, CU masks) the spinning barrier would wait for workgroups
+                    // that were never dispatched -- there the cooperative launch, which refuses what does not fit
+                    if (sw.cma_coop || (int)sgrid.x > cu_count) HIP_CHECK(hipLaunchCooperativeKernel(kfn, sgrid, sblock, kargs, blds, stream));
                     else HIP_CHECK(hipLaunchKernel(kfn, sgrid, sblock, kargs, blds, stream));
                 }
             } else {
@@ -630,8 +672,8 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                 }
             }
             if (n > 128 && n <= 2048) {
-                hipLaunchKernelGGL(k_cma_svd_norms, dim3(G), dim3(1024), 0, stream, q, c_evec.p, c_eval.p, c_info.p);
-                hipLaunchKernelGGL(k_cma_svd_build_b, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(32, 8), 0, stream, q, c_evec.p, c_eval.p, c_info.p);
+                hipLaunchKernelGGL(k_cma_svd_norms, dim3(G), dim3(1024), 0, stream, q, c_evec.p, c_eval.p, c_info.p, need);
+                hipLaunchKernelGGL(k_cma_svd_build_b, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(32, 8), 0, stream, q, c_evec.p, c_eval.p, c_info.p, need);
             } else {
                 hipLaunchKernelGGL(k_cma_svd_finish, dim3(G), dim3(n > 256 ? 1024 : 256), 0, stream, q, c_evec.p, c_eval.p, c_info.p);
             }

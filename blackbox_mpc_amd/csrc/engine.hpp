@@ -17,6 +17,7 @@
 #include "../../include/bbmpc.h"
 #include "comm.hpp"
 #include "kernels_cma.hpp"
+#include "kernels_eigh.hpp"
 #include "kernels_fused.hpp"
 #include "kernels_fused_cma.hpp"
 #include "kernels_fused_pso.hpp"
@@ -79,6 +80,7 @@ struct Engine {
     int rec;                 // record width U+S+1
     std::vector<float> lo, hi;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    int cu_count = 0;        // its compute units (kernels with spinning barriers are sized against it)
     int device = 0;          // the device the handle lives on (cfg.device, or the caller's current device when that is < 0)
     uint32_t step_counter = 0;
     bool trace_on = false, profiling = false;
@@ -89,6 +91,7 @@ struct Engine {
     // development / parity switches, read from the environment ONCE when the handle is created
     struct Switches {
         bool cma_svd_v1 = false, cma_svd_rounds = false, cma_svd_general = false, cma_svd_gram = false, cma_fused = false, cma_coop = false;
+        int cma_eigh = 1;              // BBMPC_CMA_EIGH=0: block Jacobi instead of the direct eigensolver (kernels_eigh.hpp) at 128 < n <= 320
         int cma_nb = 0;                // BBMPC_CMA_NB: 8 / 16 column blocks in the block Jacobi (0 = automatic)   // BBMPC_CMA_SVD_V1 / _ROUNDS / _GENERAL
         bool mlp_generic = false;      // BBMPC_MLP_GENERIC
         int mlp_bf16 = 0;              // BBMPC_MLP_BF16: 0 off (default, fp32), 1 plain bf16 inputs, 3 split bf16 (hi+lo, three products)
@@ -128,6 +131,11 @@ struct Engine {
     DevBuf<float> c_w, c_m, c_sigma, c_C, c_B, c_Dd, c_ps, c_pc, c_BD, c_z, c_Ye, c_xm, c_ym, c_evec, c_eval, c_E;
     DevBuf<int> c_eidx, c_info;
     DevBuf<unsigned> c_sync;       // SVD instance barriers / sweep flags [G][32]
+    // direct eigensolver scratch (kernels_eigh.hpp): tridiagonal, reflectors, eigenvectors in the tridiagonal basis, flags
+    DevBuf<float> e_d, e_e, e_tau, e_Vt, e_alpha, e_lam, e_Z, e_Z2, e_P, e_Tf;
+    DevBuf<unsigned> e_flags;
+    bool cma_use_eigh() const { return sw.cma_eigh && cma_n > 128 && cma_n <= EIGH_MAX_N && (cma_n & 3) == 0 && !sw.cma_svd_v1 && !sw.cma_svd_rounds && !sw.cma_svd_general && !sw.cma_svd_gram; }
+    void cma_eigh_launch(const CmaArgs& q);
     // evaluate() scratch (grown on demand)
     DevBuf<float> d_eval_seq, d_eval_rew, d_step_a, d_step_b, d_step_c, d_step_d;
     // injected noise (internal layout), keyed by BBMPC_NOISE_*

@@ -512,9 +512,12 @@ __global__ __launch_bounds__(256) void k_cma_warm(CmaArgs p, float* At_all) {
 // The same product on the matrix cores for large n (n % 4 == 0), as k_cma_gemm_y_mfma: for a fixed k both B[k][j0 ..] and
 // C[k][e0 ..] are contiguous, i.e. the A / B fragments of v_mfma_f32_16x16x4_f32 load straight from L2.  Workgroup tile
 // 64 (j) x 32 (e), wave w owns rows 16w .. 16w+15.  grid (ceil(n/32), ceil(n/64), G), block 256.  32 -> ~8 us at n = 300.
-__global__ __launch_bounds__(256) void k_cma_warm_mfma(CmaArgs p, float* At_all) {
+// `need` (optional, [G][8] words): the instance runs only when need[8 g] != 0 -- the direct eigensolver (kernels_eigh.hpp) leaves
+// that flag set for the instances whose result it did not accept; the same parameter on the kernels below.
+__global__ __launch_bounds__(256) void k_cma_warm_mfma(CmaArgs p, float* At_all, const unsigned* need = nullptr) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int g = blockIdx.z, n = p.n;
+    if (need && need[(size_t)g * 8] == 0u) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j0 = blockIdx.y * 64 + wave * 16, e0 = blockIdx.x * 32;
     if (j0 >= n) return;
@@ -702,8 +705,9 @@ __global__ __launch_bounds__(1024) void k_cma_svd_finish(CmaArgs p, const float*
 // The same finish for large n as two launches: norms / ranks / D per instance, then B in 32 x 32 tiles over many
 // workgroups.  (One workgroup per instance walked its n^2 elements with an integer division each and read At along the
 // strided direction: 79 us at n = 300, a tenth of which is left.)  Same arithmetic, same bits.
-__global__ __launch_bounds__(1024) void k_cma_svd_norms(CmaArgs p, const float* At_all, float* norms_all, int* perm_all) {
+__global__ __launch_bounds__(1024) void k_cma_svd_norms(CmaArgs p, const float* At_all, float* norms_all, int* perm_all, const unsigned* need = nullptr) {
     __shared__ float s_norm[2048];
+    if (need && need[(size_t)blockIdx.x * 8] == 0u) return;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n, nthr = blockDim.x, NW = nthr >> 6;
     const float* At = At_all + (size_t)g * n * n;
     float* norms = norms_all + (size_t)g * n;
@@ -730,8 +734,9 @@ __global__ __launch_bounds__(1024) void k_cma_svd_norms(CmaArgs p, const float* 
         p.Dd[(size_t)g * n + rank] = sqrtf(nj);                      // D = diag(sqrt(s)), descending
     }
 }
-__global__ __launch_bounds__(256) void k_cma_svd_build_b(CmaArgs p, const float* At_all, const float* norms_all, const int* perm_all) {
+__global__ __launch_bounds__(256) void k_cma_svd_build_b(CmaArgs p, const float* At_all, const float* norms_all, const int* perm_all, const unsigned* need = nullptr) {
     __shared__ float tile[32][33];
+    if (need && need[(size_t)blockIdx.z * 8] == 0u) return;
     __shared__ int s_src[32];
     __shared__ float s_sv[32];
     const int g = blockIdx.z, n = p.n, tx = threadIdx.x, ty = threadIdx.y;       // block (32, 8)
@@ -803,13 +808,14 @@ __device__ __forceinline__ void l2_store16(float* p, cma_f32x4 v) {
 // per-element loop has a compile-time trip count and no bounds test (at n = 300 the tests, masks and branches were two
 // thirds of the instructions of a cross round).
 template <int NC, int NB>
-__global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
+__global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps, const unsigned* need) {
     extern __shared__ __attribute__((aligned(16))) float cols[];
     // NB blocks of columns, NB / 2 workgroups per instance (8 / 4 or 16 / 8)
     constexpr int WPG = NB / 2;
     const int slot = blockIdx.x >> 3;
     const int g = (blockIdx.x & 7) + 8 * (slot / WPG), wg = slot % WPG;
     if (g >= p.G) return;
+    if (need && need[(size_t)g * 8] == 0u) return;          // (every workgroup of the instance leaves: no barrier is left waiting)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
     constexpr int ld = 64 * NC;
     const int NW = blockDim.x >> 6;

@@ -44,7 +44,8 @@ struct EighArgs {
     float* Z2;           // second buffer of the same shape (polish ping-pong)
     float* P;            // [G][EIGH_LD][EIGH_LD] 1.5 I - 0.5 Z^T Z
     float* Tf;           // [G][EIGH_LD / 32][32][32] triangular factors of the reflector blocks
-    unsigned* flags;     // [G][8]: [0] failure bits, [1] max |Z^T Z - I| (float bits) of the last Gram, [2] max residual
+    unsigned* flags;     // [G][8] (zeroed by k_eigh_tridiag): [0] 1 = the instance failed the checks below (the Jacobi takes it), float bits:
+                         // [1] max |Z^T Z - I| of the twisted vectors, [3] the same after one polish, [2] max residual |(T - lam) z|, [5] |T|
     float* B;            // [G][n][n] out: eigenvectors, columns by descending eigenvalue
     float* Dd;           // [G][n] out: sqrt(eigenvalue)
 };
@@ -438,6 +439,7 @@ __global__ __launch_bounds__(EIGH_TRI_THREADS) void k_eigh_tridiag(EighArgs q) {
     for (int w = 0; w < EIGH_TRI_THREADS / 64; ++w) alpha += s_red[w];
     alpha = alpha / (float)n;
     if (tid == 0) q.alpha[g] = alpha;
+    if (tid < 8) q.flags[(size_t)g * 8 + tid] = 0u;
     EighQuad a[EIGH_NR][EIGH_NJ];
     const bool vec = (n & 3) == 0;
 #pragma unroll
@@ -603,6 +605,7 @@ __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs 
         gu += span * (2.0f * 1.1920929e-07f * (float)n) + thr;
     }
     const float pivmin = fmaxf(1.0e-30f, tn * tn * 1.0e-30f);
+    if (blockIdx.x == 0 && tid == 0) q.flags[(size_t)g * 8 + 5] = __float_as_uint(tn);
     const int j = blockIdx.x * 16 + row;                          // eigenvalue slot of this 16-lane row
     const bool live = j < n;
     // ---- the unreduced block [s, t) around every index: running maximum of the split positions from the left, running
@@ -893,6 +896,16 @@ __global__ __launch_bounds__(256) void k_eigh_gemm(EighArgs q, const float* __re
 // Epilogue: eigenvalue + alpha, ranks by descending value (ties: lower slot first), D = sqrt, B[i][rank].
 // grid (EIGH_LD / 16, G), block 256
 // ---------------------------------------------------------------------------------------------------------------------
+// The checks an instance has to pass for its result to be taken (anything else, NaNs included, goes to the block Jacobi):
+//   every twisted vector's residual |(T - lam) z| <= 1e-5 max(|alpha|, |T|)   (typical: 1e-7 |T|)
+//   |Z^T Z - I| <= 0.25 before the polish (Newton-Schulz converges) and <= 2e-3 after its first round (< 1e-5 after the second)
+__device__ __forceinline__ bool eigh_instance_ok(const EighArgs& q, int g) {
+    const unsigned* f = q.flags + (size_t)g * 8;
+    const float g0 = __uint_as_float(f[1]), g1 = __uint_as_float(f[3]), res = __uint_as_float(f[2]), tn = __uint_as_float(f[5]);
+    const float scale = fmaxf(fabsf(q.alpha[g]), tn);
+    return (g0 <= 0.25f) && (g1 <= 2.0e-3f) && (res <= 1.0e-5f * scale) && (scale < 3.0e38f);
+}
+
 __global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, const float* __restrict__ Z_all) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     __shared__ float w1p[4][32][17];            // per-wave partial W1
@@ -904,6 +917,10 @@ __global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, const fl
     const int g = blockIdx.y, n = q.n, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, lm = lane & 15, lk = lane >> 4;
     const int j0 = blockIdx.x * 16;
+    if (!eigh_instance_ok(q, g)) {                          // B, D stay as they are: the Jacobi's warm start
+        if (blockIdx.x == 0 && tid == 0) q.flags[(size_t)g * 8] = 1u;
+        return;
+    }
     const float* Z = Z_all + (size_t)g * EIGH_LD * EIGH_LD;
     const float* Vt = q.Vt + (size_t)g * EIGH_LD * EIGH_LD;
     // slab: wave w owns row tiles w, w + 4, ..., w + 16
