@@ -88,6 +88,7 @@ class Workload:
         N, A, H, iters, k = c["N"], c["A"], c["H"], c["iters"], c["k"]
         self.mlp = c["env"] == "cheetah"
         quirks = L.CMAES_PER_AGENT if c["opt"] == "CMA-ES" else 0   # the shardable CMA-ES mode
+        quirks |= int(os.environ.get("BENCH_EXTRA_QUIRKS", "0"))       # (value_strict_math: the same calls with BBMPC_STRICT_MATH)
         opt_args = dict(planning_horizon=H, population_size=N, seed=0, quirks=quirks, agent_offset=rank * A,
                         num_agents_global=world * A, device=local)
         if c["opt"] != "RandomSearch":
@@ -420,6 +421,24 @@ def measure(W, steps, warmup, dist, use_dist, red_dev, act_only=False):
                 prof_every=every, gather_rows_checked=rows_act + rows_dev, n_samples=n_samples)
 
 
+SHAPE_KEYS = ("env", "opt", "N", "A", "H", "iters")
+
+
+def profile_config_for(c):
+    """Name of the bench configuration whose SHAPE equals c's (the key the committed profiles are stored under), or None."""
+    for nm, cc in CONFIGS.items():
+        if all(cc.get(k) == c.get(k) for k in SHAPE_KEYS):
+            return nm
+    return None
+
+
+def profile_shape_matches(profile_json, prof_name, c):
+    """The profile file records the shape it was taken at ("_shapes", tools/summarize_profiles.py); older files are taken
+    at CONFIGS[prof_name]."""
+    shp = profile_json.get("_shapes", {}).get(prof_name) or {k: CONFIGS[prof_name].get(k) for k in SHAPE_KEYS}
+    return all(shp.get(k) == c.get(k) for k in SHAPE_KEYS)
+
+
 def roofline(W, m, name, world):
     c = W.c
     N, A, H, iters = c["N"], c["A"], c["H"], c["iters"]
@@ -449,31 +468,37 @@ def roofline(W, m, name, world):
                  "launches_note": "HIP-event pairs on the launch stream around %s launch of the kernel in the "
                                   "device-resident timed region" % ("every" if m["prof_every"] == 1 else "every %dth" % m["prof_every"])})
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    # collected separately, (2*FETCH + WRITE)*1024 -- tools/profile_round.sh, profiles/*_hbm_traffic.json)
+    # collected separately, (2*FETCH + WRITE)*1024 -- tools/profile_round.sh, profiles/*_hbm_traffic.json).  Counters are
+    # attached only when the PROFILED shape is the timed one: the lookup goes by (environment, optimizer, N, A, H,
+    # iterations), not by the configuration's name (run_block times "cfg3" with other agent counts).
     import glob
+    prof_name = profile_config_for(c)
+    if prof_name is None:
+        roof["counters_note"] = "no committed profile of this shape (agents=%d): traffic / valu_issue not attached" % A
     try:
         tr = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]))
         # (the resident LINGER instantiation of the persistent kernel serves many control steps per dispatch: not a per-launch figure)
-        hit = [v for kn, v in tr.get(name, {}).items() if kname in kn and not (kname.startswith("k_fused_pendulum") and kn.rstrip().endswith("true>"))]
-        if hit and world == 1:
+        hit = [v for kn, v in tr.get(prof_name, {}).items()
+               if kname in kn and not (kname.startswith("k_fused_pendulum") and kn.rstrip().endswith("true>"))] if prof_name else []
+        if hit and world == 1 and profile_shape_matches(tr, prof_name, c):
             roof["traffic"] = hit[0]
-            roof["traffic_source"] = "profiles/ (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes)"
+            roof["traffic_source"] = "profiles/ (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes; configuration %s)" % prof_name
     except Exception:
         pass
     # A bound that means something for the persistent pendulum kernels (their HBM fraction is nominal): VALU issue.
     # Wave-instructions per launch come from the committed rocprofv3 PMC pass (SQ_INSTS_VALU); the kernel occupies
     # one CU per agent, each CU issues at most one VALU instruction per SIMD per 1.07 ns (tools/microbench/pk_fp32.hip)
     try:
-        if not mlp and m["roll_n"] and world == 1:
+        if not mlp and m["roll_n"] and world == 1 and prof_name:
             sqc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))[-1]))
-            hit = [v for kn, v in sqc.get(name, {}).items() if kname in kn and "noise" not in kn and not kn.rstrip().endswith("true>")]
-            if hit:
+            hit = [v for kn, v in sqc.get(prof_name, {}).items() if kname in kn and "noise" not in kn and not kn.rstrip().endswith("true>")]
+            if hit and profile_shape_matches(sqc, prof_name, c):
                 insts = hit[0]["SQ_INSTS_VALU"]
                 peak = A * 4 / 1.07e-9
                 ach = insts / (avg_ms * 1e-3)
                 roof["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "wave-instructions/s", "frac": ach / peak,
                                       "insts_per_launch": insts, "cus": A,
-                                      "source": "profiles/*_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+                                      "source": "profiles/*_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU; configuration %s)" % prof_name}
     except Exception:
         pass
     return roof
@@ -666,6 +691,23 @@ def main():
                 blk["value_launch_per_call"] = A_tot / ml["median"]
                 blk["launch_per_call_median_ms"] = ml["median"] * 1e3
                 blk["launch_per_call_p10_ms"], blk["launch_per_call_p90_ms"] = ml["p10"] * 1e3, ml["p90"] * 1e3
+            # the same calls with the pendulum model evaluated op for op as the reference writes it (BBMPC_STRICT_MATH:
+            # atan2 / sin / cos every step instead of the carried angle): what the default's
+            # reformulation buys, in the same units as `value`
+            if CONFIGS[name]["env"] == "pendulum" and not stub:
+                from blackbox_mpc_amd import _lib as _L
+                os.environ["BENCH_EXTRA_QUIRKS"] = str(_L.STRICT_MATH)
+                try:
+                    Ws = cls(name, rank, world, local, dev, use_dist, backend, gather_mode, agents=agents)
+                    ms = measure(Ws, min(steps, 200), min(warmup, 10), dist, use_dist, red_dev, act_only=True)
+                    Ws.close()
+                    del Ws
+                finally:
+                    os.environ.pop("BENCH_EXTRA_QUIRKS", None)
+                if rank == 0:
+                    A_tot = world * (agents if agents is not None else CONFIGS[name]["A"])
+                    blk["value_strict_math"] = A_tot / ms["median"]
+                    blk["strict_math_median_ms"] = ms["median"] * 1e3
         return blk
 
     out = run_block(args.config, args.steps, args.warmup)

@@ -26,7 +26,7 @@ NOISE_TRUNC_NORMAL, NOISE_UNIFORM, NOISE_RADEMACHER, NOISE_NORMAL, NOISE_PSO_SCA
 NOISE_PSO_RESEED_TRUNC, NOISE_PSO_RESEED_UNIFORM, NOISE_PSO_RESET_POS, NOISE_PSO_RESET_VEL = 6, 7, 8, 9
 NOISE_EXPLORATION = 10
 TRACE_REWARDS, TRACE_MEAN, TRACE_VAR, TRACE_ELITES, TRACE_SAMPLES = 1, 2, 3, 4, 5
-TRACE_CMA_B, TRACE_CMA_C, TRACE_CMA_D = 6, 7, 8
+TRACE_CMA_B, TRACE_CMA_C, TRACE_CMA_D, TRACE_CMA_SVD_STATS = 6, 7, 8, 9
 
 E_INVALID, E_NO_DEVICE, E_HIP, E_STATE, E_UNSUPPORTED = -1, -2, -3, -4, -5
 

@@ -699,6 +699,16 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             HIP_CHECK(hipMemcpyAsync(t_cma_B.p + gnn * it, c_B.p, gnn * 4, hipMemcpyDeviceToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(t_cma_C.p + gnn * it, c_C.p, gnn * 4, hipMemcpyDeviceToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(t_cma_D.p + (size_t)G * n * it, c_Dd.p, (size_t)G * n * 4, hipMemcpyDeviceToDevice, stream));
+            if (!t_cma_stats.p) { t_cma_stats.alloc((size_t)G * 16 * std::max(iters, 1)); t_cma_stats.zero(stream); }
+            if (n <= 512 && !sw.cma_svd_v1) {
+                // rotation counts of the sweeps ([G][CMA_SYNC_WORDS] words -> [G][16]); word 15: did the Jacobi run for the instance
+                HIP_CHECK(hipMemcpy2DAsync(t_cma_stats.p + (size_t)G * 16 * it, 16 * sizeof(int), c_sync.p + CMA_SYNC_ROTATIONS,
+                                           CMA_SYNC_WORDS * sizeof(unsigned), 15 * sizeof(int), G, hipMemcpyDeviceToDevice, stream));
+                if (eigh) HIP_CHECK(hipMemcpy2DAsync(t_cma_stats.p + (size_t)G * 16 * it + 15, 16 * sizeof(int), e_flags.p, 8 * sizeof(unsigned),
+                                                     sizeof(int), G, hipMemcpyDeviceToDevice, stream));
+                else HIP_CHECK(hipMemcpy2DAsync(t_cma_stats.p + (size_t)G * 16 * it + 15, 16 * sizeof(int), c_sync.p + 1, CMA_SYNC_WORDS * sizeof(unsigned),
+                                                sizeof(int), G, hipMemcpyDeviceToDevice, stream));
+            }
         }
     }
     hipLaunchKernelGGL(k_take_first, dim3((A * U + 63) / 64), dim3(64), 0, stream, A, HU, U, c_m.p, d_action.p);   // :211-212
@@ -2429,6 +2439,12 @@ void Engine::get_trace(int it, int item, void* out, int64_t bytes) {
             std::vector<float> tmp(ns);
             HIP_CHECK(hipMemcpy(tmp.data(), t_samples.p + ns * it, ns * 4, hipMemcpyDeviceToHost));
             from_internal(tmp.data(), N, (float*)out);
+            break;
+        }
+        case BBMPC_TRACE_CMA_SVD_STATS: {
+            REQUIRE(cfg.optimizer == BBMPC_OPT_CMAES && t_cma_stats.p, BBMPC_E_STATE, "CMA-ES trace items need a traced CMA-ES control step");
+            REQUIRE(bytes == (int64_t)cma_G * 16 * 4, BBMPC_E_INVALID, "CMA-ES SVD statistics: [G,16] int32");
+            HIP_CHECK(hipMemcpy(out, t_cma_stats.p + (size_t)cma_G * 16 * it, (size_t)cma_G * 16 * 4, hipMemcpyDeviceToHost));
             break;
         }
         case BBMPC_TRACE_CMA_B:

@@ -143,6 +143,7 @@ struct Engine {
     // traces
     DevBuf<float> t_rewards, t_mean, t_var, t_samples;
     DevBuf<int> t_elites;
+    DevBuf<int> t_cma_stats;                     // [iters][G][16] BBMPC_TRACE_CMA_SVD_STATS
     DevBuf<float> t_cma_B, t_cma_C, t_cma_D;   // CMA-ES: eigenvectors / covariance / sqrt eigenvalues after each iteration
     // pinned staging
     float* h_pin = nullptr;

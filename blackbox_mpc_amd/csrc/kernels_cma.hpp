@@ -576,7 +576,8 @@ __device__ __forceinline__ void cma_instance_barrier_light(unsigned* ctr, unsign
 }
 
 constexpr int CMA_SYNC_WORDS = 512;
-constexpr int CMA_SYNC_XCC_MASK = 24;                  // k_cma_svd_block: bit x = some workgroup of the instance runs on XCD x
+constexpr int CMA_SYNC_XCC_MASK = 24;
+constexpr int CMA_SYNC_ROTATIONS = 480;               // k_cma_svd_block: [480 + sweep] column pairs rotated in that sweep (statistics)                  // k_cma_svd_block: bit x = some workgroup of the instance runs on XCD x
 // sync: [G][CMA_SYNC_WORDS] unsigned: [0] barrier counter, [1 + sweep] "some pair rotated in this sweep"; the block kernel keeps
 // its block-pair bookkeeping in words 32.. (2 * NB + NB * NB of them)
 __global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps, int lds_floats) {
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
     unsigned* ver = sync + 32;
     unsigned* iseen = ver + NB;
     unsigned* pseen = iseen + NB;                   // [NB][NB]
-    static_assert(32 + 2 * NB + NB * NB <= CMA_SYNC_WORDS, "sync words");
+    static_assert(32 + 2 * NB + NB * NB <= CMA_SYNC_ROTATIONS && CMA_SYNC_ROTATIONS + 16 <= CMA_SYNC_WORDS, "sync words");
     __shared__ int s_skip[3], s_rotf[3];          // [0] cross pairs, [1] inner pairs of block x, [2] of block y
     __shared__ int s_same_xcd;
     __shared__ float s_ynrm[64], s_ysc[64];     // tracked |y_j|^2 and scale of the resident y-columns (bs <= 64)
@@ -900,6 +901,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
 #else
 #define SVDB_MARK(i) do {} while (0)
 #endif
+    unsigned nrot = 0;                                  // rotations this 16-lane row performed in the current sweep (lane 0 of the row counts)
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         bool rotated = false;
         for (int R = 0; R < NB - 1; ++R) {
@@ -964,7 +966,9 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                                 if (i == 0) { pa = m - 1; pb = r; }
                                 else { pa = (r + i) % (m - 1); pb = (r - i + (m - 1)) % (m - 1); }
                                 const bool act = i < m / 2 && pa < cnt && pb < cnt;
-                                rot_here |= rotate16(base + (act ? pa : 0), base + (act ? pb : 0), act);
+                                const bool rt = rotate16(base + (act ? pa : 0), base + (act ? pb : 0), act);
+                                rot_here |= rt;
+                                nrot += (rt && sub == 0) ? 1u : 0u;
                             }
                         }
                         __syncthreads();
@@ -1116,6 +1120,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
                             alx = fmaf(-t, ga, al);
                             if (sub == 0) { s_ysc[jc] = sy * cs; s_ynrm[jc] = fmaf(t, ga, be); }
                             rot_cross = true;
+                            nrot += sub == 0 ? 1u : 0u;
                         }
                         SVDB_CLK(2);
                     }
@@ -1189,6 +1194,10 @@ __global__ __launch_bounds__(1024) void k_cma_svd_block(CmaArgs p, float* At_all
             }
             }   // not everything skipped
             if (R == NB - 2 && rotated && lane == 0) __hip_atomic_store(sync + 1 + sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (R == NB - 2) {
+                if (nrot) __hip_atomic_fetch_add(sync + CMA_SYNC_ROTATIONS + sweep, nrot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                nrot = 0;
+            }
             SVDB_MARK(3);
             ++bar;
             cma_instance_barrier_light(sync, bar * (unsigned)WPG);
@@ -1440,6 +1449,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_gram(CmaArgs p, float* At_all,
                 }
             }
             if (R == NB - 2 && rotated && lane == 0) __hip_atomic_store(sync + 1 + sweep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
             ++bar;
             cma_instance_barrier_light(sync, bar * (unsigned)WPG);
         }

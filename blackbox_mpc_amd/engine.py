@@ -330,6 +330,8 @@ class Engine:
             groups = self.A if per_agent else 1
             n = self.H * self.U * (1 if per_agent else self.A)
             out = np.empty((groups, n) if item == L.TRACE_CMA_D else (groups, n, n), np.float32)
+        elif item == L.TRACE_CMA_SVD_STATS:
+            out = np.empty((self.A if (self.cfg.quirks & L.CMAES_PER_AGENT) else 1, 16), np.int32)
         else:
             raise ValueError(item)
         L.check(L.lib.bbmpc_get_trace(self._h, int(iteration), int(item), L.ptr(out), out.nbytes))

@@ -96,6 +96,7 @@ extern "C" {
 #define BBMPC_TRACE_SAMPLES 5   /* [N,A,H,U] action sequences that were rolled out */
 #define BBMPC_TRACE_CMA_B   6   /* CMA-ES [G,n,n] eigenvectors B after the iteration (cma_es.py:195-198,204)   */
 #define BBMPC_TRACE_CMA_C   7   /* CMA-ES [G,n,n] covariance C after the iteration (cma_es.py:183-190,202)     */
+#define BBMPC_TRACE_CMA_SVD_STATS 9 /* CMA-ES int32 [G,16]: the iteration's eigen-decomposition -- [0..14] column pairs the block Jacobi rotated in sweep s (all zero when the direct solver's result was taken), [15] 1 = the Jacobi ran */
 #define BBMPC_TRACE_CMA_D   8   /* CMA-ES [G,n]   diag(D) = sqrt(eigenvalues) after the iteration (:197,205)   */
 
 typedef struct bbmpc_handle_s* bbmpc_handle;

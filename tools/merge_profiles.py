@@ -24,5 +24,10 @@ for name in ("hbm_traffic", "sq_counters"):
     if not os.path.exists(new):
         continue
     d = json.load(open(old)) if os.path.exists(old) else {}
-    d.update(json.load(open(new)))
+    nd = json.load(open(new))
+    shapes = dict(d.get("_shapes", {}))
+    shapes.update(nd.get("_shapes", {}))          # (configurations that were not re-profiled keep their recorded shape)
+    d.update(nd)
+    if shapes:
+        d["_shapes"] = shapes
     json.dump(d, open(old, "w"), indent=1, sort_keys=True)

@@ -3,7 +3,7 @@
 # SQ busy counters) for the bench configurations.  Raw output goes to gpurun_out/prof_$TAG, the summaries that
 # get committed are written by tools/summarize_profiles.py into gpurun_out/profiles_$TAG (copy them to profiles/).
 TAG=${1:-r2}
-CFGS=${2:-"cfg2 cfg3 cfg4 cfg4pi2 cfg5cem cfg5cma cfg2cma"}
+CFGS=${2:-"cfg2 cfg3 cfg3full cfg4 cfg4pi2 cfg5cem cfg5cma cfg2cma"}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG

@@ -75,6 +75,15 @@ for cfg_dir in sorted(glob.glob(os.path.join(src, "cfg*"))):
                                  % (avg_ns[k] * 1e-3, clk * 1e-9, d["SQ_VALU_MFMA_BUSY_CYCLES"] / (dur * clk * 256 * 4)))
         lines.append("")
     open(os.path.join(dst, "%s_%s.md" % (tag, cfg)), "w").write("\n".join(lines) + "\n")
+# the shape every configuration was profiled at (bench.py attaches counters only to a run of the same shape)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+try:
+    import bench as _bench
+    shapes = {c: {k: _bench.CONFIGS[c].get(k) for k in _bench.SHAPE_KEYS} for c in set(traffic) | set(sq) if c in _bench.CONFIGS}
+    traffic["_shapes"] = shapes
+    sq["_shapes"] = dict(shapes)
+except Exception as exc:
+    print("summarize_profiles: shapes not recorded (%s)" % exc)
 json.dump(traffic, open(os.path.join(dst, "%s_hbm_traffic.json" % tag), "w"), indent=1, sort_keys=True)
 json.dump(sq, open(os.path.join(dst, "%s_sq_counters.json" % tag), "w"), indent=1, sort_keys=True)
 print("wrote", os.listdir(dst))
