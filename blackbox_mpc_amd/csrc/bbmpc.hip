@@ -162,10 +162,11 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
     if (c.population_global != 0 || c.population_offset != 0) {
         REQUIRE(c.population_global >= N && c.population_offset >= 0 && c.population_offset + N <= c.population_global, BBMPC_E_INVALID,
                 "population_offset / population_global: this handle's particles must lie inside the global population");
-        if (c.population_global > N)
+        if (c.population_global > N) {
             REQUIRE(c.optimizer != BBMPC_OPT_NONE, BBMPC_E_UNSUPPORTED, "population sharding needs an optimizer (evaluate-only handles roll out what they are given)");
             if (c.optimizer == BBMPC_OPT_CMAES)
                 REQUIRE(k <= N && k <= 1024, BBMPC_E_UNSUPPORTED, "sharded CMA-ES: num_elite must not exceed this rank's share of the population (nor 1024)");
+        }
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -2490,6 +2491,9 @@ cma_names:
         return;
     }
     if (!src && cfg.optimizer == BBMPC_OPT_PSO) {
+        if (name == "pos" || name == "vel" || name == "pbest" || name == "pbest_r")
+            REQUIRE(auto_split <= 1, BBMPC_E_UNSUPPORTED,      // (the loopback TEST hook keeps its documented meaning: shard 0's particles)
+                    "per-particle state of a population_size > 32768 is kept per shard of the split: not available");
         const float* big = nullptr;
         if (name == "pos") big = d_cand_a.p;
         else if (name == "vel") big = d_vel.p;
@@ -3259,8 +3263,9 @@ int bbmpc_gather_records_dev(bbmpc_handle h, const float* d_records, float* d_ga
     CHECK_HANDLE(h);
     // the communicator of a population-sharded handle carries the per-iteration partials on the LAUNCH stream; one RCCL
     // communicator must not be driven from two unsynchronised streams, so such a handle has no record gather (its ranks
-    // all hold the same agents: there is nothing to gather)
-    if (h->e->pop_sharded()) throw HipError(BBMPC_E_UNSUPPORTED, "record gather on a population-sharded handle (every rank already holds every agent's record)");
+    // all hold the same agents: there is nothing to gather).  A population that is only split into shards on THIS GPU
+    // (population_size > 32768, or the loopback hook) never drives the communicator and gathers like any other handle
+    if (h->e->pop_sharded_across_ranks()) throw HipError(BBMPC_E_UNSUPPORTED, "record gather on a handle whose population is sharded over ranks (every rank already holds every agent's record)");
     CHECK_PTR(d_records);
     CHECK_PTR(d_gathered);
     Engine* e = h->e;
@@ -3279,8 +3284,9 @@ int bbmpc_optimize_gather_dev(bbmpc_handle h, const float* d_state, int32_t, int
     CHECK_HANDLE(h);
     // the communicator of a population-sharded handle carries the per-iteration partials on the LAUNCH stream; one RCCL
     // communicator must not be driven from two unsynchronised streams, so such a handle has no record gather (its ranks
-    // all hold the same agents: there is nothing to gather)
-    if (h->e->pop_sharded()) throw HipError(BBMPC_E_UNSUPPORTED, "record gather on a population-sharded handle (every rank already holds every agent's record)");
+    // all hold the same agents: there is nothing to gather).  A population that is only split into shards on THIS GPU
+    // (population_size > 32768, or the loopback hook) never drives the communicator and gathers like any other handle
+    if (h->e->pop_sharded_across_ranks()) throw HipError(BBMPC_E_UNSUPPORTED, "record gather on a handle whose population is sharded over ranks (every rank already holds every agent's record)");
     CHECK_PTR(d_state);
     CHECK_PTR(d_records);
     CHECK_PTR(d_gathered);
@@ -3325,8 +3331,9 @@ int bbmpc_optimize_gather(bbmpc_handle h, const float* state, int32_t, int32_t n
     CHECK_HANDLE_NOSETTLE(h);            // as bbmpc_optimize: consecutive calls are ordered by the stream / the resident kernel
     // the communicator of a population-sharded handle carries the per-iteration partials on the LAUNCH stream; one RCCL
     // communicator must not be driven from two unsynchronised streams, so such a handle has no record gather (its ranks
-    // all hold the same agents: there is nothing to gather)
-    if (h->e->pop_sharded()) throw HipError(BBMPC_E_UNSUPPORTED, "record gather on a population-sharded handle (every rank already holds every agent's record)");
+    // all hold the same agents: there is nothing to gather).  A population that is only split into shards on THIS GPU
+    // (population_size > 32768, or the loopback hook) never drives the communicator and gathers like any other handle
+    if (h->e->pop_sharded_across_ranks()) throw HipError(BBMPC_E_UNSUPPORTED, "record gather on a handle whose population is sharded over ranks (every rank already holds every agent's record)");
     CHECK_PTR(state);
     CHECK_PTR(d_gathered);
     Engine* e = h->e;

@@ -254,6 +254,8 @@ struct Engine {
     int ps_loopback = 0;     // BBMPC_POPSHARD_LOOPBACK=G: one handle plays all G shards in turn (single-GPU test / measurement hook)
     bool ps_force = false;   // BBMPC_POPSHARD_FORCE: take the sharded code path (incl. the collective) even with one shard
     bool pop_sharded() const { return cfg.population_global > N || ps_loopback > 1 || ps_force; }
+    // ... and over RANKS (the per-iteration exchange goes through the communicator): not the one-GPU splits
+    bool pop_sharded_across_ranks() const { return ps_force || (ps_loopback <= 1 && cfg.population_global > N); }
     int pending_warm = 0;    // learned-dynamics path: warm start the tail kernel performs (kernels_tail.hpp TailArgs::warm_mode)
     RowMlp row_mlp() const;
     const float* injected(int kind) const {

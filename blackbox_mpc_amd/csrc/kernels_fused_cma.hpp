@@ -135,7 +135,7 @@ __global__ __launch_bounds__(1024) void k_fused_cma_pendulum(FusedCmaArgs f) {
                 if (r > c) continue;
                 float ys = 0.0f;
                 for (int i = 0; i < p.k; ++i) ys = fmaf(Ye[(size_t)i * n + r] * Ye[(size_t)i * n + c], p.weights[i], ys);
-                const float v = ((1.0f - p.c.c1) - p.c.c_mu) * C[(size_t)r * n + c] + p.c.c1 * (p.p_C[off + r] * p.p_C[off + c]) +
+                const float v = ((1.0f - p.c.c1) - p.c.c_mu) * C[(size_t)r * n + c] + (p.c.c1 * p.p_C[off + r]) * p.p_C[off + c] +      /* (c1 * p_C) * p_C^T as cma_es.py:183 evaluates it */
                                 p.c.c_mu * ys;
                 C[(size_t)r * n + c] = v;
                 C[(size_t)c * n + r] = v;

@@ -43,18 +43,22 @@ class Engine:
         self.U, self.S = c.dim_u, c.dim_s
         self.iters = 1 if optimizer == L.OPT_RANDOM_SEARCH else c.max_iterations
         self.k = c.num_elite
+        self._device = self._current_device() if c.device < 0 else int(c.device)    # where the handle lives, fixed at creation
         L.check(L.lib.bbmpc_create(ctypes.byref(c), ctypes.byref(self._h)))
+
+    @staticmethod
+    def _current_device():
+        try:
+            import torch
+            return int(torch.cuda.current_device()) if torch.cuda.is_available() else 0
+        except Exception:                                 # noqa: BLE001
+            return 0
 
     @property
     def device(self):
-        """The GPU this handle lives on (bbmpc_config.device; -1 = the process's current device)."""
-        if self.cfg.device >= 0:
-            return int(self.cfg.device)
-        try:
-            import torch
-            return int(torch.cuda.current_device())
-        except Exception:                                 # noqa: BLE001
-            return 0
+        """The GPU this handle lives on: bbmpc_config.device, or (-1) the process's current device AT CREATION -- the
+        torch callbacks alias the engine's HBM pointers and stream on this device whatever is current later."""
+        return self._device
 
     # -- lifecycle -------------------------------------------------------------------------
     def close(self):

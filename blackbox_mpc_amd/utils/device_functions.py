@@ -172,15 +172,35 @@ class TorchRewardFunction(_TorchCallback):
         return self.fn(t(current_state), t(actions), t(next_state)).to(torch.float32).cpu().numpy()
 
 
+def _takes_train_argument(fn):
+    """Does dynamics_function accept a second positional argument (the reference's `train`, deterministic.py:99-100)?
+    Decided ONCE from the signature: calling fn(x, False) and retrying fn(x) on TypeError would hide a TypeError raised
+    inside the function itself."""
+    import inspect
+    try:
+        params = list(inspect.signature(fn).parameters.values())
+    except (TypeError, ValueError):
+        return True                                       # no introspectable signature: the reference's call form
+    if any(p.kind == p.VAR_POSITIONAL for p in params):
+        return True
+    positional = [p for p in params if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+    return len(positional) >= 2
+
+
 def call_torch_dynamics(fn, x):
-    """dynamics_function(x, train=False) (deterministic.py:99-100); a torch.nn.Module takes x alone."""
+    """dynamics_function(x, train=False) (deterministic.py:99-100); a torch.nn.Module, or a callable of one argument,
+    takes x alone."""
     import torch
     if isinstance(fn, torch.nn.Module):
         return fn(x)
-    try:
-        return fn(x, False)
-    except TypeError:
-        return fn(x)
+    takes = getattr(fn, "_bbmpc_takes_train", None)
+    if takes is None:
+        takes = _takes_train_argument(fn)
+        try:
+            fn._bbmpc_takes_train = takes
+        except (AttributeError, TypeError):
+            pass
+    return fn(x, False) if takes else fn(x)
 
 
 class TorchDynamicsFunction(_TorchCallback):

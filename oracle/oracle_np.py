@@ -647,10 +647,15 @@ class CMAES(OptimizerBase):
             coef_c = (self.h_sigma * sqrt32(((cc * (F(2) - cc).astype(F)).astype(F) * c["mu_eff"]).astype(F))).astype(F)
             p_C = (((F(1) - cc).astype(F) * self.p_C).astype(F) + (coef_c * y_mean).astype(F)).astype(F)   # :177
             y_unw = (x_diff / self.sigma).astype(F)                             # :180
-            yk = y_unw[:self.k].astype(np.float64)
-            y_s = ((yk * w[:self.k, None].astype(np.float64)).T @ yk).astype(F)     # :181-182 (zero weights dropped)
+            # :181-182  map_fn(e * e^T) in fp32, times the weight in fp32, reduce_sum over the population.  TF's reduction
+            # order is unspecified, so the SUM (here, in x_mean and in every matmul of this class) is accumulated in
+            # float64 and rounded once -- the neutral reference the engine's fp32 orders are held to (the tolerances in
+            # tests/test_gpu_cmaes.py, 2e-5 absolute, cover both); the PRODUCTS keep the reference's association
+            yk = y_unw[:self.k]
+            outer = (yk[:, :, None] * yk[:, None, :]).astype(F)                 # zero weights dropped
+            y_s = (outer * w[:self.k, None, None]).astype(F).astype(np.float64).sum(0).astype(F)
             C = ((((F(1) - c["c1"]).astype(F) - c["c_mu"]).astype(F) * self.C).astype(F)
-                 + (c["c1"] * np.outer(p_C, p_C).astype(F)).astype(F)).astype(F)
+                 + ((c["c1"] * p_C[:, None]).astype(F) * p_C[None, :]).astype(F)).astype(F)   # :183  (c1 * p_C) * p_C^T
             C = (C + (c["c_mu"] * y_s).astype(F)).astype(F)                      # :183-184
             up = np.triu(C)                                                     # :188
             C = (up + np.triu(C, 1).T).astype(F)                                # :189-190

@@ -68,6 +68,26 @@ def test_config3_pi2_full_population_8_agents(L):
     np.testing.assert_allclose(act, a_c, rtol=0, atol=5e-3)
 
 
+def test_config3_pi2_all_64_agents_on_one_gpu(L):
+    # BASELINE config 3 as stated -- PI2, N=1000, A=64, H=30, 5 iterations -- on ONE GPU: the shape bench.py's `config3` block
+    # times (64 workgroups of the persistent kernel).  Lock-step against the C oracle on the engine's own draws.
+    from blackbox_mpc_amd.engine import Engine
+    N, A, H, iters = 1000, 64, 30, 5
+    eng = Engine(L.OPT_PI2, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=A, planning_horizon=H,
+                 population_size=N, max_iterations=iters, lamda=1.0, seed=11)
+    eng.set_trace(True)
+    states = O.pendulum_start_states(A)
+    co = OC.COracle("pendulum", "pendulum", [-2.0], [2.0], N, A, H, 3, iters=iters, lamda=1.0)
+    for step in range(2):                                  # the second control step starts from the shifted solution (pi2.py:92-93)
+        act, nxt, rew = eng.optimize(states)
+        noise = [eng.dump_noise(L.NOISE_TRUNC_NORMAL, step, it, (N, A, H, 1)) for it in range(iters)]
+        a_c, n_c, r_c, tr = co.optimize("PI2", states, noise=noise, trace=True)
+        np.testing.assert_allclose(eng.get_trace(iters - 1, L.TRACE_MEAN), tr["mean"], rtol=0, atol=5e-3)
+        np.testing.assert_allclose(act, a_c, rtol=0, atol=5e-3)
+        np.testing.assert_allclose(nxt, n_c, rtol=1e-4, atol=2e-3)
+        states = n_c
+
+
 def test_config3_evaluator_all_64_agents(L):
     from blackbox_mpc_amd.engine import Engine
     N, A, H = 1000, 64, 30
