@@ -195,7 +195,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.cma_svd_general = flag("BBMPC_CMA_SVD_GENERAL");
         sw.cma_svd_gram = flag("BBMPC_CMA_SVD_GRAM");
         sw.cma_coop = flag("BBMPC_CMA_COOP"); sw.cma_nb = ival("BBMPC_CMA_NB", 0);
-        sw.cma_eigh = ival("BBMPC_CMA_EIGH", 1);
+        sw.cma_eigh = ival("BBMPC_CMA_EIGH", 1); sw.cma_eigh_fail = flag("BBMPC_CMA_EIGH_FAIL");
         sw.cma_fused = flag("BBMPC_CMA_FUSED");
         sw.mlp_generic = flag("BBMPC_MLP_GENERIC");
         { const int b = ival("BBMPC_MLP_BF16", 0); sw.mlp_bf16 = (b == 1 || b == 3) ? b : 0; }
@@ -519,6 +519,7 @@ void Engine::cma_eigh_launch(const CmaArgs& cq) {
     EighArgs q;
     memset(&q, 0, sizeof(q));
     q.n = cma_n; q.G = cma_G;
+    q.force_fail = sw.cma_eigh_fail ? 1 : 0;
     q.C = cq.C; q.B = cq.B; q.Dd = cq.Dd;
     q.d = e_d.p; q.e = e_e.p; q.tau = e_tau.p; q.Vt = e_Vt.p; q.alpha = e_alpha.p; q.lam = e_lam.p;
     q.Z = e_Z.p; q.Z2 = e_Z2.p; q.P = e_P.p; q.Tf = e_Tf.p; q.flags = e_flags.p;

@@ -91,6 +91,7 @@ struct Engine {
     // development / parity switches, read from the environment ONCE when the handle is created
     struct Switches {
         bool cma_svd_v1 = false, cma_svd_rounds = false, cma_svd_general = false, cma_svd_gram = false, cma_fused = false, cma_coop = false;
+        bool cma_eigh_fail = false;    // BBMPC_CMA_EIGH_FAIL: test hook, the direct solver reports every instance as failed
         int cma_eigh = 1;              // BBMPC_CMA_EIGH=0: block Jacobi instead of the direct eigensolver (kernels_eigh.hpp) at 128 < n <= 320
         int cma_nb = 0;                // BBMPC_CMA_NB: 8 / 16 column blocks in the block Jacobi (0 = automatic)   // BBMPC_CMA_SVD_V1 / _ROUNDS / _GENERAL
         bool mlp_generic = false;      // BBMPC_MLP_GENERIC

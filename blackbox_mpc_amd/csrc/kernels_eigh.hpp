@@ -33,6 +33,7 @@ constexpr int EIGH_MAX_N = 320;
 
 struct EighArgs {
     int n, G;
+    int force_fail;      // test hook (BBMPC_CMA_EIGH_FAIL): every instance is reported as failed, i.e. handed to the block Jacobi
     const float* C;      // [G][n][n] symmetric
     float* d;            // [G][EIGH_LD] diagonal of T
     float* e;            // [G][EIGH_LD] e[k] couples k and k + 1 (e[n-1] = 0)
@@ -903,7 +904,7 @@ __device__ __forceinline__ bool eigh_instance_ok(const EighArgs& q, int g) {
     const unsigned* f = q.flags + (size_t)g * 8;
     const float g0 = __uint_as_float(f[1]), g1 = __uint_as_float(f[3]), res = __uint_as_float(f[2]), tn = __uint_as_float(f[5]);
     const float scale = fmaxf(fabsf(q.alpha[g]), tn);
-    return (g0 <= 0.25f) && (g1 <= 2.0e-3f) && (res <= 1.0e-5f * scale) && (scale < 3.0e38f);
+    return !q.force_fail && (g0 <= 0.25f) && (g1 <= 2.0e-3f) && (res <= 1.0e-5f * scale) && (scale < 3.0e38f);
 }
 
 __global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, const float* __restrict__ Z_all) {

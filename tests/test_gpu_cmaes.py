@@ -211,3 +211,59 @@ def test_fused_control_step_is_bit_identical_to_the_per_iteration_kernels(L, mon
     fused_applies = n <= 64 and G == A
     assert fus.get_profile()[2] == ("k_fused_cma_pendulum" if fused_applies else "k_rollout_pendulum")
     assert ref.get_profile()[2] == "k_rollout_pendulum"
+
+
+def _config5_cma_engine(L, A=2, N=400, k=40):
+    from blackbox_mpc_amd.engine import Engine
+    S, U, H = 20, 6, 50                                    # n = H * U = 300: BASELINE config 5's per-agent search dimension
+    eng = Engine(L.OPT_CMAES, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=A, planning_horizon=H,
+                 population_size=N, max_iterations=5, num_elite=k, seed=4, quirks=L.CMAES_PER_AGENT)
+    ws, bs = O.make_mlp_params([S + U, 200, 200, S], seed=42)
+    stats = [np.zeros(S, np.float32), np.ones(S, np.float32), np.zeros(U, np.float32), np.ones(U, np.float32),
+             np.zeros(S, np.float32), np.full(S, 0.1, np.float32)]
+    eng.set_mlp(ws, bs, [L.ACT_TANH, L.ACT_TANH, L.ACT_NONE], stats)
+    eng.set_trace(True)
+    return eng, O.cheetah_start_states(A, S)
+
+
+def _check_factorisation(eng, L, A, n, iters, atol):
+    worst = 0.0
+    for it in range(iters):
+        B = eng.get_trace(it, L.TRACE_CMA_B).astype(np.float64)
+        C = eng.get_trace(it, L.TRACE_CMA_C).astype(np.float64)
+        D = eng.get_trace(it, L.TRACE_CMA_D).astype(np.float64)
+        for g in range(A):
+            assert np.all(np.diff(D[g]) <= 0), "D must be sorted descending (tf.linalg.svd order)"
+            worst = max(worst, np.abs(B[g] @ np.diag(D[g] ** 2) @ B[g].T - C[g]).max(), np.abs(B[g].T @ B[g] - np.eye(n)).max())
+            np.testing.assert_allclose(D[g] ** 2, np.linalg.eigvalsh(C[g])[::-1], rtol=0, atol=atol)
+    return worst
+
+
+def test_direct_eigensolver_over_a_closed_loop(L):
+    # s, U, _ = tf.linalg.svd(C) (cma_es.py:195) at n = 300 by the direct solver (csrc/kernels_eigh.hpp): the rank-deficient
+    # covariances of the first iterations (C = alpha I + low rank: the tridiagonal splits) AND the full-rank ones later
+    # in the episode.  Every decomposition must be accepted by the solver's own checks (statistics word 15 == 0: the
+    # block Jacobi did not run) and hold the invariants to 5e-6 -- the Jacobi's threshold alone is 9e-6.
+    A, n, iters = 2, 300, 5
+    eng, state = _config5_cma_engine(L, A)
+    for step in range(6):
+        act, state, rew = eng.optimize(state)
+        for it in range(iters):
+            st = eng.get_trace(it, L.TRACE_CMA_SVD_STATS)
+            assert np.all(st[:, 15] == 0) and np.all(st[:, :15] == 0), (step, it, st)
+        assert _check_factorisation(eng, L, A, n, iters, 5e-6) <= 5e-6
+
+
+def test_direct_eigensolver_failure_hands_over_to_the_jacobi(L, monkeypatch):
+    # BBMPC_CMA_EIGH_FAIL: the direct solver reports failure for every instance -> B, D must come from the block Jacobi
+    # (rotations counted, word 15 == 1) and still factorise C; the same control steps as the direct path within the
+    # eigenvector-basis freedom, i.e. the same eigenvalues
+    monkeypatch.setenv("BBMPC_CMA_EIGH_FAIL", "1")
+    A, n, iters = 2, 300, 5
+    eng, state = _config5_cma_engine(L, A)
+    for step in range(2):
+        act, state, rew = eng.optimize(state)
+        for it in range(iters):
+            st = eng.get_trace(it, L.TRACE_CMA_SVD_STATS)
+            assert np.all(st[:, 15] == 1) and np.all(st[:, 0] > 0), (step, it, st)
+        assert _check_factorisation(eng, L, A, n, iters, 5e-5) <= 5e-5
