@@ -531,11 +531,11 @@ void Engine::cma_eigh_launch(const CmaArgs& cq) {
     hipLaunchKernelGGL(k_eigh_tridiag, dim3(G), dim3(EIGH_TRI_THREADS), lds1, stream, q);
     hipLaunchKernelGGL(k_eigh_tri_solve, dim3(EIGH_SLOT_WGS + EIGH_TF_WGS, G), dim3(EIGH_SOLVE_THREADS), lds2, stream, q);
     const dim3 gg(EIGH_LD / 64, EIGH_LD / 64, G);
-    hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, stream, q, (const float*)q.Z, (const float*)nullptr, q.P, 1);
-    hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, stream, q, (const float*)q.Z, (const float*)q.P, q.Z2, 0);
-    hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, stream, q, (const float*)q.Z2, (const float*)nullptr, q.P, 3);
-    hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, stream, q, (const float*)q.Z2, (const float*)q.P, q.Z, 0);
-    hipLaunchKernelGGL(k_eigh_backtransform, dim3(EIGH_LD / 16, G), dim3(256), 0, stream, q, (const float*)q.Z);
+    hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, stream, q, (const float*)q.Z, (const float*)nullptr, q.P, 1, 0);
+    hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, stream, q, (const float*)q.Z, (const float*)q.P, q.Z2, 0, 0);
+    hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, stream, q, (const float*)q.Z2, (const float*)nullptr, q.P, 3, 1);
+    hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, stream, q, (const float*)q.Z2, (const float*)q.P, q.Z, 0, 1);
+    hipLaunchKernelGGL(k_eigh_backtransform, dim3(EIGH_LD / 16, G), dim3(256), 0, stream, q, (const float*)q.Z, (const float*)q.Z2);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -638,7 +638,7 @@ __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs 
     const int m = (live ? j : 0) - s;
     SOLVE_MARK(0);
     // ---- multisection: 32 shifts per slot and pass (two per lane: two independent chains share the latency of the
-    // reciprocal), five passes of 33-fold narrowing.  d and e^2 come from LDS four steps at a time, one group ahead of
+    // reciprocal), six passes of 33-fold narrowing.  d and e^2 come from LDS four steps at a time, one group ahead of
     // the chain.  (Measured and dropped: the product form p_{i+1} = (d_i - x) p_i - e^2 p_{i-1} with a power-of-two
     // rescale every four steps -- one FMA on the chain instead of rcp / mul / sub / pivmin test, but more instructions
     // per step, and with one wave per SIMD the loop is issue bound: 190 against 137 cycles per step.)
@@ -647,7 +647,8 @@ __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs 
         const float4* dd4 = reinterpret_cast<const float4*>(L.dd);
         const float4* e24 = reinterpret_cast<const float4*>(L.e2p);
         const int n4 = (n + 3) >> 2;                              // (entries beyond n are zero and lie outside every block)
-        for (int pass = 0; pass < 5; ++pass) {
+        for (int pass = 0; pass < 6; ++pass) {               // 33^6 = 1.3e9: the interval ends below the last bit of |T| (with five passes the
+                                                             // eigenvalues are 10x coarser and the twisted vectors 10x less orthogonal)
             const float h = (hi - lo) * (1.0f / 33.0f);
             const float xa = fmaf((float)(sub + 1), h, lo), xb = fmaf((float)(sub + 17), h, lo);
             int ca = 0, cb = 0;
@@ -696,7 +697,9 @@ __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs 
                 if (st + 1 < len) {
                     const int in = fwd ? i + 1 : i - 1;
                     const float ec = fwd ? L.ee[i] : L.ee[i - 1];           // coupling between i and the next index
-                    piv = (L.dd[in] - lam) - (ec * __builtin_amdgcn_rcpf(piv)) * ec;     // (1-ulp reciprocal: the chain is the cost)
+                    float rp = __builtin_amdgcn_rcpf(piv);
+                    rp = rp * fmaf(-piv, rp, 2.0f);     // one Newton step: with 1-ulp quotients the vectors come out 10x less orthogonal
+                    piv = (L.dd[in] - lam) - (ec * rp) * ec;                            // (1.4e-3 instead of 6e-5) and the second polish round is needed
                 }
             }
         }
@@ -725,9 +728,9 @@ __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs 
         const bool up = sub == 0;
         float z = 1.0f;
         if (up) {
-            for (int i = r - 1; i >= s; --i) { z = -(L.ee[i] * __builtin_amdgcn_rcpf(fw[i])) * z; fw[i] = z; }
+            for (int i = r - 1; i >= s; --i) { const float pv = fw[i]; float rp = __builtin_amdgcn_rcpf(pv); rp = rp * fmaf(-pv, rp, 2.0f); z = -(L.ee[i] * rp) * z; fw[i] = z; }
         } else {
-            for (int i = r; i < t - 1; ++i) { z = -(L.ee[i] * __builtin_amdgcn_rcpf(bw[i + 1])) * z; bw[i + 1] = z; }
+            for (int i = r; i < t - 1; ++i) { const float pv = bw[i + 1]; float rp = __builtin_amdgcn_rcpf(pv); rp = rp * fmaf(-pv, rp, 2.0f); z = -(L.ee[i] * rp) * z; bw[i + 1] = z; }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -817,11 +820,16 @@ __device__ __forceinline__ void eigh_tfactor_block(const EighArgs& q, int g, int
 //   MODE 1:  Zout = A P                                                        (a lane's four k of A are one 16-byte load)
 // grid (EIGH_LD / 64, EIGH_LD / 64, G), block 256
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr float EIGH_ONE_ROUND = 1.0e-3f;
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_eigh_gemm(EighArgs q, const float* __restrict__ A_all, const float* __restrict__ P_all,
-                                                    float* __restrict__ out_all, int slot) {
+                                                    float* __restrict__ out_all, int slot, int second_round) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int g = blockIdx.z, n = q.n;
+    // the second polish round is skipped when the twisted vectors were orthogonal to EIGH_ONE_ROUND already (one round
+    // then leaves ~1e-6: measured 5.6e-4 -> 5.4e-7, 2.5e-3 -> 6.8e-6); the back-transformation reads Z2 in that case
+    if (second_round && __uint_as_float(q.flags[(size_t)g * 8 + 1]) <= EIGH_ONE_ROUND) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lm = lane & 15, lk = lane >> 4;
     const int r0 = blockIdx.y * 64 + wave * 16, c0 = blockIdx.x * 64;
@@ -907,7 +915,7 @@ __device__ __forceinline__ bool eigh_instance_ok(const EighArgs& q, int g) {
     return !q.force_fail && (g0 <= 0.25f) && (g1 <= 2.0e-3f) && (res <= 1.0e-5f * scale) && (scale < 3.0e38f);
 }
 
-__global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, const float* __restrict__ Z_all) {
+__global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, const float* __restrict__ Z_two_rounds, const float* __restrict__ Z_one_round) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     __shared__ float w1p[4][32][17];            // per-wave partial W1
     __shared__ float w1[32][17];
@@ -922,7 +930,8 @@ __global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, const fl
         if (blockIdx.x == 0 && tid == 0) q.flags[(size_t)g * 8] = 1u;
         return;
     }
-    const float* Z = Z_all + (size_t)g * EIGH_LD * EIGH_LD;
+    const bool one_round = __uint_as_float(q.flags[(size_t)g * 8 + 1]) <= EIGH_ONE_ROUND;
+    const float* Z = (one_round ? Z_one_round : Z_two_rounds) + (size_t)g * EIGH_LD * EIGH_LD;
     const float* Vt = q.Vt + (size_t)g * EIGH_LD * EIGH_LD;
     // slab: wave w owns row tiles w, w + 4, ..., w + 16
     f4 zs[5];
