@@ -1,5 +1,6 @@
 // C ABI (include/bbmpc.h) + engine implementation.  gfx950 only, no CPU fallback.
 #include "engine.hpp"
+#include "engine_util.hpp"
 
 #include <math.h>
 #include <stdio.h>
@@ -17,6 +18,7 @@ namespace bbmpc {
 static std::mutex g_engines_mu;
 static std::set<Engine*> g_engines;
 static std::atomic<int> g_resident_handles{0};
+void note_resident_handle() { g_resident_handles.fetch_add(1, std::memory_order_relaxed); }   // (bbmpc_fused.hip publishes a mailbox)
 
 // Called at every entry point: resident workgroups of OTHER handles on this device are asked to leave (a few stores into
 // pinned memory, no synchronisation); costs one relaxed load when nothing is resident.
@@ -73,37 +75,11 @@ static void init_tnq_table() {
     q[TNQ_SIZE] = 2.0f;
     std::vector<float2> tab(TNQ_SIZE);
     for (int i = 0; i < TNQ_SIZE; ++i) tab[i] = make_float2(q[i], q[i + 1] - q[i]);
-    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tnq), tab.data(), sizeof(float2) * TNQ_SIZE));
+    tnq_upload(tab.data());                                  // this translation unit's copy ...
+    bbmpc_tu_cma_upload_tnq(tab.data());                     // ... and the other two
+    bbmpc_tu_mlp_upload_tnq(tab.data());
+    bbmpc_tu_fused_upload_tnq(tab.data());
     done.insert(dev);                                       // only after the upload succeeded
-}
-
-static void upload(DevBuf<float>& b, const std::vector<float>& v) {
-    b.alloc(v.size());
-    HIP_CHECK(hipMemcpy(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
-}
-
-// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (device, kernel)
-// -- a process may hold handles on several devices (bbmpc_config.device).
-static void ensure_max_lds(const void* fn, int bytes) {
-    static std::mutex mu;
-    static std::set<std::pair<int, const void*>> done;
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    if (done.find({dev, fn}) == done.end()) {
-        HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        done.insert({dev, fn});
-    }
-}
-
-// kernels whose dynamic LDS grows with the population (an agent's rewards, Nst floats): past the 64 KB default they need
-// the attribute raised
-// static_bytes: what the kernel declares as static __shared__ on top (the two together must fit the CU's 160 KB)
-static void want_lds(const void* fn, size_t bytes, size_t static_bytes = 0) {
-    if (bytes > 64 * 1024) {
-        REQUIRE(bytes + static_bytes <= 159 * 1024, BBMPC_E_UNSUPPORTED, "population too large for one CU's LDS");
-        ensure_max_lds(fn, (int)(159 * 1024 - static_bytes));
-    }
 }
 
 Engine::Engine(const bbmpc_config& c) : cfg(c) {
@@ -427,295 +403,6 @@ PsoState Engine::pso_state(int shard) {
     return s;
 }
 
-// ---- CMA-ES host side -----------------------------------------------------------------------------
-void Engine::cma_init() {
-    const bool per_agent = fix(BBMPC_CMAES_PER_AGENT);
-    cma_G = per_agent ? A : 1;
-    cma_n = per_agent ? HU : A * HU;
-    const int n = cma_n, G = cma_G;
-    // recombination weights + constants, fp32 with the reference's op order (cma_es.py:62-92, 118-126)
-    std::vector<float> w((size_t)k);
-    const float lk = (float)log((double)((float)k + 0.5f));
-    float wsum = 0.0f;
-    for (int i = 0; i < k; ++i) { w[i] = lk - (float)log((double)(float)(i + 1)); wsum += w[i]; }
-    float s1 = 0.0f, s2 = 0.0f;
-    for (int i = 0; i < k; ++i) { w[i] = w[i] / wsum; s1 += w[i]; s2 += w[i] * w[i]; }
-    CmaConst& c = cma_c;
-    const float nf = (float)n, ac = cfg.cma_alpha_cov;
-    c.mu_eff = (s1 * s1) / s2;
-    c.c_sigma = (c.mu_eff + 2.0f) / ((nf + c.mu_eff) + 5.0f);
-    c.d_sigma = (1.0f + 2.0f * std::max(0.0f, sqrtf((c.mu_eff - 1.0f) / (nf + 1.0f)) - 1.0f)) + c.c_sigma;
-    c.cc = (4.0f + c.mu_eff / nf) / ((nf + 4.0f) + (2.0f * c.mu_eff) / nf);
-    c.c1 = ac / ((nf + 1.3f) * (nf + 1.3f) + c.mu_eff);
-    const float cmu2 = ac * ((c.mu_eff - 2.0f) + 1.0f / c.mu_eff) / ((nf + 2.0f) * (nf + 2.0f) + (ac * c.mu_eff) / 2.0f);
-    c.c_mu = std::min(1.0f - c.c1, cmu2);
-    c.e_norm = sqrtf(nf * ((1.0f - 1.0f / (4.0f * nf)) + 1.0f / (21.0f * (nf * nf))));
-    c.h_sigma = cfg.cma_h_sigma;
-    upload(c_w, w);
-    const size_t gn = (size_t)G * n, gnn = gn * n;
-    c_m.alloc(gn); c_sigma.alloc(gn); c_Dd.alloc(gn); c_ps.alloc(gn); c_pc.alloc(gn); c_xm.alloc(gn); c_ym.alloc(gn);
-    c_eval.alloc(gn); c_E.alloc(gn);
-    c_C.alloc(gnn); c_B.alloc(gnn); c_BD.alloc(gnn); c_evec.alloc(gnn);
-    c_z.alloc((size_t)A * HU * Nst);
-    c_Ye.alloc((size_t)G * k * n);
-    c_eidx.alloc((size_t)G * k);
-    c_info.alloc(gn);           // SVD: column permutation
-    c_sync.alloc((size_t)G * CMA_SYNC_WORDS);
-    if (cma_use_eigh()) {
-        const size_t ld = EIGH_LD, mat = ld * ld;
-        e_d.alloc(G * ld); e_e.alloc(G * ld); e_tau.alloc(G * ld); e_alpha.alloc(G); e_lam.alloc(G * ld);
-        e_Vt.alloc(G * mat); e_Z.alloc(G * mat); e_Z2.alloc(G * mat); e_P.alloc(G * mat);
-        e_Tf.alloc((size_t)G * EIGH_TF_WGS * 1024);
-        e_flags.alloc((size_t)G * 8);
-        e_flags.zero(stream);
-    }
-    // C = B = D = I, paths = 0 (cma_es.py:98-117)
-    std::vector<float> eye(gnn, 0.0f), ones(gn, 1.0f);
-    for (int g = 0; g < G; ++g)
-        for (int i = 0; i < n; ++i) eye[(size_t)g * n * n + (size_t)i * n + i] = 1.0f;
-    HIP_CHECK(hipMemcpy(c_C.p, eye.data(), gnn * 4, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(c_B.p, eye.data(), gnn * 4, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(c_Dd.p, ones.data(), gn * 4, hipMemcpyHostToDevice));
-    c_ps.zero(stream);
-    c_pc.zero(stream);
-    cma_reset_mean_sigma();
-}
-
-void Engine::cma_reset_mean_sigma() {
-    // m = bounds midpoint, sigma = sqrt((lo-hi)^2/16) per coordinate (cma_es.py:48-59,95-97; reset :215-227)
-    const size_t gn = (size_t)cma_G * cma_n;          // == A*HU in both modes, same (a,h,u) order
-    std::vector<float> m(gn), sg(gn);
-    for (size_t i = 0; i < gn; ++i) {
-        const int u = (int)(i % U);
-        m[i] = (lo[u] + hi[u]) / 2.0f;
-        const float d = lo[u] - hi[u];
-        sg[i] = sqrtf((d * d) / 16.0f);
-    }
-    HIP_CHECK(hipMemcpy(c_m.p, m.data(), gn * 4, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(c_sigma.p, sg.data(), gn * 4, hipMemcpyHostToDevice));
-}
-
-CmaArgs Engine::cma_args(uint32_t step, uint32_t iter) {
-    CmaArgs q;
-    memset(&q, 0, sizeof(q));
-    q.N = N; q.A = A; q.HU = HU; q.Nst = Nst; q.k = k;
-    q.G = cma_G; q.n = cma_n;
-    q.agents_per_group = fix(BBMPC_CMAES_PER_AGENT) ? 1 : A;
-    q.agent_offset = cfg.agent_offset;
-    q.c = cma_c;
-    q.weights = c_w.p;
-    q.m = c_m.p; q.sigma = c_sigma.p; q.C = c_C.p; q.B = c_B.p; q.Dd = c_Dd.p; q.p_sigma = c_ps.p; q.p_C = c_pc.p;
-    q.BD = c_BD.p; q.z = c_z.p; q.cand = d_cand_a.p; q.rewards = d_rewards.p; q.eidx = c_eidx.p; q.Ye = c_Ye.p;
-    q.xmean = c_xm.p; q.ymean = c_ym.p;
-    q.key = key(step);
-    q.iter = iter;
-    q.pop_offset = cfg.population_offset;
-    return q;
-}
-
-// s, U, _ = tf.linalg.svd(C); B = U, D = diag(sqrt(s))  (cma_es.py:195-198) by the direct eigensolver of kernels_eigh.hpp:
-// eight launches on the handle's stream; instances that fail its checks keep e_flags[8 g] = 1 and B, D untouched
-void Engine::cma_eigh_launch(const CmaArgs& cq) {
-    EighArgs q;
-    memset(&q, 0, sizeof(q));
-    q.n = cma_n; q.G = cma_G;
-    q.force_fail = sw.cma_eigh_fail ? 1 : 0;
-    q.C = cq.C; q.B = cq.B; q.Dd = cq.Dd;
-    q.d = e_d.p; q.e = e_e.p; q.tau = e_tau.p; q.Vt = e_Vt.p; q.alpha = e_alpha.p; q.lam = e_lam.p;
-    q.Z = e_Z.p; q.Z2 = e_Z2.p; q.P = e_P.p; q.Tf = e_Tf.p; q.flags = e_flags.p;
-    const int G = cma_G;
-    const size_t lds1 = sizeof(EighTriLds);
-    const size_t lds2 = std::max(sizeof(EighSolveLds), (size_t)(32 * (EIGH_LD + 1) + 32 * 33) * sizeof(float));
-    ensure_max_lds((const void*)k_eigh_tridiag, (int)lds1);
-    ensure_max_lds((const void*)k_eigh_tri_solve, (int)lds2);
-    hipLaunchKernelGGL(k_eigh_tridiag, dim3(G), dim3(EIGH_TRI_THREADS), lds1, stream, q);
-    hipLaunchKernelGGL(k_eigh_tri_solve, dim3(EIGH_SLOT_WGS + EIGH_TF_WGS, G), dim3(EIGH_SOLVE_THREADS), lds2, stream, q);
-    const dim3 gg(EIGH_LD / 64, EIGH_LD / 64, G);
-    hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, stream, q, (const float*)q.Z, (const float*)nullptr, q.P, 1, 0);
-    hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, stream, q, (const float*)q.Z, (const float*)q.P, q.Z2, 0, 0);
-    hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, stream, q, (const float*)q.Z2, (const float*)nullptr, q.P, 3, 1);
-    hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, stream, q, (const float*)q.Z2, (const float*)q.P, q.Z, 0, 1);
-    hipLaunchKernelGGL(k_eigh_backtransform, dim3(EIGH_LD / 16, G), dim3(256), 0, stream, q, (const float*)q.Z, (const float*)q.Z2);
-    HIP_CHECK(hipGetLastError());
-}
-
-// CMAESOptimizer._optimize  cma_es.py:129-213
-void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
-    const int n = cma_n, G = cma_G;
-    const float* inj_n = injected(BBMPC_NOISE_NORMAL);
-    const size_t inj_stride = (size_t)A * HU * Nst;
-    const size_t gnn = (size_t)G * n * n;
-    for (int it = 0; it < iters; ++it) {
-        CmaArgs q = cma_args(step, (uint32_t)it);
-        q.inj = inj_n ? inj_n + inj_stride * it : nullptr;
-        hipLaunchKernelGGL(k_cma_bd, dim3((unsigned)((gnn + 255) / 256)), dim3(256), 0, stream, q);
-        const int kp = (k + 3) & ~3;
-        const size_t lds = (size_t)(Nst + TOPK_HIST_WORDS + 2 * kp) * 4;
-        want_lds((const void*)k_cma_select, lds, 4096 + 512);       // eidx_s[1024] + the selection's small static words
-        // sample -> roll out -> sorted top-k of this handle's particles (part != null: sharded population)
-        auto shard_pass = [&](float* part) {
-            hipLaunchKernelGGL(k_cma_noise, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, q);
-            if (n > 128 && (n & 3) == 0) hipLaunchKernelGGL(k_cma_gemm_y_mfma, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
-            else hipLaunchKernelGGL(k_cma_gemm_y, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
-            HIP_CHECK(hipGetLastError());
-            ra.cand = d_cand_a.p; ra.samples = d_cand_a.p; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
-            launch_rollout(SRC_BUF, true, ra);                          // clip + penalty (cma_es.py:147-157)
-            hipLaunchKernelGGL(k_cma_select, dim3(G), dim3(REFIT_THREADS), lds, stream, q, part);
-            HIP_CHECK(hipGetLastError());
-        };
-        if (pop_sharded()) {
-            // population sharded over ranks: every rank samples and rolls out ITS particles, the sorted local
-            // elites (reward, global index, candidate) are exchanged and merged (kernels_cma.hpp); the path / covariance
-            // update and the eigen-decomposition run replicated on every rank
-            const int R = ps_loopback > 1 ? ps_loopback : std::max(1, rc.comm ? rc.nranks : 1);
-            const size_t pw = (size_t)G * k * (n + 2);
-            if (!ps_part.p || ps_part.n < pw) ps_part.alloc(pw);
-            if (ps_all.n < pw * R) ps_all.alloc(pw * R);
-            if (ps_loopback > 1) {
-                for (int r = 0; r < R; ++r) {
-                    q.pop_offset = r * N;
-                    shard_pass(ps_all.p + pw * r);
-                }
-                q.pop_offset = cfg.population_offset;
-            } else {
-                shard_pass(ps_part.p);
-                if (rc.comm) {
-                    const Rccl& r = Rccl::get();
-                    r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (CMA-ES local elites)");
-                } else {
-                    REQUIRE(cfg.population_global <= N, BBMPC_E_STATE, "population sharding needs a communicator: call bbmpc_comm_init first");
-                    HIP_CHECK(hipMemcpyAsync(ps_all.p, ps_part.p, pw * 4, hipMemcpyDeviceToDevice, stream));
-                }
-            }
-            if (trace_on && !c_eidx_glob.p) c_eidx_glob.alloc((size_t)G * k);
-            hipLaunchKernelGGL(k_cma_merge, dim3(G), dim3(1024), 0, stream, q, ps_all.p, R, trace_on ? c_eidx_glob.p : (int*)nullptr);
-            HIP_CHECK(hipGetLastError());
-        } else {
-            shard_pass(nullptr);
-        }
-        hipLaunchKernelGGL(k_cma_paths, dim3(G), dim3(n > 128 ? 1024 : REFIT_THREADS), 0, stream, q);
-        hipLaunchKernelGGL(k_cma_cov, dim3((n + 15) / 16, (n + 15) / 16, G), dim3(16, 16), 0, stream, q);
-        HIP_CHECK(hipGetLastError());
-        const bool eigh = cma_use_eigh();
-        const unsigned* need = eigh ? e_flags.p : nullptr;      // the Jacobi below then runs only for instances the direct solver gave up
-        if (eigh) cma_eigh_launch(q);
-        if (n <= 512 && !sw.cma_svd_v1) {
-            // warm-started Jacobi, one 1024-thread workgroup per instance (kernels_cma.hpp)
-            HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * CMA_SYNC_WORDS * sizeof(unsigned), stream));
-            if (n > 128 && (n & 3) == 0) hipLaunchKernelGGL(k_cma_warm_mfma, dim3((n + 31) / 32, (n + 63) / 64, G), dim3(256), 0, stream, q, c_evec.p, need);
-            else hipLaunchKernelGGL(k_cma_warm, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(256), 0, stream, q, c_evec.p);
-            const int bsz = (n + 7) / 8;
-            const int ncb = (n + 63) / 64;                               // k_cma_svd_block<ncb, NB>: LDS column pitch 64 * ncb
-            // NB = 16 column blocks on 8 workgroups per instance when there are CUs for them (BBMPC_CMA_NB overrides)
-            // 20 blocks for 256 < n <= 320: 15-16 columns per block = 16-lane rows of FOUR waves, one per SIMD, in the cross rounds
-            // (19 columns are five waves, two of them on one SIMD: a round is instruction-issue bound and takes twice as long)
-            const int nb_auto = (ncb == 5 && 80 * ((G + 7) / 8) <= 256) ? 20 : ((64 * ((G + 7) / 8) <= 256 && n >= 256) ? 16 : 8);
-            const int nbk = (sw.cma_nb == 8 || sw.cma_nb == 16 || (sw.cma_nb == 20 && ncb == 5)) ? sw.cma_nb : nb_auto;
-            const int bsk = (n + nbk - 1) / nbk;
-            const size_t blds = (size_t)2 * bsk * 64 * ncb * sizeof(float);
-            if (n >= 128 && (n & 3) == 0 && bsz <= 64 && cma_gram_lds_bytes(n) <= 159 * 1024 && cma_gram_wp(n) <= 128 && G * 4 <= 256 &&
-                !sw.cma_svd_rounds && sw.cma_svd_gram) {
-                // block Jacobi in the Gram domain: Gram matrix / column update on the matrix cores, rotations on 2bs x 2bs data
-                ensure_max_lds((const void*)k_cma_svd_gram, 159 * 1024);     // + a few static words
-                float* evp = c_evec.p;
-                unsigned* syp = c_sync.p;
-                int sweeps = 15;
-                void* kargs[] = {(void*)&q, (void*)&evp, (void*)&syp, (void*)&sweeps};
-                HIP_CHECK(hipLaunchCooperativeKernel((const void*)k_cma_svd_gram, dim3(4, G), dim3(1024), kargs, cma_gram_lds_bytes(n), stream));
-            } else if (n >= 128 && (n & 3) == 0 && bsz <= 64 && blds <= 159 * 1024 && 8 * (nbk / 2) * ((G + 7) / 8) <= 256 && !sw.cma_svd_rounds) {
-                // block Jacobi: 4 workgroups per instance, block pairs resident in LDS, 7 instance barriers per sweep
-                const void* kfn = nullptr;
-#define BBMPC_SVD_CASE(NC_) case NC_: kfn = nbk == 16 ? (const void*)k_cma_svd_block<NC_, 16> : (const void*)k_cma_svd_block<NC_, 8>; break;
-                if (nbk == 20) kfn = (const void*)k_cma_svd_block<5, 20>;
-                else
-                switch (ncb) {
-                    BBMPC_SVD_CASE(2) BBMPC_SVD_CASE(3) BBMPC_SVD_CASE(4) BBMPC_SVD_CASE(5) BBMPC_SVD_CASE(6) BBMPC_SVD_CASE(7)
-                    default: kfn = nbk == 16 ? (const void*)k_cma_svd_block<8, 16> : (const void*)k_cma_svd_block<8, 8>; break;
-                }
-#undef BBMPC_SVD_CASE
-                ensure_max_lds(kfn, 159 * 1024);     // + a few static words
-                // The instance barrier spins, so an instance's workgroups must be resident together.  The grid is at most
-                // 256 workgroups of one per CU (97 KB of LDS each), i.e. it always fits the idle part of a 256-CU device, and
-                // a plain launch has the residency of a cooperative one (MI355X_MICROARCH.md); the cooperative form only
-                // adds the launch-time size check -- and 15-19 us of host time per launch during which this thread cannot
-                // run ahead of the GPU (five of them per control step: act() 10.5 ms against 9.3 ms device-resident).
-                // BBMPC_CMA_COOP=1 brings it back.
-                {
-                    float* evp = c_evec.p;
-                    unsigned* syp = c_sync.p;
-                    int sweeps = 15;
-                    const unsigned* needp = need;
-                    void* kargs[] = {(void*)&q, (void*)&evp, (void*)&syp, (void*)&sweeps, (void*)&needp};
-                    // 1-D grid, an instance's four workgroups on one XCD (kernels_cma.hpp); surplus workgroups return at once
-                    const dim3 sgrid(8 * (nbk / 2) * ((G + 7) / 8)), sblock(nbk >= 16 ? 512 : 1024);
-                    // the plain launch is only as good as a cooperative one while every workgroup finds a CU of its own at once:
-                    // on a partition with fewer CUs (CPX / DPX modes, CU masks) the spinning barrier would wait for workgroups
-                    // that were never dispatched -- there the cooperative launch, which refuses what does not fit
-                    if (sw.cma_coop || (int)sgrid.x > cu_count) HIP_CHECK(hipLaunchCooperativeKernel(kfn, sgrid, sblock, kargs, blds, stream));
-                    else HIP_CHECK(hipLaunchKernel(kfn, sgrid, sblock, kargs, blds, stream));
-                }
-            } else {
-                if (n <= 128 && !sw.cma_svd_general) {
-                    const int pairs = (n + 1) / 2;
-                    if (n <= 64) {
-                        hipLaunchKernelGGL(k_cma_svd_small<4>, dim3(G), dim3(64 * ((pairs + 3) / 4)), (size_t)n * n * sizeof(float), stream,
-                                           q, c_evec.p, c_sync.p, 15);
-                    } else {
-                        if ((size_t)n * n * sizeof(float) > 48 * 1024) ensure_max_lds((const void*)k_cma_svd_small<8>, 96 * 1024);
-                        hipLaunchKernelGGL(k_cma_svd_small<8>, dim3(G), dim3(64 * ((pairs + 3) / 4)), (size_t)n * n * sizeof(float), stream,
-                                           q, c_evec.p, c_sync.p, 15);
-                    }
-                } else {
-                // small n: the matrix fits LDS; a workgroup sized to the number of pairs
-                const size_t rl = (size_t)n * n * sizeof(float) <= 64 * 1024 ? (size_t)n * n * sizeof(float) : 0;
-                const int rthreads = std::min(1024, std::max(64, 64 * ((n + 1) / 2)));
-                hipLaunchKernelGGL(k_cma_svd_rounds, dim3(1, G), dim3(rthreads), rl, stream, q, c_evec.p, c_sync.p, 15,
-                                   (int)(rl / sizeof(float)));
-                }
-            }
-            if (n > 128 && n <= 2048) {
-                hipLaunchKernelGGL(k_cma_svd_norms, dim3(G), dim3(1024), 0, stream, q, c_evec.p, c_eval.p, c_info.p, need);
-                hipLaunchKernelGGL(k_cma_svd_build_b, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(32, 8), 0, stream, q, c_evec.p, c_eval.p, c_info.p, need);
-            } else {
-                hipLaunchKernelGGL(k_cma_svd_finish, dim3(G), dim3(n > 256 ? 1024 : 256), 0, stream, q, c_evec.p, c_eval.p, c_info.p);
-            }
-        } else {
-            hipLaunchKernelGGL(k_cma_svd, dim3(G), dim3(REFIT_THREADS), 0, stream, q, c_evec.p, c_eval.p, c_info.p, 15);
-        }
-        HIP_CHECK(hipGetLastError());
-        if (trace_on) {
-            ensure_trace();
-            const size_t nr = (size_t)A * Nst, nm = (size_t)A * HU, ns = (size_t)A * HU * Nst;
-            HIP_CHECK(hipMemcpyAsync(t_rewards.p + nr * it, d_rewards.p, nr * 4, hipMemcpyDeviceToDevice, stream));
-            HIP_CHECK(hipMemcpyAsync(t_mean.p + nm * it, c_m.p, nm * 4, hipMemcpyDeviceToDevice, stream));
-            HIP_CHECK(hipMemcpyAsync(t_samples.p + ns * it, d_cand_a.p, ns * 4, hipMemcpyDeviceToDevice, stream));
-            HIP_CHECK(hipMemcpyAsync(t_elites.p + (size_t)A * std::max(k, 1) * it, pop_sharded() ? c_eidx_glob.p : c_eidx.p, (size_t)G * k * 4,
-                                     hipMemcpyDeviceToDevice, stream));      // (sharded: the GLOBAL particle indices of the elites)
-            // the eigen-system this iteration produced (B, D) and the covariance it factorises: parity tests feed the
-            // oracle the engine's own (D^2, B) every iteration and check the factorisation's invariants
-            if (!t_cma_B.p) {
-                t_cma_B.alloc(gnn * std::max(iters, 1));
-                t_cma_C.alloc(gnn * std::max(iters, 1));
-                t_cma_D.alloc((size_t)G * n * std::max(iters, 1));
-            }
-            HIP_CHECK(hipMemcpyAsync(t_cma_B.p + gnn * it, c_B.p, gnn * 4, hipMemcpyDeviceToDevice, stream));
-            HIP_CHECK(hipMemcpyAsync(t_cma_C.p + gnn * it, c_C.p, gnn * 4, hipMemcpyDeviceToDevice, stream));
-            HIP_CHECK(hipMemcpyAsync(t_cma_D.p + (size_t)G * n * it, c_Dd.p, (size_t)G * n * 4, hipMemcpyDeviceToDevice, stream));
-            if (!t_cma_stats.p) { t_cma_stats.alloc((size_t)G * 16 * std::max(iters, 1)); t_cma_stats.zero(stream); }
-            if (n <= 512 && !sw.cma_svd_v1) {
-                // rotation counts of the sweeps ([G][CMA_SYNC_WORDS] words -> [G][16]); word 15: did the Jacobi run for the instance
-                HIP_CHECK(hipMemcpy2DAsync(t_cma_stats.p + (size_t)G * 16 * it, 16 * sizeof(int), c_sync.p + CMA_SYNC_ROTATIONS,
-                                           CMA_SYNC_WORDS * sizeof(unsigned), 15 * sizeof(int), G, hipMemcpyDeviceToDevice, stream));
-                if (eigh) HIP_CHECK(hipMemcpy2DAsync(t_cma_stats.p + (size_t)G * 16 * it + 15, 16 * sizeof(int), e_flags.p, 8 * sizeof(unsigned),
-                                                     sizeof(int), G, hipMemcpyDeviceToDevice, stream));
-                else HIP_CHECK(hipMemcpy2DAsync(t_cma_stats.p + (size_t)G * 16 * it + 15, 16 * sizeof(int), c_sync.p + 1, CMA_SYNC_WORDS * sizeof(unsigned),
-                                                sizeof(int), G, hipMemcpyDeviceToDevice, stream));
-            }
-        }
-    }
-    hipLaunchKernelGGL(k_take_first, dim3((A * U + 63) / 64), dim3(64), 0, stream, A, HU, U, c_m.p, d_action.p);   // :211-212
-    HIP_CHECK(hipGetLastError());
-}
 
 void Engine::reset() {
     // CEM/PI2/SPSA reset(): previous solution <- bounds midpoint (cem.py:138-149, pi2.py:98-105)
@@ -810,288 +497,6 @@ void Engine::get_profile(double* ms, int64_t* launches) {
     ev_used = 0;
 }
 
-// ------------------------------------------------------------------------------------------------
-// launches
-// ------------------------------------------------------------------------------------------------
-void Engine::set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, const float* const* w, const float* const* b,
-                     int is_normalized, const float* const* stats) {
-    REQUIRE(cfg.dynamics == BBMPC_DYN_MLP, BBMPC_E_STATE, "handle was not created with BBMPC_DYN_MLP");
-    REQUIRE(n_layers >= 1 && n_layers <= MLP_MAX_LAYERS, BBMPC_E_UNSUPPORTED, "1..8 Dense layers are supported");
-    REQUIRE(dims && acts && w && b, BBMPC_E_INVALID, "null argument");
-    REQUIRE(dims[0] == S + U && dims[n_layers] == S, BBMPC_E_INVALID, "MLP must map dim_S+dim_U -> dim_S");
-    HIP_CHECK(hipStreamSynchronize(stream));
-    memset(&mlp, 0, sizeof(mlp));
-    mlp.n_layers = n_layers;
-    int hidden_tiles = 1;
-    for (int l = 0; l <= n_layers; ++l) {
-        REQUIRE(dims[l] >= 1, BBMPC_E_INVALID, "layer width must be >= 1");
-        mlp.dims[l] = dims[l];
-        mlp.tiles[l] = (dims[l] + 15) / 16;
-        if (l >= 1 && l < n_layers) hidden_tiles = std::max(hidden_tiles, mlp.tiles[l]);
-    }
-    REQUIRE(hidden_tiles <= 16 * MLP_TMAX, BBMPC_E_UNSUPPORTED, "hidden width > 512 not supported");
-    REQUIRE(mlp.tiles[0] <= 8 && mlp.tiles[n_layers] <= 4, BBMPC_E_UNSUPPORTED, "dim_S+dim_U <= 128 and dim_S <= 64 supported");
-    mlp_nw = std::min(16, hidden_tiles);
-    for (int l = 1; l < n_layers; ++l) {
-        const int tail = dims[l] - 16 * (mlp.tiles[l] - 1);
-        mlp.half_tail[l] = (tail <= 8 && !sw.mlp_no_half_tail) ? 1 : 0;
-    }
-    for (int l = 0; l < n_layers; ++l) {
-        REQUIRE(acts[l] >= BBMPC_ACT_NONE && acts[l] <= BBMPC_ACT_SIGMOID, BBMPC_E_INVALID, "unknown activation");
-        REQUIRE(w[l] && b[l], BBMPC_E_INVALID, "null weight/bias pointer");
-        mlp.act[l] = acts[l];
-        const int K = dims[l], M = dims[l + 1], IT = mlp.tiles[l], OT = mlp.tiles[l + 1];
-        std::vector<float> wp((size_t)OT * IT * 256, 0.0f), bp((size_t)OT * 256, 0.0f);
-        // Hidden features are internal, so their order inside a tile is free.  When the last tile of a hidden layer
-        // holds <= 8 features (200 units = 12 tiles + 8) they are put into the slots 4g + {0, 1}: as the next layer's
-        // K tile that leaves MFMAs 2 and 3 (k = 4g + 2, 4g + 3) with nothing but zeros, and the pipelined kernel
-        // skips them.  slot -> feature (or -1 = padding); inputs (layer 0) and outputs (last layer) keep their order.
-        auto feature_of_slot = [&](int layer_of_feature, int slot) -> int {
-            const int width = dims[layer_of_feature], tiles = (width + 15) / 16, t = slot >> 4, q = slot & 15;
-            if (layer_of_feature >= 1 && layer_of_feature < n_layers && t == tiles - 1 && mlp.half_tail[layer_of_feature]) {
-                if ((q & 3) >= 2) return -1;
-                const int f = 16 * t + 2 * (q >> 2) + (q & 3);
-                return f < width ? f : -1;
-            }
-            return slot < width ? slot : -1;
-        };
-        for (int ot = 0; ot < OT; ++ot) {
-            for (int it = 0; it < IT; ++it)
-                for (int s = 0; s < 4; ++s)
-                    for (int ln = 0; ln < 64; ++ln) {
-                        const int k = feature_of_slot(l, it * 16 + 4 * (ln >> 4) + s), o = feature_of_slot(l + 1, ot * 16 + (ln & 15));
-                        if (k >= 0 && o >= 0) wp[(((size_t)ot * IT + it) * 4 + s) * 64 + ln] = w[l][(size_t)k * M + o];
-                    }
-            for (int ln = 0; ln < 64; ++ln)
-                for (int r = 0; r < 4; ++r) {
-                    const int o = feature_of_slot(l + 1, ot * 16 + (ln >> 4) * 4 + r);
-                    if (o >= 0) bp[((size_t)ot * 64 + ln) * 4 + r] = b[l][o];
-                }
-        }
-        upload(d_wpack[l], wp);
-        upload(d_bpack[l], bp);
-        upload(d_wraw[l], std::vector<float>(w[l], w[l] + (size_t)K * M));
-        upload(d_braw[l], std::vector<float>(b[l], b[l] + M));
-        {   // quad-mode operand order [k/4][Mp][4]; the k/4 axis is zero padded to a multiple of 64 groups so that the
-            // kernels can load a fixed number of groups per lane without bounds (group 63 of a <= 252-input layer is a zero row)
-            const int Mp = (M + 63) & ~63, KG = ((K + 3) / 4 + 63) & ~63;
-            std::vector<float> wq((size_t)KG * Mp * 4, 0.0f);
-            for (int kk = 0; kk < K; ++kk)
-                for (int o = 0; o < M; ++o) wq[((size_t)(kk >> 2) * Mp + o) * 4 + (kk & 3)] = w[l][(size_t)kk * M + o];
-            upload(d_wq4[l], wq);
-        }
-        {   // optional bf16 mode operands: [OT][IT][64] x (4 bf16 hi | 4 bf16 lo), k = 16*it + 4*(lane>>4) + r, row = 16*ot + (lane&15)
-            auto bf16_rne = [](float x) -> uint16_t {
-                uint32_t u; memcpy(&u, &x, 4);
-                u += 0x7fffu + ((u >> 16) & 1u);
-                return (uint16_t)(u >> 16);
-            };
-            auto bf16_f = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
-            const int IT = (K + 15) / 16, OT = (M + 15) / 16;
-            std::vector<float> wb((size_t)OT * IT * 64 * 4, 0.0f);          // 16 bytes per lane, kept in a float buffer
-            uint16_t* hw = reinterpret_cast<uint16_t*>(wb.data());
-            for (int ot = 0; ot < OT; ++ot)
-                for (int it = 0; it < IT; ++it)
-                    for (int ln = 0; ln < 64; ++ln)
-                        for (int r = 0; r < 4; ++r) {
-                            // same slot -> feature map as the fp32 operands (the biases come from bpack)
-                            const int kk = feature_of_slot(l, 16 * it + 4 * (ln >> 4) + r), o = feature_of_slot(l + 1, 16 * ot + (ln & 15));
-                            const float v = (kk >= 0 && o >= 0) ? w[l][(size_t)kk * M + o] : 0.0f;
-                            const uint16_t h = bf16_rne(v), lo = bf16_rne(v - bf16_f(h));
-                            uint16_t* d = hw + (((size_t)ot * IT + it) * 64 + ln) * 8;
-                            d[r] = h;
-                            d[4 + r] = lo;
-                        }
-            upload(d_wbf[l], wb);
-        }
-        mlp.wpack[l] = d_wpack[l].p;
-        mlp.bpack[l] = d_bpack[l].p;
-    }
-    mlp.normalized = is_normalized ? 1 : 0;
-    if (is_normalized) {
-        REQUIRE(stats, BBMPC_E_INVALID, "normalisation statistics are required when is_normalized != 0");
-        std::vector<float> st;
-        const int lens[6] = {S, S, U, U, S, S};
-        for (int i = 0; i < 6; ++i) {
-            REQUIRE(stats[i], BBMPC_E_INVALID, "null statistics vector");
-            st.insert(st.end(), stats[i], stats[i] + lens[i]);
-        }
-        upload(d_stats, st);
-        float* q = d_stats.p;
-        mlp.mean_s = q; q += S;
-        mlp.std_s = q; q += S;
-        mlp.mean_a = q; q += U;
-        mlp.std_a = q; q += U;
-        mlp.mean_t = q; q += S;
-        mlp.std_t = q;
-    }
-    mlp_ready = true;
-}
-
-void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_particle_state, float* final_state) {
-    REQUIRE(mlp_ready, BBMPC_E_STATE, "learned dynamics: call bbmpc_set_mlp before computing");
-    MlpRolloutArgs q;
-    memset(&q, 0, sizeof(q));
-    q.r = ra;
-    q.m = mlp;
-    q.mode = mode;
-    q.pen = pen ? 1 : 0;
-    q.per_particle_state = per_particle_state ? 1 : 0;
-    q.final_state = final_state;
-    q.nw = mlp_nw;
-    q.traj = mlp_traj_out;
-    const bool record = mlp_traj_out != nullptr;       // trajectory recording lives in rollout_mlp_body's epilogue only
-    for (int l = 0; l < mlp.n_layers; ++l) { q.wraw[l] = d_wraw[l].p; q.braw[l] = d_braw[l].p; q.wq4[l] = d_wq4[l].p; q.wbf[l] = reinterpret_cast<const uint4*>(d_wbf[l].p); }
-    const MlpLds lay = mlp_lds_layout(mlp, ra.H, U, S, mlp_nw);
-    const size_t lds = (size_t)lay.total * sizeof(float);
-    REQUIRE(lds <= 159 * 1024, BBMPC_E_UNSUPPORTED,
-            "learned-model rollout: a 16-particle tile's action block (planning_horizon x 16 x dim_u floats) plus the activation / "
-            "partial-sum buffers of this network do not fit one CU's LDS (shorten the horizon or narrow the network)");
-    // weights-stationary specialisations (kernels_mlp.hpp)
-    int spec = 0;
-    const bool small_io = mlp.tiles[0] <= 2 && mlp.tiles[mlp.n_layers] <= 2;
-    if (small_io && mlp.n_layers == 3 && mlp.tiles[1] == mlp.tiles[2] && mlp.tiles[1] <= 16 && mlp_nw == mlp.tiles[1]) spec = 1;
-    if (small_io && mlp.n_layers == 4 && mlp.tiles[1] == mlp.tiles[2] && mlp.tiles[2] == mlp.tiles[3] && mlp.tiles[1] <= 4 &&
-        mlp_nw == mlp.tiles[1]) spec = 2;
-    if (sw.mlp_generic) spec = 0;
-    const bool single_step = per_particle_state && ra.H == 1;
-    if (single_step) spec = 3;
-    if (sw.mlp_bf16 && spec == 1 && !per_particle_state && !final_state && !record) {
-        // opt-in reduced-precision mode (kernels_mlp.hpp): never selected automatically
-        dim3 bgrid((ra.n_pop + MLP_TP - 1) / MLP_TP, A), bblock(mlp_nw * 64);
-        dominant_kernel = sw.mlp_bf16 == 3 ? "k_rollout_mlp_bf16<3>" : "k_rollout_mlp_bf16<1>";
-        const void* bfn = sw.mlp_bf16 == 3 ? (const void*)k_rollout_mlp_bf16<3> : (const void*)k_rollout_mlp_bf16<1>;
-        if (lds > 64 * 1024) ensure_max_lds(bfn, 159 * 1024);
-        prof_begin();
-        if (sw.mlp_bf16 == 3) hipLaunchKernelGGL(k_rollout_mlp_bf16<3>, bgrid, bblock, lds, stream, q);
-        else hipLaunchKernelGGL(k_rollout_mlp_bf16<1>, bgrid, bblock, lds, stream, q);
-        HIP_CHECK(hipGetLastError());
-        prof_end();
-        return;
-    }
-    // small networks: one wave per 16-particle tile, the whole Dense stack in its registers (kernels_mlp_wave.hpp)
-    if (!sw.mlp_generic && sw.mlp_wave != 0 && !single_step && small_io && mlp.n_layers >= 2 && mlp.n_layers <= 4 && mlp.tiles[1] <= 4) {
-        bool same = true;
-        for (int l = 2; l < mlp.n_layers; ++l) same = same && mlp.tiles[l] == mlp.tiles[1];
-        if (same) {
-            using KFn = void (*)(MlpRolloutArgs);
-            static const KFn table[2][3][4] = {
-                {{k_rollout_mlp_wave<1, 1, false>, k_rollout_mlp_wave<1, 2, false>, k_rollout_mlp_wave<1, 3, false>, k_rollout_mlp_wave<1, 4, false>},
-                 {k_rollout_mlp_wave<2, 1, false>, k_rollout_mlp_wave<2, 2, false>, k_rollout_mlp_wave<2, 3, false>, k_rollout_mlp_wave<2, 4, false>},
-                 {k_rollout_mlp_wave<3, 1, false>, k_rollout_mlp_wave<3, 2, false>, k_rollout_mlp_wave<3, 3, false>, k_rollout_mlp_wave<3, 4, false>}},
-                {{k_rollout_mlp_wave<1, 1, true>, k_rollout_mlp_wave<1, 2, true>, k_rollout_mlp_wave<1, 3, true>, k_rollout_mlp_wave<1, 4, true>},
-                 {k_rollout_mlp_wave<2, 1, true>, k_rollout_mlp_wave<2, 2, true>, k_rollout_mlp_wave<2, 3, true>, k_rollout_mlp_wave<2, 4, true>},
-                 {k_rollout_mlp_wave<3, 1, true>, k_rollout_mlp_wave<3, 2, true>, k_rollout_mlp_wave<3, 3, true>, k_rollout_mlp_wave<3, 4, true>}}};
-            bool tanh_net = mlp.act[mlp.n_layers - 1] == BBMPC_ACT_NONE;
-            for (int l = 0; l + 1 < mlp.n_layers; ++l) tanh_net = tanh_net && mlp.act[l] == BBMPC_ACT_TANH;
-            const KFn wfn = table[tanh_net ? 1 : 0][mlp.n_layers - 2][mlp.tiles[1] - 1];
-            const int wht = mlp.tiles[1];
-            const size_t wlds = (size_t)mlp_wave_lds_layout(ra.H, U, S, mlp.n_layers - 1, wht).total * sizeof(float);
-            if (wlds <= 159 * 1024) {
-                if (wlds > 64 * 1024) ensure_max_lds((const void*)wfn, 159 * 1024);
-                dim3 wgrid((ra.n_pop + MLP_TP - 1) / MLP_TP, per_particle_state ? 1 : A), wblock(64 * mlp_wave_waves(wht));
-                dominant_kernel = "k_rollout_mlp_wave";
-                prof_begin();
-                hipLaunchKernelGGL(wfn, wgrid, wblock, wlds, stream, q);
-                HIP_CHECK(hipGetLastError());
-                prof_end();
-                return;
-            }
-        }
-    }
-    const void* fn = spec == 3 ? (const void*)k_step_mlp : spec == 1 ? (const void*)k_rollout_mlp<1> : (spec == 2 ? (const void*)k_rollout_mlp<2> : (const void*)k_rollout_mlp<0>);
-    if (lds > 64 * 1024) ensure_max_lds(fn, 159 * 1024);
-    // pair mode (two tiles per workgroup, software-pipelined) when there are more tiles than CUs can hold one each
-    const long tiles_total = (long)((ra.n_pop + MLP_TP - 1) / MLP_TP) * A;
-    // the 26-200-200-20 tanh/tanh/linear family has its own kernels (all of them can record the trajectory)
-    const bool fam_ok = spec == 1 && mlp.tiles[1] == 13 && !per_particle_state && mlp.act[0] == BBMPC_ACT_TANH &&
-                        mlp.act[1] == BBMPC_ACT_TANH && mlp.act[2] == BBMPC_ACT_NONE;
-    const bool pair_ok = fam_ok;
-    int pair = (pair_ok && tiles_total > 256) ? 1 : 0;
-    if (sw.mlp_pair >= 0) pair = (sw.mlp_pair != 0 && pair_ok) ? 1 : 0;
-    // quad mode (4 particles per workgroup, 4x4x1_16b MFMA, all weights in registers) when the population is too
-    // small to give every CU a 16-particle tile
-    {
-        const bool q4_ok = fam_ok && mlp.dims[0] <= 28 && mlp.dims[1] == 200 && mlp.dims[2] == 200 && mlp.dims[3] <= 64;
-        // measured on MI355X (tools/q4_sweep.py, PI2, H = 30, us per control step): a "wave" of 256 quad workgroups (one
-        // per CU, 1024 particles) costs ~400 us, the 16-particle tiling ~850 us for anything up to 4096 particles:
-        // quads win up to two waves (N*A <= 2048: 810 vs 860), lose from the third on (2500: 1177 vs 868)
-        const long quads_total = (long)((ra.n_pop + 3) / 4) * A;
-        int q4 = (q4_ok && quads_total <= 512) ? 1 : 0;
-        if (sw.mlp_q4 >= 0) q4 = (sw.mlp_q4 != 0 && q4_ok) ? 1 : 0;
-        // register-resident-state form (two barriers per model step, kernels_mlp_q4r.hpp): dim_S == 20, cheetah reward or none
-        if (q4 && !sw.mlp_generic && sw.mlp_q4r && S == 20 && U <= 8 && mlp.dims[3] == 20 &&
-            (ra.reward_kind == REW_CHEETAH || ra.reward_kind == REW_NONE)) {
-            const size_t qlds = (size_t)mlp_q4r_lds_floats(50, 7, ra.H, U) * sizeof(float);
-            const int qpairs = 4 * ((ra.H * U + 3) / 4);
-            if (qlds <= 160 * 1024 && qpairs <= Q4R_MAX_ACTION_PAIRS) {
-                auto fn = (qpairs <= 256) ? k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1>
-                                          : k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>;
-                if (qlds > 64 * 1024) ensure_max_lds((const void*)fn, 160 * 1024);
-                dim3 qgrid((ra.n_pop + 3) / 4, A), qblock(256);
-                dominant_kernel = "k_rollout_mlp_q4r";
-                prof_begin();
-                hipLaunchKernelGGL(fn, qgrid, qblock, qlds, stream, q);
-                HIP_CHECK(hipGetLastError());
-                prof_end();
-                return;
-            }
-        }
-        if (q4 && !sw.mlp_generic) {
-            const size_t qlds = (size_t)mlp_q4_lds_floats(50, 7, 4, ra.H, U, S) * sizeof(float);
-            if (qlds <= 160 * 1024) {
-                auto fn = k_rollout_mlp_q4<50, 7, 4, ACT_TANH, ACT_TANH, ACT_NONE>;
-                if (qlds > 64 * 1024) ensure_max_lds((const void*)fn, 160 * 1024);
-                dim3 qgrid((ra.n_pop + 3) / 4, A), qblock(256);
-                dominant_kernel = "k_rollout_mlp_q4";
-                prof_begin();
-                hipLaunchKernelGGL(fn, qgrid, qblock, qlds, stream, q);
-                HIP_CHECK(hipGetLastError());
-                prof_end();
-                return;
-            }
-        }
-    }
-    if (pair_ok && !sw.mlp_generic) {
-        // pipelined kernel for the 26-200-200-20 family: two tiles per workgroup when tiles outnumber the CUs,
-        // one tile per workgroup otherwise (more workgroups beat better per-workgroup efficiency then)
-        const int nt = pair ? 2 : 1;
-        const size_t plds = (size_t)mlp_pair_lds_floats(13, ra.H, U, S, nt) * sizeof(float);
-        if (plds <= 159 * 1024) {
-            dim3 pgrid((ra.n_pop + nt * MLP_TP - 1) / (nt * MLP_TP), A), pblock(mlp_pair_waves(13, nt) * 64);
-            dominant_kernel = "k_rollout_mlp_pair";
-            prof_begin();
-            if (nt == 2 && S == 20 && U == 6 && ra.H == 50 && ra.reward_kind == REW_CHEETAH && !q.traj && mlp.half_tail[1] && mlp.half_tail[2]) {
-                // BASELINE config 5: dimensions and the reward at compile time (no register spills, kernels_mlp.hpp)
-                ensure_max_lds((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2, 20, 6, 50, REW_CHEETAH, 1>), 159 * 1024);
-                hipLaunchKernelGGL((k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2, 20, 6, 50, REW_CHEETAH, 1>), pgrid, pblock, plds, stream, q);
-            } else if (nt == 2 && S == 20 && U == 6 && ra.H == 50) {
-                ensure_max_lds((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2, 20, 6, 50>), 159 * 1024);
-                hipLaunchKernelGGL((k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2, 20, 6, 50>), pgrid, pblock, plds, stream, q);
-            } else if (nt == 2 && S == 20 && U == 6) {
-                ensure_max_lds((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2, 20, 6>), 159 * 1024);
-                hipLaunchKernelGGL((k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2, 20, 6>), pgrid, pblock, plds, stream, q);
-            } else if (nt == 2) {
-                ensure_max_lds((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2>), 159 * 1024);
-                hipLaunchKernelGGL((k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 2>), pgrid, pblock, plds, stream, q);
-            } else {
-                ensure_max_lds((const void*)(k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 1>), 159 * 1024);
-                hipLaunchKernelGGL((k_rollout_mlp_pair<13, ACT_TANH, ACT_TANH, ACT_NONE, 1>), pgrid, pblock, plds, stream, q);
-            }
-            HIP_CHECK(hipGetLastError());
-            prof_end();
-            return;
-        }
-    }
-    dim3 grid((ra.n_pop + MLP_TP - 1) / MLP_TP, per_particle_state ? 1 : A), block(mlp_nw * 64);
-    prof_begin();
-    if (spec == 3) hipLaunchKernelGGL(k_step_mlp, grid, block, lds, stream, q);
-    else if (spec == 1) hipLaunchKernelGGL(k_rollout_mlp<1>, grid, block, lds, stream, q);
-    else if (spec == 2) hipLaunchKernelGGL(k_rollout_mlp<2>, grid, block, lds, stream, q);
-    else hipLaunchKernelGGL(k_rollout_mlp<0>, grid, block, lds, stream, q);
-    HIP_CHECK(hipGetLastError());
-    prof_end();
-}
 
 // ------------------------------------------------------------------------------------------------
 // user device functions (rtc.hpp) + the step-wise evaluator (kernels_user.hpp)
@@ -1389,18 +794,6 @@ void Engine::capture_trace(int it) {
     HIP_CHECK(hipMemcpyAsync(t_elites.p + ne * it, d_elites.p, ne * 4, hipMemcpyDeviceToDevice, stream));
 }
 
-// Launch the last kernel of a control step.  When the caller asked for a completion event (the record all-gather
-// waits on it from its own stream) the event rides on the kernel's own dispatch packet: a separate
-// hipEventRecord costs the launch stream ~5 us per control step (tools/gather_overhead.py).
-template <class F, class Args>
-static void launch_with_tail(Engine& e, F fn, dim3 grid, dim3 block, size_t lds, const Args& args) {
-    if (e.tail_event) {
-        hipExtLaunchKernelGGL(fn, grid, block, lds, e.stream, nullptr, e.tail_event, 0, args);
-        e.tail_attached = true;
-    } else {
-        hipLaunchKernelGGL(fn, grid, block, lds, e.stream, args);
-    }
-}
 
 void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step) {
     FinalArgs fa;
@@ -1472,267 +865,6 @@ RowMlp Engine::row_mlp() const {
     return r;
 }
 
-bool Engine::use_fused() const {
-    if (cfg.dynamics != BBMPC_DYN_PENDULUM || cfg.reward != BBMPC_REW_PENDULUM) return false;
-    if (pop_sharded()) return false;            // the refit is split around a collective: per-iteration kernels
-    if (cfg.optimizer == BBMPC_OPT_SPSA) {
-        if (iters > FUSED_MAX_SPSA_ITERS) return false;
-    } else if (cfg.optimizer != BBMPC_OPT_RANDOM_SEARCH && cfg.optimizer != BBMPC_OPT_CEM && cfg.optimizer != BBMPC_OPT_PI2) {
-        return false;
-    }
-    if (fused_mode == 0) return false;
-    if (fused_mode == 1) return true;
-    // auto: one workgroup per agent keeps a whole control step in one launch.  When a handful of agents
-    // own very large populations the per-iteration kernels spread the rollouts over more CUs instead.
-    return (long)N <= 2048 || A >= 64;
-}
-
-template <int OPT, bool FASTM, int INJ, int ILP>
-static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
-#ifdef BBMPC_KERNEL_DBG
-    const size_t limit = 158 * 1024;   // the debug clocks live in static LDS
-#else
-    const size_t limit = 160 * 1024;   // all of a CU's LDS
-#endif
-    if (lds_base + lds_samples <= limit) {
-        fa.test_quit_agent = -1;
-        if constexpr (INJ == 2 && FASTM && ILP == 1) {
-            if (e.linger_launch && e.subset_n == 0 && fa.done_flag && e.tail_event == nullptr) {
-                // the resident form: this launch serves the current call and then every workgroup waits for its agent's next
-                // request on its own (kernels_fused.hpp)
-                auto fl = k_fused_pendulum<OPT, true, FASTM, INJ, ILP, true>;
-                ensure_max_lds((const void*)fl, (int)limit);
-                for (int a = 0; a < e.A; ++a) {
-                    volatile uint32_t* m = e.mbox_host(a);
-                    for (int i = 0; i < 13; ++i) m[i] = fa.done_value & 0xffffu;   // no payload word may carry the next request's tag by accident
-                    m[15] = fa.done_value;                            // nothing pending (a stale stop word must not end it)
-                    *(volatile uint32_t*)e.gone_host(a) = 0u;
-                }
-                std::atomic_thread_fence(std::memory_order_release);
-                fa.done_flag = e.sync_dev(e.ack_host(0));
-                fa.mbox = e.sync_dev(e.mbox_host(0));
-                fa.gone = e.sync_dev(e.gone_host(0));
-                fa.linger_ticks = (unsigned)e.sw.linger_us * 100u;
-                fa.test_quit_agent = e.linger_test_quit;
-                hipLaunchKernelGGL(fl, dim3(e.A), dim3(threads), lds_base + lds_samples, e.stream, fa);
-                HIP_CHECK(hipGetLastError());
-                e.resident_alive = true;
-                if (!e.mbox_pub.load(std::memory_order_relaxed)) {
-                    e.mbox_pub_agents = e.A;
-                    e.mbox_pub.store(e.mbox_host(0), std::memory_order_release);
-                    g_resident_handles.fetch_add(1, std::memory_order_relaxed);
-                }
-                return;
-            }
-        }
-        if (e.subset_n > 0) {
-            // the agents whose resident workgroups had left when this control step was posted (Engine::resident_step)
-            auto fs = k_fused_pendulum<OPT, true, FASTM, INJ, ILP>;
-            ensure_max_lds((const void*)fs, (int)limit);
-            fa.amap = reinterpret_cast<const int*>(e.sync_dev(e.amap_host()));
-            hipLaunchKernelGGL(fs, dim3(e.subset_n), dim3(threads), lds_base + lds_samples, e.stream, fa);
-            HIP_CHECK(hipGetLastError());
-            e.subset_n = 0;
-            return;
-        }
-        auto fn = k_fused_pendulum<OPT, true, FASTM, INJ, ILP>;
-        ensure_max_lds((const void*)fn, (int)limit);
-        launch_with_tail(e, fn, dim3(e.A), dim3(threads), lds_base + lds_samples, fa);
-    } else {
-        auto fn = k_fused_pendulum<OPT, false, FASTM, INJ, ILP>;
-        launch_with_tail(e, fn, dim3(e.A), dim3(threads), lds_base, fa);
-    }
-    HIP_CHECK(hipGetLastError());
-}
-
-template <int OPT>
-static void launch_fused(Engine& e, FusedArgs& fa, int ilp, int threads, size_t lds_base, size_t lds_samples, int inj_layout) {
-    const bool fastm = !e.fix(BBMPC_STRICT_MATH);
-    const int inj = fa.inj == nullptr ? 0 : inj_layout;     // 0 in-kernel Philox, 1 caller-injected, 2 prefetched float4
-#define LF(F, I)                                                                              \
-    do {                                                                                      \
-        if (ilp == 2) launch_fused4<OPT, F, I, 2>(e, fa, threads, lds_base, lds_samples);    \
-        else launch_fused4<OPT, F, I, 1>(e, fa, threads, lds_base, lds_samples);             \
-    } while (0)
-    if (inj == 2) {                                         // ILP = 1 only
-        if (fastm) launch_fused4<OPT, true, 2, 1>(e, fa, threads, lds_base, lds_samples);
-        else launch_fused4<OPT, false, 2, 1>(e, fa, threads, lds_base, lds_samples);
-    } else if (fastm && !inj) LF(true, 0);
-    else if (fastm && inj) LF(true, 1);
-    else if (!fastm && !inj) LF(false, 0);
-    else LF(false, 1);
-#undef LF
-}
-
-// Standard draws for a chunk of control steps in the layout the persistent kernel's INJ=2 path reads:
-// [step][iter][A][Nst][Q] float4, one float4 = the 4 words of Philox block q of particle n.  Same counters and
-// transforms as the in-kernel generator (rng.hpp), so the values are bit-identical.  thread = (n, q), coalesced.
-__global__ void k_noise_fill(RngKey key, uint32_t rstream, int kind /* 0 trunc normal, 1 uniform, 2 rademacher */, int n_it, int N, int Nst, int A, int Q,
-                             int agent_offset, float4* __restrict__ out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * Q) return;
-    const int n = idx / Q, q = idx % Q;
-    const int z = blockIdx.y;
-    const int a = z % A, it = (z / A) % n_it, s = z / (A * n_it);
-    key.step += (uint32_t)s;
-    const U4 w = rng_block(key, rstream, (uint32_t)it, (uint32_t)n, (uint32_t)(agent_offset + a), (uint32_t)(4 * q));
-    float4 v;
-    if (kind == 1) v = make_float4(word_to_uniform(w.x), word_to_uniform(w.y), word_to_uniform(w.z), word_to_uniform(w.w));
-    else if (kind == 2) v = make_float4(word_to_rademacher(w.x), word_to_rademacher(w.y), word_to_rademacher(w.z), word_to_rademacher(w.w));
-    else v = make_float4(word_to_trunc_normal(w.x), word_to_trunc_normal(w.y), word_to_trunc_normal(w.z), word_to_trunc_normal(w.w));
-    out[(((size_t)s * n_it + it) * A + a) * Nst * Q + (size_t)n * Q + q] = v;
-}
-
-void Engine::launch_noise_fill(int64_t chunk, int buf, hipStream_t on) {
-    const bool rs = cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH, sp = cfg.optimizer == BBMPC_OPT_SPSA;
-    const int n_it = rs ? 1 : iters, Q = (HU + 3) / 4;
-    dim3 grid((N * Q + 255) / 256, A * n_it * pf_steps), block(256);
-    hipLaunchKernelGGL(k_noise_fill, grid, block, 0, on, key((uint32_t)(chunk * pf_steps)), rs ? 2u : (sp ? 3u : 1u), rs ? 1 : (sp ? 2 : 0), n_it,
-                       N, Nst, A, Q, cfg.agent_offset, reinterpret_cast<float4*>(d_noise_pf[buf].p));
-    HIP_CHECK(hipGetLastError());
-}
-
-void Engine::optimize_fused(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step) {
-    FusedArgs fa;
-    memset(&fa, 0, sizeof(fa));
-    fa.N = N; fa.A = A; fa.H = H; fa.U = U; fa.HU = HU; fa.Nst = Nst; fa.k = k; fa.iters = iters;
-    fa.agent_offset = cfg.agent_offset;
-    fa.fix_q1 = fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
-    fa.fix_q7 = fix(BBMPC_FIX_Q7_EXPL_NOISE_ZERO_MEAN);
-    fa.add_noise = add_noise;
-    fa.warm_start = fix(BBMPC_FIX_Q2_CEM_WARM_START);
-    fa.balance = sw.balance;
-    if (tail_flag) {
-        fa.done_flag = tail_flag; fa.done_count = tail_count; fa.done_value = tail_value;
-        tail_attached = true;
-    }
-    fa.alpha = cfg.alpha;
-    fa.inv_lamda = 1.0f / cfg.lamda;
-    fa.state = d_state_in;
-    fa.lo = d_lo.p; fa.hi = d_hi.p;
-    fa.prev_mean = d_prev_mean.p; fa.var0 = d_var0.p;
-    fa.mean_out = d_mean.p; fa.var_out = d_var.p;
-    fa.samples_g = d_samples.p;
-    fa.inj = injected(cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH ? BBMPC_NOISE_UNIFORM
-                      : cfg.optimizer == BBMPC_OPT_SPSA ? BBMPC_NOISE_RADEMACHER : BBMPC_NOISE_TRUNC_NORMAL);
-    fa.inj_expl = injected(BBMPC_NOISE_EXPLORATION);
-    if (cfg.optimizer == BBMPC_OPT_SPSA) {                                   // gain sequences spsa.py:56,69-70
-        const float big_a = (float)iters / 10.0f;
-        for (int it = 0; it < iters && it < FUSED_MAX_SPSA_ITERS; ++it) {
-            const float tf = (float)it;
-            fa.spsa_ak[it] = cfg.spsa_a / (float)pow((double)((tf + 1.0f) + big_a), (double)cfg.spsa_alpha);
-            fa.spsa_ck[it] = cfg.spsa_c / (float)pow((double)(tf + 1.0f), (double)cfg.spsa_gamma);
-        }
-    }
-    fa.record = d_record_out;
-    fa.next_state = d_next_out;
-    if (trace_on) {
-        ensure_trace();
-        fa.t_rewards = t_rewards.p; fa.t_mean = t_mean.p; fa.t_var = t_var.p; fa.t_elites = t_elites.p; fa.t_samples = t_samples.p;
-        if (cfg.optimizer == BBMPC_OPT_SPSA) {
-            if (!t_rewards2.p) t_rewards2.alloc((size_t)A * Nst * std::max(iters, 1));
-            fa.t_rewards2 = t_rewards2.p;
-        }
-    }
-#ifdef BBMPC_KERNEL_DBG
-    static long long* dbg_buf = nullptr;
-    if (sw.dbg) {
-        if (!dbg_buf) HIP_CHECK(hipHostMalloc((void**)&dbg_buf, 64 * 8, hipHostMallocDefault));
-        fa.dbg = dbg_buf;
-    }
-#endif
-    fa.key = key(step);
-    // ---- noise prefetch (see engine.hpp): unless the caller injected its own draws.  One fill launch covers a
-    // chunk of pf_steps control steps (the host adds one launch + three event calls per chunk, not per step).
-    const int pf_nit = cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH ? 1 : iters;
-    if (pf_mode < 0) {
-        const char* ev = getenv("BBMPC_NOISE_PREFETCH");
-        pf_step_floats = (size_t)pf_nit * A * Nst * ((HU + 3) / 4) * 4;
-        const size_t budget = (size_t)128 << 20;     // bytes per chunk buffer
-        pf_steps = pf_step_floats ? (int)std::min<size_t>(8, budget / (pf_step_floats * 4)) : 0;
-        pf_mode = ((ev ? atoi(ev) != 0 : true) && pf_steps >= 1 && U == 1) ? 1 : 0;
-        if (pf_mode) {
-            {   // its own priority class, hence its own pool of hardware queues: a fill must never sit in the queue
-                // behind a resident control-step kernel of the launch stream (normal priority)
-                int least = 0, greatest = 0;
-                HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-                HIP_CHECK(hipStreamCreateWithPriority(&pf_stream, hipStreamNonBlocking, greatest));
-            }
-            HIP_CHECK(hipEventCreateWithFlags(&pf_free, hipEventDisableTiming));
-            for (int b = 0; b < 2; ++b) {
-                d_noise_pf[b].alloc(pf_step_floats * pf_steps);
-                HIP_CHECK(hipEventCreateWithFlags(&pf_done[b], hipEventDisableTiming));
-            }
-        }
-    }
-    const bool use_pf = pf_mode == 1 && fa.inj == nullptr && pf_nit > 0;
-    if (use_pf) {
-        const int64_t c = (int64_t)step / pf_steps;
-        const int pb = (int)(c & 1), nb = pb ^ 1;
-        if (pf_chunk[pb] != c) {                   // not prefetched (first step, or steps did not advance by one): in line
-            if (pf_inflight[pb]) HIP_CHECK(hipStreamWaitEvent(stream, pf_done[pb], 0));   // stale fill still running
-            launch_noise_fill(c, pb, stream);
-            pf_chunk[pb] = c; pf_waited[pb] = true; pf_inflight[pb] = false;
-        } else if (!pf_waited[pb]) {
-            HIP_CHECK(hipStreamWaitEvent(stream, pf_done[pb], 0));
-            pf_waited[pb] = true; pf_inflight[pb] = false;
-        }
-        fa.inj = d_noise_pf[pb].p + (size_t)((int64_t)step - c * pf_steps) * pf_step_floats;
-        if (pf_chunk[nb] != c + 1) {
-            // the other buffer was last read by kernels already enqueued on `stream`: the side stream fills it for
-            // the next chunk while this chunk's control steps run
-            HIP_CHECK(hipEventRecord(pf_free, stream));
-            HIP_CHECK(hipStreamWaitEvent(pf_stream, pf_free, 0));
-            launch_noise_fill(c + 1, nb, pf_stream);
-            HIP_CHECK(hipEventRecord(pf_done[nb], pf_stream));
-            pf_chunk[nb] = c + 1; pf_waited[nb] = false; pf_inflight[nb] = true;
-        }
-    }
-    // two trajectories per lane (one wave per SIMD for N <= 512) unless overridden
-    int ilp = 1;                 // measured: 2 waves/SIMD x 1 trajectory beats 1 wave/SIMD x 2 trajectories
-    ilp = sw.ilp;
-    if (use_pf) ilp = 1;
-    const int per = (N + ilp - 1) / ilp;
-    const int threads = std::min(1024, std::max(((per + 63) / 64) * 64, ((std::max(k, 1) + 63) / 64) * 64));   // top-k needs k <= threads
-    const int HUp = (HU + 3) & ~3, kp = (std::max(k, 1) + 3) & ~3;
-    const size_t lds_base = (size_t)(Nst + 3 * HUp + kp + 64 + TOPK_HIST_WORDS + 2 * kp) * 4;
-    const size_t lds_samples = (size_t)HU * Nst * 4;
-    prof_begin();
-    switch (cfg.optimizer) {
-        case BBMPC_OPT_RANDOM_SEARCH: launch_fused<FOPT_RS>(*this, fa, ilp, threads, lds_base, lds_samples, use_pf ? 2 : 1); break;
-        case BBMPC_OPT_CEM: launch_fused<FOPT_CEM>(*this, fa, ilp, threads, lds_base, lds_samples, use_pf ? 2 : 1); break;
-        case BBMPC_OPT_SPSA: {
-            const bool fastm = !fix(BBMPC_STRICT_MATH);
-            if (use_pf) {
-                if (fastm) launch_fused4<FOPT_SPSA, true, 2, 1>(*this, fa, threads, lds_base, lds_samples);
-                else launch_fused4<FOPT_SPSA, false, 2, 1>(*this, fa, threads, lds_base, lds_samples);
-            } else if (fa.inj) {
-                if (fastm) launch_fused4<FOPT_SPSA, true, 1, 1>(*this, fa, threads, lds_base, lds_samples);
-                else launch_fused4<FOPT_SPSA, false, 1, 1>(*this, fa, threads, lds_base, lds_samples);
-            } else {
-                if (fastm) launch_fused4<FOPT_SPSA, true, 0, 1>(*this, fa, threads, lds_base, lds_samples);
-                else launch_fused4<FOPT_SPSA, false, 0, 1>(*this, fa, threads, lds_base, lds_samples);
-            }
-            break;
-        }
-        default: launch_fused<FOPT_PI2>(*this, fa, ilp, threads, lds_base, lds_samples, use_pf ? 2 : 1); break;
-    }
-    prof_end();
-    if (fa.dbg) {
-        HIP_CHECK(hipStreamSynchronize(stream));
-        if (step == 5) {
-            fprintf(stderr, "[dbg] phase clocks (10ns units) rel. to start:");
-            for (int i = 0; i <= 1 + iters * 4; ++i) fprintf(stderr, " %lld", fa.dbg[i] - fa.dbg[0]);
-            fprintf(stderr, "\n[dbg] iter0 per-wave rollout end:");
-            for (int i = 24; i < 32; ++i) fprintf(stderr, " %lld", fa.dbg[i] - fa.dbg[0]);
-            fprintf(stderr, "  gather-done %lld stats-done %lld", fa.dbg[32] - fa.dbg[0], fa.dbg[33] - fa.dbg[0]);
-            fprintf(stderr, "\n[dbg] iter1 top-k select marks rel. to rollout end:");
-            for (int i = 0; i < 10; ++i) fprintf(stderr, " %lld", fa.dbg[48 + i] - fa.dbg[3 + 4]);
-            fprintf(stderr, "  (iter1 marks: start %lld rollout-end %lld barrier %lld topk-end %lld)", fa.dbg[5] - fa.dbg[0], fa.dbg[6] - fa.dbg[0], fa.dbg[7] - fa.dbg[0], fa.dbg[8] - fa.dbg[0]);
-            fprintf(stderr, "\n[dbg] shader clocks: %lld over %lld wall ticks => %.1f MHz\n", fa.dbg[41] - fa.dbg[40], fa.dbg[1 + iters * 4] - fa.dbg[0], (double)(fa.dbg[41] - fa.dbg[40]) / ((double)(fa.dbg[1 + iters * 4] - fa.dbg[0]) * 0.01));
-        }
-    }
-}
 
 void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out) {
     REQUIRE(cfg.optimizer != BBMPC_OPT_NONE, BBMPC_E_STATE, "handle was created without an optimizer");
@@ -1973,49 +1105,6 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
     finalize(d_state_in, add_noise, d_record_out, d_next_out, step);
 }
 
-// CMA-ES on the analytic pendulum in one launch per control step when the search dimension is small (kernels_fused_cma.hpp)
-bool Engine::use_fused_cma() const {
-    if (cfg.optimizer != BBMPC_OPT_CMAES || cfg.dynamics != BBMPC_DYN_PENDULUM || cfg.reward != BBMPC_REW_PENDULUM) return false;
-    // opt-in: measured no faster than the per-iteration kernels (both are bound by the Jacobi sweeps)
-    if (!sw.cma_fused || fused_mode == 0 || trace_on || pop_sharded()) return false;      // the parity trace is captured between the per-iteration kernels
-    if (sw.cma_svd_v1 || sw.cma_svd_rounds || sw.cma_svd_general) return false;
-    return cma_G == A && cma_n <= 64 && N <= 1024 && k <= 1024;
-}
-
-void Engine::optimize_fused_cma(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step) {
-    FusedCmaArgs fa;
-    memset(&fa, 0, sizeof(fa));
-    fa.q = cma_args(step, 0u);
-    fa.iters = iters; fa.H = H;
-    fa.inj = injected(BBMPC_NOISE_NORMAL);
-    fa.inj_stride = (size_t)A * HU * Nst;
-    fa.evec = c_evec.p; fa.eval = c_eval.p; fa.info = c_info.p;
-    FinalArgs& fin = fa.fin;
-    fin.A = A; fin.U = U; fin.S = S;
-    fin.agent_offset = cfg.agent_offset;
-    fin.fix_q1 = fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
-    fin.fix_q7 = fix(BBMPC_FIX_Q7_EXPL_NOISE_ZERO_MEAN);
-    fin.add_noise = add_noise;
-    fin.state = d_state_in;
-    fin.action = d_action.p;
-    fin.lo = d_lo.p; fin.hi = d_hi.p;
-    fin.inj = injected(BBMPC_NOISE_EXPLORATION);
-    fin.record = d_record_out;
-    fin.next_state = d_next_out;
-    fin.key = key(step);
-    fin.key.q_per_agent = (uint32_t)((U + 3) / 4);
-    if (tail_flag) {
-        fa.done_flag = tail_flag; fa.done_count = tail_count; fa.done_value = tail_value;
-        tail_attached = true;
-    }
-    const int kp = (k + 3) & ~3;
-    const size_t lds = std::max((size_t)(Nst + TOPK_HIST_WORDS + 2 * kp) * 4, (size_t)cma_n * cma_n * 4);
-    prof_begin();
-    if (!fix(BBMPC_STRICT_MATH)) launch_with_tail(*this, k_fused_cma_pendulum<true>, dim3(cma_G), dim3(1024), lds, fa);
-    else launch_with_tail(*this, k_fused_cma_pendulum<false>, dim3(cma_G), dim3(1024), lds, fa);
-    HIP_CHECK(hipGetLastError());
-    prof_end();
-}
 
 // SPSAOptimizer._optimize  spsa.py:61-117
 void Engine::optimize_spsa(RolloutArgs& ra, uint32_t step) {
@@ -2092,61 +1181,6 @@ void Engine::optimize_spsa(RolloutArgs& ra, uint32_t step) {
     }
 }
 
-// PSO on the true pendulum model in one launch per control step (kernels_fused_pso.hpp) when the swarm's positions
-// and velocities fit one CU's LDS
-static size_t fused_pso_lds(int H, int Nst) { return ((size_t)2 * H * Nst + ((H + 3) & ~3) + 16 + 16 + 8) * sizeof(float); }
-
-bool Engine::use_fused_pso() const {
-    if (cfg.dynamics != BBMPC_DYN_PENDULUM || cfg.reward != BBMPC_REW_PENDULUM || cfg.optimizer != BBMPC_OPT_PSO || U != 1) return false;
-    if (fused_mode == 0 || pop_sharded()) return false;           // a sharded swarm exchanges its bests every iteration
-    return N <= 1024 && fused_pso_lds(H, Nst) <= 160 * 1024;
-}
-
-void Engine::optimize_fused_pso(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step) {
-    FusedPsoArgs fa;
-    memset(&fa, 0, sizeof(fa));
-    fa.N = N; fa.A = A; fa.H = H; fa.Nst = Nst; fa.iters = iters;
-    fa.agent_offset = cfg.agent_offset;
-    fa.fix_q1 = fix(BBMPC_FIX_Q1_REWARD_ARG_ORDER);
-    fa.fix_q7 = fix(BBMPC_FIX_Q7_EXPL_NOISE_ZERO_MEAN);
-    fa.add_noise = add_noise;
-    fa.w = cfg.pso_w; fa.c1 = cfg.pso_c1; fa.c2 = cfg.pso_c2; fa.v0frac = cfg.pso_v0_fraction;
-    if (tail_flag) {             // the records are complete when this kernel ends (k_pso_seed only re-seeds the swarm)
-        fa.done_flag = tail_flag; fa.done_count = tail_count; fa.done_value = tail_value;
-        tail_attached = true;
-    }
-    fa.state = d_state_in;
-    fa.lo = d_lo.p; fa.hi = d_hi.p; fa.var0 = d_var0.p;
-    fa.s = pso_state();
-    fa.inj2 = injected(BBMPC_NOISE_PSO_SCALARS);
-    fa.inj_pos = injected(BBMPC_NOISE_PSO_RESEED_TRUNC);
-    fa.inj_vel = injected(BBMPC_NOISE_PSO_RESEED_UNIFORM);
-    fa.inj_expl = injected(BBMPC_NOISE_EXPLORATION);
-    fa.record = d_record_out;
-    fa.next_state = d_next_out;
-    if (trace_on) {
-        ensure_trace();
-        fa.t_rewards = t_rewards.p; fa.t_mean = t_mean.p; fa.t_elites = t_elites.p;
-        fa.t_elite_stride = std::max(k, 1);
-    }
-    fa.key = key(step);
-    const size_t lds = fused_pso_lds(H, Nst);
-    const int threads = std::max(64, ((N + 63) / 64) * 64);
-    prof_begin();
-    if (!fix(BBMPC_STRICT_MATH)) {
-        ensure_max_lds((const void*)k_fused_pso_pendulum<true>, 160 * 1024);
-        hipLaunchKernelGGL(k_fused_pso_pendulum<true>, dim3(A), dim3(threads), lds, stream, fa);
-    } else {
-        ensure_max_lds((const void*)k_fused_pso_pendulum<false>, 160 * 1024);
-        hipLaunchKernelGGL(k_fused_pso_pendulum<false>, dim3(A), dim3(threads), lds, stream, fa);
-    }
-    HIP_CHECK(hipGetLastError());
-    prof_end();
-    const OptArgs oa = opt_args(step, 0u);
-    hipLaunchKernelGGL(k_pso_seed, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, oa, fa.s, d_var0.p, cfg.pso_v0_fraction, 0,
-                       fa.inj_pos, fa.inj_vel);                                                                         // :116-138
-    HIP_CHECK(hipGetLastError());
-}
 
 // PSOOptimizer._optimize  pso.py:70-141
 void Engine::optimize_pso(RolloutArgs& ra, uint32_t step) {

@@ -57,8 +57,13 @@ __device__ __forceinline__ float elem_normal(const RngKey& key, uint32_t iter, i
     return (j & 1) ? z1 : z0;
 }
 
+
+// Everything below -- device code and the host-side size helpers -- is compiled in the CMA-ES translation unit only
+// (csrc/bbmpc_cma.hip defines BBMPC_TU_CMA); the other units see the argument structures above.
+#ifdef BBMPC_TU_CMA
+
 // grid (ceil(N/256), HU, A)
-__global__ void k_cma_noise(CmaArgs p) {
+static __global__ void k_cma_noise(CmaArgs p) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y, a = blockIdx.z;
     if (n >= p.N) return;
@@ -67,7 +72,7 @@ __global__ void k_cma_noise(CmaArgs p) {
 }
 
 // BD = B @ D (D diagonal)   cma_es.py:140
-__global__ void k_cma_bd(CmaArgs p) {
+static __global__ void k_cma_bd(CmaArgs p) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nn = (size_t)p.n * p.n;
     if (i >= nn * p.G) return;
@@ -77,7 +82,7 @@ __global__ void k_cma_bd(CmaArgs p) {
 
 // Y^T[i][q] = sum_l BD[l][i] * Z^T[l][q]      (y = z @ BD, cma_es.py:140)  64x64 tiles, 4x4 per thread
 // grid (ceil(N/64), ceil(n/64), G), block 256
-__global__ __launch_bounds__(256) void k_cma_gemm_y(CmaArgs p) {
+static __global__ __launch_bounds__(256) void k_cma_gemm_y(CmaArgs p) {
     __shared__ float As[16][64 + 1];
     __shared__ float Bs[16][64 + 1];
     const int g = blockIdx.z;
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256) void k_cma_gemm_y(CmaArgs p) {
 // lane (l & 3, i or q) -- no LDS staging.  Workgroup tile 64 (i) x 64 (q): wave w owns rows 16w .. 16w+15 and four
 // q fragments; the B fragments are shared by the four waves through L1.  76 -> ~20 us at n = 300, N = 2000, G = 4.
 // (The small-n path keeps k_cma_gemm_y: its accumulation order is what the fused control-step kernel reproduces.)
-__global__ __launch_bounds__(256) void k_cma_gemm_y_mfma(CmaArgs p) {
+static __global__ __launch_bounds__(256) void k_cma_gemm_y_mfma(CmaArgs p) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int g = blockIdx.z, n = p.n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -191,7 +196,7 @@ __device__ __forceinline__ void cma_select_body(const CmaArgs& p, int g, float* 
     }
     for (int e = tid; e < p.k; e += REFIT_THREADS) p.eidx[g * p.k + e] = eidx_s[e];
 }
-__global__ __launch_bounds__(REFIT_THREADS) void k_cma_select(CmaArgs p, float* part) {
+static __global__ __launch_bounds__(REFIT_THREADS) void k_cma_select(CmaArgs p, float* part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     cma_select_body(p, blockIdx.x, smem, part);
 }
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_cma_select(CmaArgs p, float* 
 // for every other list, the number of entries that precede it there (binary search); the first k take columns 0..k-1 of
 // the candidate matrix (the local candidates are not needed any more) and eidx = 0..k-1, so the path / covariance update
 // runs unchanged; gidx (optional) receives the global particle indices for the parity trace.  grid G, block 1024, k <= 1024
-__global__ __launch_bounds__(1024) void k_cma_merge(CmaArgs p, const float* all, int R, int* gidx) {
+static __global__ __launch_bounds__(1024) void k_cma_merge(CmaArgs p, const float* all, int R, int* gidx) {
     __shared__ int s_src[1024];
     const int g = blockIdx.x, tid = threadIdx.x, n = p.n, k = p.k, rowlen = n + 2;
     const size_t pw = (size_t)p.G * k * rowlen;
@@ -363,11 +368,11 @@ __device__ __forceinline__ void cma_paths_body(const CmaArgs& p, int g) {
         p.m[off + c] = p.m[off + c] + p.xmean[off + c];                    // :163
     }
 }
-__global__ __launch_bounds__(1024) void k_cma_paths(CmaArgs p) { cma_paths_body(p, blockIdx.x); }
+static __global__ __launch_bounds__(1024) void k_cma_paths(CmaArgs p) { cma_paths_body(p, blockIdx.x); }
 
 // C = (1-c1-cmu) C + c1 pC pC^T + cmu sum_i w_i y_i y_i^T on the upper triangle, mirrored (cma_es.py:179-190)
 // grid (ceil(n/16), ceil(n/16), G), block (16,16)
-__global__ void k_cma_cov(CmaArgs p) {
+static __global__ void k_cma_cov(CmaArgs p) {
     const int g = blockIdx.z, n = p.n;
     const int c = blockIdx.x * 16 + threadIdx.x, r = blockIdx.y * 16 + threadIdx.y;
     if (r >= n || c >= n || r > c) return;
@@ -391,7 +396,7 @@ __global__ void k_cma_cov(CmaArgs p) {
 // ROWS of At (C is symmetric, so At = C to start with) to make every access contiguous.  Singular values
 // are sorted descending at the end, as TF returns them.
 // scratch: At [G][n][n], norms [G*n], perm (int) [G*n]
-__global__ __launch_bounds__(REFIT_THREADS) void k_cma_svd(CmaArgs p, float* At_all, float* norms_all, int* perm_all,
+static __global__ __launch_bounds__(REFIT_THREADS) void k_cma_svd(CmaArgs p, float* At_all, float* norms_all, int* perm_all,
                                                            int max_sweeps) {
     __shared__ int s_rotated;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_cma_svd(CmaArgs p, float* At_
 //    ~10 us for the whole round in one workgroup, so WPG = 1 is what the engine launches.
 // k_cma_warm: At[j][:] = C * B0[:, j] (C symmetric => coalesced along the column);  k_cma_svd_rounds: the sweeps;
 // k_cma_svd_finish: norms, descending order, B and D.
-__global__ __launch_bounds__(256) void k_cma_warm(CmaArgs p, float* At_all) {
+static __global__ __launch_bounds__(256) void k_cma_warm(CmaArgs p, float* At_all) {
     // At[j][e] = sum_k C[k][e] * B[k][j]: 32x32 output tile per workgroup, K staged through LDS in slabs of 32,
     // each thread owns a 2x2 micro tile.  grid (ceil(n/32), ceil(n/32), G), block 256 = 16 x 16
     __shared__ float sC[32][33], sB[32][33];
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(256) void k_cma_warm(CmaArgs p, float* At_all) {
 // 64 (j) x 32 (e), wave w owns rows 16w .. 16w+15.  grid (ceil(n/32), ceil(n/64), G), block 256.  32 -> ~8 us at n = 300.
 // `need` (optional, [G][8] words): the instance runs only when need[8 g] != 0 -- the direct eigensolver (kernels_eigh.hpp) leaves
 // that flag set for the instances whose result it did not accept; the same parameter on the kernels below.
-__global__ __launch_bounds__(256) void k_cma_warm_mfma(CmaArgs p, float* At_all, const unsigned* need = nullptr) {
+static __global__ __launch_bounds__(256) void k_cma_warm_mfma(CmaArgs p, float* At_all, const unsigned* need = nullptr) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int g = blockIdx.z, n = p.n;
     if (need && need[(size_t)g * 8] == 0u) return;
@@ -580,7 +585,7 @@ constexpr int CMA_SYNC_XCC_MASK = 24;
 constexpr int CMA_SYNC_ROTATIONS = 480;               // k_cma_svd_block: [480 + sweep] column pairs rotated in that sweep (statistics)                  // k_cma_svd_block: bit x = some workgroup of the instance runs on XCD x
 // sync: [G][CMA_SYNC_WORDS] unsigned: [0] barrier counter, [1 + sweep] "some pair rotated in this sweep"; the block kernel keeps
 // its block-pair bookkeeping in words 32.. (2 * NB + NB * NB of them)
-__global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps, int lds_floats) {
+static __global__ __launch_bounds__(1024) void k_cma_svd_rounds(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps, int lds_floats) {
     const int g = blockIdx.y, WPG = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
     const int NW = blockDim.x >> 6;
     // rotation threshold on the cosine between two columns: the fp32 dot-product noise floor grows with n
@@ -699,14 +704,14 @@ __device__ __forceinline__ void cma_svd_finish_body(const CmaArgs& p, int g, con
     }
     for (int c = tid; c < n; c += nthr) p.Dd[(size_t)g * n + c] = sqrtf(s_norm[s_perm[c]]);   // D = diag(sqrt(s))
 }
-__global__ __launch_bounds__(1024) void k_cma_svd_finish(CmaArgs p, const float* At_all, float* norms_all, int* perm_all) {
+static __global__ __launch_bounds__(1024) void k_cma_svd_finish(CmaArgs p, const float* At_all, float* norms_all, int* perm_all) {
     cma_svd_finish_body(p, blockIdx.x, At_all, norms_all, perm_all);
 }
 
 // The same finish for large n as two launches: norms / ranks / D per instance, then B in 32 x 32 tiles over many
 // workgroups.  (One workgroup per instance walked its n^2 elements with an integer division each and read At along the
 // strided direction: 79 us at n = 300, a tenth of which is left.)  Same arithmetic, same bits.
-__global__ __launch_bounds__(1024) void k_cma_svd_norms(CmaArgs p, const float* At_all, float* norms_all, int* perm_all, const unsigned* need = nullptr) {
+static __global__ __launch_bounds__(1024) void k_cma_svd_norms(CmaArgs p, const float* At_all, float* norms_all, int* perm_all, const unsigned* need = nullptr) {
     __shared__ float s_norm[2048];
     if (need && need[(size_t)blockIdx.x * 8] == 0u) return;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n, nthr = blockDim.x, NW = nthr >> 6;
@@ -735,7 +740,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_norms(CmaArgs p, const float* 
         p.Dd[(size_t)g * n + rank] = sqrtf(nj);                      // D = diag(sqrt(s)), descending
     }
 }
-__global__ __launch_bounds__(256) void k_cma_svd_build_b(CmaArgs p, const float* At_all, const float* norms_all, const int* perm_all, const unsigned* need = nullptr) {
+static __global__ __launch_bounds__(256) void k_cma_svd_build_b(CmaArgs p, const float* At_all, const float* norms_all, const int* perm_all, const unsigned* need = nullptr) {
     __shared__ float tile[32][33];
     if (need && need[(size_t)blockIdx.z * 8] == 0u) return;
     __shared__ int s_src[32];
@@ -1232,7 +1237,7 @@ inline size_t cma_gram_lds_bytes(int n) {
     return ((size_t)Wp * n + 2 * (size_t)Wp * (Wp + 1) + 4 * 64 + 16) * sizeof(float);
 }
 
-__global__ __launch_bounds__(1024) void k_cma_svd_gram(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
+static __global__ __launch_bounds__(1024) void k_cma_svd_gram(CmaArgs p, float* At_all, unsigned* sync_all, int max_sweeps) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     constexpr int NB = 8;
     const int g = blockIdx.y, wg = blockIdx.x, WPG = gridDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n;
@@ -1529,5 +1534,7 @@ __global__ __launch_bounds__(1024) void k_cma_svd_small(CmaArgs p, float* At_all
     (void)sync_all;
     cma_svd_small_body<EC>(p, blockIdx.x, At_all, max_sweeps, at_s);
 }
+
+#endif  // BBMPC_TU_CMA
 
 }  // namespace bbmpc

@@ -51,6 +51,8 @@ struct EighArgs {
     float* Dd;           // [G][n] out: sqrt(eigenvalue)
 };
 
+#ifdef BBMPC_TU_CMA      // the kernels are compiled in the CMA-ES translation unit only (csrc/bbmpc_cma.hip, tools/eigh)
+
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. Householder tridiagonalisation, one 512-thread workgroup per instance, the matrix in registers.
 // Thread (tr, tc), tr = tid / 16 in [0, 32), tc = tid % 16: rows tr + 32 i (i < 10), columns 4 (tc + 16 jj) + c (jj < 5,
@@ -419,7 +421,7 @@ __device__ __forceinline__ void eigh_row_to_lds(const EighQuad (&a)[EIGH_NR][EIG
 }
 
 // grid G, block 512, dynamic LDS sizeof(EighTriLds); 66 <= n <= 320
-__global__ __launch_bounds__(EIGH_TRI_THREADS) void k_eigh_tridiag(EighArgs q) {
+static __global__ __launch_bounds__(EIGH_TRI_THREADS) void k_eigh_tridiag(EighArgs q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char eigh_smem[];
     EighTriLds& L = *reinterpret_cast<EighTriLds*>(eigh_smem);
     __shared__ float s_red[EIGH_TRI_THREADS / 64];
@@ -537,7 +539,7 @@ __device__ __forceinline__ float row16_max(float v) { return -row16_min(-v); }
 
 __device__ __forceinline__ void eigh_tfactor_block(const EighArgs& q, int g, int b, float* smem);
 
-__global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs q) {
+static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char eigh_smem2[];
     const int g = blockIdx.y, tid = threadIdx.x, n = q.n;
     if (blockIdx.x >= EIGH_SLOT_WGS) {
@@ -915,7 +917,7 @@ __device__ __forceinline__ bool eigh_instance_ok(const EighArgs& q, int g) {
     return !q.force_fail && (g0 <= 0.25f) && (g1 <= 2.0e-3f) && (res <= 1.0e-5f * scale) && (scale < 3.0e38f);
 }
 
-__global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, const float* __restrict__ Z_two_rounds, const float* __restrict__ Z_one_round) {
+static __global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, const float* __restrict__ Z_two_rounds, const float* __restrict__ Z_one_round) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     __shared__ float w1p[4][32][17];            // per-wave partial W1
     __shared__ float w1[32][17];
@@ -1022,5 +1024,7 @@ __global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, const fl
         }
     }
 }
+
+#endif  // BBMPC_TU_CMA
 
 }  // namespace bbmpc

@@ -17,6 +17,7 @@
 #include "kernels_rollout.hpp"
 
 namespace bbmpc {
+#ifdef BBMPC_TU_CMA      // compiled in the CMA-ES translation unit only (csrc/bbmpc_cma.hip)
 
 struct FusedCmaArgs {
     CmaArgs q;                 // q.iter / q.inj are set per iteration inside the kernel
@@ -167,4 +168,5 @@ __global__ __launch_bounds__(1024) void k_fused_cma_pendulum(FusedCmaArgs f) {
     }
 }
 
+#endif  // BBMPC_TU_CMA
 }  // namespace bbmpc

@@ -476,14 +476,14 @@ __global__ void k_rollout_mlp(MlpRolloutArgs q) {
 }
 // same body under its own name for the H = 1 model step (predict_next_state / the __call__ tail), so that
 // profiler averages of the rollout kernel are not diluted by the tiny launches
-__global__ void k_step_mlp(MlpRolloutArgs q) {
+static __global__ void k_step_mlp(MlpRolloutArgs q) {
     rollout_mlp_body<0>(q);
 }
 
 // ---- small helpers for the OptimizerBase.__call__ tail on the learned-dynamics path ----------------
 
 // action[a][u] += exploration noise, clip (optimizer_base.py:82-90)
-__global__ void k_explore(FinalArgs p, float* action) {
+static __global__ void k_explore(FinalArgs p, float* action) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.A * p.U) return;
     const int a = i / p.U, u = i % p.U;
@@ -491,7 +491,7 @@ __global__ void k_explore(FinalArgs p, float* action) {
 }
 
 // record[a] = (action | next_state | reward)
-__global__ void k_pack_record(int A, int U, int S, const float* action, const float* next_state, const float* reward,
+static __global__ void k_pack_record(int A, int U, int S, const float* action, const float* next_state, const float* reward,
                               float* record, float* next_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int rec = U + S + 1;

@@ -32,7 +32,7 @@ __device__ __forceinline__ uint32_t elem_word(const RngKey& key, uint32_t stream
 // ------------------------------------------------------------------------------------------------
 // delta in {-1,+1}; theta+- = solution +- c_k*delta   (spsa.py:73-77).  Clipping + penalties happen in the
 // rollout kernel (SRC_BUF, pen).  grid (ceil(N/256), HU, A)
-__global__ void k_spsa_candidates(OptArgs p, const float* solution /*[A][HU]*/, float ck, const float* inj /*[A][HU][Nst]|null*/,
+static __global__ void k_spsa_candidates(OptArgs p, const float* solution /*[A][HU]*/, float ck, const float* inj /*[A][HU][Nst]|null*/,
                                   float* delta, float* cand_plus, float* cand_minus) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y, a = blockIdx.z;
@@ -51,7 +51,7 @@ __global__ void k_spsa_candidates(OptArgs p, const float* solution /*[A][HU]*/, 
 // workgroup per agent walked all H*U rows: 180 k divisions and 720 KB of delta through one CU at the north-star shape).
 // `part` != null (population sharded over ranks): this rank's particles only -- the row sums go to part[a][j] and the
 // update is k_spsa_merge's.
-__global__ __launch_bounds__(REFIT_THREADS) void k_refit_spsa(OptArgs p, const float* rew_plus, const float* rew_minus,
+static __global__ __launch_bounds__(REFIT_THREADS) void k_refit_spsa(OptArgs p, const float* rew_plus, const float* rew_minus,
                                                               const float* delta, float ak, float ck, float* solution,
                                                               float* action, float* part) {
     extern __shared__ float diff[];
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_refit_spsa(OptArgs p, const f
 // every rank sums its own pairs (k_refit_spsa with `part`), one all-gather hands every rank all G row-sum vectors
 // all[r][a][j], and each rank adds them in rank order, divides by the GLOBAL population and takes the step: identical bits
 // on every rank; against the unsharded refit only the order of the fp32 sums differs.  grid (ceil(HU/256), A)
-__global__ void k_spsa_merge(OptArgs p, const float* all, int G, int n_global, float ak, float* solution, float* action) {
+static __global__ void k_spsa_merge(OptArgs p, const float* all, int G, int n_global, float ak, float* solution, float* action) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, a = blockIdx.y;
     if (j >= p.HU) return;
     float acc = 0.0f;
@@ -112,7 +112,7 @@ struct PsoState {
 // per agent: personal-best rewards, global best index (first maximum), global best position (pso.py:84-100)
 // `part` != null (population sharded over ranks): this rank's particles only -- the local best goes to
 // part[a] = (value, GLOBAL particle index as bits, position[HU]) and k_pso_merge picks the swarm's.
-__global__ __launch_bounds__(REFIT_THREADS) void k_pso_best(OptArgs p, PsoState s, const float* rewards, float* part) {
+static __global__ __launch_bounds__(REFIT_THREADS) void k_pso_best(OptArgs p, PsoState s, const float* rewards, float* part) {
     __shared__ float sv[REFIT_THREADS / 64];
     __shared__ int si[REFIT_THREADS / 64];
     __shared__ int s_gi;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_pso_best(OptArgs p, PsoState 
 // PSO with the swarm sharded over ranks: all[r][a] = (best value, global index, position[HU]) of rank r's particles; the
 // swarm's best is the first maximum by GLOBAL index (tf.argmax over the whole population: pso.py:94), so the sharded run
 // is the unsharded one bit for bit (the only cross-particle operation of PSO is this argmax).  grid A
-__global__ void k_pso_merge(OptArgs p, PsoState s, const float* all, int G) {
+static __global__ void k_pso_merge(OptArgs p, PsoState s, const float* all, int G) {
     const int a = blockIdx.x, tid = threadIdx.x;
     const size_t pw = (size_t)p.A * (p.HU + 2);
     int br = 0, bi = 0x7fffffff;
@@ -187,7 +187,7 @@ __device__ __forceinline__ void pso_scalars(const OptArgs& p, const float* inj2,
 }
 
 // velocity / position update (pso.py:86-88, 104-108).  grid (ceil(N/256), HU, A)
-__global__ void k_pso_move(OptArgs p, PsoState s, float w, float c1, float c2, const float* inj2) {
+static __global__ void k_pso_move(OptArgs p, PsoState s, float w, float c1, float c2, const float* inj2) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y, a = blockIdx.z;
     if (n >= p.N) return;
@@ -210,7 +210,7 @@ __global__ void k_pso_move(OptArgs p, PsoState s, float w, float c1, float c2, c
 //   reseed: pos = shift_left(gbest) + sqrt(constrained var) * xi_trunc ; vel = U(-v0, v0)
 //   reset : pos = U(lo, hi)                                           ; vel = U(-v0, v0)
 // grid (ceil(N/256), HU, A)
-__global__ void k_pso_seed(OptArgs p, PsoState s, const float* var0 /*[A][HU]*/, float v0frac, int is_reset,
+static __global__ void k_pso_seed(OptArgs p, PsoState s, const float* var0 /*[A][HU]*/, float v0frac, int is_reset,
                            const float* inj_pos, const float* inj_vel) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y, a = blockIdx.z;
@@ -242,7 +242,7 @@ __global__ void k_pso_seed(OptArgs p, PsoState s, const float* var0 /*[A][HU]*/,
 }
 
 // action = gbest[:, 0, :]
-__global__ void k_take_first(int A, int HU, int U, const float* src, float* action) {
+static __global__ void k_take_first(int A, int HU, int U, const float* src, float* action) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A * U) return;
     action[i] = src[(i / U) * HU + (i % U)];

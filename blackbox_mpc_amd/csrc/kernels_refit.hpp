@@ -91,7 +91,7 @@ __device__ __forceinline__ float cem_sigma(float mean, float var, float lo, floa
 // CEM quirk Q2: every control step restarts from the constructor mean/variance (cem.py:129-134).
 // state_src (optional): the [A,S] state of a host-in / host-out call, in pinned host memory -- the first kernel of the
 // control step brings it to HBM (state_dst) itself instead of a copy-engine transfer in front of it
-__global__ void k_dist_init(int A, int HU, int U, const float* lo, const float* hi, const float* prev_mean,
+static __global__ void k_dist_init(int A, int HU, int U, const float* lo, const float* hi, const float* prev_mean,
                             const float* var0, float* mean, float* var, float* sigma, int constrain,
                             const float* state_src, float* state_dst, int nstate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,7 +109,7 @@ __global__ void k_dist_init(int A, int HU, int U, const float* lo, const float* 
 // CEM refit  cem.py:97-125: top-k (sorted, ties -> lower index), elite mean / biased variance
 // (accumulated sequentially in elite order), alpha smoothing.
 // LDS: rewards[Nst] | elite idx[kpad] | hist[272] | ekeys[2*kpad] | elite tile [k][JC]
-__global__ __launch_bounds__(REFIT_THREADS) void k_refit_cem(RefitArgs p, int JC) {
+static __global__ __launch_bounds__(REFIT_THREADS) void k_refit_cem(RefitArgs p, int JC) {
     extern __shared__ float smem[];
     const int a = blockIdx.x;
     const int tid = threadIdx.x;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_refit_cem(RefitArgs p, int JC
 // particle-minor axis), k x HU lines through one CU's L1 -- 1.2 MB at config 4, 1.9 MB at config 5 and most of the
 // kernel's time.  So G workgroups per agent each repeat the (cheap, reward-only) selection and take HU / G rows.
 // LDS: rewards[Nst] | elite idx[kpad] | hist[TOPK_HIST_WORDS] | ekeys[2*kpad]
-__global__ __launch_bounds__(1024) void k_refit_cem_v2(RefitArgs p) {
+static __global__ __launch_bounds__(1024) void k_refit_cem_v2(RefitArgs p) {
     extern __shared__ float smem[];
     const int a = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
     const int rows_wg = (p.HU + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(1024) void k_refit_cem_v2(RefitArgs p) {
 
 // PI2 refit  pi2.py:78-87: softmin weights over the population, weighted mean of the (feasible) samples.
 // LDS: omega[Nst] | scratch[32]
-__global__ __launch_bounds__(REFIT_THREADS) void k_refit_pi2(RefitArgs p) {
+static __global__ __launch_bounds__(REFIT_THREADS) void k_refit_pi2(RefitArgs p) {
     extern __shared__ float smem[];
     float* om = smem;
     float* red = smem + p.Nst;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_refit_pi2(RefitArgs p) {
 }
 
 // warm start: prev = [mean[:,1:], mean[:,-1:]]   pi2.py:92-93 / spsa.py:114-115
-__global__ void k_shift_left(int A, int H, int U, const float* mean, float* prev) {
+static __global__ void k_shift_left(int A, int H, int U, const float* mean, float* prev) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A * H * U) return;
     const int u = i % U, h = (i / U) % H, a = i / (U * H);
@@ -299,7 +299,7 @@ __global__ void k_shift_left(int A, int H, int U, const float* mean, float* prev
 // RandomSearch refit  random_search.py:43-47: per-agent argmax (first maximum), take its first action.
 // `part` != null (population sharded over ranks): part[a] = (best value, GLOBAL particle index as bits,
 // its first action[U]) of this rank's particles; k_argmax_merge takes the first maximum by global index.
-__global__ __launch_bounds__(REFIT_THREADS) void k_refit_argmax(RefitArgs p, float* part, int pop_offset) {
+static __global__ __launch_bounds__(REFIT_THREADS) void k_refit_argmax(RefitArgs p, float* part, int pop_offset) {
     __shared__ float sv[REFIT_THREADS / 64];
     __shared__ int si[REFIT_THREADS / 64];
     const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(REFIT_THREADS) void k_refit_argmax(RefitArgs p, flo
 }
 
 // RandomSearch with the population sharded over ranks: all[r][a] = (value, global index, action[U]).  grid A, block 64
-__global__ void k_argmax_merge(RefitArgs p, const float* all, int G) {
+static __global__ void k_argmax_merge(RefitArgs p, const float* all, int G) {
     const int a = blockIdx.x, lane = threadIdx.x;
     const size_t pw = (size_t)p.A * (p.U + 2);
     int br = 0, bi = 0x7fffffff;
@@ -423,7 +423,7 @@ __device__ __forceinline__ void publish_records_done(unsigned* flag, unsigned* c
 }
 
 // done_flag: optional publish_records_done -- the host-polled bbmpc_optimize returns when it sees it
-__global__ void k_finalize_pendulum(FinalArgs p, unsigned* done_flag, unsigned* done_count, unsigned done_value) {
+static __global__ void k_finalize_pendulum(FinalArgs p, unsigned* done_flag, unsigned* done_count, unsigned done_value) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a < p.A) finalize_pendulum_agent(p, a, p.action[a]);
     if (done_flag) {

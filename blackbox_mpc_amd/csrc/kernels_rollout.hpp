@@ -175,7 +175,7 @@ __global__ void k_rollout_pendulum(RolloutArgs p) {
 
 // Single environment/model step on [B] rows: predict_next_state + evaluate_next_reward
 // (deterministic.py:79-127) for the analytic pendulum.  actions rows are `astride` floats apart.
-__global__ void k_step_pendulum(const float* states, const float* actions, int astride, int batch, int fix_q1,
+static __global__ void k_step_pendulum(const float* states, const float* actions, int astride, int batch, int fix_q1,
                                 float* next_states, float* rewards) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
@@ -192,7 +192,7 @@ __global__ void k_step_pendulum(const float* states, const float* actions, int a
 }
 
 // evaluate_next_reward on caller-provided (cur, next, actions) rows, any reward kind.
-__global__ void k_reward_only(const float* cur, const float* nxt, const float* act, int batch, int S, int U,
+static __global__ void k_reward_only(const float* cur, const float* nxt, const float* act, int batch, int S, int U,
                               int reward_kind, int fix_q1, float* rewards) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;

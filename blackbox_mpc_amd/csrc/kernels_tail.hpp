@@ -128,7 +128,7 @@ struct TailArgs {
 };
 
 // grid A, block TAIL_THREADS
-__global__ __launch_bounds__(TAIL_THREADS) void k_tail_mlp(TailArgs p) {
+static __global__ __launch_bounds__(TAIL_THREADS) void k_tail_mlp(TailArgs p) {
     __shared__ float cur[64], act[128], nxt[64], x[192];
     __shared__ float bufA[TAIL_MAXW], bufB[TAIL_MAXW], part[(TAIL_THREADS / 64) * TAIL_MAXW];
     const int a = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_mlp(TailArgs p) {
 }
 
 // grid = rows, block TAIL_THREADS.  next_states and/or rewards may be null.
-__global__ __launch_bounds__(TAIL_THREADS) void k_rows_mlp(RowMlp net, int S, int U, int reward_kind, int fix_q1,
+static __global__ __launch_bounds__(TAIL_THREADS) void k_rows_mlp(RowMlp net, int S, int U, int reward_kind, int fix_q1,
                                                            const float* states, const float* actions, int action_stride,
                                                            float* next_states, float* rewards) {
     __shared__ float cur[64], act[128], nxt[64], x[192];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_rows_mlp(RowMlp net, int S, in
 // N = 1000, HU = 180: 11 rows per wave, each a 16-deep chain of dependent L2 round trips.
 // grid (ceil(HU / PI2_ROWS), A), block 64 * PI2_ROWS.   LDS: omega[Nst] | red[PI2_ROWS]
 constexpr int PI2_ROWS = 4;
-__global__ __launch_bounds__(64 * PI2_ROWS) void k_refit_pi2_mw(RefitArgs p) {
+static __global__ __launch_bounds__(64 * PI2_ROWS) void k_refit_pi2_mw(RefitArgs p) {
     extern __shared__ float smem[];
     float* om = smem;
     float* red = smem + p.Nst;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * PI2_ROWS) void k_refit_pi2_mw(RefitArgs p) {
 // The only difference to the un-sharded refit is the order of the fp32 sums (tolerance stated in the tests: 2e-5).
 // part layout per agent: [0] beta_r, [1] eta_r, [2 .. 2+HU) S_r.
 // k_refit_pi2_partial: grid (ceil(HU / PI2_ROWS), A), block 64 * PI2_ROWS, LDS pr[Nst] | red[PI2_ROWS]
-__global__ __launch_bounds__(64 * PI2_ROWS) void k_refit_pi2_partial(RefitArgs p, float* part) {
+static __global__ __launch_bounds__(64 * PI2_ROWS) void k_refit_pi2_partial(RefitArgs p, float* part) {
     extern __shared__ float smem[];
     float* pr = smem;
     float* red = smem + p.Nst;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64 * PI2_ROWS) void k_refit_pi2_partial(RefitArgs p
 }
 
 // gathered: [G][A][HU+2].  grid (ceil(HU/256), A), block 256
-__global__ void k_refit_pi2_merge(RefitArgs p, const float* gathered, int G) {
+static __global__ void k_refit_pi2_merge(RefitArgs p, const float* gathered, int G) {
     const int a = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= p.HU) return;
     const size_t stride = (size_t)p.A * (p.HU + 2);
@@ -362,7 +362,7 @@ __global__ void k_refit_pi2_merge(RefitArgs p, const float* gathered, int G) {
 // its share of the H*U columns -- the scattered gather of k x H*U sample values, and the strided reads of the merge's
 // statistics, are what these kernels spend their time on (one workgroup per agent: +34 us per iteration at N = 1000).
 // k_cem_local_topk: grid (Gw, A), block 1024.  LDS: rewards[Nst] | eidx[kpad] | hist | ekeys[2*kpad]
-__global__ __launch_bounds__(1024) void k_cem_local_topk(RefitArgs p, int pop_offset, float* cand) {
+static __global__ __launch_bounds__(1024) void k_cem_local_topk(RefitArgs p, int pop_offset, float* cand) {
     extern __shared__ float smem[];
     const int a = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
     float* r = smem;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_cem_local_topk(RefitArgs p, int pop_of
 
 // gathered: [G][A][k][HU+2].  grid (Gw, A), block 256.  LDS: key rewards[G*k] | global idx[G*k] | chosen slot[k]
 // Statistics of a row on a 16-lane group (elites over the lanes, DPP reduction), as in k_refit_cem_v2.
-__global__ __launch_bounds__(256) void k_cem_merge(RefitArgs p, const float* gathered, int G) {
+static __global__ __launch_bounds__(256) void k_cem_merge(RefitArgs p, const float* gathered, int G) {
     extern __shared__ float smem[];
     const int a = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
     const int W = p.HU + 2, M = G * p.k;

@@ -54,7 +54,7 @@ struct RowsArgs {
 };
 
 // grid (ceil(n_pop/256), A), block 256
-__global__ void k_rows_prepare(RowsArgs p) {
+static __global__ void k_rows_prepare(RowsArgs p) {
     const int a = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= p.n_pop) return;
     const size_t B = (size_t)p.A * p.n_pop, b = (size_t)a * p.n_pop + n;
@@ -79,7 +79,7 @@ __global__ void k_rows_prepare(RowsArgs p) {
 }
 
 // built-in reward on rows, accumulated over the planning steps
-__global__ void k_reward_rows_acc(const float* cur, const float* nxt, const float* act, int astride, int batch, int S, int U,
+static __global__ void k_reward_rows_acc(const float* cur, const float* nxt, const float* act, int astride, int batch, int S, int U,
                                   int reward_kind, int fix_q1, float* total, int accumulate) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
@@ -88,7 +88,7 @@ __global__ void k_reward_rows_acc(const float* cur, const float* nxt, const floa
 }
 
 // grid (ceil(n_pop/256), A)
-__global__ void k_rows_finish(int n_pop, int A, int Nst, int pen, const float* total, const float* penalty, float* rewards,
+static __global__ void k_rows_finish(int n_pop, int A, int Nst, int pen, const float* total, const float* penalty, float* rewards,
                               float* penalty_out) {
     const int a = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_pop) return;
@@ -105,7 +105,7 @@ __global__ void k_rows_finish(int n_pop, int A, int Nst, int pen, const float* t
 // SystemDynamicsHandler.process_input / process_output as stand-alone calls
 // (dynamics_handlers/system_dynamics_handler.py:97-126, 128-161 + utils/transforms.py:20-34).
 // stats = mean_states | std_states | mean_actions | std_actions | mean_targets | std_targets (contiguous) or null.
-__global__ void k_process_input(const float* states, const float* actions, int batch, int S, int U, const float* stats, float* out) {
+static __global__ void k_process_input(const float* states, const float* actions, int batch, int S, int U, const float* stats, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= batch * (S + U)) return;
     const int b = i / (S + U), f = i % (S + U);
@@ -117,7 +117,7 @@ __global__ void k_process_input(const float* states, const float* actions, int b
     }
     out[i] = v;
 }
-__global__ void k_process_output(const float* states, const float* raw, int batch, int S, int U, const float* stats, float* out) {
+static __global__ void k_process_output(const float* states, const float* raw, int batch, int S, int U, const float* stats, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= batch * S) return;
     const int f = i % S;

@@ -29,6 +29,8 @@
 //   normal      : Box-Muller on word pairs (x0,x1),(x2,x3).
 //   rademacher  : +1 if top bit set else -1.
 #pragma once
+#include <stdexcept>
+#include <string>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -70,7 +72,11 @@ __host__ __device__ __forceinline__ float word_to_uniform(uint32_t x) {
 constexpr int TNQ_BITS = 11;
 constexpr int TNQ_SIZE = 1 << TNQ_BITS;                    // 2048 intervals
 // (q[i], q[i+1]-q[i]) pairs, filled once per device by the host (Engine constructor)
-__device__ float2 g_tnq[TNQ_SIZE];
+static __device__ float2 g_tnq[TNQ_SIZE];     // one copy per translation unit (no relocatable device code): tnq_upload fills it
+static inline void tnq_upload(const float2* table) {
+    hipError_t e_ = hipMemcpyToSymbol(HIP_SYMBOL(g_tnq), table, sizeof(float2) * TNQ_SIZE);
+    if (e_ != hipSuccess) throw std::runtime_error(std::string("hipMemcpyToSymbol(g_tnq): ") + hipGetErrorString(e_));
+}
 
 __device__ __forceinline__ float word_to_trunc_normal(uint32_t x) {
     const uint32_t v = x >> 9;                              // 23 random bits

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#define BBMPC_TU_CMA
 #include "../../blackbox_mpc_amd/csrc/kernels_eigh.hpp"
 using namespace bbmpc;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
