@@ -512,8 +512,7 @@ static __global__ __launch_bounds__(EIGH_TRI_THREADS) void k_eigh_tridiag(EighAr
 // ---------------------------------------------------------------------------------------------------------------------
 // 2. Eigen-decomposition of the tridiagonal T (d, e) -- and, in the surplus workgroups of the same launch, the
 // triangular factors of the reflector blocks for stage 4.
-// grid (EIGH_LD / 16 + EIGH_LD / 32, G), block 256.  Workgroups x < 20: 16 eigenvalue slots each, one 16-lane DPP row
-// per slot.  T is split where |e_k| <= 4 eps max(|alpha|, |T|); slot j belongs to the unreduced block [s, t) that
+// grid (EIGH_LD / 4 + EIGH_LD / 32, G), block 256.  Workgroups x < 80: four eigenvalue slots each, one wave per slot.  T is split where |e_k| <= 4 eps max(|alpha|, |T|); slot j belongs to the unreduced block [s, t) that
 // contains index j and takes that block's (j - s)-th eigenvalue:
 //   multisection   the row's 16 lanes try 16 shifts per pass; Sturm count = negative pivots of T - x inside [s, t)
 //                  (the recurrence runs over the whole matrix: e^2 = 0 at a split restarts it); 7 passes of 17-fold
@@ -523,14 +522,16 @@ static __global__ __launch_bounds__(EIGH_TRI_THREADS) void k_eigh_tridiag(EighAr
 //                  vector out from z_r = 1 upwards / downwards; normalised, residual |gamma_r| / |z| recorded
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int EIGH_SOLVE_THREADS = 256;
-constexpr int EIGH_SLOT_WGS = EIGH_LD / 16, EIGH_TF_WGS = EIGH_LD / 32;
+constexpr int EIGH_SLOTS_PER_WG = EIGH_SOLVE_THREADS / 64;      // one wave per eigenvalue slot
+constexpr int EIGH_SLOT_WGS = EIGH_LD / EIGH_SLOTS_PER_WG, EIGH_TF_WGS = EIGH_LD / 32;
+static_assert(EIGH_SLOTS_PER_WG == 4, "k_eigh_tri_solve writes the four slots of a workgroup as one float4 per row");
 
 struct EighSolveLds {
     float dd[EIGH_LD];          // d
     float ee[EIGH_LD];          // thresholded e (ee[k] couples k, k + 1)
     float e2p[EIGH_LD];         // e2p[i] = ee[i-1]^2 (0 for i = 0)
-    float fw[16][EIGH_LD + 4];  // per slot: D+ pivots, then the upper part of z
-    float bw[16][EIGH_LD + 4];  // per slot: D- pivots, then the lower part of z
+    float fw[EIGH_SLOTS_PER_WG][EIGH_LD + 4];  // per slot: D+ pivots, then the upper part of z
+    float bw[EIGH_SLOTS_PER_WG][EIGH_LD + 4];  // per slot: D- pivots, then the lower part of z
     float red[8];
     short bs[EIGH_LD], bt[EIGH_LD];   // unreduced block [bs[i], bt[i]) around index i
 };
@@ -556,7 +557,7 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     const float* d = q.d + (size_t)g * EIGH_LD;
     const float* e = q.e + (size_t)g * EIGH_LD;
     const float alpha = q.alpha[g];
-    const int lane = tid & 63, wv = tid >> 6, sub = lane & 15, row = wv * 4 + (lane >> 4);
+    const int lane = tid & 63, wv = tid >> 6, sub = lane & 15, row = wv;      // slot `row` of this workgroup = wave wv
     // ---- T into LDS, split threshold, Gershgorin interval
     float tn = 0.0f;
     for (int i = tid; i < EIGH_LD; i += EIGH_SOLVE_THREADS) {
@@ -594,7 +595,10 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
         if (i < EIGH_LD) L.ee[i] = eth[it];
     }
     __syncthreads();
-    for (int i = tid; i < EIGH_LD; i += EIGH_SOLVE_THREADS) L.e2p[i] = i > 0 ? L.ee[i - 1] * L.ee[i - 1] : 0.0f;
+    // e^2 of the coupling to the previous index; 1e-36 instead of 0 at a split (and at i = 0): the Sturm chain below then
+    // needs no pivmin test -- a pivot that is exactly zero gives e^2 * inf = inf and the next pivot -inf, counted as the one
+    // negative pivot the pivmin rule would count, where 0 * inf would be a NaN; against pivots of |T| 1e-36 couples nothing
+    for (int i = tid; i < EIGH_LD; i += EIGH_SOLVE_THREADS) L.e2p[i] = (i > 0 && i < n) ? fmaxf(L.ee[i - 1] * L.ee[i - 1], 1.0e-36f) : 1.0e-36f;
     gl = fminf(gl, __shfl_xor(gl, 32, 64)); gu = fmaxf(gu, __shfl_xor(gu, 32, 64));
     gl = row16_min(gl); gu = row16_max(gu);
     gl = fminf(gl, __shfl_xor(gl, 16, 64)); gu = fmaxf(gu, __shfl_xor(gu, 16, 64));
@@ -609,7 +613,7 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     }
     const float pivmin = fmaxf(1.0e-30f, tn * tn * 1.0e-30f);
     if (blockIdx.x == 0 && tid == 0) q.flags[(size_t)g * 8 + 5] = __float_as_uint(tn);
-    const int j = blockIdx.x * 16 + row;                          // eigenvalue slot of this 16-lane row
+    const int j = blockIdx.x * EIGH_SLOTS_PER_WG + row;           // eigenvalue slot of this wave
     const bool live = j < n;
     // ---- the unreduced block [s, t) around every index: running maximum of the split positions from the left, running
     // minimum from the right (log-step scans over the 320 entries, two per thread)
@@ -639,22 +643,21 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     const int s = live ? (int)L.bs[j] : 0, t = live ? (int)L.bt[j] : 1;
     const int m = (live ? j : 0) - s;
     SOLVE_MARK(0);
-    // ---- multisection: 32 shifts per slot and pass (two per lane: two independent chains share the latency of the
-    // reciprocal), six passes of 33-fold narrowing.  d and e^2 come from LDS four steps at a time, one group ahead of
-    // the chain.  (Measured and dropped: the product form p_{i+1} = (d_i - x) p_i - e^2 p_{i-1} with a power-of-two
-    // rescale every four steps -- one FMA on the chain instead of rcp / mul / sub / pivmin test, but more instructions
-    // per step, and with one wave per SIMD the loop is issue bound: 190 against 137 cycles per step.)
+    // ---- multisection: the wave's 64 lanes try 64 shifts per pass, five passes of 65-fold narrowing (65^5 = 1.2e9: the
+    // interval ends below the last bit of |T|).  One Sturm chain per lane -- the loop is a dependent chain (rcp, product,
+    // difference: ~55 cycles per step), so the shifts go across lanes and workgroups (300 waves per
+    // instance over the whole chip) rather than several per lane; d and e^2 come from LDS four steps at a time, one
+    // group ahead of the chain.
     float lo = gl, hi = gu;
     if (t - s > 1) {
         const float4* dd4 = reinterpret_cast<const float4*>(L.dd);
         const float4* e24 = reinterpret_cast<const float4*>(L.e2p);
         const int n4 = (n + 3) >> 2;                              // (entries beyond n are zero and lie outside every block)
-        for (int pass = 0; pass < 6; ++pass) {               // 33^6 = 1.3e9: the interval ends below the last bit of |T| (with five passes the
-                                                             // eigenvalues are 10x coarser and the twisted vectors 10x less orthogonal)
-            const float h = (hi - lo) * (1.0f / 33.0f);
-            const float xa = fmaf((float)(sub + 1), h, lo), xb = fmaf((float)(sub + 17), h, lo);
-            int ca = 0, cb = 0;
-            float qa = 1.0f, qb = 1.0f;
+        for (int pass = 0; pass < 5; ++pass) {
+            const float h = (hi - lo) * (1.0f / 65.0f);
+            const float x = fmaf((float)(lane + 1), h, lo);
+            int cnt = 0;
+            float qv = 1.0f;
             float4 dA = dd4[0], eA = e24[0];
             for (int i4 = 0; i4 < n4; ++i4) {
                 const float4 dB = dd4[i4 + 1], eB = e24[i4 + 1];  // (one group ahead; the arrays are followed by more LDS)
@@ -662,19 +665,18 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int i = 4 * i4 + c;
-                    const bool in = (unsigned)(i - s) < (unsigned)(t - s);
-                    qa = (dv[c] - xa) - ev[c] * __builtin_amdgcn_rcpf(qa);
-                    qb = (dv[c] - xb) - ev[c] * __builtin_amdgcn_rcpf(qb);
-                    qa = fabsf(qa) < pivmin ? -pivmin : qa;
-                    qb = fabsf(qb) < pivmin ? -pivmin : qb;
-                    ca += (in && qa < 0.0f) ? 1 : 0;
-                    cb += (in && qb < 0.0f) ? 1 : 0;
+                    qv = (dv[c] - x) - ev[c] * __builtin_amdgcn_rcpf(qv);          // (no pivmin test: see e2p)
+                    cnt += ((unsigned)(i - s) < (unsigned)(t - s) && qv < 0.0f) ? 1 : 0;
                 }
                 dA = dB; eA = eB;
             }
             // eigenvalue m of the block lies above every shift with count <= m and not above any shift with count > m
-            const float below = cb <= m ? xb : (ca <= m ? xa : lo), above = ca > m ? xa : (cb > m ? xb : hi);
-            lo = row16_max(below); hi = row16_min(above);
+            float below = cnt <= m ? x : lo, above = cnt > m ? x : hi;
+            below = row16_max(below); above = row16_min(above);
+            lo = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(below), 0)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(below), 16))),
+                       fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(below), 32)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(below), 48))));
+            hi = fminf(fminf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(above), 0)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(above), 16))),
+                       fminf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(above), 32)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(above), 48))));
             if (!(hi > lo)) hi = lo;
         }
     } else {
@@ -686,24 +688,40 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     float* fw = L.fw[row];
     float* bw = L.bw[row];
     const int len = t - s;
-    int lenmax = len;
-    lenmax = max(lenmax, __shfl_xor(lenmax, 16, 64)); lenmax = max(lenmax, __shfl_xor(lenmax, 32, 64));
-    if (sub < 2) {
-        const bool fwd = sub == 0;
-        float piv = fwd ? L.dd[s] - lam : L.dd[t - 1] - lam;
-        for (int st = 0; st < lenmax; ++st) {
-            if (st < len) {
-                const int i = fwd ? s + st : t - 1 - st;
-                piv = fabsf(piv) < pivmin ? -pivmin : piv;
-                (fwd ? fw : bw)[i] = piv;
-                if (st + 1 < len) {
-                    const int in = fwd ? i + 1 : i - 1;
-                    const float ec = fwd ? L.ee[i] : L.ee[i - 1];           // coupling between i and the next index
+    // lane 0 runs the forward, lane 1 the backward recurrence.  The operands of step st + 1 .. st + 4 (couplings and the
+    // next diagonal entries) are loaded before the chain of the current four steps: as plain code every step waited for
+    // two LDS round trips behind the store of its own pivot (390 cycles per step measured, 4/5 of it LDS latency)
+    if (lane < 2) {
+        const bool fwd = lane == 0;
+        const int dir = fwd ? 1 : -1, i0 = fwd ? s : t - 1;
+        float piv = L.dd[i0] - lam;
+        float* out = fwd ? fw : bw;
+        float ec[4], dn[4];
+        auto load4 = [&](int st, float (&e4)[4], float (&d4)[4]) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = i0 + dir * (st + c);                              // current index of that step
+                const bool ok = st + c + 1 < len;                               // it has a successor
+                const int ic = ok ? (fwd ? i : i - 1) : s, in = ok ? i + dir : s;
+                e4[c] = L.ee[ic]; d4[c] = L.dd[in];
+            }
+        };
+        load4(0, ec, dn);
+        for (int st = 0; st < len; st += 4) {
+            float en[4], dq[4];
+            load4(st + 4, en, dq);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (st + c < len) {
+                    piv = fabsf(piv) < pivmin ? -pivmin : piv;
+                    out[i0 + dir * (st + c)] = piv;
                     float rp = __builtin_amdgcn_rcpf(piv);
                     rp = rp * fmaf(-piv, rp, 2.0f);     // one Newton step: with 1-ulp quotients the vectors come out 10x less orthogonal
-                    piv = (L.dd[in] - lam) - (ec * rp) * ec;                            // (1.4e-3 instead of 6e-5) and the second polish round is needed
+                    piv = (dn[c] - lam) - (ec[c] * rp) * ec[c];
                 }
             }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { ec[c] = en[c]; dn[c] = dq[c]; }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -711,12 +729,12 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     // gamma_i = D+_i + D-_i - (d_i - lam); r = argmin |gamma_i|
     float gmin = 3.0e38f;
     int rbest = s;
-    for (int i = s + sub; i < t; i += 16) {
+    for (int i = s + lane; i < t; i += 64) {
         const float gam = fabsf((fw[i] + bw[i]) - (L.dd[i] - lam));
         if (gam < gmin) { gmin = gam; rbest = i; }
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
+    for (int o = 32; o > 0; o >>= 1) {
         const float og = __shfl_xor(gmin, o, 64);
         const int orr = __shfl_xor(rbest, o, 64);
         if (og < gmin || (og == gmin && orr < rbest)) { gmin = og; rbest = orr; }
@@ -725,32 +743,53 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     __builtin_amdgcn_wave_barrier();
     SOLVE_MARK(3);
     // z_r = 1;  upwards z_i = -(e_i / D+_i) z_{i+1};  downwards z_{i+1} = -(e_i / D-_{i+1}) z_i
-    // (z_i overwrites D+_i for i <= r and D-_i for i > r)
-    if (sub < 2) {
-        const bool up = sub == 0;
-        float z = 1.0f;
-        if (up) {
-            for (int i = r - 1; i >= s; --i) { const float pv = fw[i]; float rp = __builtin_amdgcn_rcpf(pv); rp = rp * fmaf(-pv, rp, 2.0f); z = -(L.ee[i] * rp) * z; fw[i] = z; }
-        } else {
-            for (int i = r; i < t - 1; ++i) { const float pv = bw[i + 1]; float rp = __builtin_amdgcn_rcpf(pv); rp = rp * fmaf(-pv, rp, 2.0f); z = -(L.ee[i] * rp) * z; bw[i + 1] = z; }
+    // (z_i overwrites D+_i for i <= r and D-_i for i > r); operands four steps ahead of the chain, as above
+    if (lane < 2) {
+        const bool up = lane == 0;
+        const int cnt_z = up ? r - s : t - 1 - r;                    // steps of this direction
+        float* arr = up ? fw : bw;
+        auto load4 = [&](int st, float (&e4)[4], float (&p4)[4]) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool ok = st + c < cnt_z;
+                const int i = up ? r - 1 - (st + c) : r + (st + c);  // coupling index e_i; pivot index: i (up) or i + 1 (down)
+                e4[c] = L.ee[ok ? i : s]; p4[c] = arr[ok ? (up ? i : i + 1) : s];
+            }
+        };
+        float z = 1.0f, ec[4], pv[4];
+        load4(0, ec, pv);
+        for (int st = 0; st < cnt_z; st += 4) {
+            float en[4], pn[4];
+            load4(st + 4, en, pn);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (st + c < cnt_z) {
+                    float rp = __builtin_amdgcn_rcpf(pv[c]);
+                    rp = rp * fmaf(-pv[c], rp, 2.0f);
+                    z = -(ec[c] * rp) * z;
+                    arr[up ? r - 1 - (st + c) : r + (st + c) + 1] = z;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { ec[c] = en[c]; pv[c] = pn[c]; }
         }
     }
     __builtin_amdgcn_wave_barrier();
     SOLVE_MARK(4);
-    if (sub == 0) fw[r] = 1.0f;
+    if (lane == 0) fw[r] = 1.0f;
     __builtin_amdgcn_wave_barrier();
     float zz = 0.0f;
-    for (int i = s + sub; i < t; i += 16) { const float z = i <= r ? fw[i] : bw[i]; zz = fmaf(z, z, zz); }
-    zz = row16_sum(zz);
+    for (int i = s + lane; i < t; i += 64) { const float z = i <= r ? fw[i] : bw[i]; zz = fmaf(z, z, zz); }
+    zz = wave_sum(zz);
     const float rn = 1.0f / sqrtf(zz);
-    if (live && sub == 0) {
+    if (live && lane == 0) {
         q.lam[(size_t)g * EIGH_LD + j] = lam;
         const float resid = gmin * rn;                                       // |(T - lam) z| for the normalised z
         atomicMax(q.flags + (size_t)g * 8 + 2, __float_as_uint(resid));
     }
     // normalised vector back into fw (zero outside [s, t)), for every i < EIGH_LD
     __builtin_amdgcn_wave_barrier();
-    for (int i = sub; i < EIGH_LD; i += 16) {
+    for (int i = lane; i < EIGH_LD; i += 64) {
         float z = 0.0f;
         if (live && i >= s && i < t) z = (i <= r ? fw[i] : bw[i]) * rn;
         __builtin_amdgcn_wave_barrier();
@@ -758,13 +797,11 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     }
     __syncthreads();
     SOLVE_MARK(5);
-    // ---- Z[i][j0 + jj] for the 16 slots of this workgroup: 64-byte segments
-    float* Z = q.Z + (size_t)g * EIGH_LD * EIGH_LD + blockIdx.x * 16;
-    for (int idx = tid; idx < EIGH_LD * 16; idx += EIGH_SOLVE_THREADS) {
-        const int i = idx >> 4, jj = idx & 15;
-        Z[(size_t)i * EIGH_LD + jj] = L.fw[jj][i];
-    }
-    if (tid < 16 && blockIdx.x * 16 + tid >= n) q.lam[(size_t)g * EIGH_LD + blockIdx.x * 16 + tid] = -3.0e38f;   // padding slots sort last
+    // ---- Z[i][j0 .. j0 + 3] for the four slots of this workgroup: one 16-byte store per row
+    float* Z = q.Z + (size_t)g * EIGH_LD * EIGH_LD + blockIdx.x * EIGH_SLOTS_PER_WG;
+    for (int i = tid; i < EIGH_LD; i += EIGH_SOLVE_THREADS)
+        *reinterpret_cast<float4*>(Z + (size_t)i * EIGH_LD) = make_float4(L.fw[0][i], L.fw[1][i], L.fw[2][i], L.fw[3][i]);
+    if (tid < EIGH_SLOTS_PER_WG && blockIdx.x * EIGH_SLOTS_PER_WG + tid >= n) q.lam[(size_t)g * EIGH_LD + blockIdx.x * EIGH_SLOTS_PER_WG + tid] = -3.0e38f;   // padding slots sort last
     SOLVE_MARK(6);
 #ifdef EIGH_CLK
     if (blockIdx.x == 9 && blockIdx.y == 1 && tid == 0) for (int i = 0; i < 8; ++i) g_eigh_clk[i] = clk_[i];
