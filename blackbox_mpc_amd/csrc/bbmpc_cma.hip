@@ -112,7 +112,7 @@ void Engine::cma_eigh_launch(const CmaArgs& cq) {
     ensure_max_lds((const void*)k_eigh_tri_solve, (int)lds2);
     hipLaunchKernelGGL(k_eigh_tridiag, dim3(G), dim3(EIGH_TRI_THREADS), lds1, stream, q);
     hipLaunchKernelGGL(k_eigh_tri_solve, dim3(EIGH_SLOT_WGS + EIGH_TF_WGS, G), dim3(EIGH_SOLVE_THREADS), lds2, stream, q);
-    const dim3 gg(EIGH_LD / 64, EIGH_LD / 64, G);
+    const dim3 gg(EIGH_LD / 64, EIGH_LD / 16, G);
     hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, stream, q, (const float*)q.Z, (const float*)nullptr, q.P, 1, 0);
     hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, stream, q, (const float*)q.Z, (const float*)q.P, q.Z2, 0, 0);
     hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, stream, q, (const float*)q.Z2, (const float*)nullptr, q.P, 3, 1);

@@ -857,7 +857,7 @@ __device__ __forceinline__ void eigh_tfactor_block(const EighArgs& q, int g, int
 // v_mfma_f32_16x16x4_f32 straight from L2 (the matrices are 400 KB), 64 x 64 tile per workgroup.
 //   MODE 0:  P = 1.5 I - 0.5 A^T A   and  flags[slot] = max |A^T A - I|        (fragments contiguous for a fixed k)
 //   MODE 1:  Zout = A P                                                        (a lane's four k of A are one 16-byte load)
-// grid (EIGH_LD / 64, EIGH_LD / 64, G), block 256
+// grid (EIGH_LD / 64, EIGH_LD / 16, G), block 256
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr float EIGH_ONE_ROUND = 1.0e-3f;
 
@@ -865,13 +865,17 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_eigh_gemm(EighArgs q, const float* __restrict__ A_all, const float* __restrict__ P_all,
                                                     float* __restrict__ out_all, int slot, int second_round) {
     typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ f4 part[4][4][64];                          // [k quarter][column fragment][lane]
     const int g = blockIdx.z, n = q.n;
     // the second polish round is skipped when the twisted vectors were orthogonal to EIGH_ONE_ROUND already (one round
     // then leaves ~1e-6: measured 5.6e-4 -> 5.4e-7, 2.5e-3 -> 6.8e-6); the back-transformation reads Z2 in that case
     if (second_round && __uint_as_float(q.flags[(size_t)g * 8 + 1]) <= EIGH_ONE_ROUND) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lm = lane & 15, lk = lane >> 4;
-    const int r0 = blockIdx.y * 64 + wave * 16, c0 = blockIdx.x * 64;
+    // a 16 x 64 tile per workgroup; wave w sums the k quarter [80 w, 80 w + 80): the loop is a chain of L2 round trips, so
+    // it is cut four ways (and the grid is 100 workgroups per instance instead of 25) rather than given more rows
+    const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 64;
+    const int kq0 = wave * (EIGH_LD / 4), kq1 = kq0 + EIGH_LD / 4;
     const float* A = A_all + (size_t)g * EIGH_LD * EIGH_LD;
     float* out = out_all + (size_t)g * EIGH_LD * EIGH_LD;
     f4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -879,8 +883,8 @@ __global__ __launch_bounds__(256) void k_eigh_gemm(EighArgs q, const float* __re
         // out[a][b] = sum_i A[i][a] A[i][b]
         const float* pa = A + r0 + lm;
         const float* pb = A + c0 + lm;
-#pragma unroll 4
-        for (int k0 = 0; k0 < EIGH_LD; k0 += 4) {
+#pragma unroll 5
+        for (int k0 = kq0; k0 < kq1; k0 += 4) {
             const size_t kr = (size_t)(k0 + lk) * EIGH_LD;
             const float a = pa[kr];
             const float b0 = pb[kr], b1 = pb[kr + 16], b2 = pb[kr + 32], b3 = pb[kr + 48];
@@ -889,28 +893,13 @@ __global__ __launch_bounds__(256) void k_eigh_gemm(EighArgs q, const float* __re
             acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc[2], 0, 0, 0);
             acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b3, acc[3], 0, 0, 0);
         }
-        float dmax = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = r0 + 4 * lk + r;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const int col = c0 + 16 * f + lm;
-                const float gv = acc[f][r], id = row == col ? 1.0f : 0.0f;
-                if (row < n && col < n) dmax = fmaxf(dmax, fabsf(gv - id));
-                out[(size_t)row * EIGH_LD + col] = (row < n && col < n) ? fmaf(-0.5f, gv, 1.5f * id) : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
-        if (lane == 0) atomicMax(q.flags + (size_t)g * 8 + slot, __float_as_uint(dmax));
     } else {
         // out[i][c] = sum_b A[i][b] P[b][c]
         const float* P = P_all + (size_t)g * EIGH_LD * EIGH_LD;
         const float* pa = A + (size_t)(r0 + lm) * EIGH_LD + 4 * lk;
         const float* pb = P + c0 + lm;
-#pragma unroll 2
-        for (int k0 = 0; k0 < EIGH_LD; k0 += 16) {
+#pragma unroll 5
+        for (int k0 = kq0; k0 < kq1; k0 += 16) {
             const float4 a4 = *reinterpret_cast<const float4*>(pa + k0);
             const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
@@ -923,12 +912,31 @@ __global__ __launch_bounds__(256) void k_eigh_gemm(EighArgs q, const float* __re
                 acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], b3, acc[3], 0, 0, 0);
             }
         }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) part[wave][f][lane] = acc[f];
+    __syncthreads();
+    // wave f finishes column fragment f: the four k quarters in order
+    const int f = wave;
+    f4 sum = part[0][f][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { const f4 pq = part[w][f][lane]; sum[0] += pq[0]; sum[1] += pq[1]; sum[2] += pq[2]; sum[3] += pq[3]; }
+    const int col = c0 + 16 * f + lm;
+    if (MODE == 0) {
+        float dmax = 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = r0 + 4 * lk + r;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) out[(size_t)row * EIGH_LD + c0 + 16 * f + lm] = acc[f][r];
+            const float gv = sum[r], id = row == col ? 1.0f : 0.0f;
+            if (row < n && col < n) dmax = fmaxf(dmax, fabsf(gv - id));
+            out[(size_t)row * EIGH_LD + col] = (row < n && col < n) ? fmaf(-0.5f, gv, 1.5f * id) : 0.0f;
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
+        if (lane == 0) atomicMax(q.flags + (size_t)g * 8 + slot, __float_as_uint(dmax));
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(r0 + 4 * lk + r) * EIGH_LD + col] = sum[r];
     }
 }
 

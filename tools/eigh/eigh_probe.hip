@@ -131,7 +131,7 @@ int main(int argc, char** argv) {
     }
     // ---- stages 3, 4
     auto polish_and_back = [&]() {
-        const dim3 gg(EIGH_LD / 64, EIGH_LD / 64, G);
+        const dim3 gg(EIGH_LD / 64, EIGH_LD / 16, G);
         hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, 0, q, (const float*)q.Z, (const float*)nullptr, q.P, 1, 0);
         hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, 0, q, (const float*)q.Z, (const float*)q.P, q.Z2, 0, 0);
         hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, 0, q, (const float*)q.Z2, (const float*)nullptr, q.P, 3, 1);
@@ -151,7 +151,7 @@ int main(int argc, char** argv) {
         polish_and_back();
         CK(hipEventRecord(ev[3])); CK(hipEventSynchronize(ev[3]));
         {   // the five launches of stages 3, 4 one by one (results unchanged: the polish of an orthogonal Z is the identity)
-            const dim3 gg(EIGH_LD / 64, EIGH_LD / 64, G);
+            const dim3 gg(EIGH_LD / 64, EIGH_LD / 16, G);
             hipEvent_t f[6]; for (auto& x : f) CK(hipEventCreate(&x));
             CK(hipEventRecord(f[0]));
             hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, 0, q, (const float*)q.Z, (const float*)nullptr, q.P, 4, 0);
