@@ -229,6 +229,8 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
                 if (qlds > 64 * 1024) ensure_max_lds((const void*)fn, 160 * 1024);
                 dim3 qgrid((ra.n_pop + 3) / 4, A), qblock(256);
                 dominant_kernel = "k_rollout_mlp_q4r";
+                q.state_copy = mlp_state_copy;
+                mlp_state_copy = nullptr;
                 prof_begin();
                 hipLaunchKernelGGL(fn, qgrid, qblock, qlds, stream, q);
                 HIP_CHECK(hipGetLastError());

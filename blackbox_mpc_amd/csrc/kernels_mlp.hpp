@@ -68,6 +68,8 @@ struct MlpRolloutArgs {
     const float* wq4[MLP_MAX_LAYERS];    // quad-mode operands [ceil(in/4)][Mp][4], Mp = out rounded up to 64, zero padded
     const uint4* wbf[MLP_MAX_LAYERS];    // bf16 mode operands [OT][IT][64] x (4 bf16 hi | 4 bf16 lo), k = 16*it + 4*(lane>>4) + r
     float* traj;              // optional [H][A][Nst][S]: the state after every step (a user reward function scores them afterwards)
+    float* state_copy;        // optional [A][S] (k_rollout_mlp_q4r): r.state is the pinned host buffer of this control step, workgroup 0 of
+                              // an agent's row stores the state here for the later launches and the tail
 };
 
 // tanh on the hardware exp/rcp units: sign(x) * (1 - 2 / (2^{c|x|} + 1)), c = 2 log2(e): six instructions

@@ -337,6 +337,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
 
     // ---- the small results: constants to LDS; the action block (mlp_fill_actions' arithmetic, every thread clipping its
     // own elements; xa is scratch for the squared clip distances, summed per (particle, u) in step order below)
+    if (q.state_copy && blockIdx.x == 0 && tid < S) q.state_copy[a * S + tid] = c_st;
     if (tid < S + U) {
         nmean[tid] = normd ? c_mu : 0.0f;
         ninv[tid] = normd ? 1.0f / (c_sd + 1e-7f) : 1.0f;

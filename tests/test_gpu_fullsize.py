@@ -368,3 +368,26 @@ def test_large_population_beyond_one_lds_default(L, monkeypatch, opt_name):
     with pytest.raises(L.BBMPCError):          # above 32768 a population is played as equal shards (test_gpu_popshard.py): 32771 is prime
         Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=1, planning_horizon=4,
                population_size=32771, max_iterations=1, num_elite=8)
+
+
+@pytest.mark.parametrize("N,A", [(1000, 1), (500, 2)])
+def test_pi2_control_step_without_the_opening_launch(L, monkeypatch, N, A):
+    # North-star target 2 (PI2 on the learned model, H=30): from the second control step on k_dist_init is skipped -- the
+    # first rollout samples around prev_mean and reads the state from the pinned buffer, its workgroup 0 stores it for the
+    # later launches (BBMPC_PI2_SKIP_INIT, default on).  A closed loop is bit-identical to the one with the launch.
+    H, iters = 30, 5
+    out = {}
+    for skip in ("0", "1"):
+        monkeypatch.setenv("BBMPC_PI2_SKIP_INIT", skip)
+        eng, _ = _cheetah(L, L.OPT_PI2, N, A, H, iters, lamda=1.0, seed=9)
+        states = O.cheetah_start_states(A, 20)
+        rec = []
+        for step in range(4):
+            act, nxt, rew = eng.optimize(states)
+            rec.append((act.copy(), nxt.copy(), rew.copy(), eng.get_state("mean", (A * H * 6,)).copy()))
+            states = nxt
+        out[skip] = rec
+    for r0, r1 in zip(out["0"], out["1"]):
+        for x0, x1 in zip(r0, r1):
+            np.testing.assert_array_equal(x0, x1)
+    assert np.all(np.isfinite(out["1"][-1][0]))
