@@ -181,7 +181,11 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
         const bool eigh = cma_use_eigh();
         const unsigned* need = eigh ? e_flags.p : nullptr;      // the Jacobi below then runs only for instances the direct solver gave up
         if (eigh) cma_eigh_launch(q);
-        if (n <= 512 && !sw.cma_svd_v1) {
+        if (cma_use_eigh_small()) {
+            // one workgroup per instance: direct solver, the Jacobi only for an instance it refuses (kernels_eigh_small.hpp)
+            hipLaunchKernelGGL(k_cma_factor_small, dim3(G), dim3(1024), (size_t)n * n * sizeof(float), stream, q, c_evec.p, c_eval.p, c_info.p,
+                               sw.cma_eigh_fail ? 1 : 0);
+        } else if (n <= 512 && !sw.cma_svd_v1) {
             // warm-started Jacobi, one 1024-thread workgroup per instance (kernels_cma.hpp)
             HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * CMA_SYNC_WORDS * sizeof(unsigned), stream));
             if (n > 128 && (n & 3) == 0) hipLaunchKernelGGL(k_cma_warm_mfma, dim3((n + 31) / 32, (n + 63) / 64, G), dim3(256), 0, stream, q, c_evec.p, need);
@@ -316,6 +320,7 @@ void Engine::optimize_fused_cma(const float* d_state_in, int add_noise, float* d
     fa.inj = injected(BBMPC_NOISE_NORMAL);
     fa.inj_stride = (size_t)A * HU * Nst;
     fa.evec = c_evec.p; fa.eval = c_eval.p; fa.info = c_info.p;
+    fa.eigh_small = cma_use_eigh_small() ? 1 : 0; fa.eigh_fail = sw.cma_eigh_fail ? 1 : 0;
     FinalArgs& fin = fa.fin;
     fin.A = A; fin.U = U; fin.S = S;
     fin.agent_offset = cfg.agent_offset;
@@ -336,6 +341,10 @@ void Engine::optimize_fused_cma(const float* d_state_in, int add_noise, float* d
     }
     const int kp = (k + 3) & ~3;
     const size_t lds = std::max((size_t)(Nst + TOPK_HIST_WORDS + 2 * kp) * 4, (size_t)cma_n * cma_n * 4);
+    // (the factorisation's workspace is static LDS: with the dynamic part the kernel is past the 64 KB default)
+    ensure_max_lds((const void*)k_fused_cma_pendulum<true>, 32 * 1024);
+    ensure_max_lds((const void*)k_fused_cma_pendulum<false>, 32 * 1024);
+    REQUIRE(lds <= 32 * 1024, BBMPC_E_UNSUPPORTED, "fused CMA-ES control step: population too large for the workgroup's LDS");
     prof_begin();
     if (!fix(BBMPC_STRICT_MATH)) launch_with_tail(*this, k_fused_cma_pendulum<true>, dim3(cma_G), dim3(1024), lds, fa);
     else launch_with_tail(*this, k_fused_cma_pendulum<false>, dim3(cma_G), dim3(1024), lds, fa);

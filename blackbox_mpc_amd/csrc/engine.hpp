@@ -18,6 +18,7 @@
 #include "comm.hpp"
 #include "kernels_cma.hpp"
 #include "kernels_eigh.hpp"
+#include "kernels_eigh_small.hpp"
 #include "kernels_fused.hpp"
 #include "kernels_fused_cma.hpp"
 #include "kernels_fused_pso.hpp"
@@ -136,6 +137,8 @@ struct Engine {
     // direct eigensolver scratch (kernels_eigh.hpp): tridiagonal, reflectors, eigenvectors in the tridiagonal basis, flags
     DevBuf<float> e_d, e_e, e_tau, e_Vt, e_alpha, e_lam, e_Z, e_Z2, e_P, e_Tf;
     DevBuf<unsigned> e_flags;
+    // the one-workgroup direct solver of kernels_eigh_small.hpp
+    bool cma_use_eigh_small() const { return sw.cma_eigh && cma_n >= 2 && cma_n <= ES_N && !sw.cma_svd_v1 && !sw.cma_svd_rounds && !sw.cma_svd_general && !sw.cma_svd_gram; }
     bool cma_use_eigh() const { return sw.cma_eigh && cma_n > 128 && cma_n <= EIGH_MAX_N && (cma_n & 3) == 0 && !sw.cma_svd_v1 && !sw.cma_svd_rounds && !sw.cma_svd_general && !sw.cma_svd_gram; }
     void cma_eigh_launch(const CmaArgs& q);
     // evaluate() scratch (grown on demand)

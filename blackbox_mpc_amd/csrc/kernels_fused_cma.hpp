@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels_cma.hpp"
+#include "kernels_eigh_small.hpp"
 #include "kernels_opt.hpp"
 #include "kernels_refit.hpp"
 #include "kernels_rollout.hpp"
@@ -31,6 +32,7 @@ struct FusedCmaArgs {
     unsigned* done_flag;       // publish_records_done or null
     unsigned* done_count;
     unsigned done_value;
+    int eigh_small, eigh_fail; // Engine::cma_use_eigh_small(), BBMPC_CMA_EIGH_FAIL
 };
 
 template <bool FASTM>
@@ -42,6 +44,12 @@ __global__ __launch_bounds__(1024) void k_fused_cma_pendulum(FusedCmaArgs f) {
     const size_t off = (size_t)g * n, nn = (size_t)n * n;
     const int ga = p.agent_offset + g;                       // global agent id of this instance (agents_per_group == 1)
     const float lo0 = f.fin.lo[0], hi0 = f.fin.hi[0];
+#ifdef BBMPC_KERNEL_DBG
+    long long fc_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fc_t0 = (long long)wall_clock64();
+#define FCMA_MARK(i) do { __syncthreads(); const long long now_ = (long long)wall_clock64(); fc_acc[i] += now_ - fc_t0; fc_t0 = now_; } while (0)
+#else
+#define FCMA_MARK(i) do {} while (0)
+#endif
     for (int it = 0; it < f.iters; ++it) {
         p.iter = (uint32_t)it;
         p.inj = f.inj ? f.inj + f.inj_stride * it : nullptr;
@@ -68,6 +76,7 @@ __global__ __launch_bounds__(1024) void k_fused_cma_pendulum(FusedCmaArgs f) {
         }
         for (int i = tid; i < (int)nn; i += nthr) fsm[i] = p.B[(size_t)g * nn + i] * p.Dd[off + i % n];
         __syncthreads();
+        FCMA_MARK(0);
         // ---- y = z (B D), samples = m + sigma * y  (k_cma_gemm_y: one fmaf chain over l per element)    :140-141
         // thread = (block of rows i, particle q); five chains share each z load, B D is read from LDS (broadcast)
         {
@@ -95,6 +104,7 @@ __global__ __launch_bounds__(1024) void k_fused_cma_pendulum(FusedCmaArgs f) {
             }
         }
         __syncthreads();
+        FCMA_MARK(1);
         // ---- rollouts: clip + penalty, H pendulum steps  (k_rollout_pendulum<SRC_BUF, PEN>)              :147-157
         for (int q = tid; q < N; q += nthr) {
             Roller<FASTM> roll(f.fin.fix_q1 != 0, f.fin.state[g * 3 + 0], f.fin.state[g * 3 + 1], f.fin.state[g * 3 + 2]);
@@ -123,10 +133,13 @@ __global__ __launch_bounds__(1024) void k_fused_cma_pendulum(FusedCmaArgs f) {
             const_cast<float*>(p.rewards)[(size_t)g * Nst + q] = total;
         }
         __syncthreads();
+        FCMA_MARK(2);
         cma_select_body(p, g, fsm);                                                                      // :158-159
         __syncthreads();
+        FCMA_MARK(3);
         cma_paths_body(p, g);                                                                            // :161-177
         __syncthreads();
+        FCMA_MARK(4);
         // ---- covariance on the upper triangle, mirrored  (k_cma_cov)                                    :179-190
         {
             const float* Ye = p.Ye + (size_t)g * p.k * n;
@@ -143,25 +156,26 @@ __global__ __launch_bounds__(1024) void k_fused_cma_pendulum(FusedCmaArgs f) {
             }
         }
         __syncthreads();
-        // ---- warm start: At[j][:] = C B0[:, j]  (k_cma_warm: fmaf chain over k)
-        {
-            const float* C = p.C + (size_t)g * nn;
-            const float* B = p.B + (size_t)g * nn;
-            float* At = f.evec + (size_t)g * nn;
-            for (int idx = tid; idx < (int)nn; idx += nthr) {
-                const int j = idx / n, e = idx - j * n;
-                float acc = 0.0f;
-                for (int kk = 0; kk < n; ++kk) acc = fmaf(C[(size_t)kk * n + e], B[(size_t)kk * n + j], acc);
-                At[(size_t)j * n + e] = acc;
-            }
+        FCMA_MARK(5);
+        // ---- B, D from C: the direct solver (kernels_eigh_small.hpp) or warm start + Jacobi + finish            :195-206
+        if (f.eigh_small) {
+            cma_factor_small_body(p, g, f.evec, f.eval, f.info, f.eigh_fail != 0, fsm);
+        } else {
+            cma_warm_small_body(p, g, f.evec);
+            __syncthreads();
+            cma_svd_small_body<4>(p, g, f.evec, 15, fsm);
+            __syncthreads();
+            cma_svd_finish_body(p, g, f.evec, f.eval, f.info);
         }
         __syncthreads();
-        cma_svd_small_body<4>(p, g, f.evec, 15, fsm);                                                    // :195 s, U, _ = svd(C)
-        __syncthreads();
-        cma_svd_finish_body(p, g, f.evec, f.eval, f.info);                                               // :196-206
-        __syncthreads();
+        FCMA_MARK(8);
     }
     // ---- action = m[:, 0] (:211-212); exploration noise, predicted next state + reward (optimizer_base.py:82-94)
+#ifdef BBMPC_KERNEL_DBG
+    if (g == 0 && tid == 0)
+        printf("[fcma] n=%d N=%d k=%d iters=%d | noise+BD %lld  gemm_y %lld  rollout %lld  select %lld  paths %lld  cov %lld  factor %lld (10 ns units, all iterations)\n",
+               n, N, p.k, f.iters, fc_acc[0], fc_acc[1], fc_acc[2], fc_acc[3], fc_acc[4], fc_acc[5], fc_acc[8]);
+#endif
     if (tid == 0) {
         finalize_pendulum_agent(f.fin, g, p.m[off]);
         publish_records_done(f.done_flag, f.done_count, f.done_value, gridDim.x);
