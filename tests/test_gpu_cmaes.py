@@ -267,3 +267,43 @@ def test_direct_eigensolver_failure_hands_over_to_the_jacobi(L, monkeypatch):
             st = eng.get_trace(it, L.TRACE_CMA_SVD_STATS)
             assert np.all(st[:, 15] == 1) and np.all(st[:, 0] > 0), (step, it, st)
         assert _check_factorisation(eng, L, A, n, iters, 5e-5) <= 5e-5
+
+
+def _small_cma_invariants(eng, G, n, atol):
+    worst = 0.0
+    for g in range(G):
+        B = eng.get_state("B", (G, n, n))[g].astype(np.float64)
+        C = eng.get_state("C", (G, n, n))[g].astype(np.float64)
+        D = eng.get_state("D", (G * n,))[g * n:(g + 1) * n].astype(np.float64)
+        assert np.all(np.isfinite(B)) and np.all(D > 0)
+        assert np.all(np.diff(D) <= 0), "D must be sorted descending (tf.linalg.svd order)"
+        worst = max(worst, np.abs(B @ np.diag(D ** 2) @ B.T - C).max(), np.abs(B.T @ B - np.eye(n)).max())
+        np.testing.assert_allclose(D ** 2, np.linalg.eigvalsh(C)[::-1], rtol=0, atol=atol)
+    return worst
+
+
+@pytest.mark.parametrize("H,A,per_agent", [(2, 1, False), (3, 1, False), (7, 1, False), (30, 1, False), (31, 1, False),
+                                           (32, 1, False), (16, 2, False), (10, 3, True)])
+def test_small_direct_eigensolver_sizes(L, H, A, per_agent):
+    # n = A*H <= 32 (per-agent mode: n = H, one instance per agent): the one-workgroup direct solver of
+    # csrc/kernels_eigh_small.hpp.  Closed loop, so both the split tridiagonals of the first iterations (C = I, then
+    # I + low rank) and the full ones later are decomposed; invariants to 5e-6 (the Jacobi's own threshold is 9e-6).
+    N, k, iters = 128, 16, 3
+    eng = _engine(L, A, H, N, iters, k, seed=5, **({"quirks": L.CMAES_PER_AGENT} if per_agent else {}))
+    G, n = (A, H) if per_agent else (1, A * H)
+    states = O.pendulum_start_states(A)
+    for step in range(5):
+        act, states, rew = eng.optimize(states)
+        assert np.all(np.isfinite(act))
+        assert _small_cma_invariants(eng, G, n, 5e-6) <= 5e-6
+
+
+def test_small_direct_eigensolver_failure_hands_over_to_the_jacobi(L, monkeypatch):
+    # BBMPC_CMA_EIGH_FAIL: the solver refuses every instance -> the same kernel runs warm start + Jacobi + finish as before
+    monkeypatch.setenv("BBMPC_CMA_EIGH_FAIL", "1")
+    N, A, H, k, iters = 128, 1, 30, 16, 3
+    eng = _engine(L, A, H, N, iters, k, seed=5)
+    states = O.pendulum_start_states(A)
+    for step in range(3):
+        act, states, rew = eng.optimize(states)
+        assert _small_cma_invariants(eng, 1, A * H, 5e-5) <= 5e-5
