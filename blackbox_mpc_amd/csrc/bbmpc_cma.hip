@@ -87,6 +87,7 @@ CmaArgs Engine::cma_args(uint32_t step, uint32_t iter) {
     q.c = cma_c;
     q.weights = c_w.p;
     q.m = c_m.p; q.sigma = c_sigma.p; q.C = c_C.p; q.B = c_B.p; q.Dd = c_Dd.p; q.p_sigma = c_ps.p; q.p_C = c_pc.p;
+    q.lo = d_lo.p; q.hi = d_hi.p; q.U = U;
     q.BD = c_BD.p; q.z = c_z.p; q.cand = d_cand_a.p; q.rewards = d_rewards.p; q.eidx = c_eidx.p; q.Ye = c_Ye.p;
     q.xmean = c_xm.p; q.ymean = c_ym.p;
     q.key = key(step);
@@ -140,7 +141,11 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             if (n > 128 && (n & 3) == 0) hipLaunchKernelGGL(k_cma_gemm_y_mfma, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
             else hipLaunchKernelGGL(k_cma_gemm_y, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
             HIP_CHECK(hipGetLastError());
-            ra.cand = d_cand_a.p; ra.samples = d_cand_a.p; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
+            // the clipped candidates go back to the buffer only where somebody reads them whole (the parity trace, the sharded
+            // selection, user functions): the path update clips the k elites it reads itself, and the write-back is 9.6 MB of
+            // strided stores per launch at config 5's shape
+            const bool write_back = trace_on || pop_sharded() || user_path();
+            ra.cand = d_cand_a.p; ra.samples = write_back ? d_cand_a.p : nullptr; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
             launch_rollout(SRC_BUF, true, ra);                          // clip + penalty (cma_es.py:147-157)
             hipLaunchKernelGGL(k_cma_select, dim3(G), dim3(REFIT_THREADS), lds, stream, q, part);
             HIP_CHECK(hipGetLastError());

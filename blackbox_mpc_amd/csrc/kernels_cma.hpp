@@ -46,6 +46,9 @@ struct CmaArgs {
     uint32_t iter;
     const float* inj;        // injected z (internal layout) or null
     int pop_offset;          // global index of local particle 0 (population sharding): draws keyed by the GLOBAL particle
+    const float* lo;         // [U] action bounds: the elites are clipped where they are read (samples_feasible, cma_es.py:144-145) -- the
+    const float* hi;         // rollout does not have to write the clipped candidates back (clipping twice changes nothing)
+    int U;
 };
 
 // z ~ N(0,1): element j of a 4-block uses Box-Muller on word pairs (w0,w1)->(z0,z1), (w2,w3)->(z2,z3)
@@ -259,11 +262,14 @@ __device__ __forceinline__ void cma_paths_body(const CmaArgs& p, int g) {
     // x_diff, x_mean, y_mean, Ye
     for (int c = tid; c < n; c += nthr) {
         const float mc = p.m[off + c], sc = p.sigma[off + c];
+        const float lo_c = p.lo[c % p.U], hi_c = p.hi[c % p.U];     // solution layout [agents][H][U]
         float xm = 0.0f;
         for (int i0 = 0; i0 < p.k; i0 += 8) {
             float xv[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) xv[q] = (i0 + q < p.k) ? X[(size_t)c * p.Nst + s_el[i0 + q]] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xv[q] = clipf(xv[q], lo_c, hi_c);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if (i0 + q < p.k) {
