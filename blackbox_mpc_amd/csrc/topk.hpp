@@ -243,24 +243,47 @@ __device__ __forceinline__ void block_topk_finish_sorted(const float* vals, int 
     // ---- compaction of the winners (any order); `top` low bits may be undecided after an early exit
     const uint32_t Tp = (top >= 32) ? 0u : (T >> top);
     for (int e = tid; e < k; e += nthr) eidx[e] = 0;             // rank counters for the next phase
-    for (int n = tid; n < N; n += nthr) {
-        const uint32_t key = reward_key(vals[n]);
-        const uint32_t kp_ = (top >= 32) ? 0u : (key >> top);
-        bool take = kp_ < Tp;
-        if (kp_ == Tp) {
-            if (eq_total == remaining) take = true;              // the whole boundary bucket is in
-            else {                                               // top == 0 here: exact ties, lowest indices win
-                uint32_t before = 0;
-                for (int m = 0; m < n; ++m) before += (reward_key(vals[m]) == T) ? 1u : 0u;
-                take = before < remaining;
+    if (eq_total == remaining) {                                 // the whole boundary bucket is in (the usual case)
+        for (int n = tid; n < N; n += nthr) {
+            const uint32_t key = reward_key(vals[n]);
+            const uint32_t kp_ = (top >= 32) ? 0u : (key >> top);
+            if (kp_ <= Tp) {
+                const uint32_t slot = atomicAdd(&ctrl[3], 1u);
+                ekeys[slot] = ((unsigned long long)key << 32) | (uint32_t)n;
             }
         }
-        if (take) {
-            const uint32_t slot = atomicAdd(&ctrl[3], 1u);
-            ekeys[slot] = ((unsigned long long)key << 32) | (uint32_t)n;
+        __syncthreads();
+    } else {
+        // top == 0 here: more keys EQUAL the k-th one than are wanted, the lowest indices win.  The number of equal keys
+        // ahead of element n comes from a ballot / prefix count per wave and the waves' totals (one barrier per round of
+        // nthr elements) -- counting them one by one per element was 25-30 us when a hundred candidates tie, which is the
+        // steady state of CMA-ES on the pendulum: its step size is never reset (cma_es.py:215-227 restores m and sigma at
+        // an episode's start only), after 40 control steps sigma is 2e-5 and the 500 rewards take ten distinct values
+        // (profiles/NOTES_r4.md)
+        const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+        uint32_t* wtot = hist;                                   // [2][16] wave totals, double buffered per round
+        uint32_t base = 0;
+        int round = 0;
+        for (int n0 = 0; n0 < N; n0 += nthr, ++round) {
+            const int n = n0 + tid;
+            const uint32_t key = n < N ? reward_key(vals[n]) : 0xFFFFFFFFu;
+            const bool tie = n < N && key == T;
+            const unsigned long long bal = __ballot(tie);
+            const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            uint32_t* wt = wtot + (round & 1) * 16;
+            if (lane == 0) wt[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t ahead = base, tot = 0;
+            for (int w = 0; w < nw; ++w) { const uint32_t c = wt[w]; ahead += (w < wave) ? c : 0u; tot += c; }
+            const bool take = n < N && (key < T || (tie && ahead + pre < remaining));
+            if (take) {
+                const uint32_t slot = atomicAdd(&ctrl[3], 1u);
+                ekeys[slot] = ((unsigned long long)key << 32) | (uint32_t)n;
+            }
+            base += tot;
         }
+        __syncthreads();
     }
-    __syncthreads();
     // ---- rank the k winners among themselves with the whole workgroup: thread (e, chunk) counts how many
     // winners in its chunk precede winner e, partial counts meet in LDS (eidx doubles as the counter array).
     const int kp64 = (k + 63) & ~63;                 // e runs over full waves so chunk ids are wave-uniform
