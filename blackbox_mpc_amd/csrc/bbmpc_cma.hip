@@ -131,9 +131,23 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
     for (int it = 0; it < iters; ++it) {
         CmaArgs q = cma_args(step, (uint32_t)it);
         q.inj = inj_n ? inj_n + inj_stride * it : nullptr;
-        hipLaunchKernelGGL(k_cma_bd, dim3((unsigned)((gnn + 255) / 256)), dim3(256), 0, stream, q);
         const int kp = (k + 3) & ~3;
         const size_t lds = (size_t)(Nst + TOPK_HIST_WORDS + 2 * kp) * 4;
+        const bool small3 = sw.cma_small3 && cma_use_eigh_small() && !pop_sharded();
+        if (small3) {
+            // n <= 32: sample | roll out | update, three launches per iteration (kernels_eigh_small.hpp)
+            hipLaunchKernelGGL(k_cma_sample_small, dim3((N + 63) / 64, G), dim3(256), 0, stream, q);
+            const bool write_back = trace_on || user_path();
+            ra.cand = d_cand_a.p; ra.samples = write_back ? d_cand_a.p : nullptr; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
+            launch_rollout(SRC_BUF, true, ra);                          // clip + penalty (cma_es.py:147-157)
+            // (the elite deviations, k x n floats, go through LDS for the covariance sums when they fit beside the static words)
+            const size_t yef = (size_t)(n * n + k * n + 2 * n) * sizeof(float) <= 48 * 1024 ? (size_t)(n * n + k * n + 2 * n) : 0;
+            const size_t ulds = std::max(std::max(lds, (size_t)n * n * sizeof(float)), yef * sizeof(float));
+            want_lds((const void*)k_cma_update_small, ulds, 48 * 1024);
+            hipLaunchKernelGGL(k_cma_update_small, dim3(G), dim3(1024), ulds, stream, q, c_evec.p, c_eval.p, c_info.p, sw.cma_eigh_fail ? 1 : 0, (int)yef);
+            HIP_CHECK(hipGetLastError());
+        } else {
+        hipLaunchKernelGGL(k_cma_bd, dim3((unsigned)((gnn + 255) / 256)), dim3(256), 0, stream, q);
         want_lds((const void*)k_cma_select, lds, 4096 + 512);       // eidx_s[1024] + the selection's small static words
         // sample -> roll out -> sorted top-k of this handle's particles (part != null: sharded population)
         auto shard_pass = [&](float* part) {
@@ -274,6 +288,7 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             hipLaunchKernelGGL(k_cma_svd, dim3(G), dim3(REFIT_THREADS), 0, stream, q, c_evec.p, c_eval.p, c_info.p, 15);
         }
         HIP_CHECK(hipGetLastError());
+        }   // !small3
         if (trace_on) {
             ensure_trace();
             const size_t nr = (size_t)A * Nst, nm = (size_t)A * HU, ns = (size_t)A * HU * Nst;
@@ -297,7 +312,7 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                 // rotation counts of the sweeps ([G][CMA_SYNC_WORDS] words -> [G][16]); word 15: did the Jacobi run for the instance
                 HIP_CHECK(hipMemcpy2DAsync(t_cma_stats.p + (size_t)G * 16 * it, 16 * sizeof(int), c_sync.p + CMA_SYNC_ROTATIONS,
                                            CMA_SYNC_WORDS * sizeof(unsigned), 15 * sizeof(int), G, hipMemcpyDeviceToDevice, stream));
-                if (eigh) HIP_CHECK(hipMemcpy2DAsync(t_cma_stats.p + (size_t)G * 16 * it + 15, 16 * sizeof(int), e_flags.p, 8 * sizeof(unsigned),
+                if (cma_use_eigh()) HIP_CHECK(hipMemcpy2DAsync(t_cma_stats.p + (size_t)G * 16 * it + 15, 16 * sizeof(int), e_flags.p, 8 * sizeof(unsigned),
                                                      sizeof(int), G, hipMemcpyDeviceToDevice, stream));
                 else HIP_CHECK(hipMemcpy2DAsync(t_cma_stats.p + (size_t)G * 16 * it + 15, 16 * sizeof(int), c_sync.p + 1, CMA_SYNC_WORDS * sizeof(unsigned),
                                                 sizeof(int), G, hipMemcpyDeviceToDevice, stream));

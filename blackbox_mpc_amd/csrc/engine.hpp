@@ -99,6 +99,7 @@ struct Engine {
         int mlp_bf16 = 0;              // BBMPC_MLP_BF16: 0 off (default, fp32), 1 plain bf16 inputs, 3 split bf16 (hi+lo, three products)
         int mlp_pair = -1, mlp_q4 = -1;   // BBMPC_MLP_PAIR / BBMPC_MLP_Q4: -1 automatic, 0 / 1 forced
         int mlp_q4r = 1;                  // BBMPC_MLP_Q4R=0: keep k_rollout_mlp_q4 where k_rollout_mlp_q4r would run
+        int cma_small3 = 1;               // BBMPC_CMA_SMALL3=0: n <= 32 keeps one launch per phase (eleven per iteration) instead of sample | roll out | update
         int pi2_skip_init = 1;            // BBMPC_PI2_SKIP_INIT=0: k_dist_init opens every PI2 control step on the learned-model path too
         int refit_wgs = 0;                // BBMPC_REFIT_WGS=n: workgroups per agent in k_refit_cem_v2 (0 = by problem size)
         int mlp_wave = 1;                 // BBMPC_MLP_WAVE=0: never the one-wave-per-tile kernel for small networks

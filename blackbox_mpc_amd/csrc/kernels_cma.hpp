@@ -246,7 +246,11 @@ static __global__ __launch_bounds__(1024) void k_cma_merge(CmaArgs p, const floa
 
 // per group: elite deviations, weighted mean step, evolution paths, step size, new mean
 // (cma_es.py:161-177).  One workgroup per group; threads stride the n coordinates.
-__device__ __forceinline__ void cma_paths_body(const CmaArgs& p, int g) {
+// STAGE (small instances, one launch for the whole update): B, the k elite columns and the two intermediate vectors live in
+// `stage` (n*n + k*n + 2n floats of LDS) -- every dependent access is then an LDS access instead of an L2 round trip (the
+// chain of ~15 round trips is what the stand-alone kernel's 11-12 us at n = 30 consist of); same sums in the same order.
+template <bool STAGE>
+__device__ __forceinline__ void cma_paths_body_t(const CmaArgs& p, int g, float* stage) {
     // blockDim: any multiple of 64 up to 1024.  The loops keep several independent loads in flight and the row-wise
     // product runs one wave per row (coalesced), instead of one L2 latency per term of an n-term sum.
     __shared__ float red[16];
@@ -258,7 +262,17 @@ __device__ __forceinline__ void cma_paths_body(const CmaArgs& p, int g) {
     const float* __restrict__ X = p.cand + off * p.Nst;
     float* __restrict__ Ye = p.Ye + (size_t)g * p.k * n;
     for (int i = tid; i < p.k; i += nthr) { s_el[i] = p.eidx[g * p.k + i]; s_w[i] = p.weights[i]; }
+    float* lB = stage;
+    float* xe = stage + (STAGE ? n * n : 0);
+    float* lym = xe + (STAGE ? p.k * n : 0);
+    float* lt2 = lym + (STAGE ? n : 0);
+    if (STAGE)
+        for (int i = tid; i < n * n; i += nthr) lB[i] = p.B[(size_t)g * n * n + i];
     __syncthreads();
+    if (STAGE) {
+        for (int i = tid; i < p.k * n; i += nthr) { const int e = i / n, c = i - e * n; xe[i] = X[(size_t)c * p.Nst + s_el[e]]; }
+        __syncthreads();
+    }
     // x_diff, x_mean, y_mean, Ye
     for (int c = tid; c < n; c += nthr) {
         const float mc = p.m[off + c], sc = p.sigma[off + c];
@@ -267,7 +281,7 @@ __device__ __forceinline__ void cma_paths_body(const CmaArgs& p, int g) {
         for (int i0 = 0; i0 < p.k; i0 += 8) {
             float xv[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xv[q] = (i0 + q < p.k) ? X[(size_t)c * p.Nst + s_el[i0 + q]] : 0.0f;
+            for (int q = 0; q < 8; ++q) xv[q] = (i0 + q < p.k) ? (STAGE ? xe[(i0 + q) * n + c] : X[(size_t)c * p.Nst + s_el[i0 + q]]) : 0.0f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) xv[q] = clipf(xv[q], lo_c, hi_c);
 #pragma unroll
@@ -281,12 +295,13 @@ __device__ __forceinline__ void cma_paths_body(const CmaArgs& p, int g) {
         }
         p.xmean[off + c] = xm;
         p.ymean[off + c] = xm / sc;                                        // :167
+        if (STAGE) lym[c] = xm / sc;
     }
     __syncthreads();
     // t1 = B^T y_mean ; t2 = t1 / diag(D)   (C^{-1/2} y = B D^{-1} B^T y, :168-169)
-    float* t2 = p.BD + (size_t)g * n * n;      // BD scratch is free after the sampling GEMM
-    const float* __restrict__ B = p.B + (size_t)g * n * n;
-    const float* __restrict__ ym = p.ymean + off;
+    float* t2 = STAGE ? lt2 : p.BD + (size_t)g * n * n;      // BD scratch is free after the sampling GEMM
+    const float* __restrict__ B = STAGE ? lB : p.B + (size_t)g * n * n;
+    const float* __restrict__ ym = STAGE ? lym : p.ymean + off;
     {
         // the sum over i is split into K-slices over thread groups of ceil(n / 64) waves (as many as the workgroup holds,
         // at most 4) and combined in slice order: one thread per column walked all n terms, eight L2 trips at a time
@@ -374,6 +389,7 @@ __device__ __forceinline__ void cma_paths_body(const CmaArgs& p, int g) {
         p.m[off + c] = p.m[off + c] + p.xmean[off + c];                    // :163
     }
 }
+__device__ __forceinline__ void cma_paths_body(const CmaArgs& p, int g) { cma_paths_body_t<false>(p, g, nullptr); }
 static __global__ __launch_bounds__(1024) void k_cma_paths(CmaArgs p) { cma_paths_body(p, blockIdx.x); }
 
 // C = (1-c1-cmu) C + c1 pC pC^T + cmu sum_i w_i y_i y_i^T on the upper triangle, mirrored (cma_es.py:179-190)

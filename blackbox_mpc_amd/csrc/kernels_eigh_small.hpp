@@ -384,5 +384,111 @@ static __global__ __launch_bounds__(1024) void k_cma_factor_small(CmaArgs p, flo
     cma_factor_small_body(p, blockIdx.x, evec, eval, info, force_fail != 0, at_s);
 }
 
+// ---- Three launches per iteration for small instances (n <= 32) instead of eleven: sample | roll out | update.
+// The per-iteration kernels of kernels_cma.hpp are a few microseconds of work each behind ~4.5 us of launch (and the
+// host cannot enqueue 57 launches per control step as fast as the device retires them); the one-launch control step
+// (kernels_fused_cma.hpp) puts phases that want many workgroups on one.  Here the phases that are one workgroup per
+// instance anyway (selection, evolution paths, covariance, factorisation) share a launch, and noise + B D + the sampling
+// product share another, spread over the population.  Same device functions / same operation order as the separate
+// kernels: bit-identical control steps (tests/test_gpu_cmaes.py).
+
+// z ~ N(0, I), y = z (B D), samples = m + sigma y  (cma_es.py:139-141; k_cma_noise + k_cma_bd + k_cma_gemm_y)
+// grid (ceil(N / 64), G), block 256: 64 particles per workgroup, the four waves share the Philox blocks of the draws and
+// take eight rows of the product each.  LDS: B D (pitch 32) | z [n][64]
+static __global__ __launch_bounds__(256) void k_cma_sample_small(CmaArgs p) {
+    __shared__ __attribute__((aligned(16))) float bd[ES_N * ES_N];
+    __shared__ float zs[ES_N][64];
+    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n, Nst = p.Nst;
+    const int q = blockIdx.x * 64 + lane;
+    const size_t off = (size_t)g * n, nn = (size_t)n * n;
+    for (int i = tid; i < ES_N * ES_N; i += 256) {
+        const int l = i >> 5, c = i & 31;
+        bd[i] = (l < n && c < n) ? p.B[(size_t)g * nn + (size_t)l * n + c] * p.Dd[off + c] : 0.0f;      // k_cma_bd
+    }
+    const bool live = q < p.N;
+    if (p.inj) {
+        for (int l = wv; l < n; l += 4) zs[l][lane] = live ? p.inj[(off + l) * Nst + q] : 0.0f;
+    } else {
+        // elem_normal's draws (k_cma_noise): one Philox block gives the normals of four consecutive elements of an agent
+        const int apg = p.agents_per_group, hu = n / apg, nb = (hu + 3) >> 2;
+        for (int t = wv; t < apg * nb; t += 4) {
+            const int a = t / nb, j4 = (t - a * nb) * 4;
+            const U4 b = rng_block(p.key, 4u, p.iter, (uint32_t)(q + p.pop_offset), (uint32_t)(p.agent_offset + g * apg + a), (uint32_t)j4);
+            float z4[4];
+            words_to_normal2(b.x, b.y, z4[0], z4[1]);
+            words_to_normal2(b.z, b.w, z4[2], z4[3]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j4 + u < hu) zs[a * hu + j4 + u][lane] = z4[u];
+        }
+    }
+    __syncthreads();
+    const int i0 = 8 * wv;
+    if (!live || i0 >= n) return;
+    // one fmaf chain over l per element (k_cma_gemm_y's order), eight rows share each z load
+    float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int l = 0; l < n; ++l) {
+        const float zv = zs[l][lane];
+        const float4 b0 = *reinterpret_cast<const float4*>(&bd[l * ES_N + i0]);
+        const float4 b1 = *reinterpret_cast<const float4*>(&bd[l * ES_N + i0 + 4]);
+        acc[0] = fmaf(b0.x, zv, acc[0]); acc[1] = fmaf(b0.y, zv, acc[1]); acc[2] = fmaf(b0.z, zv, acc[2]); acc[3] = fmaf(b0.w, zv, acc[3]);
+        acc[4] = fmaf(b1.x, zv, acc[4]); acc[5] = fmaf(b1.y, zv, acc[5]); acc[6] = fmaf(b1.z, zv, acc[6]); acc[7] = fmaf(b1.w, zv, acc[7]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (i0 + u < n) p.cand[(off + i0 + u) * Nst + q] = p.m[off + i0 + u] + p.sigma[off + i0 + u] * acc[u];
+}
+
+// covariance on the upper triangle, mirrored (k_cma_cov's sums), by one workgroup.  ye: k * n floats of LDS when the elite
+// deviations fit there (one round trip for all of them instead of two loads per term of every sum), or null
+__device__ __forceinline__ void cma_cov_small_body(const CmaArgs& p, int g, float* ye = nullptr) {
+    const int n = p.n, nn = n * n;
+    const size_t off = (size_t)g * n;
+    const float* Ye = p.Ye + (size_t)g * p.k * n;
+    float* C = p.C + off * n;
+    if (ye) {
+        for (int i = threadIdx.x; i < p.k * n; i += blockDim.x) ye[i] = Ye[i];
+        __syncthreads();
+        Ye = ye;
+    }
+    for (int idx = threadIdx.x; idx < nn; idx += blockDim.x) {
+        const int r = idx / n, c = idx - r * n;
+        if (r > c) continue;
+        float ys = 0.0f;
+        for (int i = 0; i < p.k; ++i) ys = fmaf(Ye[(size_t)i * n + r] * Ye[(size_t)i * n + c], p.weights[i], ys);
+        const float v = ((1.0f - p.c.c1) - p.c.c_mu) * C[(size_t)r * n + c] + (p.c.c1 * p.p_C[off + r]) * p.p_C[off + c] +      /* (c1 * p_C) * p_C^T as cma_es.py:183 evaluates it */
+                        p.c.c_mu * ys;
+        C[(size_t)r * n + c] = v;
+        C[(size_t)c * n + r] = v;
+    }
+}
+
+// selection, evolution paths / step size / mean, covariance, factorisation  (cma_es.py:158-206)
+// grid G, block 1024; dynamic LDS: max(selection's words, n * n floats, ye_floats [>= n*n + k*n + 2n: the path update's staging], or ye_floats = 0)
+static __global__ __launch_bounds__(1024) void k_cma_update_small(CmaArgs p, float* evec, float* eval, int* info, int force_fail, int ye_floats) {
+    extern __shared__ __attribute__((aligned(16))) float usm[];
+    const int g = blockIdx.x;
+#ifdef BBMPC_KERNEL_DBG
+    long long um[5]; um[0] = (long long)wall_clock64();
+#define UPD_MARK(i) do { um[i] = (long long)wall_clock64(); } while (0)
+#else
+#define UPD_MARK(i) do {} while (0)
+#endif
+    cma_select_body(p, g, usm);
+    __syncthreads();
+    UPD_MARK(1);
+    if (ye_floats) cma_paths_body_t<true>(p, g, usm); else cma_paths_body(p, g);
+    __syncthreads();
+    UPD_MARK(2);
+    cma_cov_small_body(p, g, (size_t)p.k * p.n <= (size_t)ye_floats ? usm : nullptr);
+    __syncthreads();
+    UPD_MARK(3);
+    cma_factor_small_body(p, g, evec, eval, info, force_fail != 0, usm);
+#ifdef BBMPC_KERNEL_DBG
+    UPD_MARK(4);
+    if (g == 0 && threadIdx.x == 0 && p.iter == 2) printf("[upd] select %lld  paths %lld  cov %lld  factor %lld (10 ns)\n", um[1] - um[0], um[2] - um[1], um[3] - um[2], um[4] - um[3]);
+#endif
+}
+
 #endif  // BBMPC_TU_CMA
 }  // namespace bbmpc

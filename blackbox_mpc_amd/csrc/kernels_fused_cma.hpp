@@ -140,21 +140,7 @@ __global__ __launch_bounds__(1024) void k_fused_cma_pendulum(FusedCmaArgs f) {
         cma_paths_body(p, g);                                                                            // :161-177
         __syncthreads();
         FCMA_MARK(4);
-        // ---- covariance on the upper triangle, mirrored  (k_cma_cov)                                    :179-190
-        {
-            const float* Ye = p.Ye + (size_t)g * p.k * n;
-            float* C = p.C + off * n;
-            for (int idx = tid; idx < (int)nn; idx += nthr) {
-                const int r = idx / n, c = idx - r * n;
-                if (r > c) continue;
-                float ys = 0.0f;
-                for (int i = 0; i < p.k; ++i) ys = fmaf(Ye[(size_t)i * n + r] * Ye[(size_t)i * n + c], p.weights[i], ys);
-                const float v = ((1.0f - p.c.c1) - p.c.c_mu) * C[(size_t)r * n + c] + (p.c.c1 * p.p_C[off + r]) * p.p_C[off + c] +      /* (c1 * p_C) * p_C^T as cma_es.py:183 evaluates it */
-                                p.c.c_mu * ys;
-                C[(size_t)r * n + c] = v;
-                C[(size_t)c * n + r] = v;
-            }
-        }
+        cma_cov_small_body(p, g);                                                                        // :179-190 (k_cma_cov)
         __syncthreads();
         FCMA_MARK(5);
         // ---- B, D from C: the direct solver (kernels_eigh_small.hpp) or warm start + Jacobi + finish            :195-206

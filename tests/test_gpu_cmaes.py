@@ -307,3 +307,25 @@ def test_small_direct_eigensolver_failure_hands_over_to_the_jacobi(L, monkeypatc
     for step in range(3):
         act, states, rew = eng.optimize(states)
         assert _small_cma_invariants(eng, 1, A * H, 5e-5) <= 5e-5
+
+
+@pytest.mark.parametrize("H,A,per_agent", [(30, 1, False), (8, 3, False), (10, 3, True)])
+def test_three_launches_per_iteration_are_bit_identical_to_eleven(L, monkeypatch, H, A, per_agent):
+    # n <= 32: sample | roll out | update (k_cma_sample_small, the rollout, k_cma_update_small; BBMPC_CMA_SMALL3, default
+    # on) against one launch per phase -- the same device functions / operation order, so a closed loop agrees bit for bit
+    N, k, iters = 200, 20, 3
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("BBMPC_CMA_SMALL3", mode)
+        eng = _engine(L, A, H, N, iters, k, seed=11, **({"quirks": L.CMAES_PER_AGENT} if per_agent else {}))
+        G, n = (A, H) if per_agent else (1, A * H)
+        states = O.pendulum_start_states(A)
+        rec = []
+        for step in range(4):
+            act, states, rew = eng.optimize(states)
+            st = _state(eng, n, G)
+            rec.append((act.copy(), states.copy(), rew.copy()) + tuple(st[name].copy() for name in sorted(st)))
+        out[mode] = rec
+    for r0, r1 in zip(out["0"], out["1"]):
+        for x0, x1 in zip(r0, r1):
+            np.testing.assert_array_equal(x0, x1)
