@@ -32,7 +32,7 @@ struct alignas(16) EighSmallLds {
     float ee[ES_N + 8];          // thresholded e (ee[k] couples k, k + 1)
     float tau[ES_N], lam[ES_N];
     float V[ES_N][ES_PV];        // reflector k in row k (read back four elements at a time, every lane the same address)
-    float xb[ES_N + 4], wb[ES_N + 4];   // the step's x and w for the same kind of read
+    float xb[ES_N + 4], wb[ES_N + 4];   // the step's x and w for the same kind of read (all three: element i at (i & 1) * 16 + (i >> 1))
     float Z[ES_N][ES_P];         // Z[i][j]: component i of the eigenvector of slot j
     float Z2[ES_N][ES_P];
     float Pm[ES_N][ES_P];        // 1.5 I - 0.5 Z^T Z
@@ -50,6 +50,11 @@ __device__ __forceinline__ float es_half_max(float v) { return -es_half_min(-v);
 // sums / minima over the wave when lanes 32..63 hold the neutral element
 __device__ __forceinline__ float es_sum32(float v) { v = row16_sum(v); return es_readlane(v, 0) + es_readlane(v, 16); }
 __device__ __forceinline__ float es_min32(float v) { v = row16_min(v); return fminf(es_readlane(v, 0), es_readlane(v, 16)); }
+// the value the lower half (lanes 0..31) / the upper half holds in the lane's column, in both halves
+__device__ __forceinline__ void es_halves(float v, float& lo, float& hi) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    lo = __int_as_float(r[0]); hi = __int_as_float(r[1]);
+}
 // 1/x to fp32 accuracy: v_rcp_f32 (1 ulp) and one Newton step
 __device__ __forceinline__ float es_rcp(float x) { const float r = __builtin_amdgcn_rcpf(x); return r * fmaf(-x, r, 2.0f); }
 
@@ -67,78 +72,95 @@ __device__ __attribute__((noinline)) bool cma_eigh_small_body(const CmaArgs& p, 
 #else
 #define ES_MARK(i) do {} while (0)
 #endif
-    // ---- 1. tridiagonalisation (wave 0)
+    // ---- 1. tridiagonalisation (wave 0): lane (h, j) = (lane >> 5, lane & 31) holds the rows of parity h of column j of
+    // E = C - alpha I, row i = 2 r + h in register r.  Vector elements needed "by row" (x_i, v_i, w_i) are read from LDS,
+    // de-interleaved by parity so that a half's sixteen are four 16-byte reads at an address the half shares; values needed
+    // "by column" are the same in both halves.  The halves meet through v_permlane32_swap (no LDS round trip).
     if (wv == 0) {
-        const bool cj = lane < n;
-        float a[ES_N];
+        const int h = lane >> 5, j = lane & 31;
+        const bool cj = j < n;
+        float a[ES_N / 2];
 #pragma unroll
-        for (int i = 0; i < ES_N; ++i) {
-            const float v = C[(size_t)min(i, n - 1) * n + min(lane, n - 1)];
-            a[i] = (cj && i < n) ? v : 0.0f;
+        for (int r = 0; r < ES_N / 2; ++r) {
+            const int i = 2 * r + h;
+            const float v = C[(size_t)min(i, n - 1) * n + min(j, n - 1)];
+            a[r] = (cj && i < n) ? v : 0.0f;
         }
         const float dj = C[(size_t)min(lane, n - 1) * (n + 1)];
-        const float alpha = es_sum32(cj ? dj : 0.0f) / (float)n;
+        const float alpha = es_sum32(lane < n ? dj : 0.0f) / (float)n;
 #pragma unroll
-        for (int i = 0; i < ES_N; ++i) a[i] = a[i] - ((i == lane && cj) ? alpha : 0.0f);
-        float dv = 0.0f, ev = 0.0f, tv = 0.0f;
+        for (int r = 0; r < ES_N / 2; ++r) a[r] = a[r] - ((2 * r + h == j && cj) ? alpha : 0.0f);
+        float* xb = L.xb;                                          // [2][16]: x_i at (i & 1) * 16 + (i >> 1), as V[k] and wb
+        const int dei = (j & 1) * 16 + (j >> 1);                   // where element j of a column-wise vector goes
 #pragma unroll
         for (int k = 0; k < ES_N; ++k) {
-            if (lane == k) dv = a[k];
+            const int hk = k & 1, rk = k >> 1;                     // row k: half hk, register rk
+            if (lane == k + 32 * hk) L.dd[k] = a[rk];
             if (k + 2 < n) {
-                // x = E[k+1.., k] (lane j holds E[k][j] = E[j][k]); the product E x does not wait for the reflector's scalars:
-                // v = scale x + (1 - scale x_{k+1}) e_{k+1}, so E v = scale (E x) + (1 - scale x_{k+1}) E[:, k+1].
-                // Vector elements are broadcast through LDS (every lane reads the same 16 bytes: four elements per
-                // instruction, into VGPRs) -- by v_readlane each element costs an instruction and a wait state before the
-                // fma that takes the SGPR
-                const float x = (lane > k) ? a[k] : 0.0f;                 // (zero on lanes >= n)
-                if (lane < ES_N) L.xb[lane] = x;
+                // x = E[k+1.., k] (= row k, by symmetry); E x does not wait for the reflector's scalars:
+                // v = scale x + (1 - scale x_{k+1}) e_{k+1}, so E v = scale (E x) + (1 - scale x_{k+1}) E[:, k+1]
+                float xlo, xhi;
+                es_halves(a[rk], xlo, xhi);
+                const float xr = hk ? xhi : xlo;                   // E[k][j] in both halves
+                const float x = (j > k) ? xr : 0.0f;               // (zero for columns >= n)
+                if (h == 0) xb[dei] = x;
                 const float ain = es_readlane(x, k + 1);
-                const float xs = (lane > k + 1) ? x : 0.0f;
+                const float xs = (j > k + 1) ? x : 0.0f;
                 const float sig = es_sum32(xs * xs);
-                const int I0 = (k + 1) & ~3;                               // (x_i = 0 for i <= k: the group may start below k + 1)
+                const int R0 = (((k + 1) >> 1) & ~3);              // first register group with a live row (rows <= k: x_i = 0)
                 float pa[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int i4 = I0; i4 < ES_N; i4 += 4) {
-                    const float4 xq = *reinterpret_cast<const float4*>(&L.xb[i4]);
-                    pa[0] = fmaf(a[i4], xq.x, pa[0]); pa[1] = fmaf(a[i4 + 1], xq.y, pa[1]);
-                    pa[2] = fmaf(a[i4 + 2], xq.z, pa[2]); pa[3] = fmaf(a[i4 + 3], xq.w, pa[3]);
+                for (int r4 = R0; r4 < ES_N / 2; r4 += 4) {
+                    const float4 xq = *reinterpret_cast<const float4*>(&xb[h * 16 + r4]);
+                    pa[0] = fmaf(a[r4], xq.x, pa[0]); pa[1] = fmaf(a[r4 + 1], xq.y, pa[1]);
+                    pa[2] = fmaf(a[r4 + 2], xq.z, pa[2]); pa[3] = fmaf(a[r4 + 3], xq.w, pa[3]);
                 }
+                float plo, phi;
+                es_halves((pa[0] + pa[1]) + (pa[2] + pa[3]), plo, phi);
+                const float ex = plo + phi;                        // (E x)_j, the same in both halves
                 float beta = ain, tauk = 0.0f, scale = 0.0f;
                 if (sig != 0.0f) {                                         // slarfg with v_sqrt / v_rcp + Newton
                     beta = -copysignf(__builtin_amdgcn_sqrtf(fmaf(ain, ain, sig)), ain);
                     tauk = (beta - ain) * es_rcp(beta);
                     scale = es_rcp(ain - beta);
                 }
-                const float v = (lane == k + 1) ? 1.0f : xs * scale;
-                if (lane == k) { ev = beta; tv = tauk; }
-                if (lane < ES_N) L.V[k][lane] = v;
+                const float v = (j == k + 1) ? 1.0f : xs * scale;
+                if (lane == 0) { L.ee[k] = beta; L.tau[k] = tauk; }
+                if (h == 0) L.V[k][dei] = v;
                 if (tauk != 0.0f) {
                     // p = tau E v, w = p - (tau/2 p.v) v, E -= v w^T + w v^T
-                    const float ex = (pa[0] + pa[1]) + (pa[2] + pa[3]);
-                    const float pj = tauk * fmaf(scale, ex, fmaf(-scale, ain, 1.0f) * a[k + 1 < ES_N ? k + 1 : k]);
+                    float clo, chi;
+                    es_halves(a[(k + 1) >> 1], clo, chi);
+                    const float ek1 = ((k + 1) & 1) ? chi : clo;           // E[k+1][j]
+                    const float pj = tauk * fmaf(scale, ex, fmaf(-scale, ain, 1.0f) * ek1);
                     const float pv = es_sum32(pj * v);
                     const float cc = 0.5f * tauk * pv;
-                    const float w = (lane > k) ? fmaf(-cc, v, pj) : 0.0f;
-                    if (lane < ES_N) L.wb[lane] = w;
+                    const float w = (j > k) ? fmaf(-cc, v, pj) : 0.0f;
+                    if (h == 0) L.wb[dei] = w;
 #pragma unroll
-                    for (int i4 = I0; i4 < ES_N; i4 += 4) {
-                        const float4 vq = *reinterpret_cast<const float4*>(&L.V[k][i4]);
-                        const float4 wq = *reinterpret_cast<const float4*>(&L.wb[i4]);
+                    for (int r4 = R0; r4 < ES_N / 2; r4 += 4) {
+                        const float4 vq = *reinterpret_cast<const float4*>(&L.V[k][h * 16 + r4]);
+                        const float4 wq = *reinterpret_cast<const float4*>(&L.wb[h * 16 + r4]);
                         // (v_i = w_i = 0 for i <= k)
-                        a[i4] = fmaf(-vq.x, w, fmaf(-wq.x, v, a[i4]));
-                        a[i4 + 1] = fmaf(-vq.y, w, fmaf(-wq.y, v, a[i4 + 1]));
-                        a[i4 + 2] = fmaf(-vq.z, w, fmaf(-wq.z, v, a[i4 + 2]));
-                        a[i4 + 3] = fmaf(-vq.w, w, fmaf(-wq.w, v, a[i4 + 3]));
+                        a[r4] = fmaf(-vq.x, w, fmaf(-wq.x, v, a[r4]));
+                        a[r4 + 1] = fmaf(-vq.y, w, fmaf(-wq.y, v, a[r4 + 1]));
+                        a[r4 + 2] = fmaf(-vq.z, w, fmaf(-wq.z, v, a[r4 + 2]));
+                        a[r4 + 3] = fmaf(-vq.w, w, fmaf(-wq.w, v, a[r4 + 3]));
                     }
                 }
             } else {
-                if (lane == k) { ev = (k + 1 < ES_N) ? a[(k + 1 < ES_N) ? k + 1 : k] : 0.0f; tv = 0.0f; }
-                if (lane < ES_N) L.V[k][lane] = 0.0f;
+                // no reflector: e_k = E[k+1][k] sits in lane (half of row k + 1, column k)
+                if (k + 1 < ES_N) { if (lane == k + 32 * ((k + 1) & 1)) L.ee[k] = a[(k + 1 < ES_N ? k + 1 : k) >> 1]; }
+                else if (lane == 0) L.ee[k] = 0.0f;
+                if (lane == 0) L.tau[k] = 0.0f;
+                if (h == 0) L.V[k][dei] = 0.0f;
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        const float dv = L.dd[j], ev = L.ee[j], tv = L.tau[j];
         ES_MARK(0);
         // ---- T (lane i: d_i, e_i): norm, split threshold, Gershgorin interval, e^2, the unreduced blocks -- from registers
-        const float di = cj ? dv : 0.0f, ei = (lane + 1 < n) ? ev : 0.0f;
+        const float di = lane < n ? dv : 0.0f, ei = (lane + 1 < n) ? ev : 0.0f;
         const float tn = -es_min32(-fmaxf(fabsf(di), fabsf(ei)));
         const float thr = 4.0f * 1.1920929e-07f * fmaxf(fabsf(alpha), tn);
         const float eth = fabsf(ei) <= thr ? 0.0f : ei;
@@ -146,7 +168,7 @@ __device__ __attribute__((noinline)) bool cma_eigh_small_body(const CmaArgs& p, 
         const float ei_up = __shfl_up(ei, 1, 64), eth_up = __shfl_up(eth, 1, 64);
         const float em = lane > 0 ? ei_up : 0.0f, ethm = lane > 0 ? eth_up : 0.0f;
         const float rad = fabsf(eth) + fabsf(em);                       // (unthresholded neighbour: only widens the interval)
-        float gl = es_min32(cj ? di - rad : 3.0e38f), gu = -es_min32(cj ? -(di + rad) : 3.0e38f);
+        float gl = es_min32(lane < n ? di - rad : 3.0e38f), gu = -es_min32(lane < n ? -(di + rad) : 3.0e38f);
         const float span = gu - gl;
         gl -= span * (2.0f * 1.1920929e-07f * (float)n) + thr;
         gu += span * (2.0f * 1.1920929e-07f * (float)n) + thr;
@@ -333,7 +355,7 @@ __device__ __attribute__((noinline)) bool cma_eigh_small_body(const CmaArgs& p, 
         const bool live = j < n;
         float z = Zf[sub][j & (ES_N - 1)];
         for (int k = n - 3; k >= 0; --k) {
-            const float v = L.V[k][sub];
+            const float v = L.V[k][(sub & 1) * 16 + (sub >> 1)];          // (stored de-interleaved by row parity)
             const float tk = L.tau[k];
             const float dot = es_half_sum(v * z);
             z = fmaf(-(tk * dot), v, z);
