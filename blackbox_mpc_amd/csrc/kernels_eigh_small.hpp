@@ -275,28 +275,30 @@ __device__ __attribute__((noinline)) bool cma_eigh_small_body(const CmaArgs& p, 
         // z_r = 1 and, from the twist outwards on the lane's own side (q < q_r), z_q = -(E_{q+1} / P_q) z_{q+1}
         const int q_r = half ? ES_N - 1 - r : r, q_lo = half ? ES_N - t : s;
         float zz = half ? 0.0f : 1.0f;                                 // sum of squares of this half's part (z_r counted by the upper half)
-        if (!half) L.Z[r][slot] = live ? 1.0f : 0.0f;
+        // the pivots come in as one batch of reads in front of the chain and the vector stays in the same registers until it
+        // is normalised: one store per row, no read-modify-write pass
+        float P[ES_N];
+#pragma unroll
+        for (int q = 0; q < ES_N - 1; ++q) P[q] = own[half ? ES_N - 1 - q : q][slot];
         {
             float z = 1.0f;
 #pragma unroll
             for (int q = ES_N - 2; q >= 0; --q) {
-                const int i = half ? ES_N - 1 - q : q;
-                const float pvt = own[i][slot];
                 const bool act = live && q < q_r && q >= q_lo;
                 if (act) {
-                    z = -(El[q + 1] * es_rcp(pvt)) * z;
+                    z = -(El[q + 1] * es_rcp(P[q])) * z;
                     zz = fmaf(z, z, zz);
                 }
-                if (q < q_r) L.Z[i][slot] = act ? z : 0.0f;           // (outside the block the vector is zero)
+                P[q] = act ? z : 0.0f;                                // (outside the block the vector is zero)
             }
         }
-        __builtin_amdgcn_wave_barrier();
         zz = zz + __shfl_xor(zz, 32, 64);
         const float rn = 1.0f / sqrtf(zz);
+        if (!half) L.Z[r][slot] = live ? rn : 0.0f;
 #pragma unroll
-        for (int q = 0; q < ES_N; ++q) {
+        for (int q = 0; q < ES_N - 1; ++q) {
             const int i = half ? ES_N - 1 - q : q;
-            if (q < q_r || (!half && q == q_r)) L.Z[i][slot] = L.Z[i][slot] * rn;
+            if (q < q_r) L.Z[i][slot] = P[q] * rn;
         }
         float res = (live && !half) ? gmin * rn : 0.0f;             // |(T - lam) z| for the normalised z
         res = -es_min32(-res);
