@@ -407,6 +407,7 @@ PsoState Engine::pso_state(int shard) {
 void Engine::reset() {
     // CEM/PI2/SPSA reset(): previous solution <- bounds midpoint (cem.py:138-149, pi2.py:98-105)
     if (cfg.optimizer == BBMPC_OPT_NONE || cfg.optimizer == BBMPC_OPT_RANDOM_SEARCH) return;
+    cem_sigma0_ready = false;                      // (prev_mean is rewritten below)
     if (cfg.optimizer == BBMPC_OPT_CMAES) {          // restores m and sigma only (cma_es.py:215-227)
         HIP_CHECK(hipStreamSynchronize(stream));
         cma_reset_mean_sigma();
@@ -953,8 +954,25 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
             break;
         }
         case BBMPC_OPT_CEM: {
-            hipLaunchKernelGGL(k_dist_init, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, HU, U, d_lo.p, d_hi.p,
-                               d_prev_mean.p, d_var0.p, d_mean.p, d_var.p, d_sigma.p, 1, stage_state_src, d_state.p, A * S);
+            // Learned model on the quad kernel, the reference's restart from the constructor distribution every control step
+            // (no BBMPC_FIX_Q2_CEM_WARM_START): prev_mean, var0 and the sigma they give are constants, so from the second
+            // control step on k_dist_init is skipped as for PI2 below -- the first rollout samples from (prev_mean, sigma0)
+            // and reads the state from the pinned buffer, the first refit smooths against (prev_mean, var0)
+            const bool cem_skip = sw.pi2_skip_init && cfg.dynamics == BBMPC_DYN_MLP && !user_path() && !pop_sharded() && !trace_on &&
+                                  iters >= 1 && k <= 64 && !sw.refit_v1 && !fix(BBMPC_FIX_Q2_CEM_WARM_START) && cem_sigma0_ready &&
+                                  pi2_copy_seen && stage_state_src != nullptr;
+            const float* cem_pinned = nullptr;
+            if (cem_skip) {
+                cem_pinned = stage_state_src;
+            } else {
+                hipLaunchKernelGGL(k_dist_init, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, HU, U, d_lo.p, d_hi.p,
+                                   d_prev_mean.p, d_var0.p, d_mean.p, d_var.p, d_sigma.p, 1, stage_state_src, d_state.p, A * S);
+                if (!cem_sigma0_ready && !fix(BBMPC_FIX_Q2_CEM_WARM_START)) {
+                    d_sigma0.alloc(nelem);
+                    HIP_CHECK(hipMemcpyAsync(d_sigma0.p, d_sigma.p, (size_t)nelem * 4, hipMemcpyDeviceToDevice, stream));
+                    cem_sigma0_ready = true;
+                }
+            }
             stage_state_src = nullptr;
             // iters == 0: action = mean[:,0] of the untouched distribution (otherwise the last refit writes it)
             if (iters == 0)
@@ -1009,11 +1027,28 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                     capture_trace(it);
                     continue;
                 }
-                launch_rollout(SRC_TRUNC, false, ra);
+                bool first_from_constants = false;
+                if (it == 0 && cfg.dynamics == BBMPC_DYN_MLP && !user_path()) {
+                    if (cem_skip) { ra.mean = d_prev_mean.p; ra.sigma = d_sigma0.p; ra.state = cem_pinned; }
+                    mlp_state_copy = d_state.p;                        // (without the skip: only asks whether the kernel would take it)
+                    launch_rollout(SRC_TRUNC, false, ra);
+                    const bool took = mlp_state_copy == nullptr;
+                    mlp_state_copy = nullptr;
+                    pi2_copy_seen = took;
+                    if (cem_skip) {
+                        if (!took)                                       // a shape the quad kernel refused after all: nobody stored the state
+                            HIP_CHECK(hipMemcpyAsync(d_state.p, cem_pinned, (size_t)A * S * 4, hipMemcpyDefault, stream));
+                        ra.mean = d_mean.p; ra.sigma = d_sigma.p; ra.state = d_state_in;
+                        first_from_constants = true;
+                    }
+                } else {
+                    launch_rollout(SRC_TRUNC, false, ra);
+                }
                 if (k <= 64 && !sw.refit_v1) {
                     const int rthreads = N > 512 ? 1024 : (N > 256 ? 512 : 256);
                     RefitArgs rf2 = rf;
                     if (!trace_on) rf2.elites = nullptr;          // the sorted elite list is only needed by the parity trace
+                    if (first_from_constants) { rf2.mean_in = d_prev_mean.p; rf2.var_in = d_var0.p; }
                     // G workgroups per agent share the elite gather (kernels_refit.hpp); at least 16 rows each
                     const int rg = sw.refit_wgs > 0 ? sw.refit_wgs : std::max(1, std::min(8, HU / 16));
                     hipLaunchKernelGGL(k_refit_cem_v2, dim3(rg, A), dim3(rthreads), (size_t)fixed * 4, stream, rf2);
@@ -1592,6 +1627,7 @@ void Engine::set_state(const std::string& name, const float* data, int64_t count
     float* dst = nullptr;
     if (name == "prev_mean") dst = d_prev_mean.p;
     else if (name == "var0") { dst = d_var0.p; pi2_dist_ready = false; }
+    cem_sigma0_ready = false;                  // (sigma0 follows prev_mean and var0)
     REQUIRE(dst, BBMPC_E_INVALID, "unknown/unsettable state tensor '" + name + "'");
     REQUIRE(count == (int64_t)nm, BBMPC_E_INVALID, "state tensor has A*H*U elements");
     HIP_CHECK(hipMemcpy(dst, data, nm * 4, hipMemcpyHostToDevice));

@@ -100,7 +100,7 @@ struct Engine {
         int mlp_pair = -1, mlp_q4 = -1;   // BBMPC_MLP_PAIR / BBMPC_MLP_Q4: -1 automatic, 0 / 1 forced
         int mlp_q4r = 1;                  // BBMPC_MLP_Q4R=0: keep k_rollout_mlp_q4 where k_rollout_mlp_q4r would run
         int cma_small3 = 1;               // BBMPC_CMA_SMALL3=0: n <= 32 keeps one launch per phase (eleven per iteration) instead of sample | roll out | update
-        int pi2_skip_init = 1;            // BBMPC_PI2_SKIP_INIT=0: k_dist_init opens every PI2 control step on the learned-model path too
+        int pi2_skip_init = 1;            // BBMPC_PI2_SKIP_INIT=0: k_dist_init opens every PI2 / CEM control step on the learned-model path too
         int refit_wgs = 0;                // BBMPC_REFIT_WGS=n: workgroups per agent in k_refit_cem_v2 (0 = by problem size)
         int mlp_wave = 1;                 // BBMPC_MLP_WAVE=0: never the one-wave-per-tile kernel for small networks
         int linger_us = 200;              // BBMPC_LINGER_US: how long a one-agent control-step kernel waits for the next call (0 = never)
@@ -247,6 +247,8 @@ struct Engine {
     float* mlp_state_copy = nullptr;
     bool pi2_dist_ready = false;       // d_sigma holds the constructor variance's root (PI2 never changes it)
     bool pi2_copy_seen = false;        // the previous control step's first rollout took such a request
+    bool cem_sigma0_ready = false;     // d_sigma0 holds cem_sigma(prev_mean, var0): constant while CEM restarts from the constructor distribution
+    DevBuf<float> d_sigma0;
     DevBuf<float> u_rows, u_x0, u_x1, u_total, u_pen, u_next;
     bool user_path() const { return cfg.reward == BBMPC_REW_USER || cfg.dynamics == BBMPC_DYN_USER; }
     int builtin_reward_kind() const { return cfg.reward == BBMPC_REW_USER ? REW_NONE : cfg.reward; }

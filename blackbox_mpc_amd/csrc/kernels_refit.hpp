@@ -78,6 +78,8 @@ struct RefitArgs {
     float* sigma;          // [A][HU]  out: sqrt of the constrained variance the NEXT iteration samples with
     int* elites;           // [A][k] out (sorted, best first)   | RandomSearch/PSO: [A] best index
     float* action;         // [A][U] out
+    const float* mean_in;  // CEM (k_refit_cem_v2): the distribution the smoothing starts from when it is not mean / var themselves
+    const float* var_in;   // (first iteration of a control step that skipped k_dist_init: prev_mean / var0), or null
 };
 
 // sigma = sqrt(min(((mean-lo)/2)^2, ((hi-mean)/2)^2, var))        cem.py:79-88
@@ -226,8 +228,8 @@ static __global__ __launch_bounds__(1024) void k_refit_cem_v2(RefitArgs p) {
             if (j < jhi && sub == 0) {
                 const float ev = vs / kf;                                  // cem.py:113-119
                 const int aj = a * p.HU + j;
-                const float m = p.alpha * p.mean[aj] + one_m * em;         // cem.py:121-122
-                const float v = p.alpha * p.var[aj] + one_m * ev;          // cem.py:123-125
+                const float m = p.alpha * (p.mean_in ? p.mean_in : p.mean)[aj] + one_m * em;         // cem.py:121-122
+                const float v = p.alpha * (p.var_in ? p.var_in : p.var)[aj] + one_m * ev;            // cem.py:123-125
                 p.mean[aj] = m;
                 p.var[aj] = v;
                 const int u = j % p.U;

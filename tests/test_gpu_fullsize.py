@@ -391,3 +391,28 @@ def test_pi2_control_step_without_the_opening_launch(L, monkeypatch, N, A):
         for x0, x1 in zip(r0, r1):
             np.testing.assert_array_equal(x0, x1)
     assert np.all(np.isfinite(out["1"][-1][0]))
+
+
+@pytest.mark.parametrize("N,A", [(1000, 1), (500, 2)])
+def test_cem_control_step_without_the_opening_launch(L, monkeypatch, N, A):
+    # BASELINE config 4 (CEM on the learned model, H=30): as for PI2 above -- CEM restarts from the constructor distribution
+    # every control step (cem.py:129-134), so (prev_mean, var0, sigma0) are constants: the first rollout samples from them,
+    # the first refit smooths against them, k_dist_init is not launched.  Bit-identical closed loop, reset() included.
+    H, iters, k = 30, 5, 50
+    out = {}
+    for skip in ("0", "1"):
+        monkeypatch.setenv("BBMPC_PI2_SKIP_INIT", skip)
+        eng, _ = _cheetah(L, L.OPT_CEM, N, A, H, iters, k, alpha=0.25, seed=9)
+        states = O.cheetah_start_states(A, 20)
+        rec = []
+        for step in range(5):
+            if step == 3:
+                eng.reset()
+            act, nxt, rew = eng.optimize(states)
+            rec.append((act.copy(), nxt.copy(), rew.copy(), eng.get_state("mean", (A * H * 6,)).copy(),
+                        eng.get_state("var", (A * H * 6,)).copy(), eng.get_state("sigma", (A * H * 6,)).copy()))
+            states = nxt
+        out[skip] = rec
+    for r0, r1 in zip(out["0"], out["1"]):
+        for x0, x1 in zip(r0, r1):
+            np.testing.assert_array_equal(x0, x1)
