@@ -175,7 +175,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.cma_fused = flag("BBMPC_CMA_FUSED");
         sw.mlp_generic = flag("BBMPC_MLP_GENERIC");
         { const int b = ival("BBMPC_MLP_BF16", 0); sw.mlp_bf16 = (b == 1 || b == 3) ? b : 0; }
-        sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1); sw.mlp_q4r = ival("BBMPC_MLP_Q4R", 1); sw.pi2_skip_init = ival("BBMPC_PI2_SKIP_INIT", 1); sw.cma_small3 = ival("BBMPC_CMA_SMALL3", 1);
+        sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1); sw.mlp_q4r = ival("BBMPC_MLP_Q4R", 1); sw.pi2_skip_init = ival("BBMPC_PI2_SKIP_INIT", 1); sw.step_graph = ival("BBMPC_STEP_GRAPH", 1); sw.cma_small3 = ival("BBMPC_CMA_SMALL3", 1);
         sw.refit_wgs = ival("BBMPC_REFIT_WGS", 0);
         sw.mlp_wave = ival("BBMPC_MLP_WAVE", 1);
         sw.linger_us = std::max(0, ival("BBMPC_LINGER_US", 200));
@@ -249,6 +249,9 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
 
 Engine::~Engine() {
     try { resident_stop(); } catch (...) {}
+    if (step_graph) { (void)hipGraphExecDestroy(step_graph); step_graph = nullptr; }
+    if (step_words) { (void)hipHostFree(step_words); step_words = nullptr; }
+    if (step_words_dev) { (void)hipFree(step_words_dev); step_words_dev = nullptr; }
     { std::lock_guard<std::mutex> lock(g_engines_mu); g_engines.erase(this); }
     if (lazy_sync && stream) (void)hipStreamSynchronize(stream);
     if (own_stream) (void)hipStreamSynchronize(own_stream);
@@ -852,6 +855,7 @@ void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_ou
     pending_warm = 0;
     if (tail_flag) {             // the record is complete when this kernel ends: it publishes the sequence number itself
         ta.done_flag = tail_flag; ta.done_count = tail_count; ta.done_value = tail_value;
+        ta.step_words = step_capturing ? step_words_dev : nullptr;
         tail_attached = true;
     }
     launch_with_tail(*this, k_tail_mlp, dim3(A), dim3(TAIL_THREADS), 0, ta);
@@ -962,6 +966,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                                   iters >= 1 && k <= 64 && !sw.refit_v1 && !fix(BBMPC_FIX_Q2_CEM_WARM_START) && cem_sigma0_ready &&
                                   pi2_copy_seen && stage_state_src != nullptr;
             const float* cem_pinned = nullptr;
+            last_step_steady = cem_skip;
             if (cem_skip) {
                 cem_pinned = stage_state_src;
             } else {
@@ -1072,6 +1077,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
             const bool skip_init = sw.pi2_skip_init && cfg.dynamics == BBMPC_DYN_MLP && !user_path() && !pop_sharded() && !trace_on &&
                                    iters >= 1 && pi2_dist_ready && pi2_copy_seen && stage_state_src != nullptr;
             const float* pinned_state = nullptr;
+            last_step_steady = skip_init;
             if (skip_init) {
                 pinned_state = stage_state_src;
             } else {
@@ -1737,6 +1743,7 @@ int bbmpc_destroy(bbmpc_handle h) {
 int bbmpc_set_stream(bbmpc_handle h, void* s) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     HIP_CHECK(hipStreamSynchronize(h->e->stream));
     h->e->stream = s ? (hipStream_t)s : h->e->own_stream;
     API_END
@@ -1745,6 +1752,7 @@ int bbmpc_set_stream(bbmpc_handle h, void* s) {
 int bbmpc_set_stream_default(bbmpc_handle h) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     HIP_CHECK(hipStreamSynchronize(h->e->stream));
     h->e->stream = nullptr;
     API_END
@@ -1754,6 +1762,7 @@ int bbmpc_set_mlp(bbmpc_handle h, int32_t n_layers, const int32_t* dims, const i
                   const float* const* b, int32_t is_normalized, const float* const* stats) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     h->e->set_mlp(n_layers, dims, acts, w, b, is_normalized, stats);
     API_END
 }
@@ -1761,6 +1770,7 @@ int bbmpc_set_mlp(bbmpc_handle h, int32_t n_layers, const int32_t* dims, const i
 int bbmpc_set_reward_source(bbmpc_handle h, const char* src) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     CHECK_PTR(src);
     h->e->set_user_source(bbmpc::USER_KIND_REWARD, src);
     API_END
@@ -1769,6 +1779,7 @@ int bbmpc_set_reward_source(bbmpc_handle h, const char* src) {
 int bbmpc_set_reward_callback(bbmpc_handle h, bbmpc_rows_callback fn, void* user) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     h->e->set_user_callback(bbmpc::USER_KIND_REWARD, fn, user);
     API_END
 }
@@ -1776,6 +1787,7 @@ int bbmpc_set_reward_callback(bbmpc_handle h, bbmpc_rows_callback fn, void* user
 int bbmpc_set_dynamics_callback(bbmpc_handle h, bbmpc_rows_callback fn, void* user) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     h->e->set_user_callback(bbmpc::USER_KIND_DYNAMICS, fn, user);
     API_END
 }
@@ -1783,6 +1795,7 @@ int bbmpc_set_dynamics_callback(bbmpc_handle h, bbmpc_rows_callback fn, void* us
 int bbmpc_set_dynamics_source(bbmpc_handle h, const char* src) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     CHECK_PTR(src);
     h->e->set_user_source(bbmpc::USER_KIND_DYNAMICS, src);
     API_END
@@ -1881,6 +1894,7 @@ int bbmpc_process_output(bbmpc_handle h, const float* states, const float* raw_o
 int bbmpc_reset(bbmpc_handle h) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     h->e->reset();
     API_END
 }
@@ -1889,6 +1903,7 @@ int bbmpc_optimize_dev(bbmpc_handle h, const float* d_state, int32_t, int32_t no
                        float* d_next_state) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     CHECK_PTR(d_state);
     CHECK_PTR(d_record);
     if (d_next_state == d_state) throw HipError(BBMPC_E_INVALID, "d_next_state must not alias d_state");
@@ -1960,12 +1975,68 @@ static const float* optimize_host(bbmpc::Engine& e, const float* state, int32_t 
                 // CEM / PI2 begin with k_dist_init, which fetches it from the pinned buffer itself; the others get a copy
                 const bool stage = (e.cfg.optimizer == BBMPC_OPT_CEM || e.cfg.optimizer == BBMPC_OPT_PI2) && !e.pop_sharded() &&
                                    !e.user_path();
+                // steady state of the learned-model PI2 / CEM path: the same launches with the same arguments every call --
+                // replayed as a graph (engine.hpp: step_graph)
+                const bool graph_ok = e.sw.step_graph && stage && e.cfg.dynamics == BBMPC_DYN_MLP && e.tail_flag != nullptr &&
+                                      e.tail_event == nullptr && !e.profiling && !e.trace_on && e.stream == e.own_stream && !e.any_injected();
+                const uint64_t sig = ((uint64_t)e.mutations << 8) | (uint64_t)(noise ? 1 : 0) | 2u;
+                bool replayed = false;
+                if (graph_ok && e.step_graph && e.step_graph_sig == sig) {
+                    replayed = true;
+                } else if (graph_ok && e.step_graph_warm >= 3 && e.step_warm_sig == sig) {
+                    if (e.step_graph) { (void)hipGraphExecDestroy(e.step_graph); e.step_graph = nullptr; }      // (captured for other arguments)
+                    // capture this call's launches; nothing runs until the graph is launched below
+                    if (!e.step_words) {
+                        HIP_CHECK(hipHostMalloc((void**)&e.step_words, 64, 0));        // staging for the (rare) re-synchronisation of the device words
+                        memset(e.step_words, 0, 64);
+                        HIP_CHECK(hipMalloc((void**)&e.step_words_dev, 64));
+                        HIP_CHECK(hipMemset(e.step_words_dev, 0, 64));
+                        e.step_mirror[0] = e.step_mirror[1] = 0xFFFFFFFFu;
+                    }
+                    const uint32_t saved_step = e.step_counter;
+                    hipGraph_t g = nullptr;
+                    bool ok = hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                    if (ok) {
+                        e.step_capturing = true;
+                        try {
+                            e.stage_state_src = dpin;
+                            e.optimize_dev(e.d_state.p, noise, dpin + ns, nullptr);
+                        } catch (...) { ok = false; }
+                        e.step_capturing = false;
+                        ok = (hipStreamEndCapture(e.stream, &g) == hipSuccess) && ok && g != nullptr && e.last_step_steady && e.stage_state_src == nullptr;
+                        e.stage_state_src = nullptr;
+                        if (ok) ok = hipGraphInstantiate(&e.step_graph, g, nullptr, nullptr, 0) == hipSuccess;
+                        if (g) (void)hipGraphDestroy(g);
+                    }
+                    e.step_counter = saved_step;                 // the captured call has not run
+                    (void)hipGetLastError();
+                    if (ok) { replayed = true; e.step_graph_sig = sig; }
+                    else { e.step_graph = nullptr; e.sw.step_graph = 0; }      // this handle keeps enqueueing its launches one by one
+                }
+                if (replayed) {
+                    // the device's (control step, completion value) advance by themselves at the end of every replay; calls that
+                    // did not go through the graph in between put them out of step with the host's: one 8-byte copy then
+                    if (e.step_mirror[0] != e.step_counter || e.step_mirror[1] != e.host_seq) {
+                        HIP_CHECK(hipStreamSynchronize(e.stream));           // (the staging words may still be in use by an earlier copy)
+                        e.step_words[0] = e.step_counter; e.step_words[1] = e.host_seq;
+                        HIP_CHECK(hipMemcpyAsync(e.step_words_dev, e.step_words, 8, hipMemcpyHostToDevice, e.stream));
+                    }
+                    HIP_CHECK(hipGraphLaunch(e.step_graph, e.stream));
+                    ++e.calls_graph;
+                    ++e.step_counter;
+                    e.step_mirror[0] = e.step_counter;
+                    e.step_mirror[1] = e.host_seq + 1u == 0u ? 1u : e.host_seq + 1u;
+                    e.tail_attached = true;
+                } else {
                 if (stage) e.stage_state_src = dpin;
                 else HIP_CHECK(hipMemcpyAsync(e.d_state.p, pin, ns * 4, hipMemcpyHostToDevice, e.stream));
                 e.optimize_dev(e.d_state.p, noise, dpin + ns, nullptr);
                 if (e.stage_state_src) {
                     e.stage_state_src = nullptr;
                     throw HipError(BBMPC_E_HIP, "internal: the control step did not stage its state");
+                }
+                if (graph_ok && e.last_step_steady && e.step_warm_sig == sig) ++e.step_graph_warm;
+                else { e.step_graph_warm = (graph_ok && e.last_step_steady) ? 1 : 0; e.step_warm_sig = sig; }
                 }
             }
             e.linger_launch = false;
@@ -2045,6 +2116,7 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t t, int32_t noise,
 int bbmpc_rollout_episode(bbmpc_handle h, const float* start_state, int32_t num_steps, int32_t noise, float* records_out) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     CHECK_PTR(start_state);
     CHECK_PTR(records_out);
     Engine& e = *h->e;
@@ -2142,6 +2214,7 @@ int bbmpc_evaluate_next_reward(bbmpc_handle h, const float* states, const float*
 int bbmpc_inject_noise(bbmpc_handle h, int32_t kind, const float* data, int64_t count) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     HIP_CHECK(hipStreamSynchronize(h->e->stream));
     h->e->inject(kind, data, count);
     API_END
@@ -2158,6 +2231,7 @@ int bbmpc_dump_noise(bbmpc_handle h, int32_t kind, int32_t control_step, int32_t
 int bbmpc_set_trace(bbmpc_handle h, int32_t enabled) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     if (enabled && h->e->auto_split > 1)
         throw HipError(BBMPC_E_UNSUPPORTED, "the parity trace is per shard: not available for a population > 32768 (played as shards)");
     h->e->trace_on = enabled != 0;
@@ -2184,6 +2258,7 @@ int bbmpc_get_state(bbmpc_handle h, const char* name, float* out, int64_t count)
 int bbmpc_set_state(bbmpc_handle h, const char* name, const float* data, int64_t count) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     CHECK_PTR(name);
     CHECK_PTR(data);
     h->e->set_state(name, data, count);
@@ -2193,6 +2268,7 @@ int bbmpc_set_state(bbmpc_handle h, const char* name, const float* data, int64_t
 int bbmpc_set_profiling(bbmpc_handle h, int32_t enabled) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     h->e->profiling = enabled != 0;
     h->e->prof_every = enabled > 1 ? enabled : 1;
     h->e->prof_seq = 0;
@@ -2231,6 +2307,7 @@ int bbmpc_comm_unique_id(void* out, int64_t bytes) {
 int bbmpc_comm_init(bbmpc_handle h, const void* unique_id, int32_t nranks, int32_t rank) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     CHECK_PTR(unique_id);
     Engine* e = h->e;
     if (nranks < 1 || rank < 0 || rank >= nranks) throw HipError(BBMPC_E_INVALID, "bbmpc_comm_init: rank / nranks out of range");
@@ -2379,6 +2456,7 @@ int bbmpc_optimize_gather_dev(bbmpc_handle h, const float* d_state, int32_t, int
                               float* d_next_state, float* d_gathered, int32_t slot) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     // the communicator of a population-sharded handle carries the per-iteration partials on the LAUNCH stream; one RCCL
     // communicator must not be driven from two unsynchronised streams, so such a handle has no record gather (its ranks
     // all hold the same agents: there is nothing to gather).  A population that is only split into shards on THIS GPU
@@ -2426,6 +2504,7 @@ int bbmpc_optimize_gather(bbmpc_handle h, const float* state, int32_t, int32_t n
                           float* reward, float* d_gathered, int32_t slot) {
     API_BEGIN
     CHECK_HANDLE_NOSETTLE(h);            // as bbmpc_optimize: consecutive calls are ordered by the stream / the resident kernel
+    h->e->invalidate_step_graph();
     // the communicator of a population-sharded handle carries the per-iteration partials on the LAUNCH stream; one RCCL
     // communicator must not be driven from two unsynchronised streams, so such a handle has no record gather (its ranks
     // all hold the same agents: there is nothing to gather).  A population that is only split into shards on THIS GPU
@@ -2473,6 +2552,13 @@ int bbmpc_call_stats(bbmpc_handle h, int64_t* served_resident, int64_t* launched
     CHECK_HANDLE(h);
     if (served_resident) *served_resident = h->e->calls_resident;
     if (launched) *launched = h->e->calls_launched;
+    API_END
+}
+
+int bbmpc_graph_stats(bbmpc_handle h, int64_t* replayed) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    if (replayed) *replayed = h->e->calls_graph;
     API_END
 }
 
@@ -2541,6 +2627,7 @@ int bbmpc_gather_wait(bbmpc_handle h, int32_t slot, int32_t host_block) {
 int bbmpc_comm_destroy(bbmpc_handle h) {
     API_BEGIN
     CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
     h->e->rc.destroy();
     API_END
 }

@@ -84,6 +84,28 @@ struct Engine {
     int cu_count = 0;        // its compute units (kernels with spinning barriers are sized against it)
     int device = 0;          // the device the handle lives on (cfg.device, or the caller's current device when that is < 0)
     uint32_t step_counter = 0;
+    // A steady-state control step of the learned-model PI2 / CEM path replayed as a hipGraph (bbmpc_optimize): its eleven
+    // dependent launches follow each other ~1 us closer than enqueued one by one (tools/microbench/launch_chain.hip:
+    // 2.9 us per tiny dependent kernel on a stream, 1.95 us as a graph).  The launch arguments are frozen at capture; the two
+    // words that change per call -- the control step the draws are keyed by and the completion value the tail publishes --
+    // are read by the kernels from device memory that the step's last kernel advances (and the host re-synchronises
+    // after calls that did not go through the graph).
+    hipGraphExec_t step_graph = nullptr;
+    uint64_t step_graph_sig = 0;           // what the graph was captured for (mutation count, exploration-noise flag)
+    uint64_t step_warm_sig = 0;            // ... and what the current run of identical calls looks like
+    int step_graph_warm = 0;               // consecutive eligible calls that ran the steady-state launch sequence
+    uint32_t mutations = 0;                // bumped by everything that can change what a control step launches
+    uint32_t* step_words_dev = nullptr;    // device memory: [0] control step, [1] completion value, [2] arrival counter of the tail's workgroups
+    uint32_t* step_words = nullptr;        // pinned staging for re-synchronising them
+    uint32_t step_mirror[2] = {0, 0};      // what the device words hold now
+    bool step_capturing = false;
+    int64_t calls_graph = 0;               // replays so far (bbmpc_graph_stats)
+    bool last_step_steady = false;         // the last optimize_dev ran without k_dist_init (kernels as they will be replayed)
+    void invalidate_step_graph() {
+        ++mutations;
+        step_graph_warm = 0;
+        if (step_graph) { (void)hipGraphExecDestroy(step_graph); step_graph = nullptr; }
+    }
     bool trace_on = false, profiling = false;
     int prof_every = 1;      // events around every prof_every-th launch of the dominant kernel
     uint64_t prof_seq = 0;
@@ -100,6 +122,7 @@ struct Engine {
         int mlp_pair = -1, mlp_q4 = -1;   // BBMPC_MLP_PAIR / BBMPC_MLP_Q4: -1 automatic, 0 / 1 forced
         int mlp_q4r = 1;                  // BBMPC_MLP_Q4R=0: keep k_rollout_mlp_q4 where k_rollout_mlp_q4r would run
         int cma_small3 = 1;               // BBMPC_CMA_SMALL3=0: n <= 32 keeps one launch per phase (eleven per iteration) instead of sample | roll out | update
+        int step_graph = 1;               // BBMPC_STEP_GRAPH=0: never replay a control step as a hipGraph
         int pi2_skip_init = 1;            // BBMPC_PI2_SKIP_INIT=0: k_dist_init opens every PI2 / CEM control step on the learned-model path too
         int refit_wgs = 0;                // BBMPC_REFIT_WGS=n: workgroups per agent in k_refit_cem_v2 (0 = by problem size)
         int mlp_wave = 1;                 // BBMPC_MLP_WAVE=0: never the one-wave-per-tile kernel for small networks
@@ -231,6 +254,7 @@ struct Engine {
         kk.k1 = (uint32_t)(cfg.seed >> 32);
         kk.step = step;
         kk.q_per_agent = (uint32_t)((HU + 3) / 4);
+        kk.step_src = step_capturing ? step_words_dev : nullptr;
         return kk;
     }
     bool fix(uint32_t bit) const { return (cfg.quirks & bit) != 0; }
@@ -271,6 +295,10 @@ struct Engine {
     bool pop_sharded_across_ranks() const { return ps_force || (ps_loopback <= 1 && cfg.population_global > N); }
     int pending_warm = 0;    // learned-dynamics path: warm start the tail kernel performs (kernels_tail.hpp TailArgs::warm_mode)
     RowMlp row_mlp() const;
+    bool any_injected() const {
+        for (const auto& kv : inj) if (kv.second.p) return true;
+        return false;
+    }
     const float* injected(int kind) const {
         auto it = inj.find(kind);
         return (it == inj.end() || !it->second.p) ? nullptr : it->second.p;

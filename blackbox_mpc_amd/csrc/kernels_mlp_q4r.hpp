@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     const float* lo_base = has_bounds ? p.lo : p.state;
     const float* hi_base = has_bounds ? p.hi : p.state;
     const bool has_rng = !has_raw;                         // draws made here (rng.hpp counters), SRC_UNIFORM or truncated normal
+    const RngKey key_now = rng_key_now(p.key);               // (the control step from memory when the launch is a graph node)
     float a_raw[NE][4], a_sg[NE][4], a_mn[NE][4], a_lo[NE][4], a_hi[NE][4], a_f[NE][4], a_tq[NE][4];
     int a_n[NE], a_j0[NE], a_tu[NE];                     // particle (-1: no such pair / particle), first j, (t << 8) | u of the first element
 #pragma unroll
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
         // other small results -- as one piece it would sit behind the operand loads.  One unconditional pair of loads
         // per element whatever the mode (a load inside a branch costs a wait at the join).
         U4 blk4 = {0u, 0u, 0u, 0u};
-        if (has_rng) blk4 = rng_block(p.key, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j0);
+        if (has_rng) blk4 = rng_block(key_now, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j0);
         const bool tn = has_rng && !m_uni;
 #pragma unroll
         for (int l = 0; l < 4; ++l) {

@@ -372,7 +372,7 @@ __device__ __forceinline__ float exploration_action(const FinalArgs& p, int a, i
     float xi;
     if (p.inj) xi = p.inj[a * p.U + u];
     else {
-        U4 b = rng_block(p.key, 10u /*BBMPC_NOISE_EXPLORATION*/, 0u, 0u, (uint32_t)(p.agent_offset + a), (uint32_t)u);
+        U4 b = rng_block(rng_key_now(p.key), 10u /*BBMPC_NOISE_EXPLORATION*/, 0u, 0u, (uint32_t)(p.agent_offset + a), (uint32_t)u);
         xi = word_to_trunc_normal(pick_word(b, (uint32_t)u));
     }
     const float lo = p.lo[u], hi = p.hi[u];

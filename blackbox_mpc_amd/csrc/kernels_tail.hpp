@@ -125,6 +125,10 @@ struct TailArgs {
     unsigned* done_flag;    // publish_records_done (kernels_refit.hpp) or null
     unsigned* done_count;
     unsigned done_value;
+    // a control step replayed as a graph (engine.hpp: step_graph): [0] the control step its draws are keyed by (rng.hpp:
+    // RngKey::step_src), [1] the completion value -- device memory, read at the start of this kernel and advanced by its
+    // last workgroup for the next replay
+    unsigned* step_words;
 };
 
 // grid A, block TAIL_THREADS
@@ -133,6 +137,7 @@ static __global__ __launch_bounds__(TAIL_THREADS) void k_tail_mlp(TailArgs p) {
     __shared__ float bufA[TAIL_MAXW], bufB[TAIL_MAXW], part[(TAIL_THREADS / 64) * TAIL_MAXW];
     const int a = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int S = p.f.S, U = p.f.U;
+    const unsigned done_value = p.step_words ? p.step_words[1] : p.done_value;
     if (tid < S) cur[tid] = p.f.state[a * S + tid];
     if (tid >= 64 && tid < 64 + U) {
         const int u = tid - 64;
@@ -162,7 +167,19 @@ static __global__ __launch_bounds__(TAIL_THREADS) void k_tail_mlp(TailArgs p) {
     if (tid == 128) out[U + S] = r;
     if (p.done_flag) {
         __syncthreads();
-        if (tid == 0) publish_records_done(p.done_flag, p.done_count, p.done_value, gridDim.x);
+        if (tid == 0) {
+            publish_records_done(p.done_flag, p.done_count, done_value, gridDim.x);
+            if (p.step_words) {
+                // every workgroup has read the words by the time the last one gets here (they are read first thing)
+                const unsigned old = gridDim.x == 1u ? 0u : __hip_atomic_fetch_add(p.step_words + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == gridDim.x - 1u) {
+                    if (gridDim.x > 1u) __hip_atomic_store(p.step_words + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    p.step_words[0] = p.step_words[0] + 1u;
+                    const unsigned nv = done_value + 1u;
+                    p.step_words[1] = nv == 0u ? 1u : nv;            // (as bbmpc_optimize counts: 0 is never a completion value)
+                }
+            }
+        }
     }
 }
 

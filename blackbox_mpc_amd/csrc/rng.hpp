@@ -105,7 +105,15 @@ struct RngKey {
     uint32_t k0, k1;      // seed
     uint32_t step;        // control step
     uint32_t q_per_agent; // Q = ceil(H*U/4)
+    // a control step replayed as a hipGraph (engine: step_graph) has its launch arguments frozen: the kernels on that path
+    // take the control step from this word (device memory, advanced by the step's last kernel) instead
+    const uint32_t* step_src;
 };
+__device__ __forceinline__ RngKey rng_key_now(const RngKey& k) {
+    RngKey r = k;
+    if (k.step_src) r.step = *k.step_src;
+    return r;
+}
 
 // Raw words for the 4-element block containing element j of particle n, global agent ga.
 __device__ __forceinline__ U4 rng_block(const RngKey& key, uint32_t stream, uint32_t iter, uint32_t n,

@@ -184,6 +184,12 @@ class Engine:
                                                 ctypes.c_void_p(d_next_state or 0), ctypes.c_void_p(d_gathered),
                                                 int(slot)))
 
+    def graph_stats(self):
+        """Host-in / host-out calls served by replaying a captured hipGraph -- bbmpc_graph_stats."""
+        a = ctypes.c_int64(0)
+        L.check(L.lib.bbmpc_graph_stats(self._h, ctypes.byref(a)))
+        return a.value
+
     def call_stats(self):
         """(calls served by the resident kernel of the previous call, calls that launched) -- bbmpc_call_stats."""
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)

@@ -232,6 +232,9 @@ int bbmpc_optimize(bbmpc_handle h, const float* state, int32_t time_step, int32_
  * No counterpart in the reference (its act() is one TF graph call per control step, policies/mpc_policy.py:160-164);
  * exists so that a benchmark can say which of the two paths its number was measured on. */
 int bbmpc_call_stats(bbmpc_handle h, int64_t* served_resident, int64_t* launched);
+/* ... and how many of the launched ones were replays of a captured hipGraph (the steady-state control step of the
+ * learned-model PI2 / CEM path: same launches, same arguments every call).  No counterpart in the reference. */
+int bbmpc_graph_stats(bbmpc_handle h, int64_t* replayed);
 
 /* Same with device pointers; record is [A, U+S+1] = (action | next_state | reward) per agent.
  * d_next_state (optional, may be NULL) additionally receives the predicted next state as a contiguous

@@ -416,3 +416,31 @@ def test_cem_control_step_without_the_opening_launch(L, monkeypatch, N, A):
     for r0, r1 in zip(out["0"], out["1"]):
         for x0, x1 in zip(r0, r1):
             np.testing.assert_array_equal(x0, x1)
+
+
+@pytest.mark.parametrize("opt,N,A", [("PI2", 1000, 1), ("PI2", 500, 2), ("CEM", 1000, 1), ("CEM", 500, 2)])
+def test_steady_state_control_step_replayed_as_a_graph(L, monkeypatch, opt, N, A):
+    # Learned-model PI2 / CEM through bbmpc_optimize: after a few identical calls the control step's launches are captured
+    # once and replayed as a hipGraph (BBMPC_STEP_GRAPH, default on); the control step number the draws are keyed by and the
+    # completion value live in device memory and advance by themselves.  Bit-identical closed loop against one launch at a
+    # time -- across a reset() (which drops the graph), a call with exploration noise (another graph) and back.
+    H, iters = 30, 5
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("BBMPC_STEP_GRAPH", mode)
+        kw = dict(lamda=1.0) if opt == "PI2" else dict(alpha=0.25)
+        eng, _ = _cheetah(L, getattr(L, "OPT_" + opt), N, A, H, iters, 0 if opt == "PI2" else 50, seed=13, **kw)
+        states = O.cheetah_start_states(A, 20)
+        rec = []
+        for step in range(22):
+            if step == 12:
+                eng.reset()
+            noise = step in (16, 17)
+            act, nxt, rew = eng.optimize(states, add_exploration_noise=noise)
+            rec.append((act.copy(), nxt.copy(), rew.copy()))
+            states = nxt
+        out[mode] = rec
+        assert (eng.graph_stats() >= 6) == (mode == "1"), eng.graph_stats()      # replays did happen (and only when asked for)
+    for i, (r0, r1) in enumerate(zip(out["0"], out["1"])):
+        for x0, x1 in zip(r0, r1):
+            np.testing.assert_array_equal(x0, x1, err_msg="control step %d" % i)
