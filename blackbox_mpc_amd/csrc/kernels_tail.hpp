@@ -25,6 +25,9 @@ namespace bbmpc {
 constexpr int TAIL_THREADS = 1024;
 constexpr int TAIL_MAXW = 512;                 // widest layer (set_mlp enforces hidden <= 512, S+U <= 128, S <= 64)
 
+#ifdef BBMPC_KERNEL_DBG
+__device__ long long g_tail_dbg[16];
+#endif
 struct RowMlp {
     MlpDesc m;
     const float* wraw[MLP_MAX_LAYERS];         // Dense kernels [in][out] (reference layout)
@@ -38,10 +41,10 @@ __device__ __forceinline__ const float* row_mlp_forward(const RowMlp& q, const f
     const float* in = x;
     for (int l = 0; l < q.m.n_layers; ++l) {
         const int K = q.m.dims[l], M = q.m.dims[l + 1];
+        const float* __restrict__ W = q.wraw[l];
         const int Mr = (M + 63) & ~63;                           // outputs per K-slice, wave aligned
         const int G = max(1, min(nthr / Mr, (K + 7) / 8));       // K-slices (>= 8 terms each)
         const int Kc = (K + G - 1) / G;
-        const float* __restrict__ W = q.wraw[l];
         for (int t = tid; t < G * Mr; t += nthr) {
             const int g = t / Mr, o = t - g * Mr;
             if (o < M) {
@@ -78,6 +81,9 @@ __device__ __forceinline__ const float* row_mlp_forward(const RowMlp& q, const f
             }
         }
         __syncthreads();
+#ifdef BBMPC_KERNEL_DBG
+        if (tid == 0 && blockIdx.x == 0) g_tail_dbg[1 + 2 * l] = (long long)wall_clock64();
+#endif
         float* out = (l & 1) ? bufB : bufA;
         for (int o = tid; o < M; o += nthr) {
             float acc = q.braw[l][o];
@@ -85,6 +91,9 @@ __device__ __forceinline__ const float* row_mlp_forward(const RowMlp& q, const f
             out[o] = apply_act(acc, q.m.act[l]);
         }
         __syncthreads();
+#ifdef BBMPC_KERNEL_DBG
+        if (tid == 0 && blockIdx.x == 0) g_tail_dbg[2 + 2 * l] = (long long)wall_clock64();
+#endif
         in = out;
     }
     return in;
@@ -138,6 +147,9 @@ static __global__ __launch_bounds__(TAIL_THREADS) void k_tail_mlp(TailArgs p) {
     const int a = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int S = p.f.S, U = p.f.U;
     const unsigned done_value = p.step_words ? p.step_words[1] : p.done_value;
+#ifdef BBMPC_KERNEL_DBG
+    if (tid == 0 && a == 0) g_tail_dbg[0] = (long long)wall_clock64();
+#endif
     if (tid < S) cur[tid] = p.f.state[a * S + tid];
     if (tid >= 64 && tid < 64 + U) {
         const int u = tid - 64;
@@ -165,6 +177,13 @@ static __global__ __launch_bounds__(TAIL_THREADS) void k_tail_mlp(TailArgs p) {
         if (p.f.next_state) p.f.next_state[a * S + tid - 64] = v;
     }
     if (tid == 128) out[U + S] = r;
+#ifdef BBMPC_KERNEL_DBG
+    if (tid == 0 && a == 0) {
+        const long long t1 = (long long)wall_clock64();
+        printf("[tail] stage + L0 mac %lld (= %lld) red %lld | L1 mac %lld red %lld | L2 mac %lld red %lld | out %lld (10 ns)\n", g_tail_dbg[1] - g_tail_dbg[0],
+               g_tail_dbg[1] - g_tail_dbg[0], g_tail_dbg[2] - g_tail_dbg[1], g_tail_dbg[3] - g_tail_dbg[2], g_tail_dbg[4] - g_tail_dbg[3], g_tail_dbg[5] - g_tail_dbg[4], g_tail_dbg[6] - g_tail_dbg[5], t1 - g_tail_dbg[6]);
+    }
+#endif
     if (p.done_flag) {
         __syncthreads();
         if (tid == 0) {
