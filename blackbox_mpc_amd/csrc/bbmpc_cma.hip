@@ -136,10 +136,17 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
         const bool small3 = sw.cma_small3 && cma_use_eigh_small() && !pop_sharded();
         if (small3) {
             // n <= 32: sample | roll out | update, three launches per iteration (kernels_eigh_small.hpp)
-            hipLaunchKernelGGL(k_cma_sample_small, dim3((N + 63) / 64, G), dim3(256), 0, stream, q);
             const bool write_back = trace_on || user_path();
-            ra.cand = d_cand_a.p; ra.samples = write_back ? d_cand_a.p : nullptr; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
-            launch_rollout(SRC_BUF, true, ra);                          // clip + penalty (cma_es.py:147-157)
+            // the analytic pendulum, one agent per instance: the rollouts ride on the sampling launch
+            const bool roll_in = !write_back && cfg.dynamics == BBMPC_DYN_PENDULUM && cfg.reward == BBMPC_REW_PENDULUM && cma_G == A && U == 1 && S == 3;
+            if (roll_in) {
+                if (!fix(BBMPC_STRICT_MATH)) hipLaunchKernelGGL(k_cma_sample_roll_small<true>, dim3((N + 63) / 64, G), dim3(256), 0, stream, q, ra.state, ra.fix_q1 ? 1 : 0);
+                else hipLaunchKernelGGL(k_cma_sample_roll_small<false>, dim3((N + 63) / 64, G), dim3(256), 0, stream, q, ra.state, ra.fix_q1 ? 1 : 0);
+            } else {
+                hipLaunchKernelGGL(k_cma_sample_small, dim3((N + 63) / 64, G), dim3(256), 0, stream, q);
+                ra.cand = d_cand_a.p; ra.samples = write_back ? d_cand_a.p : nullptr; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
+                launch_rollout(SRC_BUF, true, ra);                          // clip + penalty (cma_es.py:147-157)
+            }
             // (the elite deviations, k x n floats, go through LDS for the covariance sums when they fit beside the static words)
             const size_t yef = (size_t)(n * n + k * n + 2 * n) * sizeof(float) <= 48 * 1024 ? (size_t)(n * n + k * n + 2 * n) : 0;
             const size_t ulds = std::max(std::max(lds, (size_t)n * n * sizeof(float)), yef * sizeof(float));

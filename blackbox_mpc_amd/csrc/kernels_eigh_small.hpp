@@ -19,6 +19,7 @@
 
 #include "kernels_cma.hpp"
 #include "kernels_refit.hpp"
+#include "kernels_rollout.hpp"
 
 namespace bbmpc {
 
@@ -419,10 +420,9 @@ static __global__ __launch_bounds__(1024) void k_cma_factor_small(CmaArgs p, flo
 // z ~ N(0, I), y = z (B D), samples = m + sigma y  (cma_es.py:139-141; k_cma_noise + k_cma_bd + k_cma_gemm_y)
 // grid (ceil(N / 64), G), block 256: 64 particles per workgroup, the four waves share the Philox blocks of the draws and
 // take eight rows of the product each.  LDS: B D (pitch 32) | z [n][64]
-static __global__ __launch_bounds__(256) void k_cma_sample_small(CmaArgs p) {
-    __shared__ __attribute__((aligned(16))) float bd[ES_N * ES_N];
-    __shared__ float zs[ES_N][64];
-    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n, Nst = p.Nst;
+// cs (optional): [n][64] floats of LDS that receive the samples too (for the rollouts of k_cma_sample_roll_small)
+__device__ __forceinline__ void cma_sample_small_body(const CmaArgs& p, int g, float* bd, float (*zs)[64], float (*cs)[64]) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = p.n, Nst = p.Nst;
     const int q = blockIdx.x * 64 + lane;
     const size_t off = (size_t)g * n, nn = (size_t)n * n;
     for (int i = tid; i < ES_N * ES_N; i += 256) {
@@ -448,19 +448,62 @@ static __global__ __launch_bounds__(256) void k_cma_sample_small(CmaArgs p) {
     }
     __syncthreads();
     const int i0 = 8 * wv;
-    if (!live || i0 >= n) return;
-    // one fmaf chain over l per element (k_cma_gemm_y's order), eight rows share each z load
-    float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    for (int l = 0; l < n; ++l) {
-        const float zv = zs[l][lane];
-        const float4 b0 = *reinterpret_cast<const float4*>(&bd[l * ES_N + i0]);
-        const float4 b1 = *reinterpret_cast<const float4*>(&bd[l * ES_N + i0 + 4]);
-        acc[0] = fmaf(b0.x, zv, acc[0]); acc[1] = fmaf(b0.y, zv, acc[1]); acc[2] = fmaf(b0.z, zv, acc[2]); acc[3] = fmaf(b0.w, zv, acc[3]);
-        acc[4] = fmaf(b1.x, zv, acc[4]); acc[5] = fmaf(b1.y, zv, acc[5]); acc[6] = fmaf(b1.z, zv, acc[6]); acc[7] = fmaf(b1.w, zv, acc[7]);
-    }
+    if (live && i0 < n) {
+        // one fmaf chain over l per element (k_cma_gemm_y's order), eight rows share each z load
+        float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int l = 0; l < n; ++l) {
+            const float zv = zs[l][lane];
+            const float4 b0 = *reinterpret_cast<const float4*>(&bd[l * ES_N + i0]);
+            const float4 b1 = *reinterpret_cast<const float4*>(&bd[l * ES_N + i0 + 4]);
+            acc[0] = fmaf(b0.x, zv, acc[0]); acc[1] = fmaf(b0.y, zv, acc[1]); acc[2] = fmaf(b0.z, zv, acc[2]); acc[3] = fmaf(b0.w, zv, acc[3]);
+            acc[4] = fmaf(b1.x, zv, acc[4]); acc[5] = fmaf(b1.y, zv, acc[5]); acc[6] = fmaf(b1.z, zv, acc[6]); acc[7] = fmaf(b1.w, zv, acc[7]);
+        }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-        if (i0 + u < n) p.cand[(off + i0 + u) * Nst + q] = p.m[off + i0 + u] + p.sigma[off + i0 + u] * acc[u];
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u < n) {
+                const float x = p.m[off + i0 + u] + p.sigma[off + i0 + u] * acc[u];
+                p.cand[(off + i0 + u) * Nst + q] = x;
+                if (cs) cs[i0 + u][lane] = x;
+            }
+    }
+}
+
+static __global__ __launch_bounds__(256) void k_cma_sample_small(CmaArgs p) {
+    __shared__ __attribute__((aligned(16))) float bd[ES_N * ES_N];
+    __shared__ float zs[ES_N][64];
+    cma_sample_small_body(p, blockIdx.y, bd, zs, nullptr);
+}
+
+// ... and, for the analytic pendulum with one agent per instance, the rollouts of the workgroup's 64 particles behind it
+// (k_rollout_pendulum<SRC_BUF, penalty>: clip, squared clip distance, H steps, reward minus penalty -- cma_es.py:144-157),
+// one launch fewer per iteration.  The clipped candidates are not written back (kernels_cma.hpp: the path update clips
+// the elites it reads).
+template <bool FASTM>
+__global__ __launch_bounds__(256) void k_cma_sample_roll_small(CmaArgs p, const float* state, int fix_q1) {
+    __shared__ __attribute__((aligned(16))) float bd[ES_N * ES_N];
+    __shared__ float zs[ES_N][64];
+    __shared__ float cs[ES_N][64];
+    const int g = blockIdx.y;
+    cma_sample_small_body(p, g, bd, zs, cs);
+    __syncthreads();
+    const int tid = threadIdx.x, q = blockIdx.x * 64 + tid;
+    if (tid >= 64 || q >= p.N) return;
+    const float lo0 = p.lo[0], hi0 = p.hi[0];
+    Roller<FASTM> roll(fix_q1 != 0, state[g * 3 + 0], state[g * 3 + 1], state[g * 3 + 2]);
+    float total = 0.0f, pen = 0.0f;
+    for (int t = 0; t < p.n; ++t) {
+        float x = cs[t][tid];
+        const float xf = clipf(x, lo0, hi0);
+        const float d = x - xf;
+        pen = pen + d * d;
+        x = xf;
+        total = total + roll.step(x);
+    }
+    if (total != total) total = -1.0e6f;
+    const float nr = sqrtf(pen);
+    pen = nr * nr;
+    total = total - pen;
+    const_cast<float*>(p.rewards)[(size_t)g * p.Nst + q] = total;
 }
 
 // covariance on the upper triangle, mirrored (k_cma_cov's sums), by one workgroup.  ye: k * n floats of LDS when the elite
