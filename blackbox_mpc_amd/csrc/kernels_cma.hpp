@@ -249,8 +249,15 @@ static __global__ __launch_bounds__(1024) void k_cma_merge(CmaArgs p, const floa
 // STAGE (small instances, one launch for the whole update): B, the k elite columns and the two intermediate vectors live in
 // `stage` (n*n + k*n + 2n floats of LDS) -- every dependent access is then an LDS access instead of an L2 round trip (the
 // chain of ~15 round trips is what the stand-alone kernel's 11-12 us at n = 30 consist of); same sums in the same order.
+#ifdef BBMPC_KERNEL_DBG
+__device__ long long g_paths_dbg[8];
+#define PATHS_MARK(i) do { if (threadIdx.x == 0 && g == 0) g_paths_dbg[i] = (long long)wall_clock64(); } while (0)
+#else
+#define PATHS_MARK(i) do {} while (0)
+#endif
 template <bool STAGE>
 __device__ __forceinline__ void cma_paths_body_t(const CmaArgs& p, int g, float* stage) {
+    PATHS_MARK(7);
     // blockDim: any multiple of 64 up to 1024.  The loops keep several independent loads in flight and the row-wise
     // product runs one wave per row (coalesced), instead of one L2 latency per term of an n-term sum.
     __shared__ float red[16];
@@ -273,7 +280,28 @@ __device__ __forceinline__ void cma_paths_body_t(const CmaArgs& p, int g, float*
         for (int i = tid; i < p.k * n; i += nthr) { const int e = i / n, c = i - e * n; xe[i] = X[(size_t)c * p.Nst + s_el[e]]; }
         __syncthreads();
     }
+    PATHS_MARK(0);
     // x_diff, x_mean, y_mean, Ye
+    if (STAGE) {
+        // every thread one (elite, coordinate) element: clip, x_diff (left in xe), Ye; the weighted sums over the elites then
+        // run from LDS in elite order -- n threads walking k elites each, a division and a global store per term, was 6 us of
+        // the 12 us this body took at n = 30, k = 50
+        for (int i = tid; i < p.k * n; i += nthr) {
+            const int e = i / n, c = i - e * n;
+            const float xd = clipf(xe[i], p.lo[c % p.U], p.hi[c % p.U]) - p.m[off + c];      // :161
+            xe[i] = xd;
+            Ye[(size_t)e * n + c] = xd / p.sigma[off + c];                                    // :180
+        }
+        __syncthreads();
+        for (int c = tid; c < n; c += nthr) {
+            const float sc = p.sigma[off + c];
+            float xm = 0.0f;
+            for (int e = 0; e < p.k; ++e) xm = xm + xe[e * n + c] * s_w[e];                      // :162
+            p.xmean[off + c] = xm;
+            p.ymean[off + c] = xm / sc;                                                       // :167
+            lym[c] = xm / sc;
+        }
+    } else
     for (int c = tid; c < n; c += nthr) {
         const float mc = p.m[off + c], sc = p.sigma[off + c];
         const float lo_c = p.lo[c % p.U], hi_c = p.hi[c % p.U];     // solution layout [agents][H][U]
@@ -298,6 +326,7 @@ __device__ __forceinline__ void cma_paths_body_t(const CmaArgs& p, int g, float*
         if (STAGE) lym[c] = xm / sc;
     }
     __syncthreads();
+    PATHS_MARK(1);
     // t1 = B^T y_mean ; t2 = t1 / diag(D)   (C^{-1/2} y = B D^{-1} B^T y, :168-169)
     float* t2 = STAGE ? lt2 : p.BD + (size_t)g * n * n;      // BD scratch is free after the sampling GEMM
     const float* __restrict__ B = STAGE ? lB : p.B + (size_t)g * n * n;
@@ -351,6 +380,7 @@ __device__ __forceinline__ void cma_paths_body_t(const CmaArgs& p, int g, float*
         }
     }
     __syncthreads();
+    PATHS_MARK(2);
     const float cs = p.c.c_sigma, cc = p.c.cc;
     const float coef_s = sqrtf((cs * (2.0f - cs)) * p.c.mu_eff);
     const float coef_c = p.c.h_sigma * sqrtf((cc * (2.0f - cc)) * p.c.mu_eff);
@@ -375,6 +405,7 @@ __device__ __forceinline__ void cma_paths_body_t(const CmaArgs& p, int g, float*
             }
         }
     }
+    PATHS_MARK(3);
     if (lane == 0) red[wv] = part;
     __syncthreads();
     if (tid == 0) {
@@ -388,6 +419,12 @@ __device__ __forceinline__ void cma_paths_body_t(const CmaArgs& p, int g, float*
         p.sigma[off + c] = p.sigma[off + c] * fac;
         p.m[off + c] = p.m[off + c] + p.xmean[off + c];                    // :163
     }
+#ifdef BBMPC_KERNEL_DBG
+    if (threadIdx.x == 0 && g == 0 && p.iter == 2) {
+        const long long t1 = (long long)wall_clock64();
+        printf("[paths] stage %lld  Ye/xmean %lld  t2 %lld  rows %lld  norm+update %lld (10 ns)\n", g_paths_dbg[0] - g_paths_dbg[7], g_paths_dbg[1] - g_paths_dbg[0], g_paths_dbg[2] - g_paths_dbg[1], g_paths_dbg[3] - g_paths_dbg[2], t1 - g_paths_dbg[3]);
+    }
+#endif
 }
 __device__ __forceinline__ void cma_paths_body(const CmaArgs& p, int g) { cma_paths_body_t<false>(p, g, nullptr); }
 static __global__ __launch_bounds__(1024) void k_cma_paths(CmaArgs p) { cma_paths_body(p, blockIdx.x); }
