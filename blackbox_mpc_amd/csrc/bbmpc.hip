@@ -814,6 +814,10 @@ void Engine::finalize(const float* d_state_in, int add_noise, float* d_record_ou
     fa.next_state = d_next_out;
     fa.key = key(step);
     fa.key.q_per_agent = (uint32_t)((U + 3) / 4);
+    if (pending_cma_update.set) {                     // (analytic pendulum, CMA-ES at n <= 32: bbmpc_cma.hip)
+        launch_pending_cma_update(fa);
+        return;
+    }
     if (cfg.dynamics == BBMPC_DYN_PENDULUM && !user_path()) {
         if (tail_flag) tail_attached = true;         // the record is complete when this kernel ends: it publishes the sequence number
         hipLaunchKernelGGL(k_finalize_pendulum, dim3((A + 63) / 64), dim3(64), 0, stream, fa, tail_flag, tail_count, tail_value);
@@ -874,6 +878,7 @@ RowMlp Engine::row_mlp() const {
 void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out) {
     REQUIRE(cfg.optimizer != BBMPC_OPT_NONE, BBMPC_E_STATE, "handle was created without an optimizer");
     const uint32_t step = step_counter++;
+    pending_cma_update.set = false;
     if (use_fused()) {
         dominant_kernel = "k_fused_pendulum";
         optimize_fused(d_state_in, add_noise, d_record_out, d_next_out, step);

@@ -151,6 +151,11 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             const size_t yef = (size_t)(n * n + k * n + 2 * n) * sizeof(float) <= 48 * 1024 ? (size_t)(n * n + k * n + 2 * n) : 0;
             const size_t ulds = std::max(std::max(lds, (size_t)n * n * sizeof(float)), yef * sizeof(float));
             want_lds((const void*)k_cma_update_small, ulds, 48 * 1024);
+            if (roll_in && it == iters - 1) {
+                // held back: finalize() launches it together with the tail of the control step (k_cma_update_final_small)
+                want_lds((const void*)k_cma_update_final_small, ulds, 48 * 1024);
+                pending_cma_update.set = true; pending_cma_update.q = q; pending_cma_update.lds = ulds; pending_cma_update.yef = (int)yef;
+            } else
             hipLaunchKernelGGL(k_cma_update_small, dim3(G), dim3(1024), ulds, stream, q, c_evec.p, c_eval.p, c_info.p, sw.cma_eigh_fail ? 1 : 0, (int)yef);
             HIP_CHECK(hipGetLastError());
         } else {
@@ -326,7 +331,17 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             }
         }
     }
+    if (!pending_cma_update.set)
     hipLaunchKernelGGL(k_take_first, dim3((A * U + 63) / 64), dim3(64), 0, stream, A, HU, U, c_m.p, d_action.p);   // :211-212
+    HIP_CHECK(hipGetLastError());
+}
+
+void Engine::launch_pending_cma_update(const FinalArgs& fa) {
+    PendingCmaUpdate pu = pending_cma_update;
+    pending_cma_update.set = false;
+    if (tail_flag) tail_attached = true;
+    launch_with_tail(*this, k_cma_update_final_small, dim3(cma_G), dim3(1024), pu.lds, pu.q, c_evec.p, c_eval.p, c_info.p, sw.cma_eigh_fail ? 1 : 0, pu.yef,
+                     fa, tail_flag, tail_count, tail_value);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -293,6 +293,9 @@ struct Engine {
     bool pop_sharded() const { return cfg.population_global > N || ps_loopback > 1 || ps_force; }
     // ... and over RANKS (the per-iteration exchange goes through the communicator): not the one-GPU splits
     bool pop_sharded_across_ranks() const { return ps_force || (ps_loopback <= 1 && cfg.population_global > N); }
+    // CMA-ES at n <= 32 on the analytic pendulum: the last iteration's update launch is held back until finalize() knows the
+    // record's arguments and then carries the tail of the control step as well (kernels_eigh_small.hpp)
+    struct PendingCmaUpdate { bool set = false; CmaArgs q; size_t lds = 0; int yef = 0; } pending_cma_update;
     int pending_warm = 0;    // learned-dynamics path: warm start the tail kernel performs (kernels_tail.hpp TailArgs::warm_mode)
     RowMlp row_mlp() const;
     bool any_injected() const {
@@ -307,6 +310,7 @@ struct Engine {
 
     void reset();
     void optimize_dev(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out);
+    void launch_pending_cma_update(const FinalArgs& fa);
     bool use_fused_pso() const;
     void optimize_fused_pso(const float* d_state_in, int add_noise, float* d_record_out, float* d_next_out, uint32_t step);
     bool use_fused_cma() const;

@@ -42,13 +42,13 @@ inline void want_lds(const void* fn, size_t bytes, size_t static_bytes = 0) {
 // Launch the last kernel of a control step.  When the caller asked for a completion event (the record all-gather
 // waits on it from its own stream) the event rides on the kernel's own dispatch packet: a separate
 // hipEventRecord costs the launch stream ~5 us per control step (tools/gather_overhead.py).
-template <class F, class Args>
-inline void launch_with_tail(Engine& e, F fn, dim3 grid, dim3 block, size_t lds, const Args& args) {
+template <class F, class... Args>
+inline void launch_with_tail(Engine& e, F fn, dim3 grid, dim3 block, size_t lds, const Args&... args) {
     if (e.tail_event) {
-        hipExtLaunchKernelGGL(fn, grid, block, lds, e.stream, nullptr, e.tail_event, 0, args);
+        hipExtLaunchKernelGGL(fn, grid, block, lds, e.stream, nullptr, e.tail_event, 0, args...);
         e.tail_attached = true;
     } else {
-        hipLaunchKernelGGL(fn, grid, block, lds, e.stream, args);
+        hipLaunchKernelGGL(fn, grid, block, lds, e.stream, args...);
     }
 }
 

@@ -557,5 +557,26 @@ static __global__ __launch_bounds__(1024) void k_cma_update_small(CmaArgs p, flo
 #endif
 }
 
+// the last iteration's update on the analytic pendulum (one agent per instance, dim_U = 1): action = m[0] (cma_es.py:211-212),
+// exploration noise, predicted next state + reward, packed record, completion word (optimizer_base.py:82-94) in the same
+// launch -- k_take_first and k_finalize_pendulum otherwise
+static __global__ __launch_bounds__(1024) void k_cma_update_final_small(CmaArgs p, float* evec, float* eval, int* info, int force_fail, int ye_floats,
+                                                                        FinalArgs fin, unsigned* done_flag, unsigned* done_count, unsigned done_value) {
+    extern __shared__ __attribute__((aligned(16))) float usm[];
+    const int g = blockIdx.x;
+    cma_select_body(p, g, usm);
+    __syncthreads();
+    if (ye_floats) cma_paths_body_t<true>(p, g, usm); else cma_paths_body(p, g);
+    __syncthreads();
+    // the mean is final here: the record does not wait for the covariance and its factorisation
+    if (threadIdx.x == 0) {
+        finalize_pendulum_agent(fin, g, p.m[(size_t)g * p.n]);
+        publish_records_done(done_flag, done_count, done_value, gridDim.x);
+    }
+    cma_cov_small_body(p, g, (size_t)p.k * p.n <= (size_t)ye_floats ? usm : nullptr);
+    __syncthreads();
+    cma_factor_small_body(p, g, evec, eval, info, force_fail != 0, usm);
+}
+
 #endif  // BBMPC_TU_CMA
 }  // namespace bbmpc
