@@ -140,8 +140,11 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             // the analytic pendulum, one agent per instance: the rollouts ride on the sampling launch
             const bool roll_in = !write_back && cfg.dynamics == BBMPC_DYN_PENDULUM && cfg.reward == BBMPC_REW_PENDULUM && cma_G == A && U == 1 && S == 3;
             if (roll_in) {
+                dominant_kernel = "k_cma_sample_roll_small";          // (the launch that carries the rollouts)
+                prof_begin();
                 if (!fix(BBMPC_STRICT_MATH)) hipLaunchKernelGGL(k_cma_sample_roll_small<true>, dim3((N + 63) / 64, G), dim3(256), 0, stream, q, ra.state, ra.fix_q1 ? 1 : 0);
                 else hipLaunchKernelGGL(k_cma_sample_roll_small<false>, dim3((N + 63) / 64, G), dim3(256), 0, stream, q, ra.state, ra.fix_q1 ? 1 : 0);
+                prof_end();
             } else {
                 hipLaunchKernelGGL(k_cma_sample_small, dim3((N + 63) / 64, G), dim3(256), 0, stream, q);
                 ra.cand = d_cand_a.p; ra.samples = write_back ? d_cand_a.p : nullptr; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
