@@ -103,6 +103,7 @@ void Engine::cma_eigh_launch(const CmaArgs& cq) {
     memset(&q, 0, sizeof(q));
     q.n = cma_n; q.G = cma_G;
     q.force_fail = sw.cma_eigh_fail ? 1 : 0;
+    q.jacobi_sync = c_sync.p; q.jacobi_sync_words = CMA_SYNC_WORDS;
     q.C = cq.C; q.B = cq.B; q.Dd = cq.Dd;
     q.d = e_d.p; q.e = e_e.p; q.tau = e_tau.p; q.Vt = e_Vt.p; q.alpha = e_alpha.p; q.lam = e_lam.p;
     q.Z = e_Z.p; q.Z2 = e_Z2.p; q.P = e_P.p; q.Tf = e_Tf.p; q.flags = e_flags.p;
@@ -162,12 +163,16 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             hipLaunchKernelGGL(k_cma_update_small, dim3(G), dim3(1024), ulds, stream, q, c_evec.p, c_eval.p, c_info.p, sw.cma_eigh_fail ? 1 : 0, (int)yef);
             HIP_CHECK(hipGetLastError());
         } else {
-        hipLaunchKernelGGL(k_cma_bd, dim3((unsigned)((gnn + 255) / 256)), dim3(256), 0, stream, q);
+        const bool mfma_y = n > 128 && (n & 3) == 0;              // k_cma_gemm_y_mfma forms B D itself
+        if (!mfma_y) hipLaunchKernelGGL(k_cma_bd, dim3((unsigned)((gnn + 255) / 256)), dim3(256), 0, stream, q);
         want_lds((const void*)k_cma_select, lds, 4096 + 512);       // eidx_s[1024] + the selection's small static words
+        // selection + path update of an unsharded population share a launch (both one workgroup per instance)
+        const bool merge_sp = !pop_sharded() && n > 128;
+        if (merge_sp) want_lds((const void*)k_cma_select_paths, lds, 4096 + 512 + 4 * 512 * 4 + 2 * 4096 + 256);
         // sample -> roll out -> sorted top-k of this handle's particles (part != null: sharded population)
         auto shard_pass = [&](float* part) {
             hipLaunchKernelGGL(k_cma_noise, dim3((N + 255) / 256, HU, A), dim3(256), 0, stream, q);
-            if (n > 128 && (n & 3) == 0) hipLaunchKernelGGL(k_cma_gemm_y_mfma, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
+            if (mfma_y) hipLaunchKernelGGL(k_cma_gemm_y_mfma, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
             else hipLaunchKernelGGL(k_cma_gemm_y, dim3((N + 63) / 64, (n + 63) / 64, G), dim3(256), 0, stream, q);
             HIP_CHECK(hipGetLastError());
             // the clipped candidates go back to the buffer only where somebody reads them whole (the parity trace, the sharded
@@ -176,7 +181,7 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             const bool write_back = trace_on || pop_sharded() || user_path();
             ra.cand = d_cand_a.p; ra.samples = write_back ? d_cand_a.p : nullptr; ra.rewards = d_rewards.p; ra.penalty_out = nullptr;
             launch_rollout(SRC_BUF, true, ra);                          // clip + penalty (cma_es.py:147-157)
-            hipLaunchKernelGGL(k_cma_select, dim3(G), dim3(REFIT_THREADS), lds, stream, q, part);
+            if (part || !merge_sp) hipLaunchKernelGGL(k_cma_select, dim3(G), dim3(REFIT_THREADS), lds, stream, q, part);
             HIP_CHECK(hipGetLastError());
         };
         if (pop_sharded()) {
@@ -209,7 +214,8 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
         } else {
             shard_pass(nullptr);
         }
-        hipLaunchKernelGGL(k_cma_paths, dim3(G), dim3(n > 128 ? 1024 : REFIT_THREADS), 0, stream, q);
+        if (merge_sp) hipLaunchKernelGGL(k_cma_select_paths, dim3(G), dim3(1024), lds, stream, q);
+        else hipLaunchKernelGGL(k_cma_paths, dim3(G), dim3(n > 128 ? 1024 : REFIT_THREADS), 0, stream, q);
         hipLaunchKernelGGL(k_cma_cov, dim3((n + 15) / 16, (n + 15) / 16, G), dim3(16, 16), 0, stream, q);
         HIP_CHECK(hipGetLastError());
         const bool eigh = cma_use_eigh();
@@ -221,7 +227,7 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
                                sw.cma_eigh_fail ? 1 : 0);
         } else if (n <= 512 && !sw.cma_svd_v1) {
             // warm-started Jacobi, one 1024-thread workgroup per instance (kernels_cma.hpp)
-            HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * CMA_SYNC_WORDS * sizeof(unsigned), stream));
+            if (!eigh) HIP_CHECK(hipMemsetAsync(c_sync.p, 0, (size_t)G * CMA_SYNC_WORDS * sizeof(unsigned), stream));      // (with the direct solver: k_eigh_tri_solve clears it)
             if (n > 128 && (n & 3) == 0) hipLaunchKernelGGL(k_cma_warm_mfma, dim3((n + 31) / 32, (n + 63) / 64, G), dim3(256), 0, stream, q, c_evec.p, need);
             else hipLaunchKernelGGL(k_cma_warm, dim3((n + 31) / 32, (n + 31) / 32, G), dim3(256), 0, stream, q, c_evec.p);
             const int bsz = (n + 7) / 8;

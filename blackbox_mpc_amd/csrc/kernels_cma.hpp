@@ -137,13 +137,15 @@ static __global__ __launch_bounds__(256) void k_cma_gemm_y_mfma(CmaArgs p) {
     const int i0 = blockIdx.y * 64 + wave * 16, q0 = blockIdx.x * 64;
     if (i0 >= n) return;
     const int lm = lane & 15, lk = lane >> 4;
-    const float* A = p.BD + (size_t)g * n * n + min(i0 + lm, n - 1);                 // + l * n
+    // B D is formed where it is loaded (the product k_cma_bd would have stored: same bits, one launch fewer)
+    const float* A = p.B + (size_t)g * n * n + min(i0 + lm, n - 1);                  // + l * n
+    const float dsc = p.Dd[(size_t)g * n + min(i0 + lm, n - 1)];
     const float* Z = p.z + (size_t)g * n * p.Nst + q0 + lm;                           // + l * Nst (+ 16 * f); Nst is a multiple of 64
     f4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 5
     for (int l0 = 0; l0 < n; l0 += 4) {
         const int l = l0 + lk;
-        const float a = A[(size_t)l * n];
+        const float a = A[(size_t)l * n] * dsc;
         const float* zr = Z + (size_t)l * p.Nst;
         const float b0 = zr[0], b1 = zr[16], b2 = zr[32], b3 = zr[48];
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
@@ -428,6 +430,13 @@ __device__ __forceinline__ void cma_paths_body_t(const CmaArgs& p, int g, float*
 }
 __device__ __forceinline__ void cma_paths_body(const CmaArgs& p, int g) { cma_paths_body_t<false>(p, g, nullptr); }
 static __global__ __launch_bounds__(1024) void k_cma_paths(CmaArgs p) { cma_paths_body(p, blockIdx.x); }
+// selection and path update of an instance in one launch (both are one workgroup per instance); dynamic LDS: the selection's
+static __global__ __launch_bounds__(1024) void k_cma_select_paths(CmaArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    cma_select_body(p, blockIdx.x, smem, nullptr);
+    __syncthreads();
+    cma_paths_body(p, blockIdx.x);
+}
 
 // C = (1-c1-cmu) C + c1 pC pC^T + cmu sum_i w_i y_i y_i^T on the upper triangle, mirrored (cma_es.py:179-190)
 // grid (ceil(n/16), ceil(n/16), G), block (16,16)

@@ -49,6 +49,8 @@ struct EighArgs {
                          // [1] max |Z^T Z - I| of the twisted vectors, [3] the same after one polish, [2] max residual |(T - lam) z|, [5] |T|
     float* B;            // [G][n][n] out: eigenvectors, columns by descending eigenvalue
     float* Dd;           // [G][n] out: sqrt(eigenvalue)
+    unsigned* jacobi_sync;   // [G][jacobi_sync_words] words of the fall-back Jacobi that have to be zero when it starts: cleared by
+    int jacobi_sync_words;   // k_eigh_tri_solve (a memset launch of its own otherwise), or null
 };
 
 #ifdef BBMPC_TU_CMA      // the kernels are compiled in the CMA-ES translation unit only (csrc/bbmpc_cma.hip, tools/eigh)
@@ -613,6 +615,8 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     }
     const float pivmin = fmaxf(1.0e-30f, tn * tn * 1.0e-30f);
     if (blockIdx.x == 0 && tid == 0) q.flags[(size_t)g * 8 + 5] = __float_as_uint(tn);
+    if (blockIdx.x == 0 && q.jacobi_sync)
+        for (int i = tid; i < q.jacobi_sync_words; i += EIGH_SOLVE_THREADS) q.jacobi_sync[(size_t)g * q.jacobi_sync_words + i] = 0u;
     const int j = blockIdx.x * EIGH_SLOTS_PER_WG + row;           // eigenvalue slot of this wave
     const bool live = j < n;
     // ---- the unreduced block [s, t) around every index: running maximum of the split positions from the left, running
