@@ -740,18 +740,24 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4r(MlpRolloutArgs q) {
     }
 #endif
     // ---- rewards: cost_func.py:5-22 per step, summed in step order (deterministic.py:62-73)
+    // (the H x 4 step rewards by all threads -- each has a division -- then four threads add them up in step order: one
+    // thread per particle walking all of it was 1.5 us at the end of every launch, at a lone wave's issue rate)
+    __syncthreads();
+    float* rstep = h0;                                     // [H][QP]: the activations are dead
+    if (rew_on)
+        for (int e = tid; e < H * QP; e += NT) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(rwd + e * 4);   // (d17, flag 5, flag 6, flag 7) of (step, particle) e
+            float r = 0.0f;
+            r = r + w.y; r = r + w.z; r = r + w.w;
+            r = r + w.x / 0.01f;
+            r = r - zs[e];
+            rstep[e] = r;
+        }
     __syncthreads();
     if (tid < QP) {
         float total = 0.0f;
         if (rew_on)
-            for (int t = 0; t < H; ++t) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(rwd + (t * QP + tid) * 4);   // (d17, flag 5, flag 6, flag 7)
-                float r = 0.0f;
-                r = r + w.y; r = r + w.z; r = r + w.w;
-                r = r + w.x / 0.01f;
-                r = r - zs[t * QP + tid];
-                total = total + r;
-            }
+            for (int t = 0; t < H; ++t) total = total + rstep[t * QP + tid];
         const int n = n0 + tid;
         if (n < p.n_pop) {
             if (total != total) total = -1.0e6f;
