@@ -119,7 +119,7 @@ void Engine::cma_eigh_launch(const CmaArgs& cq) {
     hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, stream, q, (const float*)q.Z, (const float*)q.P, q.Z2, 0, 0);
     hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, stream, q, (const float*)q.Z2, (const float*)nullptr, q.P, 3, 1);
     hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, stream, q, (const float*)q.Z2, (const float*)q.P, q.Z, 0, 1);
-    hipLaunchKernelGGL(k_eigh_backtransform, dim3(EIGH_LD / 16, G), dim3(256), 0, stream, q, (const float*)q.Z, (const float*)q.Z2);
+    hipLaunchKernelGGL(k_eigh_backtransform, dim3(EIGH_LD / 16, G), dim3(EIGH_BT_THREADS), 0, stream, q, (const float*)q.Z, (const float*)q.Z2);
     HIP_CHECK(hipGetLastError());
 }
 

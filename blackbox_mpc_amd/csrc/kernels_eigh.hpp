@@ -966,9 +966,10 @@ __device__ __forceinline__ bool eigh_instance_ok(const EighArgs& q, int g) {
     return !q.force_fail && (g0 <= 0.25f) && (g1 <= 2.0e-3f) && (res <= 1.0e-5f * scale) && (scale < 3.0e38f);
 }
 
-static __global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, const float* __restrict__ Z_two_rounds, const float* __restrict__ Z_one_round) {
+constexpr int EIGH_BT_WAVES = 8, EIGH_BT_THREADS = 64 * EIGH_BT_WAVES, EIGH_BT_UT = (EIGH_LD / 16 + EIGH_BT_WAVES - 1) / EIGH_BT_WAVES;
+static __global__ __launch_bounds__(EIGH_BT_THREADS) void k_eigh_backtransform(EighArgs q, const float* __restrict__ Z_two_rounds, const float* __restrict__ Z_one_round) {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    __shared__ float w1p[4][32][17];            // per-wave partial W1
+    __shared__ float w1p[EIGH_BT_WAVES][32][17];            // per-wave partial W1
     __shared__ float w1[32][17];
     __shared__ float w2[32][17];
     __shared__ float tf[32][33];
@@ -984,28 +985,64 @@ static __global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, c
     const bool one_round = __uint_as_float(q.flags[(size_t)g * 8 + 1]) <= EIGH_ONE_ROUND;
     const float* Z = (one_round ? Z_one_round : Z_two_rounds) + (size_t)g * EIGH_LD * EIGH_LD;
     const float* Vt = q.Vt + (size_t)g * EIGH_LD * EIGH_LD;
-    // slab: wave w owns row tiles w, w + 4, ..., w + 16
-    f4 zs[5];
+    // slab: wave w owns row tiles w, w + 8, w + 16 (eight waves: the block loop is matrix-issue bound per SIMD, and a
+    // slab of sixteen columns cannot be cut any narrower)
+    constexpr int UT = EIGH_BT_UT, NWV = EIGH_BT_WAVES, NTH = EIGH_BT_THREADS;
+    f4 zs[UT];
 #pragma unroll
-    for (int u = 0; u < 5; ++u) {
-        const int i0 = 16 * (wave + 4 * u);
+    for (int u = 0; u < UT; ++u) {
+        const int i0 = 16 * min(wave + NWV * u, EIGH_LD / 16 - 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) zs[u][r] = Z[(size_t)(i0 + 4 * lk + r) * EIGH_LD + j0 + lm];
     }
+#ifdef EIGH_CLK
+    const long long bt0 = (long long)__builtin_readcyclecounter();
+#endif
     const int nblk = (n - 2 + 31) / 32;
+    // The reflector block and its T factor are loaded one block AHEAD, into registers: a block is three small products with
+    // barriers in between, and as written first (loads where they are used) each of the ten blocks waited twice for L2
+    // (44 us per launch, the matrix cores 5 % busy).  va / vb: rows 32 b + lm and 32 b + 16 + lm of V^T, four columns per
+    // tile (the A operands of W1 = V^T Zs); vu: V^T[32 b + k0 + lk][i0 + lm] (the A operands of Zs -= V W2); tfr: four
+    // elements of T per thread.
+    float4 va[UT], vb[UT];
+    float vu[UT][8], tfr[1024 / NTH];
+    auto load_block = [&](int b) {
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const int i0 = 16 * min(wave + NWV * u, EIGH_LD / 16 - 1);
+            va[u] = *reinterpret_cast<const float4*>(Vt + (size_t)(32 * b + lm) * EIGH_LD + i0 + 4 * lk);
+            vb[u] = *reinterpret_cast<const float4*>(Vt + (size_t)(32 * b + 16 + lm) * EIGH_LD + i0 + 4 * lk);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) vu[u][kk] = Vt[(size_t)(32 * b + 4 * kk + lk) * EIGH_LD + i0 + lm];
+        }
+#pragma unroll
+        for (int c = 0; c < 1024 / NTH; ++c) tfr[c] = q.Tf[((size_t)g * EIGH_TF_WGS + b) * 1024 + tid + NTH * c];
+    };
+    load_block(nblk - 1);
+#ifdef EIGH_CLK
+    const long long bt1 = (long long)__builtin_readcyclecounter();
+#endif
     for (int b = nblk - 1; b >= 0; --b) {
         const int first_tile = (32 * b + 1) / 16;                  // reflector 32 b has its leading 1 in row 32 b + 1
-        // T factor of the block
-        for (int idx = tid; idx < 32 * 32; idx += 256) tf[idx >> 5][idx & 31] = q.Tf[((size_t)g * EIGH_TF_WGS + b) * 1024 + idx];
+        // this block's operands out of the prefetch registers (tf is read after the next two barriers only)
+        float4 ca[UT], cb[UT];
+        float cu[UT][8];
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            ca[u] = va[u]; cb[u] = vb[u];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) cu[u][kk] = vu[u][kk];
+        }
+#pragma unroll
+        for (int c = 0; c < 1024 / NTH; ++c) { const int idx = tid + NTH * c; tf[idx >> 5][idx & 31] = tfr[c]; }
+        if (b > 0) load_block(b - 1);
         // ---- W1 partial of this wave
         f4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int tile = wave + 4 * u, i0 = 16 * tile;
-            if (tile < first_tile) continue;
-            const float4 va = *reinterpret_cast<const float4*>(Vt + (size_t)(32 * b + lm) * EIGH_LD + i0 + 4 * lk);
-            const float4 vb = *reinterpret_cast<const float4*>(Vt + (size_t)(32 * b + 16 + lm) * EIGH_LD + i0 + 4 * lk);
-            const float a0[4] = {va.x, va.y, va.z, va.w}, a1[4] = {vb.x, vb.y, vb.z, vb.w};
+        for (int u = 0; u < UT; ++u) {
+            const int tile = wave + NWV * u;
+            if (tile < first_tile || tile >= EIGH_LD / 16) continue;
+            const float a0[4] = {ca[u].x, ca[u].y, ca[u].z, ca[u].w}, a1[4] = {cb[u].x, cb[u].y, cb[u].z, cb[u].w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], zs[u][r], p0, 0, 0, 0);
@@ -1014,12 +1051,15 @@ static __global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, c
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { w1p[wave][4 * lk + r][lm] = p0[r]; w1p[wave][16 + 4 * lk + r][lm] = p1[r]; }
-        __syncthreads();
-        for (int idx = tid; idx < 32 * 16; idx += 256) {
+        eigh_lds_barrier();                                     // (LDS only: __syncthreads would wait for the prefetch too)
+        for (int idx = tid; idx < 32 * 16; idx += NTH) {
             const int a = idx >> 4, c = idx & 15;
-            w1[a][c] = (w1p[0][a][c] + w1p[1][a][c]) + (w1p[2][a][c] + w1p[3][a][c]);
+            float acc = w1p[0][a][c];
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) acc = acc + w1p[w][a][c];
+            w1[a][c] = acc;
         }
-        __syncthreads();
+        eigh_lds_barrier();                                     // (LDS only: __syncthreads would wait for the prefetch too)
         // ---- W2 = T W1 (wave 0 and 1: one 16-row half each)
         if (wave < 2) {
             f4 o = {0.f, 0.f, 0.f, 0.f};
@@ -1028,25 +1068,26 @@ static __global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, c
 #pragma unroll
             for (int r = 0; r < 4; ++r) w2[16 * wave + 4 * lk + r][lm] = o[r];
         }
-        __syncthreads();
+        eigh_lds_barrier();                                     // (LDS only: __syncthreads would wait for the prefetch too)
         // ---- Zs -= V W2
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int tile = wave + 4 * u, i0 = 16 * tile;
-            if (tile < first_tile) continue;
+        for (int u = 0; u < UT; ++u) {
+            const int tile = wave + NWV * u;
+            if (tile < first_tile || tile >= EIGH_LD / 16) continue;
 #pragma unroll
-            for (int k0 = 0; k0 < 32; k0 += 4) {
-                const float a = Vt[(size_t)(32 * b + k0 + lk) * EIGH_LD + i0 + lm];
-                zs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a, w2[k0 + lk][lm], zs[u], 0, 0, 0);
-            }
+            for (int kk = 0; kk < 8; ++kk)
+                zs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(-cu[u][kk], w2[4 * kk + lk][lm], zs[u], 0, 0, 0);
         }
-        __syncthreads();
+        eigh_lds_barrier();                                     // (LDS only: __syncthreads would wait for the prefetch too)
     }
+#ifdef EIGH_CLK
+    const long long bt2 = (long long)__builtin_readcyclecounter();
+#endif
     // ---- ranks of this slab's eigenvalues, D, B
     const float alpha = q.alpha[g];
-    for (int i = tid; i < EIGH_LD; i += 256) s_lam[i] = q.lam[(size_t)g * EIGH_LD + i];
+    for (int i = tid; i < EIGH_LD; i += NTH) s_lam[i] = q.lam[(size_t)g * EIGH_LD + i];
     __syncthreads();
-    {
+    if (tid < 256) {
         // 16 lanes per slot count the eigenvalues ahead of it
         const int slot = tid >> 4, sub = tid & 15, j = j0 + slot;
         const float lj = s_lam[j];
@@ -1063,8 +1104,9 @@ static __global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, c
     if (j0 + lm < n) {
         float* B = q.B + (size_t)g * n * n + s_rank[lm];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int i0 = 16 * (wave + 4 * u);
+        for (int u = 0; u < UT; ++u) {
+            if (wave + NWV * u >= EIGH_LD / 16) continue;
+            const int i0 = 16 * (wave + NWV * u);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + 4 * lk + r;
@@ -1072,6 +1114,9 @@ static __global__ __launch_bounds__(256) void k_eigh_backtransform(EighArgs q, c
             }
         }
     }
+#ifdef EIGH_CLK
+    if (blockIdx.x == 3 && blockIdx.y == 1 && tid == 0) printf("[back] slab load %lld  blocks %lld  ranks+store %lld cycles\n", bt1 - bt0, bt2 - bt1, (long long)__builtin_readcyclecounter() - bt2);
+#endif
 }
 
 #endif  // BBMPC_TU_CMA

@@ -136,7 +136,7 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, 0, q, (const float*)q.Z, (const float*)q.P, q.Z2, 0, 0);
         hipLaunchKernelGGL(k_eigh_gemm<0>, gg, dim3(256), 0, 0, q, (const float*)q.Z2, (const float*)nullptr, q.P, 3, 1);
         hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, 0, q, (const float*)q.Z2, (const float*)q.P, q.Z, 0, 1);
-        hipLaunchKernelGGL(k_eigh_backtransform, dim3(EIGH_LD / 16, G), dim3(256), 0, 0, q, (const float*)q.Z, (const float*)q.Z2);
+        hipLaunchKernelGGL(k_eigh_backtransform, dim3(EIGH_LD / 16, G), dim3(EIGH_BT_THREADS), 0, 0, q, (const float*)q.Z, (const float*)q.Z2);
     };
     for (int rep = 0; rep < 3; ++rep) {
         // (the polish overwrites Z: run the whole pipeline per repetition)
@@ -158,7 +158,7 @@ int main(int argc, char** argv) {
             CK(hipEventRecord(f[1]));
             hipLaunchKernelGGL(k_eigh_gemm<1>, gg, dim3(256), 0, 0, q, (const float*)q.Z, (const float*)q.P, q.Z2, 0, 0);
             CK(hipEventRecord(f[2]));
-            hipLaunchKernelGGL(k_eigh_backtransform, dim3(EIGH_LD / 16, G), dim3(256), 0, 0, q, (const float*)q.Z, (const float*)q.Z2);
+            hipLaunchKernelGGL(k_eigh_backtransform, dim3(EIGH_LD / 16, G), dim3(EIGH_BT_THREADS), 0, 0, q, (const float*)q.Z, (const float*)q.Z2);
             CK(hipEventRecord(f[3])); CK(hipEventSynchronize(f[3]));
             float a, b, c; CK(hipEventElapsedTime(&a, f[0], f[1])); CK(hipEventElapsedTime(&b, f[1], f[2])); CK(hipEventElapsedTime(&c, f[2], f[3]));
             if (rep == 2) printf("   single launches: gram %.1f  multiply %.1f  backtransform %.1f us\n", a * 1e3, b * 1e3, c * 1e3);
