@@ -199,6 +199,7 @@ __device__ __attribute__((noinline)) bool cma_eigh_small_body(const CmaArgs& p, 
         const int s = live ? L.bs[j] : 0, t = live ? L.bt[j] : 1;
         const int m = (live ? j : 0) - s;
         float lo = L.gl, hi = L.gu;
+        const bool whole_w = __all(!live || (s == 0 && t == n)) != 0;
         if (t - s > 1) {
             const float4* dd4 = reinterpret_cast<const float4*>(L.dd);
             const float4* e24 = reinterpret_cast<const float4*>(L.e2p);
@@ -209,6 +210,29 @@ __device__ __attribute__((noinline)) bool cma_eigh_small_body(const CmaArgs& p, 
                 int cnt = 0;
                 float qv = 1.0f;
                 float4 dA = dd4[0], eA = e24[0];
+                if (whole_w) {
+                    // every slot of the wave belongs to the one unreduced block [0, n) (the usual case once C has left the
+                    // identity): no range test on the chain -- with four waves per SIMD the phase is issue bound
+                    for (int i4 = 0; i4 < (n >> 2); ++i4) {
+                        const float4 dB = dd4[i4 + 1], eB = e24[i4 + 1];
+                        const float dx4[4] = {dA.x - x, dA.y - x, dA.z - x, dA.w - x}, ev4[4] = {eA.x, eA.y, eA.z, eA.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            qv = fmaf(-ev4[c], __builtin_amdgcn_rcpf(qv), dx4[c]);
+                            cnt += qv < 0.0f ? 1 : 0;
+                        }
+                        dA = dB; eA = eB;
+                    }
+                    {
+                        const float dx4[4] = {dA.x - x, dA.y - x, dA.z - x, dA.w - x}, ev4[4] = {eA.x, eA.y, eA.z, eA.w};
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            if (c < (n & 3)) {                                         // (uniform)
+                                qv = fmaf(-ev4[c], __builtin_amdgcn_rcpf(qv), dx4[c]);
+                                cnt += qv < 0.0f ? 1 : 0;
+                            }
+                    }
+                } else
                 for (int i4 = 0; i4 < n4; ++i4) {
                     const float4 dB = dd4[i4 + 1], eB = e24[i4 + 1];
                     const float dx4[4] = {dA.x - x, dA.y - x, dA.z - x, dA.w - x}, ev4[4] = {eA.x, eA.y, eA.z, eA.w};
