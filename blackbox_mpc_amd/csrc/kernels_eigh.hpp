@@ -663,6 +663,19 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
             int cnt = 0;
             float qv = 1.0f;
             float4 dA = dd4[0], eA = e24[0];
+            if (s == 0 && t == n && (n & 3) == 0) {
+                // the slot's block is the whole matrix (the usual case once C has left the identity): no range test
+                for (int i4 = 0; i4 < n4; ++i4) {
+                    const float4 dB = dd4[i4 + 1], eB = e24[i4 + 1];
+                    const float dv[4] = {dA.x, dA.y, dA.z, dA.w}, ev[4] = {eA.x, eA.y, eA.z, eA.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        qv = (dv[c] - x) - ev[c] * __builtin_amdgcn_rcpf(qv);
+                        cnt += qv < 0.0f ? 1 : 0;
+                    }
+                    dA = dB; eA = eB;
+                }
+            } else
             for (int i4 = 0; i4 < n4; ++i4) {
                 const float4 dB = dd4[i4 + 1], eB = e24[i4 + 1];  // (one group ahead; the arrays are followed by more LDS)
                 const float dv[4] = {dA.x, dA.y, dA.z, dA.w}, ev[4] = {eA.x, eA.y, eA.z, eA.w};
