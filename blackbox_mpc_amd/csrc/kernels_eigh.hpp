@@ -670,7 +670,7 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
                     const float dv[4] = {dA.x, dA.y, dA.z, dA.w}, ev[4] = {eA.x, eA.y, eA.z, eA.w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        qv = (dv[c] - x) - ev[c] * __builtin_amdgcn_rcpf(qv);
+                        qv = fmaf(-ev[c], __builtin_amdgcn_rcpf(qv), dv[c] - x);   // (two instructions on the chain)
                         cnt += qv < 0.0f ? 1 : 0;
                     }
                     dA = dB; eA = eB;
@@ -734,7 +734,7 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
                     out[i0 + dir * (st + c)] = piv;
                     float rp = __builtin_amdgcn_rcpf(piv);
                     rp = rp * fmaf(-piv, rp, 2.0f);     // one Newton step: with 1-ulp quotients the vectors come out 10x less orthogonal
-                    piv = (dn[c] - lam) - (ec[c] * rp) * ec[c];
+                    piv = fmaf(-(ec[c] * ec[c]), rp, dn[c] - lam);      // (e^2 and d - lam do not wait for the chain)
                 }
             }
 #pragma unroll
