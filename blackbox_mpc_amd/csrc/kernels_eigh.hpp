@@ -529,6 +529,7 @@ constexpr int EIGH_SLOT_WGS = EIGH_LD / EIGH_SLOTS_PER_WG, EIGH_TF_WGS = EIGH_LD
 static_assert(EIGH_SLOTS_PER_WG == 4, "k_eigh_tri_solve writes the four slots of a workgroup as one float4 per row");
 
 struct EighSolveLds {
+    float pad_front[8];         // (the recurrences below read a few entries past a block's ends instead of clamping indices)
     float dd[EIGH_LD];          // d
     float ee[EIGH_LD];          // thresholded e (ee[k] couples k, k + 1)
     float e2p[EIGH_LD];         // e2p[i] = ee[i-1]^2 (0 for i = 0)
@@ -709,29 +710,27 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     // next diagonal entries) are loaded before the chain of the current four steps: as plain code every step waited for
     // two LDS round trips behind the store of its own pivot (390 cycles per step measured, 4/5 of it LDS latency)
     if (lane < 2) {
+        // (every instruction of these loops is issued in order in front of the chain's next link: running pointers, no index
+        // clamps -- the loads run up to eight entries past the block's end, inside the LDS structure, and are not used --,
+        // a scalar trip count)
         const bool fwd = lane == 0;
         const int dir = fwd ? 1 : -1, i0 = fwd ? s : t - 1;
+        const int ulen = __builtin_amdgcn_readfirstlane(len);
         float piv = L.dd[i0] - lam;
-        float* out = fwd ? fw : bw;
-        float ec[4], dn[4];
-        auto load4 = [&](int st, float (&e4)[4], float (&d4)[4]) {
+        float* po = (fwd ? fw : bw) + i0;
+        const float* pe = L.ee + i0 + (fwd ? 0 : -1);                   // coupling of index i0 + dir k to its successor
+        const float* pd = L.dd + i0 + dir;                              // the successor's diagonal entry
+        const int d2 = 2 * dir, d3 = 3 * dir, d4 = 4 * dir;
+        float ec[4] = {pe[0], pe[dir], pe[d2], pe[d3]}, dn[4] = {pd[0], pd[dir], pd[d2], pd[d3]};
+        for (int st = 0; st < ulen; st += 4) {
+            pe += d4; pd += d4;
+            const float en[4] = {pe[0], pe[dir], pe[d2], pe[d3]}, dq[4] = {pd[0], pd[dir], pd[d2], pd[d3]};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int i = i0 + dir * (st + c);                              // current index of that step
-                const bool ok = st + c + 1 < len;                               // it has a successor
-                const int ic = ok ? (fwd ? i : i - 1) : s, in = ok ? i + dir : s;
-                e4[c] = L.ee[ic]; d4[c] = L.dd[in];
-            }
-        };
-        load4(0, ec, dn);
-        for (int st = 0; st < len; st += 4) {
-            float en[4], dq[4];
-            load4(st + 4, en, dq);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (st + c < len) {
+                if (st + c < ulen) {
                     piv = fabsf(piv) < pivmin ? -pivmin : piv;
-                    out[i0 + dir * (st + c)] = piv;
+                    *po = piv;
+                    po += dir;
                     float rp = __builtin_amdgcn_rcpf(piv);
                     rp = rp * fmaf(-piv, rp, 2.0f);     // one Newton step: with 1-ulp quotients the vectors come out 10x less orthogonal
                     piv = fmaf(-(ec[c] * ec[c]), rp, dn[c] - lam);      // (e^2 and d - lam do not wait for the chain)
@@ -764,27 +763,22 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     if (lane < 2) {
         const bool up = lane == 0;
         const int cnt_z = up ? r - s : t - 1 - r;                    // steps of this direction
-        float* arr = up ? fw : bw;
-        auto load4 = [&](int st, float (&e4)[4], float (&p4)[4]) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const bool ok = st + c < cnt_z;
-                const int i = up ? r - 1 - (st + c) : r + (st + c);  // coupling index e_i; pivot index: i (up) or i + 1 (down)
-                e4[c] = L.ee[ok ? i : s]; p4[c] = arr[ok ? (up ? i : i + 1) : s];
-            }
-        };
-        float z = 1.0f, ec[4], pv[4];
-        load4(0, ec, pv);
+        const int d = up ? -1 : 1, d2 = 2 * d, d3 = 3 * d, d4 = 4 * d;
+        float* pa = (up ? fw : bw) + (up ? r - 1 : r + 1);           // pivot of step 0, replaced by z
+        const float* pe = L.ee + (up ? r - 1 : r);                   // its coupling
+        float z = 1.0f;
+        float ec[4] = {pe[0], pe[d], pe[d2], pe[d3]}, pv[4] = {pa[0], pa[d], pa[d2], pa[d3]};
         for (int st = 0; st < cnt_z; st += 4) {
-            float en[4], pn[4];
-            load4(st + 4, en, pn);
+            pe += d4;
+            const float en[4] = {pe[0], pe[d], pe[d2], pe[d3]}, pn[4] = {pa[d4], pa[d4 + d], pa[d4 + d2], pa[d4 + d3]};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (st + c < cnt_z) {
                     float rp = __builtin_amdgcn_rcpf(pv[c]);
                     rp = rp * fmaf(-pv[c], rp, 2.0f);
                     z = -(ec[c] * rp) * z;
-                    arr[up ? r - 1 - (st + c) : r + (st + c) + 1] = z;
+                    *pa = z;
+                    pa += d;
                 }
             }
 #pragma unroll
