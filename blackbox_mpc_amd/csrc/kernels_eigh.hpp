@@ -620,32 +620,24 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
         for (int i = tid; i < q.jacobi_sync_words; i += EIGH_SOLVE_THREADS) q.jacobi_sync[(size_t)g * q.jacobi_sync_words + i] = 0u;
     const int j = blockIdx.x * EIGH_SLOTS_PER_WG + row;           // eigenvalue slot of this wave
     const bool live = j < n;
-    // ---- the unreduced block [s, t) around every index: running maximum of the split positions from the left, running
-    // minimum from the right (log-step scans over the 320 entries, two per thread)
-    for (int i = tid; i < EIGH_LD; i += EIGH_SOLVE_THREADS) {
-        L.bs[i] = (short)((i == 0 || i >= n || L.ee[i - 1] == 0.0f) ? i : 0);
-        L.bt[i] = (short)((i >= n - 1 || L.ee[i] == 0.0f) ? i + 1 : EIGH_LD);
-    }
-    __syncthreads();
-    for (int off = 1; off < EIGH_LD; off <<= 1) {
-        short vs[2], vt[2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int i = tid + it * EIGH_SOLVE_THREADS;
-            if (i < EIGH_LD) {
-                vs[it] = i >= off ? max(L.bs[i], L.bs[i - off]) : L.bs[i];
-                vt[it] = i + off < EIGH_LD ? min(L.bt[i], L.bt[i + off]) : L.bt[i];
-            }
+    // ---- the unreduced block [s, t) around this wave's slot: the wave looks for the nearest zero coupling below j (64
+    // positions per ballot, downwards) and at or above j (upwards) -- no barrier; log-step scans for every index, which
+    // only the four slots of the workgroup were read from, took eighteen
+    int s = 0, t = 1;
+    if (live) {
+        s = 0;
+        for (int b = j; b > 0; b -= 64) {                        // split between i - 1 and i, i = b - lane: the block starts at i
+            const int i = b - lane;
+            const unsigned long long hit = __ballot(i > 0 && L.ee[i - 1] == 0.0f);
+            if (hit) { s = b - (int)__builtin_ctzll(hit); break; }
         }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int i = tid + it * EIGH_SOLVE_THREADS;
-            if (i < EIGH_LD) { L.bs[i] = vs[it]; L.bt[i] = vt[it]; }
+        t = n;
+        for (int b = j; b < n - 1; b += 64) {                    // split between i and i + 1, i = b + lane: the block ends behind i
+            const int i = b + lane;
+            const unsigned long long hit = __ballot(i < n - 1 && L.ee[i] == 0.0f);
+            if (hit) { t = b + (int)__builtin_ctzll(hit) + 1; break; }
         }
-        __syncthreads();
     }
-    const int s = live ? (int)L.bs[j] : 0, t = live ? (int)L.bt[j] : 1;
     const int m = (live ? j : 0) - s;
     SOLVE_MARK(0);
     // ---- multisection: the wave's 64 lanes try 64 shifts per pass, five passes of 65-fold narrowing (65^5 = 1.2e9: the
