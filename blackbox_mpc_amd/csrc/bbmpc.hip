@@ -1628,15 +1628,16 @@ cma_names:
         }
     }
     REQUIRE(src, BBMPC_E_INVALID, "unknown state tensor '" + name + "'");
-    REQUIRE(count == (int64_t)nm, BBMPC_E_INVALID, "state tensor has A*H*U elements");
+    REQUIRE(count == (int64_t)nm, BBMPC_E_INVALID, "state tensor has A*H*U elements (C: G*n*n)");
     HIP_CHECK(hipMemcpy(out, src, nm * 4, hipMemcpyDeviceToHost));
 }
 
 void Engine::set_state(const std::string& name, const float* data, int64_t count) {
     HIP_CHECK(hipStreamSynchronize(stream));
-    const size_t nm = (size_t)A * HU;
+    size_t nm = (size_t)A * HU;
     float* dst = nullptr;
     if (name == "prev_mean") dst = d_prev_mean.p;
+    else if (name == "C" && cfg.optimizer == BBMPC_OPT_CMAES) { dst = c_C.p; nm = (size_t)cma_G * cma_n * cma_n; }   // (tests: a covariance at another scale)
     else if (name == "var0") { dst = d_var0.p; pi2_dist_ready = false; }
     cem_sigma0_ready = false;                  // (sigma0 follows prev_mean and var0)
     REQUIRE(dst, BBMPC_E_INVALID, "unknown/unsettable state tensor '" + name + "'");

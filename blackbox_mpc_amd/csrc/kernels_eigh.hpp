@@ -656,18 +656,34 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
             int cnt = 0;
             float qv = 1.0f;
             float4 dA = dd4[0], eA = e24[0];
-            if (s == 0 && t == n && (n & 3) == 0) {
-                // the slot's block is the whole matrix (the usual case once C has left the identity): no range test
+            if (s == 0 && t == n && (n & 3) == 0 && tn > 0.00390625f && tn < 256.0f) {
+                // the slot's block is the whole matrix (the usual case once C has left the identity) and |T| is within 2^+-8 (any
+                // other scale takes the quotient form below, which has no range to mind).  Sturm sequence without
+                // the division: p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2} is ONE dependent fma per step (the quotient form
+                // q_i = p_i / p_{i-1} waits ~70 cycles for v_rcp_f32 + fma), a negative pivot is a sign change p_{i-1} -> p_i,
+                // an exact zero counts as one (it becomes a tiny value of the opposite sign: the pivmin rule), and the pair is
+                // rescaled by a power of two every eight steps (|q| ~ |T|: 2^+-64 between rescalings, 2^-24 more next to a root)
+                float p0 = 0.0f, p1 = 1.0f;                                   // p_{i-2}, p_{i-1}
+                unsigned sg = 0u;                                              // the signs of p_{i-1}, p_i, ... (newest in bit 0)
                 for (int i4 = 0; i4 < n4; ++i4) {
                     const float4 dB = dd4[i4 + 1], eB = e24[i4 + 1];
                     const float dv[4] = {dA.x, dA.y, dA.z, dA.w}, ev[4] = {eA.x, eA.y, eA.z, eA.w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        qv = fmaf(-ev[c], __builtin_amdgcn_rcpf(qv), dv[c] - x);   // (two instructions on the chain)
-                        cnt += qv < 0.0f ? 1 : 0;
+                        float pn = fmaf(dv[c] - x, p1, -(ev[c] * p0));
+                        pn = fmaf(p1, -5.4210109e-20f, pn);                    // an exact zero becomes -2^-64 p_{i-1}; else a no-op
+                        sg = __builtin_amdgcn_alignbit(sg, __float_as_uint(pn), 31);
+                        p0 = p1; p1 = pn;
+                    }
+                    if (i4 & 1) {
+                        cnt += __popc((sg ^ (sg >> 1)) & 0xFFu);
+                        // |p1| back to [1, 2): exact scaling of both, the signs and the ratio are untouched
+                        const int ex = 1 - __builtin_amdgcn_frexp_expf(p1);
+                        p1 = __builtin_amdgcn_ldexpf(p1, ex); p0 = __builtin_amdgcn_ldexpf(p0, ex);
                     }
                     dA = dB; eA = eB;
                 }
+                if (n4 & 1) cnt += __popc((sg ^ (sg >> 1)) & 0xFu);
             } else
             for (int i4 = 0; i4 < n4; ++i4) {
                 const float4 dB = dd4[i4 + 1], eB = e24[i4 + 1];  // (one group ahead; the arrays are followed by more LDS)

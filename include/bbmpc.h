@@ -281,7 +281,8 @@ int bbmpc_dump_noise(bbmpc_handle h, int32_t kind, int32_t control_step, int32_t
 int bbmpc_set_trace(bbmpc_handle h, int32_t enabled);
 int bbmpc_get_trace(bbmpc_handle h, int32_t iteration, int32_t item, void* out, int64_t bytes);
 /* Read / write optimizer state tensors by name ("mean","var","pos","vel","pbest","pbest_r",
- * "gbest","gbest_r","m","sigma","C","B","D","p_sigma","p_C"), reference layout. */
+ * "gbest","gbest_r","m","sigma","C","B","D","p_sigma","p_C"), reference layout.  Settable: "prev_mean", "var0",
+ * and with CMA-ES "C" (G*n*n). */
 int bbmpc_get_state(bbmpc_handle h, const char* name, float* out, int64_t count);
 int bbmpc_set_state(bbmpc_handle h, const char* name, const float* data, int64_t count);
 

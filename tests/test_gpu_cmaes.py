@@ -255,6 +255,33 @@ def test_direct_eigensolver_over_a_closed_loop(L):
         assert _check_factorisation(eng, L, A, n, iters, 5e-6) <= 5e-6
 
 
+@pytest.mark.parametrize("scale", [1.0e-5, 3.0e4])
+def test_direct_eigensolver_at_other_scales(L, scale):
+    # the multisection's division-free Sturm sequence is taken for |T| within 2^+-8 only (kernels_eigh.hpp); a covariance
+    # far above that scale goes through the quotient form -- still the direct solver (word 15 == 0), the same invariants
+    # relative to |C|.  The small scale is a different animal: the update adds its O(c1 + cmu) rank-40 terms to 1e-5 C, i.e.
+    # 260 eigenvalues within 1e-5 of each other under a norm of 1e-2 -- the direct solver's vectors fail its own checks
+    # there (as they did with the quotient form) and the block Jacobi takes over; what is asserted is the factorisation.
+    A, n, iters = 2, 300, 5
+    eng, state = _config5_cma_engine(L, A)
+    for step in range(2):
+        act, state, rew = eng.optimize(state)
+    eng.set_state("C", eng.get_state("C", (A, n, n)) * np.float32(scale))
+    act, state, rew = eng.optimize(state)
+    st = eng.get_trace(0, L.TRACE_CMA_SVD_STATS)
+    if scale > 1.0:
+        assert np.all(st[:, 15] == 0), st
+    tol = 5e-6 if scale > 1.0 else 5e-5
+    B = eng.get_trace(0, L.TRACE_CMA_B).astype(np.float64)
+    C = eng.get_trace(0, L.TRACE_CMA_C).astype(np.float64)
+    D = eng.get_trace(0, L.TRACE_CMA_D).astype(np.float64)
+    for g in range(A):
+        cn = np.abs(np.linalg.eigvalsh(C[g])).max()
+        assert (cn > 1024.0) if scale > 1.0 else (cn < 0.1), cn
+        assert np.abs(B[g] @ np.diag(D[g] ** 2) @ B[g].T - C[g]).max() <= tol * max(cn, 1.0)
+        assert np.abs(B[g].T @ B[g] - np.eye(n)).max() <= tol
+
+
 def test_direct_eigensolver_failure_hands_over_to_the_jacobi(L, monkeypatch):
     # BBMPC_CMA_EIGH_FAIL: the direct solver reports failure for every instance -> B, D must come from the block Jacobi
     # (rotations counted, word 15 == 1) and still factorise C; the same control steps as the direct path within the
