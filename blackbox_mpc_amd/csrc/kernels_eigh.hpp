@@ -543,6 +543,9 @@ __device__ __forceinline__ float row16_max(float v) { return -row16_min(-v); }
 
 __device__ __forceinline__ void eigh_tfactor_block(const EighArgs& q, int g, int b, float* smem);
 
+#ifndef EIGH_MS_PASSES
+#define EIGH_MS_PASSES 5
+#endif
 static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(EighArgs q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char eigh_smem2[];
     const int g = blockIdx.y, tid = threadIdx.x, n = q.n;
@@ -650,7 +653,7 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
         const float4* dd4 = reinterpret_cast<const float4*>(L.dd);
         const float4* e24 = reinterpret_cast<const float4*>(L.e2p);
         const int n4 = (n + 3) >> 2;                              // (entries beyond n are zero and lie outside every block)
-        for (int pass = 0; pass < 5; ++pass) {
+        for (int pass = 0; pass < EIGH_MS_PASSES; ++pass) {
             const float h = (hi - lo) * (1.0f / 65.0f);
             const float x = fmaf((float)(lane + 1), h, lo);
             int cnt = 0;
