@@ -529,12 +529,13 @@ constexpr int EIGH_SLOT_WGS = EIGH_LD / EIGH_SLOTS_PER_WG, EIGH_TF_WGS = EIGH_LD
 static_assert(EIGH_SLOTS_PER_WG == 4, "k_eigh_tri_solve writes the four slots of a workgroup as one float4 per row");
 
 struct EighSolveLds {
-    float pad_front[8];         // (the recurrences below read a few entries past a block's ends instead of clamping indices)
+    float pad_front[16];        // (the recurrences below read a few entries past a block's ends instead of clamping indices)
     float dd[EIGH_LD];          // d
     float ee[EIGH_LD];          // thresholded e (ee[k] couples k, k + 1)
     float e2p[EIGH_LD];         // e2p[i] = ee[i-1]^2 (0 for i = 0)
-    float fw[EIGH_SLOTS_PER_WG][EIGH_LD + 4];  // per slot: D+ pivots, then the upper part of z
-    float bw[EIGH_SLOTS_PER_WG][EIGH_LD + 4];  // per slot: D- pivots, then the lower part of z
+    float fw[EIGH_SLOTS_PER_WG][EIGH_LD + 24]; // per slot (8 entries of padding in front): D+ pivots / the p sequence, then the upper part of z
+    float bw[EIGH_SLOTS_PER_WG][EIGH_LD + 24]; // per slot: D- pivots / the backward sequence, then the lower part of z
+    int px[EIGH_SLOTS_PER_WG][2][EIGH_LD / 8 + 2];  // power-of-two rescalings of the two sequences, one per eight steps
     float red[8];
     short bs[EIGH_LD], bt[EIGH_LD];   // unreduced block [bs[i], bt[i]) around index i
 };
@@ -714,9 +715,106 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     SOLVE_MARK(1);
     const float lam = 0.5f * (lo + hi);
     // ---- twisted factorisation of T - lam on [s, t)
-    float* fw = L.fw[row];
-    float* bw = L.bw[row];
+    float* fw = L.fw[row] + 8;
+    float* bw = L.bw[row] + 8;
     const int len = t - s;
+    int r;
+    float gmin = 3.0e38f;
+    if (tn > 0.00390625f && tn < 256.0f) {
+        // ---- |T| within 2^+-8: D+_i = p_i / p_{i-1} and D-_i = q_i / q_{i+1} from the two three-term sequences
+        //   p_i = (d_i - lam) p_{i-1} - e_{i-1}^2 p_{i-2},  q_i = (d_i - lam) q_{i+1} - e_i^2 q_{i+2}
+        // one dependent fma per step on lanes 0 / 1 (the quotient recurrences below wait for rcp + Newton + fma: 130 cycles a
+        // step), rescaled by a power of two every eight steps; an exact zero becomes -2^-64 of its predecessor (pivmin).
+        // The divisions, gamma, and the multipliers of the eigenvector recurrence are then formed by all 64 lanes.
+        // No per-step range tests: the last group runs up to seven steps past the block (padding around fw / bw).
+        if (lane < 2) {
+            const bool fwd = lane == 0;
+            const int dir = fwd ? 1 : -1, i0 = fwd ? s : t - 1;
+            const int ulen = __builtin_amdgcn_readfirstlane(len);
+            float* po = (fwd ? fw : bw) + i0;
+            int* pxo = L.px[row][fwd ? 0 : 1];
+            const float* pd = L.dd + i0;
+            const float* pe = L.e2p + i0 + (fwd ? 0 : 1);                  // forward: e_{i-1}^2 = e2p[i]; backward: e_i^2 = e2p[i + 1]
+            const int d2 = 2 * dir, d3 = 3 * dir, d4 = 4 * dir, d5 = 5 * dir, d6 = 6 * dir, d7 = 7 * dir, d8 = 8 * dir;
+            float p0 = 0.0f, p1 = 1.0f;
+            float ec[8] = {pe[0], pe[dir], pe[d2], pe[d3], pe[d4], pe[d5], pe[d6], pe[d7]};
+            float dc[8] = {pd[0], pd[dir], pd[d2], pd[d3], pd[d4], pd[d5], pd[d6], pd[d7]};
+            for (int st = 0; st < ulen; st += 8) {
+                pe += d8; pd += d8;
+                const float en[8] = {pe[0], pe[dir], pe[d2], pe[d3], pe[d4], pe[d5], pe[d6], pe[d7]};
+                const float dq[8] = {pd[0], pd[dir], pd[d2], pd[d3], pd[d4], pd[d5], pd[d6], pd[d7]};
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float pn = fmaf(dc[c] - lam, p1, -(ec[c] * p0));
+                    pn = fmaf(p1, -5.4210109e-20f, pn);
+                    *po = pn;
+                    po += dir;
+                    p0 = p1; p1 = pn;
+                }
+                const int ex = 1 - __builtin_amdgcn_frexp_expf(p1);
+                p1 = __builtin_amdgcn_ldexpf(p1, ex); p0 = __builtin_amdgcn_ldexpf(p0, ex);
+                *pxo++ = ex;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { ec[c] = en[c]; dc[c] = dq[c]; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        SOLVE_MARK(2);
+        constexpr int NIT = EIGH_LD / 64;
+        float Dp[NIT], Dm[NIT];
+        int rbest = s;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = lane + 64 * it, i = s + idx, kb = len - 1 - idx;     // forward step idx, backward step kb
+            Dp[it] = 1.0f; Dm[it] = 1.0f;
+            if (idx < len) {
+                float dp = idx > 0 ? fw[i - 1] : 1.0f, dm = kb > 0 ? bw[i + 1] : 1.0f;
+                if (idx > 0 && (idx & 7) == 0) dp = __builtin_amdgcn_ldexpf(dp, L.px[row][0][(idx >> 3) - 1]);
+                if (kb > 0 && (kb & 7) == 0) dm = __builtin_amdgcn_ldexpf(dm, L.px[row][1][(kb >> 3) - 1]);
+                Dp[it] = __fdiv_rn(fw[i], dp);
+                Dm[it] = __fdiv_rn(bw[i], dm);
+                const float gam = fabsf((Dp[it] + Dm[it]) - (L.dd[i] - lam));
+                if (gam < gmin) { gmin = gam; rbest = i; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float og = __shfl_xor(gmin, o, 64);
+            const int orr = __shfl_xor(rbest, o, 64);
+            if (og < gmin || (og == gmin && orr < rbest)) { gmin = og; rbest = orr; }
+        }
+        r = rbest;
+        __builtin_amdgcn_wave_barrier();
+        // multipliers: z_i = -(e_i / D+_i) z_{i+1} below r, z_i = -(e_{i-1} / D-_i) z_{i-1} above
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = lane + 64 * it, i = s + idx;
+            if (idx < len) {
+                if (i < r) fw[i] = -__fdiv_rn(L.ee[i], Dp[it]);
+                if (i > r) bw[i] = -__fdiv_rn(L.ee[i - 1], Dm[it]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        SOLVE_MARK(3);
+        if (lane < 2) {
+            const bool up = lane == 0;
+            const int cnt_z = up ? r - s : t - 1 - r;
+            const int d = up ? -1 : 1, d2 = 2 * d, d3 = 3 * d, d4 = 4 * d;
+            float* pa = (up ? fw : bw) + (up ? r - 1 : r + 1);
+            float z = 1.0f;
+            float mc[4] = {pa[0], pa[d], pa[d2], pa[d3]};
+            for (int st = 0; st < cnt_z; st += 4) {                      // (up to three entries past the block: padding)
+                const float mn[4] = {pa[d4], pa[d4 + d], pa[d4 + d2], pa[d4 + d3]};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { z *= mc[c]; pa[c * d] = z; }
+                pa += d4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) mc[c] = mn[c];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        SOLVE_MARK(4);
+    } else {
     // lane 0 runs the forward, lane 1 the backward recurrence.  The operands of step st + 1 .. st + 4 (couplings and the
     // next diagonal entries) are loaded before the chain of the current four steps: as plain code every step waited for
     // two LDS round trips behind the store of its own pivot (390 cycles per step measured, 4/5 of it LDS latency)
@@ -754,7 +852,6 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     __builtin_amdgcn_wave_barrier();
     SOLVE_MARK(2);
     // gamma_i = D+_i + D-_i - (d_i - lam); r = argmin |gamma_i|
-    float gmin = 3.0e38f;
     int rbest = s;
     for (int i = s + lane; i < t; i += 64) {
         const float gam = fabsf((fw[i] + bw[i]) - (L.dd[i] - lam));
@@ -766,7 +863,7 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
         const int orr = __shfl_xor(rbest, o, 64);
         if (og < gmin || (og == gmin && orr < rbest)) { gmin = og; rbest = orr; }
     }
-    const int r = rbest;
+    r = rbest;
     __builtin_amdgcn_wave_barrier();
     SOLVE_MARK(3);
     // z_r = 1;  upwards z_i = -(e_i / D+_i) z_{i+1};  downwards z_{i+1} = -(e_i / D-_{i+1}) z_i
@@ -798,6 +895,7 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     }
     __builtin_amdgcn_wave_barrier();
     SOLVE_MARK(4);
+    }
     if (lane == 0) fw[r] = 1.0f;
     __builtin_amdgcn_wave_barrier();
     float zz = 0.0f;
@@ -822,7 +920,7 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     // ---- Z[i][j0 .. j0 + 3] for the four slots of this workgroup: one 16-byte store per row
     float* Z = q.Z + (size_t)g * EIGH_LD * EIGH_LD + blockIdx.x * EIGH_SLOTS_PER_WG;
     for (int i = tid; i < EIGH_LD; i += EIGH_SOLVE_THREADS)
-        *reinterpret_cast<float4*>(Z + (size_t)i * EIGH_LD) = make_float4(L.fw[0][i], L.fw[1][i], L.fw[2][i], L.fw[3][i]);
+        *reinterpret_cast<float4*>(Z + (size_t)i * EIGH_LD) = make_float4(L.fw[0][8 + i], L.fw[1][8 + i], L.fw[2][8 + i], L.fw[3][8 + i]);
     if (tid < EIGH_SLOTS_PER_WG && blockIdx.x * EIGH_SLOTS_PER_WG + tid >= n) q.lam[(size_t)g * EIGH_LD + blockIdx.x * EIGH_SLOTS_PER_WG + tid] = -3.0e38f;   // padding slots sort last
     SOLVE_MARK(6);
 #ifdef EIGH_CLK
