@@ -577,7 +577,13 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     if (lane == 0) L.red[wv] = tn;
     __syncthreads();
     tn = fmaxf(fmaxf(L.red[0], L.red[1]), fmaxf(L.red[2], L.red[3]));
-    const float thr = 4.0f * 1.1920929e-07f * fmaxf(fabsf(alpha), tn);
+    // T is scaled by a power of two so that |T| lies in [1, 2): nothing below then has a range to mind (the three-term
+    // sequences of the multisection and of the twisted factorisation run eight steps between rescalings); the scaling is
+    // exact, the eigenvalues and the residual are scaled back at the end, the eigenvectors do not see it
+    const int sce = tn > 0.0f ? max(-100, min(100, 1 - __builtin_amdgcn_frexp_expf(tn))) : 0;
+    const float tn_unscaled = tn;
+    const float thr = __builtin_amdgcn_ldexpf(4.0f * 1.1920929e-07f * fmaxf(fabsf(alpha), tn), sce);
+    tn = __builtin_amdgcn_ldexpf(tn, sce);
     __syncthreads();
     float gl = 3.0e38f, gu = -3.0e38f;
     float eth[2] = {0.0f, 0.0f};                                   // EIGH_LD <= 2 * EIGH_SOLVE_THREADS
@@ -585,12 +591,14 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     for (int it = 0; it < 2; ++it) {
         const int i = tid + it * EIGH_SOLVE_THREADS;
         if (i < EIGH_LD) {
-            float ei = L.ee[i];
+            float ei = __builtin_amdgcn_ldexpf(L.ee[i], sce);
             if (fabsf(ei) <= thr) ei = 0.0f;
-            const float em = i > 0 ? L.ee[i - 1] : 0.0f;          // (unthresholded neighbour: only widens the interval)
+            const float em = i > 0 ? __builtin_amdgcn_ldexpf(L.ee[i - 1], sce) : 0.0f;   // (unthresholded neighbour: only widens the interval)
+            const float di = __builtin_amdgcn_ldexpf(L.dd[i], sce);
+            L.dd[i] = di;                                         // (only this thread reads dd[i] before the barrier)
             if (i < n) {
                 const float rad = fabsf(ei) + fabsf(em);
-                gl = fminf(gl, L.dd[i] - rad); gu = fmaxf(gu, L.dd[i] + rad);
+                gl = fminf(gl, di - rad); gu = fmaxf(gu, di + rad);
             }
             eth[it] = ei;
         }
@@ -618,8 +626,7 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
         gl -= span * (2.0f * 1.1920929e-07f * (float)n) + thr;
         gu += span * (2.0f * 1.1920929e-07f * (float)n) + thr;
     }
-    const float pivmin = fmaxf(1.0e-30f, tn * tn * 1.0e-30f);
-    if (blockIdx.x == 0 && tid == 0) q.flags[(size_t)g * 8 + 5] = __float_as_uint(tn);
+    if (blockIdx.x == 0 && tid == 0) q.flags[(size_t)g * 8 + 5] = __float_as_uint(tn_unscaled);
     if (blockIdx.x == 0 && q.jacobi_sync)
         for (int i = tid; i < q.jacobi_sync_words; i += EIGH_SOLVE_THREADS) q.jacobi_sync[(size_t)g * q.jacobi_sync_words + i] = 0u;
     const int j = blockIdx.x * EIGH_SLOTS_PER_WG + row;           // eigenvalue slot of this wave
@@ -660,13 +667,13 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
             int cnt = 0;
             float qv = 1.0f;
             float4 dA = dd4[0], eA = e24[0];
-            if (s == 0 && t == n && (n & 3) == 0 && tn > 0.00390625f && tn < 256.0f) {
-                // the slot's block is the whole matrix (the usual case once C has left the identity) and |T| is within 2^+-8 (any
-                // other scale takes the quotient form below, which has no range to mind).  Sturm sequence without
+            if (s == 0 && t == n && (n & 3) == 0) {
+                // the slot's block is the whole matrix (the usual case once C has left the identity).  Sturm sequence without
                 // the division: p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2} is ONE dependent fma per step (the quotient form
                 // q_i = p_i / p_{i-1} waits ~70 cycles for v_rcp_f32 + fma), a negative pivot is a sign change p_{i-1} -> p_i,
                 // an exact zero counts as one (it becomes a tiny value of the opposite sign: the pivmin rule), and the pair is
-                // rescaled by a power of two every eight steps (|q| ~ |T|: 2^+-64 between rescalings, 2^-24 more next to a root)
+                // rescaled by a power of two every eight steps (|q| <~ 2 |T| < 4: 2^16 between rescalings at most, and down to
+                // 2^-24 per step next to a root)
                 float p0 = 0.0f, p1 = 1.0f;                                   // p_{i-2}, p_{i-1}
                 unsigned sg = 0u;                                              // the signs of p_{i-1}, p_i, ... (newest in bit 0)
                 for (int i4 = 0; i4 < n4; ++i4) {
@@ -720,11 +727,11 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     const int len = t - s;
     int r;
     float gmin = 3.0e38f;
-    if (tn > 0.00390625f && tn < 256.0f) {
-        // ---- |T| within 2^+-8: D+_i = p_i / p_{i-1} and D-_i = q_i / q_{i+1} from the two three-term sequences
+    {
+        // ---- D+_i = p_i / p_{i-1} and D-_i = q_i / q_{i+1} from the two three-term sequences
         //   p_i = (d_i - lam) p_{i-1} - e_{i-1}^2 p_{i-2},  q_i = (d_i - lam) q_{i+1} - e_i^2 q_{i+2}
-        // one dependent fma per step on lanes 0 / 1 (the quotient recurrences below wait for rcp + Newton + fma: 130 cycles a
-        // step), rescaled by a power of two every eight steps; an exact zero becomes -2^-64 of its predecessor (pivmin).
+        // one dependent fma per step on lanes 0 / 1 (the quotient recurrences D+_{i+1} = (d_{i+1} - lam) - e_i^2 / D+_i waited for
+        // rcp + Newton step + fma: 130 cycles a step), rescaled by a power of two every eight steps; an exact zero becomes -2^-64 of its predecessor (pivmin).
         // The divisions, gamma, and the multipliers of the eigenvector recurrence are then formed by all 64 lanes.
         // No per-step range tests: the last group runs up to seven steps past the block (padding around fw / bw).
         if (lane < 2) {
@@ -814,87 +821,6 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
         }
         __builtin_amdgcn_wave_barrier();
         SOLVE_MARK(4);
-    } else {
-    // lane 0 runs the forward, lane 1 the backward recurrence.  The operands of step st + 1 .. st + 4 (couplings and the
-    // next diagonal entries) are loaded before the chain of the current four steps: as plain code every step waited for
-    // two LDS round trips behind the store of its own pivot (390 cycles per step measured, 4/5 of it LDS latency)
-    if (lane < 2) {
-        // (every instruction of these loops is issued in order in front of the chain's next link: running pointers, no index
-        // clamps -- the loads run up to eight entries past the block's end, inside the LDS structure, and are not used --,
-        // a scalar trip count)
-        const bool fwd = lane == 0;
-        const int dir = fwd ? 1 : -1, i0 = fwd ? s : t - 1;
-        const int ulen = __builtin_amdgcn_readfirstlane(len);
-        float piv = L.dd[i0] - lam;
-        float* po = (fwd ? fw : bw) + i0;
-        const float* pe = L.ee + i0 + (fwd ? 0 : -1);                   // coupling of index i0 + dir k to its successor
-        const float* pd = L.dd + i0 + dir;                              // the successor's diagonal entry
-        const int d2 = 2 * dir, d3 = 3 * dir, d4 = 4 * dir;
-        float ec[4] = {pe[0], pe[dir], pe[d2], pe[d3]}, dn[4] = {pd[0], pd[dir], pd[d2], pd[d3]};
-        for (int st = 0; st < ulen; st += 4) {
-            pe += d4; pd += d4;
-            const float en[4] = {pe[0], pe[dir], pe[d2], pe[d3]}, dq[4] = {pd[0], pd[dir], pd[d2], pd[d3]};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (st + c < ulen) {
-                    piv = fabsf(piv) < pivmin ? -pivmin : piv;
-                    *po = piv;
-                    po += dir;
-                    float rp = __builtin_amdgcn_rcpf(piv);
-                    rp = rp * fmaf(-piv, rp, 2.0f);     // one Newton step: with 1-ulp quotients the vectors come out 10x less orthogonal
-                    piv = fmaf(-(ec[c] * ec[c]), rp, dn[c] - lam);      // (e^2 and d - lam do not wait for the chain)
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { ec[c] = en[c]; dn[c] = dq[c]; }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    SOLVE_MARK(2);
-    // gamma_i = D+_i + D-_i - (d_i - lam); r = argmin |gamma_i|
-    int rbest = s;
-    for (int i = s + lane; i < t; i += 64) {
-        const float gam = fabsf((fw[i] + bw[i]) - (L.dd[i] - lam));
-        if (gam < gmin) { gmin = gam; rbest = i; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float og = __shfl_xor(gmin, o, 64);
-        const int orr = __shfl_xor(rbest, o, 64);
-        if (og < gmin || (og == gmin && orr < rbest)) { gmin = og; rbest = orr; }
-    }
-    r = rbest;
-    __builtin_amdgcn_wave_barrier();
-    SOLVE_MARK(3);
-    // z_r = 1;  upwards z_i = -(e_i / D+_i) z_{i+1};  downwards z_{i+1} = -(e_i / D-_{i+1}) z_i
-    // (z_i overwrites D+_i for i <= r and D-_i for i > r); operands four steps ahead of the chain, as above
-    if (lane < 2) {
-        const bool up = lane == 0;
-        const int cnt_z = up ? r - s : t - 1 - r;                    // steps of this direction
-        const int d = up ? -1 : 1, d2 = 2 * d, d3 = 3 * d, d4 = 4 * d;
-        float* pa = (up ? fw : bw) + (up ? r - 1 : r + 1);           // pivot of step 0, replaced by z
-        const float* pe = L.ee + (up ? r - 1 : r);                   // its coupling
-        float z = 1.0f;
-        float ec[4] = {pe[0], pe[d], pe[d2], pe[d3]}, pv[4] = {pa[0], pa[d], pa[d2], pa[d3]};
-        for (int st = 0; st < cnt_z; st += 4) {
-            pe += d4;
-            const float en[4] = {pe[0], pe[d], pe[d2], pe[d3]}, pn[4] = {pa[d4], pa[d4 + d], pa[d4 + d2], pa[d4 + d3]};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (st + c < cnt_z) {
-                    float rp = __builtin_amdgcn_rcpf(pv[c]);
-                    rp = rp * fmaf(-pv[c], rp, 2.0f);
-                    z = -(ec[c] * rp) * z;
-                    *pa = z;
-                    pa += d;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { ec[c] = en[c]; pv[c] = pn[c]; }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    SOLVE_MARK(4);
     }
     if (lane == 0) fw[r] = 1.0f;
     __builtin_amdgcn_wave_barrier();
@@ -903,8 +829,8 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     zz = wave_sum(zz);
     const float rn = 1.0f / sqrtf(zz);
     if (live && lane == 0) {
-        q.lam[(size_t)g * EIGH_LD + j] = lam;
-        const float resid = gmin * rn;                                       // |(T - lam) z| for the normalised z
+        q.lam[(size_t)g * EIGH_LD + j] = __builtin_amdgcn_ldexpf(lam, -sce);
+        const float resid = __builtin_amdgcn_ldexpf(gmin * rn, -sce);                                      // |(T - lam) z| for the normalised z
         atomicMax(q.flags + (size_t)g * 8 + 2, __float_as_uint(resid));
     }
     // normalised vector back into fw (zero outside [s, t)), for every i < EIGH_LD

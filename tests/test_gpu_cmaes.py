@@ -257,8 +257,9 @@ def test_direct_eigensolver_over_a_closed_loop(L):
 
 @pytest.mark.parametrize("scale", [1.0e-5, 3.0e4])
 def test_direct_eigensolver_at_other_scales(L, scale):
-    # the multisection's division-free Sturm sequence is taken for |T| within 2^+-8 only (kernels_eigh.hpp); a covariance
-    # far above that scale goes through the quotient form -- still the direct solver (word 15 == 0), the same invariants
+    # the solver's three-term sequences run eight steps between rescalings, so k_eigh_tri_solve scales T by a power of two
+    # into [1, 2) first (kernels_eigh.hpp): a covariance far from unit scale must decompose like any other -- the direct
+    # solver (word 15 == 0), the same invariants
     # relative to |C|.  The small scale is a different animal: the update adds its O(c1 + cmu) rank-40 terms to 1e-5 C, i.e.
     # 260 eigenvalues within 1e-5 of each other under a norm of 1e-2 -- the direct solver's vectors fail its own checks
     # there (as they did with the quotient form) and the block Jacobi takes over; what is asserted is the factorisation.
