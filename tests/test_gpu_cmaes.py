@@ -214,9 +214,9 @@ def test_fused_control_step_is_bit_identical_to_the_per_iteration_kernels(L, mon
     assert ref.get_profile()[2] == ("k_cma_sample_roll_small" if (n <= 32 and G == A) else "k_rollout_pendulum")
 
 
-def _config5_cma_engine(L, A=2, N=400, k=40):
+def _config5_cma_engine(L, A=2, N=400, k=40, H=50):
     from blackbox_mpc_amd.engine import Engine
-    S, U, H = 20, 6, 50                                    # n = H * U = 300: BASELINE config 5's per-agent search dimension
+    S, U = 20, 6                                           # n = H * U = 300: BASELINE config 5's per-agent search dimension
     eng = Engine(L.OPT_CMAES, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=A, planning_horizon=H,
                  population_size=N, max_iterations=5, num_elite=k, seed=4, quirks=L.CMAES_PER_AGENT)
     ws, bs = O.make_mlp_params([S + U, 200, 200, S], seed=42)
@@ -248,6 +248,21 @@ def test_direct_eigensolver_over_a_closed_loop(L):
     A, n, iters = 2, 300, 5
     eng, state = _config5_cma_engine(L, A)
     for step in range(6):
+        act, state, rew = eng.optimize(state)
+        for it in range(iters):
+            st = eng.get_trace(it, L.TRACE_CMA_SVD_STATS)
+            assert np.all(st[:, 15] == 0) and np.all(st[:, :15] == 0), (step, it, st)
+        assert _check_factorisation(eng, L, A, n, iters, 5e-6) <= 5e-6
+
+
+@pytest.mark.parametrize("H", [22, 30, 52])
+def test_direct_eigensolver_other_sizes(L, H):
+    # n = 132 (just above the one-sided Jacobi's range), 180 and 312 (the direct solver takes n % 4 == 0 up to 320; other
+    # sizes stay with the block Jacobi): the same checks as at n = 300 -- row classes that are partly or wholly padding,
+    # 45 / 78 multisection groups
+    A, n, iters = 2, 6 * H, 5
+    eng, state = _config5_cma_engine(L, A, H=H)
+    for step in range(3):
         act, state, rew = eng.optimize(state)
         for it in range(iters):
             st = eng.get_trace(it, L.TRACE_CMA_SVD_STATS)
