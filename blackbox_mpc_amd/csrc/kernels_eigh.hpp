@@ -532,7 +532,7 @@ struct EighSolveLds {
     float pad_front[16];        // (the recurrences below read a few entries past a block's ends instead of clamping indices)
     float dd[EIGH_LD];          // d
     float ee[EIGH_LD];          // thresholded e (ee[k] couples k, k + 1)
-    float e2p[EIGH_LD];         // e2p[i] = ee[i-1]^2 (0 for i = 0)
+    float e2p[EIGH_LD + 8];     // e2p[i] = ee[i-1]^2 (1e-36 for i = 0 and from n on: the backward sequence starts at e2p[t], t <= EIGH_LD)
     float fw[EIGH_SLOTS_PER_WG][EIGH_LD + 24]; // per slot (8 entries of padding in front): D+ pivots / the p sequence, then the upper part of z
     float bw[EIGH_SLOTS_PER_WG][EIGH_LD + 24]; // per slot: D- pivots / the backward sequence, then the lower part of z
     int px[EIGH_SLOTS_PER_WG][2][EIGH_LD / 8 + 2];  // power-of-two rescalings of the two sequences, one per eight steps
@@ -613,7 +613,7 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     // e^2 of the coupling to the previous index; 1e-36 instead of 0 at a split (and at i = 0): the Sturm chain below then
     // needs no pivmin test -- a pivot that is exactly zero gives e^2 * inf = inf and the next pivot -inf, counted as the one
     // negative pivot the pivmin rule would count, where 0 * inf would be a NaN; against pivots of |T| 1e-36 couples nothing
-    for (int i = tid; i < EIGH_LD; i += EIGH_SOLVE_THREADS) L.e2p[i] = (i > 0 && i < n) ? fmaxf(L.ee[i - 1] * L.ee[i - 1], 1.0e-36f) : 1.0e-36f;
+    for (int i = tid; i < EIGH_LD + 8; i += EIGH_SOLVE_THREADS) L.e2p[i] = (i > 0 && i < n) ? fmaxf(L.ee[i - 1] * L.ee[i - 1], 1.0e-36f) : 1.0e-36f;
     gl = fminf(gl, __shfl_xor(gl, 32, 64)); gu = fmaxf(gu, __shfl_xor(gu, 32, 64));
     gl = row16_min(gl); gu = row16_max(gu);
     gl = fminf(gl, __shfl_xor(gl, 16, 64)); gu = fmaxf(gu, __shfl_xor(gu, 16, 64));

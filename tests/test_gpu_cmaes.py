@@ -270,6 +270,21 @@ def test_direct_eigensolver_other_sizes(L, H):
         assert _check_factorisation(eng, L, A, n, iters, 5e-6) <= 5e-6
 
 
+def test_direct_eigensolver_at_the_padded_length(L):
+    # n = 320 = the padded length of every vector on the direct solver's path (pendulum, one agent, H = 320): nothing may
+    # rely on a zero behind the last entry
+    A, H, N, k, iters = 1, 320, 256, 32, 3
+    eng = _engine(L, A, H, N, iters, k, seed=5)
+    eng.set_trace(True)
+    states = O.pendulum_start_states(A)
+    for step in range(3):
+        act, states, rew = eng.optimize(states)
+        for it in range(iters):
+            st = eng.get_trace(it, L.TRACE_CMA_SVD_STATS)
+            assert np.all(st[:, 15] == 0) and np.all(st[:, :15] == 0), (step, it, st)
+        assert _check_factorisation(eng, L, 1, H, iters, 5e-6) <= 5e-6
+
+
 @pytest.mark.parametrize("scale", [1.0e-5, 3.0e4])
 def test_direct_eigensolver_at_other_scales(L, scale):
     # the solver's three-term sequences run eight steps between rescalings, so k_eigh_tri_solve scales T by a power of two
