@@ -533,8 +533,10 @@ struct EighSolveLds {
     float dd[EIGH_LD];          // d
     float ee[EIGH_LD];          // thresholded e (ee[k] couples k, k + 1)
     float e2p[EIGH_LD + 8];     // e2p[i] = ee[i-1]^2 (1e-36 for i = 0 and from n on: the backward sequence starts at e2p[t], t <= EIGH_LD)
+    float ddR[EIGH_LD + 16];    // ddR[m] = dd[n-1-m], e2R[m] = e_{n-1-m}^2 = e2p[n-m]: the backward sequence of the twisted factorisation walks
+    float e2R[EIGH_LD + 16];    // them upwards, so that both of its lanes run the same code with immediate offsets
     float fw[EIGH_SLOTS_PER_WG][EIGH_LD + 24]; // per slot (8 entries of padding in front): D+ pivots / the p sequence, then the upper part of z
-    float bw[EIGH_SLOTS_PER_WG][EIGH_LD + 24]; // per slot: D- pivots / the backward sequence, then the lower part of z
+    float bw[EIGH_SLOTS_PER_WG][EIGH_LD + 24]; // per slot: the backward sequence, then the lower part of z -- MIRRORED inside the block: index s + t - 1 - i
     int px[EIGH_SLOTS_PER_WG][2][EIGH_LD / 8 + 2];  // power-of-two rescalings of the two sequences, one per eight steps
     float red[8];
     short bs[EIGH_LD], bt[EIGH_LD];   // unreduced block [bs[i], bt[i]) around index i
@@ -614,6 +616,11 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     // needs no pivmin test -- a pivot that is exactly zero gives e^2 * inf = inf and the next pivot -inf, counted as the one
     // negative pivot the pivmin rule would count, where 0 * inf would be a NaN; against pivots of |T| 1e-36 couples nothing
     for (int i = tid; i < EIGH_LD + 8; i += EIGH_SOLVE_THREADS) L.e2p[i] = (i > 0 && i < n) ? fmaxf(L.ee[i - 1] * L.ee[i - 1], 1.0e-36f) : 1.0e-36f;
+    for (int m = tid; m < EIGH_LD + 16; m += EIGH_SOLVE_THREADS) {
+        const int i = n - 1 - m;                                       // e_i couples i, i + 1
+        L.ddR[m] = i >= 0 ? L.dd[i] : 0.0f;
+        L.e2R[m] = (i >= 0 && i < n - 1) ? fmaxf(L.ee[i] * L.ee[i], 1.0e-36f) : 1.0e-36f;
+    }
     gl = fminf(gl, __shfl_xor(gl, 32, 64)); gu = fmaxf(gu, __shfl_xor(gu, 32, 64));
     gl = row16_min(gl); gu = row16_max(gu);
     gl = fminf(gl, __shfl_xor(gl, 16, 64)); gu = fmaxf(gu, __shfl_xor(gu, 16, 64));
@@ -735,29 +742,31 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
         // The divisions, gamma, and the multipliers of the eigenvector recurrence are then formed by all 64 lanes.
         // No per-step range tests: the last group runs up to seven steps past the block (padding around fw / bw).
         if (lane < 2) {
+            // lane 0: p over i = s, s + 1, ...; lane 1: q over i = t - 1, t - 2, ... read from the reversed copies and stored
+            // mirrored (bw[s + k] = q_{t-1-k}) -- one instruction stream, every address a pointer + immediate
             const bool fwd = lane == 0;
-            const int dir = fwd ? 1 : -1, i0 = fwd ? s : t - 1;
             const int ulen = __builtin_amdgcn_readfirstlane(len);
-            float* po = (fwd ? fw : bw) + i0;
+            float* po = (fwd ? fw : bw) + s;
             int* pxo = L.px[row][fwd ? 0 : 1];
-            const float* pd = L.dd + i0;
-            const float* pe = L.e2p + i0 + (fwd ? 0 : 1);                  // forward: e_{i-1}^2 = e2p[i]; backward: e_i^2 = e2p[i + 1]
-            const int d2 = 2 * dir, d3 = 3 * dir, d4 = 4 * dir, d5 = 5 * dir, d6 = 6 * dir, d7 = 7 * dir, d8 = 8 * dir;
+            const float* pd = fwd ? L.dd + s : L.ddR + (n - t);
+            const float* pe = fwd ? L.e2p + s : L.e2R + (n - t);               // forward: e_{i-1}^2 = e2p[i]; backward: e_i^2 = e2R[n-1-i]
             float p0 = 0.0f, p1 = 1.0f;
-            float ec[8] = {pe[0], pe[dir], pe[d2], pe[d3], pe[d4], pe[d5], pe[d6], pe[d7]};
-            float dc[8] = {pd[0], pd[dir], pd[d2], pd[d3], pd[d4], pd[d5], pd[d6], pd[d7]};
+            float ec[8], dc[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { ec[c] = pe[c]; dc[c] = pd[c]; }
             for (int st = 0; st < ulen; st += 8) {
-                pe += d8; pd += d8;
-                const float en[8] = {pe[0], pe[dir], pe[d2], pe[d3], pe[d4], pe[d5], pe[d6], pe[d7]};
-                const float dq[8] = {pd[0], pd[dir], pd[d2], pd[d3], pd[d4], pd[d5], pd[d6], pd[d7]};
+                pe += 8; pd += 8;
+                float en[8], dq[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { en[c] = pe[c]; dq[c] = pd[c]; }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     float pn = fmaf(dc[c] - lam, p1, -(ec[c] * p0));
                     pn = fmaf(p1, -5.4210109e-20f, pn);
-                    *po = pn;
-                    po += dir;
+                    po[c] = pn;
                     p0 = p1; p1 = pn;
                 }
+                po += 8;
                 const int ex = 1 - __builtin_amdgcn_frexp_expf(p1);
                 p1 = __builtin_amdgcn_ldexpf(p1, ex); p0 = __builtin_amdgcn_ldexpf(p0, ex);
                 *pxo++ = ex;
@@ -775,11 +784,12 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
             const int idx = lane + 64 * it, i = s + idx, kb = len - 1 - idx;     // forward step idx, backward step kb
             Dp[it] = 1.0f; Dm[it] = 1.0f;
             if (idx < len) {
-                float dp = idx > 0 ? fw[i - 1] : 1.0f, dm = kb > 0 ? bw[i + 1] : 1.0f;
+                const int mi = s + kb;                                           // mirror of i
+                float dp = idx > 0 ? fw[i - 1] : 1.0f, dm = kb > 0 ? bw[mi - 1] : 1.0f;
                 if (idx > 0 && (idx & 7) == 0) dp = __builtin_amdgcn_ldexpf(dp, L.px[row][0][(idx >> 3) - 1]);
                 if (kb > 0 && (kb & 7) == 0) dm = __builtin_amdgcn_ldexpf(dm, L.px[row][1][(kb >> 3) - 1]);
                 Dp[it] = __fdiv_rn(fw[i], dp);
-                Dm[it] = __fdiv_rn(bw[i], dm);
+                Dm[it] = __fdiv_rn(bw[mi], dm);
                 const float gam = fabsf((Dp[it] + Dm[it]) - (L.dd[i] - lam));
                 if (gam < gmin) { gmin = gam; rbest = i; }
             }
@@ -798,23 +808,24 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
             const int idx = lane + 64 * it, i = s + idx;
             if (idx < len) {
                 if (i < r) fw[i] = -__fdiv_rn(L.ee[i], Dp[it]);
-                if (i > r) bw[i] = -__fdiv_rn(L.ee[i - 1], Dm[it]);
+                if (i > r) bw[s + t - 1 - i] = -__fdiv_rn(L.ee[i - 1], Dm[it]);
             }
         }
         __builtin_amdgcn_wave_barrier();
         SOLVE_MARK(3);
         if (lane < 2) {
+            // upper part: i = r - 1 down to s in fw; lower part: i = r + 1 up to t - 1, i.e. DOWN from s + t - 2 - r in the
+            // mirrored bw -- the same descending code for both lanes
             const bool up = lane == 0;
             const int cnt_z = up ? r - s : t - 1 - r;
-            const int d = up ? -1 : 1, d2 = 2 * d, d3 = 3 * d, d4 = 4 * d;
-            float* pa = (up ? fw : bw) + (up ? r - 1 : r + 1);
+            float* pa = up ? fw + (r - 1) : bw + (s + t - 2 - r);
             float z = 1.0f;
-            float mc[4] = {pa[0], pa[d], pa[d2], pa[d3]};
+            float mc[4] = {pa[0], pa[-1], pa[-2], pa[-3]};
             for (int st = 0; st < cnt_z; st += 4) {                      // (up to three entries past the block: padding)
-                const float mn[4] = {pa[d4], pa[d4 + d], pa[d4 + d2], pa[d4 + d3]};
+                const float mn[4] = {pa[-4], pa[-5], pa[-6], pa[-7]};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { z *= mc[c]; pa[c * d] = z; }
-                pa += d4;
+                for (int c = 0; c < 4; ++c) { z *= mc[c]; pa[-c] = z; }
+                pa -= 4;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) mc[c] = mn[c];
             }
@@ -825,7 +836,7 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     if (lane == 0) fw[r] = 1.0f;
     __builtin_amdgcn_wave_barrier();
     float zz = 0.0f;
-    for (int i = s + lane; i < t; i += 64) { const float z = i <= r ? fw[i] : bw[i]; zz = fmaf(z, z, zz); }
+    for (int i = s + lane; i < t; i += 64) { const float z = i <= r ? fw[i] : bw[s + t - 1 - i]; zz = fmaf(z, z, zz); }
     zz = wave_sum(zz);
     const float rn = 1.0f / sqrtf(zz);
     if (live && lane == 0) {
@@ -837,7 +848,7 @@ static __global__ __launch_bounds__(EIGH_SOLVE_THREADS) void k_eigh_tri_solve(Ei
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < EIGH_LD; i += 64) {
         float z = 0.0f;
-        if (live && i >= s && i < t) z = (i <= r ? fw[i] : bw[i]) * rn;
+        if (live && i >= s && i < t) z = (i <= r ? fw[i] : bw[s + t - 1 - i]) * rn;
         __builtin_amdgcn_wave_barrier();
         fw[i] = z;
     }
