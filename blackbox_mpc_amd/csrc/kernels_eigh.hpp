@@ -514,14 +514,19 @@ static __global__ __launch_bounds__(EIGH_TRI_THREADS) void k_eigh_tridiag(EighAr
 // ---------------------------------------------------------------------------------------------------------------------
 // 2. Eigen-decomposition of the tridiagonal T (d, e) -- and, in the surplus workgroups of the same launch, the
 // triangular factors of the reflector blocks for stage 4.
-// grid (EIGH_LD / 4 + EIGH_LD / 32, G), block 256.  Workgroups x < 80: four eigenvalue slots each, one wave per slot.  T is split where |e_k| <= 4 eps max(|alpha|, |T|); slot j belongs to the unreduced block [s, t) that
-// contains index j and takes that block's (j - s)-th eigenvalue:
-//   multisection   the row's 16 lanes try 16 shifts per pass; Sturm count = negative pivots of T - x inside [s, t)
-//                  (the recurrence runs over the whole matrix: e^2 = 0 at a split restarts it); 7 passes of 17-fold
-//                  narrowing take the Gershgorin interval to below the last bit of |T|
-//   eigenvector    twisted factorisation: lane 0 runs the forward (L D+ L^T), lane 1 the backward (U D- U^T)
-//                  recurrence of T - lambda, both into LDS; the row finds r = argmin |gamma_i| and the two lanes run the
-//                  vector out from z_r = 1 upwards / downwards; normalised, residual |gamma_r| / |z| recorded
+// grid (EIGH_LD / 4 + EIGH_LD / 32, G), block 256.  Workgroups x < 80: four eigenvalue slots each, one wave per slot.
+// T is scaled by a power of two into [1, 2) (exact) and split where |e_k| <= 4 eps max(|alpha|, |T|); slot j belongs to
+// the unreduced block [s, t) that contains index j and takes that block's (j - s)-th eigenvalue:
+//   multisection   the wave's 64 lanes try 64 shifts per pass, five passes of 65-fold narrowing take the Gershgorin
+//                  interval to below the last bit of |T|.  Sturm count of a shift = sign changes of the sequence
+//                  p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2} when the block is the whole matrix (one dependent fma per
+//                  step, rescaled every eight steps), negative pivots of the quotient recurrence with a block test
+//                  otherwise (e^2 = 1e-36 at a split restarts it)
+//   eigenvector    twisted factorisation of T - lambda: lanes 0 / 1 run the sequence forwards (p) and backwards (q, on
+//                  reversed copies of d and e^2); all lanes form D+_i = p_i / p_{i-1}, D-_i = q_i / q_{i+1}, gamma_i and
+//                  r = argmin |gamma_i|, and the multipliers -e / D of the vector recurrence; lanes 0 / 1 run the vector
+//                  out from z_r = 1 upwards / downwards (one multiply per step); normalised, residual |gamma_r| / |z|
+//                  recorded
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int EIGH_SOLVE_THREADS = 256;
 constexpr int EIGH_SLOTS_PER_WG = EIGH_SOLVE_THREADS / 64;      // one wave per eigenvalue slot
