@@ -56,6 +56,9 @@ DEFAULT_STEPS = {"cfg1": 2000, "cfg2": 2000, "cfg3": 2000, "cfg3full": 300, "cfg
                  "cfg5pso": 60, "cfg5full": 10, "cfg5cma": 30}
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
+VALU_ISSUE_NS_MEASURED = 1.07       # one VALU instruction per SIMD, measured on one CU (tools/microbench/pk_fp32.hip)
+VALU_ISSUE_CYCLES_GUIDE = 2         # v_fma_f32, wave64 on a SIMD-32 (MI355X_MICROARCH.md)
+CLOCK_GHZ = 2.4
 MLP_DIMS = [26, 200, 200, 20]
 SECONDARY = "cfg4pi2"
 
@@ -261,6 +264,9 @@ class Workload:
     def get_profile(self):
         return self.eng.get_profile()
 
+    def profile_instantiation(self):
+        return self.eng.profile_instantiation()
+
     def check_gather(self, host_records):
         """The gathered rows of this rank's own agents must be the records it produced (bit for bit), and the row
         blocks of the other ranks must be populated.  Returns the number of rows checked."""
@@ -342,6 +348,9 @@ class StubWorkload:
     def get_profile(self):
         return 0.0, 0, "stub"
 
+    def profile_instantiation(self):
+        return "stub"
+
     check_gather = Workload.check_gather
 
     def call_stats(self):
@@ -407,6 +416,7 @@ def measure(W, steps, warmup, dist, use_dist, red_dev, act_only=False):
     W.fence()
     t3 = time.perf_counter()
     roll_ms, roll_n, kname = W.get_profile()
+    kinst = W.profile_instantiation()          # the template instantiation those events bracketed
     W.set_profiling(False)
     W.fence()
     t4 = time.perf_counter()
@@ -417,7 +427,7 @@ def measure(W, steps, warmup, dist, use_dist, red_dev, act_only=False):
     rows_dev = W.check_gather(None)
     dev_elapsed = reduce_max(t5 - t4)
     return dict(walls=walls, act_elapsed=act_elapsed, median=med, p10=p10, p90=p90, dev_elapsed=dev_elapsed,
-                dev_elapsed_instrumented=reduce_max(t3 - t2), roll_ms=roll_ms, roll_n=roll_n, kname=kname,
+                dev_elapsed_instrumented=reduce_max(t3 - t2), roll_ms=roll_ms, roll_n=roll_n, kname=kname, kinst=kinst,
                 prof_every=every, gather_rows_checked=rows_act + rows_dev, n_samples=n_samples)
 
 
@@ -437,6 +447,27 @@ def profile_shape_matches(profile_json, prof_name, c):
     at CONFIGS[prof_name]."""
     shp = profile_json.get("_shapes", {}).get(prof_name) or {k: CONFIGS[prof_name].get(k) for k in SHAPE_KEYS}
     return all(shp.get(k) == c.get(k) for k in SHAPE_KEYS)
+
+
+def _plain_name(kn):
+    """rocprofv3's kernel name without the leading "void " and without template arguments."""
+    kn = kn.strip()
+    if kn.startswith("void "):
+        kn = kn[5:]
+    return kn.split("<", 1)[0].strip()
+
+
+def profile_entry(entries, kname, inst):
+    """(profile key, value) of the kernel a measurement belongs to, or None.  `inst` is what the engine reports
+    (bbmpc_profile_instantiation): with template arguments it must equal the profile's kernel name exactly (the profile may
+    hold several instantiations of one kernel -- strict-math, resident -- whose counters differ by 2-8x); a plain name is
+    accepted only when the profile holds exactly ONE instantiation of that kernel."""
+    norm = lambda x: x.strip()[5:].strip() if x.strip().startswith("void ") else x.strip()
+    if "<" in inst:
+        hit = [(kn, v) for kn, v in entries.items() if norm(kn) == inst]
+    else:
+        hit = [(kn, v) for kn, v in entries.items() if _plain_name(kn) == _plain_name(kname)]
+    return hit[0] if len(hit) == 1 else None
 
 
 def roofline(W, m, name, world):
@@ -469,35 +500,44 @@ def roofline(W, m, name, world):
                                   "device-resident timed region" % ("every" if m["prof_every"] == 1 else "every %dth" % m["prof_every"])})
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     # collected separately, (2*FETCH + WRITE)*1024 -- tools/profile_round.sh, profiles/*_hbm_traffic.json).  Counters are
-    # attached only when the PROFILED shape is the timed one: the lookup goes by (environment, optimizer, N, A, H,
-    # iterations), not by the configuration's name (run_block times "cfg3" with other agent counts).
+    # attached only when the PROFILED shape is the timed one -- the lookup goes by (environment, optimizer, N, A, H,
+    # iterations), not by the configuration's name (run_block times "cfg3" with other agent counts) -- and only from the
+    # profile entry of the template INSTANTIATION the engine says it timed (bbmpc_profile_instantiation): the strict-math and
+    # the resident instantiations of the persistent kernel sit in the same profile files under the same plain name.
     import glob
+    inst = m.get("kinst") or kname
+    roof["kernel_instantiation"] = inst
     prof_name = profile_config_for(c)
     if prof_name is None:
         roof["counters_note"] = "no committed profile of this shape (agents=%d): traffic / valu_issue not attached" % A
     try:
         tr = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]))
-        # (the resident LINGER instantiation of the persistent kernel serves many control steps per dispatch: not a per-launch figure)
-        hit = [v for kn, v in tr.get(prof_name, {}).items()
-               if kname in kn and not (kname.startswith("k_fused_pendulum") and kn.rstrip().endswith("true>"))] if prof_name else []
-        if hit and world == 1 and profile_shape_matches(tr, prof_name, c):
-            roof["traffic"] = hit[0]
-            roof["traffic_source"] = "profiles/ (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes; configuration %s)" % prof_name
+        ent = profile_entry(tr.get(prof_name, {}), kname, inst) if prof_name else None
+        if ent is not None and world == 1 and profile_shape_matches(tr, prof_name, c):
+            roof["traffic"] = ent[1]
+            roof["traffic_source"] = ("profiles/ (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes; configuration %s, "
+                                      "kernel %s)" % (prof_name, ent[0]))
     except Exception:
         pass
     # A bound that means something for the persistent pendulum kernels (their HBM fraction is nominal): VALU issue.
     # Wave-instructions per launch come from the committed rocprofv3 PMC pass (SQ_INSTS_VALU); the kernel occupies
-    # one CU per agent, each CU issues at most one VALU instruction per SIMD per 1.07 ns (tools/microbench/pk_fp32.hip)
+    # one CU per agent.  Two peaks: the rate one CU was MEASURED to issue at (one VALU instruction per SIMD per 1.07 ns,
+    # tools/microbench/pk_fp32.hip) and the guide's figure (v_fma_f32: 2 cycles per wave64 instruction per SIMD at 2.4 GHz).
     try:
         if not mlp and m["roll_n"] and world == 1 and prof_name:
             sqc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))[-1]))
-            hit = [v for kn, v in sqc.get(prof_name, {}).items() if kname in kn and "noise" not in kn and not kn.rstrip().endswith("true>")]
-            if hit and profile_shape_matches(sqc, prof_name, c):
-                insts = hit[0]["SQ_INSTS_VALU"]
-                peak = A * 4 / 1.07e-9
+            ent = profile_entry(sqc.get(prof_name, {}), kname, inst)
+            if ent is not None and profile_shape_matches(sqc, prof_name, c):
+                insts = ent[1]["SQ_INSTS_VALU"]
+                peak = A * 4 / VALU_ISSUE_NS_MEASURED * 1e9
+                peak_guide = A * 4 * CLOCK_GHZ * 1e9 / VALU_ISSUE_CYCLES_GUIDE
                 ach = insts / (avg_ms * 1e-3)
                 roof["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "wave-instructions/s", "frac": ach / peak,
-                                      "insts_per_launch": insts, "cus": A,
+                                      "peak_guide": peak_guide, "frac_guide": ach / peak_guide,
+                                      "insts_per_launch": insts, "cus": A, "kernel": ent[0],
+                                      "peaks": "peak = 4 SIMDs x 1 instruction / %.2f ns measured on one CU; peak_guide = 4 SIMDs x %.1f GHz "
+                                               "/ %d cycles per wave64 v_fma_f32 (MI355X_MICROARCH.md)"
+                                               % (VALU_ISSUE_NS_MEASURED, CLOCK_GHZ, VALU_ISSUE_CYCLES_GUIDE),
                                       "source": "profiles/*_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU; configuration %s)" % prof_name}
     except Exception:
         pass

@@ -64,7 +64,7 @@ SYMBOLS = [
     "bbmpc_set_stream", "bbmpc_set_mlp", "bbmpc_reset", "bbmpc_optimize", "bbmpc_optimize_dev", "bbmpc_evaluate",
     "bbmpc_evaluate_dev", "bbmpc_predict_next_state", "bbmpc_evaluate_next_reward", "bbmpc_step_dev",
     "bbmpc_inject_noise", "bbmpc_dump_noise", "bbmpc_set_trace", "bbmpc_get_trace", "bbmpc_get_state",
-    "bbmpc_set_state", "bbmpc_set_profiling", "bbmpc_get_profile", "bbmpc_synchronize", "bbmpc_rollout_episode",
+    "bbmpc_set_state", "bbmpc_set_profiling", "bbmpc_get_profile", "bbmpc_profile_instantiation", "bbmpc_synchronize", "bbmpc_rollout_episode",
     "bbmpc_comm_unique_id", "bbmpc_comm_init", "bbmpc_gather_records_dev", "bbmpc_gather_wait", "bbmpc_comm_destroy",
     "bbmpc_optimize_gather_dev", "bbmpc_set_stream_default", "bbmpc_optimize_gather", "bbmpc_comm_info", "bbmpc_call_stats",
     "bbmpc_graph_stats",
@@ -119,6 +119,7 @@ def _load():
     lib.bbmpc_set_profiling.argtypes = [vp, i32]
     lib.bbmpc_get_profile.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64),
                                       ctypes.POINTER(ctypes.c_char_p)]
+    lib.bbmpc_profile_instantiation.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p)]
     lib.bbmpc_synchronize.argtypes = [vp]
     lib.bbmpc_rollout_episode.argtypes = [vp, vp, i32, i32, vp]
     lib.bbmpc_comm_unique_id.argtypes = [vp, i64]

@@ -2291,6 +2291,18 @@ int bbmpc_get_profile(bbmpc_handle h, double* ms, int64_t* launches, const char*
     API_END
 }
 
+int bbmpc_profile_instantiation(bbmpc_handle h, const char** name) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(name);
+    const Engine& e = *h->e;
+    // the recorded instantiation belongs to the dominant kernel only while that kernel is the one being launched
+    const size_t nb = strlen(e.dominant_kernel);
+    *name = (e.dominant_inst[0] && strncmp(e.dominant_inst, e.dominant_kernel, nb) == 0 && e.dominant_inst[nb] == '<') ? e.dominant_inst
+                                                                                                                    : e.dominant_kernel;
+    API_END
+}
+
 int bbmpc_synchronize(bbmpc_handle h) {
     API_BEGIN
     CHECK_HANDLE(h);

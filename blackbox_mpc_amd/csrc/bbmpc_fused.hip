@@ -27,6 +27,11 @@ bool Engine::use_fused() const {
     return (long)N <= 2048 || A >= 64;
 }
 
+static void note_inst(Engine& e, int opt, bool samples_lds, bool fastm, int inj, int ilp, bool linger) {
+    snprintf(e.dominant_inst, sizeof(e.dominant_inst), "k_fused_pendulum<%d, %s, %s, %d, %d, %s>", opt, samples_lds ? "true" : "false",
+             fastm ? "true" : "false", inj, ilp, linger ? "true" : "false");
+}
+
 template <int OPT, bool FASTM, int INJ, int ILP>
 static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base, size_t lds_samples) {
 #ifdef BBMPC_KERNEL_DBG
@@ -41,6 +46,7 @@ static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base
                 // the resident form: this launch serves the current call and then every workgroup waits for its agent's next
                 // request on its own (kernels_fused.hpp)
                 auto fl = k_fused_pendulum<OPT, true, FASTM, INJ, ILP, true>;
+                note_inst(e, OPT, true, FASTM, INJ, ILP, true);
                 ensure_max_lds((const void*)fl, (int)limit);
                 for (int a = 0; a < e.A; ++a) {
                     volatile uint32_t* m = e.mbox_host(a);
@@ -68,6 +74,7 @@ static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base
         if (e.subset_n > 0) {
             // the agents whose resident workgroups had left when this control step was posted (Engine::resident_step)
             auto fs = k_fused_pendulum<OPT, true, FASTM, INJ, ILP>;
+            note_inst(e, OPT, true, FASTM, INJ, ILP, false);
             ensure_max_lds((const void*)fs, (int)limit);
             fa.amap = reinterpret_cast<const int*>(e.sync_dev(e.amap_host()));
             hipLaunchKernelGGL(fs, dim3(e.subset_n), dim3(threads), lds_base + lds_samples, e.stream, fa);
@@ -76,10 +83,12 @@ static void launch_fused4(Engine& e, FusedArgs& fa, int threads, size_t lds_base
             return;
         }
         auto fn = k_fused_pendulum<OPT, true, FASTM, INJ, ILP>;
+        note_inst(e, OPT, true, FASTM, INJ, ILP, false);
         ensure_max_lds((const void*)fn, (int)limit);
         launch_with_tail(e, fn, dim3(e.A), dim3(threads), lds_base + lds_samples, fa);
     } else {
         auto fn = k_fused_pendulum<OPT, false, FASTM, INJ, ILP>;
+        note_inst(e, OPT, false, FASTM, INJ, ILP, false);
         launch_with_tail(e, fn, dim3(e.A), dim3(threads), lds_base, fa);
     }
     HIP_CHECK(hipGetLastError());

@@ -244,6 +244,9 @@ struct Engine {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     const char* dominant_kernel = "k_rollout_pendulum";
+    // the template instantiation of the dominant kernel that the last control step launched, spelt the way rocprofv3 prints
+    // kernel names (minus "void "): the key bench.py matches the committed PMC profiles on.  Empty = the plain name is unique.
+    char dominant_inst[128] = "";
 
     explicit Engine(const bbmpc_config& c);
     ~Engine();

@@ -365,3 +365,9 @@ class Engine:
         ms, n, name = ctypes.c_double(), ctypes.c_int64(), ctypes.c_char_p()
         L.check(L.lib.bbmpc_get_profile(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(name)))
         return ms.value, n.value, (name.value or b"").decode()
+
+    def profile_instantiation(self):
+        """The dominant kernel with its template arguments, as rocprofv3 names it minus "void " (include/bbmpc.h)."""
+        name = ctypes.c_char_p()
+        L.check(L.lib.bbmpc_profile_instantiation(self._h, ctypes.byref(name)))
+        return (name.value or b"").decode()

@@ -294,6 +294,13 @@ int bbmpc_set_state(bbmpc_handle h, const char* name, const float* data, int64_t
 int bbmpc_set_profiling(bbmpc_handle h, int32_t enabled);
 int bbmpc_get_profile(bbmpc_handle h, double* rollout_ms_total, int64_t* rollout_launches,
                       const char** kernel_name);
+/* The dominant kernel of the last control step with its template arguments, spelt as rocprofv3 prints kernel names minus the
+ * leading "void " (e.g. "k_fused_pendulum<2, true, true, 2, 1, false>": optimizer, samples in LDS, carried-angle model,
+ * noise source, trajectories per lane, resident) when the engine holds several instantiations of it, the plain name
+ * otherwise.  bench.py attaches the committed PMC counters (profiles/) to a measurement by THIS name, so that a counter of
+ * the BBMPC_STRICT_MATH or the resident instantiation can never be divided by the default instantiation's time.
+ * The string lives in the handle and changes with the next control step. */
+int bbmpc_profile_instantiation(bbmpc_handle h, const char** kernel_instantiation);
 /* Block until everything enqueued on the handle's stream (and its communication stream) has finished. */
 int bbmpc_synchronize(bbmpc_handle h);
 
