@@ -51,15 +51,26 @@ CONFIGS = {
     # BASELINE config 5 proper (its two optimizers), one GPU's share of the 32 agents
     "cfg5pso": dict(env="cheetah", opt="PSO", N=2000, A=4, H=50, iters=5, k=0),
     "cfg5cma": dict(env="cheetah", opt="CMA-ES", N=2000, A=4, H=50, iters=5, k=50),  # per-agent CMA-ES (n = 300 each)
+    # the one learned-model configuration the reference itself pins (tutorials/mujoco/tutorial_two.py:23-33,52-53):
+    # DeterministicMLP 26-500-500-500-20 tanh x3 + linear, RandomSearch, population 4048, planning horizon 15, one agent
+    "cfg_tut2": dict(env="cheetah", opt="RandomSearch", N=4048, A=1, H=15, iters=1, k=0, dims=[26, 500, 500, 500, 20]),
 }
 DEFAULT_STEPS = {"cfg1": 2000, "cfg2": 2000, "cfg3": 2000, "cfg3full": 300, "cfg4": 400, "cfg4pi2": 400, "cfg5cem": 60,
-                 "cfg5pso": 60, "cfg5full": 10, "cfg5cma": 30}
+                 "cfg5pso": 60, "cfg5full": 10, "cfg5cma": 30, "cfg_tut2": 100}
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
 VALU_ISSUE_NS_MEASURED = 1.07       # one VALU instruction per SIMD, measured on one CU (tools/microbench/pk_fp32.hip)
 VALU_ISSUE_CYCLES_GUIDE = 2         # v_fma_f32, wave64 on a SIMD-32 (MI355X_MICROARCH.md)
 CLOCK_GHZ = 2.4
 MLP_DIMS = [26, 200, 200, 20]
+
+
+def mlp_dims(c):
+    return list(c.get("dims") or MLP_DIMS)
+
+
+def mlp_acts(c):
+    return ["tanh"] * (len(mlp_dims(c)) - 2) + [None]
 SECONDARY = "cfg4pi2"
 
 
@@ -102,8 +113,8 @@ class Workload:
             from blackbox_mpc_amd.utils.cheetah import reward_function
             self.U, self.S = 6, 20
             act_space, obs_space = Box([-1.0] * self.U, [1.0] * self.U), Box([-10.0] * self.S, [10.0] * self.S)
-            net = DeterministicMLP(layers=MLP_DIMS, activation_functions=SY.CHEETAH_ACTIVATIONS, seed=1)
-            net.set_weights(*SY.make_mlp_params(MLP_DIMS, seed=42))      # Glorot-uniform / zero bias, last layer x0.1
+            net = DeterministicMLP(layers=mlp_dims(c), activation_functions=mlp_acts(c), seed=1)
+            net.set_weights(*SY.make_mlp_params(mlp_dims(c), seed=42))      # Glorot-uniform / zero bias, last layer x0.1
             handler = SystemDynamicsHandler(act_space, obs_space, dynamics_function=net, true_model=False,
                                             is_normalized=True)
             handler.set_normalization_stats(*SY.cheetah_stats(self.S, self.U))
@@ -481,7 +492,8 @@ def roofline(W, m, name, world):
     # local agent in one launch, the per-iteration kernels one iteration (SPSA: two launches of N per iteration)
     launch_traj = N * A * (iters if fused else 1)
     if mlp:
-        flops_per_traj = H * 2.0 * sum(MLP_DIMS[i] * MLP_DIMS[i + 1] for i in range(len(MLP_DIMS) - 1))
+        dims = mlp_dims(c)
+        flops_per_traj = H * 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
         achieved = launch_traj * flops_per_traj / (avg_ms * 1e-3) / 1e12 if m["roll_n"] else None
         roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None, "traffic": None,
@@ -574,7 +586,7 @@ def result_block(name, W, m, world, steps, warmup):
     traj = c["N"] * c["iters"] * (2 if c["opt"] == "SPSA" else 1)
     return {
         "metric": "MPC control-steps/sec (agent-control-steps; %s, %s N=%d H=%d)"
-                  % ("HalfCheetah learned MLP 26-200-200-20" if W.mlp else "Pendulum true model", c["opt"], c["N"], c["H"]),
+                  % (("HalfCheetah learned MLP %s" % "-".join(map(str, mlp_dims(c)))) if W.mlp else "Pendulum true model", c["opt"], c["N"], c["H"]),
         "value": value,
         "unit": "control-steps/s",
         "value_definition": ("agents / median wall time of MPCPolicy.act(obs, t): NumPy observation in, all optimizer "
@@ -758,7 +770,7 @@ def main():
             s_steps = max(30, min(DEFAULT_STEPS[SECONDARY], args.steps))
             sec = run_block(SECONDARY, s_steps, 5, launch_per_call=False)
             if not args.no_cpu_baseline:
-                sec["cpu_baseline"] = cpu_baseline(CONFIGS[SECONDARY], budget_s=10.0)
+                sec["cpu_baseline"] = cpu_baseline(CONFIGS[SECONDARY], budget_s=6.0)
             out["secondary"] = sec
         # ---- BASELINE config 3 as it is stated: 64 agents IN TOTAL (strong scaling: 64 / N per GPU), Pendulum PI2
         # N=1000 H=30.  One GPU takes all 64 in about the time it takes 8 (the persistent kernel is one workgroup per
@@ -787,32 +799,40 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(c, budget_s=12.0):
-    """The CPU restatement of the same hot path timed on this host: oracle/oracle_c.c (plain C, OpenMP over candidate
-    trajectories -- the axis the reference's TF-CPU executor parallelises), closed loop, noise drawn inside the timed
-    region as the reference's graph does.  Also reported for context: the same C path on one core and (pendulum only)
-    the NumPy op-for-op oracle (Python-overhead bound, like an eager TF run).  This is the ONLY place bench.py touches
-    oracle/."""
+def cpu_baseline(c, budget_s=8.0):
+    """The CPU restatements of the same hot path timed on this host, closed loop, noise drawn inside the timed region as
+    the reference's graph does.  No TF-CPU number can exist (TensorFlow absent, the reference publishes none), so:
+
+    * learned-model configurations: `value` = oracle/oracle_torch.py, the op graph of deterministic.py:62-73 /
+      deterministic_mlp.py:49-50 one torch-CPU op per TF op, fp32, the framework's multi-threaded sgemm on every host
+      thread (the closest stand-in for TF-CPU's Eigen contraction + executor); `checker_value` = the plain-C
+      checker oracle/oracle_c.c (a per-row double-precision matvec: a parity tool, not a fast CPU implementation);
+    * pendulum configurations: `value` = oracle/oracle_c.c with OpenMP over candidate trajectories (the axis the reference's
+      TF-CPU executor parallelises), best team size of a short ladder; `torch_value` = the op-by-op torch restatement,
+      which at 500 x 3 floats per op is bound by the framework's per-op overhead, like an eager TF run.
+
+    This is the ONLY place bench.py touches oracle/.  The whole leg is capped at about 2 x budget_s of wall time."""
     os.environ.setdefault("OMP_WAIT_POLICY", "ACTIVE")
+    import torch
     from oracle import oracle_c as OC
-    from oracle import oracle_np as O
+    from oracle import oracle_torch as OT
     from blackbox_mpc_amd.utils import synthetic as SY
     N, A, H, iters, k = c["N"], c["A"], c["H"], c["iters"], c["k"]
     mlp = c["env"] == "cheetah"
     if mlp:
         S, U = 20, 6
-        ws, bs = SY.make_mlp_params(MLP_DIMS, seed=42)
-        acts, stats = SY.CHEETAH_ACTIVATIONS, SY.cheetah_stats(S, U)
+        ws, bs = SY.make_mlp_params(mlp_dims(c), seed=42)
+        acts, stats = mlp_acts(c), SY.cheetah_stats(S, U)
         lo, hi = [-1.0] * U, [1.0] * U
         start = SY.cheetah_start_states(A, S)
         co = OC.COracle("mlp", "cheetah", lo, hi, N, A, H, S, iters=iters, k=max(k, 1), mlp=(ws, bs, acts), stats=stats)
-        ev = None
+        to = OT.make(c["opt"], "cheetah", lo, hi, N, A, H, iters, k, mlp=(ws, bs, acts), stats=stats)
     else:
         S, U = 3, 1
         lo, hi = [-2.0], [2.0]
         start = SY.pendulum_start_states(A)
         co = OC.COracle("pendulum", "pendulum", lo, hi, N, A, H, S, iters=iters, k=max(k, 1))
-        ev = O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))
+        to = OT.make(c["opt"], "pendulum", lo, hi, N, A, H, iters, k)
 
     def run_c(budget, max_n):
         co.reset()
@@ -825,51 +845,69 @@ def cpu_baseline(c, budget_s=12.0):
             n += 1
         return n, n * A / t_used
 
-    # thread count: a control step at N*A = a few hundred rows is too small for every core of a big host (fork/join
-    # cost outgrows the work), so probe a ladder of team sizes briefly and keep the fastest
+    def run_torch(budget, max_n):
+        to.reset()
+        state, n, t_used = torch.from_numpy(start), 0, 0.0
+        with torch.no_grad():
+            while t_used < budget and n < max_n:
+                t0 = time.perf_counter()
+                _, nxt, _ = to.call(state)
+                t_used += time.perf_counter() - t0
+                state = nxt
+                n += 1
+        return n, n * A / t_used
+
     max_t = OC.num_threads()
-    run_c(0.3, 3)                                   # warm the thread pool / page in
-    ladder = sorted({t for t in ((16, 32, 64, max_t) if mlp else (1, 2, 4, 8, 16, 32, 64, max_t)) if t <= max_t})
-    probe = {}
-    for t in ladder:
-        OC.set_num_threads(t)
-        probe[t] = run_c(1.0 if mlp else 0.4, 400)[1]
-    cores = max(probe, key=probe.get)
-    OC.set_num_threads(cores)
-    n_all, v_all = run_c(budget_s, 40000)
-    OC.set_num_threads(1)
-    n_one, v_one = run_c(3.0, 400)
-    OC.set_num_threads(max_t)
-    res = {"value": v_all, "unit": "control-steps/s", "cores": cores, "kind": "port",
-           "sample": "%d closed-loop control steps of the same workload with the C restatement oracle/oracle_c.c "
-                     "(OpenMP over trajectories, best of a thread-count ladder = %d of %d threads, noise drawn in the "
-                     "timed region)" % (n_all, cores, max_t),
-           "thread_ladder": {str(t): round(v, 2) for t, v in probe.items()},
-           "single_core_value": v_one,
-           "note": "no TF-CPU number exists for the reference (TensorFlow absent, reference publishes none); "
-                   "single_core_value = same C path on 1 thread (%d steps)" % n_one}
-    if ev is not None:
-        # NumPy op-for-op oracle, a short sample (noise generation excluded)
-        rng = np.random.default_rng(0)
-        if c["opt"] == "CEM":
-            opt = O.CEM(ev, lo, hi, horizon=H, max_iterations=iters, population=N, num_elite=k, num_agents=A)
-            mk = lambda: {"trunc": [O.truncated_normal_noise(rng, (N, A, H, U)) for _ in range(iters)]}
-        elif c["opt"] == "PI2":
-            opt = O.PI2(ev, lo, hi, horizon=H, max_iterations=iters, population=N, num_agents=A)
-            mk = lambda: {"trunc": [O.truncated_normal_noise(rng, (N, A, H, U)) for _ in range(iters)]}
+    host_threads = os.cpu_count() or max_t
+    saved_torch_threads = torch.get_num_threads()
+    res = {"unit": "control-steps/s", "kind": "port",
+           "note": "no TF-CPU number exists for the reference (TensorFlow absent, reference publishes none)"}
+    try:
+        if mlp:
+            # ---- torch-CPU op by op on every host thread (a short ladder: a small sgemm does not always want them all)
+            probe = {}
+            for t in sorted({min(host_threads, x) for x in (8, 16, 32, host_threads)}):
+                torch.set_num_threads(t)
+                run_torch(0.2, 1)
+                probe[t] = run_torch(0.6, 50)[1]
+            cores = max(probe, key=probe.get)
+            torch.set_num_threads(cores)
+            n_t, v_t = run_torch(budget_s, 40000)
+            OC.set_num_threads(min(max_t, 32))
+            n_c, v_c = run_c(2.0, 400)
+            res.update({"value": v_t, "cores": cores,
+                        "sample": "%d closed-loop control steps of the same workload with oracle/oracle_torch.py: torch-CPU fp32, one op "
+                                  "per TF op of deterministic.py:62-73 / deterministic_mlp.py:49-50, multi-threaded sgemm, best of a thread "
+                                  "ladder = %d of %d host threads, draws generated in the timed region" % (n_t, cores, host_threads),
+                        "thread_ladder": {str(t): round(v, 2) for t, v in probe.items()},
+                        "checker_value": v_c,
+                        "checker_note": "oracle/oracle_c.c (the parity checker: per-row double-precision matvec, OpenMP over "
+                                        "trajectories, %d threads, %d steps) -- not a tuned CPU implementation" % (min(max_t, 32), n_c)})
         else:
-            opt = O.RandomSearch(ev, lo, hi, horizon=H, population=N, num_agents=A)
-            mk = lambda: {"uniform": rng.random((N, A, H, U)).astype(np.float32)}
-        state, n_np, t_np = start, 0, 0.0
-        while t_np < 3.0 and n_np < 50:
-            noise = mk()
-            t0 = time.perf_counter()
-            _, nxt, _ = opt.call(state, noise)
-            t_np += time.perf_counter() - t0
-            state = nxt
-            n_np += 1
-        res["numpy_oracle_value"] = n_np * A / t_np
-        res["note"] += "; numpy_oracle_value = op-for-op NumPy oracle (%d steps, noise excluded)" % n_np
+            run_c(0.2, 3)                                   # warm the thread pool / page in
+            ladder = sorted({t for t in (1, 4, 8, 16, 32, max_t) if t <= max_t})
+            probe = {}
+            for t in ladder:
+                OC.set_num_threads(t)
+                probe[t] = run_c(0.3, 400)[1]
+            cores = max(probe, key=probe.get)
+            OC.set_num_threads(cores)
+            n_all, v_all = run_c(budget_s, 40000)
+            torch.set_num_threads(min(host_threads, 8))
+            run_torch(0.2, 1)
+            n_t, v_t = run_torch(2.0, 200)
+            res.update({"value": v_all, "cores": cores,
+                        "sample": "%d closed-loop control steps of the same workload with the C restatement oracle/oracle_c.c "
+                                  "(OpenMP over trajectories, best of a thread-count ladder = %d of %d threads, noise drawn in the "
+                                  "timed region)" % (n_all, cores, max_t),
+                        "thread_ladder": {str(t): round(v, 2) for t, v in probe.items()},
+                        "single_core_value": probe.get(1),
+                        "torch_value": v_t,
+                        "torch_note": "oracle/oracle_torch.py, one torch-CPU op per TF op (%d steps): per-op overhead bound at this "
+                                      "size, like an eager TF run" % n_t})
+    finally:
+        torch.set_num_threads(saved_torch_threads)
+        OC.set_num_threads(max_t)
     return res
 
 
