@@ -559,7 +559,7 @@ def roofline(W, m, name, world):
 def describe(name, W, world):
     c = W.c
     return ("BASELINE %s: %s, %s, num_agents=%d/GPU, N=%d, H=%d, %d iters%s, closed loop (the model is the environment)"
-            % (name, "HalfCheetah(mod) S=20 U=6 learned MLP 26-200-200-20 dynamics" if W.mlp else "Pendulum-v0 true dynamics",
+            % (name, ("HalfCheetah(mod) S=20 U=6 learned MLP %s dynamics" % "-".join(map(str, mlp_dims(c)))) if W.mlp else "Pendulum-v0 true dynamics",
                c["opt"], c["A"], c["N"], c["H"], c["iters"], (", k=%d" % c["k"]) if c["k"] else ""))
 
 
@@ -804,8 +804,8 @@ def cpu_baseline(c, budget_s=8.0):
     the reference's graph does.  No TF-CPU number can exist (TensorFlow absent, the reference publishes none), so:
 
     * learned-model configurations: `value` = oracle/oracle_torch.py, the op graph of deterministic.py:62-73 /
-      deterministic_mlp.py:49-50 one torch-CPU op per TF op, fp32, the framework's multi-threaded sgemm on every host
-      thread (the closest stand-in for TF-CPU's Eigen contraction + executor); `checker_value` = the plain-C
+      deterministic_mlp.py:49-50 one torch-CPU op per TF op, fp32, the framework's multi-threaded sgemm at the best
+      thread count of a short ladder (the closest stand-in for TF-CPU's Eigen contraction + executor); `checker_value` = the plain-C
       checker oracle/oracle_c.c (a per-row double-precision matvec: a parity tool, not a fast CPU implementation);
     * pendulum configurations: `value` = oracle/oracle_c.c with OpenMP over candidate trajectories (the axis the reference's
       TF-CPU executor parallelises), best team size of a short ladder; `torch_value` = the op-by-op torch restatement,
@@ -866,7 +866,7 @@ def cpu_baseline(c, budget_s=8.0):
         if mlp:
             # ---- torch-CPU op by op on every host thread (a short ladder: a small sgemm does not always want them all)
             probe = {}
-            for t in sorted({min(host_threads, x) for x in (8, 16, 32, host_threads)}):
+            for t in sorted({min(host_threads, x) for x in (8, 16, 32)}):       # (every thread of a 256-thread host: 0.01 steps/s)
                 torch.set_num_threads(t)
                 run_torch(0.2, 1)
                 probe[t] = run_torch(0.6, 50)[1]

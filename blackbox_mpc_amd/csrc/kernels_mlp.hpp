@@ -80,11 +80,13 @@ struct MlpRolloutArgs {
 // max), so every VALU instruction shaved off the activations is matrix time gained: this form replaced
 // exp(2|x|) -> 1 - 2r spelled as (|x|+|x|) * log2e, exp2, +1, rcp, r+r, 1-  (eight instructions).
 __device__ __forceinline__ float bb_tanhf(float x) {
-    const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * fabsf(x));   // +inf for large |x| -> 1 - 0
+    // tanh x = 1 - 2 / (1 + e^(2x)) holds for either sign: +inf for large x -> 1 - 0, 0 for large -x -> 1 - 2; round 5 dropped the
+    // |x| / copysign pair around it (one v_bfi per value: five instructions instead of six, same absolute error bound -- the
+    // reciprocal's argument lies in [1, 2) for x < 0 and the cancellation near zero is the positive side's mirrored).
+    const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * x);
     // v_rcp_f32 (1 ulp).  __frcp_rn is the correctly rounded reciprocal, i.e. a full IEEE division: ten instructions
     // (v_div_scale x2, v_rcp, four fmas, v_div_fmas, v_div_fixup) per activation value, on the MFMAs' issue port.
-    const float r = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
-    return copysignf(r, x);                                  // NaN stays NaN (exp2(NaN) = NaN)
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);   // NaN stays NaN (exp2(NaN) = NaN)
 }
 
 __device__ __forceinline__ float apply_act(float x, int act) {
@@ -578,6 +580,28 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     const bool normd = m.normalized != 0;
     const bool half1 = CHALF >= 0 ? CHALF != 0 : m.half_tail[1] != 0;      // inputs of layer 1 / of the last layer
     const bool half2 = CHALF >= 0 ? CHALF != 0 : m.half_tail[2] != 0;
+    // Round 5, padding MFMAs.  (i) The last K tile of layer 0 holds rem0 = (S + U) - 16 (it0n - 1) input features; placed into the
+    // slots 4g + {0 .. tk0-1} (tk0 = ceil(rem0 / 4): the half_tail rule of the hidden tiles, generalised) they leave the tile's
+    // MFMAs tk0 .. 3 with nothing but zeros, and those are not issued (26 inputs: seven MFMAs per feature tile instead of
+    // eight).  The operands come from the one packed array every kernel shares (set_mlp keeps the inputs in order), gathered in
+    // this kernel's slot order by the prologue.  (ii) With 16 < dim_S <= 20 the second output tile of the last layer has at
+    // most four live rows: its K slab runs as four v_mfma_f32_4x4x1_16b_f32 (block = (k row g, particle quad): 4 features x 16
+    // particles x 4 k per instruction, 8 cycles) instead of four 16x16x4 (32 cycles each, twelve of sixteen rows zero); the four
+    // k-row partials of a (feature, particle) go to LDS side by side and the epilogue thread adds them, in g order, ahead of
+    // the sum over the waves.
+    constexpr bool CT0 = CS != 0 && CU != 0;
+    constexpr int C_IT0N = CT0 ? (CS + CU + 15) / 16 : 0;
+    const int it0n = CT0 ? C_IT0N : m.tiles[0];
+    const int rem0 = (CT0 ? CS + CU : m.dims[0]) - 16 * (it0n - 1);
+    const int tk0 = (rem0 + 3) >> 2;
+    const bool out4 = S > 16 && S <= 20;
+    auto l0_live = [&](int it, int sidx) { return it + 1 < it0n || (it + 1 == it0n && sidx < tk0); };
+    // LDS address of input feature f of particle pp in the xs tiles (tile_addr with the last tile's slots permuted)
+    auto xs_addr = [&](int f, int pp) {
+        const int t = f >> 4, j = f & 15;
+        const int slot = (t + 1 == it0n) ? 4 * (j / tk0) + (j % tk0) : j;
+        return ((t * 64) + ((slot >> 2) * 16 + pp)) * 4 + (slot & 3);
+    };
     // ---- LDS carve
     const int sz_xs = IT0 * 256, sz_h0 = HT * 256, sz_part = NW * OTL * 256, sz_st = 2 * MLP_TP * Sp,
               sz_acts = (H * MLP_TP * U + 3) & ~3, sz_pen = (MLP_TP * U + 63) & ~63;
@@ -602,16 +626,21 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     float wr_in[IT0 * 4], wr_hid[HT * 4], wr_out[OTL * 4];
     // per-lane 32-bit offsets from the (uniform) packed-array bases: the loads take an SGPR base + VGPR offset and no
     // 64-bit per-lane pointer has to stay live across the recurrence
-    const int it0n = m.tiles[0];
-    const unsigned w_in_off = (unsigned)(wave * it0n * 256 + lane);
     const float* __restrict__ w_in_b = m.wpack[0];
-    auto load_w_in = [&](float* w, unsigned off) {
+    auto load_w_in = [&](float* w, int ft) {
+        const unsigned base = (unsigned)(ft * it0n * 256);
 #pragma unroll
         for (int it = 0; it < IT0; ++it)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) w[it * 4 + s] = (it < it0n) ? w_in_b[off + (unsigned)((it * 4 + s) * 64)] : 0.0f;
+            for (int s = 0; s < 4; ++s) {
+                // packed order: [it][s'][lane'] holds k slot 4 (lane' >> 4) + s' of tile it; this kernel's slot 4g + s of the last
+                // tile is the packed slot j = tk0 g + s
+                const int g = lane >> 4, j = (it + 1 == it0n) ? tk0 * g + s : 4 * g + s;
+                const bool live = l0_live(it, s) && (it + 1 < it0n || j < rem0);
+                w[it * 4 + s] = live ? w_in_b[base + (unsigned)((it * 4 + (j & 3)) * 64 + 16 * (j >> 2) + (lane & 15))] : 0.0f;
+            }
     };
-    load_w_in(wr_in, w_in_off);
+    load_w_in(wr_in, wave);
 #pragma unroll
     for (int it = 0; it < HT; ++it)
 #pragma unroll
@@ -635,7 +664,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
         }
         if (owner) {
             float t8[IT0 * 4];
-            load_w_in(t8, (unsigned)(XT * it0n * 256 + lane));
+            load_w_in(t8, XT);
 #pragma unroll
             for (int it = 0; it < IT0; ++it)
 #pragma unroll
@@ -643,8 +672,10 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
 #pragma unroll
             for (int ot = 0; ot < OTL; ++ot)
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    xo[((IT0 + ot) * 64 + lane) * 4 + s] = (ot < m.tiles[3]) ? m.wpack[2][(((size_t)ot * HT + XT) * 4 + s) * 64 + lane] : 0.0f;
+                for (int s = 0; s < 4; ++s) {
+                    const int ln = (ot == 1 && out4) ? 16 * (lane >> 4) + (lane & 3) : lane;      // 4x4x1: A lane 4b + i = row i of block b (its k row: lane >> 4)
+                    xo[((IT0 + ot) * 64 + lane) * 4 + s] = (ot < m.tiles[3]) ? m.wpack[2][(((size_t)ot * HT + XT) * 4 + s) * 64 + ln] : 0.0f;
+                }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 xo[(XO_B0 * 64 + lane) * 4 + s] = m.bpack[0][(unsigned)((XT * 64 + lane) * 4 + s)];
@@ -664,7 +695,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     if constexpr (NTILES == 2) {
         if (t2 >= 0) {
             float t8[IT0 * 4];
-            load_w_in(t8, (unsigned)(t2 * it0n * 256 + lane));
+            load_w_in(t8, t2);
 #pragma unroll
             for (int it = 0; it < IT0; ++it)
 #pragma unroll
@@ -676,8 +707,10 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
 #pragma unroll
     for (int ot = 0; ot < OTL; ++ot)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            wr_out[ot * 4 + s] = (ot < m.tiles[3]) ? m.wpack[2][(((size_t)ot * HT + wave) * 4 + s) * 64 + lane] : 0.0f;
+        for (int s = 0; s < 4; ++s) {
+            const int ln = (ot == 1 && out4) ? 16 * (lane >> 4) + (lane & 3) : lane;
+            wr_out[ot * 4 + s] = (ot < m.tiles[3]) ? m.wpack[2][(((size_t)ot * HT + wave) * 4 + s) * 64 + ln] : 0.0f;
+        }
     const unsigned bias_off = (unsigned)((wave * 64 + lane) * 4);
     const f32x4 bias0_r = *reinterpret_cast<const f32x4*>(m.bpack[0] + bias_off);
     const f32x4 bias1_r = *reinterpret_cast<const f32x4*>(m.bpack[1] + bias_off);
@@ -713,21 +746,86 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
         for (int i = tid; i < MLP_TP * (S + U); i += NT) {
             const int f = i / MLP_TP, pp = i % MLP_TP;
             const float v = (f < S) ? st[pp * Sp + f] : acts[pp * U + (f - S)];
-            xs[tile_addr(f, pp)] = (v - nmean[f]) * ninv[f];
+            xs[xs_addr(f, pp)] = (v - nmean[f]) * ninv[f];
         }
     }
     __syncthreads();
 
+    // epilogue of step t: one thread per (feature, particle); index math is done unconditionally on a clamped
+    // index so that it can be scheduled under the other tile's MFMAs, only the stores are predicated
+    const int ef = min(tid / MLP_TP, S + U - 1), epp = tid % MLP_TP;
+    const bool e_live = tid < MLP_TP * (S + U);
+    const int e_ot = ef >> 4, e_ln = ((ef & 15) >> 2) * 16 + epp, e_rg = ef & 3;
+    const int e_xaddr = xs_addr(ef, epp);
+    // (4-row form of output tile 1: the four k-row partials of feature ef >= 16 lie side by side, [ef - 16][particle][g])
+    const bool e4 = out4 && ef >= 16;
+    auto epi_part = [&](int ti) {
+        return T_part(ti) + (e4 ? 256 + (((ef - 16) & 3) * 16 + epp) * 4 : (((size_t)e_ot) * 64 + e_ln) * 4 + e_rg);
+    };
+    // one wave's contribution to the pre-activation of this thread's feature
+    auto epi_term = [&](const float* pw) {
+        if (e4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(pw);
+            return ((v.x + v.y) + v.z) + v.w;
+        }
+        return pw[0];
+    };
+    auto epi_reduce = [&](int ti) {
+        if (NTILES == 2 && wid * 64 >= MLP_TP * S) return 0.0f;      // a wave of action features only: nothing to reduce
+        const float* part = epi_part(ti);
+        float acc = lbias[min(ef, S - 1)];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc = acc + epi_term(part + (size_t)w * OTL * 256);
+        return acc;
+    };
     // ---- stages
+    // the live MFMAs of K tile `it` of layer 0 (w0 .. w3: the tile's four operands)
+    auto l0_tile = [&](int it, float w0, float w1, float w2, float w3, const f32x4& b, f32x4 acc) {
+        if (l0_live(it, 0)) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, b.x, acc, 0, 0, 0);
+        if (l0_live(it, 1)) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, b.y, acc, 0, 0, 0);
+        if (l0_live(it, 2)) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2, b.z, acc, 0, 0, 0);
+        if (l0_live(it, 3)) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w3, b.w, acc, 0, 0, 0);
+        return acc;
+    };
+    // the K slab of the last layer from one feature tile's activations `h` (wo0: operands of output tile 0, wo1: of tile 1);
+    // `tail_half`: the slab is the half-empty hidden tile (its k slots 4g + {2, 3} are padding)
+    auto out_slab = [&](int ft, const f32x4& h, const f32x4& wo0, const f32x4& wo1, bool tail_half, float* part) {
+        f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo0.x, h.x, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo0.y, h.y, o, 0, 0, 0);
+        if (!tail_half) {
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo0.z, h.z, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo0.w, h.w, o, 0, 0, 0);
+        }
+        *reinterpret_cast<f32x4*>(part + (((size_t)ft * OTL + 0) * 64 + lane) * 4) = o;
+        f32x4 o1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (out4) {
+            // block b = lane >> 2 = (k row g = lane >> 4, particle quad): D register i, lane 4b + j = feature 16 + i of particle
+            // lane & 15 over the k slots 4g + {0..3} of this tile; stored [i][particle][g]
+            o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo1.x, h.x, o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo1.y, h.y, o1, 0, 0, 0);
+            if (!tail_half) {
+                o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo1.z, h.z, o1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo1.w, h.w, o1, 0, 0, 0);
+            }
+            float* p1 = part + ((size_t)ft * OTL + 1) * 256 + (lane & 15) * 4 + (lane >> 4);
+            p1[0] = o1.x; p1[64] = o1.y; p1[128] = o1.z; p1[192] = o1.w;
+        } else {
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wo1.x, h.x, o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wo1.y, h.y, o1, 0, 0, 0);
+            if (!tail_half) {
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wo1.z, h.z, o1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wo1.w, h.w, o1, 0, 0, 0);
+            }
+            *reinterpret_cast<f32x4*>(part + (((size_t)ft * OTL + 1) * 64 + lane) * 4) = o1;
+        }
+    };
     auto layer0 = [&](int ti, int ft, const float* w, f32x4 acc) {
         const float* xs = T_xs(ti);
 #pragma unroll
         for (int it = 0; it < IT0; ++it) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(xs + ((size_t)it * 64 + lane) * 4);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[it * 4 + 0], b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[it * 4 + 1], b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[it * 4 + 2], b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[it * 4 + 3], b.w, acc, 0, 0, 0);
+            acc = l0_tile(it, w[it * 4 + 0], w[it * 4 + 1], w[it * 4 + 2], w[it * 4 + 3], b, acc);
         }
         acc.x = apply_act_ct<A0>(acc.x); acc.y = apply_act_ct<A0>(acc.y);
         acc.z = apply_act_ct<A0>(acc.z); acc.w = apply_act_ct<A0>(acc.w);
@@ -757,16 +855,10 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
 #pragma unroll
         for (int it = 0; it < IT0; ++it) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(xs + ((size_t)it * 64 + lane) * 4);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 0], b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 1], b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 2], b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[it * 4 + 3], b.w, acc, 0, 0, 0);
+            acc = l0_tile(it, wr_in[it * 4 + 0], wr_in[it * 4 + 1], wr_in[it * 4 + 2], wr_in[it * 4 + 3], b, acc);
             if (has2) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(w2 + ((size_t)it * 64 + lane) * 4);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b.x, acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b.y, acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b.z, acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b.w, acc2, 0, 0, 0);
+                acc2 = l0_tile(it, w.x, w.y, w.z, w.w, b, acc2);
             }
         }
         acc.x = apply_act_ct<A0>(acc.x); acc.y = apply_act_ct<A0>(acc.y);
@@ -794,19 +886,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
         }
         acc.x = apply_act_ct<A1>(acc.x); acc.y = apply_act_ct<A1>(acc.y);
         acc.z = apply_act_ct<A1>(acc.z); acc.w = apply_act_ct<A1>(acc.w);
-        float* part = T_part(ti);
-#pragma unroll
-        for (int ot = 0; ot < OTL; ++ot) {
-            f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
-            const f32x4 wo = xo_get(IT0 + ot);
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo.x, acc.x, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo.y, acc.y, o, 0, 0, 0);
-            if (!half2) {
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo.z, acc.z, o, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(wo.w, acc.w, o, 0, 0, 0);
-            }
-            *reinterpret_cast<f32x4*>(part + (((size_t)XT * OTL + ot) * 64 + lane) * 4) = o;
-        }
+        out_slab(XT, acc, xo_get(IT0 + 0), xo_get(IT0 + 1), half2, T_part(ti));
     };
     // Layer 1 + K split of tile `ti`.  When `co` >= 0 the partial-sum reduction of tile `co`'s epilogue
     // (one LDS read + one add per producing wave) is issued between this tile's dependent MFMA groups, so
@@ -857,7 +937,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
                 const f32x4 b = bn;                       // operand of this group was loaded during the previous one
                 if (it + 1 < HT) bn = *reinterpret_cast<const f32x4*>(h0 + ((size_t)(it + 1) * 64 + lane) * 4);
                 float pv = 0.0f;
-                if (co >= 0) pv = cpart[(size_t)it * OTL * 256];
+                if (co >= 0) pv = epi_term(cpart + (size_t)it * OTL * 256);
                 if constexpr (NTILES == 2) {
                     if (it < KQ && helper && kbase + it < HT) {               // wave-uniform
                         const f32x4 bx = *reinterpret_cast<const f32x4*>(h0 + ((size_t)(kbase + it) * 64 + lane) * 4);
@@ -872,18 +952,12 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
                     for (int j = 0; j < IT0; ++j) {
                         if (ta >= 0 && it == apos + j) {
                             const f32x4 ba = *reinterpret_cast<const f32x4*>(xsa + ((size_t)j * 64 + lane) * 4);
-                            acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[j * 4 + 0], ba.x, acca, 0, 0, 0);
-                            acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[j * 4 + 1], ba.y, acca, 0, 0, 0);
-                            acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[j * 4 + 2], ba.z, acca, 0, 0, 0);
-                            acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_in[j * 4 + 3], ba.w, acca, 0, 0, 0);
+                            acca = l0_tile(j, wr_in[j * 4 + 0], wr_in[j * 4 + 1], wr_in[j * 4 + 2], wr_in[j * 4 + 3], ba, acca);
                         }
                         if (ta >= 0 && owner && it == apos + IT0 + j) {
                             const f32x4 ba = *reinterpret_cast<const f32x4*>(xsa + ((size_t)j * 64 + lane) * 4);
                             const f32x4 wa = xo_get(j);
-                            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, ba.x, accb, 0, 0, 0);
-                            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, ba.y, accb, 0, 0, 0);
-                            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, ba.z, accb, 0, 0, 0);
-                            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, ba.w, accb, 0, 0, 0);
+                            accb = l0_tile(j, wa.x, wa.y, wa.z, wa.w, ba, accb);
                         }
                     }
                 }
@@ -929,33 +1003,11 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
         }
         acc.x = apply_act_ct<A1>(acc.x); acc.y = apply_act_ct<A1>(acc.y);
         acc.z = apply_act_ct<A1>(acc.z); acc.w = apply_act_ct<A1>(acc.w);
-        float* part = T_part(ti);
-#pragma unroll
-        for (int ot = 0; ot < OTL; ++ot) {
-            f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 0], acc.x, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 1], acc.y, o, 0, 0, 0);
-            if (NTILES == 2 || wave + 1 < HT || !half2) {       // one-tile mode: the last wave's K slice is the half-empty tile
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 2], acc.z, o, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_out[ot * 4 + 3], acc.w, o, 0, 0, 0);
-            }
-            *reinterpret_cast<f32x4*>(part + (((size_t)wave * OTL + ot) * 64 + lane) * 4) = o;
+        {
+            const f32x4 wo0 = {wr_out[0], wr_out[1], wr_out[2], wr_out[3]}, wo1 = {wr_out[4], wr_out[5], wr_out[6], wr_out[7]};
+            // one-tile mode: the last wave's K slice is the half-empty tile
+            out_slab(wave, acc, wo0, wo1, !(NTILES == 2 || wave + 1 < HT || !half2), T_part(ti));
         }
-    };
-    // epilogue of step t: one thread per (feature, particle); index math is done unconditionally on a clamped
-    // index so that it can be scheduled under the other tile's MFMAs, only the stores are predicated
-    const int ef = min(tid / MLP_TP, S + U - 1), epp = tid % MLP_TP;
-    const bool e_live = tid < MLP_TP * (S + U);
-    const int e_ot = ef >> 4, e_ln = ((ef & 15) >> 2) * 16 + epp, e_rg = ef & 3;
-    const int e_xaddr = tile_addr(ef, epp);
-    auto epi_part = [&](int ti) { return T_part(ti) + (((size_t)e_ot) * 64 + e_ln) * 4 + e_rg; };
-    auto epi_reduce = [&](int ti) {
-        if (NTILES == 2 && wid * 64 >= MLP_TP * S) return 0.0f;      // a wave of action features only: nothing to reduce
-        const float* part = epi_part(ti);
-        float acc = lbias[min(ef, S - 1)];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) acc = acc + part[(size_t)w * OTL * 256];
-        return acc;
     };
     // finish the epilogue of step t given the reduced pre-activation `acc`
     // cheetah reward (cost_func.py:5-22) needs cur[5..7], cur[17], next[17] and the actions only: the epilogue

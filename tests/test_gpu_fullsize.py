@@ -444,3 +444,35 @@ def test_steady_state_control_step_replayed_as_a_graph(L, monkeypatch, opt, N, A
     for i, (r0, r1) in enumerate(zip(out["0"], out["1"])):
         for x0, x1 in zip(r0, r1):
             np.testing.assert_array_equal(x0, x1, err_msg="control step %d" % i)
+
+
+def test_tutorial_two_random_search_full_size(L):
+    # The one learned-model configuration the reference pins (tutorials/mujoco/tutorial_two.py:23-33,52-53): DeterministicMLP
+    # 26-500-500-500-20 tanh x 3 + linear, RandomSearch, population 4048, planning horizon 15, one agent -- bench.py's cfg_tut2.
+    # Rewards of all 4048 candidates against the C oracle, then the argmax / first action / tail in lock-step.
+    from blackbox_mpc_amd.engine import Engine
+    S, U, N, A, H = 20, 6, 4048, 1, 15
+    dims, acts = [26, 500, 500, 500, 20], ["tanh", "tanh", "tanh", None]
+    ws, bs = O.make_mlp_params(dims, seed=42)
+    stats = _cheetah_stats(S, U)
+    eng = Engine(L.OPT_RANDOM_SEARCH, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=A, planning_horizon=H,
+                 population_size=N)
+    eng.set_mlp(ws, bs, [1, 1, 1, 0], stats)
+    eng.set_trace(True)
+    co = OC.COracle("mlp", "cheetah", [-1.0] * U, [1.0] * U, N, A, H, S, iters=1, k=1, mlp=(ws, bs, acts), stats=stats)
+    rng = np.random.default_rng(52)
+    states = O.cheetah_start_states(A, S)
+    RT, AT = 1e-3, 1e-3 * H
+    for step in range(2):
+        u01 = rng.random((N, A, H, U)).astype(F)
+        eng.inject_noise(L.NOISE_UNIFORM, u01)
+        act, nxt, rew = eng.optimize(states)
+        s, r = eng.get_trace(0, L.TRACE_SAMPLES), eng.get_trace(0, L.TRACE_REWARDS)
+        np.testing.assert_allclose(s, (u01 * F(2.0) - F(1.0)).astype(F), rtol=0, atol=1e-6)      # random_search.py:40-41
+        r_c = co.evaluate(states, s)
+        np.testing.assert_allclose(r, r_c, rtol=RT, atol=AT)
+        best = int(np.argmax(r[:, 0]))                                                           # :43 (first maximum)
+        assert r_c[best, 0] >= r_c[:, 0].max() - (AT + RT * abs(r_c[:, 0].max()))
+        np.testing.assert_array_equal(act[0], s[best, 0, 0])                                     # :44-47
+        np.testing.assert_allclose(nxt, co.predict_next_state(states, act), rtol=1e-4, atol=2e-4)      # optimizer_base.py:91-94
+        states = nxt
