@@ -79,7 +79,19 @@ struct MlpRolloutArgs {
 // executes at the vector rate on the same datapath as VALU work (measured: step time = MFMA time + VALU time, not the
 // max), so every VALU instruction shaved off the activations is matrix time gained: this form replaced
 // exp(2|x|) -> 1 - 2r spelled as (|x|+|x|) * log2e, exp2, +1, rcp, r+r, 1-  (eight instructions).
+// A/B switches of the round-5 changes (tools/build_variant.py): bit 0 layer-0 tail MFMAs skipped, bit 1 4-row last-layer tile,
+// bit 2 signed tanh
+#ifndef BBMPC_PAIR_OPTS
+#define BBMPC_PAIR_OPTS 55
+#endif
 __device__ __forceinline__ float bb_tanhf(float x) {
+#if !(BBMPC_PAIR_OPTS & 4)
+    {
+        const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * fabsf(x));
+        const float r = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+        return copysignf(r, x);
+    }
+#endif
     // tanh x = 1 - 2 / (1 + e^(2x)) holds for either sign: +inf for large x -> 1 - 0, 0 for large -x -> 1 - 2; round 5 dropped the
     // |x| / copysign pair around it (one v_bfi per value: five instructions instead of six, same absolute error bound -- the
     // reciprocal's argument lies in [1, 2) for x < 0 and the cancellation near zero is the positive side's mirrored).
@@ -549,6 +561,9 @@ constexpr int mlp_pair_waves(int HT, int NTILES) { return NTILES == 2 ? HT - 1 :
 #ifndef BBMPC_PAIR_CLK
 #define BBMPC_PAIR_CLK(slot)
 #endif
+#ifndef BBMPC_PAIR_CLK2
+#define BBMPC_PAIR_CLK2(slot, seq)      // inside stage_B: slot 8 + 8 * tile + {0: loop entry, 1..3: behind k tile 3 / 7 / 11, 4: loop exit, 5: slab stored}
+#endif
 constexpr int mlp_pair_kq(int HT) { return (HT + 3) / 4; }          // k tiles per helper quarter
 template <int V> struct IC { static constexpr int value = V; };
 
@@ -587,14 +602,15 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     // this kernel's slot order by the prologue.  (ii) With 16 < dim_S <= 20 the second output tile of the last layer has at
     // most four live rows: its K slab runs as four v_mfma_f32_4x4x1_16b_f32 (block = (k row g, particle quad): 4 features x 16
     // particles x 4 k per instruction, 8 cycles) instead of four 16x16x4 (32 cycles each, twelve of sixteen rows zero); the four
-    // k-row partials of a (feature, particle) go to LDS side by side and the epilogue thread adds them, in g order, ahead of
-    // the sum over the waves.
+    // k-row partials of a (feature, particle) are summed in registers by lane swaps before the partial sum goes to LDS (left to
+    // the epilogue thread -- four words side by side, a 16-byte read and three adds behind a test of the feature index inside
+    // the layer-1 loop -- the change cost 10 us of the 422 instead of saving any).
     constexpr bool CT0 = CS != 0 && CU != 0;
     constexpr int C_IT0N = CT0 ? (CS + CU + 15) / 16 : 0;
     const int it0n = CT0 ? C_IT0N : m.tiles[0];
     const int rem0 = (CT0 ? CS + CU : m.dims[0]) - 16 * (it0n - 1);
-    const int tk0 = (rem0 + 3) >> 2;
-    const bool out4 = S > 16 && S <= 20;
+    const int tk0 = (BBMPC_PAIR_OPTS & 1) ? (rem0 + 3) >> 2 : 4;
+    const bool out4 = (BBMPC_PAIR_OPTS & 2) && S > 16 && S <= 20;
     auto l0_live = [&](int it, int sidx) { return it + 1 < it0n || (it + 1 == it0n && sidx < tk0); };
     // LDS address of input feature f of particle pp in the xs tiles (tile_addr with the last tile's slots permuted)
     auto xs_addr = [&](int f, int pp) {
@@ -757,19 +773,14 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     const bool e_live = tid < MLP_TP * (S + U);
     const int e_ot = ef >> 4, e_ln = ((ef & 15) >> 2) * 16 + epp, e_rg = ef & 3;
     const int e_xaddr = xs_addr(ef, epp);
-    // (4-row form of output tile 1: the four k-row partials of feature ef >= 16 lie side by side, [ef - 16][particle][g])
+    // (4-row form of output tile 1: the producing wave has summed the four k rows; feature 16 + i of a particle is the word of
+    // lane 16 {0, 2, 1, 3}[i] + particle)
     const bool e4 = out4 && ef >= 16;
     auto epi_part = [&](int ti) {
-        return T_part(ti) + (e4 ? 256 + (((ef - 16) & 3) * 16 + epp) * 4 : (((size_t)e_ot) * 64 + e_ln) * 4 + e_rg);
+        const int i4 = (ef - 16) & 3, r4 = ((i4 & 1) << 1) | (i4 >> 1);
+        return T_part(ti) + (e4 ? 256 + 16 * r4 + epp : (((size_t)e_ot) * 64 + e_ln) * 4 + e_rg);
     };
-    // one wave's contribution to the pre-activation of this thread's feature
-    auto epi_term = [&](const float* pw) {
-        if (e4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(pw);
-            return ((v.x + v.y) + v.z) + v.w;
-        }
-        return pw[0];
-    };
+    auto epi_term = [&](const float* pw) { return pw[0]; };
     auto epi_reduce = [&](int ti) {
         if (NTILES == 2 && wid * 64 >= MLP_TP * S) return 0.0f;      // a wave of action features only: nothing to reduce
         const float* part = epi_part(ti);
@@ -801,15 +812,22 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
         f32x4 o1 = {0.0f, 0.0f, 0.0f, 0.0f};
         if (out4) {
             // block b = lane >> 2 = (k row g = lane >> 4, particle quad): D register i, lane 4b + j = feature 16 + i of particle
-            // lane & 15 over the k slots 4g + {0..3} of this tile; stored [i][particle][g]
+            // lane & 15 over the k slots 4g + {0..3} of this tile.  (Alternating this chain with the 16x16x4 one above, MFMA by
+            // MFMA, measured 3 us slower: 399 against 396.)
             o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo1.x, h.x, o1, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo1.y, h.y, o1, 0, 0, 0);
             if (!tail_half) {
                 o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo1.z, h.z, o1, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wo1.w, h.w, o1, 0, 0, 0);
             }
-            float* p1 = part + ((size_t)ft * OTL + 1) * 256 + (lane & 15) * 4 + (lane >> 4);
-            p1[0] = o1.x; p1[64] = o1.y; p1[128] = o1.z; p1[192] = o1.w;
+            // the four k rows are summed in registers (two lane swaps + adds fold four registers into one: row r of the
+            // wave ends up with feature 16 + {0, 2, 1, 3}[r]) and ONE word per lane goes to LDS
+            float a0 = o1.x, a1 = o1.y, a2 = o1.z, a3 = o1.w;
+            auto r01 = __builtin_amdgcn_permlane32_swap(__float_as_int(a0), __float_as_int(a1), false, false);
+            auto r23 = __builtin_amdgcn_permlane32_swap(__float_as_int(a2), __float_as_int(a3), false, false);
+            float t01 = __int_as_float(r01[0]) + __int_as_float(r01[1]), t23 = __int_as_float(r23[0]) + __int_as_float(r23[1]);
+            auto rr = __builtin_amdgcn_permlane16_swap(__float_as_int(t01), __float_as_int(t23), false, false);
+            part[((size_t)ft * OTL + 1) * 256 + lane] = __int_as_float(rr[0]) + __int_as_float(rr[1]);
         } else {
             o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wo1.x, h.x, o1, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wo1.y, h.y, o1, 0, 0, 0);
@@ -931,7 +949,89 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
                 acc.x = acc.x + aq[h].x; acc.y = acc.y + aq[h].y; acc.z = acc.z + aq[h].z; acc.w = acc.w + aq[h].w;
             }
         } else {
+#if BBMPC_PAIR_OPTS & 8
+            // Round 5: the K loop takes the k tiles in pairs and alternates the two accumulators MFMA by MFMA (even tile -> acc,
+            // odd tile -> acc2, as before: the sums keep their order).  Four MFMAs in a row on ONE accumulator issue 40 cycles
+            // apart (the dependent latency of v_mfma_f32_16x16x4_f32) unless another wave of the SIMD fills the gaps, and the
+            // last wave of a SIMD to finish its chain -- a third of every layer-1 interval -- has nobody to fill them.
+            auto ld_b = [&](int it) { return *reinterpret_cast<const f32x4*>(h0 + ((size_t)it * 64 + lane) * 4); };
+            // everything a k tile carries besides the main chain's MFMAs, in front of them ...
+            auto pre = [&](int it, float& pv) {
+                if (co >= 0) pv = epi_term(cpart + (size_t)it * OTL * 256);
+                if constexpr (NTILES == 2) {
+                    if (it < KQ && helper && kbase + it < HT) {               // wave-uniform
+                        const f32x4 bx = ld_b(kbase + it);
+                        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[it * 4 + 0], bx.x, accx, 0, 0, 0);
+                        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[it * 4 + 1], bx.y, accx, 0, 0, 0);
+                        if (kbase + it + 1 < HT || !half1) {
+                            accx = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[it * 4 + 2], bx.z, accx, 0, 0, 0);
+                            accx = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[it * 4 + 3], bx.w, accx, 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < IT0; ++j) {
+                        if (ta >= 0 && it == apos + j) {
+                            const f32x4 ba = *reinterpret_cast<const f32x4*>(xsa + ((size_t)j * 64 + lane) * 4);
+                            acca = l0_tile(j, wr_in[j * 4 + 0], wr_in[j * 4 + 1], wr_in[j * 4 + 2], wr_in[j * 4 + 3], ba, acca);
+                        }
+                        if (ta >= 0 && owner && it == apos + IT0 + j) {
+                            const f32x4 ba = *reinterpret_cast<const f32x4*>(xsa + ((size_t)j * 64 + lane) * 4);
+                            const f32x4 wa = xo_get(j);
+                            accb = l0_tile(j, wa.x, wa.y, wa.z, wa.w, ba, accb);
+                        }
+                    }
+                }
+            };
+            // ... and behind them
+            auto post = [&](int it, float pv) {
+                if (co >= 0) cacc = cacc + pv;
+                if constexpr (NTILES == 2) {
+                    if (it == KQ - 1 && helper && !owner) {
+                        float* qp = T_qp(ti);
+                        *reinterpret_cast<f32x4*>(qp + ((size_t)hq * 64 + lane) * 4) = accx;
+                        // LDS operations of a wave complete in order: whoever sees the flag sees the partials
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0)
+                            __hip_atomic_store(reinterpret_cast<int*>(qp + 3 * 256) + hq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    if (ta >= 0 && it == apos + IT0 - 1) {
+                        acca.x = apply_act_ct<A0>(acca.x); acca.y = apply_act_ct<A0>(acca.y);
+                        acca.z = apply_act_ct<A0>(acca.z); acca.w = apply_act_ct<A0>(acca.w);
+                        *reinterpret_cast<f32x4*>(T_h0(ta) + ((size_t)wave * 64 + lane) * 4) = acca;
+                    }
+                    if (ta >= 0 && owner && it == apos + 2 * IT0 - 1) {
+                        accb.x = apply_act_ct<A0>(accb.x); accb.y = apply_act_ct<A0>(accb.y);
+                        accb.z = apply_act_ct<A0>(accb.z); accb.w = apply_act_ct<A0>(accb.w);
+                        *reinterpret_cast<f32x4*>(T_h0(ta) + ((size_t)XT * 64 + lane) * 4) = accb;
+                    }
+                    if (it == (2 * HT) / 3 && owner) finish_x(ti, seq, accx);
+                }
+            };
+            f32x4 bn0 = ld_b(0), bn1 = ld_b(HT > 1 ? 1 : 0);
+#pragma unroll
+            for (int it = 0; it < HT; it += 2) {
+                const bool two = it + 1 < HT;
+                const f32x4 b0 = bn0, b1 = bn1;           // operands of this pair were loaded during the previous one
+                if (it + 2 < HT) bn0 = ld_b(it + 2);
+                if (it + 3 < HT) bn1 = ld_b(it + 3);
+                float pv0 = 0.0f, pv1 = 0.0f;
+                pre(it, pv0);
+                if (two) pre(it + 1, pv1);
+                const bool full0 = it + 1 < HT || !half1, full1 = it + 2 < HT || !half1;   // the padded half of the last K tile multiplies zeros
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 0], b0.x, acc, 0, 0, 0);
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[(it + 1) * 4 + 0], b1.x, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 1], b0.y, acc, 0, 0, 0);
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[(it + 1) * 4 + 1], b1.y, acc2, 0, 0, 0);
+                if (full0) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 2], b0.z, acc, 0, 0, 0);
+                if (two && full1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[(it + 1) * 4 + 2], b1.z, acc2, 0, 0, 0);
+                if (full0) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 3], b0.w, acc, 0, 0, 0);
+                if (two && full1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[(it + 1) * 4 + 3], b1.w, acc2, 0, 0, 0);
+                post(it, pv0);
+                if (two) post(it + 1, pv1);
+            }
+#else
             f32x4 bn = *reinterpret_cast<const f32x4*>(h0 + (size_t)lane * 4);
+            BBMPC_PAIR_CLK2(8 + 8 * ti + 0, seq);
 #pragma unroll
             for (int it = 0; it < HT; ++it) {
                 const f32x4 b = bn;                       // operand of this group was loaded during the previous one
@@ -998,7 +1098,12 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
                     }
                     if (it == (2 * HT) / 3 && owner) finish_x(ti, seq, accx);
                 }
+                if (it == 3) { BBMPC_PAIR_CLK2(8 + 8 * ti + 1, seq); }
+                if (it == 7) { BBMPC_PAIR_CLK2(8 + 8 * ti + 2, seq); }
+                if (it == 11) { BBMPC_PAIR_CLK2(8 + 8 * ti + 3, seq); }
             }
+            BBMPC_PAIR_CLK2(8 + 8 * ti + 4, seq);
+#endif
             acc.x = acc.x + acc2.x; acc.y = acc.y + acc2.y; acc.z = acc.z + acc2.z; acc.w = acc.w + acc2.w;
         }
         acc.x = apply_act_ct<A1>(acc.x); acc.y = apply_act_ct<A1>(acc.y);
@@ -1008,6 +1113,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             // one-tile mode: the last wave's K slice is the half-empty tile
             out_slab(wave, acc, wo0, wo1, !(NTILES == 2 || wave + 1 < HT || !half2), T_part(ti));
         }
+        BBMPC_PAIR_CLK2(8 + 8 * ti + 5, seq);
     };
     // finish the epilogue of step t given the reduced pre-activation `acc`
     // cheetah reward (cost_func.py:5-22) needs cur[5..7], cur[17], next[17] and the actions only: the epilogue
@@ -1084,7 +1190,16 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
         // alternates within each SIMD.
         const bool grp = ((wid >> 2) & 1) != 0;
         const bool epi_wave = wid * 64 < MLP_TP * (S + U);
+#if BBMPC_PAIR_OPTS & 64
+        if (helper) __builtin_amdgcn_s_setprio(2);
+        else if (grp) __builtin_amdgcn_s_setprio(1);
+#elif BBMPC_PAIR_OPTS & 32
+        if (helper || grp) __builtin_amdgcn_s_setprio(1);
+#elif BBMPC_PAIR_OPTS & 128
+        if (grp) __builtin_amdgcn_s_setprio(1);
+#else
         if (helper) __builtin_amdgcn_s_setprio(1);        // the longest instruction streams of their SIMDs go first
+#endif
         for (int t = 0; t < H; ++t) {
             BBMPC_PAIR_CLK(0);
             // epilogue threads are tid < 16 (S + U): waves 0 .. EW-1 (the others have nothing to reduce)
@@ -1111,7 +1226,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             BBMPC_PAIR_CLK(4);
             if (!epi_wave) {
                 stage_B(1, -1, nullptr, dummy, t + 1, IC<-1>{}, IC<0>{});
-            } else if (!grp) {
+            } else if (!grp || ((BBMPC_PAIR_OPTS & 16) && wid * 64 < MLP_TP * S)) {
                 float cacc = lbias[min(ef, S - 1)];                   // C_X(t): reduction rides under B_Y(t)'s MFMA chain
                 stage_B(1, 0, epi_part(0), cacc, t + 1, IC<-1>{}, IC<0>{});
                 epi_finish(0, t, cacc);

@@ -3,9 +3,11 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -Iblackbox_mpc_amd/csrc -Iinclude
 //         tools/microbench/pair_probe.hip -o /tmp/pair_probe && /tmp/pair_probe
 #include <hip/hip_runtime.h>
-__device__ long long g_pair_clk[16 * 8];
+__device__ long long g_pair_clk[16 * 24];
 #define BBMPC_PAIR_CLK(slot) \
-    do { if (blockIdx.x == 1 && blockIdx.y == 0 && t == 20 && lane == 0) g_pair_clk[wid * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+    do { if (blockIdx.x == 1 && blockIdx.y == 0 && t == 20 && lane == 0) g_pair_clk[wid * 24 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define BBMPC_PAIR_CLK2(slot, seq) \
+    do { if (blockIdx.x == 1 && blockIdx.y == 0 && (seq) == 21 && lane == 0) g_pair_clk[wid * 24 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #include "engine.hpp"
 using namespace bbmpc;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -53,11 +55,19 @@ int main() {
     std::vector<float> rew(A * Nst); hipMemcpy(rew.data(), r.rewards, rew.size() * 4, hipMemcpyDeviceToHost);
     double cs = 0; for (int a = 0; a < A; ++a) for (int n = 0; n < N; ++n) cs += rew[a * Nst + n];
     printf("k_rollout_mlp_pair: %.1f us per launch (%d waves, lds %zu B), reward checksum %.6e\n", ms * 1000.0f / reps, (int)block.x / 64, lds, cs);
-    long long clk[16 * 8]; hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_pair_clk), sizeof(clk));
+    long long clk[16 * 24]; hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_pair_clk), sizeof(clk));
     printf("wave: work1 wait1 | work2 wait2 | work3 wait3   (cycles of the shader clock, step 20 of workgroup (1,0))\n");
     for (int w = 0; w < (int)block.x / 64; ++w) {
-        long long* c = clk + w * 8;
+        long long* c = clk + w * 24;
         printf("%2d: %6lld %6lld | %6lld %6lld | %6lld %6lld   total %lld\n", w, c[1] - c[0], c[2] - c[1], c[3] - c[2], c[4] - c[3], c[5] - c[4], c[6] - c[5], c[6] - c[0]);
     }
+    printf("inside the layer-1 stage (cycles since the interval's barrier release): loop entry | behind k tile 3 | 7 | 11 | loop exit | slab stored\n");
+    for (int half = 0; half < 2; ++half)
+        for (int w = 0; w < (int)block.x / 64; ++w) {
+            long long* c = clk + w * 24;
+            const long long t0 = c[half ? 4 : 2];
+            long long* d = c + 8 + 8 * half;
+            printf("I%d wave %2d: %6lld %6lld %6lld %6lld %6lld %6lld\n", half + 2, w, d[0] - t0, d[1] - t0, d[2] - t0, d[3] - t0, d[4] - t0, d[5] - t0);
+        }
     return 0;
 }
