@@ -47,7 +47,11 @@ def _fingerprint(src):
             continue
         text = open(os.path.join(CSRC, f)).read()
         if f in GUARDED and GUARDED[f][0] != src and GUARDED[f][1] in text:
-            text = text[:text.index(GUARDED[f][1])]
+            # the other units see the text in front of the guard AND whatever follows its #endif (by convention only the
+            # namespace's closing brace): both are hashed, so code placed behind the guard still rebuilds everybody
+            head, rest = text.split(GUARDED[f][1], 1)
+            tail = rest.rsplit("#endif", 1)[1] if "#endif" in rest else ""
+            text = head + "\n/*guarded*/\n" + tail
         h.update(f.encode())
         h.update(text.encode())
     return h.hexdigest()
@@ -65,14 +69,36 @@ def _stale_units():
 LIB_STAMP = LIB + ".sha"       # fingerprint of every unit the library was linked from: travels with the .so (the objects do not)
 
 
-def _lib_fingerprint():
+LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
+_TOOLCHAIN = None
+
+
+def _toolchain():
+    """`hipcc --version` (a library linked by another ROCm must not be taken for current)."""
+    global _TOOLCHAIN
+    if _TOOLCHAIN is None:
+        try:
+            out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout
+            # the version lines only (install paths may differ between boxes of one image)
+            _TOOLCHAIN = "\n".join(ln.strip() for ln in out.splitlines() if "version" in ln.lower())
+        except Exception:                                  # noqa: BLE001
+            _TOOLCHAIN = "unknown"
+    return _TOOLCHAIN
+
+
+def _lib_fingerprint(with_toolchain=True):
+    """Every translation unit's fingerprint, the link line, this file and (where hipcc exists) the toolchain's version."""
     import hashlib
-    return hashlib.sha256("".join(_fingerprint(s) for s in SOURCES).encode()).hexdigest()
+    h = hashlib.sha256("".join(_fingerprint(s) for s in SOURCES).encode())
+    h.update(" ".join(LINK_FLAGS).encode())
+    h.update(open(os.path.abspath(__file__), "rb").read())
+    return h.hexdigest() + ("|" + hashlib.sha256(_toolchain().encode()).hexdigest()[:16] if with_toolchain else "")
 
 
 def needs_build():
-    """False when libbbmpc.so was linked from exactly the sources in the tree (on the GPU box: the .so and its stamp
-    arrive with the snapshot, the object cache does not -- nothing is compiled there)."""
+    """False when libbbmpc.so was linked from exactly the sources in the tree, by this link line and toolchain (on the GPU
+    box: the .so and its stamp arrive with the snapshot, the object cache does not -- nothing is compiled there; the image,
+    hence the toolchain, is the same)."""
     return not (os.path.exists(LIB) and os.path.exists(LIB_STAMP) and open(LIB_STAMP).read().strip() == _lib_fingerprint())
 
 
@@ -131,7 +157,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
     tmp = "%s.tmp.%d" % (LIB, os.getpid())
-    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJ_DIR, s_ + ".o") for s_ in SOURCES] + ["-o", tmp]
+    link = [_hipcc()] + LINK_FLAGS + [os.path.join(OBJ_DIR, s_ + ".o") for s_ in SOURCES] + ["-o", tmp]
     if verbose:
         print(" ".join(link), file=sys.stderr)
     res = subprocess.run(link, capture_output=True, text=True)

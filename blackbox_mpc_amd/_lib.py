@@ -67,7 +67,7 @@ SYMBOLS = [
     "bbmpc_set_state", "bbmpc_set_profiling", "bbmpc_get_profile", "bbmpc_profile_instantiation", "bbmpc_synchronize", "bbmpc_rollout_episode",
     "bbmpc_comm_unique_id", "bbmpc_comm_init", "bbmpc_gather_records_dev", "bbmpc_gather_wait", "bbmpc_comm_destroy",
     "bbmpc_optimize_gather_dev", "bbmpc_set_stream_default", "bbmpc_optimize_gather", "bbmpc_comm_info", "bbmpc_call_stats",
-    "bbmpc_graph_stats",
+    "bbmpc_graph_stats", "bbmpc_handle_device",
     "bbmpc_set_reward_source", "bbmpc_set_dynamics_source", "bbmpc_check_user_source", "bbmpc_mlp_forward",
     "bbmpc_set_reward_callback", "bbmpc_set_dynamics_callback",
     "bbmpc_process_input", "bbmpc_process_output", "bbmpc_check_user_rollout",
@@ -132,6 +132,7 @@ def _load():
     lib.bbmpc_comm_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.bbmpc_call_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.bbmpc_graph_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64)]
+    lib.bbmpc_handle_device.argtypes = [vp, ctypes.POINTER(i32)]
     lib.bbmpc_set_reward_source.argtypes = [vp, ctypes.c_char_p]
     lib.bbmpc_set_dynamics_source.argtypes = [vp, ctypes.c_char_p]
     lib.bbmpc_set_reward_callback.argtypes = [vp, ROWS_CALLBACK, vp]

@@ -377,6 +377,7 @@ void Engine::resident_stop() {
 
 float* Engine::pinned(size_t count) {
     if (count > h_pin_n) {
+        invalidate_step_graph();             // a captured control step reads and writes the old buffer through h_pin_dev
         if (h_pin) (void)hipHostFree(h_pin);
         h_pin = nullptr;
         h_pin_n = 0;
@@ -978,6 +979,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                 hipLaunchKernelGGL(k_dist_init, dim3((nelem + 255) / 256), dim3(256), 0, stream, A, HU, U, d_lo.p, d_hi.p,
                                    d_prev_mean.p, d_var0.p, d_mean.p, d_var.p, d_sigma.p, 1, stage_state_src, d_state.p, A * S);
                 if (!cem_sigma0_ready && !fix(BBMPC_FIX_Q2_CEM_WARM_START)) {
+                    if (!step_capturing) invalidate_step_graph();   // (a replayed control step samples from d_sigma0: never capture across its allocation)
                     d_sigma0.alloc(nelem);
                     HIP_CHECK(hipMemcpyAsync(d_sigma0.p, d_sigma.p, (size_t)nelem * 4, hipMemcpyDeviceToDevice, stream));
                     cem_sigma0_ready = true;
@@ -2017,7 +2019,13 @@ static const float* optimize_host(bbmpc::Engine& e, const float* state, int32_t 
                     e.step_counter = saved_step;                 // the captured call has not run
                     (void)hipGetLastError();
                     if (ok) { replayed = true; e.step_graph_sig = sig; }
-                    else { e.step_graph = nullptr; e.sw.step_graph = 0; }      // this handle keeps enqueueing its launches one by one
+                    else {
+                        // this handle keeps enqueueing its launches one by one; why is kept (bbmpc_graph_stats' callers see 0 replays,
+                        // BBMPC_TRACE_GRAPH=1 prints it): a capture-illegal call added to the steady path must not go unnoticed
+                        e.step_graph = nullptr; e.sw.step_graph = 0;
+                        ++e.graph_capture_failures;
+                        if (getenv("BBMPC_TRACE_GRAPH")) fprintf(stderr, "[bbmpc] control-step graph capture / instantiate failed (steady=%d): replay disabled for this handle\n", (int)e.last_step_steady);
+                    }
                 }
                 if (replayed) {
                     // the device's (control step, completion value) advance by themselves at the end of every replay; calls that
@@ -2577,6 +2585,14 @@ int bbmpc_graph_stats(bbmpc_handle h, int64_t* replayed) {
     API_BEGIN
     CHECK_HANDLE(h);
     if (replayed) *replayed = h->e->calls_graph;
+    API_END
+}
+
+int bbmpc_handle_device(bbmpc_handle h, int32_t* device) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    CHECK_PTR(device);
+    *device = h->e->device;
     API_END
 }
 

@@ -329,7 +329,10 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             HIP_CHECK(hipMemcpyAsync(t_cma_C.p + gnn * it, c_C.p, gnn * 4, hipMemcpyDeviceToDevice, stream));
             HIP_CHECK(hipMemcpyAsync(t_cma_D.p + (size_t)G * n * it, c_Dd.p, (size_t)G * n * 4, hipMemcpyDeviceToDevice, stream));
             if (!t_cma_stats.p) { t_cma_stats.alloc((size_t)G * 16 * std::max(iters, 1)); t_cma_stats.zero(stream); }
-            if (n <= 512 && !sw.cma_svd_v1) {
+            if (small3 || cma_use_eigh_small()) {
+                // (n <= 32: the factorisation kernel keeps no statistics -- include/bbmpc.h)
+                HIP_CHECK(hipMemsetAsync(t_cma_stats.p + (size_t)G * 16 * it, 0, (size_t)G * 16 * sizeof(int), stream));
+            } else if (n <= 512 && !sw.cma_svd_v1) {
                 // rotation counts of the sweeps ([G][CMA_SYNC_WORDS] words -> [G][16]); word 15: did the Jacobi run for the instance
                 HIP_CHECK(hipMemcpy2DAsync(t_cma_stats.p + (size_t)G * 16 * it, 16 * sizeof(int), c_sync.p + CMA_SYNC_ROTATIONS,
                                            CMA_SYNC_WORDS * sizeof(unsigned), 15 * sizeof(int), G, hipMemcpyDeviceToDevice, stream));

@@ -100,6 +100,7 @@ struct Engine {
     uint32_t step_mirror[2] = {0, 0};      // what the device words hold now
     bool step_capturing = false;
     int64_t calls_graph = 0;               // replays so far (bbmpc_graph_stats)
+    int64_t graph_capture_failures = 0;    // captures / instantiations that failed (the handle then stops trying)
     bool last_step_steady = false;         // the last optimize_dev ran without k_dist_init (kernels as they will be replayed)
     void invalidate_step_graph() {
         ++mutations;

@@ -1149,8 +1149,12 @@ static __global__ __launch_bounds__(EIGH_BT_THREADS) void k_eigh_backtransform(E
         // 16 lanes per slot count the eigenvalues ahead of it
         const int slot = tid >> 4, sub = tid & 15, j = j0 + slot;
         const float lj = s_lam[j];
+        // ranked by the SINGULAR value |eigenvalue of C| (tf.linalg.svd's order, cma_es.py:195-197, and the Jacobi fall-back's),
+        // not by the signed eigenvalue: the same for a positive definite C, and an indefinite one (fp32 drift, set_state("C"))
+        // keeps D descending on this path too
+        const float sj = fabsf(lj + alpha);
         int cnt = 0;
-        for (int o = sub; o < n; o += 16) { const float lo = s_lam[o]; cnt += (lo > lj || (lo == lj && o < j)) ? 1 : 0; }
+        for (int o = sub; o < n; o += 16) { const float so = fabsf(s_lam[o] + alpha); cnt += (so > sj || (so == sj && o < j)) ? 1 : 0; }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
         if (sub == 0) {

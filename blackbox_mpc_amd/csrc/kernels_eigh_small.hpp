@@ -388,7 +388,9 @@ __device__ __attribute__((noinline)) bool cma_eigh_small_body(const CmaArgs& p, 
             z = fmaf(-(tk * dot), v, z);
         }
         const float lj = L.lam[j & (ES_N - 1)], lo_ = L.lam[sub];
-        const float before = (sub < n && (lo_ > lj || (lo_ == lj && sub < j))) ? 1.0f : 0.0f;
+        // ranked by |eigenvalue of C| (the SVD's order, cma_es.py:195-197), as in kernels_eigh.hpp
+        const float sj = fabsf(lj + alpha), so = fabsf(lo_ + alpha);
+        const float before = (sub < n && (so > sj || (so == sj && sub < j))) ? 1.0f : 0.0f;
         const int rank = (int)es_half_sum(before);
         if (live && sub < n) p.B[(size_t)g * n * n + (size_t)sub * n + rank] = z;
         if (live && sub == 0) p.Dd[(size_t)g * n + rank] = sqrtf(fabsf(lj + alpha));

@@ -26,7 +26,7 @@ constexpr int TAIL_THREADS = 1024;
 constexpr int TAIL_MAXW = 512;                 // widest layer (set_mlp enforces hidden <= 512, S+U <= 128, S <= 64)
 
 #ifdef BBMPC_KERNEL_DBG
-__device__ long long g_tail_dbg[16];
+static __device__ long long g_tail_dbg[16];     // (static: the header is seen by four translation units)
 #endif
 struct RowMlp {
     MlpDesc m;

@@ -43,16 +43,10 @@ class Engine:
         self.U, self.S = c.dim_u, c.dim_s
         self.iters = 1 if optimizer == L.OPT_RANDOM_SEARCH else c.max_iterations
         self.k = c.num_elite
-        self._device = self._current_device() if c.device < 0 else int(c.device)    # where the handle lives, fixed at creation
         L.check(L.lib.bbmpc_create(ctypes.byref(c), ctypes.byref(self._h)))
-
-    @staticmethod
-    def _current_device():
-        try:
-            import torch
-            return int(torch.cuda.current_device()) if torch.cuda.is_available() else 0
-        except Exception:                                 # noqa: BLE001
-            return 0
+        dev = ctypes.c_int32(-1)
+        L.check(L.lib.bbmpc_handle_device(self._h, ctypes.byref(dev)))             # where the handle lives, fixed at creation: the
+        self._device = int(dev.value)                                               # library's answer, not a guess from torch's state
 
     @property
     def device(self):

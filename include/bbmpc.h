@@ -96,7 +96,11 @@ extern "C" {
 #define BBMPC_TRACE_SAMPLES 5   /* [N,A,H,U] action sequences that were rolled out */
 #define BBMPC_TRACE_CMA_B   6   /* CMA-ES [G,n,n] eigenvectors B after the iteration (cma_es.py:195-198,204)   */
 #define BBMPC_TRACE_CMA_C   7   /* CMA-ES [G,n,n] covariance C after the iteration (cma_es.py:183-190,202)     */
-#define BBMPC_TRACE_CMA_SVD_STATS 9 /* CMA-ES int32 [G,16]: the iteration's eigen-decomposition -- [0..14] column pairs the block Jacobi rotated in sweep s (all zero when the direct solver's result was taken), [15] 1 = the Jacobi ran */
+#define BBMPC_TRACE_CMA_SVD_STATS 9 /* CMA-ES int32 [G,16]: the iteration's eigen-decomposition, for search dimensions 32 < n <= 512.
+                                     * [0..14] column pairs the Jacobi rotated in sweep s (all zero when the direct solver's result
+                                     * was taken).  [15]: with the direct solver (128 < n <= 320) 1 = it refused the instance and the
+                                     * Jacobi ran for it; on the Jacobi-only paths 1 = sweep 0 rotated something.  n <= 32 (one
+                                     * workgroup factorises, falls back and finishes in one kernel) records nothing: all zero. */
 #define BBMPC_TRACE_CMA_D   8   /* CMA-ES [G,n]   diag(D) = sqrt(eigenvalues) after the iteration (:197,205)   */
 
 typedef struct bbmpc_handle_s* bbmpc_handle;
@@ -235,6 +239,11 @@ int bbmpc_call_stats(bbmpc_handle h, int64_t* served_resident, int64_t* launched
 /* ... and how many of the launched ones were replays of a captured hipGraph (the steady-state control step of the
  * learned-model PI2 / CEM path: same launches, same arguments every call).  No counterpart in the reference. */
 int bbmpc_graph_stats(bbmpc_handle h, int64_t* replayed);
+/* (A capture or instantiation that fails switches the replay off for the handle and the calls go on as plain launches;
+ * BBMPC_TRACE_GRAPH=1 in the environment reports it on stderr.) */
+/* The GPU the handle lives on: bbmpc_config.device, or the caller's current HIP device at bbmpc_create when that was < 0.
+ * Callers that alias the handle's HBM buffers or stream in another framework must do so on THIS device. */
+int bbmpc_handle_device(bbmpc_handle h, int32_t* device);
 
 /* Same with device pointers; record is [A, U+S+1] = (action | next_state | reward) per agent.
  * d_next_state (optional, may be NULL) additionally receives the predicted next state as a contiguous
