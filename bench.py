@@ -149,7 +149,10 @@ class Workload:
                     attach_record_comm(self.eng, device=dev)
                     self.comm_info = self.eng.comm_info()
                     if self.comm_info[0] != world:
-                        raise RuntimeError("ncclCommCount = %d, expected %d" % (self.comm_info[0], world))
+                        # a communicator of the wrong size is not something to fall back from: the number would not be an
+                        # N-GPU number.  Loud, on every rank.
+                        raise SystemExit("bench.py[rank %d]: the engine's RCCL communicator has ncclCommCount = %d, the job has %d ranks"
+                                         % (rank, self.comm_info[0], world))
                 except Exception as ex:                       # e.g. librccl not loadable
                     why = "%s: %s" % (type(ex).__name__, ex)
                     print("bench[rank %d]: engine-owned record gather unavailable (%s)" % (rank, why), file=sys.stderr)

@@ -65,7 +65,7 @@ SYMBOLS = [
     "bbmpc_evaluate_dev", "bbmpc_predict_next_state", "bbmpc_evaluate_next_reward", "bbmpc_step_dev",
     "bbmpc_inject_noise", "bbmpc_dump_noise", "bbmpc_set_trace", "bbmpc_get_trace", "bbmpc_get_state",
     "bbmpc_set_state", "bbmpc_set_profiling", "bbmpc_get_profile", "bbmpc_profile_instantiation", "bbmpc_synchronize", "bbmpc_rollout_episode",
-    "bbmpc_comm_unique_id", "bbmpc_comm_init", "bbmpc_gather_records_dev", "bbmpc_gather_wait", "bbmpc_comm_destroy",
+    "bbmpc_comm_unique_id", "bbmpc_comm_init", "bbmpc_comm_init_local", "bbmpc_gather_records_dev", "bbmpc_gather_wait", "bbmpc_comm_destroy",
     "bbmpc_optimize_gather_dev", "bbmpc_set_stream_default", "bbmpc_optimize_gather", "bbmpc_comm_info", "bbmpc_call_stats",
     "bbmpc_graph_stats", "bbmpc_handle_device",
     "bbmpc_set_reward_source", "bbmpc_set_dynamics_source", "bbmpc_check_user_source", "bbmpc_mlp_forward",
@@ -124,6 +124,7 @@ def _load():
     lib.bbmpc_rollout_episode.argtypes = [vp, vp, i32, i32, vp]
     lib.bbmpc_comm_unique_id.argtypes = [vp, i64]
     lib.bbmpc_comm_init.argtypes = [vp, vp, i32, i32]
+    lib.bbmpc_comm_init_local.argtypes = [vp, ctypes.c_uint64, i32, i32]
     lib.bbmpc_gather_records_dev.argtypes = [vp, vp, vp, i64, i32]
     lib.bbmpc_gather_wait.argtypes = [vp, i32, i32]
     lib.bbmpc_optimize_gather_dev.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32]

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <atomic>
+#include <functional>
 #include <chrono>
 #include <mutex>
 #include <set>
@@ -944,7 +945,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                     launch_rollout(SRC_UNIFORM, false, ra);
                     hipLaunchKernelGGL(k_refit_argmax, dim3(A), dim3(REFIT_THREADS), 0, stream, rf, ps_part.p, (int)cfg.population_offset);
                     if (rc.comm) {
-                        const Rccl& r = Rccl::get();
+                        const Rccl& r = *rc.api;
                         r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (RandomSearch local bests)");
                     } else {
                         REQUIRE(cfg.population_global <= N, BBMPC_E_STATE, "population sharding needs a communicator: call bbmpc_comm_init first");
@@ -1024,7 +1025,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                         launch_rollout(SRC_TRUNC, false, ra);
                         hipLaunchKernelGGL(k_cem_local_topk, dim3(psg, A), dim3(1024), tl, stream, rf, (int)cfg.population_offset, ps_part.p);
                         if (rc.comm) {
-                            const Rccl& r = Rccl::get();
+                            const Rccl& r = *rc.api;
                             r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (CEM local elites)");
                         } else {
                             REQUIRE(cfg.population_global <= N, BBMPC_E_STATE, "population sharding needs a communicator: call bbmpc_comm_init first");
@@ -1123,7 +1124,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
                         hipLaunchKernelGGL(k_refit_pi2_partial, pgrid, pblock, lds, stream, rf, ps_part.p);
                         if (rc.comm) {
                             // the exchange sits ON the launch stream: the merge needs it, nothing can overlap it
-                            const Rccl& r = Rccl::get();
+                            const Rccl& r = *rc.api;
                             r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (PI2 partials)");
                         } else {
                             REQUIRE(cfg.population_global <= N, BBMPC_E_STATE, "population sharding needs a communicator: call bbmpc_comm_init first");
@@ -1227,7 +1228,7 @@ void Engine::optimize_spsa(RolloutArgs& ra, uint32_t step) {
             } else {
                 shard_pass(ps_part.p);
                 if (rc.comm) {
-                    const Rccl& r = Rccl::get();
+                    const Rccl& r = *rc.api;
                     r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (SPSA row sums)");
                 } else {
                     REQUIRE(cfg.population_global <= N, BBMPC_E_STATE, "population sharding needs a communicator: call bbmpc_comm_init first");
@@ -1284,7 +1285,7 @@ void Engine::optimize_pso(RolloutArgs& ra, uint32_t step) {
         if (sharded) {
             if (ps_loopback <= 1) {
                 if (rc.comm) {
-                    const Rccl& r = Rccl::get();
+                    const Rccl& r = *rc.api;
                     r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (PSO local bests)");
                 } else {
                     REQUIRE(cfg.population_global <= N, BBMPC_E_STATE, "population sharding needs a communicator: call bbmpc_comm_init first");
@@ -2330,29 +2331,23 @@ int bbmpc_comm_unique_id(void* out, int64_t bytes) {
     API_END
 }
 
-int bbmpc_comm_init(bbmpc_handle h, const void* unique_id, int32_t nranks, int32_t rank) {
-    API_BEGIN
-    CHECK_HANDLE(h);
-    h->e->invalidate_step_graph();
-    CHECK_PTR(unique_id);
-    Engine* e = h->e;
+// stream, events and hand-off flags of a handle's communicator, whoever serves it (`join` creates c.comm)
+static void comm_setup(Engine* e, int32_t nranks, int32_t rank, const Rccl& api, const char* what, const std::function<int(Rccl::Comm*)>& join) {
     if (nranks < 1 || rank < 0 || rank >= nranks) throw HipError(BBMPC_E_INVALID, "bbmpc_comm_init: rank / nranks out of range");
     if (e->rc.comm) throw HipError(BBMPC_E_STATE, "bbmpc_comm_init: the handle already has a communicator");
-    const Rccl& r = Rccl::get();            // (the handle's device is current: CHECK_HANDLE)
-    Rccl::UniqueId id;
-    memcpy(&id, unique_id, sizeof(id));
     RecordComm& c = e->rc;
     c.stream = create_comm_stream();
     for (int s = 0; s < RecordComm::kSlots; ++s) {
         HIP_CHECK(hipEventCreateWithFlags(&c.ready[s], hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&c.done[s], hipEventDisableTiming));
     }
-    const int irc = r.CommInitRank(&c.comm, nranks, id, rank);
+    const int irc = join(&c.comm);
     if (irc != 0) {
         c.comm = nullptr;
         c.destroy();                     // stream + events created above
-        r.check(irc, "ncclCommInitRank");
+        api.check(irc, what);
     }
+    c.api = &api;
     c.nranks = nranks;
     c.rank = rank;
     // BBMPC_COMM_SYNC=event: events only; default: flags in signal memory where the device supports stream wait-value
@@ -2385,6 +2380,27 @@ int bbmpc_comm_init(bbmpc_handle h, const void* unique_id, int32_t nranks, int32
             }
         }
     }
+}
+
+int bbmpc_comm_init(bbmpc_handle h, const void* unique_id, int32_t nranks, int32_t rank) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
+    CHECK_PTR(unique_id);
+    const Rccl& r = Rccl::get();            // (the handle's device is current: CHECK_HANDLE)
+    Rccl::UniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    comm_setup(h->e, nranks, rank, r, "ncclCommInitRank", [&](Rccl::Comm* out) { return r.CommInitRank(out, nranks, id, rank); });
+    API_END
+}
+
+int bbmpc_comm_init_local(bbmpc_handle h, uint64_t group_key, int32_t nranks, int32_t rank) {
+    API_BEGIN
+    CHECK_HANDLE(h);
+    h->e->invalidate_step_graph();
+    Engine* e = h->e;
+    comm_setup(e, nranks, rank, Rccl::local(), "bbmpc_comm_init_local",
+               [&](Rccl::Comm* out) { return bbmpc::local_comm_join(group_key, nranks, rank, e->device, out); });
     API_END
 }
 
@@ -2421,7 +2437,7 @@ static uint32_t next_comm_seq(Engine* e) {
 // the collective itself + "slot done" on the communication stream (whatever made d_records ready is already ordered before it there)
 static void gather_enqueue(Engine* e, const float* d_records, float* d_gathered, size_t count, int slot, uint32_t v) {
     RecordComm& c = e->rc;
-    const Rccl& r = Rccl::get();
+    const Rccl& r = *c.api;
     r.check(r.AllGather(d_records, d_gathered, count, Rccl::kFloat32, c.comm, c.stream), "ncclAllGather");
     if (c.sync_mode == 1) {
         HIP_CHECK(hipStreamWriteValue32(c.stream, c.done_flag[slot], v, 0));
@@ -2448,7 +2464,6 @@ static void flush_deferred_gathers(Engine* e) {
 static void gather_records(Engine* e, const float* d_records, float* d_gathered, size_t count, int slot, bool event_attached,
                            bool published, uint32_t v) {
     RecordComm& c = e->rc;
-    const Rccl& r = Rccl::get();
     if (published) {
         HIP_CHECK(hipStreamWaitValue32(c.stream, c.flag, v, hipStreamWaitValueGte, 0xffffffffu));
     } else {
@@ -2601,7 +2616,7 @@ int bbmpc_comm_info(bbmpc_handle h, int32_t* nranks, int32_t* rank, int32_t* syn
     CHECK_HANDLE(h);
     RecordComm& c = h->e->rc;
     if (!c.comm) throw HipError(BBMPC_E_STATE, "bbmpc_comm_info: no communicator (bbmpc_comm_init)");
-    const Rccl& r = Rccl::get();
+    const Rccl& r = *c.api;
     int n = 0, me = 0;
     r.check(r.CommCount(c.comm, &n), "ncclCommCount");
     r.check(r.CommUserRank(c.comm, &me), "ncclCommUserRank");

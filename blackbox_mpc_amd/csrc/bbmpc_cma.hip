@@ -201,7 +201,7 @@ void Engine::optimize_cma(RolloutArgs& ra, uint32_t step) {
             } else {
                 shard_pass(ps_part.p);
                 if (rc.comm) {
-                    const Rccl& r = Rccl::get();
+                    const Rccl& r = *rc.api;
                     r.check(r.AllGather(ps_part.p, ps_all.p, pw, Rccl::kFloat32, rc.comm, stream), "ncclAllGather (CMA-ES local elites)");
                 } else {
                     REQUIRE(cfg.population_global <= N, BBMPC_E_STATE, "population sharding needs a communicator: call bbmpc_comm_init first");

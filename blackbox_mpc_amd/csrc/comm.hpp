@@ -14,6 +14,10 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -39,6 +43,9 @@ struct Rccl {
     void check(int rc, const char* what) const {
         if (rc != 0) throw std::runtime_error(std::string(what) + ": " + (GetErrorString ? GetErrorString(rc) : "RCCL error"));
     }
+
+    // the same table served by the in-process communicator below (bbmpc_comm_init_local)
+    static const Rccl& local();
 
 private:
     static Rccl load() {
@@ -67,11 +74,159 @@ private:
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// In-process communicator: several handles of ONE process on ONE device form a group whose all-gather runs on the callers'
+// streams -- the collective contract of ncclAllGather (same count on every rank, calls in the same order on every rank,
+// asynchronous on the stream it is given) without RCCL, which refuses two ranks on one GPU.  What it is for: the rank > 0 /
+// nranks > 1 paths of the engine (record gather hand-offs, the per-iteration exchanges of a sharded population, the merges in
+// rank order) on a one-GPU box, and several handles sharing a device in one process.
+//
+// Operation q of rank r, ring slot q % kDepth:
+//   (a) stream: wait for every rank's `done` event of the slot's previous use, copy the rank's piece into the slot, record
+//       `arrive[r][slot]`;
+//   (b) HOST: rendezvous of all ranks (each rank is driven by its own host thread, as ranks are processes elsewhere);
+//   (c) stream: wait for every other rank's `arrive` event, copy the slot to the destination, record `done[r][slot]`.
+// The rendezvous is what makes it safe: every event is recorded (in host order) before anybody waits for it, so the waits
+// can never sit in a hardware queue in FRONT of the record they wait for -- the runtime multiplexes streams onto a few
+// hardware queues, and the first version (stream wait-value / write-value on signal memory, no host rendezvous) deadlocked
+// exactly there: rank 0's "wait for arrive[1]" ahead of rank 1's "arrive[1] = 1" in one queue.
+struct LocalGroup {
+    static constexpr int kDepth = 4, kMaxRanks = 16;
+    static constexpr size_t kMaxBytes = 1 << 20;          // per rank and operation
+    int nranks = 0, device = 0, refs = 0;
+    char* stage = nullptr;                                // [kDepth][nranks * kMaxBytes]
+    hipEvent_t arrive[kMaxRanks][kDepth] = {};
+    hipEvent_t done[kMaxRanks][kDepth] = {};
+    std::mutex mu;                                        // host rendezvous
+    std::condition_variable cv;
+    int waiting = 0;
+    uint64_t generation = 0;
+    bool broken = false;                                  // a rank gave up waiting: every later operation fails instead of hanging
+};
+struct LocalRank {
+    LocalGroup* grp = nullptr;
+    int rank = 0;
+    uint32_t op = 0;
+    uint64_t key = 0;
+};
+struct LocalRegistry {
+    std::mutex mu;
+    std::map<uint64_t, LocalGroup*> groups;
+    static LocalRegistry& get() { static LocalRegistry r; return r; }
+};
+
+inline int local_comm_join(uint64_t key, int nranks, int rank, int device, Rccl::Comm* out) {
+    if (nranks < 1 || nranks > LocalGroup::kMaxRanks || rank < 0 || rank >= nranks) return 4;     // ncclInvalidArgument
+    LocalRegistry& reg = LocalRegistry::get();
+    std::lock_guard<std::mutex> lk(reg.mu);
+    LocalGroup*& g = reg.groups[key];
+    if (!g) {
+        g = new LocalGroup();
+        g->nranks = nranks; g->device = device;
+        bool ok = hipMalloc((void**)&g->stage, (size_t)LocalGroup::kDepth * nranks * LocalGroup::kMaxBytes) == hipSuccess;
+        for (int r = 0; ok && r < nranks; ++r)
+            for (int d = 0; ok && d < LocalGroup::kDepth; ++d)
+                ok = hipEventCreateWithFlags(&g->arrive[r][d], hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&g->done[r][d], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); LocalGroup* dead = g; reg.groups.erase(key); delete dead; return 1; }   // ncclUnhandledCudaError
+    }
+    if (g->nranks != nranks || g->device != device) return 4;
+    LocalRank* me = new LocalRank();
+    me->grp = g; me->rank = rank; me->key = key;
+    ++g->refs;
+    *out = me;
+    return 0;
+}
+
+namespace local_api {
+// all ranks of the group, or nobody: false after `seconds` without the others (a rank that never calls is a caller's bug --
+// e.g. one host thread driving two ranks -- and must show up as an error, not as a hang)
+inline bool rendezvous(LocalGroup* g, int seconds) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (g->broken) return false;
+    const uint64_t gen = g->generation;
+    if (++g->waiting == g->nranks) {
+        g->waiting = 0;
+        ++g->generation;
+        g->cv.notify_all();
+        return true;
+    }
+    if (!g->cv.wait_for(lk, std::chrono::seconds(seconds), [&] { return g->generation != gen || g->broken; })) {
+        g->broken = true;
+        g->cv.notify_all();
+        return false;
+    }
+    return !g->broken;
+}
+inline int all_gather(const void* send, void* recv, size_t count, int dtype, Rccl::Comm comm, hipStream_t st) {
+    LocalRank* me = static_cast<LocalRank*>(comm);
+    LocalGroup* g = me->grp;
+    const size_t bytes = count * (dtype == Rccl::kFloat32 ? 4 : 1);
+    if (bytes == 0 || bytes > LocalGroup::kMaxBytes) return 4;
+    const uint32_t q = me->op++;
+    const int d = (int)(q % LocalGroup::kDepth);
+    char* slot = g->stage + (size_t)d * g->nranks * LocalGroup::kMaxBytes;
+    hipError_t e = hipSuccess;
+    if (q >= (uint32_t)LocalGroup::kDepth)                              // recorded kDepth operations ago, i.e. before the last rendezvous
+        for (int p = 0; p < g->nranks && e == hipSuccess; ++p) e = hipStreamWaitEvent(st, g->done[p][d], 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(slot + (size_t)me->rank * bytes, send, bytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(g->arrive[me->rank][d], st);
+    if (e != hipSuccess) return 1;
+    if (!rendezvous(g, 60)) return 5;
+    for (int p = 0; p < g->nranks && e == hipSuccess; ++p)
+        if (p != me->rank) e = hipStreamWaitEvent(st, g->arrive[p][d], 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(recv, slot, (size_t)g->nranks * bytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(g->done[me->rank][d], st);
+    return e == hipSuccess ? 0 : 1;
+}
+inline int comm_destroy(Rccl::Comm comm) {
+    LocalRank* me = static_cast<LocalRank*>(comm);
+    LocalRegistry& reg = LocalRegistry::get();
+    std::lock_guard<std::mutex> lk(reg.mu);
+    LocalGroup* g = me->grp;
+    {   // a rank that leaves takes the group with it: the others' next collective fails instead of waiting for it
+        std::lock_guard<std::mutex> gl(g->mu);
+        g->broken = true;
+        g->cv.notify_all();
+    }
+    if (--g->refs == 0) {
+        (void)hipFree(g->stage);
+        for (int r = 0; r < g->nranks; ++r)
+            for (int d = 0; d < LocalGroup::kDepth; ++d) { (void)hipEventDestroy(g->arrive[r][d]); (void)hipEventDestroy(g->done[r][d]); }
+        reg.groups.erase(me->key);
+        delete g;
+    }
+    delete me;
+    return 0;
+}
+inline int comm_count(Rccl::Comm comm, int* n) { *n = static_cast<LocalRank*>(comm)->grp->nranks; return 0; }
+inline int comm_user_rank(Rccl::Comm comm, int* r) { *r = static_cast<LocalRank*>(comm)->rank; return 0; }
+inline const char* error_string(int rc) {
+    return rc == 4 ? "in-process communicator: invalid argument (count, rank or group shape)"
+         : rc == 5 ? "in-process communicator: the other ranks did not arrive within 60 s (every rank needs its own host thread), or one of them has left"
+                   : "in-process communicator: HIP error";
+}
+}  // namespace local_api
+
+inline const Rccl& Rccl::local() {
+    static const Rccl api = [] {
+        Rccl a;
+        a.AllGather = local_api::all_gather;
+        a.CommDestroy = local_api::comm_destroy;
+        a.CommCount = local_api::comm_count;
+        a.CommUserRank = local_api::comm_user_rank;
+        a.GetErrorString = local_api::error_string;
+        return a;
+    }();
+    return api;
+}
+
 // Per-handle communication state: communicator, stream, and two slots of (ready, done) events so that the gather of
 // control step t overlaps step t+1 while the caller double-buffers its record / gathered arrays.
 struct RecordComm {
     static constexpr int kSlots = 2;
     Rccl::Comm comm = nullptr;
+    const Rccl* api = nullptr;         // who serves `comm`: librccl (bbmpc_comm_init) or the in-process communicator (bbmpc_comm_init_local)
     int nranks = 0, rank = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ready[kSlots] = {nullptr, nullptr};
@@ -89,8 +244,9 @@ struct RecordComm {
 
     void destroy() {
         if (stream) (void)hipStreamSynchronize(stream);
-        if (comm) (void)Rccl::get().CommDestroy(comm);
+        if (comm && api) (void)api->CommDestroy(comm);
         comm = nullptr;
+        api = nullptr;
         for (int s = 0; s < kSlots; ++s) {
             if (ready[s]) (void)hipEventDestroy(ready[s]);
             if (done[s]) (void)hipEventDestroy(done[s]);

@@ -706,18 +706,25 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     // tile i next to its own as a second, independent chain, with tile i's operands in LDS ([i][it | bias][lane][4]).
     const int EWS = (MLP_TP * S + 63) >> 6;
     const bool split_i1 = NTILES == 2 && 2 * EWS <= HT - 2;
-    const int t2 = (split_i1 && wid >= EWS && wid < 2 * EWS) ? wid - EWS : -1;         // second feature tile of this wave
+    // Round 5: with five reducing waves and thirteen feature tiles (dim_S = 20, 200 hidden units) the second chains of waves
+    // 5 .. 9 put four layer-0 jobs on SIMD 1 (waves 5, 9) against two on SIMD 0 (wave 8 alone: waves 0 and 4 reduce); wave 8 takes
+    // tile 4 as a THIRD chain instead of wave 9: three jobs on SIMDs 0 - 2, four on SIMD 3 (wave 7 twice, the owner's own + XT).
+    const bool i1_bal = (BBMPC_PAIR_OPTS & 256) && split_i1 && EWS == 5 && HT == 13;
+    const int t2 = (split_i1 && wid >= EWS && wid < 2 * EWS && !(i1_bal && wid == 2 * EWS - 1)) ? wid - EWS : -1;   // second feature tile of this wave
+    const int t3 = (i1_bal && wid == 2 * EWS - 2) ? EWS - 1 : -1;                                                // third
     float* xo2 = xo + XO_N * 256;
     if constexpr (NTILES == 2) {
-        if (t2 >= 0) {
+        for (int tt = 0; tt < 2; ++tt) {
+            const int tx = tt ? t3 : t2;
+            if (tx < 0) continue;
             float t8[IT0 * 4];
-            load_w_in(t8, t2);
+            load_w_in(t8, tx);
 #pragma unroll
             for (int it = 0; it < IT0; ++it)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) xo2[((t2 * (IT0 + 1) + it) * 64 + lane) * 4 + s] = t8[it * 4 + s];
+                for (int s = 0; s < 4; ++s) xo2[((tx * (IT0 + 1) + it) * 64 + lane) * 4 + s] = t8[it * 4 + s];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) xo2[((t2 * (IT0 + 1) + IT0) * 64 + lane) * 4 + s] = m.bpack[0][(unsigned)((t2 * 64 + lane) * 4 + s)];
+            for (int s = 0; s < 4; ++s) xo2[((tx * (IT0 + 1) + IT0) * 64 + lane) * 4 + s] = m.bpack[0][(unsigned)((tx * 64 + lane) * 4 + s)];
         }
     }
 #pragma unroll
@@ -865,11 +872,13 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     // layer 0 of this wave's tile and, as a second chain, of tile t2 (or XT for the owner): interval 1 with split_i1
     auto stage_A1 = [&](int ti) {
         const float* xs = T_xs(ti);
-        const bool has2 = t2 >= 0 || owner;
+        const bool has2 = t2 >= 0 || owner, has3 = t3 >= 0;
         const float* w2 = owner ? xo : xo2 + (size_t)(t2 < 0 ? 0 : t2) * (IT0 + 1) * 256;
         const float* b2 = owner ? xo + XO_B0 * 256 : w2 + IT0 * 256;
-        f32x4 acc = bias0_r, acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* w3 = xo2 + (size_t)(t3 < 0 ? 0 : t3) * (IT0 + 1) * 256;
+        f32x4 acc = bias0_r, acc2 = {0.0f, 0.0f, 0.0f, 0.0f}, acc3 = {0.0f, 0.0f, 0.0f, 0.0f};
         if (has2) acc2 = *reinterpret_cast<const f32x4*>(b2 + (size_t)lane * 4);
+        if (has3) acc3 = *reinterpret_cast<const f32x4*>(w3 + IT0 * 256 + (size_t)lane * 4);
 #pragma unroll
         for (int it = 0; it < IT0; ++it) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(xs + ((size_t)it * 64 + lane) * 4);
@@ -877,6 +886,10 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             if (has2) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(w2 + ((size_t)it * 64 + lane) * 4);
                 acc2 = l0_tile(it, w.x, w.y, w.z, w.w, b, acc2);
+            }
+            if (has3) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(w3 + ((size_t)it * 64 + lane) * 4);
+                acc3 = l0_tile(it, w.x, w.y, w.z, w.w, b, acc3);
             }
         }
         acc.x = apply_act_ct<A0>(acc.x); acc.y = apply_act_ct<A0>(acc.y);
@@ -886,6 +899,11 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             acc2.x = apply_act_ct<A0>(acc2.x); acc2.y = apply_act_ct<A0>(acc2.y);
             acc2.z = apply_act_ct<A0>(acc2.z); acc2.w = apply_act_ct<A0>(acc2.w);
             *reinterpret_cast<f32x4*>(T_h0(ti) + ((size_t)(owner ? XT : t2) * 64 + lane) * 4) = acc2;
+        }
+        if (has3) {
+            acc3.x = apply_act_ct<A0>(acc3.x); acc3.y = apply_act_ct<A0>(acc3.y);
+            acc3.z = apply_act_ct<A0>(acc3.z); acc3.w = apply_act_ct<A0>(acc3.w);
+            *reinterpret_cast<f32x4*>(T_h0(ti) + ((size_t)t3 * 64 + lane) * 4) = acc3;
         }
     };
     // the owner's end of feature tile XT: collect quarters 0..2, activation, K slab of the last layer

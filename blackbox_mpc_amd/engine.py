@@ -167,6 +167,11 @@ class Engine:
             raise ValueError("unique_id must be %d bytes" % L.COMM_ID_BYTES)
         L.check(L.lib.bbmpc_comm_init(self._h, ctypes.c_char_p(bytes(unique_id)), int(nranks), int(rank)))
 
+    def comm_init_local(self, group_key, nranks, rank):
+        """Rank `rank` of an in-process communicator shared by the handles that pass the same key (one device, no RCCL):
+        bbmpc_comm_init_local.  See parallel.attach_local_comm."""
+        L.check(L.lib.bbmpc_comm_init_local(self._h, ctypes.c_uint64(int(group_key)), int(nranks), int(rank)))
+
     def gather_records_dev(self, d_records, d_gathered, count_per_rank, slot):
         L.check(L.lib.bbmpc_gather_records_dev(self._h, ctypes.c_void_p(d_records), ctypes.c_void_p(d_gathered),
                                                int(count_per_rank), int(slot)))

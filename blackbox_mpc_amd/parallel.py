@@ -72,6 +72,21 @@ def attach_record_comm(engine, group=None, device=None):
     return world, rank
 
 
+_local_keys = iter(range(1, 1 << 62))
+
+
+def attach_local_comm(engines):
+    """One in-process communicator over `engines` (handles of THIS process on one device), engine i = rank i:
+    bbmpc_comm_init_local.  What RCCL does between processes on different GPUs, between handles that share a GPU: the
+    rank > 0 / nranks > 1 paths of the engine on a one-GPU box (tests/test_gpu_local_ranks.py).  Every collective holds a host
+    rendezvous of the ranks: drive each engine from its own thread (ctypes releases the GIL inside the library)."""
+    import os
+    key = (os.getpid() << 20) ^ next(_local_keys)
+    for r, e in enumerate(engines):
+        e.comm_init_local(key, len(engines), r)
+    return key
+
+
 class ShardedMPCPolicy:
     """MPCPolicy over all agents with the agents sharded across the ranks of a process group.
 

@@ -332,6 +332,15 @@ int bbmpc_synchronize(bbmpc_handle h);
 #define BBMPC_COMM_ID_BYTES 128
 int bbmpc_comm_unique_id(void* out, int64_t bytes);
 int bbmpc_comm_init(bbmpc_handle h, const void* unique_id, int32_t nranks, int32_t rank);
+/* The same communicator for `nranks` handles of ONE process on ONE device, without RCCL (which refuses two ranks on a GPU):
+ * handles that pass the same `group_key` form the group, rank = 0 .. nranks-1 (at most 16).  Its all-gather is copies and events on the callers'
+ * streams around a HOST rendezvous of the ranks (csrc/comm.hpp): every rank must be driven by its own host thread, as ranks
+ * are processes elsewhere, and a rank that does not show up within 60 s fails the others' call.  Everything else -- record gathers, the
+ * per-iteration exchanges of a sharded population, bbmpc_comm_info / _destroy -- works as with bbmpc_comm_init.  It exists so
+ * that the rank > 0 / nranks > 1 paths run on a one-GPU box (tests/test_gpu_local_ranks.py), and for several handles sharing a
+ * device.  At most 1 MiB
+ * per rank and operation.  No counterpart in the reference. */
+int bbmpc_comm_init_local(bbmpc_handle h, uint64_t group_key, int32_t nranks, int32_t rank);
 int bbmpc_gather_records_dev(bbmpc_handle h, const float* d_records, float* d_gathered, int64_t count_per_rank,
                              int32_t slot);
 /* bbmpc_optimize_dev + bbmpc_gather_records_dev in one call (count = num_agents * record width): lets a control

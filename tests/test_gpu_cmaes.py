@@ -388,3 +388,44 @@ def test_three_launches_per_iteration_are_bit_identical_to_eleven(L, monkeypatch
     for r0, r1 in zip(out["0"], out["1"]):
         for x0, x1 in zip(r0, r1):
             np.testing.assert_array_equal(x0, x1)
+
+
+@pytest.mark.parametrize("fail", ["0", "1"])
+@pytest.mark.parametrize("H,N,k", [(50, 400, 40), (5, 200, 20)])          # n = 300 (kernels_eigh.hpp) and n = 30 (kernels_eigh_small.hpp)
+def test_indefinite_covariance_is_ranked_by_singular_value(L, monkeypatch, fail, H, N, k):
+    # u, B, _ = tf.linalg.svd(C) (cma_es.py:195-197) orders by the SINGULAR value |lambda|; a slightly indefinite C (fp32 drift,
+    # set_state("C")) has a negative eigenvalue whose magnitude is not the smallest.  The direct solvers must rank it where the
+    # SVD -- and the Jacobi fall-back (BBMPC_CMA_EIGH_FAIL=1) -- put it: D descending, D^2 = |eigenvalues|, the column of the
+    # negative eigenvalue in the same place on both paths.
+    monkeypatch.setenv("BBMPC_CMA_EIGH_FAIL", fail)
+    A = 2
+    eng, state = _config5_cma_engine(L, A, N=N, k=k, H=H)
+    n = H * 6
+    rng = np.random.default_rng(17)
+    Cs = np.zeros((A, n, n), np.float32)
+    for g in range(A):
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        lam = np.linspace(0.05, 0.9, n)
+        lam[n // 3] = -0.6                                   # the odd one out: negative, in the upper half by magnitude
+        Cs[g] = ((Q * lam) @ Q.T).astype(np.float32)
+        Cs[g] = np.triu(Cs[g]) + np.triu(Cs[g], 1).T
+    eng.set_state("C", Cs)
+    act, state, rew = eng.optimize(state)
+    B = eng.get_trace(0, L.TRACE_CMA_B).astype(np.float64)
+    C = eng.get_trace(0, L.TRACE_CMA_C).astype(np.float64)
+    D = eng.get_trace(0, L.TRACE_CMA_D).astype(np.float64)
+    for g in range(A):
+        w, V = np.linalg.eigh(C[g])
+        assert w.min() < -0.1, "the update must leave the covariance indefinite for this test to mean anything"
+        sv = np.sort(np.abs(w))[::-1]
+        assert np.all(np.diff(D[g]) <= 1e-6), "D must be sorted descending (tf.linalg.svd order)"
+        np.testing.assert_allclose(D[g] ** 2, sv, rtol=0, atol=5e-5)
+        assert np.abs(B[g].T @ B[g] - np.eye(n)).max() <= 5e-5
+        # the negative eigenvalue's vector sits at the rank of its magnitude
+        rank = int(np.argmin(np.abs(sv - abs(w.min()))))
+        assert 0 < rank < n - 1, "the negative eigenvalue must not be the smallest singular value"
+        vneg = V[:, int(np.argmin(w))]
+        if min(sv[rank - 1] - sv[rank], sv[rank] - sv[rank + 1]) > 5e-3:          # (its vector is only defined when the value is isolated)
+            assert abs(abs(B[g][:, rank] @ vneg) - 1.0) <= 1e-3, (rank, B[g][:, rank] @ vneg)
+        # |C b_i| = s_i for every column (left singular vectors of a symmetric matrix)
+        np.testing.assert_allclose(np.linalg.norm(C[g] @ B[g], axis=0), D[g] ** 2, rtol=0, atol=2e-4)

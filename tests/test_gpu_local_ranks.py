@@ -1,0 +1,150 @@
+"""Two RANKS on one GPU: the engine's nranks = 2 paths -- record gather with its stream hand-offs, the per-iteration
+exchanges and rank-ordered merges of a sharded population -- driven through the in-process communicator
+(bbmpc_comm_init_local, csrc/comm.hpp), which serves the same call sites as RCCL's communicator does between processes.
+Every rank is driven by its own host thread (the communicator's collectives hold a host rendezvous).
+RCCL itself refuses two ranks on one device; tests/test_gpu_two_ranks.py is the two-process, two-GPU form of the same checks
+and skips on a one-GPU box."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def L():
+    from blackbox_mpc_amd import _build
+    _build.build()
+    from blackbox_mpc_amd import _lib
+    assert _lib.device_count() >= 1
+    return _lib
+
+
+def _in_threads(fns):
+    """Each rank on its own host thread (ctypes releases the GIL inside the library); re-raises the first failure."""
+    out, err = [None] * len(fns), [None] * len(fns)
+
+    def run(i):
+        try:
+            out[i] = fns[i]()
+        except BaseException as ex:                       # noqa: BLE001
+            err[i] = ex
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(len(fns))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert not any(t.is_alive() for t in ts), "a rank hung in its collective"
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("opt_name", ["CEM", "PI2"])
+def test_agent_shards_gather_records_on_two_ranks(L, opt_name):
+    import torch
+    from blackbox_mpc_amd import parallel as P
+    from blackbox_mpc_amd.engine import Engine
+    from blackbox_mpc_amd.utils import synthetic as SY
+    opt = getattr(L, "OPT_" + opt_name)
+    A_glob, N, H, iters, R = 4, 300, 20, 3, 2
+
+    def pend(A, **kw):
+        return Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=A, planning_horizon=H,
+                      population_size=N, max_iterations=iters, num_elite=30, seed=5, **kw)
+    full = pend(A_glob)
+    shards = [P.agent_shard(A_glob, R, r) for r in range(R)]
+    ranks = [pend(cnt, agent_offset=off, num_agents_global=A_glob) for off, cnt in shards]
+    P.attach_local_comm(ranks)
+    for r, e in enumerate(ranks):
+        assert e.comm_info()[:2] == (R, r)
+    rec_w = 1 + 3 + 1
+    gathered = [[torch.full((A_glob, rec_w), -7.0, device="cuda") for _ in range(2)] for _ in range(R)]
+    state = SY.pendulum_start_states(A_glob)
+    for t in range(4):
+        a_f, n_f, r_f = full.optimize(state)
+        want = np.concatenate([a_f, n_f, np.asarray(r_f).reshape(-1, 1)], axis=1)
+        b = t & 1
+
+        # a rank per host thread, as ranks are processes elsewhere: bbmpc_optimize_gather stages the rank's records and
+        # bbmpc_gather_wait enqueues the collective and blocks until it is through -- which takes every rank's part
+        def rank_step(r):
+            off, cnt = shards[r]
+            a_m, n_m, r_m = ranks[r].optimize_gather(state[off:off + cnt], gathered[r][b].data_ptr(), b, t)
+            ranks[r].gather_wait(b, host_block=True)
+            return a_m, n_m
+        res = _in_threads([lambda r=r: rank_step(r) for r in range(R)])
+        for r, (off, cnt) in enumerate(shards):
+            a_m, n_m = res[r]
+            assert np.array_equal(a_m, a_f[off:off + cnt]) and np.array_equal(n_m, n_f[off:off + cnt])
+            g = gathered[r][b].cpu().numpy()
+            assert np.array_equal(g.view(np.int32), want.astype(F).view(np.int32)), (t, r)      # every rank: every agent's record, bit for bit
+        state = n_f
+    for e in ranks:
+        e.comm_destroy()
+
+
+@pytest.mark.parametrize("opt_name", ["PI2", "CEM", "RandomSearch", "PSO", "SPSA"])
+def test_population_shards_on_two_ranks_match_the_one_handle_loopback(L, monkeypatch, opt_name):
+    # Two handles = two ranks, each rolling out half of ONE agent's population, exchanging partials every iteration on their launch
+    # streams.  The single-handle loopback hook (BBMPC_POPSHARD_LOOPBACK=2: one handle plays both shards in turn and merges in rank
+    # order) computes the same thing without a communicator: bit-identical.  And both stay within the sharding tolerance of the
+    # unsharded optimizer (order of the fp32 sums: DESIGN.md section 6).
+    from blackbox_mpc_amd import parallel as P
+    from blackbox_mpc_amd.engine import Engine
+    from blackbox_mpc_amd.utils import synthetic as SY
+    opt = {"PI2": L.OPT_PI2, "CEM": L.OPT_CEM, "RandomSearch": L.OPT_RANDOM_SEARCH, "PSO": L.OPT_PSO, "SPSA": L.OPT_SPSA}[opt_name]
+    S, U, H, N, R = 20, 6, 30, 1000, 2
+    ws, bs = SY.make_mlp_params()
+    stats = SY.cheetah_stats(S, U)
+
+    def mk(n, **kw):
+        e = Engine(opt, L.DYN_MLP, L.REW_CHEETAH, [-1.0] * U, [1.0] * U, dim_s=S, num_agents=1, planning_horizon=H,
+                   population_size=n, max_iterations=(0 if opt_name == "RandomSearch" else 5), num_elite=50, seed=9, **kw)
+        e.set_mlp(ws, bs, [L.ACT_TANH, L.ACT_TANH, L.ACT_NONE], stats)
+        return e
+    one = mk(N)
+    monkeypatch.setenv("BBMPC_POPSHARD_LOOPBACK", str(R))
+    loop = mk(N // R, population_global=N)
+    monkeypatch.delenv("BBMPC_POPSHARD_LOOPBACK")
+    ranks = []
+    for r in range(R):
+        off, cnt = P.population_shard(N, R, r)
+        ranks.append(mk(cnt, population_offset=off, population_global=N))
+    P.attach_local_comm(ranks)
+    for e in (one, loop, *ranks):
+        e.reset()
+    st = SY.cheetah_start_states(1, S)
+    s_one, s_loop, s_rk = st.copy(), st.copy(), st.copy()
+    for t in range(3):
+        a1, n1, _ = one.optimize(s_one, t)
+        a2, n2, _ = loop.optimize(s_loop, t)
+        res = _in_threads([lambda e=e: e.optimize(s_rk, t) for e in ranks])
+        for a3, n3, _ in res:                                   # every rank ends the control step with the same action
+            assert np.array_equal(a3, a2) and np.array_equal(n3, n2), (opt_name, t)
+        tol = 0.0 if opt_name in ("RandomSearch", "PSO") else 2e-5      # argmax-only optimizers: the unsharded bits
+        assert float(np.abs(a1 - a2).max()) <= tol and float(np.abs(n1 - n2).max()) <= tol, (opt_name, t)
+        s_one, s_loop, s_rk = n1, n2, res[0][1]
+    for e in ranks:
+        e.comm_destroy()
+
+
+def test_local_group_shape_is_checked(L):
+    from blackbox_mpc_amd.engine import Engine
+    mk = lambda: Engine(L.OPT_CEM, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=1, planning_horizon=5,
+                        population_size=64, max_iterations=2, num_elite=8)
+    a, b = mk(), mk()
+    a.comm_init_local(12345, 2, 0)
+    with pytest.raises(L.BBMPCError):
+        b.comm_init_local(12345, 3, 1)                          # another group size under the same key
+    with pytest.raises(L.BBMPCError):
+        b.comm_init_local(12345, 2, 2)                          # rank out of range
+    with pytest.raises(L.BBMPCError):
+        a.comm_init_local(12345, 2, 1)                          # the handle already has a communicator
+    b.comm_init_local(12345, 2, 1)
+    assert a.comm_info()[:2] == (2, 0) and b.comm_info()[:2] == (2, 1)
+    a.comm_destroy()
+    b.comm_destroy()
