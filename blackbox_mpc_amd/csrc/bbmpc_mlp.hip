@@ -68,6 +68,13 @@ void Engine::set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, con
                 }
         }
         upload(d_wpack[l], wp);
+        {   // the same operands with a lane's four A operands of a k tile side by side: [OT][IT][lane][s] (generic kernel)
+            std::vector<float> w4(wp.size());
+            for (size_t t = 0; t < (size_t)OT * IT; ++t)
+                for (int s = 0; s < 4; ++s)
+                    for (int ln = 0; ln < 64; ++ln) w4[(t * 64 + ln) * 4 + s] = wp[(t * 4 + s) * 64 + ln];
+            upload(d_wpack4[l], w4);
+        }
         upload(d_bpack[l], bp);
         upload(d_wraw[l], std::vector<float>(w[l], w[l] + (size_t)K * M));
         upload(d_braw[l], std::vector<float>(b[l], b[l] + M));
@@ -140,7 +147,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     q.nw = mlp_nw;
     q.traj = mlp_traj_out;
     const bool record = mlp_traj_out != nullptr;       // trajectory recording lives in rollout_mlp_body's epilogue only
-    for (int l = 0; l < mlp.n_layers; ++l) { q.wraw[l] = d_wraw[l].p; q.braw[l] = d_braw[l].p; q.wq4[l] = d_wq4[l].p; q.wbf[l] = reinterpret_cast<const uint4*>(d_wbf[l].p); }
+    for (int l = 0; l < mlp.n_layers; ++l) { q.wraw[l] = d_wraw[l].p; q.braw[l] = d_braw[l].p; q.wq4[l] = d_wq4[l].p; q.wp4[l] = d_wpack4[l].p; q.wbf[l] = reinterpret_cast<const uint4*>(d_wbf[l].p); }
     const MlpLds lay = mlp_lds_layout(mlp, ra.H, U, S, mlp_nw);
     const size_t lds = (size_t)lay.total * sizeof(float);
     REQUIRE(lds <= 159 * 1024, BBMPC_E_UNSUPPORTED,

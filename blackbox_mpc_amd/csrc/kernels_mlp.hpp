@@ -66,6 +66,7 @@ struct MlpRolloutArgs {
     const float* wraw[MLP_MAX_LAYERS];   // unpacked Dense kernels [in][out] (quad-mode kernel)
     const float* braw[MLP_MAX_LAYERS];   // unpacked biases [out]
     const float* wq4[MLP_MAX_LAYERS];    // quad-mode operands [ceil(in/4)][Mp][4], Mp = out rounded up to 64, zero padded
+    const float* wp4[MLP_MAX_LAYERS];    // the operands of MlpDesc::wpack as [OT][IT][64 lanes][4]: a lane's four A operands of a k tile in ONE 16-byte load (generic kernel)
     const uint4* wbf[MLP_MAX_LAYERS];    // bf16 mode operands [OT][IT][64] x (4 bf16 hi | 4 bf16 lo), k = 16*it + 4*(lane>>4) + r
     float* traj;              // optional [H][A][Nst][S]: the state after every step (a user reward function scores them afterwards)
     float* state_copy;        // optional [A][S] (k_rollout_mlp_q4r): r.state is the pinned host buffer of this control step, workgroup 0 of
@@ -139,50 +140,97 @@ __host__ __device__ inline MlpLds mlp_lds_layout(const MlpDesc& m, int H, int U,
 }
 
 // One dense layer, output-tile split.  in: LDS tiles [IT][64] float4; out: LDS tiles [OT][64] float4.
-__device__ __forceinline__ void mlp_layer_out_split(const MlpDesc& m, int l, const float* in, float* out, int wave,
+// Operands are streamed from L2 every model step (the generic kernel keeps nothing stationary), so the layer runs at the
+// rate the loads are in flight: round 5 reads them as ONE 16-byte load per lane and k tile from the [OT][IT][lane][4] copy
+// (four 4-byte loads 256 bytes apart before: 32 KB in flight per CU, 31 GB/s per CU at the reference's 26-500-500-500-20
+// network, a third of what the matrix pipe can take), takes a wave's output tiles two at a time -- one LDS read of the input
+// tile feeds two independent accumulator chains -- and unrolls four k tiles, i.e. eight 1-KB loads in flight per wave.
+#ifndef MLP_GEN_PF
+#define MLP_GEN_PF 2
+#endif
+__device__ __forceinline__ void mlp_layer_out_split(const MlpDesc& m, const float* wp4, int l, const float* in, float* out, int wave,
                                                     int lane, int nw) {
     const int IT = m.tiles[l], OT = m.tiles[l + 1];
-    const float* __restrict__ wp = m.wpack[l];
+    const f32x4* __restrict__ W = reinterpret_cast<const f32x4*>(wp4);
     const float* __restrict__ bp = m.bpack[l];
-    for (int ot = wave; ot < OT; ot += nw) {
-        f32x4 acc = *reinterpret_cast<const f32x4*>(bp + ((size_t)ot * 64 + lane) * 4);   // bias enters as C
-        const float* w = wp + ((size_t)ot * IT) * 256 + lane;
-#pragma unroll 2
-        for (int it = 0; it < IT; ++it) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(in + ((size_t)it * 64 + lane) * 4);
-            const float a0 = w[(size_t)it * 256 + 0];
-            const float a1 = w[(size_t)it * 256 + 64];
-            const float a2 = w[(size_t)it * 256 + 128];
-            const float a3 = w[(size_t)it * 256 + 192];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b.w, acc, 0, 0, 0);
+    const int a = m.act[l];
+    for (int ot0 = wave; ot0 < OT; ot0 += 2 * nw) {
+        const int ot1 = ot0 + nw;
+        if (ot1 < OT) {
+            f32x4 acc0 = *reinterpret_cast<const f32x4*>(bp + ((size_t)ot0 * 64 + lane) * 4);   // bias enters as C
+            f32x4 acc1 = *reinterpret_cast<const f32x4*>(bp + ((size_t)ot1 * 64 + lane) * 4);
+            const f32x4* w0 = W + (size_t)ot0 * IT * 64 + lane;
+            const f32x4* w1 = W + (size_t)ot1 * IT * 64 + lane;
+            // a ring of MLP_GEN_PF k tiles of operands in registers: 2 x MLP_GEN_PF 1-KB loads in flight per wave at all times
+            // (left to `#pragma unroll` the compiler kept the loads next to their use: 887 us per 4048 x 15-step launch of the
+            // 26-500-500-500-20 network against 1007 before; ring depth 1 / 2 / 3 / 4 / 6: 839 / 779 / 810 / 830 / 818 us.  Deeper
+            // rings do not pay: 253 CUs re-read the same 2.1 MB of operands from their XCD's L2 every model step, 1.3 TB/s per
+            // XCD at this speed -- the L2, not the latency of a load, is what the layer waits for.)
+            f32x4 r0[MLP_GEN_PF], r1[MLP_GEN_PF];
+#pragma unroll
+            for (int j = 0; j < MLP_GEN_PF; ++j) {
+                const int kk = j < IT ? j : IT - 1;
+                r0[j] = w0[(size_t)kk * 64];
+                r1[j] = w1[(size_t)kk * 64];
+            }
+            for (int it = 0; it < IT; it += MLP_GEN_PF) {
+#pragma unroll
+                for (int j = 0; j < MLP_GEN_PF; ++j) {
+                    const int k = it + j;
+                    if (k < IT) {
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(in + ((size_t)k * 64 + lane) * 4);
+                        const f32x4 a0 = r0[j], a1 = r1[j];
+                        const int kn = k + MLP_GEN_PF < IT ? k + MLP_GEN_PF : IT - 1;      // (the last ring refills re-read the last tile: no bounds branch in the stream)
+                        r0[j] = w0[(size_t)kn * 64];
+                        r1[j] = w1[(size_t)kn * 64];
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc1, 0, 0, 0);
+                    }
+                }
+            }
+            acc0.x = apply_act(acc0.x, a); acc0.y = apply_act(acc0.y, a); acc0.z = apply_act(acc0.z, a); acc0.w = apply_act(acc0.w, a);
+            acc1.x = apply_act(acc1.x, a); acc1.y = apply_act(acc1.y, a); acc1.z = apply_act(acc1.z, a); acc1.w = apply_act(acc1.w, a);
+            *reinterpret_cast<f32x4*>(out + ((size_t)ot0 * 64 + lane) * 4) = acc0;
+            *reinterpret_cast<f32x4*>(out + ((size_t)ot1 * 64 + lane) * 4) = acc1;
+        } else {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(bp + ((size_t)ot0 * 64 + lane) * 4);
+            const f32x4* w0 = W + (size_t)ot0 * IT * 64 + lane;
+#pragma unroll 4
+            for (int it = 0; it < IT; ++it) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(in + ((size_t)it * 64 + lane) * 4);
+                const f32x4 a0 = w0[(size_t)it * 64];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc, 0, 0, 0);
+            }
+            acc.x = apply_act(acc.x, a); acc.y = apply_act(acc.y, a); acc.z = apply_act(acc.z, a); acc.w = apply_act(acc.w, a);
+            *reinterpret_cast<f32x4*>(out + ((size_t)ot0 * 64 + lane) * 4) = acc;
         }
-        const int a = m.act[l];
-        acc.x = apply_act(acc.x, a);
-        acc.y = apply_act(acc.y, a);
-        acc.z = apply_act(acc.z, a);
-        acc.w = apply_act(acc.w, a);
-        *reinterpret_cast<f32x4*>(out + ((size_t)ot * 64 + lane) * 4) = acc;
     }
 }
 
 // Last layer, K split: wave multiplies the input tiles it owns (it = wave, wave+nw, ...) into every
 // output tile and leaves partial sums in part[wave][ot][lane].
-__device__ __forceinline__ void mlp_layer_k_split(const MlpDesc& m, int l, const float* in, float* part, int wave,
+__device__ __forceinline__ void mlp_layer_k_split(const MlpDesc& m, const float* wp4, int l, const float* in, float* part, int wave,
                                                   int lane, int nw) {
     const int IT = m.tiles[l], OT = m.tiles[l + 1];
-    const float* __restrict__ wp = m.wpack[l];
+    const f32x4* __restrict__ W = reinterpret_cast<const f32x4*>(wp4);
     for (int ot = 0; ot < OT; ++ot) {
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int it = wave; it < IT; it += nw) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(in + ((size_t)it * 64 + lane) * 4);
-            const float* w = wp + ((size_t)ot * IT + it) * 256 + lane;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[64], b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[128], b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[192], b.w, acc, 0, 0, 0);
+            const f32x4 w = W[((size_t)ot * IT + it) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b.w, acc, 0, 0, 0);
         }
         *reinterpret_cast<f32x4*>(part + (((size_t)wave * OT + ot) * 64 + lane) * 4) = acc;
     }
@@ -374,11 +422,11 @@ __device__ __forceinline__ void rollout_mlp_body(const MlpRolloutArgs& q) {
             const float* in = xs;
             for (int l = 0; l < L - 1; ++l) {
                 float* out = actbuf[l & 1];
-                mlp_layer_out_split(m, l, in, out, wave, lane, nw);
+                mlp_layer_out_split(m, q.wp4[l], l, in, out, wave, lane, nw);
                 __syncthreads();
                 in = out;
             }
-            mlp_layer_k_split(m, L - 1, in, part, wave, lane, nw);
+            mlp_layer_k_split(m, q.wp4[L - 1], L - 1, in, part, wave, lane, nw);
         } else {
             const int HT = m.tiles[1];
             f32x4 acc = bias_r[0];
