@@ -80,19 +80,7 @@ struct MlpRolloutArgs {
 // executes at the vector rate on the same datapath as VALU work (measured: step time = MFMA time + VALU time, not the
 // max), so every VALU instruction shaved off the activations is matrix time gained: this form replaced
 // exp(2|x|) -> 1 - 2r spelled as (|x|+|x|) * log2e, exp2, +1, rcp, r+r, 1-  (eight instructions).
-// A/B switches of the round-5 changes (tools/build_variant.py): bit 0 layer-0 tail MFMAs skipped, bit 1 4-row last-layer tile,
-// bit 2 signed tanh
-#ifndef BBMPC_PAIR_OPTS
-#define BBMPC_PAIR_OPTS 55
-#endif
 __device__ __forceinline__ float bb_tanhf(float x) {
-#if !(BBMPC_PAIR_OPTS & 4)
-    {
-        const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * fabsf(x));
-        const float r = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
-        return copysignf(r, x);
-    }
-#endif
     // tanh x = 1 - 2 / (1 + e^(2x)) holds for either sign: +inf for large x -> 1 - 0, 0 for large -x -> 1 - 2; round 5 dropped the
     // |x| / copysign pair around it (one v_bfi per value: five instructions instead of six, same absolute error bound -- the
     // reciprocal's argument lies in [1, 2) for x < 0 and the cancellation near zero is the positive side's mirrored).
@@ -657,8 +645,8 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     constexpr int C_IT0N = CT0 ? (CS + CU + 15) / 16 : 0;
     const int it0n = CT0 ? C_IT0N : m.tiles[0];
     const int rem0 = (CT0 ? CS + CU : m.dims[0]) - 16 * (it0n - 1);
-    const int tk0 = (BBMPC_PAIR_OPTS & 1) ? (rem0 + 3) >> 2 : 4;
-    const bool out4 = (BBMPC_PAIR_OPTS & 2) && S > 16 && S <= 20;
+    const int tk0 = (rem0 + 3) >> 2;
+    const bool out4 = S > 16 && S <= 20;
     auto l0_live = [&](int it, int sidx) { return it + 1 < it0n || (it + 1 == it0n && sidx < tk0); };
     // LDS address of input feature f of particle pp in the xs tiles (tile_addr with the last tile's slots permuted)
     auto xs_addr = [&](int f, int pp) {
@@ -754,25 +742,20 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     // tile i next to its own as a second, independent chain, with tile i's operands in LDS ([i][it | bias][lane][4]).
     const int EWS = (MLP_TP * S + 63) >> 6;
     const bool split_i1 = NTILES == 2 && 2 * EWS <= HT - 2;
-    // Round 5: with five reducing waves and thirteen feature tiles (dim_S = 20, 200 hidden units) the second chains of waves
-    // 5 .. 9 put four layer-0 jobs on SIMD 1 (waves 5, 9) against two on SIMD 0 (wave 8 alone: waves 0 and 4 reduce); wave 8 takes
-    // tile 4 as a THIRD chain instead of wave 9: three jobs on SIMDs 0 - 2, four on SIMD 3 (wave 7 twice, the owner's own + XT).
-    const bool i1_bal = (BBMPC_PAIR_OPTS & 256) && split_i1 && EWS == 5 && HT == 13;
-    const int t2 = (split_i1 && wid >= EWS && wid < 2 * EWS && !(i1_bal && wid == 2 * EWS - 1)) ? wid - EWS : -1;   // second feature tile of this wave
-    const int t3 = (i1_bal && wid == 2 * EWS - 2) ? EWS - 1 : -1;                                                // third
+    // (Round 5 tried wave 8 with tile 4 as a THIRD chain instead of wave 9's second -- three layer-0 jobs on SIMDs 0 - 2 and four
+    // on SIMD 3 instead of 2 / 4 / 3 / 4: 396.3 us against 396.1, nothing; not kept.)
+    const int t2 = (split_i1 && wid >= EWS && wid < 2 * EWS) ? wid - EWS : -1;         // second feature tile of this wave
     float* xo2 = xo + XO_N * 256;
     if constexpr (NTILES == 2) {
-        for (int tt = 0; tt < 2; ++tt) {
-            const int tx = tt ? t3 : t2;
-            if (tx < 0) continue;
+        if (t2 >= 0) {
             float t8[IT0 * 4];
-            load_w_in(t8, tx);
+            load_w_in(t8, t2);
 #pragma unroll
             for (int it = 0; it < IT0; ++it)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) xo2[((tx * (IT0 + 1) + it) * 64 + lane) * 4 + s] = t8[it * 4 + s];
+                for (int s = 0; s < 4; ++s) xo2[((t2 * (IT0 + 1) + it) * 64 + lane) * 4 + s] = t8[it * 4 + s];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) xo2[((tx * (IT0 + 1) + IT0) * 64 + lane) * 4 + s] = m.bpack[0][(unsigned)((tx * 64 + lane) * 4 + s)];
+            for (int s = 0; s < 4; ++s) xo2[((t2 * (IT0 + 1) + IT0) * 64 + lane) * 4 + s] = m.bpack[0][(unsigned)((t2 * 64 + lane) * 4 + s)];
         }
     }
 #pragma unroll
@@ -920,13 +903,11 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
     // layer 0 of this wave's tile and, as a second chain, of tile t2 (or XT for the owner): interval 1 with split_i1
     auto stage_A1 = [&](int ti) {
         const float* xs = T_xs(ti);
-        const bool has2 = t2 >= 0 || owner, has3 = t3 >= 0;
+        const bool has2 = t2 >= 0 || owner;
         const float* w2 = owner ? xo : xo2 + (size_t)(t2 < 0 ? 0 : t2) * (IT0 + 1) * 256;
         const float* b2 = owner ? xo + XO_B0 * 256 : w2 + IT0 * 256;
-        const float* w3 = xo2 + (size_t)(t3 < 0 ? 0 : t3) * (IT0 + 1) * 256;
-        f32x4 acc = bias0_r, acc2 = {0.0f, 0.0f, 0.0f, 0.0f}, acc3 = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 acc = bias0_r, acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
         if (has2) acc2 = *reinterpret_cast<const f32x4*>(b2 + (size_t)lane * 4);
-        if (has3) acc3 = *reinterpret_cast<const f32x4*>(w3 + IT0 * 256 + (size_t)lane * 4);
 #pragma unroll
         for (int it = 0; it < IT0; ++it) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(xs + ((size_t)it * 64 + lane) * 4);
@@ -934,10 +915,6 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             if (has2) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(w2 + ((size_t)it * 64 + lane) * 4);
                 acc2 = l0_tile(it, w.x, w.y, w.z, w.w, b, acc2);
-            }
-            if (has3) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(w3 + ((size_t)it * 64 + lane) * 4);
-                acc3 = l0_tile(it, w.x, w.y, w.z, w.w, b, acc3);
             }
         }
         acc.x = apply_act_ct<A0>(acc.x); acc.y = apply_act_ct<A0>(acc.y);
@@ -947,11 +924,6 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             acc2.x = apply_act_ct<A0>(acc2.x); acc2.y = apply_act_ct<A0>(acc2.y);
             acc2.z = apply_act_ct<A0>(acc2.z); acc2.w = apply_act_ct<A0>(acc2.w);
             *reinterpret_cast<f32x4*>(T_h0(ti) + ((size_t)(owner ? XT : t2) * 64 + lane) * 4) = acc2;
-        }
-        if (has3) {
-            acc3.x = apply_act_ct<A0>(acc3.x); acc3.y = apply_act_ct<A0>(acc3.y);
-            acc3.z = apply_act_ct<A0>(acc3.z); acc3.w = apply_act_ct<A0>(acc3.w);
-            *reinterpret_cast<f32x4*>(T_h0(ti) + ((size_t)t3 * 64 + lane) * 4) = acc3;
         }
     };
     // the owner's end of feature tile XT: collect quarters 0..2, activation, K slab of the last layer
@@ -1015,87 +987,8 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
                 acc.x = acc.x + aq[h].x; acc.y = acc.y + aq[h].y; acc.z = acc.z + aq[h].z; acc.w = acc.w + aq[h].w;
             }
         } else {
-#if BBMPC_PAIR_OPTS & 8
-            // Round 5: the K loop takes the k tiles in pairs and alternates the two accumulators MFMA by MFMA (even tile -> acc,
-            // odd tile -> acc2, as before: the sums keep their order).  Four MFMAs in a row on ONE accumulator issue 40 cycles
-            // apart (the dependent latency of v_mfma_f32_16x16x4_f32) unless another wave of the SIMD fills the gaps, and the
-            // last wave of a SIMD to finish its chain -- a third of every layer-1 interval -- has nobody to fill them.
-            auto ld_b = [&](int it) { return *reinterpret_cast<const f32x4*>(h0 + ((size_t)it * 64 + lane) * 4); };
-            // everything a k tile carries besides the main chain's MFMAs, in front of them ...
-            auto pre = [&](int it, float& pv) {
-                if (co >= 0) pv = epi_term(cpart + (size_t)it * OTL * 256);
-                if constexpr (NTILES == 2) {
-                    if (it < KQ && helper && kbase + it < HT) {               // wave-uniform
-                        const f32x4 bx = ld_b(kbase + it);
-                        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[it * 4 + 0], bx.x, accx, 0, 0, 0);
-                        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[it * 4 + 1], bx.y, accx, 0, 0, 0);
-                        if (kbase + it + 1 < HT || !half1) {
-                            accx = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[it * 4 + 2], bx.z, accx, 0, 0, 0);
-                            accx = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[it * 4 + 3], bx.w, accx, 0, 0, 0);
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < IT0; ++j) {
-                        if (ta >= 0 && it == apos + j) {
-                            const f32x4 ba = *reinterpret_cast<const f32x4*>(xsa + ((size_t)j * 64 + lane) * 4);
-                            acca = l0_tile(j, wr_in[j * 4 + 0], wr_in[j * 4 + 1], wr_in[j * 4 + 2], wr_in[j * 4 + 3], ba, acca);
-                        }
-                        if (ta >= 0 && owner && it == apos + IT0 + j) {
-                            const f32x4 ba = *reinterpret_cast<const f32x4*>(xsa + ((size_t)j * 64 + lane) * 4);
-                            const f32x4 wa = xo_get(j);
-                            accb = l0_tile(j, wa.x, wa.y, wa.z, wa.w, ba, accb);
-                        }
-                    }
-                }
-            };
-            // ... and behind them
-            auto post = [&](int it, float pv) {
-                if (co >= 0) cacc = cacc + pv;
-                if constexpr (NTILES == 2) {
-                    if (it == KQ - 1 && helper && !owner) {
-                        float* qp = T_qp(ti);
-                        *reinterpret_cast<f32x4*>(qp + ((size_t)hq * 64 + lane) * 4) = accx;
-                        // LDS operations of a wave complete in order: whoever sees the flag sees the partials
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (lane == 0)
-                            __hip_atomic_store(reinterpret_cast<int*>(qp + 3 * 256) + hq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    if (ta >= 0 && it == apos + IT0 - 1) {
-                        acca.x = apply_act_ct<A0>(acca.x); acca.y = apply_act_ct<A0>(acca.y);
-                        acca.z = apply_act_ct<A0>(acca.z); acca.w = apply_act_ct<A0>(acca.w);
-                        *reinterpret_cast<f32x4*>(T_h0(ta) + ((size_t)wave * 64 + lane) * 4) = acca;
-                    }
-                    if (ta >= 0 && owner && it == apos + 2 * IT0 - 1) {
-                        accb.x = apply_act_ct<A0>(accb.x); accb.y = apply_act_ct<A0>(accb.y);
-                        accb.z = apply_act_ct<A0>(accb.z); accb.w = apply_act_ct<A0>(accb.w);
-                        *reinterpret_cast<f32x4*>(T_h0(ta) + ((size_t)XT * 64 + lane) * 4) = accb;
-                    }
-                    if (it == (2 * HT) / 3 && owner) finish_x(ti, seq, accx);
-                }
-            };
-            f32x4 bn0 = ld_b(0), bn1 = ld_b(HT > 1 ? 1 : 0);
-#pragma unroll
-            for (int it = 0; it < HT; it += 2) {
-                const bool two = it + 1 < HT;
-                const f32x4 b0 = bn0, b1 = bn1;           // operands of this pair were loaded during the previous one
-                if (it + 2 < HT) bn0 = ld_b(it + 2);
-                if (it + 3 < HT) bn1 = ld_b(it + 3);
-                float pv0 = 0.0f, pv1 = 0.0f;
-                pre(it, pv0);
-                if (two) pre(it + 1, pv1);
-                const bool full0 = it + 1 < HT || !half1, full1 = it + 2 < HT || !half1;   // the padded half of the last K tile multiplies zeros
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 0], b0.x, acc, 0, 0, 0);
-                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[(it + 1) * 4 + 0], b1.x, acc2, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 1], b0.y, acc, 0, 0, 0);
-                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[(it + 1) * 4 + 1], b1.y, acc2, 0, 0, 0);
-                if (full0) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 2], b0.z, acc, 0, 0, 0);
-                if (two && full1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[(it + 1) * 4 + 2], b1.z, acc2, 0, 0, 0);
-                if (full0) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[it * 4 + 3], b0.w, acc, 0, 0, 0);
-                if (two && full1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr_hid[(it + 1) * 4 + 3], b1.w, acc2, 0, 0, 0);
-                post(it, pv0);
-                if (two) post(it + 1, pv1);
-            }
-#else
+            // (Taking the k tiles in pairs and alternating the two accumulators MFMA by MFMA -- so that a wave alone on its SIMD
+            // still issues back to back -- was built and measured in round 5: 407 us against 407, no change; not kept.)
             f32x4 bn = *reinterpret_cast<const f32x4*>(h0 + (size_t)lane * 4);
             BBMPC_PAIR_CLK2(8 + 8 * ti + 0, seq);
 #pragma unroll
@@ -1169,7 +1062,6 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
                 if (it == 11) { BBMPC_PAIR_CLK2(8 + 8 * ti + 3, seq); }
             }
             BBMPC_PAIR_CLK2(8 + 8 * ti + 4, seq);
-#endif
             acc.x = acc.x + acc2.x; acc.y = acc.y + acc2.y; acc.z = acc.z + acc2.z; acc.w = acc.w + acc2.w;
         }
         acc.x = apply_act_ct<A1>(acc.x); acc.y = apply_act_ct<A1>(acc.y);
@@ -1256,16 +1148,10 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
         // alternates within each SIMD.
         const bool grp = ((wid >> 2) & 1) != 0;
         const bool epi_wave = wid * 64 < MLP_TP * (S + U);
-#if BBMPC_PAIR_OPTS & 64
-        if (helper) __builtin_amdgcn_s_setprio(2);
-        else if (grp) __builtin_amdgcn_s_setprio(1);
-#elif BBMPC_PAIR_OPTS & 32
+        // the helpers (the longest instruction streams of their SIMDs) and the second-dispatched third of the waves, which lose
+        // every arbitration by age, at priority 1; waves 0 - 3 take what is left.  Measured in round 5 (us per launch): helpers
+        // only 403, helpers + waves 4 - 7 397, helpers at 2 and waves 4 - 7 at 1: 401, waves 4 - 7 only 405.
         if (helper || grp) __builtin_amdgcn_s_setprio(1);
-#elif BBMPC_PAIR_OPTS & 128
-        if (grp) __builtin_amdgcn_s_setprio(1);
-#else
-        if (helper) __builtin_amdgcn_s_setprio(1);        // the longest instruction streams of their SIMDs go first
-#endif
         for (int t = 0; t < H; ++t) {
             BBMPC_PAIR_CLK(0);
             // epilogue threads are tid < 16 (S + U): waves 0 .. EW-1 (the others have nothing to reduce)
@@ -1292,7 +1178,7 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             BBMPC_PAIR_CLK(4);
             if (!epi_wave) {
                 stage_B(1, -1, nullptr, dummy, t + 1, IC<-1>{}, IC<0>{});
-            } else if (!grp || ((BBMPC_PAIR_OPTS & 16) && wid * 64 < MLP_TP * S)) {
+            } else if (!grp || wid * 64 < MLP_TP * S) {          // every reducing wave rides (round 5: wave 4 did its epilogue first and was the interval's pole, -4 us)
                 float cacc = lbias[min(ef, S - 1)];                   // C_X(t): reduction rides under B_Y(t)'s MFMA chain
                 stage_B(1, 0, epi_part(0), cacc, t + 1, IC<-1>{}, IC<0>{});
                 epi_finish(0, t, cacc);
