@@ -425,3 +425,58 @@ def test_optional_bf16_modes_against_oracle(L, monkeypatch, mode, q99, frac_flip
         assert np.median(err) < 2e-4
     else:
         assert np.median(err) < 0.1
+
+
+@pytest.mark.parametrize("pair", ["0", "1"])
+@pytest.mark.parametrize("dims,S,U,reward", [
+    ([17, 200, 200, 16], 16, 1, "pendulum"),     # one live input in the second K tile (1 of 4 MFMAs issued); one output tile
+    ([32, 196, 196, 17], 17, 15, "pendulum"),    # both input tiles full; last hidden tile holds 4 features; ONE live row in the 4-row output tile
+    ([12, 193, 193, 10], 10, 2, "pendulum"),     # a single, partly filled input tile (3 of 4 MFMAs); last hidden tile holds 1 feature
+    ([26, 208, 208, 20], 20, 6, "cheetah"),      # thirteen FULL hidden tiles (no half-tile paths), four live rows in the 4-row tile
+    ([22, 200, 200, 18], 18, 4, "cheetah"),      # 6 live inputs in the second K tile (2 of 4 MFMAs), two live rows
+    ([28, 200, 200, 21], 21, 7, "cheetah"),      # dim_S = 21: the second output tile stays on 16x16x4 (five rows)
+])
+def test_pipelined_tile_kernel_padding_paths(L, monkeypatch, pair, dims, S, U, reward):
+    # Round 5 stopped issuing the all-zero MFMAs of the layer-0 tail (input slots permuted, operands gathered in slot order) and
+    # moved a <= 4-row second output tile to v_mfma_f32_4x4x1_16b_f32 (k rows summed by lane swaps): every combination of
+    # live MFMAs / live rows against the NumPy oracle, one-tile and two-tile form, which must also agree with each other bit for bit.
+    monkeypatch.setenv("BBMPC_MLP_Q4", "0")
+    monkeypatch.setenv("BBMPC_MLP_PAIR", pair)
+    N, A, H = 70, 2, 6
+    eng, ev, lo, hi = _problem(L, dims, ["tanh", "tanh", None], S, U, reward, True, A=A, H=H)
+    rng = np.random.default_rng(sum(dims))
+    states = (O.cheetah_start_states(A, S) if reward == "cheetah" else rng.normal(0, 0.3, (A, S)).astype(F))
+    seq = rng.uniform(-1, 1, (N, A, H, U)).astype(F)
+    eng.set_profiling(True)
+    got = eng.evaluate(states, seq)
+    assert eng.get_profile()[2] == "k_rollout_mlp_pair"
+    want = ev(states, seq)
+    assert np.all(np.isfinite(want))
+    if reward == "cheetah":
+        assert_cheetah_rewards(got, want, 1e-3, 1e-3 * H)
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3 * H)
+    monkeypatch.setenv("BBMPC_MLP_PAIR", "1" if pair == "0" else "0")
+    other, _, _, _ = _problem(L, dims, ["tanh", "tanh", None], S, U, reward, True, A=A, H=H)
+    np.testing.assert_array_equal(other.evaluate(states, seq), got)
+
+
+def test_profile_instantiation_names_the_template_that_ran(L):
+    # bbmpc_profile_instantiation: what bench.py keys the committed PMC counters by (the strict-math and the default
+    # instantiation of the persistent kernel share a plain name)
+    from blackbox_mpc_amd.engine import Engine
+    mk = lambda **kw: Engine(L.OPT_CEM, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=1, planning_horizon=30,
+                             population_size=500, max_iterations=5, num_elite=50, **kw)
+    st = O.pendulum_start_states(1)
+    fast, strict = mk(), mk(quirks=L.STRICT_MATH)
+    for e in (fast, strict):
+        e.optimize(st)
+        e.optimize(st)
+        assert e.get_profile()[2] == "k_fused_pendulum"
+        assert e.device == 0
+    a, b = fast.profile_instantiation(), strict.profile_instantiation()
+    assert a.startswith("k_fused_pendulum<2, true, true, ") and b.startswith("k_fused_pendulum<2, true, false, "), (a, b)
+    # a kernel with one instantiation per handle reports its plain name
+    eng, ev, lo, hi = _problem(L, *CHEETAH, True, A=1, H=5)
+    eng.evaluate(O.cheetah_start_states(1, 20), np.zeros((8, 1, 5, 6), F))
+    assert eng.profile_instantiation() == eng.get_profile()[2]
