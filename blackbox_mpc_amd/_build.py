@@ -74,32 +74,38 @@ _TOOLCHAIN = None
 
 
 def _toolchain():
-    """`hipcc --version` (a library linked by another ROCm must not be taken for current)."""
+    """`hipcc --version` (a library linked by another ROCm must not be taken for current); None where there is no hipcc --
+    a box that cannot build can only take the library it was shipped."""
     global _TOOLCHAIN
     if _TOOLCHAIN is None:
         try:
             out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout
             # the version lines only (install paths may differ between boxes of one image)
-            _TOOLCHAIN = "\n".join(ln.strip() for ln in out.splitlines() if "version" in ln.lower())
+            _TOOLCHAIN = "\n".join(ln.strip() for ln in out.splitlines() if "version" in ln.lower()) or "unknown"
         except Exception:                                  # noqa: BLE001
-            _TOOLCHAIN = "unknown"
-    return _TOOLCHAIN
+            _TOOLCHAIN = ""
+    return _TOOLCHAIN or None
 
 
-def _lib_fingerprint(with_toolchain=True):
-    """Every translation unit's fingerprint, the link line, this file and (where hipcc exists) the toolchain's version."""
+def _lib_fingerprint():
+    """(sources, toolchain): every translation unit's fingerprint + the link line + this file, and the toolchain's version."""
     import hashlib
     h = hashlib.sha256("".join(_fingerprint(s) for s in SOURCES).encode())
     h.update(" ".join(LINK_FLAGS).encode())
     h.update(open(os.path.abspath(__file__), "rb").read())
-    return h.hexdigest() + ("|" + hashlib.sha256(_toolchain().encode()).hexdigest()[:16] if with_toolchain else "")
+    tc = _toolchain()
+    return h.hexdigest(), (hashlib.sha256(tc.encode()).hexdigest()[:16] if tc else None)
 
 
 def needs_build():
     """False when libbbmpc.so was linked from exactly the sources in the tree, by this link line and toolchain (on the GPU
     box: the .so and its stamp arrive with the snapshot, the object cache does not -- nothing is compiled there; the image,
-    hence the toolchain, is the same)."""
-    return not (os.path.exists(LIB) and os.path.exists(LIB_STAMP) and open(LIB_STAMP).read().strip() == _lib_fingerprint())
+    hence the toolchain, is the same).  Without a hipcc on the box only the sources are compared."""
+    if not (os.path.exists(LIB) and os.path.exists(LIB_STAMP)):
+        return True
+    stamp = open(LIB_STAMP).read().strip().split("|")
+    src, tc = _lib_fingerprint()
+    return stamp[0] != src or (tc is not None and len(stamp) > 1 and stamp[1] != tc)
 
 
 EMBED = os.path.join(CSRC, "_embed.inc")
@@ -165,7 +171,8 @@ def build(force=False, verbose=False):
         raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, LIB)
     with open(LIB_STAMP, "w") as f:
-        f.write(_lib_fingerprint())
+        src_fp, tc_fp = _lib_fingerprint()
+        f.write(src_fp + "|" + (tc_fp or ""))
     return LIB
 
 
