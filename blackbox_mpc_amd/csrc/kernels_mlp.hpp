@@ -1157,6 +1157,8 @@ __global__ __launch_bounds__(mlp_pair_waves(HT, NTILES) * 64) void k_rollout_mlp
             // epilogue threads are tid < 16 (S + U): waves 0 .. EW-1 (the others have nothing to reduce)
             if (split_i1) {
                 if (wid >= EWS) stage_A1(0);                          // A_X(t), two feature tiles per wave
+                // (the reducing waves at priority 2 / 3 for this interval -- their epilogue is one dependent chain next to the other
+                // waves' layer-0 MFMAs --: 397.7 us against 395.8, not kept)
                 if (t > 0 && epi_wave) epi_finish(1, t - 1, epi_reduce(1));       // C_Y(t-1)
             } else if (!grp) {
                 stage_A(0);                                           // A_X(t)
