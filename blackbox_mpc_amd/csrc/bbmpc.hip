@@ -83,6 +83,19 @@ static void init_tnq_table() {
     done.insert(dev);                                       // only after the upload succeeded
 }
 
+// "lo-hi" in the environment variable `name` -> a stream whose workgroups only go to CUs lo .. hi (hipExtStreamCreateWithCUMask,
+// bit i of the mask = CU i), or null when the variable is not set
+hipStream_t masked_stream_from_env(const char* name, int cu_count) {
+    const char* v = getenv(name);
+    int lo = 0, hi = 0;
+    if (!v || sscanf(v, "%d-%d", &lo, &hi) != 2 || lo < 0 || hi < lo || hi >= cu_count) return nullptr;
+    std::vector<uint32_t> mask((size_t)(cu_count + 31) / 32, 0u);
+    for (int c = lo; c <= hi; ++c) mask[(size_t)c >> 5] |= 1u << (c & 31);
+    hipStream_t st = nullptr;
+    HIP_CHECK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    return st;
+}
+
 Engine::Engine(const bbmpc_config& c) : cfg(c) {
     REQUIRE(c.abi_version == BBMPC_ABI_VERSION, BBMPC_E_INVALID, "bbmpc_config.abi_version mismatch");
     stop_foreign_residents(nullptr);     // creation allocates and copies: nothing should wait behind a lingering kernel
@@ -159,7 +172,9 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         // from PyTorch's and the caller's normal-priority streams (the handles among themselves: stop_foreign_residents)
         int least = 0, greatest = 0;
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_CHECK(hipStreamCreateWithPriority(&own_stream, hipStreamNonBlocking, greatest));
+        // experiment switch (profiles/r5_cfg5cma_overlap.md): BBMPC_STREAM_CUS=lo-hi confines the handle's stream to those CUs
+        if (!(own_stream = masked_stream_from_env("BBMPC_STREAM_CUS", cu_count)))
+            HIP_CHECK(hipStreamCreateWithPriority(&own_stream, hipStreamNonBlocking, greatest));
     }
     stream = own_stream;
     init_tnq_table();
@@ -257,6 +272,11 @@ Engine::~Engine() {
     if (lazy_sync && stream) (void)hipStreamSynchronize(stream);
     if (own_stream) (void)hipStreamSynchronize(own_stream);
     rc.destroy();
+    if (eigh_side) {
+        (void)hipStreamSynchronize(eigh_side);
+        (void)hipStreamDestroy(eigh_side);
+        for (int i = 0; i < 2; ++i) if (eigh_ev[i]) (void)hipEventDestroy(eigh_ev[i]);
+    }
     if (pf_stream) {
         (void)hipStreamSynchronize(pf_stream);
         (void)hipStreamDestroy(pf_stream);

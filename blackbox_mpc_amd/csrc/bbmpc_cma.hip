@@ -112,6 +112,21 @@ void Engine::cma_eigh_launch(const CmaArgs& cq) {
     const size_t lds2 = std::max(sizeof(EighSolveLds), (size_t)(32 * (EIGH_LD + 1) + 32 * 33) * sizeof(float));
     ensure_max_lds((const void*)k_eigh_tridiag, (int)lds1);
     ensure_max_lds((const void*)k_eigh_tri_solve, (int)lds2);
+    if (eigh_side_state < 0) {
+        eigh_side = masked_stream_from_env("BBMPC_EIGH_SIDE_CUS", cu_count);
+        eigh_side_state = eigh_side ? 1 : 0;
+        if (eigh_side)
+            for (int i = 0; i < 2; ++i) HIP_CHECK(hipEventCreateWithFlags(&eigh_ev[i], hipEventDisableTiming));
+    }
+    if (eigh_side_state == 1) {
+        // experiment (profiles/r5_cfg5cma_overlap.md): the one-workgroup-per-instance phase leaves the launch stream to the
+        // handles that share the GPU; everything after it waits for it
+        HIP_CHECK(hipEventRecord(eigh_ev[0], stream));
+        HIP_CHECK(hipStreamWaitEvent(eigh_side, eigh_ev[0], 0));
+        hipLaunchKernelGGL(k_eigh_tridiag, dim3(G), dim3(EIGH_TRI_THREADS), lds1, eigh_side, q);
+        HIP_CHECK(hipEventRecord(eigh_ev[1], eigh_side));
+        HIP_CHECK(hipStreamWaitEvent(stream, eigh_ev[1], 0));
+    } else
     hipLaunchKernelGGL(k_eigh_tridiag, dim3(G), dim3(EIGH_TRI_THREADS), lds1, stream, q);
     hipLaunchKernelGGL(k_eigh_tri_solve, dim3(EIGH_SLOT_WGS + EIGH_TF_WGS, G), dim3(EIGH_SOLVE_THREADS), lds2, stream, q);
     const dim3 gg(EIGH_LD / 64, EIGH_LD / 16, G);

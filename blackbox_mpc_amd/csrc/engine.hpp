@@ -75,6 +75,8 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
 };
 
+hipStream_t masked_stream_from_env(const char* name, int cu_count);
+
 struct Engine {
     bbmpc_config cfg;
     int N, A, H, U, S, HU, Nst, iters, k;
@@ -166,6 +168,10 @@ struct Engine {
     bool cma_use_eigh_small() const { return sw.cma_eigh && cma_n >= 2 && cma_n <= ES_N && !sw.cma_svd_v1 && !sw.cma_svd_rounds && !sw.cma_svd_general && !sw.cma_svd_gram; }
     bool cma_use_eigh() const { return sw.cma_eigh && cma_n > 128 && cma_n <= EIGH_MAX_N && (cma_n & 3) == 0 && !sw.cma_svd_v1 && !sw.cma_svd_rounds && !sw.cma_svd_general && !sw.cma_svd_gram; }
     void cma_eigh_launch(const CmaArgs& q);
+    // experiment switch BBMPC_EIGH_SIDE_CUS=lo-hi: the tridiagonalisation on a side stream confined to those CUs (event hand-offs)
+    hipStream_t eigh_side = nullptr;
+    hipEvent_t eigh_ev[2] = {nullptr, nullptr};
+    int eigh_side_state = -1;         // -1 undecided, 0 off, 1 on
     // evaluate() scratch (grown on demand)
     DevBuf<float> d_eval_seq, d_eval_rew, d_step_a, d_step_b, d_step_c, d_step_d;
     // injected noise (internal layout), keyed by BBMPC_NOISE_*

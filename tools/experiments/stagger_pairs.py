@@ -20,6 +20,17 @@ def loop(ws, steps, delay_s):
         w.fence()
     return (time.perf_counter() - t0 - (delay_s if len(ws) > 1 else 0.0)) / steps * 1e3
 
+def masked(on):
+    """Round 5: the handles' launch streams on CUs 0 .. 247, the tridiagonalisations on side streams confined to CUs 248 .. 255
+    (BBMPC_STREAM_CUS / BBMPC_EIGH_SIDE_CUS, read when a handle is created / when its first decomposition is launched)."""
+    split = int(os.environ.get("STAGGER_SPLIT", "248"))
+    for k, v in (("BBMPC_STREAM_CUS", "0-%d" % (split - 1)), ("BBMPC_EIGH_SIDE_CUS", "%d-255" % split)):
+        if on:
+            os.environ[k] = v
+        else:
+            os.environ.pop(k, None)
+
+
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     delays = [float(x) for x in sys.argv[2:]] or [0.0, 0.3, 0.55, 0.8]
@@ -38,16 +49,33 @@ def main():
         half.close()
     if only not in ("", "pair"):
         return
-    pair = [bench.Workload(name, r, 2, 0, dev, False, "nccl", "none", agents=2) for r in range(2)]
-    loop(pair, 3, 0.0)
-    for d in delays:
-        print("two handles x 2 agents, second started %.2f ms late: %.4f ms per control step" % (d, loop(pair, steps, d * 1e-3)))
-    if only == "pair":
-        return
-    quad = [bench.Workload(name, r, 4, 0, dev, False, "nccl", "none", agents=1) for r in range(4)]
-    loop(quad, 3, 0.0)
-    for d in delays:
-        print("four handles x 1 agent, each started %.2f ms after the previous: %.4f ms per control step" % (d, loop(quad, steps, d * 1e-3)))
+    for mask in ((True,) if os.environ.get("STAGGER_MASKED_ONLY") else (False, True)):
+        masked(mask)
+        tag = ("CU-masked streams (launch 0-%d | tridiagonalisation %d-255)" % (int(os.environ.get("STAGGER_SPLIT", "248")) - 1, int(os.environ.get("STAGGER_SPLIT", "248")))) if mask else "plain streams"
+        pair = [bench.Workload(name, r, 2, 0, dev, False, "nccl", "none", agents=2) for r in range(2)]
+        loop(pair, 3, 0.0)
+        for d in delays:
+            print("two handles x 2 agents, %s, second started %.2f ms late: %.4f ms per control step" % (tag, d, loop(pair, steps, d * 1e-3)))
+        for w in pair:
+            w.close()
+        del pair
+        if only == "pair":
+            continue
+        quad = [bench.Workload(name, r, 4, 0, dev, False, "nccl", "none", agents=1) for r in range(4)]
+        loop(quad, 3, 0.0)
+        for d in delays:
+            print("four handles x 1 agent, %s, each started %.2f ms after the previous: %.4f ms per control step" % (tag, d, loop(quad, steps, d * 1e-3)))
+        for w in quad:
+            w.close()
+        del quad
+    masked(False)
+    # the side stream alone (one handle, all four agents in lock-step): what the two event hand-offs per decomposition cost
+    os.environ["BBMPC_EIGH_SIDE_CUS"] = "248-255"
+    one = bench.Workload(name, 0, 1, 0, dev, False, "nccl", "none")
+    loop([one], 3, 0.0)
+    print("one handle, 4 agents, tridiagonalisation on its masked side stream: %.4f ms per control step" % loop([one], steps, 0.0))
+    one.close()
+    masked(False)
 
 if __name__ == "__main__":
     main()
