@@ -777,6 +777,12 @@ def main():
             if not args.no_cpu_baseline:
                 sec["cpu_baseline"] = cpu_baseline(CONFIGS[SECONDARY], budget_s=6.0)
             out["secondary"] = sec
+            # ---- the one learned-model configuration the reference itself pins (tutorials/mujoco/tutorial_two.py:23-33,52-53):
+            # MLP 26-500-500-500-20, RandomSearch, population 4048, horizon 15 -- the generic MFMA rollout kernel
+            tut = run_block("cfg_tut2", max(30, min(100, args.steps)), 10, launch_per_call=False)
+            if not args.no_cpu_baseline:
+                tut["cpu_baseline"] = cpu_baseline(CONFIGS["cfg_tut2"], budget_s=4.0)
+            out["tutorial_two"] = tut
         # ---- BASELINE config 3 as it is stated: 64 agents IN TOTAL (strong scaling: 64 / N per GPU), Pendulum PI2
         # N=1000 H=30.  One GPU takes all 64 in about the time it takes 8 (the persistent kernel is one workgroup per
         # agent on a 256-CU part), so this curve is flat by construction -- it is reported so that nobody has to guess.
