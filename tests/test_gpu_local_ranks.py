@@ -87,7 +87,7 @@ def test_agent_shards_gather_records_on_two_ranks(L, opt_name):
         e.comm_destroy()
 
 
-@pytest.mark.parametrize("opt_name", ["PI2", "CEM", "RandomSearch", "PSO", "SPSA"])
+@pytest.mark.parametrize("opt_name", ["PI2", "CEM", "RandomSearch", "PSO", "SPSA", "CMA-ES"])
 def test_population_shards_on_two_ranks_match_the_one_handle_loopback(L, monkeypatch, opt_name):
     # Two handles = two ranks, each rolling out half of ONE agent's population, exchanging partials every iteration on their launch
     # streams.  The single-handle loopback hook (BBMPC_POPSHARD_LOOPBACK=2: one handle plays both shards in turn and merges in rank
@@ -96,7 +96,8 @@ def test_population_shards_on_two_ranks_match_the_one_handle_loopback(L, monkeyp
     from blackbox_mpc_amd import parallel as P
     from blackbox_mpc_amd.engine import Engine
     from blackbox_mpc_amd.utils import synthetic as SY
-    opt = {"PI2": L.OPT_PI2, "CEM": L.OPT_CEM, "RandomSearch": L.OPT_RANDOM_SEARCH, "PSO": L.OPT_PSO, "SPSA": L.OPT_SPSA}[opt_name]
+    opt = {"PI2": L.OPT_PI2, "CEM": L.OPT_CEM, "RandomSearch": L.OPT_RANDOM_SEARCH, "PSO": L.OPT_PSO, "SPSA": L.OPT_SPSA,
+           "CMA-ES": L.OPT_CMAES}[opt_name]
     S, U, H, N, R = 20, 6, 30, 1000, 2
     ws, bs = SY.make_mlp_params()
     stats = SY.cheetah_stats(S, U)
@@ -125,7 +126,7 @@ def test_population_shards_on_two_ranks_match_the_one_handle_loopback(L, monkeyp
         res = _in_threads([lambda e=e: e.optimize(s_rk, t) for e in ranks])
         for a3, n3, _ in res:                                   # every rank ends the control step with the same action
             assert np.array_equal(a3, a2) and np.array_equal(n3, n2), (opt_name, t)
-        tol = 0.0 if opt_name in ("RandomSearch", "PSO") else 2e-5      # argmax-only optimizers: the unsharded bits
+        tol = 0.0 if opt_name in ("RandomSearch", "PSO", "CMA-ES") else 2e-5      # argmax / sorted-elite exchanges: the unsharded bits
         assert float(np.abs(a1 - a2).max()) <= tol and float(np.abs(n1 - n2).max()) <= tol, (opt_name, t)
         s_one, s_loop, s_rk = n1, n2, res[0][1]
     for e in ranks:
