@@ -94,6 +94,7 @@ struct LocalGroup {
     static constexpr int kDepth = 4, kMaxRanks = 16;
     static constexpr size_t kMaxBytes = 1 << 20;          // per rank and operation
     int nranks = 0, device = 0, refs = 0;
+    uint32_t joined = 0;                                  // bit r: rank r has been taken
     char* stage = nullptr;                                // [kDepth][nranks * kMaxBytes]
     hipEvent_t arrive[kMaxRanks][kDepth] = {};
     hipEvent_t done[kMaxRanks][kDepth] = {};
@@ -115,6 +116,16 @@ struct LocalRegistry {
     static LocalRegistry& get() { static LocalRegistry r; return r; }
 };
 
+inline void local_group_free(LocalGroup* g) {
+    (void)hipFree(g->stage);
+    for (int r = 0; r < g->nranks; ++r)
+        for (int d = 0; d < LocalGroup::kDepth; ++d) {
+            if (g->arrive[r][d]) (void)hipEventDestroy(g->arrive[r][d]);
+            if (g->done[r][d]) (void)hipEventDestroy(g->done[r][d]);
+        }
+    delete g;
+}
+
 inline int local_comm_join(uint64_t key, int nranks, int rank, int device, Rccl::Comm* out) {
     if (nranks < 1 || nranks > LocalGroup::kMaxRanks || rank < 0 || rank >= nranks) return 4;     // ncclInvalidArgument
     LocalRegistry& reg = LocalRegistry::get();
@@ -128,9 +139,13 @@ inline int local_comm_join(uint64_t key, int nranks, int rank, int device, Rccl:
             for (int d = 0; ok && d < LocalGroup::kDepth; ++d)
                 ok = hipEventCreateWithFlags(&g->arrive[r][d], hipEventDisableTiming) == hipSuccess &&
                      hipEventCreateWithFlags(&g->done[r][d], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { (void)hipGetLastError(); LocalGroup* dead = g; reg.groups.erase(key); delete dead; return 1; }   // ncclUnhandledCudaError
+        if (!ok) { (void)hipGetLastError(); LocalGroup* dead = g; reg.groups.erase(key); local_group_free(dead); return 1; }   // ncclUnhandledCudaError
     }
-    if (g->nranks != nranks || g->device != device) return 4;
+    if (g->nranks != nranks || g->device != device || (g->joined >> rank) & 1u) {      // (a second handle claiming a taken rank)
+        if (g->refs == 0) { LocalGroup* dead = g; reg.groups.erase(key); local_group_free(dead); }
+        return 4;
+    }
+    g->joined |= 1u << rank;
     LocalRank* me = new LocalRank();
     me->grp = g; me->rank = rank; me->key = key;
     ++g->refs;
@@ -190,11 +205,8 @@ inline int comm_destroy(Rccl::Comm comm) {
         g->cv.notify_all();
     }
     if (--g->refs == 0) {
-        (void)hipFree(g->stage);
-        for (int r = 0; r < g->nranks; ++r)
-            for (int d = 0; d < LocalGroup::kDepth; ++d) { (void)hipEventDestroy(g->arrive[r][d]); (void)hipEventDestroy(g->done[r][d]); }
         reg.groups.erase(me->key);
-        delete g;
+        local_group_free(g);
     }
     delete me;
     return 0;

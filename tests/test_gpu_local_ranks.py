@@ -145,6 +145,8 @@ def test_local_group_shape_is_checked(L):
         b.comm_init_local(12345, 2, 2)                          # rank out of range
     with pytest.raises(L.BBMPCError):
         a.comm_init_local(12345, 2, 1)                          # the handle already has a communicator
+    with pytest.raises(L.BBMPCError):
+        b.comm_init_local(12345, 2, 0)                          # rank 0 is taken
     b.comm_init_local(12345, 2, 1)
     assert a.comm_info()[:2] == (2, 0) and b.comm_info()[:2] == (2, 1)
     a.comm_destroy()
