@@ -811,6 +811,15 @@ def main():
 
 
 def cpu_baseline(c, budget_s=8.0):
+    """`_cpu_baseline_impl` behind a net: the CPU leg runs after every GPU measurement of the line, so a problem in it (a torch-CPU
+    fault, the checker's build) is recorded in its block instead of costing the line."""
+    try:
+        return _cpu_baseline_impl(c, budget_s)
+    except Exception as ex:                                # noqa: BLE001
+        return {"error": "%s: %s" % (type(ex).__name__, ex), "unit": "control-steps/s", "kind": "port", "value": None}
+
+
+def _cpu_baseline_impl(c, budget_s=8.0):
     """The CPU restatements of the same hot path timed on this host, closed loop, noise drawn inside the timed region as
     the reference's graph does.  No TF-CPU number can exist (TensorFlow absent, the reference publishes none), so:
 
@@ -877,7 +886,8 @@ def cpu_baseline(c, budget_s=8.0):
         if mlp:
             # ---- torch-CPU op by op on every host thread (a short ladder: a small sgemm does not always want them all)
             probe = {}
-            for t in sorted({min(host_threads, x) for x in (8, 16, 32)}):       # (every thread of a 256-thread host: 0.01 steps/s)
+            # (every thread of a 256-thread host: 0.01 steps/s; on a small host the ladder is its halves and quarters)
+            for t in sorted({max(1, min(host_threads, x)) for x in (8, 16, 32, host_threads // 2, host_threads // 4) if x <= 32}):
                 torch.set_num_threads(t)
                 run_torch(0.2, 1)
                 probe[t] = run_torch(0.6, 50)[1]

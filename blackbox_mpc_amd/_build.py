@@ -34,6 +34,19 @@ GUARDED = {"kernels_cma.hpp": ("bbmpc_cma.hip", "#ifdef BBMPC_TU_CMA"),
            "kernels_fused_cma.hpp": ("bbmpc_cma.hip", "#ifdef BBMPC_TU_CMA")}
 
 
+def _after_matching_endif(rest):
+    """The text behind the #endif that closes a guard whose #ifdef line has just been consumed: conditionals are counted,
+    so an include guard around the whole header (or any #if inside the guarded part) does not move the cut."""
+    import re
+    depth, pos = 1, 0
+    for m in re.finditer(r"^[ \t]*#[ \t]*(if|ifdef|ifndef|endif)\b[^\n]*$", rest, flags=re.M):
+        depth += -1 if m.group(1) == "endif" else 1
+        pos = m.end()
+        if depth == 0:
+            return rest[pos:]
+    return ""
+
+
 def _fingerprint(src):
     """What translation unit `src` is compiled from: its own text, every header (for a guarded header only the part the
     unit sees), the public header, the flags."""
@@ -50,8 +63,7 @@ def _fingerprint(src):
             # the other units see the text in front of the guard AND whatever follows its #endif (by convention only the
             # namespace's closing brace): both are hashed, so code placed behind the guard still rebuilds everybody
             head, rest = text.split(GUARDED[f][1], 1)
-            tail = rest.rsplit("#endif", 1)[1] if "#endif" in rest else ""
-            text = head + "\n/*guarded*/\n" + tail
+            text = head + "\n/*guarded*/\n" + _after_matching_endif(rest)
         h.update(f.encode())
         h.update(text.encode())
     return h.hexdigest()
@@ -88,11 +100,12 @@ def _toolchain():
 
 
 def _lib_fingerprint():
-    """(sources, toolchain): every translation unit's fingerprint + the link line + this file, and the toolchain's version."""
+    """(sources, toolchain): every translation unit's fingerprint + the link line + the build lists of this file, and the toolchain's version."""
     import hashlib
     h = hashlib.sha256("".join(_fingerprint(s) for s in SOURCES).encode())
-    h.update(" ".join(LINK_FLAGS).encode())
-    h.update(open(os.path.abspath(__file__), "rb").read())
+    # what of this file decides the output (an edit to the build logic alone must not relink -- on the GPU box that is a
+    # full compile, the object cache does not travel)
+    h.update(repr((SOURCES, FLAGS, LINK_FLAGS, sorted(GUARDED.items()), EMBEDDED_HEADERS)).encode())
     tc = _toolchain()
     return h.hexdigest(), (hashlib.sha256(tc.encode()).hexdigest()[:16] if tc else None)
 

@@ -16,6 +16,7 @@
 
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -141,7 +142,9 @@ inline int local_comm_join(uint64_t key, int nranks, int rank, int device, Rccl:
                      hipEventCreateWithFlags(&g->done[r][d], hipEventDisableTiming) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); LocalGroup* dead = g; reg.groups.erase(key); local_group_free(dead); return 1; }   // ncclUnhandledCudaError
     }
-    if (g->nranks != nranks || g->device != device || (g->joined >> rank) & 1u) {      // (a second handle claiming a taken rank)
+    bool group_broken;
+    { std::lock_guard<std::mutex> gl(g->mu); group_broken = g->broken; }
+    if (g->nranks != nranks || g->device != device || (g->joined >> rank) & 1u || group_broken) {   // (a second handle claiming a taken rank; a group a rank has already left)
         if (g->refs == 0) { LocalGroup* dead = g; reg.groups.erase(key); local_group_free(dead); }
         return 4;
     }
@@ -171,13 +174,29 @@ inline bool rendezvous(LocalGroup* g, int seconds) {
         g->cv.notify_all();
         return false;
     }
-    return !g->broken;
+    return g->generation != gen;       // the generation advanced: this collective is complete even if a peer has left since
+}
+// a rank that cannot take part marks the group: its peers fail at once instead of waiting out the rendezvous
+inline int give_up(LocalGroup* g, int rc) {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->broken = true;
+    g->cv.notify_all();
+    return rc;
+}
+inline int rendezvous_seconds() {
+    static const int s = [] {
+        const char* e = getenv("BBMPC_LOCAL_COMM_TIMEOUT_S");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 60;
+    }();
+    return s;
 }
 inline int all_gather(const void* send, void* recv, size_t count, int dtype, Rccl::Comm comm, hipStream_t st) {
     LocalRank* me = static_cast<LocalRank*>(comm);
     LocalGroup* g = me->grp;
     const size_t bytes = count * (dtype == Rccl::kFloat32 ? 4 : 1);
-    if (bytes == 0 || bytes > LocalGroup::kMaxBytes) return 4;
+    if (bytes == 0) return give_up(g, 4);
+    if (bytes > LocalGroup::kMaxBytes) return give_up(g, 6);
     const uint32_t q = me->op++;
     const int d = (int)(q % LocalGroup::kDepth);
     char* slot = g->stage + (size_t)d * g->nranks * LocalGroup::kMaxBytes;
@@ -186,8 +205,8 @@ inline int all_gather(const void* send, void* recv, size_t count, int dtype, Rcc
         for (int p = 0; p < g->nranks && e == hipSuccess; ++p) e = hipStreamWaitEvent(st, g->done[p][d], 0);
     if (e == hipSuccess) e = hipMemcpyAsync(slot + (size_t)me->rank * bytes, send, bytes, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipEventRecord(g->arrive[me->rank][d], st);
-    if (e != hipSuccess) return 1;
-    if (!rendezvous(g, 60)) return 5;
+    if (e != hipSuccess) return give_up(g, 1);
+    if (!rendezvous(g, rendezvous_seconds())) return 5;
     for (int p = 0; p < g->nranks && e == hipSuccess; ++p)
         if (p != me->rank) e = hipStreamWaitEvent(st, g->arrive[p][d], 0);
     if (e == hipSuccess) e = hipMemcpyAsync(recv, slot, (size_t)g->nranks * bytes, hipMemcpyDeviceToDevice, st);
@@ -214,8 +233,10 @@ inline int comm_destroy(Rccl::Comm comm) {
 inline int comm_count(Rccl::Comm comm, int* n) { *n = static_cast<LocalRank*>(comm)->grp->nranks; return 0; }
 inline int comm_user_rank(Rccl::Comm comm, int* r) { *r = static_cast<LocalRank*>(comm)->rank; return 0; }
 inline const char* error_string(int rc) {
-    return rc == 4 ? "in-process communicator: invalid argument (count, rank or group shape)"
-         : rc == 5 ? "in-process communicator: the other ranks did not arrive within 60 s (every rank needs its own host thread), or one of them has left"
+    return rc == 4 ? "in-process communicator: invalid argument (count, rank, group shape, or a group that a rank has already left)"
+         : rc == 5 ? "in-process communicator: the other ranks did not arrive within the rendezvous time (60 s, BBMPC_LOCAL_COMM_TIMEOUT_S; "
+                     "every rank needs its own host thread), or one of them has failed or left"
+         : rc == 6 ? "in-process communicator: more than 1 MiB per rank in one all-gather (the staging ring's slot size; RCCL has no such limit)"
                    : "in-process communicator: HIP error";
 }
 }  // namespace local_api

@@ -65,9 +65,34 @@ def test_config3_pi2_full_population_8_agents(L):
         inb = np.abs(noise[it][..., 0] * np.float32(1.0)).max(axis=2) < 0.5      # sigma = 1: |xi| small => never clipped at it=0
         if it == 0:
             np.testing.assert_allclose(got[inb], pen_free[inb], rtol=2e-4, atol=2e-3)
+    _pi2_lockstep_then_free(L, eng, co, states, noise, act, N, A, H, iters, label="config 3 share, 8 agents")
+
+
+def _pi2_lockstep_then_free(L, eng, co, states, noise, act, N, A, H, iters, pi2=None, label=""):
+    """PI2 on the pendulum at full size, both ways.  Lock-step (pi2.py:78-93): the NumPy restatement runs with the C library
+    doing the rollouts, every iteration's rewards are held to the rollout tolerance and the device's values carried on, so
+    the exp-weighted mean, the chosen action and the shifted warm start are compared on identical inputs at 2e-5.
+    Free-running: the C oracle's own control step, nothing carried over, at the tolerance the reward tolerance implies
+    (lambda = 1: a reward error e moves a weight by ~e); the observed maximum is printed."""
+    hip_r = [eng.get_trace(it, L.TRACE_REWARDS) for it in range(iters)]
+    if pi2 is None:
+        pi2 = O.PI2(co.as_evaluator(), [-2.0], [2.0], horizon=H, max_iterations=iters, population=N, num_agents=A, lamda=1.0)
+
+    def lock(it, r_o):
+        np.testing.assert_allclose(hip_r[it], r_o, rtol=2e-4, atol=2e-3)
+        return hip_r[it]
+    act_o = pi2._optimize(states, {"trunc": noise}, rewards_override=lock)
+    for it in range(iters):
+        np.testing.assert_allclose(eng.get_trace(it, L.TRACE_SAMPLES), pi2.trace[it]["samples"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(eng.get_trace(it, L.TRACE_MEAN), pi2.trace[it]["mean"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(act, act_o, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(eng.get_state("prev_mean"), pi2.prev, rtol=0, atol=2e-5)
     a_c, n_c, r_c, tr = co.optimize("PI2", states, noise=noise, trace=True)
+    worst = max(float(np.abs(eng.get_trace(iters - 1, L.TRACE_MEAN) - tr["mean"]).max()), float(np.abs(act - a_c).max()))
+    print(f"[pi2 pendulum full size, {label}] lock-step held at 2e-5; free-running max |mean - oracle| = {worst:.3e}")
     np.testing.assert_allclose(eng.get_trace(iters - 1, L.TRACE_MEAN), tr["mean"], rtol=0, atol=5e-3)
     np.testing.assert_allclose(act, a_c, rtol=0, atol=5e-3)
+    return pi2, (a_c, n_c, r_c)
 
 
 def test_config3_pi2_all_64_agents_on_one_gpu(L):
@@ -80,12 +105,12 @@ def test_config3_pi2_all_64_agents_on_one_gpu(L):
     eng.set_trace(True)
     states = O.pendulum_start_states(A)
     co = OC.COracle("pendulum", "pendulum", [-2.0], [2.0], N, A, H, 3, iters=iters, lamda=1.0)
+    pi2 = None
     for step in range(2):                                  # the second control step starts from the shifted solution (pi2.py:92-93)
         act, nxt, rew = eng.optimize(states)
         noise = [eng.dump_noise(L.NOISE_TRUNC_NORMAL, step, it, (N, A, H, 1)) for it in range(iters)]
-        a_c, n_c, r_c, tr = co.optimize("PI2", states, noise=noise, trace=True)
-        np.testing.assert_allclose(eng.get_trace(iters - 1, L.TRACE_MEAN), tr["mean"], rtol=0, atol=5e-3)
-        np.testing.assert_allclose(act, a_c, rtol=0, atol=5e-3)
+        pi2, (a_c, n_c, r_c) = _pi2_lockstep_then_free(L, eng, co, states, noise, act, N, A, H, iters, pi2=pi2,
+                                                        label=f"config 3, 64 agents, control step {step}")
         np.testing.assert_allclose(nxt, n_c, rtol=1e-4, atol=2e-3)
         states = n_c
 
@@ -365,8 +390,7 @@ def test_large_population_beyond_one_lds_default(L, monkeypatch, opt_name):
     kind = L.NOISE_UNIFORM if opt_name == "RandomSearch" else L.NOISE_TRUNC_NORMAL
     noise = [eng.dump_noise(kind, 0, it, (N, A, H, 1)) for it in range(n_it)]
     if opt_name == "PI2":
-        a_c, _, _ = co.optimize("PI2", states, noise=noise)
-        np.testing.assert_allclose(act, a_c, rtol=0, atol=5e-3)
+        _pi2_lockstep_then_free(L, eng, co, states, noise, act, N, A, H, iters, label="N = 20000")
     with pytest.raises(L.BBMPCError):          # above 32768 a population is played as equal shards (test_gpu_popshard.py): 32771 is prime
         Engine(opt, L.DYN_PENDULUM, L.REW_PENDULUM, [-2.0], [2.0], dim_s=3, num_agents=1, planning_horizon=4,
                population_size=32771, max_iterations=1, num_elite=8)

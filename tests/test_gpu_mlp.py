@@ -10,7 +10,7 @@ exp / rcp units (v_exp_f32, v_rcp_f32: absolute error <= ~3e-7, csrc/kernels_mlp
 import numpy as np
 import pytest
 
-from tests.parity_util import assert_cheetah_rewards
+from tests.parity_util import assert_cheetah_rewards, cheetah_threshold_margin
 
 from oracle import oracle_np as O
 
@@ -92,7 +92,7 @@ def test_evaluator_matches_oracle(L, spec, N, A, H):
     want = ev(states, seq)
     assert np.all(np.isfinite(want))
     if reward == "cheetah":
-        assert_cheetah_rewards(got, want, 1e-3, 1e-3 * H)
+        assert_cheetah_rewards(got, want, 1e-3, 1e-3 * H, margin=lambda: cheetah_threshold_margin(ev, states, seq))
     else:
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3 * H)
 
@@ -133,7 +133,7 @@ def test_pipelined_tile_kernel_variants(L, monkeypatch, pair, dims, S, U, N, A, 
     got = eng.evaluate(states, seq)
     want = ev(states, seq)
     assert np.all(np.isfinite(want))
-    assert_cheetah_rewards(got, want, 1e-3, 1e-3 * H)
+    assert_cheetah_rewards(got, want, 1e-3, 1e-3 * H, margin=lambda: cheetah_threshold_margin(ev, states, seq))
 
 
 @pytest.mark.parametrize("q4", ["0", "1"])
@@ -158,7 +158,7 @@ def test_evaluator_properties_at_config5_size(L, monkeypatch, q4):
     np.testing.assert_array_equal(eng.evaluate(states, seq[perm]), full[perm])
     np.testing.assert_array_equal(eng.evaluate(states, seq[:100]), full[:100])
     sub = rng.choice(N, 48, replace=False)
-    assert_cheetah_rewards(full[sub], ev(states, seq[sub]), 1e-3, 1e-3 * H)
+    assert_cheetah_rewards(full[sub], ev(states, seq[sub]), 1e-3, 1e-3 * H, margin=lambda: cheetah_threshold_margin(ev, states, seq[sub]))
 
 
 @pytest.mark.parametrize("tiling", ["auto", "pair1", "pair2"])
@@ -356,7 +356,7 @@ def test_small_networks_run_the_wave_kernel_and_match(L, monkeypatch, spec, norm
     want = ev(states, seq)
     assert np.all(np.isfinite(want))
     if reward == "cheetah":
-        assert_cheetah_rewards(got, want, 1e-3, 1e-3 * H)
+        assert_cheetah_rewards(got, want, 1e-3, 1e-3 * H, margin=lambda: cheetah_threshold_margin(ev, states, seq))
     else:
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3 * H)
     monkeypatch.setenv("BBMPC_MLP_WAVE", "0")
@@ -453,7 +453,7 @@ def test_pipelined_tile_kernel_padding_paths(L, monkeypatch, pair, dims, S, U, r
     want = ev(states, seq)
     assert np.all(np.isfinite(want))
     if reward == "cheetah":
-        assert_cheetah_rewards(got, want, 1e-3, 1e-3 * H)
+        assert_cheetah_rewards(got, want, 1e-3, 1e-3 * H, margin=lambda: cheetah_threshold_margin(ev, states, seq))
     else:
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3 * H)
     monkeypatch.setenv("BBMPC_MLP_PAIR", "1" if pair == "0" else "0")
