@@ -72,8 +72,8 @@ def _pi2_lockstep_then_free(L, eng, co, states, noise, act, N, A, H, iters, pi2=
     """PI2 on the pendulum at full size, both ways.  Lock-step (pi2.py:78-93): the NumPy restatement runs with the C library
     doing the rollouts, every iteration's rewards are held to the rollout tolerance and the device's values carried on, so
     the exp-weighted mean, the chosen action and the shifted warm start are compared on identical inputs at 2e-5.
-    Free-running: the C oracle's own control step, nothing carried over, at the tolerance the reward tolerance implies
-    (lambda = 1: a reward error e moves a weight by ~e); the observed maximum is printed."""
+    Free-running: the C oracle's own control step, nothing carried over, at SURVEY 8c's chosen-action tolerance (4e-3: what the
+    reward tolerance implies at lambda = 1, where a reward error e moves a weight by ~e); the observed maximum is printed."""
     hip_r = [eng.get_trace(it, L.TRACE_REWARDS) for it in range(iters)]
     if pi2 is None:
         pi2 = O.PI2(co.as_evaluator(), [-2.0], [2.0], horizon=H, max_iterations=iters, population=N, num_agents=A, lamda=1.0)
@@ -90,8 +90,8 @@ def _pi2_lockstep_then_free(L, eng, co, states, noise, act, N, A, H, iters, pi2=
     a_c, n_c, r_c, tr = co.optimize("PI2", states, noise=noise, trace=True)
     worst = max(float(np.abs(eng.get_trace(iters - 1, L.TRACE_MEAN) - tr["mean"]).max()), float(np.abs(act - a_c).max()))
     print(f"[pi2 pendulum full size, {label}] lock-step held at 2e-5; free-running max |mean - oracle| = {worst:.3e}")
-    np.testing.assert_allclose(eng.get_trace(iters - 1, L.TRACE_MEAN), tr["mean"], rtol=0, atol=5e-3)
-    np.testing.assert_allclose(act, a_c, rtol=0, atol=5e-3)
+    np.testing.assert_allclose(eng.get_trace(iters - 1, L.TRACE_MEAN), tr["mean"], rtol=0, atol=4e-3)
+    np.testing.assert_allclose(act, a_c, rtol=0, atol=4e-3)
     return pi2, (a_c, n_c, r_c)
 
 

@@ -281,8 +281,8 @@ def test_pi2_injected_noise(L, N, A, H, iters, lam):
             np.testing.assert_allclose(hip_r[it], free.trace[it]["rewards"], rtol=R_RTOL, atol=R_ATOL)
             worst_free = max(worst_free, float(np.abs(eng.get_trace(it, L.TRACE_MEAN) - free.trace[it]["mean"]).max()))
         worst_free = max(worst_free, float(np.abs(act - act_f).max()), float(np.abs(eng.get_state("prev_mean") - free.prev).max()))
-        np.testing.assert_allclose(act, act_f, rtol=0, atol=5e-3 / lam)
-        np.testing.assert_allclose(eng.get_state("prev_mean"), free.prev, rtol=0, atol=5e-3 / lam)
+        np.testing.assert_allclose(act, act_f, rtol=0, atol=4e-3 / lam)
+        np.testing.assert_allclose(eng.get_state("prev_mean"), free.prev, rtol=0, atol=4e-3 / lam)
     print(f"[pi2 pendulum N={N} A={A} H={H} lambda={lam}] lock-step held at 2e-5; free-running max |mean - oracle| = {worst_free:.3e}")
 
 
