@@ -228,14 +228,17 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
         // register-resident-state form (two barriers per model step, kernels_mlp_q4r.hpp): dim_S == 20, cheetah reward or none
         if (q4 && !sw.mlp_generic && sw.mlp_q4r && S == 20 && U <= 8 && mlp.dims[3] == 20 &&
             (ra.reward_kind == REW_CHEETAH || ra.reward_kind == REW_NONE)) {
-            const size_t qlds = (size_t)mlp_q4r_lds_floats(50, 7, ra.H, U) * sizeof(float);
+            const bool q4s = sw.mlp_q4s != 0;      // four equal waves, the last layer from registers (kernels_mlp_q4s.hpp)
+            const size_t qlds = (size_t)(q4s ? mlp_q4s_lds_floats(50, 7, ra.H, U) : mlp_q4r_lds_floats(50, 7, ra.H, U)) * sizeof(float);
             const int qpairs = 4 * ((ra.H * U + 3) / 4);
             if (qlds <= 160 * 1024 && qpairs <= Q4R_MAX_ACTION_PAIRS) {
-                auto fn = (qpairs <= 256) ? k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1>
-                                          : k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>;
+                auto fn = q4s ? ((qpairs <= 256) ? k_rollout_mlp_q4s<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1>
+                                                 : k_rollout_mlp_q4s<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>)
+                              : ((qpairs <= 256) ? k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1>
+                                                 : k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>);
                 if (qlds > 64 * 1024) ensure_max_lds((const void*)fn, 160 * 1024);
                 dim3 qgrid((ra.n_pop + 3) / 4, A), qblock(256);
-                dominant_kernel = "k_rollout_mlp_q4r";
+                dominant_kernel = q4s ? "k_rollout_mlp_q4s" : "k_rollout_mlp_q4r";
                 q.state_copy = mlp_state_copy;
                 mlp_state_copy = nullptr;
                 prof_begin();

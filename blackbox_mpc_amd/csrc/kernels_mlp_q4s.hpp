@@ -1,0 +1,531 @@
+// Quad mode, last layer from registers ("q4s"): k_rollout_mlp_q4r with FOUR equal waves, two barriers per model step and
+// no activation of layer 1 ever leaving the registers.  Same fused path (reference files under blackbox_mpc/):
+//   SystemDynamicsHandler.process_input / process_output   dynamics_handlers/system_dynamics_handler.py:97-161
+//   DeterministicMLP.__call__                              dynamics_functions/deterministic_mlp.py:27-51
+//   reward_function                                        tutorials/mujoco/cost_func.py:5-22
+//   DeterministicTrajectoryEvaluator.__call__              trajectory_evaluators/deterministic.py:26-77
+//
+// What k_rollout_mlp_q4r paid for (profiles/r5_cfg4pi2.md: 0.31 of the fp32 matrix peak, pipe 0.43 busy): every state wave
+// computed the WHOLE 200 -> 20 layer (68 MFMAs where its share is 16) from a copy of h1 that had to cross LDS behind a
+// barrier, a helper wave held no state, and a third barrier covered the helper's late job.  Here:
+//  * layer 1 as before (jobs of 16 output features, K split over the MFMA's four 16-lane rows, reduce-scatter in
+//    registers), after which lane (row, quad g, particle p) holds tanh(h1) of feature 16*job + 4g + pr(row) -- which IS a
+//    B operand of v_mfma_f32_4x4x1_16b_f32: one k per block, the four particles in the block's four lanes.  The last layer
+//    takes it from there: per job four MFMAs for output features 0..15 (block g produces output quad g; round j multiplies
+//    the value of block g - j, fetched by a DPP row rotation, so that every block meets every k of its row) and one for
+//    features 16..19 (every block its own k): 17 MFMAs per wave instead of 68, no h1 in LDS, and the K split of the last
+//    layer is across the WAVES' own hidden features -- what crosses LDS behind the second barrier is 80 partial sums per
+//    wave instead of 800 activations;
+//  * every wave then adds the four partials and runs the epilogue (bias, de-normalisation, residual, normalisation,
+//    all-gather by lane swaps) redundantly, so all four waves hold the state and layer 0 is shared four ways: block b of
+//    wave w produces hidden quad 13w + b (26 MFMAs per wave instead of 36 on three);
+//  * the hidden features 192..199 (two quads nobody's three jobs cover) are one more chain on waves 0 and 1: block b takes
+//    k = b, b + 16, ... (13 MFMAs, one riding in each round of the three jobs), all-reduced over the 16 blocks.
+// Per wave and model step 26 + 169 + 17 = 212 MFMAs (q4r: 260 on the state waves), two barriers, 13 + 13 LDS reads behind
+// the first and 8 behind the second.
+// Requires dim_S == 20 (five state groups: four rotate inside a row, the fifth is replicated), the HalfCheetah reward or
+// none (a user function scores the recorded trajectory); everything else keeps k_rollout_mlp_q4.
+#pragma once
+#include "kernels_mlp_q4r.hpp"
+
+namespace bbmpc {
+
+// One k-group of three layer-1 jobs + one MFMA of the tail chain = 13 MFMAs in ONE asm statement (see mfma4_a_round3)
+__device__ __forceinline__ void mfma4_a_round3t(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& ct, const float* w0, const float* w1, const float* w2,
+                                                const f32x4& b, float wt, float bt) {
+    asm volatile(BBMPC_MFMA4 "%0, %4, %16, %0\n\t" BBMPC_MFMA4 "%1, %8, %16, %1\n\t" BBMPC_MFMA4 "%2, %12, %16, %2\n\t"
+                 BBMPC_MFMA4 "%0, %5, %17, %0\n\t" BBMPC_MFMA4 "%1, %9, %17, %1\n\t" BBMPC_MFMA4 "%2, %13, %17, %2\n\t"
+                 BBMPC_MFMA4 "%0, %6, %18, %0\n\t" BBMPC_MFMA4 "%1, %10, %18, %1\n\t" BBMPC_MFMA4 "%2, %14, %18, %2\n\t"
+                 BBMPC_MFMA4 "%0, %7, %19, %0\n\t" BBMPC_MFMA4 "%1, %11, %19, %1\n\t" BBMPC_MFMA4 "%2, %15, %19, %2\n\t"
+                 BBMPC_MFMA4 "%3, %20, %21, %3"
+                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(ct)
+                 : "a"(w0[0]), "a"(w0[1]), "a"(w0[2]), "a"(w0[3]), "a"(w1[0]), "a"(w1[1]), "a"(w1[2]), "a"(w1[3]),
+                   "a"(w2[0]), "a"(w2[1]), "a"(w2[2]), "a"(w2[3]), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "a"(wt), "v"(bt));
+}
+__device__ __forceinline__ void mfma4_a_round3t_first(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& ct, const float* w0, const float* w1, const float* w2,
+                                                      const f32x4& b, float wt, float bt) {
+    asm volatile(BBMPC_MFMA4 "%0, %4, %16, 0\n\t"  BBMPC_MFMA4 "%1, %8, %16, 0\n\t"  BBMPC_MFMA4 "%2, %12, %16, 0\n\t"
+                 BBMPC_MFMA4 "%0, %5, %17, %0\n\t" BBMPC_MFMA4 "%1, %9, %17, %1\n\t" BBMPC_MFMA4 "%2, %13, %17, %2\n\t"
+                 BBMPC_MFMA4 "%0, %6, %18, %0\n\t" BBMPC_MFMA4 "%1, %10, %18, %1\n\t" BBMPC_MFMA4 "%2, %14, %18, %2\n\t"
+                 BBMPC_MFMA4 "%0, %7, %19, %0\n\t" BBMPC_MFMA4 "%1, %11, %19, %1\n\t" BBMPC_MFMA4 "%2, %15, %19, %2\n\t"
+                 BBMPC_MFMA4 "%3, %20, %21, 0"
+                 : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(ct)
+                 : "a"(w0[0]), "a"(w0[1]), "a"(w0[2]), "a"(w0[3]), "a"(w1[0]), "a"(w1[1]), "a"(w1[2]), "a"(w1[3]),
+                   "a"(w2[0]), "a"(w2[1]), "a"(w2[2]), "a"(w2[3]), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "a"(wt), "v"(bt));
+}
+
+template <int HG, int K0G, int A0, int A1, int A2, int NE>
+__global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const RolloutArgs& p = q.r;
+    const MlpDesc& m = q.m;
+    constexpr int NT = 256, QP = 4, NW = 4;
+    constexpr int SG = 5, AG = K0G - SG;                 // state / action input groups (dim_S == 20)
+    constexpr int KA = (HG + 3) / 4;                     // k groups per 16-lane row when K is split over the rows
+    constexpr int HP = 64;                               // h0 is padded to 64 groups (zero): clamp-free operand addresses
+    constexpr int ZROW = HP - 1;                         // a zero group of the packed operands (bbmpc_set_mlp pads the k/4 axis to 64)
+    constexpr int NJ = HG / (4 * NW);                    // layer-1 jobs of 16 output features per wave (3: 12 jobs = 192 features)
+    constexpr int TQ = HG - 4 * NW * NJ;                 // hidden quads left over for the tail chains (2: waves 0 and 1)
+    constexpr int KT = (HG + 3) / 4;                     // tail chain: MFMAs (block (row, g) takes k = 4*(row + 4m) + g, m < KT)
+    constexpr int Q0W = (HG + NW - 1) / NW;              // layer 0: hidden quads per wave (13: blocks 0..12)
+    static_assert(HG < HP && KA * 4 <= HP && 3 + 4 * (KT - 1) < HP && K0G > SG, "padding / input groups");
+    static_assert(NJ == 3 && TQ >= 0 && TQ <= NW && KT == KA && Q0W <= 16 && AG == 2, "written for 200 hidden units, 20 + <= 8 inputs");
+    const int a = blockIdx.y, n0 = xcd_tile(blockIdx.x, gridDim.x, blockIdx.y) * QP;     // an XCD's workgroups: contiguous particles
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
+    const int S = p.S, U = p.U, H = p.H;
+    const bool normd = m.normalized != 0;
+    const int row = lane >> 4, blk = lane >> 2, fgq = blk & 3, pl = lane & 3;
+    const int pr = ((row & 1) << 1) | (row >> 1);        // element of a reduce-scattered float4 this row holds
+    // ---- LDS: h0[HP][4][4] | zx[4 waves][64 + 16] | acts[H][4][U] | pen[4U] | xa[H][AG][4][4] | zs[H][4] | rwd[H][4][4] | constants
+    float* h0 = smem;
+    float* zx = h0 + HP * 16;                             // the waves' partial sums of the last layer: [wave][lane] features 0..15, [wave][64 + row*4 + particle] features 16..19
+    float* acts = zx + NW * 80;
+    float* pens = acts + ((H * QP * U + 3) & ~3);
+    float* xa = pens + ((QP * U + 3) & ~3);
+    float* zs = xa + H * AG * 16;
+    float* rwd = zs + H * QP;                             // per step and particle: (progress difference, flag 5, flag 6, flag 7)
+    float* nmean = rwd + H * QP * 4;                      // [S+U] input mean, [S+U] 1/(std+1e-7), [S] target mean, [S] std+1e-7,
+    float* ninv = nmean + 32;                             // [S] last bias, [S] start state   (S = 20, S+U <= 28)
+    float* tmean = ninv + 32;
+    float* tstd = tmean + 32;
+    float* lbias = tstd + 32;
+    float* st0 = lbias + 32;
+#ifdef BBMPC_KERNEL_DBG
+    long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dbg_t0 = (long long)wall_clock64();
+#define Q4S_MARK(i) do { const long long now_ = (long long)wall_clock64(); dbg_acc[i] += now_ - dbg_t0; dbg_t0 = now_; } while (0)
+#else
+#define Q4S_MARK(i) do {} while (0)
+#endif
+    // ---- prologue.  Vector memory returns in order, so the SMALL loads (constants, start state, the sources of the 4
+    // particles' action block) are issued first, then the ~260 KB of stationary operands, and only then is anything
+    // consumed: the small results arrive first and are worked on while the operands stream in (the two waits used to
+    // add up, 3.2 + 4.1 us of a 70 us kernel).
+    // The action block is handled in (particle, 4 consecutive j) pairs, NE per thread (4 * ceil(H*U / 4) <= 256 * NE): the
+    // four elements of a pair share one Philox block (rng.hpp: rng_block is keyed by j >> 2), so a thread draws once,
+    // not four times -- 120 VALU instructions each at a lone wave's issue rate were a good microsecond of the prologue.
+    const int HU = p.HU, a_pairs = QP * ((HU + 3) >> 2);
+    const int ci = min(tid, S + U - 1), cs = min(tid, S - 1);
+    const float* cmu_base = !normd ? p.state : (ci < S ? m.mean_s : m.mean_a);
+    const float* csd_base = !normd ? p.state : (ci < S ? m.std_s : m.std_a);
+    const int cmi = !normd ? 0 : (ci < S ? ci : ci - S);
+    const float c_mu = cmu_base[cmi], c_sd = csd_base[cmi];
+    const float c_tm = (normd ? m.mean_t : p.state)[normd ? cs : 0], c_ts = (normd ? m.std_t : p.state)[normd ? cs : 0];
+    const float c_lb = q.braw[2][cs], c_st = p.state[a * S + cs];
+    // (branch-free: a load under a branch makes the compiler wait for everything in flight at the join, so elements that
+    // do not exist / sources a mode does not have read word 0 of the state instead)
+    const bool m_ref = q.mode == SRC_REF, m_buf = q.mode == SRC_BUF, m_uni = q.mode == SRC_UNIFORM;
+    const bool has_raw = m_ref || m_buf || p.inj != nullptr, has_dist = !m_ref && !m_buf && !m_uni, has_bounds = q.pen || m_uni;
+    const float* raw_base = m_ref ? p.seq : m_buf ? p.cand : (p.inj ? p.inj : p.state);
+    const float* sg_base = has_dist ? p.sigma : p.state;
+    const float* mn_base = has_dist ? p.mean : p.state;
+    const float* lo_base = has_bounds ? p.lo : p.state;
+    const float* hi_base = has_bounds ? p.hi : p.state;
+    const bool has_rng = !has_raw;                         // draws made here (rng.hpp counters), SRC_UNIFORM or truncated normal
+    const RngKey key_now = rng_key_now(p.key);               // (the control step from memory when the launch is a graph node)
+    float a_raw[NE][4], a_sg[NE][4], a_mn[NE][4], a_lo[NE][4], a_hi[NE][4], a_f[NE][4], a_tq[NE][4];
+    int a_n[NE], a_j0[NE], a_tu[NE];                     // particle (-1: no such pair / particle), first j, (t << 8) | u of the first element
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int pi = tid + i * NT;
+        const int pp = pi & (QP - 1), j0 = (pi >> 2) << 2;
+        const int n = n0 + pp;
+        const bool pvalid = pi < a_pairs && n < p.n_pop;
+        const int t0 = j0 / U, u0 = j0 - t0 * U;
+        a_n[i] = pvalid ? n : -1; a_j0[i] = j0; a_tu[i] = (t0 << 8) | u0;
+        // word_to_trunc_normal (rng.hpp) split in two: the table entry is loaded here, the interpolation happens with the
+        // other small results -- as one piece it would sit behind the operand loads.  One unconditional pair of loads
+        // per element whatever the mode (a load inside a branch costs a wait at the join).
+        U4 blk4 = {0u, 0u, 0u, 0u};
+        if (has_rng) blk4 = rng_block(key_now, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j0);
+        const bool tn = has_rng && !m_uni;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int j = j0 + l;
+            int u = u0 + l;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) u = (u >= U) ? u - U : u;
+            const bool valid = pvalid && j < HU;
+            const int di = (valid && has_dist) ? a * HU + j : 0;
+            a_sg[i][l] = sg_base[di]; a_mn[i][l] = mn_base[di];
+            const int ui = (valid && has_bounds) ? u : 0;
+            a_lo[i][l] = lo_base[ui]; a_hi[i][l] = hi_base[ui];
+            const uint32_t w = l == 0 ? blk4.x : (l == 1 ? blk4.y : (l == 2 ? blk4.z : blk4.w));      // pick_word(blk4, j)
+            const uint32_t v = w >> 9;
+            a_f[i][l] = m_uni ? word_to_uniform(w)
+                              : ((float)(v & ((1u << (23 - TNQ_BITS)) - 1u)) + 0.5f) * (1.0f / (float)(1u << (23 - TNQ_BITS)));
+            const size_t ri = m_ref ? ((size_t)n * p.A + a) * HU + j : ((size_t)a * HU + j) * p.Nst + n;
+            const float* tqp = reinterpret_cast<const float*>(g_tnq) + 2 * (v >> (23 - TNQ_BITS));
+            const float* rp = tn ? tqp : raw_base + ((valid && has_raw) ? ri : (size_t)0);
+            const float* tp = tn ? tqp + 1 : p.state;
+            a_raw[i][l] = *rp; a_tq[i][l] = *tp;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Q4S_MARK(11);
+    // ---- stationary A operands (packed [k/4][Mp][4] by bbmpc_set_mlp): ~215 KB per workgroup.  Operands a block or wave
+    // does not use are read from a zero row (one cached 1 KB line) instead of being branched around: a load under a branch
+    // is followed by a wait for everything issued so far.
+    const int M1 = m.dims[1], M3 = m.dims[3];
+    const int Mp1 = (M1 + 63) & ~63, Mp3 = (M3 + 63) & ~63;
+    const float4* __restrict__ Q0 = reinterpret_cast<const float4*>(q.wq4[0]);
+    const float4* __restrict__ Q1 = reinterpret_cast<const float4*>(q.wq4[1]);
+    const float* __restrict__ Q1f = q.wq4[1];
+    const float* __restrict__ Q2f = q.wq4[2];
+    // layer 0: block b of wave w produces hidden quad 13w + b (b < 13, quad < HG); D register i = feature 4*quad + i
+    const int q0 = Q0W * wave + blk;
+    const bool l0_on = blk < Q0W && q0 < HG;
+    const int f0 = l0_on ? 4 * q0 + (lane & 3) : 0;      // hidden feature of this lane's layer-0 A operands
+    float wA0r[16], wA0b[4], wA0a[AG * 4], wJ[NJ][KA * 4], wT[KT], wLA[NJ][4], wLB[NJ], wLTA, wLTB;
+#pragma unroll
+    for (int g = 0; g < AG; ++g) {
+        const float4 v = Q0[(size_t)(l0_on ? SG + g : ZROW) * Mp1 + f0];
+        wA0a[4 * g + 0] = v.x; wA0a[4 * g + 1] = v.y; wA0a[4 * g + 2] = v.z; wA0a[4 * g + 3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                        // round j of layer 0: my block multiplies state group (fgq - j) & 3
+        const float4 v = Q0[(size_t)(l0_on ? ((fgq - j) & 3) : ZROW) * Mp1 + f0];
+        wA0r[4 * j + 0] = v.x; wA0r[4 * j + 1] = v.y; wA0r[4 * j + 2] = v.z; wA0r[4 * j + 3] = v.w;
+    }
+    {
+        const float4 v = Q0[(size_t)(l0_on ? 4 : ZROW) * Mp1 + f0];
+        wA0b[0] = v.x; wA0b[1] = v.y; wA0b[2] = v.z; wA0b[3] = v.w;
+    }
+    // layer 1, K split over the rows: row r takes k groups [KA*r, KA*r + cnt)
+    const int startA = KA * row;
+    const int cntA = min(KA, HG - startA);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {                    // job = wave + 4*jj: output features 16*job + (lane & 15)
+        const int o = 16 * (wave + NW * jj) + (lane & 15);
+#pragma unroll
+        for (int c = 0; c < KA; ++c) {
+            const float4 v = Q1[(size_t)(c < cntA ? startA + c : ZROW) * Mp1 + o];
+            wJ[jj][4 * c + 0] = v.x; wJ[jj][4 * c + 1] = v.y; wJ[jj][4 * c + 2] = v.z; wJ[jj][4 * c + 3] = v.w;
+        }
+    }
+    // the tail chain (hidden quad 4*NW*NJ + wave on the first TQ waves): MFMA m of block (row, g) takes k = 4*(row + 4m) + g
+    // (groups 50, 51 of the packed operands and of h0 are zero), output feature 4*(4*NW*NJ + wave) + (lane & 3)
+    const bool tail_on = wave < TQ;
+#pragma unroll
+    for (int mm = 0; mm < KT; ++mm)
+        wT[mm] = Q1f[((size_t)(tail_on ? row + 4 * mm : ZROW) * Mp1 + 16 * NW * NJ + 4 * wave + (lane & 3)) * 4 + fgq];
+    // the last layer from registers.  After layer 1 lane (row, g, particle) holds hidden feature 16*job + 4g + pr: round j of
+    // set A multiplies the value of block (g - j) & 3, i.e. k = 16*job + 4*((g - j) & 3) + pr, into output quad g; set B
+    // multiplies the block's own k into output features 16..19.  The tail value (k = 4*(48 + wave) + pr, the same in the four
+    // blocks of a row) goes into output quad g on every block and into features 16..19 on block 0 of the row only.
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int job = wave + NW * jj;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            wLA[jj][j] = Q2f[((size_t)(4 * job + ((fgq - j) & 3)) * Mp3 + 4 * fgq + (lane & 3)) * 4 + pr];
+        wLB[jj] = Q2f[((size_t)(4 * job + fgq) * Mp3 + 16 + (lane & 3)) * 4 + pr];
+    }
+    wLTA = Q2f[((size_t)(tail_on ? 4 * NW * NJ + wave : ZROW) * Mp3 + 4 * fgq + (lane & 3)) * 4 + pr];
+    wLTB = Q2f[((size_t)((tail_on && fgq == 0) ? 4 * NW * NJ + wave : ZROW) * Mp3 + 16 + (lane & 3)) * 4 + pr];
+    // biases: layer 0 enters as the C operand of a chain's first MFMA (my 4 D rows: features 4*quad + r); the K-split
+    // products get theirs after the reduction, where a lane holds ONE feature
+    f32x4 b0;
+    {
+        const int fb = l0_on ? 4 * q0 : 0;
+        b0.x = q.braw[0][fb + 0]; b0.y = q.braw[0][fb + 1]; b0.z = q.braw[0][fb + 2]; b0.w = q.braw[0][fb + 3];
+    }
+    float b1s[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) b1s[jj] = q.braw[1][16 * (wave + NW * jj) + 4 * fgq + pr];
+    const float b1t = q.braw[1][min(16 * NW * NJ + 4 * wave + pr, M1 - 1)];                   // tail: feature 4*(48 + wave) + pr (waves < TQ)
+    __builtin_amdgcn_sched_barrier(0);
+    Q4S_MARK(5);
+
+    // ---- the small results: constants to LDS; the action block (mlp_fill_actions' arithmetic, every thread clipping its
+    // own elements; xa is scratch for the squared clip distances, summed per (particle, u) in step order below)
+    if (q.state_copy && blockIdx.x == 0 && tid < S) q.state_copy[a * S + tid] = c_st;
+    if (tid < S + U) {
+        nmean[tid] = normd ? c_mu : 0.0f;
+        ninv[tid] = normd ? 1.0f / (c_sd + 1e-7f) : 1.0f;
+        if (tid < S) {
+            tmean[tid] = normd ? c_tm : 0.0f;              // un-normalised: 0 + z * 1 = z exactly
+            tstd[tid] = normd ? (c_ts + 1e-7f) : 1.0f;
+            lbias[tid] = c_lb;
+            st0[tid] = c_st;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) asm volatile("" : "+v"(a_raw[i][l]), "+v"(a_tq[i][l]));   // the interpolation stays down here
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int pi = tid + i * NT;
+        if (pi < a_pairs) {
+            const int n = a_n[i], pp = pi & (QP - 1);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const int j = a_j0[i] + l;
+                int u = (a_tu[i] & 255) + l, t = a_tu[i] >> 8;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { t = (u >= U) ? t + 1 : t; u = (u >= U) ? u - U : u; }
+                if (j < HU) {
+                    float x = 0.0f, d2 = 0.0f;
+                    if (n >= 0) {
+                        if (m_ref || m_buf) x = a_raw[i][l];
+                        else {
+                            // word_to_trunc_normal's last line / the uniform draw / the injected draw
+                            const float xi = has_rng ? (m_uni ? a_f[i][l] : fmaf(a_f[i][l], a_tq[i][l], a_raw[i][l])) : a_raw[i][l];
+                            if (m_uni) x = xi * (a_hi[i][l] - a_lo[i][l]) + a_lo[i][l];
+                            else x = xi * a_sg[i][l] + a_mn[i][l];
+                        }
+                        if (q.pen) {
+                            const float xf = clipf(x, a_lo[i][l], a_hi[i][l]);
+                            const float d = x - xf;
+                            d2 = d * d;
+                            x = xf;
+                        }
+                        if (p.samples) p.samples[((size_t)a * HU + j) * p.Nst + n] = x;
+                    }
+                    const int e = (t * QP + pp) * U + u;
+                    acts[e] = x;
+                    xa[e] = d2;
+                }
+            }
+        }
+    }
+    for (int i = tid; i < (HP - HG) * 16; i += NT) h0[HG * 16 + i] = 0.0f;
+    __syncthreads();
+    if (tid < QP * U) {
+        const int pp = tid / U, u = tid % U;
+        float pen_part = 0.0f;
+        if (q.pen && n0 + pp < p.n_pop)
+            for (int t = 0; t < H; ++t) pen_part = pen_part + xa[(t * QP + pp) * U + u];
+        pens[tid] = pen_part;
+    }
+    __syncthreads();
+    Q4S_MARK(6);
+
+    // ---- prologue, part 2 (LDS only): normalised action groups, 0 * sum(a^2), constants
+    for (int e = tid; e < H * AG * 16; e += NT) {
+        const int c = e & 3, pp = (e >> 2) & 3, ga = (e >> 4) % AG, t = e / (16 * AG);
+        const int u = ga * 4 + c;
+        xa[e] = (u < U) ? (acts[(t * QP + pp) * U + u] - nmean[S + u]) * ninv[S + u] : 0.0f;
+    }
+    for (int e = tid; e < H * QP; e += NT) {
+        const float* ac = acts + e * U;                    // e = t*QP + pp
+        float ss = 0.0f;
+        for (int u = 0; u < U; ++u) ss = ss + ac[u] * ac[u];
+        zs[e] = 0.0f * ss;                                 // cost_func.py:21 (NaN / inf actions propagate)
+    }
+    // the two output features this lane finishes: fA = 4*fgq + pr, fB = 16 + pr
+    const int fA = 4 * fgq + pr, fB = 16 + pr;
+    const float tmA = tmean[fA], tsA = tstd[fA], tmB = tmean[fB], tsB = tstd[fB];
+    const float nmA = nmean[fA], niA = ninv[fA], nmB = nmean[fB], niB = ninv[fB];
+    const float lbA = lbias[fA], lbB = lbias[fB];
+    // start state: the scattered copies (residual) and the normalised input groups "own quad" and 4
+    float curA = st0[fA], curB = st0[fB];
+    f32x4 xA, xB;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        xA[c] = (st0[4 * fgq + c] - nmean[4 * fgq + c]) * ninv[4 * fgq + c];
+        xB[c] = (st0[16 + c] - nmean[16 + c]) * ninv[16 + c];
+    }
+    __syncthreads();
+    Q4S_MARK(8);
+
+    float* const h0w = h0 + ((size_t)q0 * 4 + pl) * 4;    // where my layer-0 D fragment goes (blocks with l0_on)
+    const bool rew_on = p.reward_kind == REW_CHEETAH;
+    const float flag_thr = (pr == 1) ? 0.2f : 0.0f;       // cur[5] >= 0.2, cur[6] >= 0, cur[7] >= 0   cost_func.py:9-17
+    // reward terms are parked per step and summed in step order after the loop (one IEEE division per (step, particle)
+    // there instead of a ~12-instruction expansion inside every step): wave 0, quad 1 rows 1..3 own the flags of
+    // cur[6], cur[5], cur[7]; wave 0, quad 0 of row 2 (feature 17) owns the progress difference
+    const bool rwd_flag_lane = rew_on && wave == 0 && fgq == 1 && pr != 0;
+    const bool rwd_prog_lane = rew_on && wave == 0 && fgq == 0 && pr == 1;
+    float* rwd_f = rwd + pl * 4 + pr;                     // + t*16
+    float* rwd_d = rwd + pl * 4;
+    const float* hA0 = h0 + ((size_t)startA * 4 + pl) * 4;                   // B operands of the jobs: group startA + c, my particle
+    const float* hT0 = h0 + ((size_t)row * 4 + pl) * 4 + fgq;                // of the tail chain: group row + 4m, element g
+    float* const zxA = zx + lane;                                            // + 80 * wave: my partial of output feature 4g + pr
+    float* const zxB = zx + 64 + row * 4 + pl;                               // + 80 * wave: of output feature 16 + pr
+    // layer-0 accumulators (three chains), started with the bias and the action part of step 0
+    f32x4 acc0, acc1, acc2;
+    // the action part: 8 MFMAs in the chains 0 1 2 0 1 2 0 1
+#define Q4S_ACTION_PART(ba0_, ba1_) do {                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        mfma4_operands_settled();                                                                                     \
+        mfma4_v_c(acc0, wA0a[0], ba0_.x, b0); mfma4_v_0(acc1, wA0a[1], ba0_.y); mfma4_v_0(acc2, wA0a[2], ba0_.z);     \
+        mfma4_v(acc0, wA0a[3], ba0_.w);       mfma4_v(acc1, wA0a[4], ba1_.x);   mfma4_v(acc2, wA0a[5], ba1_.y);       \
+        mfma4_v(acc0, wA0a[6], ba1_.z);       mfma4_v(acc1, wA0a[7], ba1_.w);                                         \
+    } while (0)
+    {
+        const f32x4 ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)0 * 4 + pl) * 4);
+        const f32x4 ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)1 * 4 + pl) * 4);
+        Q4S_ACTION_PART(ba0, ba1);
+    }
+#ifdef BBMPC_KERNEL_DBG
+    Q4S_MARK(7);
+    const long long dbg_start = dbg_t0, dbg_cyc0 = (long long)clock64();
+#endif
+    for (int t = 0; t < H; ++t) {
+        // ---- layer 0, state part: groups 0..3 rotate through the row, group 4 is replicated
+        {
+            f32x4 r1, r2, r3;
+            r1.x = dpp_mov<DPP_ROW_ROR4>(xA.x); r1.y = dpp_mov<DPP_ROW_ROR4>(xA.y);
+            r1.z = dpp_mov<DPP_ROW_ROR4>(xA.z); r1.w = dpp_mov<DPP_ROW_ROR4>(xA.w);
+            r2.x = dpp_mov<DPP_ROW_ROR8>(xA.x); r2.y = dpp_mov<DPP_ROW_ROR8>(xA.y);
+            r2.z = dpp_mov<DPP_ROW_ROR8>(xA.z); r2.w = dpp_mov<DPP_ROW_ROR8>(xA.w);
+            r3.x = dpp_mov<DPP_ROW_ROR12>(xA.x); r3.y = dpp_mov<DPP_ROW_ROR12>(xA.y);
+            r3.z = dpp_mov<DPP_ROW_ROR12>(xA.z); r3.w = dpp_mov<DPP_ROW_ROR12>(xA.w);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4_operands_settled();
+            // (the action part left the chains at acc1)
+            mfma4_v(acc2, wA0r[0], xA.x);  mfma4_v(acc0, wA0r[1], xA.y);  mfma4_v(acc1, wA0r[2], xA.z);  mfma4_v(acc2, wA0r[3], xA.w);
+            mfma4_v(acc0, wA0r[4], r1.x);  mfma4_v(acc1, wA0r[5], r1.y);  mfma4_v(acc2, wA0r[6], r1.z);  mfma4_v(acc0, wA0r[7], r1.w);
+            mfma4_v(acc1, wA0r[8], r2.x);  mfma4_v(acc2, wA0r[9], r2.y);  mfma4_v(acc0, wA0r[10], r2.z); mfma4_v(acc1, wA0r[11], r2.w);
+            mfma4_v(acc2, wA0r[12], r3.x); mfma4_v(acc0, wA0r[13], r3.y); mfma4_v(acc1, wA0r[14], r3.z); mfma4_v(acc2, wA0r[15], r3.w);
+            mfma4_v(acc0, wA0b[0], xB.x);  mfma4_v(acc1, wA0b[1], xB.y);  mfma4_v(acc2, wA0b[2], xB.z);  mfma4_v(acc0, wA0b[3], xB.w);
+            mfma4_results_ready(acc0, acc1, acc2);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 o;
+            o.x = apply_act_ct<A0>((acc0.x + acc1.x) + acc2.x); o.y = apply_act_ct<A0>((acc0.y + acc1.y) + acc2.y);
+            o.z = apply_act_ct<A0>((acc0.z + acc1.z) + acc2.z); o.w = apply_act_ct<A0>((acc0.w + acc1.w) + acc2.w);
+            if (l0_on) *reinterpret_cast<f32x4*>(h0w) = o;
+        }
+        Q4S_MARK(0);
+        __syncthreads();                                   // h0 of step t is complete
+        Q4S_MARK(1);
+        // ---- layer 1: three 16-feature jobs per wave, K split over the rows, one shared set of B operands; the tail chain
+        // rides along, one MFMA per round; stationary A operands in AccVGPRs, read by the MFMA directly
+        float h1v[NJ], h1t;
+        f32x4 ba0, ba1;
+        {
+            f32x4 bq[KA];
+            float bt[KT];
+            f32x4 cj0, cj1, cj2, ct;
+#pragma unroll
+            for (int c = 0; c < KA; ++c) bq[c] = *reinterpret_cast<const f32x4*>(hA0 + c * 16);
+#pragma unroll
+            for (int mm = 0; mm < KT; ++mm) bt[mm] = hT0[mm * 64];
+            {   // next step's normalised action groups: static data, fetched here so that the action part can follow the
+                // last layer without a wait
+                const int tn = (t + 1 < H) ? t + 1 : t;
+                ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 0) * 4 + pl) * 4);
+                ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 1) * 4 + pl) * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4_a_round3t_first(cj0, cj1, cj2, ct, wJ[0], wJ[1], wJ[2], bq[0], wT[0], bt[0]);
+#pragma unroll
+            for (int c = 1; c < KA; ++c) mfma4_a_round3t(cj0, cj1, cj2, ct, wJ[0] + 4 * c, wJ[1] + 4 * c, wJ[2] + 4 * c, bq[c], wT[c], bt[c]);
+            mfma4_results_ready(cj0, cj1, cj2, ct);
+            __builtin_amdgcn_sched_barrier(0);
+            Q4S_MARK(2);
+            h1v[0] = apply_act_ct<A1>(rows_reduce_scatter(cj0) + b1s[0]);
+            h1v[1] = apply_act_ct<A1>(rows_reduce_scatter(cj1) + b1s[1]);
+            h1v[2] = apply_act_ct<A1>(rows_reduce_scatter(cj2) + b1s[2]);
+            // the tail chain: the row's four blocks first (8, then 4: every block adds the same pairs), then the rows
+            ct.x = ct.x + dpp_mov<DPP_ROW_ROR8>(ct.x); ct.y = ct.y + dpp_mov<DPP_ROW_ROR8>(ct.y);
+            ct.z = ct.z + dpp_mov<DPP_ROW_ROR8>(ct.z); ct.w = ct.w + dpp_mov<DPP_ROW_ROR8>(ct.w);
+            ct.x = ct.x + dpp_mov<DPP_ROW_ROR4>(ct.x); ct.y = ct.y + dpp_mov<DPP_ROW_ROR4>(ct.y);
+            ct.z = ct.z + dpp_mov<DPP_ROW_ROR4>(ct.z); ct.w = ct.w + dpp_mov<DPP_ROW_ROR4>(ct.w);
+            h1t = apply_act_ct<A1>(rows_reduce_scatter(ct) + b1t);
+        }
+        Q4S_MARK(3);
+        // ---- the last layer, my hidden features only, straight from the registers: set A (output quad g on block g; round j
+        // takes the value of block g - j), set B (output features 16..19, every block its own k), the tail value last
+        {
+            f32x4 cA0, cA1, cA2, cB;
+            const float s1[NJ] = {dpp_mov<DPP_ROW_ROR4>(h1v[0]), dpp_mov<DPP_ROW_ROR4>(h1v[1]), dpp_mov<DPP_ROW_ROR4>(h1v[2])};
+            const float s2[NJ] = {dpp_mov<DPP_ROW_ROR8>(h1v[0]), dpp_mov<DPP_ROW_ROR8>(h1v[1]), dpp_mov<DPP_ROW_ROR8>(h1v[2])};
+            const float s3[NJ] = {dpp_mov<DPP_ROW_ROR12>(h1v[0]), dpp_mov<DPP_ROW_ROR12>(h1v[1]), dpp_mov<DPP_ROW_ROR12>(h1v[2])};
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4_operands_settled();
+            mfma4_a_0(cA0, wLA[0][0], h1v[0]); mfma4_a_0(cA1, wLA[1][0], h1v[1]); mfma4_a_0(cA2, wLA[2][0], h1v[2]); mfma4_a_0(cB, wLB[0], h1v[0]);
+            mfma4_a(cA0, wLA[0][1], s1[0]);    mfma4_a(cA1, wLA[1][1], s1[1]);    mfma4_a(cA2, wLA[2][1], s1[2]);    mfma4_a(cB, wLB[1], h1v[1]);
+            mfma4_a(cA0, wLA[0][2], s2[0]);    mfma4_a(cA1, wLA[1][2], s2[1]);    mfma4_a(cA2, wLA[2][2], s2[2]);    mfma4_a(cB, wLB[2], h1v[2]);
+            mfma4_a(cA0, wLA[0][3], s3[0]);    mfma4_a(cA1, wLA[1][3], s3[1]);    mfma4_a(cA2, wLA[2][3], s3[2]);    mfma4_a(cB, wLTB, h1t);
+            mfma4_a(cA0, wLTA, h1t);
+            // the action part of the NEXT step's layer 0 (independent of everything here) covers the results' latency
+            Q4S_ACTION_PART(ba0, ba1);
+            mfma4_results_ready(cA0, cA1, cA2, cB);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 sA = {(cA0.x + cA1.x) + cA2.x, (cA0.y + cA1.y) + cA2.y, (cA0.z + cA1.z) + cA2.z, (cA0.w + cA1.w) + cA2.w};
+            cB.x = cB.x + dpp_mov<DPP_ROW_ROR8>(cB.x); cB.y = cB.y + dpp_mov<DPP_ROW_ROR8>(cB.y);
+            cB.z = cB.z + dpp_mov<DPP_ROW_ROR8>(cB.z); cB.w = cB.w + dpp_mov<DPP_ROW_ROR8>(cB.w);
+            cB.x = cB.x + dpp_mov<DPP_ROW_ROR4>(cB.x); cB.y = cB.y + dpp_mov<DPP_ROW_ROR4>(cB.y);
+            cB.z = cB.z + dpp_mov<DPP_ROW_ROR4>(cB.z); cB.w = cB.w + dpp_mov<DPP_ROW_ROR4>(cB.w);
+            zxA[80 * wave] = rows_reduce_scatter(sA);      // output feature 4g + pr of my particle, my hidden features' share
+            const float pB = rows_reduce_scatter(cB);      // output feature 16 + pr
+            if (fgq == 0) zxB[80 * wave] = pB;
+        }
+        Q4S_MARK(4);
+        __syncthreads();                                   // every wave's partial sums are in zx
+        Q4S_MARK(9);
+        {
+            // ---- every wave: the sum over the waves (one order everywhere: all four hold the same bits), then the epilogue on
+            // the two features this lane finishes (process_output, then process_input of the next step)
+            const float a0 = zxA[0], a1 = zxA[80], a2 = zxA[160], a3 = zxA[240];
+            const float c0 = zxB[0], c1 = zxB[80], c2 = zxB[160], c3 = zxB[240];
+            float zA = ((a0 + a1) + (a2 + a3)) + lbA;
+            float zB = ((c0 + c1) + (c2 + c3)) + lbB;
+            zA = apply_act_ct<A2>(zA); zB = apply_act_ct<A2>(zB);
+            const float vA = (tmA + zA * tsA) + curA, vB = (tmB + zB * tsB) + curB;
+            if (rwd_flag_lane) rwd_f[t * 16] = (curA >= flag_thr) ? -10.0f : 0.0f;
+            if (rwd_prog_lane) rwd_d[t * 16] = vB - curB;
+            curA = vA; curB = vB;
+            if (q.traj) {                                  // state after step t, for a user reward function
+                const f32x4 rA = rows_all_gather(vA), rB = rows_all_gather(vB);
+                if (n0 + pl < p.n_pop) {
+                    float* dst = q.traj + ((((size_t)t * p.A + a) * p.Nst) + n0 + pl) * S;
+                    if (wave == 0 && row == 0) *reinterpret_cast<f32x4*>(dst + 4 * fgq) = rA;
+                    if (wave == 0 && row == 1 && fgq == 0) *reinterpret_cast<f32x4*>(dst + 16) = rB;
+                }
+            }
+            xA = rows_all_gather((vA - nmA) * niA);
+            xB = rows_all_gather((vB - nmB) * niB);
+        }
+        Q4S_MARK(10);
+    }
+#undef Q4S_ACTION_PART
+#ifdef BBMPC_KERNEL_DBG
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (tid == 0 || tid == 128)) {
+        printf("[q4sdbg wave %d] H=%d | small loads issued %lld  operand loads issued %lld  constants+actions %lld  LDS part 2 %lld  first mfma %lld | loop %lld (%lld shader cycles): layer0 %lld bar %lld layer1 mfma %lld reduce+tanh %lld last layer+partials %lld bar %lld sum+epilogue+gather %lld (10ns units)\n",
+               wave, H, dbg_acc[11], dbg_acc[5], dbg_acc[6], dbg_acc[8], dbg_acc[7], (long long)wall_clock64() - dbg_start, (long long)clock64() - dbg_cyc0, dbg_acc[0], dbg_acc[1], dbg_acc[2], dbg_acc[3], dbg_acc[4], dbg_acc[9], dbg_acc[10]);
+    }
+#endif
+    // ---- rewards: cost_func.py:5-22 per step, summed in step order (deterministic.py:62-73)
+    // (the H x 4 step rewards by all threads -- each has a division -- then four threads add them up in step order: one
+    // thread per particle walking all of it was 1.5 us at the end of every launch, at a lone wave's issue rate)
+    __syncthreads();
+    float* rstep = h0;                                     // [H][QP]: the activations are dead
+    if (rew_on)
+        for (int e = tid; e < H * QP; e += NT) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(rwd + e * 4);   // (d17, flag 5, flag 6, flag 7) of (step, particle) e
+            float r = 0.0f;
+            r = r + w.y; r = r + w.z; r = r + w.w;
+            r = r + w.x / 0.01f;
+            r = r - zs[e];
+            rstep[e] = r;
+        }
+    __syncthreads();
+    if (tid < QP) {
+        float total = 0.0f;
+        if (rew_on)
+            for (int t = 0; t < H; ++t) total = total + rstep[t * QP + tid];
+        const int n = n0 + tid;
+        if (n < p.n_pop) {
+            if (total != total) total = -1.0e6f;
+            if (q.pen) {
+                float pen = 0.0f;
+                for (int u = 0; u < U; ++u) pen = pen + pens[tid * U + u];
+                const float nr = sqrtf(pen);
+                pen = nr * nr;
+                total = total - pen;
+                if (p.penalty_out) p.penalty_out[(size_t)a * p.Nst + n] = pen;
+            }
+            p.rewards[(size_t)a * p.Nst + n] = total;
+        }
+    }
+}
+
+inline int mlp_q4s_lds_floats(int HG, int K0G, int H, int U) {
+    (void)HG;
+    return 64 * 16 + 4 * 80 + ((H * 4 * U + 3) & ~3) + ((4 * U + 3) & ~3) + H * (K0G - 5) * 16 + H * 4 + H * 16 + 6 * 32 + 8;
+}
+
+}  // namespace bbmpc
