@@ -69,14 +69,14 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     constexpr int KT = (HG + 3) / 4;                     // tail chain: MFMAs (block (row, g) takes k = 4*(row + 4m) + g, m < KT)
     constexpr int Q0W = (HG + NW - 1) / NW;              // layer 0: hidden quads per wave (13: blocks 0..12)
     static_assert(HG < HP && KA * 4 <= HP && 3 + 4 * (KT - 1) < HP && K0G > SG, "padding / input groups");
-    static_assert(NJ == 3 && TQ >= 0 && TQ <= NW && KT == KA && Q0W <= 16 && AG == 2, "written for 200 hidden units, 20 + <= 8 inputs");
+    static_assert(NT % (16 * AG) == 0 && NJ == 3 && TQ >= 0 && TQ <= NW && KT == KA && Q0W <= 16 && AG == 2, "written for 200 hidden units, 20 + <= 8 inputs");
     const int a = blockIdx.y, n0 = xcd_tile(blockIdx.x, gridDim.x, blockIdx.y) * QP;     // an XCD's workgroups: contiguous particles
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
     const int S = p.S, U = p.U, H = p.H;
     const bool normd = m.normalized != 0;
     const int row = lane >> 4, blk = lane >> 2, fgq = blk & 3, pl = lane & 3;
     const int pr = ((row & 1) << 1) | (row >> 1);        // element of a reduce-scattered float4 this row holds
-    // ---- LDS: h0[HP][4][4] | zx[4 waves][64 + 16] | acts[H][4][U] | pen[4U] | xa[H][AG][4][4] | zs[H][4] | rwd[H][4][4] | constants
+    // ---- LDS: h0[HP][4][4] | zx[4 waves][64 + 16] | acts[H][4][U] | pen[4U] | xa[H][AG][4][4] | zs[H][4] | rwd[H][4][4] | d2s[H][4][U]
     float* h0 = smem;
     float* zx = h0 + HP * 16;                             // the waves' partial sums of the last layer: [wave][lane] features 0..15, [wave][64 + row*4 + particle] features 16..19
     float* acts = zx + NW * 80;
@@ -84,15 +84,15 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     float* xa = pens + ((QP * U + 3) & ~3);
     float* zs = xa + H * AG * 16;
     float* rwd = zs + H * QP;                             // per step and particle: (progress difference, flag 5, flag 6, flag 7)
-    float* nmean = rwd + H * QP * 4;                      // [S+U] input mean, [S+U] 1/(std+1e-7), [S] target mean, [S] std+1e-7,
-    float* ninv = nmean + 32;                             // [S] last bias, [S] start state   (S = 20, S+U <= 28)
-    float* tmean = ninv + 32;
-    float* tstd = tmean + 32;
-    float* lbias = tstd + 32;
-    float* st0 = lbias + 32;
+    float* d2s = rwd + H * QP * 4;                        // [H][4][U] squared clip distances, summed per (particle, u) in step order at the end
 #ifdef BBMPC_KERNEL_DBG
-    long long dbg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dbg_t0 = (long long)wall_clock64();
-#define Q4S_MARK(i) do { const long long now_ = (long long)wall_clock64(); dbg_acc[i] += now_ - dbg_t0; dbg_t0 = now_; } while (0)
+    // shader-clock phase counters; the scheduling fences keep the phases' instructions on their side of a mark
+    long long dbg_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dbg_t0 = (long long)clock64();
+#if BBMPC_KERNEL_DBG >= 2
+#define Q4S_MARK(i) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = (long long)clock64(); dbg_acc[i] += now_ - dbg_t0; dbg_t0 = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define Q4S_MARK(i) do { (void)dbg_acc; (void)dbg_t0; } while (0)       // -DBBMPC_KERNEL_DBG=1: the loop's cycles and wall time only
+#endif
 #else
 #define Q4S_MARK(i) do {} while (0)
 #endif
@@ -104,13 +104,20 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     // four elements of a pair share one Philox block (rng.hpp: rng_block is keyed by j >> 2), so a thread draws once,
     // not four times -- 120 VALU instructions each at a lone wave's issue rate were a good microsecond of the prologue.
     const int HU = p.HU, a_pairs = QP * ((HU + 3) >> 2);
-    const int ci = min(tid, S + U - 1), cs = min(tid, S - 1);
-    const float* cmu_base = !normd ? p.state : (ci < S ? m.mean_s : m.mean_a);
-    const float* csd_base = !normd ? p.state : (ci < S ? m.std_s : m.std_a);
-    const int cmi = !normd ? 0 : (ci < S ? ci : ci - S);
-    const float c_mu = cmu_base[cmi], c_sd = csd_base[cmi];
-    const float c_tm = (normd ? m.mean_t : p.state)[normd ? cs : 0], c_ts = (normd ? m.std_t : p.state)[normd ? cs : 0];
-    const float c_lb = q.braw[2][cs], c_st = p.state[a * S + cs];
+    // the constants of the two output features this lane finishes (fA = 4*fgq + pr, fB = 16 + pr) and of the action element
+    // this thread normalises below (u_t: the same in every pass of that loop), straight into registers: staged through LDS
+    // (round 3-5) they cost a barrier and ~40 dependent LDS reads at a lone wave's latency, a microsecond of every launch
+    const int fA = 4 * fgq + pr, fB = 16 + pr, cs = min(tid, S - 1);
+    const int u_t = ((tid >> 4) % AG) * 4 + (tid & 3);
+    const bool u_on = u_t < U;
+    const float g_msA = (normd ? m.mean_s : p.state)[normd ? fA : 0], g_msB = (normd ? m.mean_s : p.state)[normd ? fB : 0];
+    const float g_ssA = (normd ? m.std_s : p.state)[normd ? fA : 0], g_ssB = (normd ? m.std_s : p.state)[normd ? fB : 0];
+    const float g_mtA = (normd ? m.mean_t : p.state)[normd ? fA : 0], g_mtB = (normd ? m.mean_t : p.state)[normd ? fB : 0];
+    const float g_stA = (normd ? m.std_t : p.state)[normd ? fA : 0], g_stB = (normd ? m.std_t : p.state)[normd ? fB : 0];
+    const float g_mau = (normd ? m.mean_a : p.state)[(normd && u_on) ? u_t : 0], g_sau = (normd ? m.std_a : p.state)[(normd && u_on) ? u_t : 0];
+    const float lbA = q.braw[2][fA], lbB = q.braw[2][fB];
+    float curA = p.state[a * S + fA], curB = p.state[a * S + fB];
+    const float c_st = p.state[a * S + cs];
     // (branch-free: a load under a branch makes the compiler wait for everything in flight at the join, so elements that
     // do not exist / sources a mode does not have read word 0 of the state instead)
     const bool m_ref = q.mode == SRC_REF, m_buf = q.mode == SRC_BUF, m_uni = q.mode == SRC_UNIFORM;
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     const RngKey key_now = rng_key_now(p.key);               // (the control step from memory when the launch is a graph node)
     float a_raw[NE][4], a_sg[NE][4], a_mn[NE][4], a_lo[NE][4], a_hi[NE][4], a_f[NE][4], a_tq[NE][4];
     int a_n[NE], a_j0[NE], a_tu[NE];                     // particle (-1: no such pair / particle), first j, (t << 8) | u of the first element
+    // (i) what does not wait for the generator: the elements' distribution and bounds
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int pi = tid + i * NT;
@@ -132,12 +140,6 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
         const bool pvalid = pi < a_pairs && n < p.n_pop;
         const int t0 = j0 / U, u0 = j0 - t0 * U;
         a_n[i] = pvalid ? n : -1; a_j0[i] = j0; a_tu[i] = (t0 << 8) | u0;
-        // word_to_trunc_normal (rng.hpp) split in two: the table entry is loaded here, the interpolation happens with the
-        // other small results -- as one piece it would sit behind the operand loads.  One unconditional pair of loads
-        // per element whatever the mode (a load inside a branch costs a wait at the join).
-        U4 blk4 = {0u, 0u, 0u, 0u};
-        if (has_rng) blk4 = rng_block(key_now, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j0);
-        const bool tn = has_rng && !m_uni;
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             const int j = j0 + l;
@@ -149,20 +151,11 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
             a_sg[i][l] = sg_base[di]; a_mn[i][l] = mn_base[di];
             const int ui = (valid && has_bounds) ? u : 0;
             a_lo[i][l] = lo_base[ui]; a_hi[i][l] = hi_base[ui];
-            const uint32_t w = l == 0 ? blk4.x : (l == 1 ? blk4.y : (l == 2 ? blk4.z : blk4.w));      // pick_word(blk4, j)
-            const uint32_t v = w >> 9;
-            a_f[i][l] = m_uni ? word_to_uniform(w)
-                              : ((float)(v & ((1u << (23 - TNQ_BITS)) - 1u)) + 0.5f) * (1.0f / (float)(1u << (23 - TNQ_BITS)));
-            const size_t ri = m_ref ? ((size_t)n * p.A + a) * HU + j : ((size_t)a * HU + j) * p.Nst + n;
-            const float* tqp = reinterpret_cast<const float*>(g_tnq) + 2 * (v >> (23 - TNQ_BITS));
-            const float* rp = tn ? tqp : raw_base + ((valid && has_raw) ? ri : (size_t)0);
-            const float* tp = tn ? tqp + 1 : p.state;
-            a_raw[i][l] = *rp; a_tq[i][l] = *tp;
         }
     }
     __builtin_amdgcn_sched_barrier(0);
     Q4S_MARK(11);
-    // ---- stationary A operands (packed [k/4][Mp][4] by bbmpc_set_mlp): ~215 KB per workgroup.  Operands a block or wave
+    // ---- (ii) stationary A operands (packed [k/4][Mp][4] by bbmpc_set_mlp): ~215 KB per workgroup, the first 33 loads.  Operands a block or wave
     // does not use are read from a zero row (one cached 1 KB line) instead of being branched around: a load under a branch
     // is followed by a wait for everything issued so far.
     const int M1 = m.dims[1], M3 = m.dims[3];
@@ -194,7 +187,48 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     const int startA = KA * row;
     const int cntA = min(KA, HG - startA);
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {                    // job = wave + 4*jj: output features 16*job + (lane & 15)
+    for (int jj = 0; jj < NJ - 1; ++jj) {                // (ii) job = wave + 4*jj: output features 16*job + (lane & 15)
+        const int o = 16 * (wave + NW * jj) + (lane & 15);
+#pragma unroll
+        for (int c = 0; c < KA; ++c) {
+            const float4 v = Q1[(size_t)(c < cntA ? startA + c : ZROW) * Mp1 + o];
+            wJ[jj][4 * c + 0] = v.x; wJ[jj][4 * c + 1] = v.y; wJ[jj][4 * c + 2] = v.z; wJ[jj][4 * c + 3] = v.w;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Q4S_MARK(17);
+    // (iii) the draws, while the first operands are on their way (215 KB per workgroup from every workgroup at once keep the
+    // L2s busy for ~4 us: the generator's ~250 instructions used to run BEFORE the first operand load was issued).
+    // word_to_trunc_normal (rng.hpp) split in two: the table entry is loaded here, the interpolation happens with the
+    // other small results.  One unconditional pair of loads per element whatever the mode (a load inside a branch costs a
+    // wait at the join).
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int pi = tid + i * NT;
+        const int j0 = a_j0[i], n = n0 + (pi & (QP - 1));
+        const bool pvalid = a_n[i] >= 0;
+        U4 blk4 = {0u, 0u, 0u, 0u};
+        if (has_rng) blk4 = rng_block(key_now, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j0);
+        const bool tn = has_rng && !m_uni;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int j = j0 + l;
+            const bool valid = pvalid && j < HU;
+            const uint32_t w = l == 0 ? blk4.x : (l == 1 ? blk4.y : (l == 2 ? blk4.z : blk4.w));      // pick_word(blk4, j)
+            const uint32_t v = w >> 9;
+            a_f[i][l] = m_uni ? word_to_uniform(w)
+                              : ((float)(v & ((1u << (23 - TNQ_BITS)) - 1u)) + 0.5f) * (1.0f / (float)(1u << (23 - TNQ_BITS)));
+            const size_t ri = m_ref ? ((size_t)n * p.A + a) * HU + j : ((size_t)a * HU + j) * p.Nst + n;
+            const float* tqp = reinterpret_cast<const float*>(g_tnq) + 2 * (v >> (23 - TNQ_BITS));
+            const float* rp = tn ? tqp : raw_base + ((valid && has_raw) ? ri : (size_t)0);
+            const float* tp = tn ? tqp + 1 : p.state;
+            a_raw[i][l] = *rp; a_tq[i][l] = *tp;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Q4S_MARK(18);
+#pragma unroll
+    for (int jj = NJ - 1; jj < NJ; ++jj) {              // (iv) the rest of the operands
         const int o = 16 * (wave + NW * jj) + (lane & 15);
 #pragma unroll
         for (int c = 0; c < KA; ++c) {
@@ -239,16 +273,11 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     // ---- the small results: constants to LDS; the action block (mlp_fill_actions' arithmetic, every thread clipping its
     // own elements; xa is scratch for the squared clip distances, summed per (particle, u) in step order below)
     if (q.state_copy && blockIdx.x == 0 && tid < S) q.state_copy[a * S + tid] = c_st;
-    if (tid < S + U) {
-        nmean[tid] = normd ? c_mu : 0.0f;
-        ninv[tid] = normd ? 1.0f / (c_sd + 1e-7f) : 1.0f;
-        if (tid < S) {
-            tmean[tid] = normd ? c_tm : 0.0f;              // un-normalised: 0 + z * 1 = z exactly
-            tstd[tid] = normd ? (c_ts + 1e-7f) : 1.0f;
-            lbias[tid] = c_lb;
-            st0[tid] = c_st;
-        }
-    }
+    const float nmA = normd ? g_msA : 0.0f, nmB = normd ? g_msB : 0.0f;                       // un-normalised: (x - 0) * 1, 0 + z * 1 = z exactly
+    const float niA = normd ? 1.0f / (g_ssA + 1e-7f) : 1.0f, niB = normd ? 1.0f / (g_ssB + 1e-7f) : 1.0f;
+    const float tmA = normd ? g_mtA : 0.0f, tmB = normd ? g_mtB : 0.0f;
+    const float tsA = normd ? (g_stA + 1e-7f) : 1.0f, tsB = normd ? (g_stB + 1e-7f) : 1.0f;
+    const float nmu = normd ? g_mau : 0.0f, niu = normd ? 1.0f / (g_sau + 1e-7f) : 1.0f;
 #pragma unroll
     for (int i = 0; i < NE; ++i)
 #pragma unroll
@@ -284,28 +313,19 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
                     }
                     const int e = (t * QP + pp) * U + u;
                     acts[e] = x;
-                    xa[e] = d2;
+                    d2s[e] = d2;
                 }
             }
         }
     }
     for (int i = tid; i < (HP - HG) * 16; i += NT) h0[HG * 16 + i] = 0.0f;
     __syncthreads();
-    if (tid < QP * U) {
-        const int pp = tid / U, u = tid % U;
-        float pen_part = 0.0f;
-        if (q.pen && n0 + pp < p.n_pop)
-            for (int t = 0; t < H; ++t) pen_part = pen_part + xa[(t * QP + pp) * U + u];
-        pens[tid] = pen_part;
-    }
-    __syncthreads();
     Q4S_MARK(6);
 
-    // ---- prologue, part 2 (LDS only): normalised action groups, 0 * sum(a^2), constants
-    for (int e = tid; e < H * AG * 16; e += NT) {
-        const int c = e & 3, pp = (e >> 2) & 3, ga = (e >> 4) % AG, t = e / (16 * AG);
-        const int u = ga * 4 + c;
-        xa[e] = (u < U) ? (acts[(t * QP + pp) * U + u] - nmean[S + u]) * ninv[S + u] : 0.0f;
+    // ---- prologue, part 2 (LDS only): normalised action groups, 0 * sum(a^2)
+    for (int e = tid; e < H * AG * 16; e += NT) {         // (NT is a multiple of 16 * AG: e's action element is u_t in every pass)
+        const int pp = (e >> 2) & 3, t = e / (16 * AG);
+        xa[e] = u_on ? (acts[(t * QP + pp) * U + u_t] - nmu) * niu : 0.0f;
     }
     for (int e = tid; e < H * QP; e += NT) {
         const float* ac = acts + e * U;                    // e = t*QP + pp
@@ -313,19 +333,8 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
         for (int u = 0; u < U; ++u) ss = ss + ac[u] * ac[u];
         zs[e] = 0.0f * ss;                                 // cost_func.py:21 (NaN / inf actions propagate)
     }
-    // the two output features this lane finishes: fA = 4*fgq + pr, fB = 16 + pr
-    const int fA = 4 * fgq + pr, fB = 16 + pr;
-    const float tmA = tmean[fA], tsA = tstd[fA], tmB = tmean[fB], tsB = tstd[fB];
-    const float nmA = nmean[fA], niA = ninv[fA], nmB = nmean[fB], niB = ninv[fB];
-    const float lbA = lbias[fA], lbB = lbias[fB];
-    // start state: the scattered copies (residual) and the normalised input groups "own quad" and 4
-    float curA = st0[fA], curB = st0[fB];
-    f32x4 xA, xB;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        xA[c] = (st0[4 * fgq + c] - nmean[4 * fgq + c]) * ninv[4 * fgq + c];
-        xB[c] = (st0[16 + c] - nmean[16 + c]) * ninv[16 + c];
-    }
+    // start state: the normalised input groups "own quad" and 4, by the loop's own all-gather
+    f32x4 xA = rows_all_gather((curA - nmA) * niA), xB = rows_all_gather((curB - nmB) * niB);
     __syncthreads();
     Q4S_MARK(8);
 
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     }
 #ifdef BBMPC_KERNEL_DBG
     Q4S_MARK(7);
-    const long long dbg_start = dbg_t0, dbg_cyc0 = (long long)clock64();
+    const long long dbg_cyc0 = (long long)clock64(), dbg_wall0 = (long long)wall_clock64();
 #endif
     for (int t = 0; t < H; ++t) {
         // ---- layer 0, state part: groups 0..3 rotate through the row, group 4 is replicated
@@ -382,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
             mfma4_v(acc0, wA0b[0], xB.x);  mfma4_v(acc1, wA0b[1], xB.y);  mfma4_v(acc2, wA0b[2], xB.z);  mfma4_v(acc0, wA0b[3], xB.w);
             mfma4_results_ready(acc0, acc1, acc2);
             __builtin_amdgcn_sched_barrier(0);
+            Q4S_MARK(12);
             f32x4 o;
             o.x = apply_act_ct<A0>((acc0.x + acc1.x) + acc2.x); o.y = apply_act_ct<A0>((acc0.y + acc1.y) + acc2.y);
             o.z = apply_act_ct<A0>((acc0.z + acc1.z) + acc2.z); o.w = apply_act_ct<A0>((acc0.w + acc1.w) + acc2.w);
@@ -398,17 +408,25 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
             f32x4 bq[KA];
             float bt[KT];
             f32x4 cj0, cj1, cj2, ct;
+            // LDS returns in order and a round waits for what it needs only: group c of the jobs (1 KB per instruction: 104 LDS
+            // cycles per wave for the 13, four waves at once) next to word c of the tail chain; the next step's action groups
+            // (static data, for the action part behind the last layer) last
+            bq[0] = *reinterpret_cast<const f32x4*>(hA0);
+            bt[0] = hT0[0]; bt[1] = hT0[64];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = 0; c < KA; ++c) bq[c] = *reinterpret_cast<const f32x4*>(hA0 + c * 16);
-#pragma unroll
-            for (int mm = 0; mm < KT; ++mm) bt[mm] = hT0[mm * 64];
-            {   // next step's normalised action groups: static data, fetched here so that the action part can follow the
-                // last layer without a wait
+            for (int c = 1; c < KA; ++c) {
+                bq[c] = *reinterpret_cast<const f32x4*>(hA0 + c * 16);
+                if (c + 1 < KT) bt[c + 1] = hT0[(c + 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {
                 const int tn = (t + 1 < H) ? t + 1 : t;
                 ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 0) * 4 + pl) * 4);
                 ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 1) * 4 + pl) * 4);
             }
             __builtin_amdgcn_sched_barrier(0);
+            Q4S_MARK(13);
             mfma4_a_round3t_first(cj0, cj1, cj2, ct, wJ[0], wJ[1], wJ[2], bq[0], wT[0], bt[0]);
 #pragma unroll
             for (int c = 1; c < KA; ++c) mfma4_a_round3t(cj0, cj1, cj2, ct, wJ[0] + 4 * c, wJ[1] + 4 * c, wJ[2] + 4 * c, bq[c], wT[c], bt[c]);
@@ -440,10 +458,12 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
             mfma4_a(cA0, wLA[0][2], s2[0]);    mfma4_a(cA1, wLA[1][2], s2[1]);    mfma4_a(cA2, wLA[2][2], s2[2]);    mfma4_a(cB, wLB[2], h1v[2]);
             mfma4_a(cA0, wLA[0][3], s3[0]);    mfma4_a(cA1, wLA[1][3], s3[1]);    mfma4_a(cA2, wLA[2][3], s3[2]);    mfma4_a(cB, wLTB, h1t);
             mfma4_a(cA0, wLTA, h1t);
+            Q4S_MARK(14);
             // the action part of the NEXT step's layer 0 (independent of everything here) covers the results' latency
             Q4S_ACTION_PART(ba0, ba1);
             mfma4_results_ready(cA0, cA1, cA2, cB);
             __builtin_amdgcn_sched_barrier(0);
+            Q4S_MARK(15);
             const f32x4 sA = {(cA0.x + cA1.x) + cA2.x, (cA0.y + cA1.y) + cA2.y, (cA0.z + cA1.z) + cA2.z, (cA0.w + cA1.w) + cA2.w};
             cB.x = cB.x + dpp_mov<DPP_ROW_ROR8>(cB.x); cB.y = cB.y + dpp_mov<DPP_ROW_ROR8>(cB.y);
             cB.z = cB.z + dpp_mov<DPP_ROW_ROR8>(cB.z); cB.w = cB.w + dpp_mov<DPP_ROW_ROR8>(cB.w);
@@ -463,6 +483,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
             const float c0 = zxB[0], c1 = zxB[80], c2 = zxB[160], c3 = zxB[240];
             float zA = ((a0 + a1) + (a2 + a3)) + lbA;
             float zB = ((c0 + c1) + (c2 + c3)) + lbB;
+            Q4S_MARK(16);
             zA = apply_act_ct<A2>(zA); zB = apply_act_ct<A2>(zB);
             const float vA = (tmA + zA * tsA) + curA, vB = (tmB + zB * tsB) + curB;
             if (rwd_flag_lane) rwd_f[t * 16] = (curA >= flag_thr) ? -10.0f : 0.0f;
@@ -484,8 +505,9 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
 #undef Q4S_ACTION_PART
 #ifdef BBMPC_KERNEL_DBG
     if (blockIdx.x == 0 && blockIdx.y == 0 && (tid == 0 || tid == 128)) {
-        printf("[q4sdbg wave %d] H=%d | small loads issued %lld  operand loads issued %lld  constants+actions %lld  LDS part 2 %lld  first mfma %lld | loop %lld (%lld shader cycles): layer0 %lld bar %lld layer1 mfma %lld reduce+tanh %lld last layer+partials %lld bar %lld sum+epilogue+gather %lld (10ns units)\n",
-               wave, H, dbg_acc[11], dbg_acc[5], dbg_acc[6], dbg_acc[8], dbg_acc[7], (long long)wall_clock64() - dbg_start, (long long)clock64() - dbg_cyc0, dbg_acc[0], dbg_acc[1], dbg_acc[2], dbg_acc[3], dbg_acc[4], dbg_acc[9], dbg_acc[10]);
+        printf("[q4sdbg wave %d] H=%d | small loads issued %lld  operands 1 issued %lld  draws+table loads issued %lld  operands 2 issued %lld  constants+actions %lld  LDS part 2 %lld  first mfma %lld | loop %lld shader cycles in %lld x 10 ns, per step: rot+layer0 mfma %lld  sum+tanh+store %lld  bar1 %lld  lds reads issued %lld  layer1 mfma %lld  reduce+tanh %lld  rot+last mfma %lld  action part %lld  reduce+partials out %lld  bar2 %lld  partials in+sum %lld  epilogue+gather %lld\n",
+               wave, H, dbg_acc[11], dbg_acc[17], dbg_acc[18], dbg_acc[5], dbg_acc[6], dbg_acc[8], dbg_acc[7], (long long)clock64() - dbg_cyc0, (long long)wall_clock64() - dbg_wall0, dbg_acc[12] / H, dbg_acc[0] / H, dbg_acc[1] / H, dbg_acc[13] / H,
+               dbg_acc[2] / H, dbg_acc[3] / H, dbg_acc[14] / H, dbg_acc[15] / H, dbg_acc[4] / H, dbg_acc[9] / H, dbg_acc[16] / H, dbg_acc[10] / H);
     }
 #endif
     // ---- rewards: cost_func.py:5-22 per step, summed in step order (deterministic.py:62-73)
@@ -502,6 +524,13 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
             r = r - zs[e];
             rstep[e] = r;
         }
+    if (tid >= 64 && tid < 64 + QP * U) {                  // (wave 1: next to the step rewards, not in front of the loop)
+        const int pp = (tid - 64) / U, u = (tid - 64) % U;
+        float pen_part = 0.0f;
+        if (q.pen && n0 + pp < p.n_pop)
+            for (int t = 0; t < H; ++t) pen_part = pen_part + d2s[(t * QP + pp) * U + u];
+        pens[tid - 64] = pen_part;
+    }
     __syncthreads();
     if (tid < QP) {
         float total = 0.0f;
@@ -525,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
 
 inline int mlp_q4s_lds_floats(int HG, int K0G, int H, int U) {
     (void)HG;
-    return 64 * 16 + 4 * 80 + ((H * 4 * U + 3) & ~3) + ((4 * U + 3) & ~3) + H * (K0G - 5) * 16 + H * 4 + H * 16 + 6 * 32 + 8;
+    return 64 * 16 + 4 * 80 + ((H * 4 * U + 3) & ~3) + ((4 * U + 3) & ~3) + H * (K0G - 5) * 16 + H * 4 + H * 16 + ((H * 4 * U + 3) & ~3) + 8;
 }
 
 }  // namespace bbmpc
