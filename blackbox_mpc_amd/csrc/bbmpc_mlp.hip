@@ -85,6 +85,15 @@ void Engine::set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, con
             for (int kk = 0; kk < K; ++kk)
                 for (int o = 0; o < M; ++o) wq[((size_t)(kk >> 2) * Mp + o) * 4 + (kk & 3)] = w[l][(size_t)kk * M + o];
             upload(d_wq4[l], wq);
+            if (l == 0 && S <= 20 && U <= 8) {
+                // k_rollout_mlp_q4s keeps five state groups and two action groups whatever dim_S is: the state rows padded to 20
+                std::vector<float> ws((size_t)KG * Mp * 4, 0.0f);
+                for (int kk = 0; kk < K; ++kk) {
+                    const int kp = kk < S ? kk : 20 + (kk - S);
+                    for (int o = 0; o < M; ++o) ws[((size_t)(kp >> 2) * Mp + o) * 4 + (kp & 3)] = w[l][(size_t)kk * M + o];
+                }
+                upload(d_wq4s0, ws);
+            }
         }
         {   // optional bf16 mode operands: [OT][IT][64] x (4 bf16 hi | 4 bf16 lo), k = 16*it + 4*(lane>>4) + r, row = 16*ot + (lane&15)
             auto bf16_rne = [](float x) -> uint16_t {
@@ -148,6 +157,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     q.traj = mlp_traj_out;
     const bool record = mlp_traj_out != nullptr;       // trajectory recording lives in rollout_mlp_body's epilogue only
     for (int l = 0; l < mlp.n_layers; ++l) { q.wraw[l] = d_wraw[l].p; q.braw[l] = d_braw[l].p; q.wq4[l] = d_wq4[l].p; q.wp4[l] = d_wpack4[l].p; q.wbf[l] = reinterpret_cast<const uint4*>(d_wbf[l].p); }
+    q.wq4s0 = d_wq4s0.p;
     const MlpLds lay = mlp_lds_layout(mlp, ra.H, U, S, mlp_nw);
     const size_t lds = (size_t)lay.total * sizeof(float);
     REQUIRE(lds <= 159 * 1024, BBMPC_E_UNSUPPORTED,
@@ -210,32 +220,37 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     // pair mode (two tiles per workgroup, software-pipelined) when there are more tiles than CUs can hold one each
     const long tiles_total = (long)((ra.n_pop + MLP_TP - 1) / MLP_TP) * A;
     // the 26-200-200-20 tanh/tanh/linear family has its own kernels (all of them can record the trajectory)
-    const bool fam_ok = spec == 1 && mlp.tiles[1] == 13 && !per_particle_state && mlp.act[0] == BBMPC_ACT_TANH &&
-                        mlp.act[1] == BBMPC_ACT_TANH && mlp.act[2] == BBMPC_ACT_NONE;
+    const bool fam_dims = spec == 1 && mlp.tiles[1] == 13 && !per_particle_state;     // (spec == 1: two hidden layers of equal tile count, <= 32 inputs and outputs)
+    const bool fam_ok = fam_dims && mlp.act[0] == BBMPC_ACT_TANH && mlp.act[1] == BBMPC_ACT_TANH && mlp.act[2] == BBMPC_ACT_NONE;
     const bool pair_ok = fam_ok;
     int pair = (pair_ok && tiles_total > 256) ? 1 : 0;
     if (sw.mlp_pair >= 0) pair = (sw.mlp_pair != 0 && pair_ok) ? 1 : 0;
     // quad mode (4 particles per workgroup, 4x4x1_16b MFMA, all weights in registers) when the population is too
     // small to give every CU a 16-particle tile
     {
-        const bool q4_ok = fam_ok && mlp.dims[0] <= 28 && mlp.dims[1] == 200 && mlp.dims[2] == 200 && mlp.dims[3] <= 64;
+        const bool q4_dims = mlp.dims[0] <= 28 && mlp.dims[1] == 200 && mlp.dims[2] == 200 && mlp.dims[3] <= 64;
+        const bool q4_ok = fam_ok && q4_dims;
+        const bool q4s_ok = fam_dims && q4_dims && S <= 20 && U <= 8 && mlp.dims[3] == S && d_wq4s0.p != nullptr &&
+                            (ra.reward_kind == REW_CHEETAH || ra.reward_kind == REW_NONE);     // any activations (kernels_mlp_q4s.hpp)
         // measured on MI355X (tools/q4_sweep.py, PI2, H = 30, us per control step): a "wave" of 256 quad workgroups (one
         // per CU, 1024 particles) costs ~400 us, the 16-particle tiling ~850 us for anything up to 4096 particles:
         // quads win up to two waves (N*A <= 2048: 810 vs 860), lose from the third on (2500: 1177 vs 868)
         const long quads_total = (long)((ra.n_pop + 3) / 4) * A;
-        int q4 = (q4_ok && quads_total <= 512) ? 1 : 0;
-        if (sw.mlp_q4 >= 0) q4 = (sw.mlp_q4 != 0 && q4_ok) ? 1 : 0;
+        int q4 = ((q4_ok || q4s_ok) && quads_total <= 512) ? 1 : 0;
+        if (sw.mlp_q4 >= 0) q4 = (sw.mlp_q4 != 0 && (q4_ok || q4s_ok)) ? 1 : 0;
         // register-resident-state form (two barriers per model step, kernels_mlp_q4r.hpp): dim_S == 20, cheetah reward or none
-        if (q4 && !sw.mlp_generic && sw.mlp_q4r && S == 20 && U <= 8 && mlp.dims[3] == 20 &&
-            (ra.reward_kind == REW_CHEETAH || ra.reward_kind == REW_NONE)) {
-            const bool q4s = sw.mlp_q4s != 0;      // four equal waves, the last layer from registers (kernels_mlp_q4s.hpp)
+        if (q4 && !sw.mlp_generic && sw.mlp_q4r && q4s_ok && (sw.mlp_q4s != 0 || (q4_ok && S == 20))) {
+            const bool q4s = sw.mlp_q4s != 0;      // four equal waves, the last layer from registers (kernels_mlp_q4s.hpp); 0: round 3-5's k_rollout_mlp_q4r
             const size_t qlds = (size_t)(q4s ? mlp_q4s_lds_floats(50, 7, ra.H, U) : mlp_q4r_lds_floats(50, 7, ra.H, U)) * sizeof(float);
             const int qpairs = 4 * ((ra.H * U + 3) / 4);
             if (qlds <= 160 * 1024 && qpairs <= Q4R_MAX_ACTION_PAIRS) {
-                auto fn = q4s ? ((qpairs <= 256) ? k_rollout_mlp_q4s<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1>
-                                                 : k_rollout_mlp_q4s<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>)
-                              : ((qpairs <= 256) ? k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1>
-                                                 : k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>);
+                using KFn = void (*)(MlpRolloutArgs);
+                const bool ne1 = qpairs <= 256;
+                const bool relu_net = mlp.act[0] == BBMPC_ACT_RELU && mlp.act[1] == BBMPC_ACT_RELU && mlp.act[2] == BBMPC_ACT_NONE;
+                const KFn fn = !q4s    ? (ne1 ? k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1> : k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>)
+                             : fam_ok  ? (ne1 ? k_rollout_mlp_q4s<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1> : k_rollout_mlp_q4s<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>)
+                             : relu_net ? (ne1 ? k_rollout_mlp_q4s<50, 7, ACT_RELU, ACT_RELU, ACT_NONE, 1> : k_rollout_mlp_q4s<50, 7, ACT_RELU, ACT_RELU, ACT_NONE, 2>)
+                                        : (ne1 ? k_rollout_mlp_q4s<50, 7, ACT_RT, ACT_RT, ACT_RT, 1> : k_rollout_mlp_q4s<50, 7, ACT_RT, ACT_RT, ACT_RT, 2>);
                 if (qlds > 64 * 1024) ensure_max_lds((const void*)fn, 160 * 1024);
                 dim3 qgrid((ra.n_pop + 3) / 4, A), qblock(256);
                 dominant_kernel = q4s ? "k_rollout_mlp_q4s" : "k_rollout_mlp_q4r";
@@ -248,7 +263,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
                 return;
             }
         }
-        if (q4 && !sw.mlp_generic) {
+        if (q4 && q4_ok && !sw.mlp_generic) {
             const size_t qlds = (size_t)mlp_q4_lds_floats(50, 7, 4, ra.H, U, S) * sizeof(float);
             if (qlds <= 160 * 1024) {
                 auto fn = k_rollout_mlp_q4<50, 7, 4, ACT_TANH, ACT_TANH, ACT_NONE>;

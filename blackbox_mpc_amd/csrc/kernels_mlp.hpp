@@ -66,6 +66,7 @@ struct MlpRolloutArgs {
     const float* wraw[MLP_MAX_LAYERS];   // unpacked Dense kernels [in][out] (quad-mode kernel)
     const float* braw[MLP_MAX_LAYERS];   // unpacked biases [out]
     const float* wq4[MLP_MAX_LAYERS];    // quad-mode operands [ceil(in/4)][Mp][4], Mp = out rounded up to 64, zero padded
+    const float* wq4s0;                  // layer 0 in quad-mode order with the STATE rows padded to 20: input k < dim_S at row k, action u at row 20 + u (k_rollout_mlp_q4s)
     const float* wp4[MLP_MAX_LAYERS];    // the operands of MlpDesc::wpack as [OT][IT][64 lanes][4]: a lane's four A operands of a k tile in ONE 16-byte load (generic kernel)
     const uint4* wbf[MLP_MAX_LAYERS];    // bf16 mode operands [OT][IT][64] x (4 bf16 hi | 4 bf16 lo), k = 16*it + 4*(lane>>4) + r
     float* traj;              // optional [H][A][Nst][S]: the state after every step (a user reward function scores them afterwards)

@@ -23,8 +23,10 @@
 //    k = b, b + 16, ... (13 MFMAs, one riding in each round of the three jobs), all-reduced over the 16 blocks.
 // Per wave and model step 26 + 169 + 17 = 212 MFMAs (q4r: 260 on the state waves), two barriers, 13 + 13 LDS reads behind
 // the first and 8 behind the second.
-// Requires dim_S == 20 (five state groups: four rotate inside a row, the fifth is replicated), the HalfCheetah reward or
-// none (a user function scores the recorded trajectory); everything else keeps k_rollout_mlp_q4.
+// Requires dim_S <= 20 (five state groups: four rotate inside a row, the fifth is replicated; a shorter state runs padded: zero
+// rows in the layer-0 pack wq4s0, zero columns in the last layer's, neutral constants), dim_U <= 8, two hidden layers of 200
+// units, the HalfCheetah reward or none (a user function scores the recorded trajectory); activations at compile time for the
+// tanh / relu networks, at run time (ACT_RT) for the rest; everything else keeps k_rollout_mlp_q4.
 #pragma once
 #include "kernels_mlp_q4r.hpp"
 
@@ -54,6 +56,13 @@ __device__ __forceinline__ void mfma4_a_round3t_first(f32x4& c0, f32x4& c1, f32x
                    "a"(w2[0]), "a"(w2[1]), "a"(w2[2]), "a"(w2[3]), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "a"(wt), "v"(bt));
 }
 
+constexpr int ACT_RT = -1;                                // activation taken from MlpDesc::act at run time (a scalar branch per use)
+template <int ACT>
+__device__ __forceinline__ float apply_act_q4s(float x, int rt) {
+    if constexpr (ACT == ACT_RT) return apply_act(x, rt);
+    else return apply_act_ct<ACT>(x);
+}
+
 template <int HG, int K0G, int A0, int A1, int A2, int NE>
 __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -74,6 +83,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
     const int S = p.S, U = p.U, H = p.H;
     const bool normd = m.normalized != 0;
+    const int rt0 = m.act[0], rt1 = m.act[1], rt2 = m.act[2];
     const int row = lane >> 4, blk = lane >> 2, fgq = blk & 3, pl = lane & 3;
     const int pr = ((row & 1) << 1) | (row >> 1);        // element of a reduce-scattered float4 this row holds
     // ---- LDS: h0[HP][4][4] | zx[4 waves][64 + 16] | acts[H][4][U] | pen[4U] | xa[H][AG][4][4] | zs[H][4] | rwd[H][4][4] | d2s[H][4][U]
@@ -110,13 +120,16 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     const int fA = 4 * fgq + pr, fB = 16 + pr, cs = min(tid, S - 1);
     const int u_t = ((tid >> 4) % AG) * 4 + (tid & 3);
     const bool u_on = u_t < U;
-    const float g_msA = (normd ? m.mean_s : p.state)[normd ? fA : 0], g_msB = (normd ? m.mean_s : p.state)[normd ? fB : 0];
-    const float g_ssA = (normd ? m.std_s : p.state)[normd ? fA : 0], g_ssB = (normd ? m.std_s : p.state)[normd ? fB : 0];
-    const float g_mtA = (normd ? m.mean_t : p.state)[normd ? fA : 0], g_mtB = (normd ? m.mean_t : p.state)[normd ? fB : 0];
-    const float g_stA = (normd ? m.std_t : p.state)[normd ? fA : 0], g_stB = (normd ? m.std_t : p.state)[normd ? fB : 0];
+    // (dim_S < 20: the state features past dim_S do not exist -- zero weights in the padded operand packs, neutral constants
+    // and a zero start state keep them at exactly 0 through every step)
+    const bool onA = fA < S, onB = fB < S, nA = normd && onA, nB = normd && onB;
+    const float g_msA = (nA ? m.mean_s : p.state)[nA ? fA : 0], g_msB = (nB ? m.mean_s : p.state)[nB ? fB : 0];
+    const float g_ssA = (nA ? m.std_s : p.state)[nA ? fA : 0], g_ssB = (nB ? m.std_s : p.state)[nB ? fB : 0];
+    const float g_mtA = (nA ? m.mean_t : p.state)[nA ? fA : 0], g_mtB = (nB ? m.mean_t : p.state)[nB ? fB : 0];
+    const float g_stA = (nA ? m.std_t : p.state)[nA ? fA : 0], g_stB = (nB ? m.std_t : p.state)[nB ? fB : 0];
     const float g_mau = (normd ? m.mean_a : p.state)[(normd && u_on) ? u_t : 0], g_sau = (normd ? m.std_a : p.state)[(normd && u_on) ? u_t : 0];
-    const float lbA = q.braw[2][fA], lbB = q.braw[2][fB];
-    float curA = p.state[a * S + fA], curB = p.state[a * S + fB];
+    const float g_lbA = (onA ? q.braw[2] : p.state)[onA ? fA : 0], g_lbB = (onB ? q.braw[2] : p.state)[onB ? fB : 0];
+    const float g_cA = p.state[onA ? a * S + fA : 0], g_cB = p.state[onB ? a * S + fB : 0];
     const float c_st = p.state[a * S + cs];
     // (branch-free: a load under a branch makes the compiler wait for everything in flight at the join, so elements that
     // do not exist / sources a mode does not have read word 0 of the state instead)
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     // is followed by a wait for everything issued so far.
     const int M1 = m.dims[1], M3 = m.dims[3];
     const int Mp1 = (M1 + 63) & ~63, Mp3 = (M3 + 63) & ~63;
-    const float4* __restrict__ Q0 = reinterpret_cast<const float4*>(q.wq4[0]);
+    const float4* __restrict__ Q0 = reinterpret_cast<const float4*>(q.wq4s0);          // layer 0 with the state rows padded to 20 (bbmpc_set_mlp)
     const float4* __restrict__ Q1 = reinterpret_cast<const float4*>(q.wq4[1]);
     const float* __restrict__ Q1f = q.wq4[1];
     const float* __restrict__ Q2f = q.wq4[2];
@@ -273,10 +286,12 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     // ---- the small results: constants to LDS; the action block (mlp_fill_actions' arithmetic, every thread clipping its
     // own elements; xa is scratch for the squared clip distances, summed per (particle, u) in step order below)
     if (q.state_copy && blockIdx.x == 0 && tid < S) q.state_copy[a * S + tid] = c_st;
-    const float nmA = normd ? g_msA : 0.0f, nmB = normd ? g_msB : 0.0f;                       // un-normalised: (x - 0) * 1, 0 + z * 1 = z exactly
-    const float niA = normd ? 1.0f / (g_ssA + 1e-7f) : 1.0f, niB = normd ? 1.0f / (g_ssB + 1e-7f) : 1.0f;
-    const float tmA = normd ? g_mtA : 0.0f, tmB = normd ? g_mtB : 0.0f;
-    const float tsA = normd ? (g_stA + 1e-7f) : 1.0f, tsB = normd ? (g_stB + 1e-7f) : 1.0f;
+    const float nmA = nA ? g_msA : 0.0f, nmB = nB ? g_msB : 0.0f;                             // un-normalised: (x - 0) * 1, 0 + z * 1 = z exactly
+    const float niA = nA ? 1.0f / (g_ssA + 1e-7f) : 1.0f, niB = nB ? 1.0f / (g_ssB + 1e-7f) : 1.0f;
+    const float tmA = nA ? g_mtA : 0.0f, tmB = nB ? g_mtB : 0.0f;
+    const float tsA = nA ? (g_stA + 1e-7f) : 1.0f, tsB = nB ? (g_stB + 1e-7f) : 1.0f;
+    const float lbA = onA ? g_lbA : 0.0f, lbB = onB ? g_lbB : 0.0f;
+    float curA = onA ? g_cA : 0.0f, curB = onB ? g_cB : 0.0f;
     const float nmu = normd ? g_mau : 0.0f, niu = normd ? 1.0f / (g_sau + 1e-7f) : 1.0f;
 #pragma unroll
     for (int i = 0; i < NE; ++i)
@@ -393,8 +408,8 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
             __builtin_amdgcn_sched_barrier(0);
             Q4S_MARK(12);
             f32x4 o;
-            o.x = apply_act_ct<A0>((acc0.x + acc1.x) + acc2.x); o.y = apply_act_ct<A0>((acc0.y + acc1.y) + acc2.y);
-            o.z = apply_act_ct<A0>((acc0.z + acc1.z) + acc2.z); o.w = apply_act_ct<A0>((acc0.w + acc1.w) + acc2.w);
+            o.x = apply_act_q4s<A0>((acc0.x + acc1.x) + acc2.x, rt0); o.y = apply_act_q4s<A0>((acc0.y + acc1.y) + acc2.y, rt0);
+            o.z = apply_act_q4s<A0>((acc0.z + acc1.z) + acc2.z, rt0); o.w = apply_act_q4s<A0>((acc0.w + acc1.w) + acc2.w, rt0);
             if (l0_on) *reinterpret_cast<f32x4*>(h0w) = o;
         }
         Q4S_MARK(0);
@@ -433,15 +448,15 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
             mfma4_results_ready(cj0, cj1, cj2, ct);
             __builtin_amdgcn_sched_barrier(0);
             Q4S_MARK(2);
-            h1v[0] = apply_act_ct<A1>(rows_reduce_scatter(cj0) + b1s[0]);
-            h1v[1] = apply_act_ct<A1>(rows_reduce_scatter(cj1) + b1s[1]);
-            h1v[2] = apply_act_ct<A1>(rows_reduce_scatter(cj2) + b1s[2]);
+            h1v[0] = apply_act_q4s<A1>(rows_reduce_scatter(cj0) + b1s[0], rt1);
+            h1v[1] = apply_act_q4s<A1>(rows_reduce_scatter(cj1) + b1s[1], rt1);
+            h1v[2] = apply_act_q4s<A1>(rows_reduce_scatter(cj2) + b1s[2], rt1);
             // the tail chain: the row's four blocks first (8, then 4: every block adds the same pairs), then the rows
             ct.x = ct.x + dpp_mov<DPP_ROW_ROR8>(ct.x); ct.y = ct.y + dpp_mov<DPP_ROW_ROR8>(ct.y);
             ct.z = ct.z + dpp_mov<DPP_ROW_ROR8>(ct.z); ct.w = ct.w + dpp_mov<DPP_ROW_ROR8>(ct.w);
             ct.x = ct.x + dpp_mov<DPP_ROW_ROR4>(ct.x); ct.y = ct.y + dpp_mov<DPP_ROW_ROR4>(ct.y);
             ct.z = ct.z + dpp_mov<DPP_ROW_ROR4>(ct.z); ct.w = ct.w + dpp_mov<DPP_ROW_ROR4>(ct.w);
-            h1t = apply_act_ct<A1>(rows_reduce_scatter(ct) + b1t);
+            h1t = apply_act_q4s<A1>(rows_reduce_scatter(ct) + b1t, rt1);
         }
         Q4S_MARK(3);
         // ---- the last layer, my hidden features only, straight from the registers: set A (output quad g on block g; round j
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
             float zA = ((a0 + a1) + (a2 + a3)) + lbA;
             float zB = ((c0 + c1) + (c2 + c3)) + lbB;
             Q4S_MARK(16);
-            zA = apply_act_ct<A2>(zA); zB = apply_act_ct<A2>(zB);
+            zA = apply_act_q4s<A2>(zA, rt2); zB = apply_act_q4s<A2>(zB, rt2);
             const float vA = (tmA + zA * tsA) + curA, vB = (tmB + zB * tsB) + curB;
             if (rwd_flag_lane) rwd_f[t * 16] = (curA >= flag_thr) ? -10.0f : 0.0f;
             if (rwd_prog_lane) rwd_d[t * 16] = vB - curB;
@@ -493,8 +508,16 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
                 const f32x4 rA = rows_all_gather(vA), rB = rows_all_gather(vB);
                 if (n0 + pl < p.n_pop) {
                     float* dst = q.traj + ((((size_t)t * p.A + a) * p.Nst) + n0 + pl) * S;
-                    if (wave == 0 && row == 0) *reinterpret_cast<f32x4*>(dst + 4 * fgq) = rA;
-                    if (wave == 0 && row == 1 && fgq == 0) *reinterpret_cast<f32x4*>(dst + 16) = rB;
+                    if (S == 4 * SG) {
+                        if (wave == 0 && row == 0) *reinterpret_cast<f32x4*>(dst + 4 * fgq) = rA;
+                        if (wave == 0 && row == 1 && fgq == 0) *reinterpret_cast<f32x4*>(dst + 16) = rB;
+                    } else if (wave == 0 && row == 0) {    // rows of dim_S floats are not 16-byte aligned
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (4 * fgq + c < S) dst[4 * fgq + c] = rA[c];
+                            if (fgq == 0 && 16 + c < S) dst[16 + c] = rB[c];
+                        }
+                    }
                 }
             }
             xA = rows_all_gather((vA - nmA) * niA);

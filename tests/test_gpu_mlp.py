@@ -480,3 +480,77 @@ def test_profile_instantiation_names_the_template_that_ran(L):
     eng, ev, lo, hi = _problem(L, *CHEETAH, True, A=1, H=5)
     eng.evaluate(O.cheetah_start_states(1, 20), np.zeros((8, 1, 5, 6), F))
     assert eng.profile_instantiation() == eng.get_profile()[2]
+
+
+Q4S_USER_REWARD = """
+__device__ float bbmpc_user_reward(const float* cur, const float* act, const float* nxt, int S, int U) {
+    float r = 0.0f;
+    for (int s = 0; s < S; ++s) r = r + (nxt[s] - cur[s]) * (0.25f + 0.125f * (float)(s & 3));
+    for (int u = 0; u < U; ++u) r = r - 0.0625f * (act[u] * act[u]);
+    return r;
+}
+"""
+
+
+def _q4s_user_reward_np(cur, act, nxt):
+    S, U = cur.shape[1], act.shape[1]
+    r = np.zeros(cur.shape[0], F)
+    for s in range(S):
+        r = (r + ((nxt[:, s] - cur[:, s]).astype(F) * F(0.25 + 0.125 * (s & 3))).astype(F)).astype(F)
+    for u in range(U):
+        r = (r - (F(0.0625) * (act[:, u] * act[:, u]).astype(F)).astype(F)).astype(F)
+    return r
+
+
+@pytest.mark.parametrize("acts,S,U,normalized,N,H", [
+    (["tanh", "tanh", None], 20, 6, True, 100, 30),
+    (["relu", "relu", None], 20, 6, True, 100, 30),            # compile-time relu instantiation
+    (["sigmoid", "tanh", None], 20, 6, True, 37, 12),          # run-time activations
+    (["tanh", "relu", "tanh"], 20, 6, False, 37, 12),          # an activation on the last layer, un-normalised
+    (["tanh", "tanh", None], 18, 6, True, 100, 30),            # dim_S < 20: padded state groups (cheetah reward needs 18)
+    (["relu", "relu", None], 19, 8, True, 64, 9),              # dim_U = 8: both action groups full
+    (["tanh", "tanh", None], 20, 3, False, 41, 50),            # dim_U = 3: action groups mostly padding
+    (["tanh", "tanh", None], 20, 8, False, 41, 40),            # 320 action elements per particle: two (particle, 4-element) pairs per thread
+])
+def test_quad_kernel_q4s_other_activations_and_state_widths(L, acts, S, U, normalized, N, H):
+    # k_rollout_mlp_q4s is compiled for two hidden layers of 200 units; activations and dim_S <= 20 / dim_U <= 8 are free
+    # (SURVEY 8 preamble: stock HalfCheetah-v2 has 17 states; deterministic_mlp.py:5-25 takes any activation list)
+    A = 2
+    dims = [S + U, 200, 200, S]
+    eng, ev, lo, hi = _problem(L, dims, acts, S, U, "cheetah", normalized, A=A, H=H)
+    rng = np.random.default_rng(S * 100 + U)
+    states = rng.normal(0, 0.3, (A, S)).astype(F)
+    seq = rng.uniform(-1, 1, (N, A, H, U)).astype(F)
+    eng.set_profiling(True)
+    got = eng.evaluate(states, seq)
+    assert eng.get_profile()[2] == "k_rollout_mlp_q4s"
+    want = ev(states, seq)
+    assert np.all(np.isfinite(want))
+    assert_cheetah_rewards(got, want, 1e-3, 1e-3 * H, margin=lambda: cheetah_threshold_margin(ev, states, seq))
+
+
+@pytest.mark.parametrize("S,U", [(17, 6), (9, 2)])
+def test_quad_kernel_q4s_short_state_with_user_reward(L, S, U):
+    # dim_S = 17 (stock HalfCheetah-v2) has no built-in reward (cost_func.py:18 indexes state[17]): a user function scores the
+    # trajectory the quad kernel records -- rows of dim_S floats, written element by element when dim_S is no multiple of 4
+    from blackbox_mpc_amd.engine import Engine
+    A, N, H = 2, 100, 20
+    dims, acts = [S + U, 200, 200, S], ["tanh", "tanh", None]
+    ws, bs = O.make_mlp_params(dims, seed=5)
+    rng = np.random.default_rng(S)
+    bs = [rng.normal(0, 0.05, b.shape).astype(F) for b in bs]
+    stats = _stats(S, U, 11)
+    lo, hi = [-1.0] * U, [1.0] * U
+    eng = Engine(L.OPT_NONE, L.DYN_MLP, L.REW_USER, lo, hi, dim_s=S, num_agents=A, planning_horizon=H)
+    eng.set_reward_source(Q4S_USER_REWARD)
+    eng.set_mlp(ws, bs, [ACT[a] for a in acts], stats)
+    ev = O.Evaluator(_q4s_user_reward_np, O.Handler(O.MLP(ws, bs, acts), False, True, stats))
+    states = rng.normal(0, 0.3, (A, S)).astype(F)
+    seq = rng.uniform(-1, 1, (N, A, H, U)).astype(F)
+    eng.set_profiling(True)
+    got = eng.evaluate(states, seq)
+    assert eng.get_profile()[2] == "k_rollout_mlp_q4s"
+    np.testing.assert_allclose(got, ev(states, seq), rtol=1e-3, atol=1e-3 * H)
+    # ... and the next state of a single step through the same network (the tail's kernel) agrees with the oracle
+    a1 = seq[0, :, 0]
+    np.testing.assert_allclose(eng.predict_next_state(states, a1), ev.predict_next_state(states, a1), rtol=2e-5, atol=2e-5)

@@ -43,8 +43,9 @@ SHAPES = [
     ("23-200-200-17 tanh (stock HalfCheetah-v2)", [23, 200, 200, 17], ["tanh", "tanh", None], 17, 6, "user17"),
     ("26-256-256-20 tanh", [26, 256, 256, 20], ["tanh", "tanh", None], 20, 6, "cheetah"),
     ("26-200-200-20 relu", [26, 200, 200, 20], ["relu", "relu", None], 20, 6, "cheetah"),
-    ("26-500-500-500-20 (tutorial_two.py:23-33)", [26, 500, 500, 500, 20], ["relu", "relu", "relu", None], 20, 6, "cheetah"),
-    ("4-32-32-32-3 (tutorial_one.py:38-84)", [4, 32, 32, 32, 3], ["relu", "relu", "relu", None], 3, 1, "pendulum"),
+    ("26-500-500-500-20 (mujoco/tutorial_two.py:23-33)", [26, 500, 500, 500, 20], ["tanh", "tanh", "tanh", None], 20, 6, "cheetah"),
+    ("4-32-32-32-3 (low_level_api/tutorial_one.py:38-84)", [4, 32, 32, 32, 3], ["tanh", "tanh", "tanh", None], 3, 1, "pendulum"),
+    ("26-32-32-32-20 (mujoco/tutorial_one.py:22-31)", [26, 32, 32, 32, 20], ["tanh", "tanh", "tanh", None], 20, 6, "cheetah"),
 ]
 
 
