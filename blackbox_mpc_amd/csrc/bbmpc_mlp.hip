@@ -230,8 +230,10 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     {
         const bool q4_dims = mlp.dims[0] <= 28 && mlp.dims[1] == 200 && mlp.dims[2] == 200 && mlp.dims[3] <= 64;
         const bool q4_ok = fam_ok && q4_dims;
-        const bool q4s_ok = fam_dims && q4_dims && S <= 20 && U <= 8 && mlp.dims[3] == S && d_wq4s0.p != nullptr &&
-                            (ra.reward_kind == REW_CHEETAH || ra.reward_kind == REW_NONE);     // any activations (kernels_mlp_q4s.hpp)
+        // k_rollout_mlp_q4s: two hidden layers of 200 or of 256 units, dim_S <= 20, dim_U <= 8, any activations
+        const bool wide = spec == 1 && mlp.tiles[1] == 16 && !per_particle_state && mlp.dims[0] <= 28 && mlp.dims[1] == 256 && mlp.dims[2] == 256;
+        const bool q4s_ok = ((fam_dims && q4_dims) || wide) && S <= 20 && U <= 8 && mlp.dims[3] == S && d_wq4s0.p != nullptr &&
+                            (ra.reward_kind == REW_CHEETAH || ra.reward_kind == REW_NONE);
         // measured on MI355X (tools/q4_sweep.py, PI2, H = 30, us per control step): a "wave" of 256 quad workgroups (one
         // per CU, 1024 particles) costs ~400 us, the 16-particle tiling ~850 us for anything up to 4096 particles:
         // quads win up to two waves (N*A <= 2048: 810 vs 860), lose from the third on (2500: 1177 vs 868)
@@ -239,7 +241,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
         int q4 = ((q4_ok || q4s_ok) && quads_total <= 512) ? 1 : 0;
         if (sw.mlp_q4 >= 0) q4 = (sw.mlp_q4 != 0 && (q4_ok || q4s_ok)) ? 1 : 0;
         // register-resident-state form (two barriers per model step, kernels_mlp_q4r.hpp): dim_S == 20, cheetah reward or none
-        if (q4 && !sw.mlp_generic && sw.mlp_q4r && q4s_ok && (sw.mlp_q4s != 0 || (q4_ok && S == 20))) {
+        if (q4 && !sw.mlp_generic && sw.mlp_q4r && q4s_ok && (sw.mlp_q4s != 0 || (q4_ok && S == 20 && !wide))) {
             const bool q4s = sw.mlp_q4s != 0;      // four equal waves, the last layer from registers (kernels_mlp_q4s.hpp); 0: round 3-5's k_rollout_mlp_q4r
             const size_t qlds = (size_t)(q4s ? mlp_q4s_lds_floats(50, 7, ra.H, U) : mlp_q4r_lds_floats(50, 7, ra.H, U)) * sizeof(float);
             const int qpairs = 4 * ((ra.H * U + 3) / 4);
@@ -247,7 +249,10 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
                 using KFn = void (*)(MlpRolloutArgs);
                 const bool ne1 = qpairs <= 256;
                 const bool relu_net = mlp.act[0] == BBMPC_ACT_RELU && mlp.act[1] == BBMPC_ACT_RELU && mlp.act[2] == BBMPC_ACT_NONE;
-                const KFn fn = !q4s    ? (ne1 ? k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1> : k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>)
+                const bool tanh_net = mlp.act[0] == BBMPC_ACT_TANH && mlp.act[1] == BBMPC_ACT_TANH && mlp.act[2] == BBMPC_ACT_NONE;
+                const KFn fn = wide    ? (tanh_net ? (ne1 ? k_rollout_mlp_q4s<64, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1> : k_rollout_mlp_q4s<64, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>)
+                                                   : (ne1 ? k_rollout_mlp_q4s<64, 7, ACT_RT, ACT_RT, ACT_RT, 1> : k_rollout_mlp_q4s<64, 7, ACT_RT, ACT_RT, ACT_RT, 2>))
+                             : !q4s    ? (ne1 ? k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1> : k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>)
                              : fam_ok  ? (ne1 ? k_rollout_mlp_q4s<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1> : k_rollout_mlp_q4s<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>)
                              : relu_net ? (ne1 ? k_rollout_mlp_q4s<50, 7, ACT_RELU, ACT_RELU, ACT_NONE, 1> : k_rollout_mlp_q4s<50, 7, ACT_RELU, ACT_RELU, ACT_NONE, 2>)
                                         : (ne1 ? k_rollout_mlp_q4s<50, 7, ACT_RT, ACT_RT, ACT_RT, 1> : k_rollout_mlp_q4s<50, 7, ACT_RT, ACT_RT, ACT_RT, 2>);

@@ -56,6 +56,30 @@ __device__ __forceinline__ void mfma4_a_round3t_first(f32x4& c0, f32x4& c1, f32x
                    "a"(w2[0]), "a"(w2[1]), "a"(w2[2]), "a"(w2[3]), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "a"(wt), "v"(bt));
 }
 
+// One k-group of FOUR layer-1 jobs (256 hidden units: no tail chain) = 16 MFMAs, four chains round robin
+__device__ __forceinline__ void mfma4_a_round4(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, const float* w0, const float* w1, const float* w2,
+                                               const float* w3, const f32x4& b) {
+    asm volatile(BBMPC_MFMA4 "%0, %4, %20, %0\n\t" BBMPC_MFMA4 "%1, %8, %20, %1\n\t" BBMPC_MFMA4 "%2, %12, %20, %2\n\t" BBMPC_MFMA4 "%3, %16, %20, %3\n\t"
+                 BBMPC_MFMA4 "%0, %5, %21, %0\n\t" BBMPC_MFMA4 "%1, %9, %21, %1\n\t" BBMPC_MFMA4 "%2, %13, %21, %2\n\t" BBMPC_MFMA4 "%3, %17, %21, %3\n\t"
+                 BBMPC_MFMA4 "%0, %6, %22, %0\n\t" BBMPC_MFMA4 "%1, %10, %22, %1\n\t" BBMPC_MFMA4 "%2, %14, %22, %2\n\t" BBMPC_MFMA4 "%3, %18, %22, %3\n\t"
+                 BBMPC_MFMA4 "%0, %7, %23, %0\n\t" BBMPC_MFMA4 "%1, %11, %23, %1\n\t" BBMPC_MFMA4 "%2, %15, %23, %2\n\t" BBMPC_MFMA4 "%3, %19, %23, %3"
+                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+                 : "a"(w0[0]), "a"(w0[1]), "a"(w0[2]), "a"(w0[3]), "a"(w1[0]), "a"(w1[1]), "a"(w1[2]), "a"(w1[3]),
+                   "a"(w2[0]), "a"(w2[1]), "a"(w2[2]), "a"(w2[3]), "a"(w3[0]), "a"(w3[1]), "a"(w3[2]), "a"(w3[3]),
+                   "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+}
+__device__ __forceinline__ void mfma4_a_round4_first(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, const float* w0, const float* w1, const float* w2,
+                                                     const float* w3, const f32x4& b) {
+    asm volatile(BBMPC_MFMA4 "%0, %4, %20, 0\n\t"  BBMPC_MFMA4 "%1, %8, %20, 0\n\t"  BBMPC_MFMA4 "%2, %12, %20, 0\n\t"  BBMPC_MFMA4 "%3, %16, %20, 0\n\t"
+                 BBMPC_MFMA4 "%0, %5, %21, %0\n\t" BBMPC_MFMA4 "%1, %9, %21, %1\n\t" BBMPC_MFMA4 "%2, %13, %21, %2\n\t" BBMPC_MFMA4 "%3, %17, %21, %3\n\t"
+                 BBMPC_MFMA4 "%0, %6, %22, %0\n\t" BBMPC_MFMA4 "%1, %10, %22, %1\n\t" BBMPC_MFMA4 "%2, %14, %22, %2\n\t" BBMPC_MFMA4 "%3, %18, %22, %3\n\t"
+                 BBMPC_MFMA4 "%0, %7, %23, %0\n\t" BBMPC_MFMA4 "%1, %11, %23, %1\n\t" BBMPC_MFMA4 "%2, %15, %23, %2\n\t" BBMPC_MFMA4 "%3, %19, %23, %3"
+                 : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+                 : "a"(w0[0]), "a"(w0[1]), "a"(w0[2]), "a"(w0[3]), "a"(w1[0]), "a"(w1[1]), "a"(w1[2]), "a"(w1[3]),
+                   "a"(w2[0]), "a"(w2[1]), "a"(w2[2]), "a"(w2[3]), "a"(w3[0]), "a"(w3[1]), "a"(w3[2]), "a"(w3[3]),
+                   "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+}
+
 constexpr int ACT_RT = -1;                                // activation taken from MlpDesc::act at run time (a scalar branch per use)
 template <int ACT>
 __device__ __forceinline__ float apply_act_q4s(float x, int rt) {
@@ -77,8 +101,9 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     constexpr int TQ = HG - 4 * NW * NJ;                 // hidden quads left over for the tail chains (2: waves 0 and 1)
     constexpr int KT = (HG + 3) / 4;                     // tail chain: MFMAs (block (row, g) takes k = 4*(row + 4m) + g, m < KT)
     constexpr int Q0W = (HG + NW - 1) / NW;              // layer 0: hidden quads per wave (13: blocks 0..12)
-    static_assert(HG < HP && KA * 4 <= HP && 3 + 4 * (KT - 1) < HP && K0G > SG, "padding / input groups");
-    static_assert(NT % (16 * AG) == 0 && NJ == 3 && TQ >= 0 && TQ <= NW && KT == KA && Q0W <= 16 && AG == 2, "written for 200 hidden units, 20 + <= 8 inputs");
+    static_assert(HG <= HP && KA * 4 <= HP && K0G > SG && (TQ == 0 || (HG < HP && 3 + 4 * (KT - 1) < HP)), "padding / input groups");
+    static_assert(NT % (16 * AG) == 0 && ((NJ == 3 && TQ >= 0 && TQ <= NW) || (NJ == 4 && TQ == 0)) && KT == KA && Q0W <= 16 && AG == 2,
+                  "written for 200 hidden units (three jobs per wave + tail chains) and 256 (four jobs), 20 + <= 8 inputs");
     const int a = blockIdx.y, n0 = xcd_tile(blockIdx.x, gridDim.x, blockIdx.y) * QP;     // an XCD's workgroups: contiguous particles
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
     const int S = p.S, U = p.U, H = p.H;
@@ -181,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     const int q0 = Q0W * wave + blk;
     const bool l0_on = blk < Q0W && q0 < HG;
     const int f0 = l0_on ? 4 * q0 + (lane & 3) : 0;      // hidden feature of this lane's layer-0 A operands
-    float wA0r[16], wA0b[4], wA0a[AG * 4], wJ[NJ][KA * 4], wT[KT], wLA[NJ][4], wLB[NJ], wLTA, wLTB;
+    float wA0r[16], wA0b[4], wA0a[AG * 4], wJ[NJ][KA * 4], wT[KT], wLA[NJ][4], wLB[NJ], wLTA = 0.0f, wLTB = 0.0f;
 #pragma unroll
     for (int g = 0; g < AG; ++g) {
         const float4 v = Q0[(size_t)(l0_on ? SG + g : ZROW) * Mp1 + f0];
@@ -252,9 +277,11 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     // the tail chain (hidden quad 4*NW*NJ + wave on the first TQ waves): MFMA m of block (row, g) takes k = 4*(row + 4m) + g
     // (groups 50, 51 of the packed operands and of h0 are zero), output feature 4*(4*NW*NJ + wave) + (lane & 3)
     const bool tail_on = wave < TQ;
+    if constexpr (TQ > 0) {
 #pragma unroll
-    for (int mm = 0; mm < KT; ++mm)
-        wT[mm] = Q1f[((size_t)(tail_on ? row + 4 * mm : ZROW) * Mp1 + 16 * NW * NJ + 4 * wave + (lane & 3)) * 4 + fgq];
+        for (int mm = 0; mm < KT; ++mm)
+            wT[mm] = Q1f[((size_t)(tail_on ? row + 4 * mm : ZROW) * Mp1 + 16 * NW * NJ + 4 * wave + (lane & 3)) * 4 + fgq];
+    }
     // the last layer from registers.  After layer 1 lane (row, g, particle) holds hidden feature 16*job + 4g + pr: round j of
     // set A multiplies the value of block (g - j) & 3, i.e. k = 16*job + 4*((g - j) & 3) + pr, into output quad g; set B
     // multiplies the block's own k into output features 16..19.  The tail value (k = 4*(48 + wave) + pr, the same in the four
@@ -267,8 +294,10 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
             wLA[jj][j] = Q2f[((size_t)(4 * job + ((fgq - j) & 3)) * Mp3 + 4 * fgq + (lane & 3)) * 4 + pr];
         wLB[jj] = Q2f[((size_t)(4 * job + fgq) * Mp3 + 16 + (lane & 3)) * 4 + pr];
     }
-    wLTA = Q2f[((size_t)(tail_on ? 4 * NW * NJ + wave : ZROW) * Mp3 + 4 * fgq + (lane & 3)) * 4 + pr];
-    wLTB = Q2f[((size_t)((tail_on && fgq == 0) ? 4 * NW * NJ + wave : ZROW) * Mp3 + 16 + (lane & 3)) * 4 + pr];
+    if constexpr (TQ > 0) {
+        wLTA = Q2f[((size_t)(tail_on ? 4 * NW * NJ + wave : ZROW) * Mp3 + 4 * fgq + (lane & 3)) * 4 + pr];
+        wLTB = Q2f[((size_t)((tail_on && fgq == 0) ? 4 * NW * NJ + wave : ZROW) * Mp3 + 16 + (lane & 3)) * 4 + pr];
+    }
     // biases: layer 0 enters as the C operand of a chain's first MFMA (my 4 D rows: features 4*quad + r); the K-split
     // products get theirs after the reduction, where a lane holds ONE feature
     f32x4 b0;
@@ -279,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     float b1s[NJ];
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) b1s[jj] = q.braw[1][16 * (wave + NW * jj) + 4 * fgq + pr];
-    const float b1t = q.braw[1][min(16 * NW * NJ + 4 * wave + pr, M1 - 1)];                   // tail: feature 4*(48 + wave) + pr (waves < TQ)
+    const float b1t = TQ > 0 ? q.braw[1][min(16 * NW * NJ + 4 * wave + pr, M1 - 1)] : 0.0f;                   // tail: feature 4*(48 + wave) + pr (waves < TQ)
     __builtin_amdgcn_sched_barrier(0);
     Q4S_MARK(5);
 
@@ -417,69 +446,110 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
         Q4S_MARK(1);
         // ---- layer 1: three 16-feature jobs per wave, K split over the rows, one shared set of B operands; the tail chain
         // rides along, one MFMA per round; stationary A operands in AccVGPRs, read by the MFMA directly
-        float h1v[NJ], h1t;
+        float h1v[NJ], h1t = 0.0f;
         f32x4 ba0, ba1;
         {
             f32x4 bq[KA];
-            float bt[KT];
-            f32x4 cj0, cj1, cj2, ct;
             // LDS returns in order and a round waits for what it needs only: group c of the jobs (1 KB per instruction: 104 LDS
             // cycles per wave for the 13, four waves at once) next to word c of the tail chain; the next step's action groups
             // (static data, for the action part behind the last layer) last
-            bq[0] = *reinterpret_cast<const f32x4*>(hA0);
-            bt[0] = hT0[0]; bt[1] = hT0[64];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 1; c < KA; ++c) {
-                bq[c] = *reinterpret_cast<const f32x4*>(hA0 + c * 16);
-                if (c + 1 < KT) bt[c + 1] = hT0[(c + 1) * 64];
+            if constexpr (NJ == 3) {
+                float bt[KT];
+                f32x4 cj0, cj1, cj2, ct;
+                bq[0] = *reinterpret_cast<const f32x4*>(hA0);
+                bt[0] = hT0[0]; bt[1] = hT0[64];
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            {
-                const int tn = (t + 1 < H) ? t + 1 : t;
-                ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 0) * 4 + pl) * 4);
-                ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 1) * 4 + pl) * 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            Q4S_MARK(13);
-            mfma4_a_round3t_first(cj0, cj1, cj2, ct, wJ[0], wJ[1], wJ[2], bq[0], wT[0], bt[0]);
 #pragma unroll
-            for (int c = 1; c < KA; ++c) mfma4_a_round3t(cj0, cj1, cj2, ct, wJ[0] + 4 * c, wJ[1] + 4 * c, wJ[2] + 4 * c, bq[c], wT[c], bt[c]);
-            mfma4_results_ready(cj0, cj1, cj2, ct);
-            __builtin_amdgcn_sched_barrier(0);
-            Q4S_MARK(2);
-            h1v[0] = apply_act_q4s<A1>(rows_reduce_scatter(cj0) + b1s[0], rt1);
-            h1v[1] = apply_act_q4s<A1>(rows_reduce_scatter(cj1) + b1s[1], rt1);
-            h1v[2] = apply_act_q4s<A1>(rows_reduce_scatter(cj2) + b1s[2], rt1);
-            // the tail chain: the row's four blocks first (8, then 4: every block adds the same pairs), then the rows
-            ct.x = ct.x + dpp_mov<DPP_ROW_ROR8>(ct.x); ct.y = ct.y + dpp_mov<DPP_ROW_ROR8>(ct.y);
-            ct.z = ct.z + dpp_mov<DPP_ROW_ROR8>(ct.z); ct.w = ct.w + dpp_mov<DPP_ROW_ROR8>(ct.w);
-            ct.x = ct.x + dpp_mov<DPP_ROW_ROR4>(ct.x); ct.y = ct.y + dpp_mov<DPP_ROW_ROR4>(ct.y);
-            ct.z = ct.z + dpp_mov<DPP_ROW_ROR4>(ct.z); ct.w = ct.w + dpp_mov<DPP_ROW_ROR4>(ct.w);
-            h1t = apply_act_q4s<A1>(rows_reduce_scatter(ct) + b1t, rt1);
+                for (int c = 1; c < KA; ++c) {
+                    bq[c] = *reinterpret_cast<const f32x4*>(hA0 + c * 16);
+                    if (c + 1 < KT) bt[c + 1] = hT0[(c + 1) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                {
+                    const int tn = (t + 1 < H) ? t + 1 : t;
+                    ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 0) * 4 + pl) * 4);
+                    ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 1) * 4 + pl) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                Q4S_MARK(13);
+                mfma4_a_round3t_first(cj0, cj1, cj2, ct, wJ[0], wJ[1], wJ[2], bq[0], wT[0], bt[0]);
+#pragma unroll
+                for (int c = 1; c < KA; ++c) mfma4_a_round3t(cj0, cj1, cj2, ct, wJ[0] + 4 * c, wJ[1] + 4 * c, wJ[2] + 4 * c, bq[c], wT[c], bt[c]);
+                mfma4_results_ready(cj0, cj1, cj2, ct);
+                __builtin_amdgcn_sched_barrier(0);
+                Q4S_MARK(2);
+                h1v[0] = apply_act_q4s<A1>(rows_reduce_scatter(cj0) + b1s[0], rt1);
+                h1v[1] = apply_act_q4s<A1>(rows_reduce_scatter(cj1) + b1s[1], rt1);
+                h1v[2] = apply_act_q4s<A1>(rows_reduce_scatter(cj2) + b1s[2], rt1);
+                // the tail chain: the row's four blocks first (8, then 4: every block adds the same pairs), then the rows
+                ct.x = ct.x + dpp_mov<DPP_ROW_ROR8>(ct.x); ct.y = ct.y + dpp_mov<DPP_ROW_ROR8>(ct.y);
+                ct.z = ct.z + dpp_mov<DPP_ROW_ROR8>(ct.z); ct.w = ct.w + dpp_mov<DPP_ROW_ROR8>(ct.w);
+                ct.x = ct.x + dpp_mov<DPP_ROW_ROR4>(ct.x); ct.y = ct.y + dpp_mov<DPP_ROW_ROR4>(ct.y);
+                ct.z = ct.z + dpp_mov<DPP_ROW_ROR4>(ct.z); ct.w = ct.w + dpp_mov<DPP_ROW_ROR4>(ct.w);
+                h1t = apply_act_q4s<A1>(rows_reduce_scatter(ct) + b1t, rt1);
+            } else {
+                f32x4 cj0, cj1, cj2, cj3;
+#pragma unroll
+                for (int c = 0; c < KA; ++c) {
+                    bq[c] = *reinterpret_cast<const f32x4*>(hA0 + c * 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                {
+                    const int tn = (t + 1 < H) ? t + 1 : t;
+                    ba0 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 0) * 4 + pl) * 4);
+                    ba1 = *reinterpret_cast<const f32x4*>(xa + ((size_t)(tn * AG + 1) * 4 + pl) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                Q4S_MARK(13);
+                mfma4_a_round4_first(cj0, cj1, cj2, cj3, wJ[0], wJ[1], wJ[2], wJ[3], bq[0]);
+#pragma unroll
+                for (int c = 1; c < KA; ++c) mfma4_a_round4(cj0, cj1, cj2, cj3, wJ[0] + 4 * c, wJ[1] + 4 * c, wJ[2] + 4 * c, wJ[3] + 4 * c, bq[c]);
+                mfma4_results_ready(cj0, cj1, cj2, cj3);
+                __builtin_amdgcn_sched_barrier(0);
+                Q4S_MARK(2);
+                h1v[0] = apply_act_q4s<A1>(rows_reduce_scatter(cj0) + b1s[0], rt1);
+                h1v[1] = apply_act_q4s<A1>(rows_reduce_scatter(cj1) + b1s[1], rt1);
+                h1v[2] = apply_act_q4s<A1>(rows_reduce_scatter(cj2) + b1s[2], rt1);
+                h1v[3] = apply_act_q4s<A1>(rows_reduce_scatter(cj3) + b1s[3], rt1);
+            }
         }
         Q4S_MARK(3);
         // ---- the last layer, my hidden features only, straight from the registers: set A (output quad g on block g; round j
         // takes the value of block g - j), set B (output features 16..19, every block its own k), the tail value last
         {
-            f32x4 cA0, cA1, cA2, cB;
-            const float s1[NJ] = {dpp_mov<DPP_ROW_ROR4>(h1v[0]), dpp_mov<DPP_ROW_ROR4>(h1v[1]), dpp_mov<DPP_ROW_ROR4>(h1v[2])};
-            const float s2[NJ] = {dpp_mov<DPP_ROW_ROR8>(h1v[0]), dpp_mov<DPP_ROW_ROR8>(h1v[1]), dpp_mov<DPP_ROW_ROR8>(h1v[2])};
-            const float s3[NJ] = {dpp_mov<DPP_ROW_ROR12>(h1v[0]), dpp_mov<DPP_ROW_ROR12>(h1v[1]), dpp_mov<DPP_ROW_ROR12>(h1v[2])};
+            f32x4 cA0, cA1, cA2, cA3, cB;
+            float s1[NJ], s2[NJ], s3[NJ];
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                s1[jj] = dpp_mov<DPP_ROW_ROR4>(h1v[jj]); s2[jj] = dpp_mov<DPP_ROW_ROR8>(h1v[jj]); s3[jj] = dpp_mov<DPP_ROW_ROR12>(h1v[jj]);
+            }
             __builtin_amdgcn_sched_barrier(0);
             mfma4_operands_settled();
-            mfma4_a_0(cA0, wLA[0][0], h1v[0]); mfma4_a_0(cA1, wLA[1][0], h1v[1]); mfma4_a_0(cA2, wLA[2][0], h1v[2]); mfma4_a_0(cB, wLB[0], h1v[0]);
-            mfma4_a(cA0, wLA[0][1], s1[0]);    mfma4_a(cA1, wLA[1][1], s1[1]);    mfma4_a(cA2, wLA[2][1], s1[2]);    mfma4_a(cB, wLB[1], h1v[1]);
-            mfma4_a(cA0, wLA[0][2], s2[0]);    mfma4_a(cA1, wLA[1][2], s2[1]);    mfma4_a(cA2, wLA[2][2], s2[2]);    mfma4_a(cB, wLB[2], h1v[2]);
-            mfma4_a(cA0, wLA[0][3], s3[0]);    mfma4_a(cA1, wLA[1][3], s3[1]);    mfma4_a(cA2, wLA[2][3], s3[2]);    mfma4_a(cB, wLTB, h1t);
-            mfma4_a(cA0, wLTA, h1t);
+            if constexpr (NJ == 3) {
+                mfma4_a_0(cA0, wLA[0][0], h1v[0]); mfma4_a_0(cA1, wLA[1][0], h1v[1]); mfma4_a_0(cA2, wLA[2][0], h1v[2]); mfma4_a_0(cB, wLB[0], h1v[0]);
+                mfma4_a(cA0, wLA[0][1], s1[0]);    mfma4_a(cA1, wLA[1][1], s1[1]);    mfma4_a(cA2, wLA[2][1], s1[2]);    mfma4_a(cB, wLB[1], h1v[1]);
+                mfma4_a(cA0, wLA[0][2], s2[0]);    mfma4_a(cA1, wLA[1][2], s2[1]);    mfma4_a(cA2, wLA[2][2], s2[2]);    mfma4_a(cB, wLB[2], h1v[2]);
+                mfma4_a(cA0, wLA[0][3], s3[0]);    mfma4_a(cA1, wLA[1][3], s3[1]);    mfma4_a(cA2, wLA[2][3], s3[2]);    mfma4_a(cB, wLTB, h1t);
+                mfma4_a(cA0, wLTA, h1t);
+            } else {
+                mfma4_a_0(cA0, wLA[0][0], h1v[0]); mfma4_a_0(cA1, wLA[1][0], h1v[1]); mfma4_a_0(cA2, wLA[2][0], h1v[2]); mfma4_a_0(cA3, wLA[3][0], h1v[3]);
+                mfma4_a_0(cB, wLB[0], h1v[0]);
+                mfma4_a(cA0, wLA[0][1], s1[0]);    mfma4_a(cA1, wLA[1][1], s1[1]);    mfma4_a(cA2, wLA[2][1], s1[2]);    mfma4_a(cA3, wLA[3][1], s1[3]);
+                mfma4_a(cB, wLB[1], h1v[1]);
+                mfma4_a(cA0, wLA[0][2], s2[0]);    mfma4_a(cA1, wLA[1][2], s2[1]);    mfma4_a(cA2, wLA[2][2], s2[2]);    mfma4_a(cA3, wLA[3][2], s2[3]);
+                mfma4_a(cB, wLB[2], h1v[2]);
+                mfma4_a(cA0, wLA[0][3], s3[0]);    mfma4_a(cA1, wLA[1][3], s3[1]);    mfma4_a(cA2, wLA[2][3], s3[2]);    mfma4_a(cA3, wLA[3][3], s3[3]);
+                mfma4_a(cB, wLB[3], h1v[3]);
+            }
             Q4S_MARK(14);
             // the action part of the NEXT step's layer 0 (independent of everything here) covers the results' latency
             Q4S_ACTION_PART(ba0, ba1);
-            mfma4_results_ready(cA0, cA1, cA2, cB);
+            if constexpr (NJ == 3) mfma4_results_ready(cA0, cA1, cA2, cB);
+            else mfma4_results_ready(cA0, cA1, cA2, cA3, cB);
             __builtin_amdgcn_sched_barrier(0);
             Q4S_MARK(15);
-            const f32x4 sA = {(cA0.x + cA1.x) + cA2.x, (cA0.y + cA1.y) + cA2.y, (cA0.z + cA1.z) + cA2.z, (cA0.w + cA1.w) + cA2.w};
+            f32x4 sA = {(cA0.x + cA1.x) + cA2.x, (cA0.y + cA1.y) + cA2.y, (cA0.z + cA1.z) + cA2.z, (cA0.w + cA1.w) + cA2.w};
+            if constexpr (NJ == 4) { sA.x = sA.x + cA3.x; sA.y = sA.y + cA3.y; sA.z = sA.z + cA3.z; sA.w = sA.w + cA3.w; }
             cB.x = cB.x + dpp_mov<DPP_ROW_ROR8>(cB.x); cB.y = cB.y + dpp_mov<DPP_ROW_ROR8>(cB.y);
             cB.z = cB.z + dpp_mov<DPP_ROW_ROR8>(cB.z); cB.w = cB.w + dpp_mov<DPP_ROW_ROR8>(cB.w);
             cB.x = cB.x + dpp_mov<DPP_ROW_ROR4>(cB.x); cB.y = cB.y + dpp_mov<DPP_ROW_ROR4>(cB.y);

@@ -554,3 +554,23 @@ def test_quad_kernel_q4s_short_state_with_user_reward(L, S, U):
     # ... and the next state of a single step through the same network (the tail's kernel) agrees with the oracle
     a1 = seq[0, :, 0]
     np.testing.assert_allclose(eng.predict_next_state(states, a1), ev.predict_next_state(states, a1), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("acts,S,U,normalized,N,H", [
+    (["tanh", "tanh", None], 20, 6, True, 100, 30),
+    (["relu", "sigmoid", None], 18, 8, False, 37, 40),         # run-time activations, dim_S < 20, two action pairs per thread
+])
+def test_quad_kernel_q4s_256_hidden_units(L, acts, S, U, normalized, N, H):
+    # the four-job form of k_rollout_mlp_q4s: 26-256-256-20, every wave four 16-feature jobs of layer 1 and no tail chain
+    A = 2
+    dims = [S + U, 256, 256, S]
+    eng, ev, lo, hi = _problem(L, dims, acts, S, U, "cheetah", normalized, A=A, H=H)
+    rng = np.random.default_rng(S * 10 + U)
+    states = rng.normal(0, 0.3, (A, S)).astype(F)
+    seq = rng.uniform(-1, 1, (N, A, H, U)).astype(F)
+    eng.set_profiling(True)
+    got = eng.evaluate(states, seq)
+    assert eng.get_profile()[2] == "k_rollout_mlp_q4s"
+    want = ev(states, seq)
+    assert np.all(np.isfinite(want))
+    assert_cheetah_rewards(got, want, 1e-3, 1e-3 * H, margin=lambda: cheetah_threshold_margin(ev, states, seq))
