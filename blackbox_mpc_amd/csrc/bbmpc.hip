@@ -191,7 +191,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.cma_fused = flag("BBMPC_CMA_FUSED");
         sw.mlp_generic = flag("BBMPC_MLP_GENERIC");
         { const int b = ival("BBMPC_MLP_BF16", 0); sw.mlp_bf16 = (b == 1 || b == 3) ? b : 0; }
-        sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1); sw.mlp_q4r = ival("BBMPC_MLP_Q4R", 1); sw.mlp_q4s = ival("BBMPC_MLP_Q4S", 1); sw.pi2_skip_init = ival("BBMPC_PI2_SKIP_INIT", 1); sw.step_graph = ival("BBMPC_STEP_GRAPH", 1); sw.cma_small3 = ival("BBMPC_CMA_SMALL3", 1);
+        sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1); sw.mlp_q4s = ival("BBMPC_MLP_Q4S", ival("BBMPC_MLP_Q4R", 1)); sw.pi2_skip_init = ival("BBMPC_PI2_SKIP_INIT", 1); sw.step_graph = ival("BBMPC_STEP_GRAPH", 1); sw.cma_small3 = ival("BBMPC_CMA_SMALL3", 1);
         sw.refit_wgs = ival("BBMPC_REFIT_WGS", 0);
         sw.mlp_wave = ival("BBMPC_MLP_WAVE", 1);
         sw.linger_us = std::max(0, ival("BBMPC_LINGER_US", 200));
@@ -1098,7 +1098,7 @@ void Engine::optimize_dev(const float* d_state_in, int add_noise, float* d_recor
             break;
         }
         case BBMPC_OPT_PI2: {
-            // Learned model on the quad kernel (k_rollout_mlp_q4r): from the second control step on k_dist_init (4.3 us, a
+            // Learned model on the quad kernel (k_rollout_mlp_q4s): from the second control step on k_dist_init (4.3 us, a
             // launch of its own in front of a 360 us control step) has nothing left to do -- PI2 never changes sigma, the
             // first rollout samples around prev_mean directly, the refit writes every element of the mean, and the first
             // rollout reads the state from the pinned buffer itself (its workgroup 0 stores it for the later launches).

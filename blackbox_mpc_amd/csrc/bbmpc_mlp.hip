@@ -240,25 +240,23 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
         const long quads_total = (long)((ra.n_pop + 3) / 4) * A;
         int q4 = ((q4_ok || q4s_ok) && quads_total <= 512) ? 1 : 0;
         if (sw.mlp_q4 >= 0) q4 = (sw.mlp_q4 != 0 && (q4_ok || q4s_ok)) ? 1 : 0;
-        // register-resident-state form (two barriers per model step, kernels_mlp_q4r.hpp): dim_S == 20, cheetah reward or none
-        if (q4 && !sw.mlp_generic && sw.mlp_q4r && q4s_ok && (sw.mlp_q4s != 0 || (q4_ok && S == 20 && !wide))) {
-            const bool q4s = sw.mlp_q4s != 0;      // four equal waves, the last layer from registers (kernels_mlp_q4s.hpp); 0: round 3-5's k_rollout_mlp_q4r
-            const size_t qlds = (size_t)(q4s ? mlp_q4s_lds_floats(50, 7, ra.H, U) : mlp_q4r_lds_floats(50, 7, ra.H, U)) * sizeof(float);
+        // four equal waves, the state in registers, the last layer from registers, two barriers per model step (kernels_mlp_q4s.hpp)
+        if (q4 && !sw.mlp_generic && sw.mlp_q4s && q4s_ok) {
+            const size_t qlds = (size_t)mlp_q4s_lds_floats(wide ? 64 : 50, 7, ra.H, U) * sizeof(float);
             const int qpairs = 4 * ((ra.H * U + 3) / 4);
-            if (qlds <= 160 * 1024 && qpairs <= Q4R_MAX_ACTION_PAIRS) {
+            if (qlds <= 160 * 1024 && qpairs <= Q4S_MAX_ACTION_PAIRS) {
                 using KFn = void (*)(MlpRolloutArgs);
                 const bool ne1 = qpairs <= 256;
-                const bool relu_net = mlp.act[0] == BBMPC_ACT_RELU && mlp.act[1] == BBMPC_ACT_RELU && mlp.act[2] == BBMPC_ACT_NONE;
                 const bool tanh_net = mlp.act[0] == BBMPC_ACT_TANH && mlp.act[1] == BBMPC_ACT_TANH && mlp.act[2] == BBMPC_ACT_NONE;
-                const KFn fn = wide    ? (tanh_net ? (ne1 ? k_rollout_mlp_q4s<64, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1> : k_rollout_mlp_q4s<64, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>)
-                                                   : (ne1 ? k_rollout_mlp_q4s<64, 7, ACT_RT, ACT_RT, ACT_RT, 1> : k_rollout_mlp_q4s<64, 7, ACT_RT, ACT_RT, ACT_RT, 2>))
-                             : !q4s    ? (ne1 ? k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1> : k_rollout_mlp_q4r<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>)
-                             : fam_ok  ? (ne1 ? k_rollout_mlp_q4s<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1> : k_rollout_mlp_q4s<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>)
+                const bool relu_net = mlp.act[0] == BBMPC_ACT_RELU && mlp.act[1] == BBMPC_ACT_RELU && mlp.act[2] == BBMPC_ACT_NONE;
+                const KFn fn = wide     ? (tanh_net ? (ne1 ? k_rollout_mlp_q4s<64, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1> : k_rollout_mlp_q4s<64, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>)
+                                                    : (ne1 ? k_rollout_mlp_q4s<64, 7, ACT_RT, ACT_RT, ACT_RT, 1> : k_rollout_mlp_q4s<64, 7, ACT_RT, ACT_RT, ACT_RT, 2>))
+                             : tanh_net ? (ne1 ? k_rollout_mlp_q4s<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 1> : k_rollout_mlp_q4s<50, 7, ACT_TANH, ACT_TANH, ACT_NONE, 2>)
                              : relu_net ? (ne1 ? k_rollout_mlp_q4s<50, 7, ACT_RELU, ACT_RELU, ACT_NONE, 1> : k_rollout_mlp_q4s<50, 7, ACT_RELU, ACT_RELU, ACT_NONE, 2>)
                                         : (ne1 ? k_rollout_mlp_q4s<50, 7, ACT_RT, ACT_RT, ACT_RT, 1> : k_rollout_mlp_q4s<50, 7, ACT_RT, ACT_RT, ACT_RT, 2>);
                 if (qlds > 64 * 1024) ensure_max_lds((const void*)fn, 160 * 1024);
                 dim3 qgrid((ra.n_pop + 3) / 4, A), qblock(256);
-                dominant_kernel = q4s ? "k_rollout_mlp_q4s" : "k_rollout_mlp_q4r";
+                dominant_kernel = "k_rollout_mlp_q4s";
                 q.state_copy = mlp_state_copy;
                 mlp_state_copy = nullptr;
                 prof_begin();

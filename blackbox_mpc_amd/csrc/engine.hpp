@@ -23,7 +23,6 @@
 #include "kernels_fused_cma.hpp"
 #include "kernels_fused_pso.hpp"
 #include "kernels_mlp.hpp"
-#include "kernels_mlp_q4r.hpp"
 #include "kernels_mlp_q4s.hpp"
 #include "kernels_mlp_wave.hpp"
 #include "kernels_opt.hpp"
@@ -124,8 +123,7 @@ struct Engine {
         bool mlp_generic = false;      // BBMPC_MLP_GENERIC
         int mlp_bf16 = 0;              // BBMPC_MLP_BF16: 0 off (default, fp32), 1 plain bf16 inputs, 3 split bf16 (hi+lo, three products)
         int mlp_pair = -1, mlp_q4 = -1;   // BBMPC_MLP_PAIR / BBMPC_MLP_Q4: -1 automatic, 0 / 1 forced
-        int mlp_q4r = 1;                  // BBMPC_MLP_Q4R=0: keep k_rollout_mlp_q4 where k_rollout_mlp_q4r would run
-        int mlp_q4s = 1;                  // BBMPC_MLP_Q4S=0: keep k_rollout_mlp_q4r (round 3-5) where k_rollout_mlp_q4s would run
+        int mlp_q4s = 1;                  // BBMPC_MLP_Q4S=0 (and the older spelling BBMPC_MLP_Q4R=0): keep k_rollout_mlp_q4 where k_rollout_mlp_q4s would run
         int cma_small3 = 1;               // BBMPC_CMA_SMALL3=0: n <= 32 keeps one launch per phase (eleven per iteration) instead of sample | roll out | update
         int step_graph = 1;               // BBMPC_STEP_GRAPH=0: never replay a control step as a hipGraph
         int pi2_skip_init = 1;            // BBMPC_PI2_SKIP_INIT=0: k_dist_init opens every PI2 / CEM control step on the learned-model path too
@@ -279,7 +277,7 @@ struct Engine {
     DevBuf<float> u_traj;              // [H][A][Nst][S] states after every step of the MFMA rollout
     float* mlp_traj_out = nullptr;     // set around a launch_rollout_mlp call that should record the trajectory
     // set around a launch_rollout_mlp call whose state argument is the pinned host buffer: a kernel that can store the
-    // state for the later launches itself (k_rollout_mlp_q4r) takes the request and clears it
+    // state for the later launches itself (k_rollout_mlp_q4s) takes the request and clears it
     float* mlp_state_copy = nullptr;
     bool pi2_dist_ready = false;       // d_sigma holds the constructor variance's root (PI2 never changes it)
     bool pi2_copy_seen = false;        // the previous control step's first rollout took such a request

@@ -70,7 +70,7 @@ struct MlpRolloutArgs {
     const float* wp4[MLP_MAX_LAYERS];    // the operands of MlpDesc::wpack as [OT][IT][64 lanes][4]: a lane's four A operands of a k tile in ONE 16-byte load (generic kernel)
     const uint4* wbf[MLP_MAX_LAYERS];    // bf16 mode operands [OT][IT][64] x (4 bf16 hi | 4 bf16 lo), k = 16*it + 4*(lane>>4) + r
     float* traj;              // optional [H][A][Nst][S]: the state after every step (a user reward function scores them afterwards)
-    float* state_copy;        // optional [A][S] (k_rollout_mlp_q4r): r.state is the pinned host buffer of this control step, workgroup 0 of
+    float* state_copy;        // optional [A][S] (k_rollout_mlp_q4s): r.state is the pinned host buffer of this control step, workgroup 0 of
                               // an agent's row stores the state here for the later launches and the tail
 };
 

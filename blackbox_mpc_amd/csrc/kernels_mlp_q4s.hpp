@@ -1,38 +1,120 @@
-// Quad mode, last layer from registers ("q4s"): k_rollout_mlp_q4r with FOUR equal waves, two barriers per model step and
-// no activation of layer 1 ever leaving the registers.  Same fused path (reference files under blackbox_mpc/):
+// Quad mode ("q4s"): the learned-model rollout for populations too small to give every CU a 16-particle tile -- 4 particles
+// per workgroup on v_mfma_f32_4x4x1_16b_f32, four equal waves (one per SIMD), ALL weights stationary in registers, the state
+// in registers, two barriers per model step.  The fused path (reference files under blackbox_mpc/):
 //   SystemDynamicsHandler.process_input / process_output   dynamics_handlers/system_dynamics_handler.py:97-161
 //   DeterministicMLP.__call__                              dynamics_functions/deterministic_mlp.py:27-51
 //   reward_function                                        tutorials/mujoco/cost_func.py:5-22
 //   DeterministicTrajectoryEvaluator.__call__              trajectory_evaluators/deterministic.py:26-77
 //
-// What k_rollout_mlp_q4r paid for (profiles/r5_cfg4pi2.md: 0.31 of the fp32 matrix peak, pipe 0.43 busy): every state wave
-// computed the WHOLE 200 -> 20 layer (68 MFMAs where its share is 16) from a copy of h1 that had to cross LDS behind a
-// barrier, a helper wave held no state, and a third barrier covered the helper's late job.  Here:
-//  * layer 1 as before (jobs of 16 output features, K split over the MFMA's four 16-lane rows, reduce-scatter in
-//    registers), after which lane (row, quad g, particle p) holds tanh(h1) of feature 16*job + 4g + pr(row) -- which IS a
-//    B operand of v_mfma_f32_4x4x1_16b_f32: one k per block, the four particles in the block's four lanes.  The last layer
-//    takes it from there: per job four MFMAs for output features 0..15 (block g produces output quad g; round j multiplies
-//    the value of block g - j, fetched by a DPP row rotation, so that every block meets every k of its row) and one for
-//    features 16..19 (every block its own k): 17 MFMAs per wave instead of 68, no h1 in LDS, and the K split of the last
-//    layer is across the WAVES' own hidden features -- what crosses LDS behind the second barrier is 80 partial sums per
-//    wave instead of 800 activations;
+// v_mfma_f32_4x4x1_16b_f32 is 16 independent 4x4 outer products (blocks of four lanes: A = 4 output features x 1 k, B = 1 k x
+// 4 particles), and nothing says the 16 blocks have to work on the same k or the same features:
+//  * layer 0: block b of wave w produces hidden quad 13w + b from the whole input (26 MFMAs per wave).  Every wave holds the
+//    state: a lane keeps the normalised input groups "own quad" and 4 of its particle and takes the other three state groups
+//    from its row neighbours by DPP rotation -- block g multiplies group (g - j) mod 4 in round j, its stationary A operands
+//    are loaded in that order once.  The action part (independent of the state) is issued one step ahead.  h0 crosses LDS
+//    behind the first barrier;
+//  * layer 1 runs as "jobs" of 16 output features: block (row r, quad g) = features 16j + 4g .. +3 over the k slice of
+//    16-lane row r (13 k groups), three jobs per wave sharing ONE set of B operands, the K split reduced in registers
+//    (v_permlane32_swap / v_permlane16_swap as a reduce-scatter: 4 registers -> 1 in 6 instructions), after which lane
+//    (row, quad g, particle p) holds the activation of feature 16*job + 4g + pr(row) -- which IS a B operand of the
+//    instruction: one k per block, the four particles in the block's four lanes;
+//  * so the last layer takes it from there: per job four MFMAs for output features 0..15 (block g produces output quad g;
+//    round j multiplies the value of block g - j, fetched by a DPP row rotation, so that every block meets every k of its
+//    row) and one for features 16..19 (every block its own k): 17 MFMAs per wave, no h1 in LDS, and the K split of the last
+//    layer is across the WAVES' own hidden features -- what crosses LDS behind the second barrier is 80 partial sums per wave;
 //  * every wave then adds the four partials and runs the epilogue (bias, de-normalisation, residual, normalisation,
-//    all-gather by lane swaps) redundantly, so all four waves hold the state and layer 0 is shared four ways: block b of
-//    wave w produces hidden quad 13w + b (26 MFMAs per wave instead of 36 on three);
+//    all-gather by lane swaps) redundantly: 1-2 values per lane;
 //  * the hidden features 192..199 (two quads nobody's three jobs cover) are one more chain on waves 0 and 1: block b takes
 //    k = b, b + 16, ... (13 MFMAs, one riding in each round of the three jobs), all-reduced over the 16 blocks.
-// Per wave and model step 26 + 169 + 17 = 212 MFMAs (q4r: 260 on the state waves), two barriers, 13 + 13 LDS reads behind
-// the first and 8 behind the second.
+// Per wave and model step 26 + 169 + 17 = 212 MFMAs, 13 + 13 LDS reads behind the first barrier and 8 behind the second.
+// Rounds 3-5 ran this shape as k_rollout_mlp_q4r (three state waves + a helper, every state wave computing the WHOLE 200 -> 20
+// layer from a copy of h1 in LDS: 260 MFMAs per state wave and step, three barriers): 61.4 us per 1000 x 30-step launch against
+// 57.0 us here (profiles/r5_cfg4pi2.md, r6_cfg4pi2.md; profiles/NOTES_r6.md has what was measured on the way).
 // Requires dim_S <= 20 (five state groups: four rotate inside a row, the fifth is replicated; a shorter state runs padded: zero
 // rows in the layer-0 pack wq4s0, zero columns in the last layer's, neutral constants), dim_U <= 8, two hidden layers of 200
-// units, the HalfCheetah reward or none (a user function scores the recorded trajectory); activations at compile time for the
-// tanh / relu networks, at run time (ACT_RT) for the rest; everything else keeps k_rollout_mlp_q4.
+// units (HG = 50) or of 256 (HG = 64: four jobs per wave, no tail chain), the HalfCheetah reward or none (a user function scores
+// the recorded trajectory); activations at compile time for the tanh / relu networks, at run time (ACT_RT) for the rest;
+// everything else keeps k_rollout_mlp_q4 or the 16-particle tilings.
 #pragma once
-#include "kernels_mlp_q4r.hpp"
+#include "kernels_mlp.hpp"
 
 namespace bbmpc {
 
-// One k-group of three layer-1 jobs + one MFMA of the tail chain = 13 MFMAs in ONE asm statement (see mfma4_a_round3)
+constexpr int Q4S_MAX_ACTION_PAIRS = 512;               // (particle, 4 consecutive action-sequence elements) pairs a workgroup's threads keep in registers across the operand loads
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    // all lanes are sources here (row rotations), so no "old" value has to be materialised (bound_ctrl)
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128, DPP_ROW_ROR12 = 0x12c;   // dst[i] = src[(i - n) & 15] in each 16-lane row
+// a = [a.lo32 | b.lo32], b = [a.hi32 | b.hi32]              (tools/microbench/lane_ops.hip prints the maps)
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(a), __float_as_int(b), false, false);
+    a = __int_as_float(r[0]); b = __int_as_float(r[1]);
+}
+// rows of 16 lanes: a = [a.r0, b.r0, a.r2, b.r2], b = [a.r1, b.r1, a.r3, b.r3]
+__device__ __forceinline__ void swap16(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(a), __float_as_int(b), false, false);
+    a = __int_as_float(r[0]); b = __int_as_float(r[1]);
+}
+// sum over the four 16-lane rows of four registers at once: row r of the result holds the total of v[{0,2,1,3}[r]]
+__device__ __forceinline__ float rows_reduce_scatter(f32x4 v) {
+    float a0 = v.x, a1 = v.y, a2 = v.z, a3 = v.w;
+    swap32(a0, a1);
+    swap32(a2, a3);
+    float t01 = a0 + a1, t23 = a2 + a3;
+    swap16(t01, t23);
+    return t01 + t23;
+}
+// inverse: row r holds element {0,2,1,3}[r]; afterwards every row holds all four
+__device__ __forceinline__ f32x4 rows_all_gather(float z) {
+    float v0 = z, v1 = z;
+    swap16(v0, v1);                 // v0 = [z0 z0 z2 z2], v1 = [z1 z1 z3 z3]   (z_r = row r's value)
+    float c0 = v0, c1 = v1;
+    swap32(v0, c0);                 // v0 = z0 everywhere, c0 = z2 everywhere
+    swap32(v1, c1);                 // v1 = z1,            c1 = z3
+    f32x4 o;
+    o.x = v0; o.y = c0; o.z = v1; o.w = c1;       // rows hold elements 0, 2, 1, 3: z0 = e0, z2 = e1, z1 = e2, z3 = e3
+    return o;
+}
+// ---- MFMAs through inline asm: accumulators stay in VGPRs (the compiler gives builtin MFMAs AccVGPR destinations as
+// soon as the kernel touches AccVGPRs at all and then pays a v_accvgpr_read per result register), the stationary A
+// operand comes from a VGPR ("v") or straight from an AccVGPR ("a"), and the first MFMA of a chain takes its C operand
+// from the bias registers (or the inline constant 0) instead of a copy.  The compiler neither sees the instruction nor
+// pads its hazards (cdna_hip_programming.md 5.7): every sequence below
+//   * starts behind a sched_barrier + mfma4_operands_settled() (VALU-written operands -> MFMA read: 2 wait states),
+//   * keeps consecutive MFMAs on one accumulator >= 3 issues apart (three or four chains, round robin),
+//   * ends with mfma4_results_ready() (2-pass MFMA result -> VALU read: 4 wait states), which also ties the accumulators.
+#define BBMPC_MFMA4 "v_mfma_f32_4x4x1_16b_f32 "
+__device__ __forceinline__ void mfma4_v(f32x4& acc, float a, float b) {
+    asm volatile(BBMPC_MFMA4 "%0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma4_v_c(f32x4& acc, float a, float b, const f32x4& c) {
+    asm volatile(BBMPC_MFMA4 "%0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void mfma4_v_0(f32x4& acc, float a, float b) {
+    asm volatile(BBMPC_MFMA4 "%0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma4_a(f32x4& acc, float a_in_agpr, float b) {
+    asm volatile(BBMPC_MFMA4 "%0, %1, %2, %0" : "+v"(acc) : "a"(a_in_agpr), "v"(b));
+}
+__device__ __forceinline__ void mfma4_a_0(f32x4& acc, float a_in_agpr, float b) {
+    asm volatile(BBMPC_MFMA4 "%0, %1, %2, 0" : "=&v"(acc) : "a"(a_in_agpr), "v"(b));
+}
+__device__ __forceinline__ void mfma4_operands_settled() { asm volatile("s_nop 1"); }
+__device__ __forceinline__ void mfma4_results_ready(f32x4& c0, f32x4& c1, f32x4& c2) {
+    asm volatile("s_nop 4" : "+v"(c0), "+v"(c1), "+v"(c2));
+}
+__device__ __forceinline__ void mfma4_results_ready(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3) {
+    asm volatile("s_nop 4" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+}
+__device__ __forceinline__ void mfma4_results_ready(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, f32x4& c4) {
+    asm volatile("s_nop 4" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4));
+}
+
+// One k-group of three layer-1 jobs + one MFMA of the tail chain = 13 MFMAs in ONE asm statement (four chains, round robin):
+// between separate statements the compiler pads every re-use of an accumulator with an s_nop it cannot know to be unnecessary
 __device__ __forceinline__ void mfma4_a_round3t(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& ct, const float* w0, const float* w1, const float* w2,
                                                 const f32x4& b, float wt, float bt) {
     asm volatile(BBMPC_MFMA4 "%0, %4, %16, %0\n\t" BBMPC_MFMA4 "%1, %8, %16, %1\n\t" BBMPC_MFMA4 "%2, %12, %16, %2\n\t"

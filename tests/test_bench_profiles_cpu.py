@@ -57,14 +57,14 @@ def _latest(kind):
 
 def test_profile_entry_needs_the_exact_instantiation():
     ent = {"void k_fused_pendulum<2, true, false, 2, 1, false>": 1, "void k_fused_pendulum<2, true, true, 2, 1, false>": 2,
-           "void k_fused_pendulum<2, true, true, 2, 1, true>": 3, "k_noise_fill": 4, "void k_rollout_mlp_q4r<50, 7, 1, 1, 0, 1>": 5}
+           "void k_fused_pendulum<2, true, true, 2, 1, true>": 3, "k_noise_fill": 4, "void k_rollout_mlp_q4s<50, 7, 1, 1, 0, 1>": 5}
     pe = bench.profile_entry
     assert pe(ent, "k_fused_pendulum", "k_fused_pendulum<2, true, true, 2, 1, false>")[1] == 2
     assert pe(ent, "k_fused_pendulum", "k_fused_pendulum<2, true, false, 2, 1, false>")[1] == 1
     assert pe(ent, "k_fused_pendulum", "k_fused_pendulum<2, true, true, 2, 1, true>")[1] == 3
     assert pe(ent, "k_fused_pendulum", "k_fused_pendulum") is None                      # ambiguous plain name: attach nothing
     assert pe(ent, "k_fused_pendulum", "k_fused_pendulum<3, true, true, 2, 1, false>") is None
-    assert pe(ent, "k_rollout_mlp_q4r", "k_rollout_mlp_q4r")[1] == 5                  # one instantiation: the plain name will do
+    assert pe(ent, "k_rollout_mlp_q4s", "k_rollout_mlp_q4s")[1] == 5                  # one instantiation: the plain name will do
     assert pe(ent, "k_noise_fill", "k_noise_fill")[1] == 4
     assert pe(ent, "k_rollout_mlp", "k_rollout_mlp") is None                            # not a prefix match
 
