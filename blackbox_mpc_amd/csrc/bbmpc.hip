@@ -191,7 +191,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.cma_fused = flag("BBMPC_CMA_FUSED");
         sw.mlp_generic = flag("BBMPC_MLP_GENERIC");
         { const int b = ival("BBMPC_MLP_BF16", 0); sw.mlp_bf16 = (b == 1 || b == 3) ? b : 0; }
-        sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1); sw.mlp_q4s = ival("BBMPC_MLP_Q4S", ival("BBMPC_MLP_Q4R", 1)); sw.pi2_skip_init = ival("BBMPC_PI2_SKIP_INIT", 1); sw.step_graph = ival("BBMPC_STEP_GRAPH", 1); sw.cma_small3 = ival("BBMPC_CMA_SMALL3", 1);
+        sw.mlp_pair = ival("BBMPC_MLP_PAIR", -1); sw.mlp_q4 = ival("BBMPC_MLP_Q4", -1); sw.mlp_q4s = ival("BBMPC_MLP_Q4S", ival("BBMPC_MLP_Q4R", 1)); sw.mlp_w4 = ival("BBMPC_MLP_W4", 1); sw.pi2_skip_init = ival("BBMPC_PI2_SKIP_INIT", 1); sw.step_graph = ival("BBMPC_STEP_GRAPH", 1); sw.cma_small3 = ival("BBMPC_CMA_SMALL3", 1);
         sw.refit_wgs = ival("BBMPC_REFIT_WGS", 0);
         sw.mlp_wave = ival("BBMPC_MLP_WAVE", 1);
         sw.linger_us = std::max(0, ival("BBMPC_LINGER_US", 200));

@@ -185,6 +185,28 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
         prof_end();
         return;
     }
+    // small networks, one wave per four particles and nothing through LDS between layers (kernels_mlp_w4.hpp): 2..4 Dense
+    // layers of at most 32 units, dim_S <= 20, dim_U <= 8 -- the reference tutorials' 4-32-32-32-3 and 26-32-32-32-20
+    if (!sw.mlp_generic && sw.mlp_w4 != 0 && !single_step && mlp.n_layers >= 2 && mlp.n_layers <= 4 && S <= 20 && U <= 8) {
+        bool small = true, tanh_net = mlp.act[mlp.n_layers - 1] == BBMPC_ACT_NONE;
+        for (int l = 1; l < mlp.n_layers; ++l) small = small && mlp.dims[l] <= 32;
+        for (int l = 0; l + 1 < mlp.n_layers; ++l) tanh_net = tanh_net && mlp.act[l] == BBMPC_ACT_TANH;
+        const size_t wlds = (size_t)mlp_w4_lds_layout(ra.H, U, S).total * sizeof(float);
+        if (small && wlds <= 159 * 1024) {
+            using KFn = void (*)(MlpRolloutArgs);
+            static const KFn table[2][3] = {{k_rollout_mlp_w4<2, false>, k_rollout_mlp_w4<3, false>, k_rollout_mlp_w4<4, false>},
+                                            {k_rollout_mlp_w4<2, true>, k_rollout_mlp_w4<3, true>, k_rollout_mlp_w4<4, true>}};
+            const KFn wfn = table[tanh_net ? 1 : 0][mlp.n_layers - 2];
+            if (wlds > 64 * 1024) ensure_max_lds((const void*)wfn, 159 * 1024);
+            dim3 wgrid((ra.n_pop + W4_TP - 1) / W4_TP, per_particle_state ? 1 : A), wblock(256);
+            dominant_kernel = "k_rollout_mlp_w4";
+            prof_begin();
+            hipLaunchKernelGGL(wfn, wgrid, wblock, wlds, stream, q);
+            HIP_CHECK(hipGetLastError());
+            prof_end();
+            return;
+        }
+    }
     // small networks: one wave per 16-particle tile, the whole Dense stack in its registers (kernels_mlp_wave.hpp)
     if (!sw.mlp_generic && sw.mlp_wave != 0 && !single_step && small_io && mlp.n_layers >= 2 && mlp.n_layers <= 4 && mlp.tiles[1] <= 4) {
         bool same = true;

@@ -24,6 +24,7 @@
 #include "kernels_fused_pso.hpp"
 #include "kernels_mlp.hpp"
 #include "kernels_mlp_q4s.hpp"
+#include "kernels_mlp_w4.hpp"
 #include "kernels_mlp_wave.hpp"
 #include "kernels_opt.hpp"
 #include "kernels_refit.hpp"
@@ -123,6 +124,7 @@ struct Engine {
         bool mlp_generic = false;      // BBMPC_MLP_GENERIC
         int mlp_bf16 = 0;              // BBMPC_MLP_BF16: 0 off (default, fp32), 1 plain bf16 inputs, 3 split bf16 (hi+lo, three products)
         int mlp_pair = -1, mlp_q4 = -1;   // BBMPC_MLP_PAIR / BBMPC_MLP_Q4: -1 automatic, 0 / 1 forced
+        int mlp_w4 = 1;                   // BBMPC_MLP_W4=0: keep k_rollout_mlp_wave where k_rollout_mlp_w4 (hidden <= 32) would run
         int mlp_q4s = 1;                  // BBMPC_MLP_Q4S=0 (and the older spelling BBMPC_MLP_Q4R=0): keep k_rollout_mlp_q4 where k_rollout_mlp_q4s would run
         int cma_small3 = 1;               // BBMPC_CMA_SMALL3=0: n <= 32 keeps one launch per phase (eleven per iteration) instead of sample | roll out | update
         int step_graph = 1;               // BBMPC_STEP_GRAPH=0: never replay a control step as a hipGraph

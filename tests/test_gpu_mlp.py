@@ -339,12 +339,19 @@ WAVE_SPECS = [
 ]
 
 
+@pytest.mark.parametrize("form", ["wave", "w4"])
 @pytest.mark.parametrize("spec,normalized", WAVE_SPECS)
-def test_small_networks_run_the_wave_kernel_and_match(L, monkeypatch, spec, normalized):
+def test_small_networks_run_the_wave_kernel_and_match(L, monkeypatch, spec, normalized, form):
     # hidden width <= 64: kernels_mlp_wave.hpp (one wave per hidden tile, the recurrence in registers, a reward wave);
-    # checked against the oracle at the evaluator tolerance and against the general kernel (same arithmetic up to the
-    # order in which the last layer's bias joins the K-split partial sums) much tighter
+    # hidden width <= 32: kernels_mlp_w4.hpp (one wave per four particles, nothing through LDS between layers), the default
+    # there.  Checked against the oracle at the evaluator tolerance and against the general kernel (same arithmetic up to
+    # the order in which the bias and the K-split partial sums are added) much tighter
     dims, acts, S, U, reward = spec
+    w4_shape = max(dims[1:-1]) <= 32
+    if form == "w4" and not w4_shape:
+        pytest.skip("k_rollout_mlp_w4 takes hidden layers of at most 32 units")
+    if form == "wave":
+        monkeypatch.setenv("BBMPC_MLP_W4", "0")
     N, A, H = 77, 2, 25
     rng = np.random.default_rng(11)
     states = O.cheetah_start_states(A, S) if reward == "cheetah" else O.pendulum_start_states(A)
@@ -352,7 +359,7 @@ def test_small_networks_run_the_wave_kernel_and_match(L, monkeypatch, spec, norm
     eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, normalized, A=A, H=H)
     eng.set_profiling(True)
     got = eng.evaluate(states, seq)
-    assert eng.get_profile()[2] == "k_rollout_mlp_wave"
+    assert eng.get_profile()[2] == "k_rollout_mlp_" + form
     want = ev(states, seq)
     assert np.all(np.isfinite(want))
     if reward == "cheetah":
@@ -360,17 +367,23 @@ def test_small_networks_run_the_wave_kernel_and_match(L, monkeypatch, spec, norm
     else:
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-3 * H)
     monkeypatch.setenv("BBMPC_MLP_WAVE", "0")
+    monkeypatch.setenv("BBMPC_MLP_W4", "0")
     gen, _, _, _ = _problem(L, dims, acts, S, U, reward, normalized, A=A, H=H)
     monkeypatch.delenv("BBMPC_MLP_WAVE")
+    monkeypatch.delenv("BBMPC_MLP_W4")
     gen.set_profiling(True)
     ref = gen.evaluate(states, seq)
-    assert gen.get_profile()[2] != "k_rollout_mlp_wave"
-    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * H)
+    assert gen.get_profile()[2] not in ("k_rollout_mlp_wave", "k_rollout_mlp_w4")
+    if reward == "cheetah":
+        assert_cheetah_rewards(got, ref, 2e-5, 2e-5 * H, margin=lambda: cheetah_threshold_margin(ev, states, seq))
+    else:
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * H)
 
 
-def test_wave_kernel_in_the_optimizers(L, monkeypatch):
+@pytest.mark.parametrize("form", ["wave", "w4"])
+def test_wave_kernel_in_the_optimizers(L, monkeypatch, form):
     # PI2 (clip + penalty candidates), CEM and the __call__ tail on the tutorial network: same injected draws through the
-    # wave kernel and the general kernel
+    # small-network kernel (k_rollout_mlp_wave / k_rollout_mlp_w4) and the general kernel
     dims, acts, S, U, reward = PEND_MLP
     N, A, H, iters = 200, 3, 12, 3
     states = O.pendulum_start_states(A)
@@ -378,16 +391,18 @@ def test_wave_kernel_in_the_optimizers(L, monkeypatch):
     draws = np.stack([O.truncated_normal_noise(rng, (N, A, H, U)) for _ in range(iters)])
     for opt, kw in ((L.OPT_PI2, dict(lamda=2.0)), (L.OPT_CEM, dict(k=20))):
         out = []
-        for wave in ("1", "0"):
-            monkeypatch.setenv("BBMPC_MLP_WAVE", wave)
+        for small in (True, False):
+            monkeypatch.setenv("BBMPC_MLP_WAVE", "1" if small else "0")
+            monkeypatch.setenv("BBMPC_MLP_W4", "1" if (small and form == "w4") else "0")
             eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, True, A=A, H=H, opt=opt, N=N, iters=iters, **kw)
             eng.set_trace(True)
             eng.set_profiling(True)
             eng.inject_noise(L.NOISE_TRUNC_NORMAL, draws)
             a, n, r = eng.optimize(states)
-            assert (eng.get_profile()[2] == "k_rollout_mlp_wave") == (wave == "1")
+            assert (eng.get_profile()[2] == "k_rollout_mlp_" + form) == small
             out.append((a, n, r, [eng.get_trace(it, L.TRACE_REWARDS) for it in range(iters)]))
         monkeypatch.delenv("BBMPC_MLP_WAVE")
+        monkeypatch.delenv("BBMPC_MLP_W4")
         for it in range(iters):
             np.testing.assert_allclose(out[0][3][it], out[1][3][it], rtol=1e-4, atol=1e-3)
         np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=2e-3)

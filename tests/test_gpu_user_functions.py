@@ -160,7 +160,7 @@ def test_user_reward_over_the_learned_model_agrees_with_the_fused_path(L):
 
 def test_user_reward_over_a_small_learned_pendulum_model(L, user_rollout_form):
     # the tutorials' learned Pendulum model (4-32-32-32-3) with a user reward: the small-network kernel
-    # (kernels_mlp_wave.hpp) records the trajectory, the user function scores it
+    # (kernels_mlp_w4.hpp) records the trajectory, the user function scores it
     from blackbox_mpc_amd.engine import Engine
     S, U, A, H, N = 3, 1, 2, 15, 150
     dims, acts = [4, 32, 32, 32, 3], ["tanh", "tanh", "tanh", None]
@@ -176,7 +176,7 @@ def test_user_reward_over_a_small_learned_pendulum_model(L, user_rollout_form):
     user.set_profiling(True)
     got = user.evaluate(states, seq)
     if user_rollout_form != "stepwise":
-        assert user.get_profile()[2] == "k_rollout_mlp_wave"
+        assert user.get_profile()[2] == "k_rollout_mlp_w4"           # (hidden <= 32; BBMPC_MLP_W4=0: k_rollout_mlp_wave)
     np.testing.assert_allclose(got, ev(states, seq), rtol=1e-3, atol=1e-3 * H)
 
 
