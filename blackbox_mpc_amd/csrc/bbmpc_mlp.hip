@@ -122,6 +122,21 @@ void Engine::set_mlp(int n_layers, const int32_t* dims, const int32_t* acts, con
         mlp.wpack[l] = d_wpack[l].p;
         mlp.bpack[l] = d_bpack[l].p;
     }
+    {   // k_rollout_mlp_w4 (2..4 Dense layers of at most 32 units, dim_S <= 20, dim_U <= 8): operands in lane order
+        bool small = n_layers >= 2 && n_layers <= 4 && S <= 20 && U <= 8;
+        for (int l = 1; l < n_layers; ++l) small = small && dims[l] <= 32;
+        d_w4pack.release();
+        if (small) {
+            std::vector<float> wp((size_t)n_layers * W4_OPS * 64, 0.0f);
+            for (int l = 0; l < n_layers; ++l)
+                for (int op = 0; op < W4_OPS; ++op)
+                    for (int ln = 0; ln < 64; ++ln) {
+                        const int idx = mlp_w4_operand_index(l, op, ln, dims[l], dims[l + 1], S, U);
+                        if (idx >= 0) wp[((size_t)l * W4_OPS + op) * 64 + ln] = op < 16 ? w[l][idx] : b[l][idx];
+                    }
+            upload(d_w4pack, wp);
+        }
+    }
     mlp.normalized = is_normalized ? 1 : 0;
     if (is_normalized) {
         REQUIRE(stats, BBMPC_E_INVALID, "normalisation statistics are required when is_normalized != 0");
@@ -158,6 +173,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     const bool record = mlp_traj_out != nullptr;       // trajectory recording lives in rollout_mlp_body's epilogue only
     for (int l = 0; l < mlp.n_layers; ++l) { q.wraw[l] = d_wraw[l].p; q.braw[l] = d_braw[l].p; q.wq4[l] = d_wq4[l].p; q.wp4[l] = d_wpack4[l].p; q.wbf[l] = reinterpret_cast<const uint4*>(d_wbf[l].p); }
     q.wq4s0 = d_wq4s0.p;
+    q.w4pack = d_w4pack.p;
     const MlpLds lay = mlp_lds_layout(mlp, ra.H, U, S, mlp_nw);
     const size_t lds = (size_t)lay.total * sizeof(float);
     REQUIRE(lds <= 159 * 1024, BBMPC_E_UNSUPPORTED,
@@ -187,9 +203,9 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
     }
     // small networks, one wave per four particles and nothing through LDS between layers (kernels_mlp_w4.hpp): 2..4 Dense
     // layers of at most 32 units, dim_S <= 20, dim_U <= 8 -- the reference tutorials' 4-32-32-32-3 and 26-32-32-32-20
-    if (!sw.mlp_generic && sw.mlp_w4 != 0 && !single_step && mlp.n_layers >= 2 && mlp.n_layers <= 4 && S <= 20 && U <= 8) {
-        bool small = true, tanh_net = mlp.act[mlp.n_layers - 1] == BBMPC_ACT_NONE;
-        for (int l = 1; l < mlp.n_layers; ++l) small = small && mlp.dims[l] <= 32;
+    if (!sw.mlp_generic && sw.mlp_w4 != 0 && !single_step && d_w4pack.p != nullptr) {
+        const bool small = true;                                   // (bbmpc_set_mlp packed the operands: the shape qualifies)
+        bool tanh_net = mlp.act[mlp.n_layers - 1] == BBMPC_ACT_NONE;
         for (int l = 0; l + 1 < mlp.n_layers; ++l) tanh_net = tanh_net && mlp.act[l] == BBMPC_ACT_TANH;
         const size_t wlds = (size_t)mlp_w4_lds_layout(ra.H, U, S).total * sizeof(float);
         if (small && wlds <= 159 * 1024) {

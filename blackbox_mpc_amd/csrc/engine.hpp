@@ -150,7 +150,7 @@ struct Engine {
     bool mlp_ready = false;
     MlpDesc mlp;
     int mlp_nw = 1;
-    DevBuf<float> d_wpack[MLP_MAX_LAYERS], d_wpack4[MLP_MAX_LAYERS], d_bpack[MLP_MAX_LAYERS], d_wraw[MLP_MAX_LAYERS], d_braw[MLP_MAX_LAYERS], d_wq4[MLP_MAX_LAYERS], d_wq4s0, d_wbf[MLP_MAX_LAYERS], d_stats;
+    DevBuf<float> d_wpack[MLP_MAX_LAYERS], d_wpack4[MLP_MAX_LAYERS], d_bpack[MLP_MAX_LAYERS], d_wraw[MLP_MAX_LAYERS], d_braw[MLP_MAX_LAYERS], d_wq4[MLP_MAX_LAYERS], d_wq4s0, d_w4pack, d_wbf[MLP_MAX_LAYERS], d_stats;
     DevBuf<float> d_fin_next, d_fin_rew, d_step_act;
     // SPSA / PSO state (internal layout)
     DevBuf<float> d_cand_a, d_cand_b, d_rewards2, d_vel, d_pbest, d_pbest_r, d_gbest, d_gbest_r, d_cond;

@@ -66,6 +66,7 @@ struct MlpRolloutArgs {
     const float* wraw[MLP_MAX_LAYERS];   // unpacked Dense kernels [in][out] (quad-mode kernel)
     const float* braw[MLP_MAX_LAYERS];   // unpacked biases [out]
     const float* wq4[MLP_MAX_LAYERS];    // quad-mode operands [ceil(in/4)][Mp][4], Mp = out rounded up to 64, zero padded
+    const float* w4pack;                 // k_rollout_mlp_w4's operands in lane order: [layer][16 operands + 2 biases][64 lanes] (bbmpc_set_mlp)
     const float* wq4s0;                  // layer 0 in quad-mode order with the STATE rows padded to 20: input k < dim_S at row k, action u at row 20 + u (k_rollout_mlp_q4s)
     const float* wp4[MLP_MAX_LAYERS];    // the operands of MlpDesc::wpack as [OT][IT][64 lanes][4]: a lane's four A operands of a k tile in ONE 16-byte load (generic kernel)
     const uint4* wbf[MLP_MAX_LAYERS];    // bf16 mode operands [OT][IT][64] x (4 bf16 hi | 4 bf16 lo), k = 16*it + 4*(lane>>4) + r
@@ -258,6 +259,24 @@ __device__ __forceinline__ int xcd_tile(int bx, int gx, int by) {
     return base + ((bx - ((xr - off) & 7)) >> 3);
 }
 
+// Candidate value of action-sequence element j = t*U + u of particle n (< n_pop), agent a, before the clip: the given
+// sequence (SRC_REF / SRC_BUF), or the sampling distribution around a standard draw (injected, or the engine's own counter
+// generator) -- optimizer_base.py:55-95's candidates as the rollout kernels see them.
+__device__ __forceinline__ float mlp_candidate_value(const MlpRolloutArgs& q, int a, int n, int j, int u) {
+    const RolloutArgs& p = q.r;
+    if (q.mode == SRC_REF) return p.seq[((size_t)n * p.A + a) * p.HU + j];
+    if (q.mode == SRC_BUF) return p.cand[((size_t)a * p.HU + j) * p.Nst + n];
+    float xi;
+    if (p.inj) xi = p.inj[((size_t)a * p.HU + j) * p.Nst + n];
+    else {
+        const U4 blk = rng_block(p.key, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j);
+        const uint32_t w = pick_word(blk, (uint32_t)j);
+        xi = (q.mode == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
+    }
+    if (q.mode == SRC_UNIFORM) return xi * (p.hi[u] - p.lo[u]) + p.lo[u];
+    return xi * p.sigma[a * p.HU + j] + p.mean[a * p.HU + j];
+}
+
 template <int TP>
 __device__ __forceinline__ void mlp_fill_actions(const MlpRolloutArgs& q, int a, int n0, int tid, int nthr,
                                                  float* acts, float* pens) {
@@ -275,19 +294,7 @@ __device__ __forceinline__ void mlp_fill_actions(const MlpRolloutArgs& q, int a,
         const int n = n0 + pp;
         float x = 0.0f;
         if (n < p.n_pop) {
-            if (q.mode == SRC_REF) x = p.seq[((size_t)n * p.A + a) * p.HU + j];
-            else if (q.mode == SRC_BUF) x = p.cand[((size_t)a * p.HU + j) * p.Nst + n];
-            else {
-                float xi;
-                if (p.inj) xi = p.inj[((size_t)a * p.HU + j) * p.Nst + n];
-                else {
-                    const U4 blk = rng_block(p.key, p.stream, p.iter, (uint32_t)(n + p.pop_offset), (uint32_t)(p.agent_offset + a), (uint32_t)j);
-                    const uint32_t w = pick_word(blk, (uint32_t)j);
-                    xi = (q.mode == SRC_UNIFORM) ? word_to_uniform(w) : word_to_trunc_normal(w);
-                }
-                if (q.mode == SRC_UNIFORM) x = xi * (p.hi[u] - p.lo[u]) + p.lo[u];
-                else x = xi * p.sigma[a * p.HU + j] + p.mean[a * p.HU + j];
-            }
+            x = mlp_candidate_value(q, a, n, j, u);
             if (!q.pen && p.samples) p.samples[((size_t)a * p.HU + j) * p.Nst + n] = x;
         }
         acts[e] = x;                                    // unclipped when q.pen: clipped in place below

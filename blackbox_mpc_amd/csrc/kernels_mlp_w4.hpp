@@ -26,10 +26,35 @@
 namespace bbmpc {
 
 constexpr int W4_TP = 16;                                 // particles per workgroup (four per wave)
-// LDS, in floats: acts [H][16][U] | pens | xa [H][16][8] normalised actions | ring [H+1][16][Sp] raw states | rstep [H][16]
+// LDS, in floats: acts [H][16][U] | pens | xa [H][16][8] normalised actions | ring [H+1][16][Sp] raw states | rstep [H][16] |
+//                 d2s [H][16][U] squared clip distances (summed per (particle, u) in step order behind the recurrence)
 struct MlpW4Lds {
-    int acts, pens, xa, ring, rstep, total;
+    int acts, pens, xa, ring, rstep, d2s, total;
 };
+constexpr int W4_OPS = 18;                                // operands per lane and layer: 16 A operands + 2 biases
+// lane -> (row, quad g, i): what bbmpc_set_mlp packs for it (and the kernel below reads back as one coalesced load each)
+__host__ __device__ inline void mlp_w4_lane(int lane, int& kh, int& qo, int& i0, int& g) {
+    const int row = lane >> 4;
+    g = (lane >> 2) & 3;
+    kh = row >> 1;                                        // the K half the lane's block multiplies
+    qo = 4 * (row & 1) + g;                               // the output quad the block produces
+    i0 = row >> 1;                                        // the lane keeps features 4*qo + i0 and 4*qo + i0 + 2 after the fold
+}
+// Operand `op` (< 16: rotation j = op >> 2, register c = op & 3; 16, 17: the two biases) of layer l for `lane`: index into the
+// Dense kernel [in][out] / the bias, or -1 for padding.  The first layer's k runs over (state 0..19 | action 20..27).
+__host__ __device__ inline int mlp_w4_operand_index(int l, int op, int lane, int K, int M, int S, int U) {
+    int kh, qo, i0, g;
+    mlp_w4_lane(lane, kh, qo, i0, g);
+    if (op >= 16) {
+        const int f = 4 * qo + i0 + 2 * (op - 16);
+        return f < M ? f : -1;
+    }
+    const int j = op >> 2, c = op & 3;
+    const int k = 4 * (4 * kh + ((g - j) & 3)) + c, o = 4 * qo + (lane & 3);
+    int kk = k;
+    if (l == 0) kk = k < 20 ? (k < S ? k : -1) : (k - 20 < U ? S + k - 20 : -1);
+    return (kk >= 0 && kk < K && o < M) ? kk * M + o : -1;
+}
 __host__ __device__ inline MlpW4Lds mlp_w4_lds_layout(int H, int U, int S) {
     MlpW4Lds l;
     const int Sp = (S + 3) & ~3;
@@ -39,6 +64,7 @@ __host__ __device__ inline MlpW4Lds mlp_w4_lds_layout(int H, int U, int S) {
     l.xa = o;   o += H * W4_TP * 8;
     l.ring = o; o += (H + 1) * W4_TP * Sp;
     l.rstep = o; o += H * W4_TP;
+    l.d2s = o; o += ((H * W4_TP * U + 3) & ~3);
     l.total = o;
     return l;
 }
@@ -60,7 +86,15 @@ __global__ __launch_bounds__(256) void k_rollout_mlp_w4(MlpRolloutArgs q) {
     float* xa = smem + lay.xa;
     float* ring = smem + lay.ring;
     float* rstep = smem + lay.rstep;
+    float* d2s = smem + lay.d2s;
     const bool normd = m.normalized != 0;
+#ifdef BBMPC_KERNEL_DBG
+    long long dbg_t[8]; int dbg_i = 0;
+#define W4_MARK() do { __builtin_amdgcn_sched_barrier(0); dbg_t[dbg_i++] = (long long)wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define W4_MARK() do {} while (0)
+#endif
+    W4_MARK();
     const int row = lane >> 4, g = (lane >> 2) & 3, pl = lane & 3;
     const int kh = row >> 1;                              // the K half my block multiplies
     const int qo = 4 * (row & 1) + g;                     // the output quad my block produces (and the input quad my two registers hold)
@@ -69,24 +103,15 @@ __global__ __launch_bounds__(256) void k_rollout_mlp_w4(MlpRolloutArgs q) {
     const int pp = 4 * wave + pl, n = n0 + pp;            // my particle
 
     // ---- stationary A operands: layer l, rotation j, register c multiplies k = 4*(4*kh + ((g - j) & 3)) + c into output
-    // feature 4*qo + (lane & 3); the first layer's k runs over (state 0..19 | action 20..27), padding is zero
+    // feature 4*qo + (lane & 3) (mlp_w4_operand_index); packed in lane order by bbmpc_set_mlp: one coalesced load each
+    // (gathered here from the Dense kernels with their index arithmetic they were 5.5 us of a 40 us launch)
     float wS[NL][16], bS[NL][2];
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-        const int K = m.dims[l], M = m.dims[l + 1];
-        const int o = 4 * qo + (lane & 3);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int k = 4 * (4 * kh + ((g - j) & 3)) + c;
-                int kk = k;                               // the row of the Dense kernel [in][out]
-                if (l == 0) kk = k < 20 ? (k < S ? k : -1) : (k - 20 < U ? S + k - 20 : -1);
-                const bool on = kk >= 0 && kk < K && o < M;
-                wS[l][4 * j + c] = on ? q.wraw[l][(size_t)kk * M + o] : 0.0f;
-            }
-        bS[l][0] = fa < M ? q.braw[l][fa] : 0.0f;
-        bS[l][1] = fb < M ? q.braw[l][fb] : 0.0f;
+        for (int op = 0; op < 16; ++op) wS[l][op] = q.w4pack[(l * W4_OPS + op) * 64 + lane];
+        bS[l][0] = q.w4pack[(l * W4_OPS + 16) * 64 + lane];
+        bS[l][1] = q.w4pack[(l * W4_OPS + 17) * 64 + lane];
     }
     // ---- my two slots of the (state | action) vector: constants of process_input / process_output
     //      (system_dynamics_handler.py:119-122, 152-155; un-normalised: (x - 0) * 1, 0 + z * 1)
@@ -103,8 +128,30 @@ __global__ __launch_bounds__(256) void k_rollout_mlp_w4(MlpRolloutArgs q) {
 
     // ---- prologue: the 16 particles' action block [H][16][U] (candidate -> clip / penalty -> store), as the other kernels;
     //      then the normalised copies in the slot order of the input vector, [t][particle][8]
-    mlp_fill_actions<W4_TP>(q, a, n0, tid, 256, acts, pens);
+    W4_MARK();
+    // (mlp_fill_actions' arithmetic with every element clipped by the thread that made it; the squared clip distances are
+    // parked and summed per (particle, u) in step order behind the recurrence instead of in front of it)
+    for (int e2 = tid; e2 < H * W4_TP * U; e2 += 256) {   // particle fastest: the stores to the particle-minor sample matrix are 64-byte segments
+        const int tpp = e2 % W4_TP, j = e2 / W4_TP;
+        const int t = j / U, u = j - t * U;
+        const int e = (t * W4_TP + tpp) * U + u;
+        const int nn = n0 + tpp;
+        float x = 0.0f, d2 = 0.0f;
+        if (nn < p.n_pop) {
+            x = mlp_candidate_value(q, a, nn, j, u);
+            if (q.pen) {
+                const float xf = clipf(x, p.lo[u], p.hi[u]);
+                const float d = x - xf;
+                d2 = d * d;
+                x = xf;
+            }
+            if (p.samples) p.samples[((size_t)a * p.HU + j) * p.Nst + nn] = x;
+        }
+        acts[e] = x;
+        d2s[e] = d2;
+    }
     __syncthreads();
+    W4_MARK();
     {
         const int u = tid & 7;                            // (256 is a multiple of 8: a thread's action slot is the same in every pass)
         const bool on = u < U;
@@ -125,6 +172,7 @@ __global__ __launch_bounds__(256) void k_rollout_mlp_w4(MlpRolloutArgs q) {
     // the input vector of step 0 in my two slots
     float v0 = sa ? (curA - nmA) * niA : (aa ? xaA[0] : 0.0f);
     float v1 = sb ? (curB - nmB) * niB : (ab ? xaB[0] : 0.0f);
+    W4_MARK();
     for (int t = 0; t < H; ++t) {
         const int tn = (t + 1 < H) ? t + 1 : t;
         const float an0 = xaA[tn * 128], an1 = xaB[tn * 128];      // next step's action slots: static data, a step ahead
@@ -169,10 +217,19 @@ __global__ __launch_bounds__(256) void k_rollout_mlp_w4(MlpRolloutArgs q) {
             }
         }
     }
+    W4_MARK();
     __syncthreads();
+    W4_MARK();
     // ---- step rewards by all threads from the ring (deterministic.py:62-73), summed in step order below
     for (int e = tid; e < H * W4_TP; e += 256)
         rstep[e] = reward_generic(p.reward_kind, p.fix_q1 != 0, ring + (size_t)e * Sp, acts + e * U, ring + (size_t)(e + W4_TP) * Sp, S, U);
+    if (tid >= 128 && tid < 128 + W4_TP * U) {            // clip penalties (wave 2 and up, next to the step rewards)
+        const int tpp = (tid - 128) / U, u = (tid - 128) % U;
+        float pen_part = 0.0f;
+        if (q.pen && n0 + tpp < p.n_pop)
+            for (int t = 0; t < H; ++t) pen_part = pen_part + d2s[(t * W4_TP + tpp) * U + u];
+        pens[tpp * U + u] = pen_part;
+    }
     if (q.traj) {                                         // a user reward function scores the recorded trajectory afterwards
         for (int e = tid; e < H * W4_TP * S; e += 256) {
             const int f = e % S, tp = e / S, tpp = tp % W4_TP, tt = tp / W4_TP;
@@ -200,6 +257,13 @@ __global__ __launch_bounds__(256) void k_rollout_mlp_w4(MlpRolloutArgs q) {
         }
         p.rewards[(size_t)a * p.Nst + n0 + tid] = tot;
     }
+    W4_MARK();
+#ifdef BBMPC_KERNEL_DBG
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+        printf("[w4dbg] H=%d (10 ns units) constants+weights issued %lld | action block %lld | xa+ring %lld | loop %lld | wait for the other waves %lld | rewards+sums %lld\n",
+               H, dbg_t[1] - dbg_t[0], dbg_t[2] - dbg_t[1], dbg_t[3] - dbg_t[2], dbg_t[4] - dbg_t[3], dbg_t[5] - dbg_t[4], dbg_t[6] - dbg_t[5]);
+#endif
+#undef W4_MARK
 }
 
 }  // namespace bbmpc
