@@ -216,6 +216,7 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
             if (wlds > 64 * 1024) ensure_max_lds((const void*)wfn, 159 * 1024);
             dim3 wgrid((ra.n_pop + W4_TP - 1) / W4_TP, per_particle_state ? 1 : A), wblock(256);
             dominant_kernel = "k_rollout_mlp_w4";
+            snprintf(dominant_inst, sizeof(dominant_inst), "k_rollout_mlp_w4<%d, %s>", mlp.n_layers, tanh_net ? "true" : "false");
             prof_begin();
             hipLaunchKernelGGL(wfn, wgrid, wblock, wlds, stream, q);
             HIP_CHECK(hipGetLastError());
@@ -295,6 +296,12 @@ void Engine::launch_rollout_mlp(int mode, bool pen, RolloutArgs& ra, bool per_pa
                 if (qlds > 64 * 1024) ensure_max_lds((const void*)fn, 160 * 1024);
                 dim3 qgrid((ra.n_pop + 3) / 4, A), qblock(256);
                 dominant_kernel = "k_rollout_mlp_q4s";
+                {   // the instantiation as rocprofv3 prints it (bbmpc_profile_instantiation): HG, K0G, three activations, NE
+                    const int rt = -1;
+                    const int a0 = (tanh_net || (!wide && relu_net)) ? mlp.act[0] : rt, a1 = (tanh_net || (!wide && relu_net)) ? mlp.act[1] : rt,
+                              a2 = (tanh_net || (!wide && relu_net)) ? mlp.act[2] : rt;
+                    snprintf(dominant_inst, sizeof(dominant_inst), "k_rollout_mlp_q4s<%d, 7, %d, %d, %d, %d>", wide ? 64 : 50, a0, a1, a2, ne1 ? 1 : 2);
+                }
                 q.state_copy = mlp_state_copy;
                 mlp_state_copy = nullptr;
                 prof_begin();

@@ -491,10 +491,17 @@ def test_profile_instantiation_names_the_template_that_ran(L):
         assert e.device == 0
     a, b = fast.profile_instantiation(), strict.profile_instantiation()
     assert a.startswith("k_fused_pendulum<2, true, true, ") and b.startswith("k_fused_pendulum<2, true, false, "), (a, b)
-    # a kernel with one instantiation per handle reports its plain name
+    # the quad kernel and the small-network kernel report theirs as rocprofv3 prints them (round 6: several instantiations of
+    # one plain name sit in one profile of the shape sweep); kernels that do not record one report the plain name
     eng, ev, lo, hi = _problem(L, *CHEETAH, True, A=1, H=5)
     eng.evaluate(O.cheetah_start_states(1, 20), np.zeros((8, 1, 5, 6), F))
-    assert eng.profile_instantiation() == eng.get_profile()[2]
+    assert eng.profile_instantiation() == "k_rollout_mlp_q4s<50, 7, 1, 1, 0, 1>" and eng.get_profile()[2] == "k_rollout_mlp_q4s"
+    eng, ev, lo, hi = _problem(L, *PEND_MLP, True, A=1, H=5)
+    eng.evaluate(O.pendulum_start_states(1), np.zeros((8, 1, 5, 1), F))
+    assert eng.profile_instantiation() == "k_rollout_mlp_w4<4, true>" and eng.get_profile()[2] == "k_rollout_mlp_w4"
+    eng, ev, lo, hi = _problem(L, [26, 500, 500, 500, 20], ["tanh", "tanh", "tanh", None], 20, 6, "cheetah", True, A=1, H=3)
+    eng.evaluate(O.cheetah_start_states(1, 20), np.zeros((8, 1, 3, 6), F))
+    assert eng.profile_instantiation() == eng.get_profile()[2] == "k_rollout_mlp"
 
 
 Q4S_USER_REWARD = """
@@ -539,6 +546,12 @@ def test_quad_kernel_q4s_other_activations_and_state_widths(L, acts, S, U, norma
     eng.set_profiling(True)
     got = eng.evaluate(states, seq)
     assert eng.get_profile()[2] == "k_rollout_mlp_q4s"
+    # the template instantiation as rocprofv3 names it (bench.py attaches committed counters by it): compile-time activations
+    # for the tanh / relu networks, -1 (run time) otherwise; two action pairs per thread from 257 (particle, 4-element) pairs on
+    code = {"tanh": 1, "relu": 2}
+    ct = acts[2] is None and acts[0] == acts[1] and acts[0] in code
+    a = [code[acts[0]], code[acts[1]], 0] if ct else [-1, -1, -1]
+    assert eng.profile_instantiation() == "k_rollout_mlp_q4s<50, 7, %d, %d, %d, %d>" % (a[0], a[1], a[2], 1 if 4 * ((H * U + 3) // 4) <= 256 else 2)
     want = ev(states, seq)
     assert np.all(np.isfinite(want))
     assert_cheetah_rewards(got, want, 1e-3, 1e-3 * H, margin=lambda: cheetah_threshold_margin(ev, states, seq))
