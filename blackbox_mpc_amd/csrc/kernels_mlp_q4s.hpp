@@ -563,12 +563,12 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
                 h1v[0] = apply_act_q4s<A1>(rows_reduce_scatter(cj0) + b1s[0], rt1);
                 h1v[1] = apply_act_q4s<A1>(rows_reduce_scatter(cj1) + b1s[1], rt1);
                 h1v[2] = apply_act_q4s<A1>(rows_reduce_scatter(cj2) + b1s[2], rt1);
-                // the tail chain: the row's four blocks first (8, then 4: every block adds the same pairs), then the rows
-                ct.x = ct.x + dpp_mov<DPP_ROW_ROR8>(ct.x); ct.y = ct.y + dpp_mov<DPP_ROW_ROR8>(ct.y);
-                ct.z = ct.z + dpp_mov<DPP_ROW_ROR8>(ct.z); ct.w = ct.w + dpp_mov<DPP_ROW_ROR8>(ct.w);
-                ct.x = ct.x + dpp_mov<DPP_ROW_ROR4>(ct.x); ct.y = ct.y + dpp_mov<DPP_ROW_ROR4>(ct.y);
-                ct.z = ct.z + dpp_mov<DPP_ROW_ROR4>(ct.z); ct.w = ct.w + dpp_mov<DPP_ROW_ROR4>(ct.w);
-                h1t = apply_act_q4s<A1>(rows_reduce_scatter(ct) + b1t, rt1);
+                // the tail chain: all 16 blocks hold partial sums -- the rows first (a reduce-scatter: four registers become one),
+                // then the row's four blocks on that one register (8, then 4: every block adds the same pairs)
+                float st = rows_reduce_scatter(ct);
+                st = st + dpp_mov<DPP_ROW_ROR8>(st);
+                st = st + dpp_mov<DPP_ROW_ROR4>(st);
+                h1t = apply_act_q4s<A1>(st + b1t, rt1);
             } else {
                 f32x4 cj0, cj1, cj2, cj3;
 #pragma unroll
@@ -632,12 +632,10 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
             Q4S_MARK(15);
             f32x4 sA = {(cA0.x + cA1.x) + cA2.x, (cA0.y + cA1.y) + cA2.y, (cA0.z + cA1.z) + cA2.z, (cA0.w + cA1.w) + cA2.w};
             if constexpr (NJ == 4) { sA.x = sA.x + cA3.x; sA.y = sA.y + cA3.y; sA.z = sA.z + cA3.z; sA.w = sA.w + cA3.w; }
-            cB.x = cB.x + dpp_mov<DPP_ROW_ROR8>(cB.x); cB.y = cB.y + dpp_mov<DPP_ROW_ROR8>(cB.y);
-            cB.z = cB.z + dpp_mov<DPP_ROW_ROR8>(cB.z); cB.w = cB.w + dpp_mov<DPP_ROW_ROR8>(cB.w);
-            cB.x = cB.x + dpp_mov<DPP_ROW_ROR4>(cB.x); cB.y = cB.y + dpp_mov<DPP_ROW_ROR4>(cB.y);
-            cB.z = cB.z + dpp_mov<DPP_ROW_ROR4>(cB.z); cB.w = cB.w + dpp_mov<DPP_ROW_ROR4>(cB.w);
             zxA[80 * wave] = rows_reduce_scatter(sA);      // output feature 4g + pr of my particle, my hidden features' share
-            const float pB = rows_reduce_scatter(cB);      // output feature 16 + pr
+            float pB = rows_reduce_scatter(cB);            // output feature 16 + pr: the rows first, then the row's four blocks
+            pB = pB + dpp_mov<DPP_ROW_ROR8>(pB);
+            pB = pB + dpp_mov<DPP_ROW_ROR4>(pB);
             if (fgq == 0) zxB[80 * wave] = pB;
         }
         Q4S_MARK(4);
