@@ -602,3 +602,70 @@ def test_quad_kernel_q4s_256_hidden_units(L, acts, S, U, normalized, N, H):
     want = ev(states, seq)
     assert np.all(np.isfinite(want))
     assert_cheetah_rewards(got, want, 1e-3, 1e-3 * H, margin=lambda: cheetah_threshold_margin(ev, states, seq))
+
+
+def _random_shapes(seed, count, hidden_choices, n_hidden_choices):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        S = int(rng.integers(1, 21))
+        U = int(rng.integers(1, 9))
+        H = int(rng.choice([1, 2, 7, 16, 31, 33, 64]))
+        while 4 * ((H * U + 3) // 4) > 512:                # the quad kernel keeps at most 512 (particle, 4-element) pairs per workgroup
+            H //= 2
+        N = int(rng.choice([1, 3, 4, 5, 17, 64, 130]))
+        A = int(rng.integers(1, 4))
+        nh = int(rng.choice(n_hidden_choices))
+        hid = [int(rng.choice(hidden_choices)) for _ in range(nh)]
+        acts = [str(rng.choice(["tanh", "relu", "sigmoid"])) for _ in range(nh)] + [None if rng.random() < 0.7 else "tanh"]
+        out.append((S, U, H, N, A, hid, acts, bool(rng.random() < 0.7)))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_shapes(601, 14, [200, 256], [2]), ids=lambda c: "S%d-U%d-H%d-N%d-A%d-%s" % (c[0], c[1], c[2], c[3], c[4], "x".join(map(str, c[5]))))
+def test_quad_kernel_q4s_random_shapes(L, case):
+    # k_rollout_mlp_q4s over drawn (dim_S, dim_U, horizon, population, agents, width, activations, normalisation): ragged
+    # populations (the last quad partly empty), one-step horizons, one or two action pairs per thread, padded state groups
+    from blackbox_mpc_amd.engine import Engine
+    S, U, H, N, A, hid, acts, normalized = case
+    if hid[0] != hid[1]:
+        hid = [hid[0], hid[0]]
+    dims = [S + U] + hid + [S]
+    ws, bs = O.make_mlp_params(dims, seed=S * 31 + U)
+    rng = np.random.default_rng(S * 1000 + U * 10 + H)
+    bs = [rng.normal(0, 0.05, b.shape).astype(F) for b in bs]
+    stats = _stats(S, U, 3) if normalized else None
+    lo, hi = [-1.0] * U, [1.0] * U
+    eng = Engine(L.OPT_NONE, L.DYN_MLP, L.REW_USER, lo, hi, dim_s=S, num_agents=A, planning_horizon=H)
+    eng.set_reward_source(Q4S_USER_REWARD)
+    eng.set_mlp(ws, bs, [ACT[a] for a in acts], stats)
+    ev = O.Evaluator(_q4s_user_reward_np, O.Handler(O.MLP(ws, bs, acts), False, normalized, stats))
+    states = rng.normal(0, 0.3, (A, S)).astype(F)
+    seq = rng.uniform(-1, 1, (N, A, H, U)).astype(F)
+    eng.set_profiling(True)
+    got = eng.evaluate(states, seq)
+    assert eng.get_profile()[2] == "k_rollout_mlp_q4s"
+    np.testing.assert_allclose(got, ev(states, seq), rtol=1e-3, atol=1e-3 * H)
+
+
+@pytest.mark.parametrize("case", _random_shapes(602, 14, [4, 8, 13, 16, 24, 32], [1, 2, 3]), ids=lambda c: "S%d-U%d-H%d-N%d-A%d-%s" % (c[0], c[1], c[2], c[3], c[4], "x".join(map(str, c[5]))))
+def test_small_network_kernel_w4_random_shapes(L, case):
+    # k_rollout_mlp_w4 over drawn shapes: 1-3 hidden layers of 4..32 units each (padded to 32 x 32 stages), any activations
+    from blackbox_mpc_amd.engine import Engine
+    S, U, H, N, A, hid, acts, normalized = case
+    dims = [S + U] + hid + [S]
+    ws, bs = O.make_mlp_params(dims, seed=S * 17 + U)
+    rng = np.random.default_rng(S * 1000 + U * 10 + H + 5)
+    bs = [rng.normal(0, 0.05, b.shape).astype(F) for b in bs]
+    stats = _stats(S, U, 4) if normalized else None
+    lo, hi = [-1.0] * U, [1.0] * U
+    eng = Engine(L.OPT_NONE, L.DYN_MLP, L.REW_USER, lo, hi, dim_s=S, num_agents=A, planning_horizon=H)
+    eng.set_reward_source(Q4S_USER_REWARD)
+    eng.set_mlp(ws, bs, [ACT[a] for a in acts], stats)
+    ev = O.Evaluator(_q4s_user_reward_np, O.Handler(O.MLP(ws, bs, acts), False, normalized, stats))
+    states = rng.normal(0, 0.3, (A, S)).astype(F)
+    seq = rng.uniform(-1, 1, (N, A, H, U)).astype(F)
+    eng.set_profiling(True)
+    got = eng.evaluate(states, seq)
+    assert eng.get_profile()[2] == "k_rollout_mlp_w4"
+    np.testing.assert_allclose(got, ev(states, seq), rtol=1e-3, atol=1e-3 * H)
