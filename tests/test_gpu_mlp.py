@@ -669,3 +669,30 @@ def test_small_network_kernel_w4_random_shapes(L, case):
     got = eng.evaluate(states, seq)
     assert eng.get_profile()[2] == "k_rollout_mlp_w4"
     np.testing.assert_allclose(got, ev(states, seq), rtol=1e-3, atol=1e-3 * H)
+
+
+@pytest.mark.parametrize("opt_name", ["RandomSearch", "PSO", "SPSA", "CMA-ES"])
+def test_small_network_kernel_w4_under_every_candidate_source(L, monkeypatch, opt_name):
+    # the optimizers hand the rollout kernels their candidates in different forms (uniform draws made in the kernel, a
+    # candidate buffer, clip + penalty): the first iteration's rewards through k_rollout_mlp_w4 and through the general kernel
+    # on the engine's own draws (counter-based: the same for both), and the control step's outputs
+    dims, acts, S, U, reward = PEND_MLP
+    N, A, H = 192, 2, 10
+    opt = {"RandomSearch": L.OPT_RANDOM_SEARCH, "PSO": L.OPT_PSO, "SPSA": L.OPT_SPSA, "CMA-ES": L.OPT_CMAES}[opt_name]
+    states = O.pendulum_start_states(A)
+    out = []
+    for small in (True, False):
+        monkeypatch.setenv("BBMPC_MLP_WAVE", "1" if small else "0")
+        monkeypatch.setenv("BBMPC_MLP_W4", "1" if small else "0")
+        eng, ev, lo, hi = _problem(L, dims, acts, S, U, reward, True, A=A, H=H, opt=opt, N=N, iters=(0 if opt_name == "RandomSearch" else 1), k=16, seed=7)
+        eng.set_trace(True)
+        eng.set_profiling(True)
+        a, n, r = eng.optimize(states)
+        assert (eng.get_profile()[2] == "k_rollout_mlp_w4") == small
+        out.append((a, n, r, eng.get_trace(0, L.TRACE_REWARDS)))
+    monkeypatch.delenv("BBMPC_MLP_WAVE")
+    monkeypatch.delenv("BBMPC_MLP_W4")
+    np.testing.assert_allclose(out[0][3], out[1][3], rtol=1e-4, atol=1e-3)
+    if opt_name != "SPSA":                          # (SPSA divides reward differences by 2 c_k: its step amplifies the kernels' last bits)
+        np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=2e-3)
