@@ -464,7 +464,10 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
     __syncthreads();
     Q4S_MARK(8);
 
-    float* const h0w = h0 + ((size_t)q0 * 4 + pl) * 4;    // where my layer-0 D fragment goes (blocks with l0_on)
+    // where my layer-0 D fragment goes; blocks without a hidden quad (3 of 16, 5 on wave 3) store theirs into a pad group nobody
+    // reads (60: the jobs read groups < 52 -- behind zero operand rows from 50 on --, the tail chains too): no exec-mask branch
+    // around the activations (a branch inside the step costs more than the instructions it skips: NOTES_r6)
+    float* const h0w = h0 + ((size_t)(l0_on ? q0 : 60) * 4 + pl) * 4;
     const bool rew_on = p.reward_kind == REW_CHEETAH;
     const float flag_thr = (pr == 1) ? 0.2f : 0.0f;       // cur[5] >= 0.2, cur[6] >= 0, cur[7] >= 0   cost_func.py:9-17
     // reward terms are parked per step and summed in step order after the loop (one IEEE division per (step, particle)
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_mlp_q4s(MlpRolloutArgs q) {
             f32x4 o;
             o.x = apply_act_q4s<A0>((acc0.x + acc1.x) + acc2.x, rt0); o.y = apply_act_q4s<A0>((acc0.y + acc1.y) + acc2.y, rt0);
             o.z = apply_act_q4s<A0>((acc0.z + acc1.z) + acc2.z, rt0); o.w = apply_act_q4s<A0>((acc0.w + acc1.w) + acc2.w, rt0);
-            if (l0_on) *reinterpret_cast<f32x4*>(h0w) = o;
+            *reinterpret_cast<f32x4*>(h0w) = o;
         }
         Q4S_MARK(0);
         __syncthreads();                                   // h0 of step t is complete
