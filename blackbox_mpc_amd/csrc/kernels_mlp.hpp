@@ -138,21 +138,17 @@ __host__ __device__ inline MlpLds mlp_lds_layout(const MlpDesc& m, int H, int U,
 #ifndef MLP_GEN_PF
 #define MLP_GEN_PF 2
 #endif
-// KS > 0: the operands of the first KS k tiles of this wave's output-tile pair are STATIONARY -- held in the registers s0 / s1
-// for the whole recurrence (rollout_mlp_body loads them once): sixteen 75-register waves leave two fifths of their register
-// budget unused, and the MFMAs on stationary operands cover the L2 round trip of the ring's first loads at the start of the
-// layer.  Same MFMAs in the same order: bit-identical to the streamed form.  Round 6, the reference's 26-500-500-500-20,
-// us per 4048 x 15-step launch, variants back to back on one box: streamed 778-788, KS = 2 / 3 / 4 / 5: 795 / 788 / 791 / 786
-// (no gain: 9 % less operand traffic does not show, so the L2s' bandwidth is not the whole story), KS = 6: 768-772 (the
-// kernel then sits at its 128-register cap).  Carrying the ring across layers instead -- the last refills of a layer
-// fetching the next layer's first tiles -- was built and measured at 895-909 us: the ring's sixteen registers live through
-// every barrier and the epilogue, and the kernel spills.
-#ifndef MLP_GEN_KS
-#define MLP_GEN_KS 6
-#endif
-template <int KS>
-__device__ __forceinline__ void mlp_layer_out_split(const MlpDesc& m, const float* wp4, int l, const float* in, float* out, int wave,
-                                                    int lane, int nw, const f32x4* s0 = nullptr, const f32x4* s1 = nullptr) {
+__device__ __forceinline__ void mlp_layer_out_split(const MlpDesc& m, const float* wp4, int l, int in_off, int out_off, int wave,
+                                                    int lane, int nw) {
+    // The activation tiles are addressed as OFFSETS into the dynamic LDS array (round 6): through the `float*` the layer loop
+    // swaps between two buffers the compiler loses the address space and reads them with flat_load -- which counts on the
+    // vector memory counter as well, so every k tile waited (s_waitcnt vmcnt(0)) for the whole operand ring it had just
+    // refilled: 778-788 -> 705-707 us per 4048 x 15-step launch of the 26-500-500-500-20 network.  With the ring working,
+    // depth 2 / 3 / 4: 706 / 734 / 747 us; six k tiles of a hidden layer stationary in the spare registers on top: 719 (it
+    // had bought 1-2 % while the flat loads were there; removed).
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const float* in = smem + in_off;
+    float* out = smem + out_off;
     const int IT = m.tiles[l], OT = m.tiles[l + 1];
     const f32x4* __restrict__ W = reinterpret_cast<const f32x4*>(wp4);
     const float* __restrict__ bp = m.bpack[l];
@@ -167,34 +163,15 @@ __device__ __forceinline__ void mlp_layer_out_split(const MlpDesc& m, const floa
             // a ring of MLP_GEN_PF k tiles of operands in registers: 2 x MLP_GEN_PF 1-KB loads in flight per wave at all times
             // (left to `#pragma unroll` the compiler kept the loads next to their use: 887 us per 4048 x 15-step launch of the
             // 26-500-500-500-20 network against 1007 before; ring depth 1 / 2 / 3 / 4 / 6: 839 / 779 / 810 / 830 / 818 us.  Deeper
-            // rings do not pay: 253 CUs re-read the same 2.1 MB of operands from their XCD's L2 every model step, 1.3 TB/s per
-            // XCD at this speed -- the L2, not the latency of a load, is what the layer waits for.)
+            // rings did not pay -- the flat loads above, not the L2s: see the top of the function.)
             f32x4 r0[MLP_GEN_PF], r1[MLP_GEN_PF];
-            const int kfirst = (KS > 0 && ot0 == wave) ? KS : 0;       // (only the wave's first pair has stationary operands)
 #pragma unroll
             for (int j = 0; j < MLP_GEN_PF; ++j) {
-                const int kk = kfirst + j < IT ? kfirst + j : IT - 1;
+                const int kk = j < IT ? j : IT - 1;
                 r0[j] = w0[(size_t)kk * 64];
                 r1[j] = w1[(size_t)kk * 64];
             }
-            if constexpr (KS > 0) {
-                if (ot0 == wave) {
-#pragma unroll
-                    for (int k = 0; k < KS; ++k) {
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(in + ((size_t)k * 64 + lane) * 4);
-                        const f32x4 a0 = s0[k], a1 = s1[k];
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc1, 0, 0, 0);
-                    }
-                }
-            }
-            for (int it = kfirst; it < IT; it += MLP_GEN_PF) {
+            for (int it = 0; it < IT; it += MLP_GEN_PF) {
 #pragma unroll
                 for (int j = 0; j < MLP_GEN_PF; ++j) {
                     const int k = it + j;
@@ -239,8 +216,11 @@ __device__ __forceinline__ void mlp_layer_out_split(const MlpDesc& m, const floa
 
 // Last layer, K split: wave multiplies the input tiles it owns (it = wave, wave+nw, ...) into every
 // output tile and leaves partial sums in part[wave][ot][lane].
-__device__ __forceinline__ void mlp_layer_k_split(const MlpDesc& m, const float* wp4, int l, const float* in, float* part, int wave,
+__device__ __forceinline__ void mlp_layer_k_split(const MlpDesc& m, const float* wp4, int l, int in_off, int part_off, int wave,
                                                   int lane, int nw) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];        // (offsets, not pointers: see mlp_layer_out_split)
+    const float* in = smem + in_off;
+    float* part = smem + part_off;
     const int IT = m.tiles[l], OT = m.tiles[l + 1];
     const f32x4* __restrict__ W = reinterpret_cast<const f32x4*>(wp4);
     for (int ot = 0; ot < OT; ++ot) {
@@ -439,22 +419,6 @@ __device__ __forceinline__ void rollout_mlp_body(const MlpRolloutArgs& q) {
     }
     __syncthreads();
 
-    // generic form: the first MLP_GEN_KS k tiles of my output-tile pair of the first hidden -> hidden layer stay in registers
-    // (horizons long enough to pay for the load; the pair form needs output tile wave + nw to exist)
-    f32x4 gs0[MLP_GEN_KS > 0 ? MLP_GEN_KS : 1], gs1[MLP_GEN_KS > 0 ? MLP_GEN_KS : 1];
-    bool gen_stat = false;
-    if constexpr (SPEC == 0 && MLP_GEN_KS > 0) {
-        gen_stat = L >= 3 && H >= 4 && m.tiles[1] >= MLP_GEN_KS + MLP_GEN_PF && wave + nw < m.tiles[2];
-        if (gen_stat) {
-            const f32x4* __restrict__ W = reinterpret_cast<const f32x4*>(q.wp4[1]);
-            const int IT = m.tiles[1];
-#pragma unroll
-            for (int k = 0; k < MLP_GEN_KS; ++k) {
-                gs0[k] = W[((size_t)wave * IT + k) * 64 + lane];
-                gs1[k] = W[((size_t)(wave + nw) * IT + k) * 64 + lane];
-            }
-        }
-    }
     float total = 0.0f;                       // lanes 0..15 of wave 0: reward accumulator of particle `lane`
     const int OTl = m.tiles[L];
     for (int t = 0; t < H; ++t) {
@@ -462,15 +426,14 @@ __device__ __forceinline__ void rollout_mlp_body(const MlpRolloutArgs& q) {
         float* nxt = st + ((t + 1) & 1) * MLP_TP * Sp;
         // ---- dense layers
         if constexpr (SPEC == 0) {
-            const float* in = xs;
+            int in_off = lay.xs;
             for (int l = 0; l < L - 1; ++l) {
-                float* out = actbuf[l & 1];
-                if (l == 1 && gen_stat) mlp_layer_out_split<MLP_GEN_KS>(m, q.wp4[l], l, in, out, wave, lane, nw, gs0, gs1);
-                else mlp_layer_out_split<0>(m, q.wp4[l], l, in, out, wave, lane, nw);
+                const int out_off = (l & 1) ? lay.actB : lay.actA;
+                mlp_layer_out_split(m, q.wp4[l], l, in_off, out_off, wave, lane, nw);
                 __syncthreads();
-                in = out;
+                in_off = out_off;
             }
-            mlp_layer_k_split(m, q.wp4[L - 1], L - 1, in, part, wave, lane, nw);
+            mlp_layer_k_split(m, q.wp4[L - 1], L - 1, in_off, lay.part, wave, lane, nw);
         } else {
             const int HT = m.tiles[1];
             f32x4 acc = bias_r[0];
