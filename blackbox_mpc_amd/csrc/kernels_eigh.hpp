@@ -123,11 +123,19 @@ struct EighTriLds {
 #define EIGH_U(x) __builtin_amdgcn_readfirstlane(x)
 #define EIGH_UF(x) __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)))
 
+// every phase derives its row / column indices from the thread index again: whatever the phases share (tr, tc, 4 tc,
+// comparisons, LDS addresses) otherwise stays in registers THROUGH the phases that do not use it
+#define EIGH_PHASE_INDICES int tid_ = tid; asm volatile("" : "+v"(tid_)); const int tr = tid_ >> 4, tc = tid_ & 15
+
 struct EighStepScalars {
     float scale, wk1, c1, c2, c3, n1, n2, n3, beta, t, yk;
 };
 
 // slarfg + the coefficients of w and of the next row, from |x~|^2 (sig, without the leading entry), x~ . p~ (g1), x~ . y (g2)
+// SG: which results move to SGPRs (bit 0: scale; bit 1: wk1, c1 .. c3; bit 2: n2, n3).  Every lane computes the
+// same values, so the moves are there for the registers only -- and they come LAST: a v_readfirstlane inside the
+// dependent chain (scale -> p_{k+1} -> gamma -> w_{k+1} -> n3) costs ~40 cycles per link on every step of every wave.
+template <int SG>
 __device__ __forceinline__ EighStepScalars eigh_step_scalars(float sig, float g1, float g2, float ain, float ptk, float yk) {
     float beta = ain, t = 0.0f, scale = 0.0f;
     if (sig > 0.0f) {                                    // hardware sqrt / rcp + one Newton step each
@@ -143,23 +151,27 @@ __device__ __forceinline__ EighStepScalars eigh_step_scalars(float sig, float g1
         scale = rd * fmaf(-dd, rd, 2.0f);
     }
     EighStepScalars q;
-    q.scale = EIGH_UF(scale); q.t = EIGH_UF(t); q.beta = EIGH_UF(beta); q.yk = yk;
+    q.scale = scale; q.t = t; q.beta = beta; q.yk = yk;
     const float sb = q.scale * q.beta;
-    const float pk1 = EIGH_UF(fmaf(q.scale, ptk, -(sb * yk)));                  // p at index k + 1
+    const float pk1 = fmaf(q.scale, ptk, -(sb * yk));                           // p at index k + 1
     // v = scale x~ + (1 - scale ain) e_{k+1};  p = scale p~ - scale beta y;  gamma = v . p
-    const float gam = EIGH_UF(fmaf(q.scale, fmaf(q.scale, g1, -(sb * g2)), (1.0f - ain * q.scale) * pk1));
+    const float gam = fmaf(q.scale, fmaf(q.scale, g1, -(sb * g2)), (1.0f - ain * q.scale) * pk1);
     const float coef = 0.5f * q.t * q.t * gam;
     q.wk1 = fmaf(q.t, pk1, -coef);                                              // w at index k + 1 (v = 1 there)
     // w = c1 p~ + c2 y + c3 x~ ;  next row  xn = y - w - wk1 v = n2 y + n1 p~ + n3 x~   (entries > k + 1)
     q.c1 = q.t * q.scale; q.c2 = -(q.t * sb); q.c3 = -(coef * q.scale);
-    q.n1 = -q.c1; q.n2 = 1.0f - q.c2; q.n3 = -(q.c3 + q.wk1 * q.scale);
+    q.n2 = 1.0f - q.c2; q.n3 = -(q.c3 + q.wk1 * q.scale);
+    if (SG & 1) q.scale = EIGH_UF(q.scale);
+    if (SG & 2) { q.wk1 = EIGH_UF(q.wk1); q.c1 = EIGH_UF(q.c1); q.c2 = EIGH_UF(q.c2); q.c3 = EIGH_UF(q.c3); }
+    if (SG & 4) { q.n2 = EIGH_UF(q.n2); q.n3 = EIGH_UF(q.n3); }
+    q.n1 = -q.c1;
     return q;
 }
 
 // x~ of column group JB: entries up to index k (kb inside the group) are dead
 __device__ __forceinline__ void eigh_mask_group(EighQuad& x, int cbase, int kb) {
-    x.x = cbase + 0 > kb ? x.x : 0.0f; x.y = cbase + 1 > kb ? x.y : 0.0f;
-    x.z = cbase + 2 > kb ? x.z : 0.0f; x.w = cbase + 3 > kb ? x.w : 0.0f;
+    x.x = cbase > kb ? x.x : 0.0f; x.y = cbase > kb - 1 ? x.y : 0.0f;
+    x.z = cbase > kb - 2 ? x.z : 0.0f; x.w = cbase > kb - 3 ? x.w : 0.0f;
 }
 // v, w at a thread's columns of one group (JBG: the group of index k + 1 -- dead entries, v = 1 / w = wk1 at k + 1)
 template <bool JBG>
@@ -169,22 +181,36 @@ __device__ __forceinline__ void eigh_col_vw(const EighStepScalars& q, const Eigh
     wc.x = fmaf(q.c1, pc.x, fmaf(q.c2, yc.x, q.c3 * x.x)); wc.y = fmaf(q.c1, pc.y, fmaf(q.c2, yc.y, q.c3 * x.y));
     wc.z = fmaf(q.c1, pc.z, fmaf(q.c2, yc.z, q.c3 * x.z)); wc.w = fmaf(q.c1, pc.w, fmaf(q.c2, yc.w, q.c3 * x.w));
     if (JBG) {
-        vc.x = cbase + 0 == kb + 1 ? 1.0f : vc.x; vc.y = cbase + 1 == kb + 1 ? 1.0f : vc.y;
-        vc.z = cbase + 2 == kb + 1 ? 1.0f : vc.z; vc.w = cbase + 3 == kb + 1 ? 1.0f : vc.w;
-        wc.x = cbase + 0 == kb + 1 ? q.wk1 : (cbase + 0 > kb + 1 ? wc.x : 0.0f); wc.y = cbase + 1 == kb + 1 ? q.wk1 : (cbase + 1 > kb + 1 ? wc.y : 0.0f);
-        wc.z = cbase + 2 == kb + 1 ? q.wk1 : (cbase + 2 > kb + 1 ? wc.z : 0.0f); wc.w = cbase + 3 == kb + 1 ? q.wk1 : (cbase + 3 > kb + 1 ? wc.w : 0.0f);
+        vc.x = cbase == kb + 1 ? 1.0f : vc.x; vc.y = cbase == kb ? 1.0f : vc.y;
+        vc.z = cbase == kb - 1 ? 1.0f : vc.z; vc.w = cbase == kb - 2 ? 1.0f : vc.w;
+        wc.x = cbase == kb + 1 ? q.wk1 : (cbase > kb + 1 ? wc.x : 0.0f); wc.y = cbase == kb ? q.wk1 : (cbase > kb ? wc.y : 0.0f);
+        wc.z = cbase == kb - 1 ? q.wk1 : (cbase > kb - 1 ? wc.z : 0.0f); wc.w = cbase == kb - 2 ? q.wk1 : (cbase > kb - 2 ? wc.w : 0.0f);
     }
 }
-// v, w at row r = tr + 32 i (IBR: row class IB -- rows <= k are dead, row k + 1 has v = 1, w = wk1; kr = k inside the class)
-template <bool IBR>
-__device__ __forceinline__ void eigh_row_vw(const EighStepScalars& q, const float* Xc, const float* Pt, const float* Yc, int r, int tr, int kr,
-                                            float& vr, float& wr) {
-    const float xr = Xc[r], ptr = Pt[r], yr = Yc[r];
-    vr = xr * q.scale;
-    wr = fmaf(q.c1, ptr, fmaf(q.c2, yr, q.c3 * xr));
-    if (IBR) {
-        vr = tr == kr + 1 ? 1.0f : (tr > kr + 1 ? vr : 0.0f);
-        wr = tr == kr + 1 ? q.wk1 : (tr > kr + 1 ? wr : 0.0f);
+// v, w at the thread's rows r = tr + 32 i, i >= IB (row class IB: rows <= k are dead, row k + 1 has v = 1, w = wk1; kr = k
+// inside the class).  The three vector entries per row are loaded BEFORE the step's scalars are formed (their chain of
+// sqrt / rcp / Newton steps hides the LDS latency), the results are formed right after and pinned: left to itself the
+// compiler sinks the arithmetic into the blocks of the first use and carries the 30 loaded values instead of 20 results.
+template <int IB>
+__device__ __forceinline__ void eigh_rows_load(const float* Xc, const float* Pt, const float* Yc, int tr, float (&xr)[EIGH_NI], float (&pr)[EIGH_NI],
+                                               float (&yr)[EIGH_NI]) {
+#pragma unroll
+    for (int i = IB; i < EIGH_NI; ++i) { xr[i] = Xc[tr + 32 * i]; pr[i] = Pt[tr + 32 * i]; yr[i] = Yc[tr + 32 * i]; }
+}
+template <int IB>
+__device__ __forceinline__ void eigh_rows_vw(const EighStepScalars& q, const float (&xr)[EIGH_NI], const float (&pr)[EIGH_NI], const float (&yr)[EIGH_NI],
+                                             int tr, int kr, float (&vr)[EIGH_NI], float (&wr)[EIGH_NI]) {
+#pragma unroll
+    for (int i = IB; i < EIGH_NI; ++i) {
+        vr[i] = xr[i] * q.scale;
+        wr[i] = fmaf(q.c1, pr[i], fmaf(q.c2, yr[i], q.c3 * xr[i]));
+    }
+    vr[IB] = tr == kr + 1 ? 1.0f : (tr > kr + 1 ? vr[IB] : 0.0f);
+    wr[IB] = tr == kr + 1 ? q.wk1 : (tr > kr + 1 ? wr[IB] : 0.0f);
+#pragma unroll
+    for (int i = IB; i < EIGH_NI; i += 2) {
+        if (i + 1 < EIGH_NI) asm volatile("" : "+v"(vr[i]), "+v"(wr[i]), "+v"(vr[i + 1 < EIGH_NI ? i + 1 : i]), "+v"(wr[i + 1 < EIGH_NI ? i + 1 : i]));
+        else asm volatile("" : "+v"(vr[i]), "+v"(wr[i]));
     }
 }
 __device__ __forceinline__ void eigh_rank2(EighQuad& ar, float vr, float wr, const float4& vc, const float4& wc) {
@@ -196,13 +222,18 @@ __device__ __forceinline__ void eigh_rank2(EighQuad& ar, float vr, float wr, con
 // their DPP chains interleave, and no more than two sums are live -- the register file is full of matrix
 template <int IB, int JB>
 __device__ __forceinline__ void eigh_matvec(const EighQuad (&a)[EIGH_NR][EIGH_NJ], const EighQuad (&x)[EIGH_NJ], int tr, int tc, int cbase, float* Pt,
-                                            const float (*AL)[EIGH_LD]) {
+                                            const float* AL0 = nullptr, int al_off = 0, float* Yc = nullptr, bool own = false) {
     float s0 = 0.0f;
 #pragma unroll
-    for (int i = IB; i < EIGH_IL; ++i) {                 // rows held in LDS
+    for (int i = IB; i < EIGH_IL; ++i) {                 // rows held in LDS (schedule a; AL0 + al_off = this thread's AL[tr][cbase])
         float acc = 0.0f;
 #pragma unroll
-        for (int jj = JB; jj < EIGH_NJ; ++jj) acc = eigh_dot4(*reinterpret_cast<const float4*>(&AL[tr + 32 * i][cbase + 64 * jj]), x[jj], acc);
+        for (int jj = JB; jj < EIGH_NJ; ++jj) {
+            const float4 r = *reinterpret_cast<const float4*>(AL0 + (al_off + 32 * i * EIGH_LD + 64 * jj));
+            // the owner of row k + 1 (row class IB) publishes y from the same loads -- row k + 1 is updated in place later
+            if (i == IB && own) *reinterpret_cast<float4*>(Yc + cbase + 64 * jj) = r;
+            acc = eigh_dot4(r, x[jj], acc);
+        }
         acc = row16_sum(acc);
         s0 = tc == i ? acc : s0;
         EIGH_SB;
@@ -232,9 +263,10 @@ __device__ __forceinline__ void eigh_matvec(const EighQuad (&a)[EIGH_NR][EIGH_NJ
 
 // ---- schedule a: steps k < EIGH_KA with (k + 1) / 32 == IB (IB = 0, 1)
 template <int IB>
-__device__ __forceinline__ void eigh_tri_steps_a(EighQuad (&a)[EIGH_NR][EIGH_NJ], const int n, const int tr, const int tc, EighTriLds& L,
+__device__ __forceinline__ void eigh_tri_steps_a(EighQuad (&a)[EIGH_NR][EIGH_NJ], const int n, const int tid, EighTriLds& L,
                                                  float* __restrict__ d, float* __restrict__ e, float* __restrict__ tau, float* __restrict__ Vt) {
     constexpr int JB = IB / 2;
+    EIGH_PHASE_INDICES;
     const int k_lo = IB == 0 ? 0 : 32 * IB - 1;
     const int k_hi = min(min(n - 3, 32 * IB + 30), EIGH_KA - 1);
     const int cbase = 4 * tc;
@@ -249,6 +281,8 @@ __device__ __forceinline__ void eigh_tri_steps_a(EighQuad (&a)[EIGH_NR][EIGH_NJ]
         // rows k and k + 1 are LDS rows here: x~ is read in place (row k is dead: nothing writes it any more), y is copied
         // after the first barrier (row k + 1 is updated in place later in this step)
         const float* Xc = L.AL[k];
+        int al_off = tr * EIGH_LD + cbase;                // (one address + immediate offsets: as loop invariants the ten
+        asm volatile("" : "+v"(al_off));                  //  addresses tr + 32 i, cbase + 64 jj each take a register)
         eigh_lds_barrier();
         // ---- x~, |x~|^2 without the leading entry, p~ = A x~
         {
@@ -256,12 +290,8 @@ __device__ __forceinline__ void eigh_tri_steps_a(EighQuad (&a)[EIGH_NR][EIGH_NJ]
 #pragma unroll
             for (int jj = JB; jj < EIGH_NJ; ++jj) xt[jj] = EighQuad(*reinterpret_cast<const float4*>(Xc + cbase + 64 * jj));
             eigh_mask_group(xt[JB], cbase, kb);
-            if (tr == EIGH_U((k + 1) & 31)) {               // owner of row k + 1: its 20 columns -> Yc
-#pragma unroll
-                for (int jj = JB; jj < EIGH_NJ; ++jj)
-                    *reinterpret_cast<float4*>(Yc + cbase + 64 * jj) = *reinterpret_cast<const float4*>(&L.AL[tr + 32 * IB][cbase + 64 * jj]);
-            }
-            eigh_matvec<IB, JB>(a, xt, tr, tc, cbase, Pt, L.AL);
+            // (the owner of row k + 1 copies its 20 columns to Yc inside the product)
+            eigh_matvec<IB, JB>(a, xt, tr, tc, cbase, Pt, &L.AL[0][0], al_off, Yc, tr == EIGH_U((k + 1) & 31));
         }
         eigh_lds_barrier();
         float sig = 0.0f, g1 = 0.0f, g2 = 0.0f;
@@ -272,8 +302,8 @@ __device__ __forceinline__ void eigh_tri_steps_a(EighQuad (&a)[EIGH_NR][EIGH_NJ]
             const float4 yc = *reinterpret_cast<const float4*>(Yc + cbase + 64 * jj);
             if (jj == JB) {
                 eigh_mask_group(x, cbase, kb);
-                sig = fmaf(cbase + 0 > kb + 1 ? x.x : 0.0f, x.x, sig); sig = fmaf(cbase + 1 > kb + 1 ? x.y : 0.0f, x.y, sig);
-                sig = fmaf(cbase + 2 > kb + 1 ? x.z : 0.0f, x.z, sig); sig = fmaf(cbase + 3 > kb + 1 ? x.w : 0.0f, x.w, sig);
+                sig = fmaf(cbase > kb + 1 ? x.x : 0.0f, x.x, sig); sig = fmaf(cbase > kb ? x.y : 0.0f, x.y, sig);
+                sig = fmaf(cbase > kb - 1 ? x.z : 0.0f, x.z, sig); sig = fmaf(cbase > kb - 2 ? x.w : 0.0f, x.w, sig);
             } else {
                 sig = eigh_dot4(x, x, sig);
             }
@@ -282,20 +312,19 @@ __device__ __forceinline__ void eigh_tri_steps_a(EighQuad (&a)[EIGH_NR][EIGH_NJ]
             EIGH_SBA;
         }
         sig = row16_sum(sig); g1 = row16_sum(g1); g2 = row16_sum(g2);
-        const EighStepScalars q = eigh_step_scalars(sig, g1, g2, Xc[k + 1], Pt[k + 1], Yc[k + 1]);
-        float vr[EIGH_NI], wr[EIGH_NI];
-        eigh_row_vw<true>(q, Xc, Pt, Yc, tr + 32 * IB, tr, kr, vr[IB], wr[IB]);
-#pragma unroll
-        for (int i = IB + 1; i < EIGH_NI; ++i) {
-            eigh_row_vw<false>(q, Xc, Pt, Yc, tr + 32 * i, tr, kr, vr[i], wr[i]);
-            if (((i - IB) & 3) == 3) EIGH_SBA;
-        }
-        float* vrow = Vt + (size_t)k * EIGH_LD;
+        float xr[EIGH_NI], pr[EIGH_NI], yr[EIGH_NI], vr[EIGH_NI], wr[EIGH_NI];
+        eigh_rows_load<IB>(Xc, Pt, Yc, tr, xr, pr, yr);
+        const EighStepScalars q = eigh_step_scalars<3>(sig, g1, g2, Xc[k + 1], Pt[k + 1], Yc[k + 1]);
+        if (tr == 0 && tc == 0) { e[k] = q.beta; tau[k] = q.t; d[k + 1] = q.yk - 2.0f * q.wk1; }   // (here: t, beta, yk die before the update)
+        eigh_rows_vw<IB>(q, xr, pr, yr, tr, kr, vr, wr);
+        float* vrow = Vt + (size_t)k * EIGH_LD;            // uniform base; the thread's column offset is formed per step
+        int vcol = cbase;
+        asm volatile("" : "+v"(vcol));
         EIGH_SBA;
 #pragma unroll
         for (int jj = 0; jj < EIGH_NJ; ++jj) {
             if (jj < JB) {
-                if (tr == 0) *reinterpret_cast<float4*>(vrow + cbase + 64 * jj) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (tr == 0) *reinterpret_cast<float4*>(vrow + (vcol + 64 * jj)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 continue;
             }
             EighQuad x(*reinterpret_cast<const float4*>(Xc + cbase + 64 * jj));
@@ -304,10 +333,10 @@ __device__ __forceinline__ void eigh_tri_steps_a(EighQuad (&a)[EIGH_NR][EIGH_NJ]
             float4 vc, wc;
             if (jj == JB) { eigh_mask_group(x, cbase, kb); eigh_col_vw<true>(q, x, pc, yc, cbase, kb, vc, wc); }
             else eigh_col_vw<false>(q, x, pc, yc, cbase, kb, vc, wc);
-            if (tr == 0) *reinterpret_cast<float4*>(vrow + cbase + 64 * jj) = vc;
+            if (tr == 0) *reinterpret_cast<float4*>(vrow + (vcol + 64 * jj)) = vc;
 #pragma unroll
             for (int i = IB; i < EIGH_IL; ++i) {          // rows held in LDS
-                float4* ap = reinterpret_cast<float4*>(&L.AL[tr + 32 * i][cbase + 64 * jj]);
+                float4* ap = reinterpret_cast<float4*>(&L.AL[0][0] + (al_off + 32 * i * EIGH_LD + 64 * jj));
                 EighQuad al(*ap);
                 eigh_rank2(al, vr[i], wr[i], vc, wc);
                 *ap = (float4)al;
@@ -316,7 +345,6 @@ __device__ __forceinline__ void eigh_tri_steps_a(EighQuad (&a)[EIGH_NR][EIGH_NJ]
             for (int i = EIGH_IL; i < EIGH_NI; ++i) eigh_rank2(a[i - EIGH_IL][jj], vr[i], wr[i], vc, wc);
             EIGH_SBA;
         }
-        if (tr == 0 && tc == 0) { e[k] = q.beta; tau[k] = q.t; d[k + 1] = q.yk - 2.0f * q.wk1; }
     }
 #ifdef EIGH_CLK
     if (blockIdx.x == 0 && threadIdx.x == 0) g_eigh_clk[IB] += (long long)__builtin_readcyclecounter() - t0_;
@@ -325,10 +353,11 @@ __device__ __forceinline__ void eigh_tri_steps_a(EighQuad (&a)[EIGH_NR][EIGH_NJ]
 
 // ---- schedule b: steps k >= EIGH_KA with (k + 1) / 32 == IB (IB >= 2); xn = the thread's 20 columns of row k on entry
 template <int IB>
-__device__ __forceinline__ void eigh_tri_steps_b(EighQuad (&a)[EIGH_NR][EIGH_NJ], EighQuad (&xn)[EIGH_NJ], const int n, const int tr, const int tc,
+__device__ __forceinline__ void eigh_tri_steps_b(EighQuad (&a)[EIGH_NR][EIGH_NJ], EighQuad (&xn)[EIGH_NJ], const int n, const int tid,
                                                  EighTriLds& L, float* __restrict__ d, float* __restrict__ e, float* __restrict__ tau,
                                                  float* __restrict__ Vt) {
     constexpr int JB = IB / 2;
+    EIGH_PHASE_INDICES;
     const int k_lo = max(32 * IB - 1, EIGH_KA);
     const int k_hi = min(n - 3, 32 * IB + 30);
     const int cbase = 4 * tc;
@@ -344,8 +373,8 @@ __device__ __forceinline__ void eigh_tri_steps_b(EighQuad (&a)[EIGH_NR][EIGH_NJ]
         // ---- x~ = row k, entries > k;  |x~|^2 without the leading entry
         eigh_mask_group(xn[JB], cbase, kb);
         float sig = 0.0f;
-        sig = fmaf(cbase + 0 > kb + 1 ? xn[JB].x : 0.0f, xn[JB].x, sig); sig = fmaf(cbase + 1 > kb + 1 ? xn[JB].y : 0.0f, xn[JB].y, sig);
-        sig = fmaf(cbase + 2 > kb + 1 ? xn[JB].z : 0.0f, xn[JB].z, sig); sig = fmaf(cbase + 3 > kb + 1 ? xn[JB].w : 0.0f, xn[JB].w, sig);
+        sig = fmaf(cbase > kb + 1 ? xn[JB].x : 0.0f, xn[JB].x, sig); sig = fmaf(cbase > kb ? xn[JB].y : 0.0f, xn[JB].y, sig);
+        sig = fmaf(cbase > kb - 1 ? xn[JB].z : 0.0f, xn[JB].z, sig); sig = fmaf(cbase > kb - 2 ? xn[JB].w : 0.0f, xn[JB].w, sig);
 #pragma unroll
         for (int jj = JB + 1; jj < EIGH_NJ; ++jj) sig = eigh_dot4(xn[jj], xn[jj], sig);
         if (tr == 0) {
@@ -356,7 +385,7 @@ __device__ __forceinline__ void eigh_tri_steps_b(EighQuad (&a)[EIGH_NR][EIGH_NJ]
 #pragma unroll
             for (int jj = JB; jj < EIGH_NJ; ++jj) *reinterpret_cast<float4*>(Yc + cbase + 64 * jj) = (float4)a[IB - EIGH_IL][jj];
         }
-        eigh_matvec<IB, JB>(a, xn, tr, tc, cbase, Pt, L.AL);
+        eigh_matvec<IB, JB>(a, xn, tr, tc, cbase, Pt);
         sig = row16_sum(sig);
         eigh_lds_barrier();
         // ---- x~ . p~ and x~ . y over the columns (x~ is zero on the dead entries)
@@ -370,20 +399,17 @@ __device__ __forceinline__ void eigh_tri_steps_b(EighQuad (&a)[EIGH_NR][EIGH_NJ]
             if (((jj - JB) & 1) == 1) EIGH_SB;
         }
         g1 = row16_sum(g1); g2 = row16_sum(g2);
-        const EighStepScalars q = eigh_step_scalars(sig, g1, g2, Xc[k + 1], Pt[k + 1], Yc[k + 1]);
-        float vr[EIGH_NI], wr[EIGH_NI];
-        eigh_row_vw<true>(q, Xc, Pt, Yc, tr + 32 * IB, tr, kr, vr[IB], wr[IB]);
-#pragma unroll
-        for (int i = IB + 1; i < EIGH_NI; ++i) {
-            eigh_row_vw<false>(q, Xc, Pt, Yc, tr + 32 * i, tr, kr, vr[i], wr[i]);
-            if (((i - IB) & 3) == 3) EIGH_SB;
-        }
+        float xr[EIGH_NI], pr[EIGH_NI], yr[EIGH_NI], vr[EIGH_NI], wr[EIGH_NI];
+        eigh_rows_load<IB>(Xc, Pt, Yc, tr, xr, pr, yr);
+        const EighStepScalars q = eigh_step_scalars<0>(sig, g1, g2, Xc[k + 1], Pt[k + 1], Yc[k + 1]);
+        if (tr == 0 && tc == 0) { e[k] = q.beta; tau[k] = q.t; d[k + 1] = q.yk - 2.0f * q.wk1; }   // (here: t, beta, yk die before the update)
+        eigh_rows_vw<IB>(q, xr, pr, yr, tr, kr, vr, wr);
         float* vrow = Vt + (size_t)k * EIGH_LD;
         EIGH_SB;
 #pragma unroll
         for (int jj = 0; jj < EIGH_NJ; ++jj) {
             if (jj < JB) {
-                if (tr == 0) *reinterpret_cast<float4*>(vrow + cbase + 64 * jj) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (tr == 0) *reinterpret_cast<float4*>(vrow + (cbase + 64 * jj)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 continue;
             }
             const float4 pc = *reinterpret_cast<const float4*>(Pt + cbase + 64 * jj);
@@ -391,7 +417,7 @@ __device__ __forceinline__ void eigh_tri_steps_b(EighQuad (&a)[EIGH_NR][EIGH_NJ]
             float4 vc, wc;
             if (jj == JB) eigh_col_vw<true>(q, xn[jj], pc, yc, cbase, kb, vc, wc);
             else eigh_col_vw<false>(q, xn[jj], pc, yc, cbase, kb, vc, wc);
-            if (tr == 0) *reinterpret_cast<float4*>(vrow + cbase + 64 * jj) = vc;
+            if (tr == 0) *reinterpret_cast<float4*>(vrow + (cbase + 64 * jj)) = vc;
 #pragma unroll
             for (int i = IB; i < EIGH_NI; ++i) eigh_rank2(a[i - EIGH_IL][jj], vr[i], wr[i], vc, wc);
             // row k + 1 after this step's update = the next step's x (its entries <= k + 1 are masked there)
@@ -399,7 +425,6 @@ __device__ __forceinline__ void eigh_tri_steps_b(EighQuad (&a)[EIGH_NR][EIGH_NJ]
             xn[jj].z = fmaf(q.n2, yc.z, fmaf(q.n1, pc.z, q.n3 * xn[jj].z)); xn[jj].w = fmaf(q.n2, yc.w, fmaf(q.n1, pc.w, q.n3 * xn[jj].w));
             EIGH_SB;
         }
-        if (tr == 0 && tc == 0) { e[k] = q.beta; tau[k] = q.t; d[k + 1] = q.yk - 2.0f * q.wk1; }
     }
 #ifdef EIGH_CLK
     if (blockIdx.x == 0 && threadIdx.x == 0) g_eigh_clk[IB] += (long long)__builtin_readcyclecounter() - t0_;
@@ -481,8 +506,8 @@ static __global__ __launch_bounds__(EIGH_TRI_THREADS) void k_eigh_tridiag(EighAr
     for (int i = (n - 2) * EIGH_LD + tid; i < EIGH_LD * EIGH_LD; i += EIGH_TRI_THREADS) Vt[i] = 0.0f;   // reflector rows n-2 .. : zero
     __syncthreads();
     if (tid == 0) d[0] = L.AL[0][0];
-    eigh_tri_steps_a<0>(a, n, tr, tc, L, d, e, tau, Vt);
-    eigh_tri_steps_a<1>(a, n, tr, tc, L, d, e, tau, Vt);
+    eigh_tri_steps_a<0>(a, n, tid, L, d, e, tau, Vt);
+    eigh_tri_steps_a<1>(a, n, tid, L, d, e, tau, Vt);
     if (n - 3 >= EIGH_KA) {
         // hand-over: row EIGH_KA (row class 1) to every thread's columns
         __syncthreads();
@@ -495,14 +520,14 @@ static __global__ __launch_bounds__(EIGH_TRI_THREADS) void k_eigh_tridiag(EighAr
 #pragma unroll
         for (int jj = 0; jj < EIGH_NJ; ++jj) xn[jj] = EighQuad(*reinterpret_cast<const float4*>(L.Xc[0] + 4 * tc + 64 * jj));
         __syncthreads();
-        eigh_tri_steps_b<2>(a, xn, n, tr, tc, L, d, e, tau, Vt);
-        eigh_tri_steps_b<3>(a, xn, n, tr, tc, L, d, e, tau, Vt);
-        eigh_tri_steps_b<4>(a, xn, n, tr, tc, L, d, e, tau, Vt);
-        eigh_tri_steps_b<5>(a, xn, n, tr, tc, L, d, e, tau, Vt);
-        eigh_tri_steps_b<6>(a, xn, n, tr, tc, L, d, e, tau, Vt);
-        eigh_tri_steps_b<7>(a, xn, n, tr, tc, L, d, e, tau, Vt);
-        eigh_tri_steps_b<8>(a, xn, n, tr, tc, L, d, e, tau, Vt);
-        eigh_tri_steps_b<9>(a, xn, n, tr, tc, L, d, e, tau, Vt);
+        eigh_tri_steps_b<2>(a, xn, n, tid, L, d, e, tau, Vt);
+        eigh_tri_steps_b<3>(a, xn, n, tid, L, d, e, tau, Vt);
+        eigh_tri_steps_b<4>(a, xn, n, tid, L, d, e, tau, Vt);
+        eigh_tri_steps_b<5>(a, xn, n, tid, L, d, e, tau, Vt);
+        eigh_tri_steps_b<6>(a, xn, n, tid, L, d, e, tau, Vt);
+        eigh_tri_steps_b<7>(a, xn, n, tid, L, d, e, tau, Vt);
+        eigh_tri_steps_b<8>(a, xn, n, tid, L, d, e, tau, Vt);
+        eigh_tri_steps_b<9>(a, xn, n, tid, L, d, e, tau, Vt);
     }
     // the trailing 2 x 2: d[n-2] is written by the last step; e[n-2] = A[n-1][n-2], d[n-1] = A[n-1][n-1]
     __syncthreads();
