@@ -98,6 +98,9 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nw)
 
 // LDS carve (4-byte words): rewards[Nst] | mean[HUp] | var[HUp] | sigma[HUp] | eidx[kp] | red[64] | hist[272] |
 //                            ekeys[2*kp] | samples[HU][Nst]      (every piece a multiple of 16 B)
+#ifndef BBMPC_FUSED_ACTIONS_AHEAD
+#define BBMPC_FUSED_ACTIONS_AHEAD 1
+#endif
 template <int OPT, bool SAMPLES_LDS, bool FASTM, int INJ, int ILP, bool LINGER = false>
 __global__ void k_fused_pendulum(FusedArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -258,9 +261,40 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                         samp[(size_t)t * p.Nst + n] = x;
                         total = total + roll.step(x);
                     };
+#if BBMPC_FUSED_ACTIONS_AHEAD
+                    // a block's four actions are formed (sigma[t], mean[t] read from LDS) BEFORE its model steps: inside the
+                    // steps the reads would sit between the sine and the angle update of the pendulum's recurrence
+                    auto block4 = [&](const float4& z, int b) {
+                        const float zz[4] = {z.x, z.y, z.z, z.w};
+                        float x[4];
+                        if (OPT == FOPT_RS) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) x[i] = zz[i] * (hi - lo) + lo;
+                        } else {
+                            // (a full block: t = 4b .. 4b + 3 < H; mean / sigma are 16-byte aligned and padded to a multiple of four)
+                            const float4 sg = *reinterpret_cast<const float4*>(sigma + 4 * b), mn = *reinterpret_cast<const float4*>(mean + 4 * b);
+                            x[0] = zz[0] * sg.x + mn.x; x[1] = zz[1] * sg.y + mn.y; x[2] = zz[2] * sg.z + mn.z; x[3] = zz[3] * sg.w + mn.w;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(x[i]));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float v = x[i];
+                            if (OPT == FOPT_PI2) {
+                                const float xf = clipf(v, lo, hi);
+                                const float d = v - xf;
+                                pen = pen + d * d;
+                                v = xf;
+                            }
+                            samp[(size_t)(4 * b + i) * p.Nst + n] = v;
+                            total = total + roll.step(v);
+                        }
+                    };
+#else
                     auto block4 = [&](const float4& z, int b) {
                         step1(4 * b + 0, z.x); step1(4 * b + 1, z.y); step1(4 * b + 2, z.z); step1(4 * b + 3, z.w);
                     };
+#endif
                     float4 c0 = ld(0), c1 = ld(1);
                     int b = 0;
                     // Waves that share a SIMD (wave ids equal mod 4) run the same instruction stream, and the arbiter

@@ -136,6 +136,80 @@ struct PendulumAngleModel {
     }
 };
 
+// The carried angle in TURNS (phi = theta / 2pi, principal value in [-0.5, 0.5]) with the hardware sine: v_sin_f32 takes
+// its argument in turns and is good to 1.25e-7 absolute on [-0.5, 0.5] (tools/microbench/hw_sin.hip: one ulp of 1 -- the
+// class of the reference's own float32 rounding of theta + pi), the wrap to the principal value is the exact
+// phi - rint(phi), and sin(theta + pi) = -sin(theta), angle_normalize(theta) = theta need no +-pi at all.  A model step's
+// dependent chain is sin -> 2 x (mul, add) -> mul, add -> rint, sub: ~12 operations where the radian form (fold to
+// [-pi/2, pi/2], degree-9 polynomial, two-constant wrap) has ~30 -- and the persistent pendulum kernels ARE that chain,
+// 150 model steps per control step.  Same parity tolerances as the two forms above (tests/test_gpu_pendulum.py).
+#ifndef BBMPC_PENDULUM_HW_SIN
+#define BBMPC_PENDULUM_HW_SIN 2
+#endif
+#define BBMPC_INV_TWO_PI_F 0.15915494309189535f
+struct PendulumTurnModel {
+    bool fix_q1;
+    float phi, thd;
+#if BBMPC_PENDULUM_HW_SIN == 2
+    float sn;                            // sin(theta) of the CURRENT state: issued the moment the angle is known (see step)
+#endif
+
+    __device__ __forceinline__ static float sin_turns(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_sinf(x);
+#else
+        return sinf(x * BBMPC_TWO_PI_F);
+#endif
+    }
+    __device__ __forceinline__ void init(float s0, float s1, float s2) {
+        phi = bb_atan2f(s1, s0) * BBMPC_INV_TWO_PI_F;
+        thd = s2;
+#if BBMPC_PENDULUM_HW_SIN == 2
+        sn = sin_turns(phi);
+#endif
+    }
+    __device__ __forceinline__ float step(float u) {
+#if BBMPC_PENDULUM_HW_SIN == 2
+        // newthdot = thdot + (15 sin(theta) + 3u) dt and newth = theta + newthdot dt with everything that does not need the
+        // sine formed beside it: behind the sine the angle is ONE fma + the wrap, and the next step's sine is issued right
+        // there -- the recurrence a model step waits for is sin -> fma -> rint -> sub -> sin, the speed, the reward and
+        // the next action fill the transcendental's latency
+        constexpr float C = 0.05f * BBMPC_INV_TWO_PI_F;                    // dt in turns per radian
+        const float b = fmaf(0.15f, u, thd);                                // thdot + 3 u dt
+        const float a = fmaf(b, C, phi);                                    // theta + (thdot + 3 u dt) dt
+        const float nphi = fmaf(0.75f * C, sn, a);                          // + 15 sin(theta) dt dt  (the unclipped speed, as the reference: quirk Q9)
+        const float phi0 = phi, sn0 = sn;
+        phi = nphi - rintf(nphi);                                           // principal value, exact
+        sn = sin_turns(phi);
+        __builtin_amdgcn_sched_barrier(0);                                  // (the chain first, in this order)
+        float nthd = fmaf(0.75f, sn0, b);                                   // thdot + (15 sin(theta) + 3u) dt
+        nthd = __builtin_amdgcn_fmed3f(nthd, -8.0f, 8.0f);                  // (a NaN speed: see PendulumAngleModel)
+        const float n2 = (nthd - thd) + thd;
+        const float ss = fix_q1 ? u * u : 1.0f + n2 * n2;
+        const float ang = phi0 * BBMPC_TWO_PI_F;                            // angle_normalize(theta): theta is a principal value
+        const float first = ang * ang + 0.1f * (thd * thd);
+        const float r = (-first) - 0.001f * ss;
+        thd = n2;
+        return r;
+#else
+        const float sn1 = sin_turns(phi);                                   // sin(theta)
+        float acc = 15.0f * sn1;                                            // -3g/(2l) sin(theta + pi)
+        acc = acc + 3.0f * u;
+        float nthd = thd + acc * 0.05f;
+        const float nphi = phi + nthd * (0.05f * BBMPC_INV_TWO_PI_F);       // theta + newthdot * dt, in turns (before the clip, as the reference)
+        nthd = __builtin_amdgcn_fmed3f(nthd, -8.0f, 8.0f);                  // (a NaN speed: see PendulumAngleModel)
+        const float n2 = (nthd - thd) + thd;
+        const float ss = fix_q1 ? u * u : 1.0f + n2 * n2;
+        const float ang = phi * BBMPC_TWO_PI_F;                             // angle_normalize(theta): theta is a principal value
+        const float first = ang * ang + 0.1f * (thd * thd);
+        const float r = (-first) - 0.001f * ss;
+        phi = nphi - rintf(nphi);                                           // principal value, exact
+        thd = n2;
+        return r;
+#endif
+    }
+};
+
 // Uniform rollout interface over the two formulations.
 template <bool FASTM>
 struct Roller;
@@ -158,7 +232,11 @@ struct Roller<false> {
 };
 template <>
 struct Roller<true> {
+#if BBMPC_PENDULUM_HW_SIN
+    PendulumTurnModel m;
+#else
     PendulumAngleModel m;
+#endif
     __device__ __forceinline__ Roller() {}
     __device__ __forceinline__ Roller(bool fix_q1, float s0, float s1, float s2) {
         m.fix_q1 = fix_q1;

@@ -95,7 +95,8 @@ def test_evaluator_matches_oracle(L, N, A, H):
     got = eng.evaluate(states, seq)
     want = _oracle_eval()(states, seq)
     assert got.shape == (N, A)
-    np.testing.assert_allclose(got, want, rtol=R_RTOL, atol=R_ATOL)
+    from tests.parity_util import assert_pendulum_rewards
+    assert_pendulum_rewards(got, want, states, seq, R_RTOL, R_ATOL, what="N=%d A=%d H=%d" % (N, A, H))
 
 
 def test_evaluator_nan_guard_and_empty_population(L):

@@ -60,3 +60,60 @@ def test_what_is_let_through():
         assert_cheetah_rewards(flip[:24], want[:24], 1e-3, 1e-3 * H, margin=margin[:24])
     margin[7, 1] = 1e-5
     assert assert_cheetah_rewards(flip[:24], want[:24], 1e-3, 1e-3 * H, margin=lambda: margin[:24]) == 1
+
+
+# ---- the pendulum helper: float64-anchored acceptance of the long-horizon sums -----------------------------------------
+def _pendulum_case(N=64, A=5, H=50):
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(N * 131 + A * 7 + H)            # tests/test_gpu_pendulum.py::test_evaluator_matches_oracle[64-5-50]
+    states = O.pendulum_start_states(A)
+    seq = rng.uniform(-2, 2, (N, A, H, 1)).astype(np.float32)
+    want = O.Evaluator("pendulum", O.Handler(O.pendulum_dynamics, True))(states, seq)
+    return states, seq, want
+
+
+def _turn_form_rewards(states, seq):
+    """csrc/models.hpp PendulumTurnModel in NumPy float32 (correctly rounded sine in place of v_sin_f32)."""
+    F = np.float32
+    N, A, H, _ = seq.shape
+    phi = (np.arctan2(states[:, 1], states[:, 0]).astype(F) * F(0.15915494309189535))[None, :].repeat(N, 0).astype(F)
+    thd = states[:, 2][None, :].repeat(N, 0).astype(F)
+    R = np.zeros((N, A), F)
+    c = F(F(0.05) * F(0.15915494309189535))
+    for t in range(H):
+        u = seq[:, :, t, 0]
+        sn = np.sin(2 * np.pi * phi.astype(np.float64)).astype(F)
+        acc = F(15) * sn
+        acc = acc + F(3) * u
+        nthd = thd + acc * F(0.05)
+        nphi = phi + nthd * c
+        nthd = np.clip(nthd, F(-8), F(8))
+        n2 = (nthd - thd) + thd
+        ang = phi * F(2 * np.pi)
+        R = R + ((-(ang * ang + F(0.1) * (thd * thd))) - F(0.001) * (F(1) + n2 * n2))
+        phi = (nphi - np.rint(nphi)).astype(F)
+        thd = n2
+    return R
+
+
+def test_pendulum_helper_accepts_a_sum_inside_the_oracles_own_rounding_uncertainty():
+    from tests.parity_util import assert_pendulum_rewards, pendulum_rewards_f64
+    states, seq, want = _pendulum_case()
+    got = _turn_form_rewards(states, seq)
+    exact = pendulum_rewards_f64(states, seq)
+    bad = np.abs(got - want) > 2e-3 + 2e-4 * np.abs(want)
+    # the case the helper exists for: the float32 oracle is further from exact arithmetic than the other float32 form
+    assert bad.sum() >= 1 and np.all(np.abs(got - exact)[bad] < np.abs(want - exact)[bad])
+    assert_pendulum_rewards(got, want, states, seq, 2e-4, 2e-3)
+
+
+def test_pendulum_helper_rejects_a_wrong_sum_and_too_many_outliers():
+    from tests.parity_util import assert_pendulum_rewards
+    states, seq, want = _pendulum_case()
+    got = np.array(want, np.float64)
+    got[3, 2] += 0.05                                            # outside the tolerance, and not towards the exact value
+    with pytest.raises(AssertionError):
+        assert_pendulum_rewards(got, want, states, seq, 2e-4, 2e-3)
+    got = np.array(want, np.float64) * (1.0 + 1e-3)              # everything off
+    with pytest.raises(AssertionError):
+        assert_pendulum_rewards(got, want, states, seq, 2e-4, 2e-3)
