@@ -248,8 +248,13 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                     Roller<FASTM> roll;
                     roll.init(p.fix_q1 != 0, s0, s1, s2);
                     float total = 0.0f, pen = 0.0f;
-                    const float4* mine = inj4 + (size_t)n * Q;
-                    auto ld = [&](int b) { return mine[min(b, Q - 1)]; };
+                    // (a GLOBAL pointer, said so: inj_s may have come out of the mailbox, and as a generic pointer its loads are
+                    // flat loads -- which count on the LDS counter too, so that every LDS wait of the loop below waited for the
+                    // block it had just prefetched: one memory round trip per eight model steps)
+                    typedef float gvec4 __attribute__((ext_vector_type(4)));
+                    typedef const __attribute__((address_space(1))) gvec4* gvec4p;
+                    const gvec4p mine = (gvec4p)(inj4 + (size_t)n * Q);
+                    auto ld = [&](int b) { const gvec4 v = mine[min(b, Q - 1)]; return make_float4(v.x, v.y, v.z, v.w); };
                     auto step1 = [&](int t, float xi) {
                         float x = (OPT == FOPT_RS) ? xi * (hi - lo) + lo : xi * sigma[t] + mean[t];
                         if (OPT == FOPT_PI2) {
