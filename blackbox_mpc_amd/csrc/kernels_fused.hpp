@@ -247,7 +247,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                 for (int n = tid; n < p.N; n += nthr) {
                     Roller<FASTM> roll;
                     roll.init(p.fix_q1 != 0, s0, s1, s2);
-                    float total = 0.0f, pen = 0.0f;
+                    float pen = 0.0f;
                     // (a GLOBAL pointer, said so: inj_s may have come out of the mailbox, and as a generic pointer its loads are
                     // flat loads -- which count on the LDS counter too, so that every LDS wait of the loop below waited for the
                     // block it had just prefetched: one memory round trip per eight model steps)
@@ -264,7 +264,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                             x = xf;
                         }
                         samp[(size_t)t * p.Nst + n] = x;
-                        total = total + roll.step(x);
+                        roll.step_acc(x);
                     };
 #if BBMPC_FUSED_ACTIONS_AHEAD
                     // a block's four actions are formed (sigma[t], mean[t] read from LDS) BEFORE its model steps: inside the
@@ -292,7 +292,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                                 v = xf;
                             }
                             samp[(size_t)(4 * b + i) * p.Nst + n] = v;
-                            total = total + roll.step(v);
+                            roll.step_acc(v);
                         }
                     };
 #else
@@ -328,7 +328,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                     if (rem > 0) step1(4 * b + 0, c0.x);
                     if (rem > 1) step1(4 * b + 1, c0.y);
                     if (rem > 2) step1(4 * b + 2, c0.z);
-                    float tot = total;
+                    float tot = roll.total();
                     if (tot != tot) tot = -1.0e6f;                                   // deterministic.py:75-77
                     if (OPT == FOPT_PI2) {
                         const float nr = sqrtf(pen);
@@ -341,13 +341,12 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                 int nn[ILP];
                 bool live[ILP];
                 Roller<FASTM> roll[ILP];
-                float total[ILP], pen[ILP], xn[ILP][4];
+                float pen[ILP], xn[ILP][4];
 #pragma unroll
                 for (int q = 0; q < ILP; ++q) {
                     live[q] = n0 + q * nthr < p.N;
                     nn[q] = live[q] ? n0 + q * nthr : n0;          // idle slots shadow particle n0 (never stored)
                     roll[q].init(p.fix_q1 != 0, s0, s1, s2);
-                    total[q] = 0.0f;
                     pen[q] = 0.0f;
                 }
                 auto gen = [&](int q, int b) {
@@ -379,7 +378,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                         x = xf;
                     }
                     if (live[q]) samp[(size_t)t * p.Nst + nn[q]] = x;
-                    total[q] = total[q] + roll[q].step(x);
+                    roll[q].step_acc(x);     // (the H-step sum is the roller's: the same form as the prefetched-draws path above, bit for bit)
                 };
 #pragma unroll
                 for (int q = 0; q < ILP; ++q) gen(q, 0);
@@ -401,7 +400,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                     for (int q = 0; q < ILP; ++q) consume(q, 4 * nblk + i, xn[q][i]);
 #pragma unroll
                 for (int q = 0; q < ILP; ++q) {
-                    float tot = total[q];
+                    float tot = roll[q].total();
                     if (tot != tot) tot = -1.0e6f;                                   // deterministic.py:75-77
                     if (OPT == FOPT_PI2) {
                         const float nr = sqrtf(pen[q]);
