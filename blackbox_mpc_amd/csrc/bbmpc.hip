@@ -196,7 +196,7 @@ Engine::Engine(const bbmpc_config& c) : cfg(c) {
         sw.mlp_wave = ival("BBMPC_MLP_WAVE", 1);
         sw.linger_us = std::max(0, ival("BBMPC_LINGER_US", 200));
         linger_test_quit = ival("BBMPC_LINGER_TEST_QUIT", 0) - 1;
-        sw.balance = ival("BBMPC_BALANCE", 1);
+        sw.balance = ival("BBMPC_BALANCE", 0);      // (1: SIMD mates pace each other in the fused pendulum rollout -- paid while a model step took 160 ns, costs 1-2 % at 60)
         sw.ilp = ival("BBMPC_ILP", 1) == 2 ? 2 : 1;
         sw.refit_v1 = flag("BBMPC_REFIT_V1");
         sw.zero_copy = !flag("BBMPC_NO_ZERO_COPY");

@@ -132,7 +132,7 @@ struct Engine {
         int refit_wgs = 0;                // BBMPC_REFIT_WGS=n: workgroups per agent in k_refit_cem_v2 (0 = by problem size)
         int mlp_wave = 1;                 // BBMPC_MLP_WAVE=0: never the one-wave-per-tile kernel for small networks
         int linger_us = 200;              // BBMPC_LINGER_US: how long a one-agent control-step kernel waits for the next call (0 = never)
-        int balance = 1;               // BBMPC_BALANCE
+        int balance = 0;               // BBMPC_BALANCE=1: SIMD mates pace each other in the fused pendulum rollout
         int ilp = 1;                   // BBMPC_ILP
         bool refit_v1 = false;         // BBMPC_REFIT_V1
         bool zero_copy = true;         // !BBMPC_NO_ZERO_COPY
