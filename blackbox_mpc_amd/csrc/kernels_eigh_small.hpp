@@ -523,8 +523,9 @@ __global__ __launch_bounds__(256) void k_cma_sample_roll_small(CmaArgs p, const 
         const float d = x - xf;
         pen = pen + d * d;
         x = xf;
-        total = total + roll.step(x);
+        roll.step_acc(x);
     }
+    total = roll.total();
     if (total != total) total = -1.0e6f;
     const float nr = sqrtf(pen);
     pen = nr * nr;

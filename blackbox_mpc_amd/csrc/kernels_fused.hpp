@@ -189,16 +189,20 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                     rp.init(p.fix_q1 != 0, s0, s1, s2);
                     rm.init(p.fix_q1 != 0, s0, s1, s2);
                     float tp = 0.0f, tm = 0.0f, pp = 0.0f, pm = 0.0f;
-                    [[maybe_unused]] const float4* mine4 = nullptr;
-                    [[maybe_unused]] float4 cur4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                    // (a GLOBAL pointer, said so: as a generic pointer -- inj_s may have come out of the mailbox -- its loads are
+                    // flat loads, which count on the LDS counter as well: the mean[t] reads below then wait for the prefetch)
+                    typedef float gvec4s __attribute__((ext_vector_type(4)));
+                    typedef const __attribute__((address_space(1))) gvec4s* gvec4sp;
+                    [[maybe_unused]] gvec4sp mine4 = nullptr;
+                    [[maybe_unused]] gvec4s cur4 = {1.0f, 1.0f, 1.0f, 1.0f};
                     if constexpr (INJ == 2) {            // draws prefetched by k_noise_fill, one float4 per 4 steps
-                        mine4 = reinterpret_cast<const float4*>(inj_s) + (((size_t)it * p.A + a) * p.Nst + n) * nb4;
+                        mine4 = (gvec4sp)(reinterpret_cast<const float4*>(inj_s) + (((size_t)it * p.A + a) * p.Nst + n) * nb4);
                         cur4 = mine4[0];
                     }
                     for (int b = 0; b < nb4; ++b) {
                         float d[4];
                         if constexpr (INJ == 2) {
-                            const float4 nxt4 = mine4[min(b + 1, nb4 - 1)];
+                            const gvec4s nxt4 = mine4[min(b + 1, nb4 - 1)];
                             d[0] = cur4.x; d[1] = cur4.y; d[2] = cur4.z; d[3] = cur4.w;
                             cur4 = nxt4;
                         } else if (INJ == 1) {
@@ -220,11 +224,12 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                                 pp = pp + dp * dp;
                                 pm = pm + dm * dm;
                                 samp[(size_t)t * p.Nst + n] = d[i];
-                                tp = tp + rp.step(xpf);
-                                tm = tm + rm.step(xmf);
+                                rp.step_acc(xpf);
+                                rm.step_acc(xmf);
                             }
                         }
                     }
+                    tp = rp.total(); tm = rm.total();
                     if (tp != tp) tp = -1.0e6f;                                                // deterministic.py:75-77
                     if (tm != tm) tm = -1.0e6f;
                     const float np_ = sqrtf(pp), nm_ = sqrtf(pm);                              // tf.norm(...)**2  spsa.py:82-89

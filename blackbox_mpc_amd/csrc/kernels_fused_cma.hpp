@@ -122,10 +122,11 @@ __global__ __launch_bounds__(1024) void k_fused_cma_pendulum(FusedCmaArgs f) {
                         pen = pen + d * d;
                         x = xf;
                         p.cand[(off + t0 + u) * Nst + q] = x;
-                        total = total + roll.step(x);
+                        roll.step_acc(x);
                     }
                 }
             }
+            total = roll.total();
             if (total != total) total = -1.0e6f;
             const float nr = sqrtf(pen);
             pen = nr * nr;

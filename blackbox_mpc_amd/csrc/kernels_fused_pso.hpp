@@ -108,8 +108,9 @@ __global__ __launch_bounds__(1024) void k_fused_pso_pendulum(FusedPsoArgs p) {
                 pen = pen + d * d;
                 x = xf;
                 posL[(size_t)t * Nst + n] = x;                            // self.pos = feasible positions (:80)
-                total = total + roll.step(x);
+                roll.step_acc(x);
             }
+            total = roll.total();
             if (total != total) total = -1.0e6f;                          // deterministic.py:75-77
             const float nr = sqrtf(pen);                                  // tf.norm(...)**2
             R = total - nr * nr;

@@ -105,7 +105,7 @@ __global__ void k_rollout_pendulum(RolloutArgs p) {
             __syncthreads();
             if (active) {
                 for (int c = 0; c < tj; c += U) {
-                    total = total + roll.step(tile[threadIdx.x * (TJ + 1) + c]);
+                    roll.step_acc(tile[threadIdx.x * (TJ + 1) + c]);
                 }
             }
         }
@@ -138,7 +138,7 @@ __global__ void k_rollout_pendulum(RolloutArgs p) {
                                 x = xf;
                             }
                             if (p.samples) p.samples[(size_t)(a * p.HU + t0 + i) * p.Nst + n] = x;
-                            total = total + roll.step(x);
+                            roll.step_acc(x);
                         }
                     }
                 }
@@ -158,11 +158,12 @@ __global__ void k_rollout_pendulum(RolloutArgs p) {
                     if (p.samples) p.samples[(size_t)(a * p.HU + j) * p.Nst + n] = x;
                     act[u] = x;
                 }
-                total = total + roll.step(act[0]);
+                roll.step_acc(act[0]);
             }
         }
     }
     if (!active) return;
+    total = roll.total();                                       // (the H-step sum is the roller's: models.hpp)
     if (total != total) total = -1.0e6f;                        // deterministic.py:75-77
     if constexpr (PEN) {
         const float nr = sqrtf(pen);                            // tf.norm(...)**2  pi2.py:72-75
