@@ -167,6 +167,20 @@ __global__ void k_fused_pendulum(FusedArgs p) {
 #ifdef BBMPC_KERNEL_DBG
         if (p.dbg && tid == 0 && a == 0) dbg_lds[40] = (long long)clock64();
 #endif
+        // (INJ == 2) the first two blocks of a thread's first trajectory are fetched while the PREVIOUS iteration selects and
+        // refits: at the top of the rollout their loads would be one exposed memory round trip per iteration
+        typedef float pfvec4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) pfvec4* pfvec4p;
+        [[maybe_unused]] pfvec4 pf0 = {0.0f, 0.0f, 0.0f, 0.0f}, pf1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        [[maybe_unused]] auto prefetch_first = [&](int it_n) {
+            if constexpr (INJ == 2 && OPT != FOPT_SPSA) {
+                const int Q = (p.HU + 3) >> 2;
+                const pfvec4p q = (pfvec4p)(reinterpret_cast<const float4*>(inj_s) + (((size_t)it_n * p.A + a) * p.Nst + min(tid, p.N - 1)) * Q);
+                pf0 = q[0];
+                pf1 = q[min(1, Q - 1)];
+            }
+        };
+        if (p.iters > 0) prefetch_first(0);
         for (int it = 0; it < p.iters; ++it) {
             BB_DBG(1 + it * 4);
             // ---- sample + rollout: one lane per trajectory, state in VGPRs
@@ -305,7 +319,9 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                         step1(4 * b + 0, z.x); step1(4 * b + 1, z.y); step1(4 * b + 2, z.z); step1(4 * b + 3, z.w);
                     };
 #endif
-                    float4 c0 = ld(0), c1 = ld(1);
+                    float4 c0, c1;
+                    if (n == tid) { c0 = make_float4(pf0.x, pf0.y, pf0.z, pf0.w); c1 = make_float4(pf1.x, pf1.y, pf1.z, pf1.w); }   // fetched an iteration ago
+                    else { c0 = ld(0); c1 = ld(1); }
                     int b = 0;
                     // Waves that share a SIMD (wave ids equal mod 4) run the same instruction stream, and the arbiter
                     // favours the older one: it finishes early and the younger one then runs alone at a lone wave's
@@ -419,6 +435,7 @@ __global__ void k_fused_pendulum(FusedArgs p) {
 #endif
             // the selection's first part reads only the rewards this thread has just written: in front of the barrier the
             // rollout needs anyway instead of behind it with a barrier of its own (topk.hpp)
+            if (it + 1 < p.iters) prefetch_first(it + 1);
             if (OPT == FOPT_CEM) block_topk_prepass(rew, p.N, p.k, hist, tid, nthr);
             BB_DBG(2 + it * 4);
             __syncthreads();
