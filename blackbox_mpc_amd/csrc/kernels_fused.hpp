@@ -173,11 +173,11 @@ __global__ void k_fused_pendulum(FusedArgs p) {
         typedef const __attribute__((address_space(1))) pfvec4* pfvec4p;
         [[maybe_unused]] pfvec4 pf0 = {0.0f, 0.0f, 0.0f, 0.0f}, pf1 = {0.0f, 0.0f, 0.0f, 0.0f};
         [[maybe_unused]] auto prefetch_first = [&](int it_n) {
-            if constexpr (INJ == 2 && OPT != FOPT_SPSA) {
+            if constexpr (INJ == 2) {
                 const int Q = (p.HU + 3) >> 2;
                 const pfvec4p q = (pfvec4p)(reinterpret_cast<const float4*>(inj_s) + (((size_t)it_n * p.A + a) * p.Nst + min(tid, p.N - 1)) * Q);
                 pf0 = q[0];
-                pf1 = q[min(1, Q - 1)];
+                if (OPT != FOPT_SPSA) pf1 = q[min(1, Q - 1)];
             }
         };
         if (p.iters > 0) prefetch_first(0);
@@ -211,7 +211,8 @@ __global__ void k_fused_pendulum(FusedArgs p) {
                     [[maybe_unused]] gvec4s cur4 = {1.0f, 1.0f, 1.0f, 1.0f};
                     if constexpr (INJ == 2) {            // draws prefetched by k_noise_fill, one float4 per 4 steps
                         mine4 = (gvec4sp)(reinterpret_cast<const float4*>(inj_s) + (((size_t)it * p.A + a) * p.Nst + n) * nb4);
-                        cur4 = mine4[0];
+                        if (n == tid) cur4 = pf0;                    // fetched while the previous iteration refitted
+                        else cur4 = mine4[0];
                     }
                     for (int b = 0; b < nb4; ++b) {
                         float d[4];
