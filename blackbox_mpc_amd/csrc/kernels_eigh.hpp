@@ -68,8 +68,12 @@ struct EighArgs {
 //   beta, tau, scale from |x~|^2 (slarfg);  v = scale (x~ - beta e_{k+1});  p = A v = scale (p~ - beta y),  y = A[:, k+1]
 //   w = tau p - (tau^2 v.p / 2) v  =  c1 p~ + c2 y + c3 x~;      A -= v w^T + w v^T
 // Two schedules of that step:
-//   eigh_tri_steps_a  (k < 63, all ten row classes alive: no register to spare)   the owners of rows k and k + 1 publish
-//                     them -> barrier -> everybody: p~ -> barrier -> scalars, update
+//   eigh_tri_steps_a  (k < 63, all ten row classes alive: no register to spare)   barrier -> everybody: p~ (x~ = row k
+//                     read in place from LDS; the owner of row k + 1 publishes y from the loads of its own share of the
+//                     product) -> barrier -> scalars, update
+//   (round 6: the rows' v / w are loaded before the scalar chain and formed right behind it, the step's scalars go to
+//   SGPRs after the chain in schedule a only, every phase re-derives its indices: the allocation is at the register cap
+//   and FRAGILE -- after an edit check `tools/kernel_resources.sh k_eigh_tridiag`; profiles/NOTES_r6.md)
 //   eigh_tri_steps_b  (k >= 63: row classes 0, 1 are dead, their 40 registers carry the next step's x)   ONE barrier:
 //                     every thread forms the next row itself,  xn = y - w - w_{k+1} v  (v_{k+1} = 1),  at the end of the
 //                     update; before the barrier only p~ = A xn, the owner of row k + 1 publishing y, one row of lanes
